@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the reference checkout (run in the authoring
+container only: /root/reference does not exist on the GPU box).
+
+What it produces is DATA only:
+  * byte copies of the reference's own test fixtures (tests/resources/*.rpw, the
+    16 kHz i16 wavs) -- the .rpw files hold the reference's own MFCC output
+    (written by tests/wakeword.rs:27-54), i.e. golden vectors for the MFCC path;
+  * expectations.json: the exact f32 values asserted by tests/detector.rs, typed
+    in by hand below with the line they come from.
+No reference source text is copied.
+"""
+import json
+import os
+import shutil
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+FILES = [
+    "oye_casa_g.rpw", "oye_casa_g_v2.rpw", "alexa.rpw", "ok_casa-tiny.rpw",
+    "oye_casa_g_1.wav", "oye_casa_g_2.wav", "oye_casa_g_3.wav", "oye_casa_g_4.wav", "oye_casa_g_5.wav",
+    "alexa.wav", "alexa2.wav", "alexa3.wav",
+]
+
+# tests/detector.rs -- simulation stream: 5 s zeros + oye_casa_g_1.wav[44:] + 5 s zeros +
+# oye_casa_g_2.wav[44:] + 5 s zeros, i16 LE bytes, fed in get_bytes_per_frame() chunks (:361-426)
+EXPECT = {
+    "source": "rustpotter v3.0.2 tests/detector.rs",
+    "simulation": {
+        "max_v2": {"lines": "9-22", "rpw": "oye_casa_g_v2.rpw", "score_mode": "max", "avg_threshold": 0.2,
+                   "threshold": 0.5, "detections": [[0.6495044, 0.7310586], [0.5804737, 0.721843]]},
+        "max": {"lines": "24-38", "rpw": "oye_casa_g.rpw", "score_mode": "max", "avg_threshold": 0.2,
+                "threshold": 0.5, "detections": [[0.6495044, 0.7310586], [0.5804737, 0.721843]]},
+        "median": {"lines": "40-54", "rpw": "oye_casa_g.rpw", "score_mode": "median", "avg_threshold": 0.2,
+                   "threshold": 0.5, "detections": [[0.64608675, 0.60123634], [0.5288923, 0.63968724]]},
+        "average": {"lines": "56-70", "rpw": "oye_casa_g.rpw", "score_mode": "average", "avg_threshold": 0.2,
+                    "threshold": 0.5, "detections": [[0.64608675, 0.60458726], [0.5750509, 0.6313083]]},
+        "vad_easy": {"lines": "72-87", "rpw": "oye_casa_g.rpw", "score_mode": "max", "avg_threshold": 0.2,
+                     "threshold": 0.5, "vad_mode": "easy",
+                     "detections": [[0.6495044, 0.7310586], [0.5804737, 0.721843]]},
+        "ignore_alexa": {"lines": "89-99", "rpw": "alexa.rpw", "score_mode": "max", "avg_threshold": 0.0,
+                         "threshold": 0.45, "min_scores": 0, "detections": []},
+        "ignore_alexa_filters": {"lines": "100-111", "rpw": "alexa.rpw", "score_mode": "max", "avg_threshold": 0.0,
+                                 "threshold": 0.45, "min_scores": 0, "gain_normalizer": True, "band_pass": True,
+                                 "detections": []},
+        "band_pass": {"lines": "112-127", "rpw": "oye_casa_g.rpw", "score_mode": "max", "avg_threshold": 0.0,
+                      "threshold": 0.5, "band_pass": True, "low_cutoff": 80.0, "high_cutoff": 400.0,
+                      "detections": [[None, 0.6858197], [None, 0.66327363]]},
+        "gain_normalizer": {"lines": "129-143", "rpw": "oye_casa_g.rpw", "score_mode": "max", "avg_threshold": 0.0,
+                            "threshold": 0.5, "gain_normalizer": True, "gains": [0.2, 5.0],
+                            "detections": [[None, 0.7304294], [None, 0.71067876]]},
+        "gain_and_band_pass": {"lines": "145-162", "rpw": "oye_casa_g.rpw", "score_mode": "median",
+                               "avg_threshold": 0.0, "threshold": 0.5, "gain_normalizer": True, "band_pass": True,
+                               "low_cutoff": 80.0, "high_cutoff": 500.0, "gains": [0.2, 5.0],
+                               "detections": [[None, 0.5775406], [None, 0.5828697]]},
+    },
+    # tests/detector.rs:216-232: score = calc_inverse_similarity(label, none, score_ref*10)
+    "nn_score_formula": {"lines": "216-232", "label_logit": 3.7506533, "none_logit": -16.83091,
+                         "score_ref": 0.22, "score": 0.9997649},
+    # tests/detector.rs:252-267 (eager): logits 23.990948 / 6.0654087 -> 0.9992142
+    "nn_score_formula_eager": {"lines": "252-267", "label_logit": 23.990948, "none_logit": 6.0654087,
+                               "score_ref": 0.22, "score": 0.9992142},
+    # frame counts of the reference's own MFCC output, SURVEY.md §4
+    "rpw_shapes": {"oye_casa_g.rpw": {"oye_casa_g_1.wav": 108, "oye_casa_g_2.wav": 96, "oye_casa_g_3.wav": 90,
+                                      "oye_casa_g_4.wav": 93, "oye_casa_g_5.wav": 102},
+                   "alexa.rpw": {"alexa.wav": 117, "alexa2.wav": 126, "alexa3.wav": 99}},
+}
+
+if __name__ == "__main__":
+    for f in FILES:
+        shutil.copyfile(os.path.join(REF, "tests", "resources", f), os.path.join(HERE, f))
+    with open(os.path.join(HERE, "expectations.json"), "w") as fh:
+        json.dump(EXPECT, fh, indent=1)
+    print("wrote", len(FILES), "fixture files + expectations.json")

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- 10 ms-frame MFCC+DTW scorings/sec on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path (MFCC of every 10 ms frame, T banded DTWs +
+score_mode aggregation per window, detection state machine) over S synthetic 16 kHz f32
+streams that are already resident in HBM.  One "scoring" = one (stream, 10 ms frame)
+step in steady state = one scored window.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded by rank
+(weak scaling: every GPU gets --streams streams), the only exchange is an RCCL all_gather
+of the per-stream detection summary at the end of each step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 0x5EED000000000001
+HBM_PEAK = 8.0e12      # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+VALU_PEAK = 157.3e12   # FLOP/s fp32 vector, same table
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=65536, help="streams per GPU (BASELINE config C3)")
+    ap.add_argument("--templates", type=int, default=8)
+    ap.add_argument("--samples", type=int, default=64000, help="samples per stream (4 s @ 16 kHz)")
+    ap.add_argument("--template-len", type=int, default=100)
+    ap.add_argument("--mfcc-size", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+
+    import rustpotter_amd as ra
+
+    S, N, T, L, K = args.streams, args.samples, args.templates, args.template_len, args.mfcc_size
+    nf = ra.mfcc_num_frames(N)
+    n_win = nf - L + 1
+    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # templates: T synthetic utterances, MFCC by the HIP path, whole-matrix mean
+    # normalisation, truncated to L frames.  Identical arrays are handed to the CPU baseline.
+    n_t = 480 * -(-(L + 3) // 3)
+    tp = torch.empty((T, n_t), dtype=torch.float32, device=dev)
+    for t in range(T):
+        ctx.synth_dev(SEED + 1 + t, 0, 1, n_t, n_t, tp[t].data_ptr())
+    tm_frames = ra.mfcc_num_frames(n_t)
+    tmf = torch.empty((T, tm_frames, K), dtype=torch.float32, device=dev)
+    ctx.mfcc_dev(tp.data_ptr(), T, n_t, n_t, K, tmf.data_ptr())
+    torch.cuda.synchronize()
+    tmf = tmf.cpu().numpy()
+    templates = [np.ascontiguousarray((m - m.mean(axis=0, dtype=np.float32))[:L], dtype=np.float32) for m in tmf]
+    tmpl = ra.Templates(ctx, templates)
+
+    # resident inputs / outputs
+    pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
+    ctx.synth_dev(SEED, rank * S, S, N, N, pcm.data_ptr())
+    mfcc = torch.empty((S, nf, K), dtype=torch.float32, device=dev)
+    scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev)
+    agg = torch.empty((S, n_win), dtype=torch.float32, device=dev)
+    max_det = 4
+    det = torch.zeros((S, max_det, 6), dtype=torch.int32, device=dev)
+    n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
+    gathered = [torch.empty_like(n_det) for _ in range(world)] if world > 1 else None
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0  # avg gate off: exactly T DTWs per scoring
+
+    def step():
+        ctx.mfcc_dev(pcm.data_ptr(), S, N, N, K, mfcc.data_ptr())
+        ctx.dtw_dev(mfcc.data_ptr(), S, nf, tmpl, cfg.score_ref, cfg.band_size, cfg.score_mode, False,
+                    scores.data_ptr(), None, agg.data_ptr())
+        ctx.scan_dev(agg.data_ptr(), None, S, nf, L, cfg, det.data_ptr(), n_det.data_ptr(), max_det)
+        if world > 1:
+            dist.all_gather(gathered, n_det)  # final per-stream result gather over xGMI
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    scorings_per_step = S * n_win * world
+    value = scorings_per_step * args.steps / dt
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(max(2, min(args.steps, 5))):
+        step()
+    torch.cuda.synchronize()
+    k_ms = {name: ctx.timing_read(i) for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
+    ctx.timing_enable(False)
+    per_gpu_scorings = S * n_win
+    # algorithmic bytes per unit: whole path 160*4 + 4*(T+2) per scoring;
+    # stage split: mfcc kernel 640 + 4K per frame, dtw kernel (reading MFCC from HBM) 4K + 4(T+2) per scoring
+    cells = sum((min(L, r + 5 - 1) - max(1, r - 5) + 1) for r in range(1, L))  # band cells of rows 1..m-1
+    f_dtw = cells * (2 * K + 7) + 2 * L * 2 * K + 2 * L * K
+    f_mfcc = 13.2e3
+    dom = max(("mfcc", "dtw"), key=lambda n: k_ms[n][0])
+    if dom == "dtw":
+        alg_bytes = per_gpu_scorings * (4 * K + 4 * (T + 2))
+        alg_flops = per_gpu_scorings * T * f_dtw
+    else:
+        alg_bytes = S * nf * (640 + 4 * K)
+        alg_flops = S * nf * f_mfcc
+    dom_s = k_ms[dom][0] * 1e-3
+    achieved = alg_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                "avg_launch_ms": k_ms[dom][0],
+                "valu_frac_fp32": (alg_flops / dom_s) / VALU_PEAK if dom_s > 0 else 0.0,
+                "kernels_ms": {k: round(v[0], 4) for k, v in k_ms.items()},
+                "path_hbm_frac": (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK,
+                "path_valu_frac_fp32": (value / world) * (f_mfcc * nf / n_win + T * f_dtw) / VALU_PEAK}
+
+    out = {
+        "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: %d synthetic 16 kHz f32 streams x %d templates per GPU (4 s streams, L=%d, K=%d, band 5, "
+                               "ScoreMode::Max, avg gate off)" % (S, T, L, K),
+                   "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
+                   "windows_per_stream": n_win, "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle's restatement of the reference algorithm on this host's cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import rp_oracle as orc
+        cores = os.cpu_count() or 1
+        secs, sc, _ = orc.bench(SEED, cores, N, templates, threads=cores)  # calibration: 1 stream per core
+        rate = sc / secs
+        s_cpu = int(max(cores, min(64 * cores, args.cpu_seconds * rate / n_win)))
+        secs, sc, _ = orc.bench(SEED, s_cpu, N, templates, threads=cores)
+        out["cpu_baseline"] = {"value": sc / secs, "unit": "scorings/s", "cores": cores, "kind": "port",
+                               "sample": "%d of the same synthetic streams x %d templates, %d scorings in %.1f s; C restatement of "
+                                         "the reference algorithm (complex FFT-480 per frame, dense mel, 3-dot cosine per DTW cell), "
+                                         "not the Rust crate" % (s_cpu, T, sc, secs)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

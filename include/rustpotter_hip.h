@@ -1,0 +1,246 @@
+/*
+ * rustpotter_hip.h -- C ABI of librustpotter_hip.so, an MI355X (gfx950) HIP
+ * implementation of rustpotter v3.0.2's MFCC + DTW wakeword scoring path.
+ *
+ * The reference has no C ABI of its own; its public surface is the
+ * Rust API re-exported in src/lib.rs:8-21.  Every entry point below cites the
+ * reference item it replaces (paths relative to the reference root).  A Rust
+ * crate binds this header with `extern "C"` (bindings/rustpotter_hip.rs,
+ * INTEGRATION.md) and re-exposes the reference's method names unchanged.
+ *
+ * Conventions (SURVEY.md §8b "Ownership/Errors/Threading"):
+ *  - all functions return plain C types; status returns are int: >=0 ok, <0 error;
+ *    the message of the last error of the calling thread is rp_last_error()
+ *    (the reference returns Result<_, String>).
+ *  - the caller owns every input buffer for the duration of the call only;
+ *    wakewords are copied into the handle (src/wakewords/comp/wakeword_comp.rs:55-63).
+ *  - strings/arrays inside rp_detection are owned by the handle and stay valid
+ *    until the next call on that handle.
+ *  - handles are NOT thread-safe (reference: every method takes &mut self); distinct
+ *    handles are independent.
+ *  - nothing in this library falls back to the CPU: without a usable HIP device
+ *    rp_new / rp_ctx_new fail with an error.
+ */
+#ifndef RUSTPOTTER_HIP_H
+#define RUSTPOTTER_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ config */
+/* src/audio/audio_types.rs:4-9 */
+typedef enum { RP_SAMPLE_I8 = 0, RP_SAMPLE_I16 = 1, RP_SAMPLE_I32 = 2, RP_SAMPLE_F32 = 3 } rp_sample_format;
+/* src/audio/audio_types.rs:52-56 */
+typedef enum { RP_ENDIAN_BIG = 0, RP_ENDIAN_LITTLE = 1, RP_ENDIAN_NATIVE = 2 } rp_endianness;
+/* src/config.rs:86-96 (declaration order) */
+typedef enum {
+    RP_SCORE_AVERAGE = 0, RP_SCORE_MAX = 1, RP_SCORE_MEDIAN = 2, RP_SCORE_P25 = 3, RP_SCORE_P50 = 4,
+    RP_SCORE_P75 = 5, RP_SCORE_P80 = 6, RP_SCORE_P90 = 7, RP_SCORE_P95 = 8
+} rp_score_mode;
+/* src/config.rs:134-138; RP_VAD_NONE == Option::None */
+typedef enum { RP_VAD_NONE = 0, RP_VAD_EASY = 1, RP_VAD_MEDIUM = 2, RP_VAD_HARD = 3 } rp_vad_mode;
+
+/* src/config.rs:10-19 AudioFmt */
+typedef struct {
+    size_t sample_rate;
+    rp_sample_format sample_format;
+    uint16_t channels;
+    rp_endianness endianness;
+} rp_audio_fmt;
+
+/* src/config.rs:172-191 DetectorConfig */
+typedef struct {
+    float avg_threshold;
+    float threshold;
+    size_t min_scores;
+    bool eager;
+    float score_ref;
+    uint16_t band_size;
+    rp_score_mode score_mode;
+    rp_vad_mode vad_mode;
+} rp_detector_config;
+
+/* src/config.rs:32-42 GainNormalizationConfig (gain_ref: Option<f32>) */
+typedef struct {
+    bool enabled;
+    bool has_gain_ref;
+    float gain_ref;
+    float min_gain;
+    float max_gain;
+} rp_gain_normalization_config;
+
+/* src/config.rs:55-62 BandPassConfig */
+typedef struct {
+    bool enabled;
+    float low_cutoff;
+    float high_cutoff;
+} rp_band_pass_config;
+
+/* src/config.rs:75-82 FiltersConfig */
+typedef struct {
+    rp_gain_normalization_config gain_normalizer;
+    rp_band_pass_config band_pass;
+} rp_filters_config;
+
+/* src/config.rs:212-219 RustpotterConfig */
+typedef struct {
+    rp_audio_fmt fmt;
+    rp_detector_config detector;
+    rp_filters_config filters;
+} rp_config;
+
+/* RustpotterConfig::default(), src/config.rs:20-29,43-52,63-71,192-207 */
+void rp_config_default(rp_config *out);
+
+/* --------------------------------------------------------------- detection */
+/* src/detector.rs:488-501 RustpotterDetection.  `scores` is the HashMap<String,f32>
+ * flattened to parallel arrays (template file names for references, label names
+ * for models). */
+typedef struct {
+    const char *name;
+    float avg_score;
+    float score;
+    size_t n_scores;
+    const char *const *score_names;
+    const float *scores;
+    size_t counter;
+    float gain;
+} rp_detection;
+
+/* ------------------------------------------- single-stream `Rustpotter` mirror */
+typedef struct rp_detector rp_detector;
+
+/* Rustpotter::new, src/detector.rs:95-141.  Errors: "Unsupported sample rate, unable
+ * to initialize the resampler" (src/audio/encoder.rs:78) for every rate != 16000 --
+ * the rubato resampler is outside this library's scope. */
+int rp_new(const rp_config *config, rp_detector **out);
+void rp_free(rp_detector *d);
+
+/* add_wakeword_from_buffer / _from_file, src/detector.rs:152-176 (WakewordV2 ->
+ * WakewordRef -> WakewordModel fall-through, decided on the CBOR map keys). */
+int rp_add_wakeword_from_buffer(rp_detector *d, const char *key, const uint8_t *buffer, size_t len);
+int rp_add_wakeword_from_file(rp_detector *d, const char *key, const char *path);
+/* remove_wakeword / remove_wakewords, src/detector.rs:180-202 */
+bool rp_remove_wakeword(rp_detector *d, const char *key);
+bool rp_remove_wakewords(rp_detector *d);
+
+/* src/detector.rs:204-229 */
+size_t rp_get_samples_per_frame(const rp_detector *d);
+size_t rp_get_bytes_per_frame(const rp_detector *d);
+/* returns 1 and fills *out if a partial detection exists, else 0 */
+int rp_get_partial_detection(const rp_detector *d, rp_detection *out);
+float rp_get_rms_level(const rp_detector *d);
+float rp_get_gain(const rp_detector *d);
+float rp_get_rms_level_ref(const rp_detector *d);
+
+/* process_bytes, src/detector.rs:234-240; process_samples::<T>, :245-254.
+ * Return 1 (detection written to *out), 0 (None: also for a wrong buffer length or
+ * no wakewords, exactly like the reference), <0 device error. */
+int rp_process_bytes(rp_detector *d, const uint8_t *audio_bytes, size_t len, rp_detection *out);
+int rp_process_samples_i8(rp_detector *d, const int8_t *samples, size_t n, rp_detection *out);
+int rp_process_samples_i16(rp_detector *d, const int16_t *samples, size_t n, rp_detection *out);
+int rp_process_samples_i32(rp_detector *d, const int32_t *samples, size_t n, rp_detection *out);
+int rp_process_samples_f32(rp_detector *d, const float *samples, size_t n, rp_detection *out);
+
+/* update_config / update_detector_config / update_filters_config / reset,
+ * src/detector.rs:257-302 */
+int rp_update_config(rp_detector *d, const rp_config *config);
+int rp_update_detector_config(rp_detector *d, const rp_detector_config *config);
+int rp_update_filters_config(rp_detector *d, const rp_filters_config *config);
+void rp_reset(rp_detector *d);
+
+/* Result<_, String> error text of the calling thread's last failing call */
+const char *rp_last_error(void);
+
+/* ------------------------------------------------- batched operator level
+ * What the HIP kernels sit behind: the reference's per-frame operators applied to
+ * S independent streams at once.  All array arguments are DEVICE pointers unless
+ * the context was created with RP_CTX_HOST_POINTERS (then the library stages
+ * them through its own device buffers). */
+typedef struct rp_ctx rp_ctx;
+typedef struct rp_templates rp_templates;
+
+enum { RP_CTX_DEVICE_POINTERS = 0, RP_CTX_HOST_POINTERS = 1 };
+
+/* device: HIP device ordinal.  Fails (<0) if no HIP device is usable. */
+int rp_ctx_new(int device, int flags, rp_ctx **out);
+void rp_ctx_free(rp_ctx *ctx);
+/* Run subsequent launches on an externally owned hipStream_t (e.g. the caller's
+ * torch stream); NULL = the context's own stream. */
+int rp_ctx_set_stream(rp_ctx *ctx, void *hip_stream);
+int rp_ctx_synchronize(rp_ctx *ctx);
+
+/* Number of MFCC frames MfccExtractor::compute yields for a stream of n_samples fed
+ * in 480-sample chunks from a fresh extractor: 3*floor(n/480) - 3
+ * (src/mfcc/extractor.rs:60-79; the frame made of the first three shifts is never
+ * emitted). */
+size_t rp_mfcc_num_frames(size_t n_samples);
+
+/* MfccExtractor::compute over whole streams, src/mfcc/extractor.rs:60-163.
+ * pcm  [S][pcm_stride] f32 16 kHz mono (n_samples valid per stream)
+ * mfcc [S][n_frames][K] f32, n_frames = rp_mfcc_num_frames(n_samples); K = mfcc_size
+ * (set_out_size(K): K+1 filters/coefficients, coefficient 0 dropped). */
+int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, int K, float *mfcc);
+
+/* A wakeword reference resident on the device: T templates [len_t][K] (already
+ * mean-normalised, as stored in a .rpw: src/wakewords/wakeword_ref.rs:12-20) given
+ * as HOST arrays; avg may be NULL. */
+int rp_templates_new(rp_ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len, const float *avg,
+                     rp_templates **out);
+void rp_templates_free(rp_templates *t);
+int rp_templates_max_len(const rp_templates *t);
+
+/* WakewordComparator::run_detection scoring for every window start of every stream,
+ * src/wakewords/comp/wakeword_comp.rs:22-37,77-139 + src/mfcc/comparator.rs +
+ * src/mfcc/dtw.rs:56-105 + src/mfcc/normalizer.rs.  n_win = n_frames - max_len + 1.
+ * scores [S][n_win][T]; avg [S][n_win] (NULL or ignored when the template set has no
+ * avg template / with_avg == 0); agg [S][n_win] = score_mode aggregate. */
+int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames, const rp_templates *t,
+                       float score_ref, int band_size, rp_score_mode score_mode, int with_avg,
+                       float *scores, float *avg, float *agg);
+
+/* One detection found by rp_detect_scan */
+typedef struct {
+    int32_t stream;
+    int32_t frame;       /* index of the MFCC frame whose processing emitted the detection */
+    int32_t window;      /* window start (frame index) of the best partial = row of `scores` */
+    int32_t counter;     /* RustpotterDetection::counter */
+    float avg_score;
+    float score;
+} rp_batch_detection;
+
+/* Rustpotter::process_new_mfccs / run_detection / reset state machine,
+ * src/detector.rs:290-302,377-454, run over precomputed window scores (no VAD).
+ * det [S][max_det] (device or host per ctx flag), n_det [S]. */
+int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, size_t n_frames, int max_len,
+                   const rp_detector_config *config, int avg_enabled, rp_batch_detection *det, int32_t *n_det,
+                   int max_det);
+
+/* WakewordNN forward, src/wakewords/nn/wakeword_nn.rs:101-106,305-389: x [B][dims[0]]
+ * -> logits [B][dims[n_layers]]; weights are HOST arrays W_l [out][in], b_l [out]. */
+int rp_mlp_forward_batch(rp_ctx *ctx, const float *x, size_t B, int n_layers, const int *dims,
+                         const float *const *weights, const float *const *biases, float *logits);
+
+/* Synthetic benchmark input of BASELINE.md §2, generated on the device:
+ * pcm[s][i] = (splitmix64(seed ^ ((first_stream+s)<<32 + i)) >> 40) / 2^24 - 0.5 */
+int rp_synth_pcm_batch(rp_ctx *ctx, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples, size_t pcm_stride,
+                       float *pcm);
+
+/* Average duration in ms of the launches of one kernel since the last reset, timed
+ * with hipEvents on the launch stream (used by bench.py's roofline block).
+ * kernel: 0 mfcc, 1 dtw, 2 aggregate, 3 scan. */
+int rp_ctx_timing_enable(rp_ctx *ctx, int enable);
+int rp_ctx_timing_read(rp_ctx *ctx, int kernel, double *avg_ms, int *launches);
+int rp_ctx_timing_reset(rp_ctx *ctx);
+
+const char *rp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTPOTTER_HIP_H */

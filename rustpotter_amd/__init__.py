@@ -1,0 +1,12 @@
+"""rustpotter_amd -- MI355X (gfx950) HIP implementation of rustpotter's MFCC + DTW
+wakeword scoring path behind a C ABI (include/rustpotter_hip.h).
+
+This Python package is a thin ctypes binding used by the tests and by bench.py; the
+product is librustpotter_hip.so (rustpotter_amd/csrc).  There is no CPU fallback: if
+the shared library is missing, or no HIP device is usable, the calls raise.
+"""
+from .api import (  # noqa: F401
+    AudioFmt, BandPassConfig, BatchContext, DetectorConfig, Endianness, FiltersConfig,
+    GainNormalizationConfig, Rustpotter, RustpotterConfig, RustpotterDetection, RustpotterError,
+    SampleFormat, ScoreMode, Templates, VADMode, lib_path, load_library, mfcc_num_frames,
+)

@@ -1,0 +1,518 @@
+"""ctypes binding of include/rustpotter_hip.h.
+
+Class and method names follow the reference's public API (src/lib.rs:8-21,
+src/detector.rs, src/config.rs) so that the parity tests read like the reference's
+own tests (tests/detector.rs).
+"""
+import ctypes as C
+import enum
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class RustpotterError(RuntimeError):
+    """Result::Err(String) of the reference."""
+
+
+def lib_path():
+    return os.path.join(_HERE, "librustpotter_hip.so")
+
+
+class SampleFormat(enum.IntEnum):  # src/audio/audio_types.rs:4-9
+    I8 = 0
+    I16 = 1
+    I32 = 2
+    F32 = 3
+
+
+class Endianness(enum.IntEnum):  # src/audio/audio_types.rs:52-56
+    Big = 0
+    Little = 1
+    Native = 2
+
+
+class ScoreMode(enum.IntEnum):  # src/config.rs:86-96
+    Average = 0
+    Max = 1
+    Median = 2
+    P25 = 3
+    P50 = 4
+    P75 = 5
+    P80 = 6
+    P90 = 7
+    P95 = 8
+
+
+class VADMode(enum.IntEnum):  # src/config.rs:134-138 (+ None)
+    Off = 0
+    Easy = 1
+    Medium = 2
+    Hard = 3
+
+
+class _AudioFmt(C.Structure):
+    _fields_ = [("sample_rate", C.c_size_t), ("sample_format", C.c_int), ("channels", C.c_uint16), ("endianness", C.c_int)]
+
+
+class _DetectorConfig(C.Structure):
+    _fields_ = [("avg_threshold", C.c_float), ("threshold", C.c_float), ("min_scores", C.c_size_t), ("eager", C.c_bool),
+                ("score_ref", C.c_float), ("band_size", C.c_uint16), ("score_mode", C.c_int), ("vad_mode", C.c_int)]
+
+
+class _GainCfg(C.Structure):
+    _fields_ = [("enabled", C.c_bool), ("has_gain_ref", C.c_bool), ("gain_ref", C.c_float), ("min_gain", C.c_float),
+                ("max_gain", C.c_float)]
+
+
+class _BandPassCfg(C.Structure):
+    _fields_ = [("enabled", C.c_bool), ("low_cutoff", C.c_float), ("high_cutoff", C.c_float)]
+
+
+class _FiltersCfg(C.Structure):
+    _fields_ = [("gain_normalizer", _GainCfg), ("band_pass", _BandPassCfg)]
+
+
+class _Config(C.Structure):
+    _fields_ = [("fmt", _AudioFmt), ("detector", _DetectorConfig), ("filters", _FiltersCfg)]
+
+
+class _Detection(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("avg_score", C.c_float), ("score", C.c_float), ("n_scores", C.c_size_t),
+                ("score_names", C.POINTER(C.c_char_p)), ("scores", C.POINTER(C.c_float)), ("counter", C.c_size_t),
+                ("gain", C.c_float)]
+
+
+class _BatchDetection(C.Structure):
+    _fields_ = [("stream", C.c_int32), ("frame", C.c_int32), ("window", C.c_int32), ("counter", C.c_int32),
+                ("avg_score", C.c_float), ("score", C.c_float)]
+
+
+# every symbol include/rustpotter_hip.h declares (tests/test_capi_symbols.py checks the header against this)
+SYMBOLS = [
+    "rp_config_default", "rp_new", "rp_free", "rp_add_wakeword_from_buffer", "rp_add_wakeword_from_file",
+    "rp_remove_wakeword", "rp_remove_wakewords", "rp_get_samples_per_frame", "rp_get_bytes_per_frame",
+    "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
+    "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
+    "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch",
+    "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan",
+    "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
+    "rp_version",
+]
+
+
+def load_library():
+    """Loads librustpotter_hip.so.  torch (if importable) is imported FIRST so that the
+    process uses torch's bundled HIP runtime (same SONAME libamdhip64.so.7) instead of
+    loading a second one."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RustpotterError(
+            "librustpotter_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C rustpotter_amd/csrc`; there is no CPU fallback" % path)
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for pure C users
+        pass
+    L = C.CDLL(path)
+    vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.rp_last_error.restype = C.c_char_p
+    L.rp_version.restype = C.c_char_p
+    L.rp_config_default.argtypes = [C.POINTER(_Config)]
+    L.rp_new.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    L.rp_free.argtypes = [vp]
+    L.rp_add_wakeword_from_buffer.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.rp_add_wakeword_from_file.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.rp_remove_wakeword.argtypes = [vp, C.c_char_p]
+    L.rp_remove_wakeword.restype = C.c_bool
+    L.rp_remove_wakewords.argtypes = [vp]
+    L.rp_remove_wakewords.restype = C.c_bool
+    L.rp_get_samples_per_frame.argtypes = [vp]
+    L.rp_get_samples_per_frame.restype = C.c_size_t
+    L.rp_get_bytes_per_frame.argtypes = [vp]
+    L.rp_get_bytes_per_frame.restype = C.c_size_t
+    L.rp_get_partial_detection.argtypes = [vp, C.POINTER(_Detection)]
+    for n in ("rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = C.c_float
+    L.rp_process_bytes.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(_Detection)]
+    for n in ("rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32"):
+        getattr(L, n).argtypes = [vp, vp, C.c_size_t, C.POINTER(_Detection)]
+    L.rp_update_config.argtypes = [vp, C.POINTER(_Config)]
+    L.rp_update_detector_config.argtypes = [vp, C.POINTER(_DetectorConfig)]
+    L.rp_update_filters_config.argtypes = [vp, C.POINTER(_FiltersCfg)]
+    L.rp_reset.argtypes = [vp]
+    L.rp_ctx_new.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.rp_ctx_free.argtypes = [vp]
+    L.rp_ctx_set_stream.argtypes = [vp, vp]
+    L.rp_ctx_synchronize.argtypes = [vp]
+    L.rp_mfcc_num_frames.argtypes = [C.c_size_t]
+    L.rp_mfcc_num_frames.restype = C.c_size_t
+    L.rp_mfcc_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
+    L.rp_templates_new.argtypes = [vp, C.c_int, C.c_int, ip, fp, C.c_int, fp, C.POINTER(vp)]
+    L.rp_templates_free.argtypes = [vp]
+    L.rp_templates_max_len.argtypes = [vp]
+    L.rp_dtw_score_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, vp, C.c_int]
+    L.rp_mlp_forward_batch.argtypes = [vp, vp, C.c_size_t, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), vp]
+    L.rp_synth_pcm_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, vp]
+    L.rp_ctx_timing_enable.argtypes = [vp, C.c_int]
+    L.rp_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), ip]
+    L.rp_ctx_timing_reset.argtypes = [vp]
+    _LIB = L
+    return L
+
+
+def _err():
+    return RustpotterError(load_library().rp_last_error().decode("utf-8", "replace"))
+
+
+def mfcc_num_frames(n_samples):
+    return int(load_library().rp_mfcc_num_frames(n_samples))
+
+
+# ------------------------------------------------------------------ config mirror
+class AudioFmt:  # src/config.rs:10-29
+    def __init__(self):
+        self.sample_rate = 16000
+        self.sample_format = SampleFormat.F32
+        self.channels = 1
+        self.endianness = Endianness.Little
+
+
+class GainNormalizationConfig:  # src/config.rs:32-52
+    def __init__(self):
+        self.enabled = False
+        self.gain_ref = None
+        self.min_gain = 0.1
+        self.max_gain = 1.0
+
+
+class BandPassConfig:  # src/config.rs:55-71
+    def __init__(self):
+        self.enabled = False
+        self.low_cutoff = 80.0
+        self.high_cutoff = 400.0
+
+
+class FiltersConfig:  # src/config.rs:75-82
+    def __init__(self):
+        self.gain_normalizer = GainNormalizationConfig()
+        self.band_pass = BandPassConfig()
+
+
+class DetectorConfig:  # src/config.rs:172-207
+    def __init__(self):
+        self.avg_threshold = 0.2
+        self.threshold = 0.5
+        self.min_scores = 5
+        self.eager = False
+        self.score_ref = 0.22
+        self.band_size = 5
+        self.score_mode = ScoreMode.Max
+        self.vad_mode = None
+
+    def _c(self):
+        c = _DetectorConfig()
+        c.avg_threshold, c.threshold, c.min_scores, c.eager = self.avg_threshold, self.threshold, self.min_scores, self.eager
+        c.score_ref, c.band_size, c.score_mode = self.score_ref, self.band_size, int(self.score_mode)
+        c.vad_mode = int(self.vad_mode) if self.vad_mode is not None else 0
+        return c
+
+
+class RustpotterConfig:  # src/config.rs:212-219
+    def __init__(self):
+        self.fmt = AudioFmt()
+        self.detector = DetectorConfig()
+        self.filters = FiltersConfig()
+
+    @staticmethod
+    def default():
+        return RustpotterConfig()
+
+    def _filters_c(self):
+        f = _FiltersCfg()
+        g, b = self.filters.gain_normalizer, self.filters.band_pass
+        f.gain_normalizer.enabled = g.enabled
+        f.gain_normalizer.has_gain_ref = g.gain_ref is not None
+        f.gain_normalizer.gain_ref = g.gain_ref if g.gain_ref is not None else 0.0
+        f.gain_normalizer.min_gain, f.gain_normalizer.max_gain = g.min_gain, g.max_gain
+        f.band_pass.enabled, f.band_pass.low_cutoff, f.band_pass.high_cutoff = b.enabled, b.low_cutoff, b.high_cutoff
+        return f
+
+    def _c(self):
+        c = _Config()
+        c.fmt.sample_rate, c.fmt.sample_format = self.fmt.sample_rate, int(self.fmt.sample_format)
+        c.fmt.channels, c.fmt.endianness = self.fmt.channels, int(self.fmt.endianness)
+        c.detector = self.detector._c()
+        c.filters = self._filters_c()
+        return c
+
+
+class RustpotterDetection:  # src/detector.rs:488-501
+    def __init__(self, d):
+        import numpy as np
+        self.name = d.name.decode()
+        self.avg_score = np.float32(d.avg_score)
+        self.score = np.float32(d.score)
+        self.scores = {d.score_names[i].decode(): np.float32(d.scores[i]) for i in range(d.n_scores)}
+        self.counter = int(d.counter)
+        self.gain = np.float32(d.gain)
+
+    def __repr__(self):
+        return "RustpotterDetection(name=%r, avg_score=%r, score=%r, counter=%d)" % (self.name, float(self.avg_score),
+                                                                                      float(self.score), self.counter)
+
+
+class Rustpotter:
+    """src/detector.rs:34-501.  Raises RustpotterError where the reference returns Err(String)."""
+
+    def __init__(self, config):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        c = config._c()
+        if self._L.rp_new(C.byref(c), C.byref(self._h)) < 0:
+            self._h = None
+            raise _err()
+
+    @staticmethod
+    def new(config):
+        return Rustpotter(config)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.rp_free(self._h)
+            self._h = None
+
+    def add_wakeword_from_file(self, key, path):
+        if self._L.rp_add_wakeword_from_file(self._h, key.encode(), path.encode()) < 0:
+            raise _err()
+
+    def add_wakeword_from_buffer(self, key, buffer):
+        if self._L.rp_add_wakeword_from_buffer(self._h, key.encode(), bytes(buffer), len(buffer)) < 0:
+            raise _err()
+
+    def remove_wakeword(self, key):
+        return bool(self._L.rp_remove_wakeword(self._h, key.encode()))
+
+    def remove_wakewords(self):
+        return bool(self._L.rp_remove_wakewords(self._h))
+
+    def get_samples_per_frame(self):
+        return int(self._L.rp_get_samples_per_frame(self._h))
+
+    def get_bytes_per_frame(self):
+        return int(self._L.rp_get_bytes_per_frame(self._h))
+
+    def get_partial_detection(self):
+        d = _Detection()
+        return RustpotterDetection(d) if self._L.rp_get_partial_detection(self._h, C.byref(d)) == 1 else None
+
+    def get_rms_level(self):
+        return float(self._L.rp_get_rms_level(self._h))
+
+    def get_gain(self):
+        return float(self._L.rp_get_gain(self._h))
+
+    def get_rms_level_ref(self):
+        return float(self._L.rp_get_rms_level_ref(self._h))
+
+    def _ret(self, r, d):
+        if r < 0:
+            raise _err()
+        return RustpotterDetection(d) if r == 1 else None
+
+    def process_bytes(self, audio_bytes):
+        d = _Detection()
+        b = bytes(audio_bytes)
+        return self._ret(self._L.rp_process_bytes(self._h, b, len(b), C.byref(d)), d)
+
+    def process_samples(self, samples):
+        """samples: numpy array of int8/int16/int32/float32 (the reference's `Sample` types)."""
+        import numpy as np
+        a = np.ascontiguousarray(samples)
+        fn = {np.dtype(np.int8): self._L.rp_process_samples_i8, np.dtype(np.int16): self._L.rp_process_samples_i16,
+              np.dtype(np.int32): self._L.rp_process_samples_i32, np.dtype(np.float32): self._L.rp_process_samples_f32}[a.dtype]
+        d = _Detection()
+        return self._ret(fn(self._h, a.ctypes.data, a.size, C.byref(d)), d)
+
+    def update_config(self, config):
+        c = config._c()
+        self._L.rp_update_config(self._h, C.byref(c))
+
+    def update_detector_config(self, config):
+        c = config._c()
+        self._L.rp_update_detector_config(self._h, C.byref(c))
+
+    def update_filters_config(self, config):
+        rc = RustpotterConfig()
+        rc.filters = config
+        f = rc._filters_c()
+        self._L.rp_update_filters_config(self._h, C.byref(f))
+
+    def reset(self):
+        self._L.rp_reset(self._h)
+
+
+# ------------------------------------------------------------- batched operators
+class Templates:
+    """rp_templates: one wakeword reference resident on the device."""
+
+    def __init__(self, ctx, templates, avg=None):
+        import numpy as np
+        self._L = load_library()
+        self.ctx = ctx
+        self.T = len(templates)
+        self.K = int(np.asarray(templates[0]).shape[1])
+        lens = np.array([len(t) for t in templates], np.int32)
+        feats = np.concatenate([np.ascontiguousarray(t, np.float32).reshape(-1) for t in templates]).astype(np.float32)
+        avg_a = None if avg is None else np.ascontiguousarray(avg, np.float32)
+        self._h = C.c_void_p()
+        r = self._L.rp_templates_new(ctx._h, self.T, self.K, lens.ctypes.data_as(C.POINTER(C.c_int)),
+                                     feats.ctypes.data_as(C.POINTER(C.c_float)), 0 if avg_a is None else avg_a.shape[0],
+                                     None if avg_a is None else avg_a.ctypes.data_as(C.POINTER(C.c_float)), C.byref(self._h))
+        if r < 0:
+            self._h = None
+            raise _err()
+        self.max_len = int(self._L.rp_templates_max_len(self._h))
+        self.has_avg = avg_a is not None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.rp_templates_free(self._h)
+            self._h = None
+
+
+class BatchContext:
+    """rp_ctx.  host_pointers=True: numpy in / numpy out (tests); False: raw device
+    pointers (bench.py passes torch tensors' data_ptr())."""
+
+    def __init__(self, device=0, host_pointers=True):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        self.host = host_pointers
+        if self._L.rp_ctx_new(device, 1 if host_pointers else 0, C.byref(self._h)) < 0:
+            self._h = None
+            raise _err()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.rp_ctx_free(self._h)
+            self._h = None
+
+    def set_stream(self, hip_stream):
+        self._L.rp_ctx_set_stream(self._h, C.c_void_p(hip_stream))
+
+    def synchronize(self):
+        if self._L.rp_ctx_synchronize(self._h) < 0:
+            raise _err()
+
+    # --- numpy convenience (host_pointers=True)
+    def mfcc(self, pcm, K):
+        import numpy as np
+        assert self.host
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        S, N = pcm.shape
+        nf = mfcc_num_frames(N)
+        out = np.empty((S, nf, K), np.float32)
+        if self._L.rp_mfcc_batch(self._h, pcm.ctypes.data, S, N, N, K, out.ctypes.data) < 0:
+            raise _err()
+        return out
+
+    def dtw_scores(self, mfcc, templates, score_ref=0.22, band_size=5, score_mode=ScoreMode.Max, with_avg=False):
+        import numpy as np
+        assert self.host
+        mfcc = np.ascontiguousarray(mfcc, np.float32)
+        if mfcc.ndim == 2:
+            mfcc = mfcc[None]
+        S, nf, K = mfcc.shape
+        assert K == templates.K
+        n_win = max(0, nf - templates.max_len + 1)
+        scores = np.empty((S, n_win, templates.T), np.float32)
+        agg = np.empty((S, n_win), np.float32)
+        avg = np.empty((S, n_win), np.float32) if (with_avg and templates.has_avg) else None
+        r = self._L.rp_dtw_score_batch(self._h, mfcc.ctypes.data, S, nf, templates._h, score_ref, band_size, int(score_mode),
+                                       1 if avg is not None else 0, scores.ctypes.data,
+                                       None if avg is None else avg.ctypes.data, agg.ctypes.data)
+        if r < 0:
+            raise _err()
+        return scores, avg, agg
+
+    def detect_scan(self, agg, avg, n_frames, max_len, detector_config, max_det=8):
+        import numpy as np
+        assert self.host
+        agg = np.ascontiguousarray(agg, np.float32)
+        S = agg.shape[0]
+        det = np.zeros((S, max_det), dtype=[("stream", "<i4"), ("frame", "<i4"), ("window", "<i4"), ("counter", "<i4"),
+                                             ("avg_score", "<f4"), ("score", "<f4")])
+        n_det = np.zeros(S, np.int32)
+        c = detector_config._c()
+        avg_a = None if avg is None else np.ascontiguousarray(avg, np.float32)
+        r = self._L.rp_detect_scan(self._h, agg.ctypes.data, None if avg_a is None else avg_a.ctypes.data, S, n_frames,
+                                   max_len, C.byref(c), 1 if avg_a is not None else 0, det.ctypes.data, n_det.ctypes.data,
+                                   max_det)
+        if r < 0:
+            raise _err()
+        return det, n_det
+
+    def mlp_forward(self, x, weights, biases):
+        import numpy as np
+        assert self.host
+        x = np.ascontiguousarray(x, np.float32)
+        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, np.float32) for b in biases]
+        dims = np.array([x.shape[1]] + [w.shape[0] for w in ws], np.int32)
+        fp = C.POINTER(C.c_float)
+        wp = (fp * len(ws))(*[w.ctypes.data_as(fp) for w in ws])
+        bp = (fp * len(bs))(*[b.ctypes.data_as(fp) for b in bs])
+        out = np.empty((x.shape[0], int(dims[-1])), np.float32)
+        if self._L.rp_mlp_forward_batch(self._h, x.ctypes.data, x.shape[0], len(ws), dims.ctypes.data_as(C.POINTER(C.c_int)),
+                                        wp, bp, out.ctypes.data) < 0:
+            raise _err()
+        return out
+
+    def synth_pcm(self, seed, first_stream, S, N):
+        import numpy as np
+        assert self.host
+        out = np.empty((S, N), np.float32)
+        if self._L.rp_synth_pcm_batch(self._h, seed, first_stream, S, N, N, out.ctypes.data) < 0:
+            raise _err()
+        return out
+
+    # --- raw device-pointer calls (host_pointers=False)
+    def mfcc_dev(self, pcm_ptr, S, N, stride, K, out_ptr):
+        if self._L.rp_mfcc_batch(self._h, pcm_ptr, S, N, stride, K, out_ptr) < 0:
+            raise _err()
+
+    def dtw_dev(self, mfcc_ptr, S, n_frames, templates, score_ref, band_size, score_mode, with_avg, scores_ptr, avg_ptr, agg_ptr):
+        if self._L.rp_dtw_score_batch(self._h, mfcc_ptr, S, n_frames, templates._h, score_ref, band_size, int(score_mode),
+                                      int(with_avg), scores_ptr, avg_ptr, agg_ptr) < 0:
+            raise _err()
+
+    def scan_dev(self, agg_ptr, avg_ptr, S, n_frames, max_len, detector_config, det_ptr, n_det_ptr, max_det):
+        c = detector_config._c()
+        if self._L.rp_detect_scan(self._h, agg_ptr, avg_ptr, S, n_frames, max_len, C.byref(c), 1 if avg_ptr else 0, det_ptr,
+                                  n_det_ptr, max_det) < 0:
+            raise _err()
+
+    def synth_dev(self, seed, first_stream, S, N, stride, out_ptr):
+        if self._L.rp_synth_pcm_batch(self._h, seed, first_stream, S, N, stride, out_ptr) < 0:
+            raise _err()
+
+    def timing_enable(self, on=True):
+        self._L.rp_ctx_timing_enable(self._h, 1 if on else 0)
+
+    def timing_reset(self):
+        self._L.rp_ctx_timing_reset(self._h)
+
+    def timing_read(self, kernel):
+        ms, n = C.c_double(), C.c_int()
+        self._L.rp_ctx_timing_read(self._h, kernel, C.byref(ms), C.byref(n))
+        return ms.value, n.value

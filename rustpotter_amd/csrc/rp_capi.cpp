@@ -1,0 +1,340 @@
+// rp_capi.cpp -- extern "C" surface declared in include/rustpotter_hip.h.
+#include <cstring>
+#include <new>
+
+#include "rp_host.h"
+
+namespace rp { const std::string &last_error(); }
+
+using namespace rp;
+
+struct rp_detector {
+    std::unique_ptr<Rustpotter> impl;
+    // storage backing the last rp_detection handed out
+    Detection last;
+    std::vector<const char *> name_ptrs;
+};
+struct rp_ctx { std::unique_ptr<Ctx> impl; };
+struct rp_templates { std::unique_ptr<Templates> impl; };
+
+static void fill_detection(rp_detector *d, const Detection &src, rp_detection *out) {
+    d->last = src;
+    d->name_ptrs.clear();
+    for (auto &s : d->last.score_names) d->name_ptrs.push_back(s.c_str());
+    out->name = d->last.name.c_str();
+    out->avg_score = d->last.avg_score;
+    out->score = d->last.score;
+    out->n_scores = d->last.scores.size();
+    out->score_names = d->name_ptrs.data();
+    out->scores = d->last.scores.data();
+    out->counter = d->last.counter;
+    out->gain = d->last.gain;
+}
+
+template <class F> static int guarded(F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { set_last_error("out of host memory"); return -1; }
+    catch (const std::exception &e) { set_last_error(e.what()); return -1; }
+    catch (...) { set_last_error("unknown error"); return -1; }
+}
+
+extern "C" {
+
+const char *rp_last_error(void) { return last_error().c_str(); }
+const char *rp_version(void) { return "rustpotter_hip 0.1.0 (gfx950; mirrors rustpotter 3.0.2)"; }
+
+void rp_config_default(rp_config *c) {
+    std::memset(c, 0, sizeof(*c));
+    c->fmt.sample_rate = 16000;  // DETECTOR_INTERNAL_SAMPLE_RATE
+    c->fmt.sample_format = RP_SAMPLE_F32;
+    c->fmt.channels = 1;
+    c->fmt.endianness = RP_ENDIAN_LITTLE;
+    c->detector.avg_threshold = 0.2f;  // src/constants.rs:4
+    c->detector.threshold = 0.5f;      // :5
+    c->detector.min_scores = 5;        // :6
+    c->detector.eager = false;
+    c->detector.score_ref = 0.22f;     // :7
+    c->detector.band_size = 5;         // :3
+    c->detector.score_mode = RP_SCORE_MAX;
+    c->detector.vad_mode = RP_VAD_NONE;
+    c->filters.gain_normalizer.enabled = false;
+    c->filters.gain_normalizer.has_gain_ref = false;
+    c->filters.gain_normalizer.min_gain = 0.1f;
+    c->filters.gain_normalizer.max_gain = 1.0f;
+    c->filters.band_pass.enabled = false;
+    c->filters.band_pass.low_cutoff = 80.f;
+    c->filters.band_pass.high_cutoff = 400.f;
+}
+
+int rp_new(const rp_config *config, rp_detector **out) {
+    return guarded([&]() -> int {
+        if (!config || !out) { set_last_error("null argument"); return -1; }
+        *out = nullptr;
+        std::unique_ptr<Rustpotter> r(Rustpotter::create(*config));
+        if (!r) return -1;
+        rp_detector *d = new rp_detector();
+        d->impl = std::move(r);
+        *out = d;
+        return 0;
+    });
+}
+void rp_free(rp_detector *d) { delete d; }
+
+int rp_add_wakeword_from_buffer(rp_detector *d, const char *key, const uint8_t *buffer, size_t len) {
+    return guarded([&]() -> int { return d->impl->add_wakeword_from_buffer(key, buffer, len) ? 0 : -1; });
+}
+int rp_add_wakeword_from_file(rp_detector *d, const char *key, const char *path) {
+    return guarded([&]() -> int { return d->impl->add_wakeword_from_file(key, path) ? 0 : -1; });
+}
+bool rp_remove_wakeword(rp_detector *d, const char *key) { return d->impl->remove_wakeword(key); }
+bool rp_remove_wakewords(rp_detector *d) { return d->impl->remove_wakewords(); }
+size_t rp_get_samples_per_frame(const rp_detector *d) { return d->impl->get_samples_per_frame(); }
+size_t rp_get_bytes_per_frame(const rp_detector *d) { return d->impl->get_bytes_per_frame(); }
+int rp_get_partial_detection(const rp_detector *d, rp_detection *out) {
+    const Detection *p = d->impl->get_partial_detection();
+    if (!p) return 0;
+    fill_detection(const_cast<rp_detector *>(d), *p, out);
+    return 1;
+}
+float rp_get_rms_level(const rp_detector *d) { return d->impl->get_rms_level(); }
+float rp_get_gain(const rp_detector *d) { return d->impl->get_gain(); }
+float rp_get_rms_level_ref(const rp_detector *d) { return d->impl->get_rms_level_ref(); }
+
+#define RP_PROCESS(call)                                              \
+    return guarded([&]() -> int {                                     \
+        Detection det;                                                \
+        int r = (call);                                               \
+        if (r == 1 && out) fill_detection(d, det, out);               \
+        return r;                                                     \
+    })
+
+int rp_process_bytes(rp_detector *d, const uint8_t *b, size_t len, rp_detection *out) { RP_PROCESS(d->impl->process_bytes(b, len, &det)); }
+int rp_process_samples_i8(rp_detector *d, const int8_t *s, size_t n, rp_detection *out) { RP_PROCESS(d->impl->process_samples<int8_t>(s, n, &det)); }
+int rp_process_samples_i16(rp_detector *d, const int16_t *s, size_t n, rp_detection *out) { RP_PROCESS(d->impl->process_samples<int16_t>(s, n, &det)); }
+int rp_process_samples_i32(rp_detector *d, const int32_t *s, size_t n, rp_detection *out) { RP_PROCESS(d->impl->process_samples<int32_t>(s, n, &det)); }
+int rp_process_samples_f32(rp_detector *d, const float *s, size_t n, rp_detection *out) { RP_PROCESS(d->impl->process_samples<float>(s, n, &det)); }
+
+int rp_update_config(rp_detector *d, const rp_config *c) {
+    d->impl->update_detector_config(c->detector);
+    d->impl->update_filters_config(c->filters);
+    return 0;
+}
+int rp_update_detector_config(rp_detector *d, const rp_detector_config *c) { d->impl->update_detector_config(*c); return 0; }
+int rp_update_filters_config(rp_detector *d, const rp_filters_config *c) { d->impl->update_filters_config(*c); return 0; }
+void rp_reset(rp_detector *d) { d->impl->reset(); }
+
+// ------------------------------------------------------------------- batched level
+int rp_ctx_new(int device, int flags, rp_ctx **out) {
+    return guarded([&]() -> int {
+        *out = nullptr;
+        std::unique_ptr<Ctx> c(Ctx::create(device, flags));
+        if (!c) return -1;
+        rp_ctx *h = new rp_ctx();
+        h->impl = std::move(c);
+        *out = h;
+        return 0;
+    });
+}
+void rp_ctx_free(rp_ctx *ctx) { delete ctx; }
+int rp_ctx_set_stream(rp_ctx *ctx, void *s) {
+    ctx->impl->stream = s ? static_cast<hipStream_t>(s) : ctx->impl->own_stream;
+    return 0;
+}
+int rp_ctx_synchronize(rp_ctx *ctx) {
+    if (!hip_ok(hipSetDevice(ctx->impl->device), "hipSetDevice")) return -1;
+    return hip_ok(hipStreamSynchronize(ctx->impl->stream), "hipStreamSynchronize") ? 0 : -1;
+}
+
+size_t rp_mfcc_num_frames(size_t n_samples) {
+    size_t chunks = n_samples / 480;
+    return chunks >= 1 ? 3 * chunks - 3 : 0;
+}
+
+namespace {
+struct Staged {  // host<->device staging for RP_CTX_HOST_POINTERS
+    Ctx *c;
+    bool host;
+    explicit Staged(Ctx *ctx) : c(ctx), host((ctx->flags & RP_CTX_HOST_POINTERS) != 0) {}
+    const void *in(const void *p, size_t bytes, DevBuf &buf) {
+        if (!host || !p) return p;
+        if (!buf.reserve(bytes)) return nullptr;
+        if (!hip_ok(hipMemcpyAsync(buf.p, p, bytes, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync(H2D)")) return nullptr;
+        return buf.p;
+    }
+    void *out(void *p, size_t bytes, DevBuf &buf) {
+        if (!host || !p) return p;
+        return buf.reserve(bytes) ? buf.p : nullptr;
+    }
+    bool back(void *host_p, const void *dev_p, size_t bytes) {
+        if (!host || !host_p) return true;
+        return hip_ok(hipMemcpyAsync(host_p, dev_p, bytes, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync(D2H)");
+    }
+    bool finish() { return !host || hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize"); }
+};
+}  // namespace
+
+int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, int K, float *mfcc) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
+        const MfccTablesDev *tb = c->tables_for(K);
+        if (!tb) return -1;
+        const size_t nf = rp_mfcc_num_frames(n_samples);
+        Staged sg(c);
+        const float *dp = static_cast<const float *>(sg.in(pcm, S * pcm_stride * sizeof(float), c->stage_in));
+        float *dm = static_cast<float *>(sg.out(mfcc, S * nf * K * sizeof(float), c->stage_out));
+        if ((S && nf) && (!dp || !dm)) return -1;
+        c->time_begin(kKernelMfcc);
+        bool ok = hip_ok(launch_mfcc(c->stream, *tb, dp, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        if (!sg.back(mfcc, dm, S * nf * K * sizeof(float)) || !sg.finish()) return -1;
+        return 0;
+    });
+}
+
+int rp_templates_new(rp_ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len, const float *avg,
+                     rp_templates **out) {
+    return guarded([&]() -> int {
+        *out = nullptr;
+        std::unique_ptr<Templates> t(Templates::create(ctx->impl.get(), T, K, lens, feats, avg_len, avg));
+        if (!t) return -1;
+        rp_templates *h = new rp_templates();
+        h->impl = std::move(t);
+        *out = h;
+        return 0;
+    });
+}
+void rp_templates_free(rp_templates *t) { delete t; }
+int rp_templates_max_len(const rp_templates *t) { return t->impl->dev.max_len; }
+
+int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames, const rp_templates *t,
+                       float score_ref, int band_size, rp_score_mode score_mode, int with_avg, float *scores,
+                       float *avg, float *agg) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        const TemplatesDev &td = t->impl->dev;
+        if (n_frames < (size_t)td.max_len) return 0;  // no complete window
+        if (band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
+        const size_t n_win = n_frames - td.max_len + 1;
+        const bool do_avg = with_avg && td.has_avg;
+        if (do_avg && !avg) { set_last_error("avg output required when with_avg is set"); return -1; }
+        Staged sg(c);
+        const size_t rows = S * n_win;
+        const float *dm = static_cast<const float *>(sg.in(mfcc, S * n_frames * td.K * sizeof(float), c->stage_in));
+        float *ds = static_cast<float *>(sg.out(scores, rows * td.T * sizeof(float), c->stage_out));
+        float *da = do_avg ? static_cast<float *>(sg.out(avg, rows * sizeof(float), c->stage_out2)) : nullptr;
+        float *dg = agg ? static_cast<float *>(sg.out(agg, rows * sizeof(float), c->stage_out3)) : nullptr;
+        if (rows && (!dm || !ds)) return -1;
+        c->time_begin(kKernelDtw);
+        bool ok = hip_ok(launch_dtw(c->stream, td, dm, S, n_frames, 0, n_win, n_win, band_size, score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+        c->time_end();
+        if (!ok) return -1;
+        if (dg) {
+            c->time_begin(kKernelAggregate);
+            ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)score_mode, dg), "aggregate_kernel");
+            c->time_end();
+            if (!ok) return -1;
+        }
+        if (!sg.back(scores, ds, rows * td.T * sizeof(float)) || (do_avg && !sg.back(avg, da, rows * sizeof(float))) ||
+            (dg && !sg.back(agg, dg, rows * sizeof(float))) || !sg.finish())
+            return -1;
+        return 0;
+    });
+}
+
+int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, size_t n_frames, int max_len,
+                   const rp_detector_config *config, int avg_enabled, rp_batch_detection *det, int32_t *n_det,
+                   int max_det) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (config->vad_mode != RP_VAD_NONE) { set_last_error("rp_detect_scan: VAD is only available on the single-stream path"); return -1; }
+        static_assert(sizeof(rp_batch_detection) == sizeof(BatchDetection), "layout");
+        ScanConfig sc;
+        sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
+        sc.eager = config->eager ? 1 : 0; sc.max_len = max_len; sc.avg_enabled = (avg_enabled && avg) ? 1 : 0;
+        const size_t n_win = n_frames >= (size_t)max_len ? n_frames - max_len + 1 : 0;
+        Staged sg(c);
+        const float *dg = static_cast<const float *>(sg.in(agg, S * n_win * sizeof(float), c->stage_in));
+        const float *da = sc.avg_enabled ? static_cast<const float *>(sg.in(avg, S * n_win * sizeof(float), c->stage_out3)) : nullptr;
+        BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
+        int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
+        c->time_begin(kKernelScan);
+        bool ok = hip_ok(launch_scan(c->stream, dg, da, S, n_frames, sc, dd, dn, max_det), "scan_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t)) || !sg.finish()) return -1;
+        return 0;
+    });
+}
+
+int rp_mlp_forward_batch(rp_ctx *ctx, const float *x, size_t B, int n_layers, const int *dims,
+                         const float *const *weights, const float *const *biases, float *logits) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (n_layers < 1 || n_layers > 8) { set_last_error("unsupported layer count"); return -1; }
+        std::vector<float *> W(n_layers, nullptr), Bv(n_layers, nullptr);
+        int maxd = 0;
+        bool ok = true;
+        for (int l = 0; l <= n_layers; ++l) maxd = std::max(maxd, dims[l]);
+        for (int l = 0; ok && l < n_layers; ++l) {
+            size_t nw = (size_t)dims[l] * dims[l + 1] * 4, nb = (size_t)dims[l + 1] * 4;
+            ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&W[l]), nw), "hipMalloc") && hip_ok(hipMalloc(reinterpret_cast<void **>(&Bv[l]), nb), "hipMalloc") &&
+                 hip_ok(hipMemcpyAsync(W[l], weights[l], nw, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync") &&
+                 hip_ok(hipMemcpyAsync(Bv[l], biases[l], nb, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync");
+        }
+        DevBuf s0, s1;
+        Staged sg(c);
+        const float *dx = nullptr; float *dl = nullptr;
+        if (ok) {
+            dx = static_cast<const float *>(sg.in(x, B * (size_t)dims[0] * 4, c->stage_in));
+            dl = static_cast<float *>(sg.out(logits, B * (size_t)dims[n_layers] * 4, c->stage_out));
+            ok = s0.reserve(B * (size_t)maxd * 4) && s1.reserve(B * (size_t)maxd * 4) && (B == 0 || (dx && dl));
+        }
+        if (ok) {
+            c->time_begin(kKernelMlp);
+            ok = hip_ok(launch_mlp(c->stream, dx, B, n_layers, dims, W.data(), Bv.data(), s0.as<float>(), s1.as<float>(), dl), "mlp kernel");
+            c->time_end();
+        }
+        if (ok) ok = sg.back(logits, dl, B * (size_t)dims[n_layers] * 4);
+        if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) ok = false;
+        for (float *p : W) if (p) (void)hipFree(p);
+        for (float *p : Bv) if (p) (void)hipFree(p);
+        return ok ? 0 : -1;
+    });
+}
+
+int rp_synth_pcm_batch(rp_ctx *ctx, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples, size_t pcm_stride,
+                       float *pcm) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        Staged sg(c);
+        float *dp = static_cast<float *>(sg.out(pcm, S * pcm_stride * sizeof(float), c->stage_out));
+        if (S && n_samples && !dp) return -1;
+        if (!hip_ok(launch_synth(c->stream, seed, first_stream, S, n_samples, pcm_stride, dp), "synth_kernel")) return -1;
+        if (!sg.back(pcm, dp, S * pcm_stride * sizeof(float)) || !sg.finish()) return -1;
+        return 0;
+    });
+}
+
+int rp_ctx_timing_enable(rp_ctx *ctx, int enable) { ctx->impl->timing = enable != 0; return 0; }
+int rp_ctx_timing_reset(rp_ctx *ctx) {
+    ctx->impl->time_collect();
+    for (int i = 0; i < kKernelCount; ++i) { ctx->impl->sum_ms[i] = 0; ctx->impl->count[i] = 0; }
+    return 0;
+}
+int rp_ctx_timing_read(rp_ctx *ctx, int kernel, double *avg_ms, int *launches) {
+    if (kernel < 0 || kernel >= kKernelCount) { set_last_error("unknown kernel id"); return -1; }
+    ctx->impl->time_collect();
+    int n = ctx->impl->count[kernel];
+    if (avg_ms) *avg_ms = n ? ctx->impl->sum_ms[kernel] / n : 0.0;
+    if (launches) *launches = n;
+    return 0;
+}
+
+}  // extern "C"

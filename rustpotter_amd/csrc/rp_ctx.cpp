@@ -1,0 +1,147 @@
+// rp_ctx.cpp -- device context, buffers, template upload, per-kernel event timing.
+#include <cmath>
+#include <cstring>
+
+#include "rp_host.h"
+
+namespace rp {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+const std::string &last_error() { return g_last_error; }
+
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    set_last_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+    return false;
+}
+
+DevBuf::~DevBuf() { if (p) (void)hipFree(p); }
+bool DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    if (!hip_ok(hipMalloc(&p, want), "hipMalloc")) { p = nullptr; return false; }
+    cap = want;
+    return true;
+}
+
+Ctx *Ctx::create(int device, int flags) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_last_error("no usable HIP device: librustpotter_hip has no CPU fallback (" +
+                       std::string(e == hipSuccess ? "device count 0" : hipGetErrorString(e)) + ")");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) { set_last_error("HIP device ordinal out of range"); return nullptr; }
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
+    std::unique_ptr<Ctx> c(new Ctx());
+    c->device = device;
+    c->flags = flags;
+    if (!hip_ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    c->stream = c->own_stream;
+    return c.release();
+}
+
+Ctx::~Ctx() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto &kv : tables) {
+        MfccTablesDev &t = kv.second;
+        (void)hipFree(t.hamming); (void)hipFree(t.tw240); (void)hipFree(t.tw480); (void)hipFree(t.fb); (void)hipFree(t.dct);
+    }
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+template <class T> static bool upload(T **dst, const std::vector<T> &src) {
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(dst), src.size() * sizeof(T)), "hipMalloc(table)")) return false;
+    return hip_ok(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(table)");
+}
+
+const MfccTablesDev *Ctx::tables_for(int K) {
+    auto it = tables.find(K);
+    if (it != tables.end()) return &it->second;
+    if (K < 1 || K > 63) { set_last_error("mfcc_size out of the supported range 1..63"); return nullptr; }
+    HostTables h = build_tables(K);
+    MfccTablesDev d;
+    d.K1 = h.K1;
+    if (!upload(&d.hamming, h.hamming) || !upload(&d.tw240, h.tw240) || !upload(&d.tw480, h.tw480) ||
+        !upload(&d.fb, h.fb) || !upload(&d.dct, h.dct))
+        return nullptr;
+    return &(tables[K] = d);
+}
+
+void Ctx::time_begin(int kernel) {
+    if (!timing) return;
+    Timed t; t.kernel = kernel;
+    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, stream);
+    pending.push_back(t);
+}
+void Ctx::time_end() {
+    if (!timing || pending.empty()) return;
+    (void)hipEventRecord(pending.back().b, stream);
+}
+void Ctx::time_collect() {
+    for (auto &t : pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            sum_ms[t.kernel] += ms; count[t.kernel] += 1;
+        }
+        (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+    }
+    pending.clear();
+}
+
+// Template rows are scaled to unit L2 norm in f64 and rounded once to f32; an all-zero
+// row stays zero so that its cosine similarity is 0 (src/mfcc/comparator.rs:43-47).
+Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len,
+                             const float *avg) {
+    if (T < 1 || K < 1) { set_last_error("Can not create an empty wakeword"); return nullptr; }  // wakeword_ref.rs:53
+    int max_len = 0, longest = 0;
+    for (int t = 0; t < T; ++t) {
+        if (lens[t] < 1) { set_last_error("wakeword template without frames"); return nullptr; }
+        if (lens[t] > max_len) max_len = lens[t];
+    }
+    longest = max_len;
+    const int has_avg = (avg && avg_len > 0) ? 1 : 0;
+    if (has_avg && avg_len > longest) longest = avg_len;
+    const int Ttot = T + has_avg, Lpad = longest;
+    std::vector<float> unit((size_t)Ttot * Lpad * K, 0.f);
+    std::vector<int> hl(Ttot);
+    size_t off = 0;
+    for (int t = 0; t < Ttot; ++t) {
+        const float *src = t < T ? feats + off : avg;
+        const int L = t < T ? lens[t] : avg_len;
+        hl[t] = L;
+        for (int r = 0; r < L; ++r) {
+            double nn = 0.0;
+            for (int k = 0; k < K; ++k) nn += (double)src[(size_t)r * K + k] * (double)src[(size_t)r * K + k];
+            // the reference tests sqrt(dot_a*dot_b) == 0 in f32; a row whose f32 squared norm is 0 is a zero row
+            float nf = 0.f;
+            for (int k = 0; k < K; ++k) nf += src[(size_t)r * K + k] * src[(size_t)r * K + k];
+            double inv = (nf > 0.f && nn > 0.0) ? 1.0 / std::sqrt(nn) : 0.0;
+            for (int k = 0; k < K; ++k) unit[((size_t)t * Lpad + r) * K + k] = (float)((double)src[(size_t)r * K + k] * inv);
+        }
+        if (t < T) off += (size_t)L * K;
+    }
+    std::unique_ptr<Templates> tp(new Templates());
+    tp->ctx = ctx;
+    TemplatesDev &d = tp->dev;
+    d.T = T; d.K = K; d.Lpad = Lpad; d.has_avg = has_avg; d.max_len = max_len; d.max_diff = longest - max_len;
+    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.lens), sizeof(int) * Ttot), "hipMalloc(lens)")) return nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.unit), sizeof(float) * unit.size()), "hipMalloc(templates)")) return nullptr;
+    if (!hip_ok(hipMemcpy(d.lens, hl.data(), sizeof(int) * Ttot, hipMemcpyHostToDevice), "hipMemcpy(lens)")) return nullptr;
+    if (!hip_ok(hipMemcpy(d.unit, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice), "hipMemcpy(templates)")) return nullptr;
+    return tp.release();
+}
+
+Templates::~Templates() {
+    if (dev.lens) (void)hipFree(dev.lens);
+    if (dev.unit) (void)hipFree(dev.unit);
+}
+
+}  // namespace rp

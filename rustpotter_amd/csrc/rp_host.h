@@ -1,0 +1,169 @@
+// rp_host.h -- host side of librustpotter_hip: constant tables, .rpw reader, device
+// context, and the C++ mirror of the reference's `Rustpotter` (src/detector.rs).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rustpotter_hip.h"
+#include "rp_kernels.h"
+
+namespace rp {
+
+// ---------------------------------------------------------------- constant tables
+struct HostTables {
+    int K1 = 0;
+    std::vector<float> hamming, fb, dct;
+    std::vector<float2> tw240, tw480;
+    std::vector<int> centres;
+};
+// MfccExtractor::new / set_out_size(K) tables, src/mfcc/extractor.rs:19-59,115-120,164-198
+HostTables build_tables(int K);
+
+// ------------------------------------------------------------------- .rpw reader
+struct WakewordRefData {  // src/wakewords/wakeword_ref.rs:12-20 (+ wakeword_v2.rs:8-16)
+    std::string name;
+    std::vector<std::string> tnames;  // file order
+    std::vector<int> lens;
+    std::vector<std::vector<float>> feats;  // [T] -> [len*K]
+    bool has_avg = false;
+    int avg_len = 0;
+    std::vector<float> avg;
+    bool has_threshold = false, has_avg_threshold = false;
+    float threshold = 0.f, avg_threshold = 0.f;
+    float rms_level = 0.f;
+    int mfcc_size = 0;
+};
+struct WakewordModelData {  // src/wakewords/wakeword_model.rs:11-18,68-72
+    std::vector<std::string> labels;
+    size_t train_size = 0;
+    int mfcc_size = 0;
+    std::string m_type;
+    std::map<std::string, std::pair<std::vector<size_t>, std::vector<float>>> weights;  // name -> (dims, data)
+    float rms_level = 0.f;
+};
+enum class RpwKind { Ref, Model };
+// WakewordV2 -> WakewordRef -> WakewordModel fall-through of src/detector.rs:152-176
+bool parse_rpw(const uint8_t *buf, size_t len, RpwKind *kind, WakewordRefData *ref, WakewordModelData *model,
+               std::string *err);
+
+// ---------------------------------------------------------------- device context
+void set_last_error(const std::string &msg);
+bool hip_ok(hipError_t e, const char *what);
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf();
+    bool reserve(size_t bytes);  // grows, contents NOT preserved
+    template <class T> T *as() const { return static_cast<T *>(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+struct Ctx {
+    int device = 0;
+    int flags = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::map<int, MfccTablesDev> tables;  // by K
+    // timing
+    bool timing = false;
+    struct Timed { hipEvent_t a, b; int kernel; };
+    std::vector<Timed> pending;
+    double sum_ms[kKernelCount] = {0};
+    int count[kKernelCount] = {0};
+    // staging for RP_CTX_HOST_POINTERS
+    DevBuf stage_in, stage_out, stage_out2, stage_out3;
+
+    static Ctx *create(int device, int flags);
+    ~Ctx();
+    const MfccTablesDev *tables_for(int K);
+    void time_begin(int kernel);
+    void time_end();
+    void time_collect();
+};
+
+struct Templates {
+    Ctx *ctx = nullptr;
+    TemplatesDev dev;
+    static Templates *create(Ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len,
+                             const float *avg);
+    ~Templates();
+};
+
+// ------------------------------------------------------------ `Rustpotter` mirror
+struct Detection {  // src/detector.rs:488-501
+    std::string name;
+    float avg_score = 0.f, score = 0.f;
+    std::vector<std::string> score_names;
+    std::vector<float> scores;
+    size_t counter = 0;
+    float gain = 0.f;
+};
+
+class Rustpotter {
+public:
+    static Rustpotter *create(const rp_config &cfg);
+    ~Rustpotter();
+    bool add_wakeword_from_buffer(const std::string &key, const uint8_t *buf, size_t len);
+    bool add_wakeword_from_file(const std::string &key, const std::string &path);
+    bool remove_wakeword(const std::string &key);
+    bool remove_wakewords();
+    size_t get_samples_per_frame() const { return 480 * (size_t)fmt_.channels; }
+    size_t get_bytes_per_frame() const;
+    const Detection *get_partial_detection() const { return has_partial_ ? &partial_ : nullptr; }
+    float get_rms_level() const { return rms_level_; }
+    float get_gain() const { return gain_; }
+    float get_rms_level_ref() const;
+    // returns 1 detection, 0 none, <0 error
+    int process_bytes(const uint8_t *bytes, size_t len, Detection *out);
+    template <class T> int process_samples(const T *samples, size_t n, Detection *out);
+    void update_detector_config(const rp_detector_config &c);
+    void update_filters_config(const rp_filters_config &c);
+    void reset();
+
+private:
+    Rustpotter() = default;
+    int process_audio(float *buf480, Detection *out);
+    void on_wakeword_change();
+    bool add_wakeword_ref(const std::string &key, WakewordRefData &&ref);
+    bool add_wakeword_model(const std::string &key, WakewordModelData &&model);
+    bool prepare_first(int K);
+    bool run_detection(int frame_slot, Detection *out);
+
+    struct Wakeword;
+    std::unique_ptr<Ctx> ctx_;
+    rp_audio_fmt fmt_{};
+    rp_detector_config det_{};
+    rp_filters_config filt_{};
+    std::vector<std::pair<std::string, std::unique_ptr<Wakeword>>> wakewords_;  // insertion order
+    int K_ = 0;
+    // extractor state (src/mfcc/extractor.rs:14, :66-79): one buffered 30 ms chunk
+    bool have_prev_ = false;
+    std::vector<float> chunk2_;  // [960] previous + current chunk
+    // audio_mfcc_window (src/detector.rs:69): device history + explicit length
+    DevBuf hist_;                // [hist_cap][K]
+    size_t hist_cap_ = 0, n_hist_ = 0, win_len_ = 0, max_mfcc_frames_ = 0;
+    DevBuf pcm_dev_, result_dev_, nn_x_, nn_s0_, nn_s1_;
+    std::vector<float> result_host_;
+    // detection state (src/detector.rs:71-79)
+    bool has_partial_ = false;
+    Detection partial_;
+    size_t countdown_ = 0;
+    float rms_level_ = 0.f, gain_ = 1.f;
+    // VAD (src/mfcc/vad.rs)
+    struct Vad { float mode_value = 2.f; size_t index = 0; float window[50]; size_t voice_countdown = 0; void reset(); bool is_voice(const float *mfcc, int K); };
+    bool has_vad_ = false;
+    Vad vad_;
+    // filters (src/audio/gain_normalizer_filter.rs, band_pass_filter.rs)
+    struct Gain { bool enabled = false, fixed = false; size_t window_size = 1; float min_gain = 0.1f, max_gain = 1.f, rms_level_ref = 0.f, rms_level_sqrt = 0.f; std::vector<float> win; };
+    struct BandPass { bool enabled = false; float a0, a1, a2, b1, b2, x1, x2, y1, y2; };
+    Gain gainf_;
+    BandPass bp_;
+    void configure_filters();
+};
+
+}  // namespace rp

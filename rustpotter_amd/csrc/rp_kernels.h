@@ -1,0 +1,73 @@
+// rp_kernels.h -- launchers of the gfx950 kernels (rp_kernels.hip) used by the
+// host-side mirror (rp_detector.cpp) and the C ABI (rp_capi.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rp {
+
+constexpr int kFrame = 480;   // src/constants.rs:2 @16 kHz
+constexpr int kShift = 160;   // src/constants.rs:8
+constexpr int kBins = 240;    // src/mfcc/extractor.rs:28
+
+// Device-resident constant tables of the MFCC pipeline for one mfcc_size K.
+struct MfccTablesDev {
+    int K1 = 0;               // K+1 filters / cepstral coefficients
+    float *hamming = nullptr; // [480]
+    float2 *tw240 = nullptr;  // [240] exp(-2*pi*i*k/240)
+    float2 *tw480 = nullptr;  // [240] exp(-2*pi*i*k/480)
+    float *fb = nullptr;      // [K1][240]
+    float *dct = nullptr;     // [K1][K1] cos table, row k col n
+};
+
+// Device-resident template set of one wakeword reference.
+struct TemplatesDev {
+    int T = 0;        // sample templates
+    int K = 0;
+    int Lpad = 0;     // row pitch (frames) of `unit`
+    int has_avg = 0;  // template index T is the averaged template
+    int max_len = 0;  // max over sample templates
+    int max_diff = 0; // max(0, longest template incl. avg - max_len): >0 forces the generic kernel
+    int *lens = nullptr;   // [T+has_avg]
+    float *unit = nullptr; // [T+has_avg][Lpad][K] rows scaled to unit L2 norm (zero rows stay zero)
+};
+
+enum KernelId { kKernelMfcc = 0, kKernelDtw = 1, kKernelAggregate = 2, kKernelScan = 3, kKernelMlp = 4, kKernelCount = 5 };
+
+struct ScanConfig {
+    float threshold, avg_threshold;
+    int min_scores, eager, max_len, avg_enabled;
+};
+
+struct BatchDetection {  // == rp_batch_detection
+    int32_t stream, frame, window, counter;
+    float avg_score, score;
+};
+
+hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
+                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc);
+
+// scores [S][n_win][T]; avg [S][n_win] or nullptr.  mfcc rows have `frame_pitch` frames per stream.
+hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                      size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
+                      float *scores, float *avg);
+
+hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg);
+
+hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, size_t S, size_t n_frames,
+                       const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det);
+
+hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
+                        size_t pcm_stride, float *pcm);
+
+// x [B][dims[0]] -> out [B][dims[n_layers]]; W/Bv device pointers per layer.
+// MfccNormalizer::normalize of windows [w, w+L) flattened row-major to x [n_win][L*K]
+// (WakewordNN::run_detection, src/wakewords/nn/wakeword_nn.rs:139-149,268-273).
+hipError_t launch_normalize_windows(hipStream_t st, const float *mfcc, size_t first_win, size_t n_win, int L, int K,
+                                    float *x);
+
+hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
+                      float *const *Bv, float *scratch0, float *scratch1, float *out);
+
+}  // namespace rp

@@ -1,0 +1,694 @@
+// rp_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the rustpotter MFCC + DTW
+// scoring path.  Written for 64-wide wavefronts; compiled with -ffp-contract=off so
+// that every fused multiply-add below is an explicit fmaf(): the reference never
+// contracts (Rust), and two places (pre-emphasis, DCT) must round exactly like it so
+// that digital silence still normalises to exactly zero (SURVEY.md §7 "Silence").
+//
+// Kernels (DESIGN.md §3 has the data layout and the roofline of each):
+//   mfcc_kernel        src/mfcc/extractor.rs:60-163   16 lanes per 30 ms frame
+//   dtw_band_kernel    src/mfcc/dtw.rs:56-105 + comparator.rs + normalizer.rs,
+//                      one lane per (window, template), band + ring in registers
+//   dtw_generic_kernel same, any K / band / m!=n, band state in LDS (fallback)
+//   aggregate_kernel   src/wakewords/comp/wakeword_comp.rs:38-49,108-139
+//   scan_kernel        src/detector.rs:290-302,377-454 (no VAD)
+//   mlp_layer_kernel   src/wakewords/nn/wakeword_nn.rs:305-389
+//   synth_kernel       BASELINE.md §2 input generator
+#include "rp_kernels.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace rp {
+
+#define RP_INF __builtin_inff()
+
+// ------------------------------------------------------------------ complex helpers
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+// forward 4-point DFT, in place, natural order
+__device__ __forceinline__ void dft4(float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
+    float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_mi(csub(x1, x3));
+    x0 = cadd(t0, t2); x1 = cadd(t1, t3); x2 = csub(t0, t2); x3 = csub(t1, t3);
+}
+
+// forward 16-point DFT in registers.  Input v[n]; output X[c + 4d] is left at v[4c + d].
+__device__ __forceinline__ void fft16(float2 (&v)[16]) {
+    // W16^e = exp(-2*pi*i*e/16) for e = b*c, b,c in 0..3
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);  // -> v[4c+b]
+    // twiddles v[4c+b] *= W16^{bc}
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], make_float2(C1, -S1));   // e=1
+    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], make_float2(R2, -R2));   // e=2
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], make_float2(S1, -C1));   // e=3
+    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], make_float2(R2, -R2));   // e=2
+    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                       // e=4
+    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], make_float2(-R2, -R2));  // e=6
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], make_float2(S1, -C1));   // e=3
+    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], make_float2(-R2, -R2));  // e=6
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-C1, S1));   // e=9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+__device__ __forceinline__ void dft3(float2 &x0, float2 &x1, float2 &x2) {
+    constexpr float C = 0.86602540378443865f;
+    float2 s = cadd(x1, x2), d = csub(x1, x2);
+    float2 m = make_float2(fmaf(-0.5f, s.x, x0.x), fmaf(-0.5f, s.y, x0.y));
+    x0 = cadd(x0, s);
+    x1 = make_float2(fmaf(C, d.y, m.x), fmaf(-C, d.x, m.y));
+    x2 = make_float2(fmaf(-C, d.y, m.x), fmaf(C, d.x, m.y));
+}
+
+__device__ __forceinline__ void dft5(float2 &x0, float2 &x1, float2 &x2, float2 &x3, float2 &x4) {
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    float2 a1 = cadd(x1, x4), a2 = cadd(x2, x3), b1 = csub(x1, x4), b2 = csub(x2, x3);
+    float2 m1 = make_float2(fmaf(c2, a2.x, fmaf(c1, a1.x, x0.x)), fmaf(c2, a2.y, fmaf(c1, a1.y, x0.y)));
+    float2 m2 = make_float2(fmaf(c1, a2.x, fmaf(c2, a1.x, x0.x)), fmaf(c1, a2.y, fmaf(c2, a1.y, x0.y)));
+    float2 n1 = make_float2(fmaf(s2, b2.x, s1 * b1.x), fmaf(s2, b2.y, s1 * b1.y));
+    float2 n2 = make_float2(fmaf(-s1, b2.x, s2 * b1.x), fmaf(-s1, b2.y, s2 * b1.y));
+    x0 = cadd(x0, cadd(a1, a2));
+    x1 = make_float2(m1.x + n1.y, m1.y - n1.x);
+    x4 = make_float2(m1.x - n1.y, m1.y + n1.x);
+    x2 = make_float2(m2.x + n2.y, m2.y - n2.x);
+    x3 = make_float2(m2.x - n2.y, m2.y + n2.x);
+}
+
+// forward 15-point DFT (Good-Thomas 3x5, no twiddles): z[k] = sum_n u[n] W15^{nk}
+__device__ __forceinline__ void dft15(const float2 (&u)[15], float2 (&z)[15]) {
+    float2 y[3][5];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        float2 a0 = u[(3 * n2) % 15], a1 = u[(5 + 3 * n2) % 15], a2 = u[(10 + 3 * n2) % 15];
+        dft3(a0, a1, a2);
+        y[0][n2] = a0; y[1][n2] = a1; y[2][n2] = a2;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        dft5(y[k1][0], y[k1][1], y[k1][2], y[k1][3], y[k1][4]);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) z[(10 * k1 + 6 * k2) % 15] = y[k1][k2];
+    }
+}
+
+// ------------------------------------------------------------------------- MFCC
+// One workgroup = 256 lanes = 16 consecutive frames of one stream, 16 lanes per frame.
+// Frame j covers samples [(j+1)*160, (j+4)*160) of the stream (the frame made of the
+// first three shifts is never emitted, src/mfcc/extractor.rs:69-79).  The real
+// 480-point DFT is one 240-point complex FFT (16 x 15 four-step: FFT16 per lane over
+// n1, twiddle, transpose through LDS, DFT15 per lane over n2) plus the even/odd
+// untangling step; only bins 0..239 are formed (src/mfcc/extractor.rs:28,111-113).
+constexpr int kMfccFramesPerBlock = 16;
+constexpr int kMfccThreads = 256;
+constexpr int kMfccStage = kMfccFramesPerBlock * kShift + 2 * kShift;  // 2880 samples
+
+__host__ __device__ inline size_t mfcc_lds_bytes(int K1) {
+    size_t f = kMfccStage + 480 + (size_t)K1 * kBins + (size_t)K1 * K1 + (size_t)kMfccFramesPerBlock * K1;
+    size_t c = (size_t)kMfccFramesPerBlock * 240 + 240 + 240;
+    return c * sizeof(float2) + f * sizeof(float);
+}
+
+__global__ __launch_bounds__(kMfccThreads) void mfcc_kernel(
+    const float *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t first_frame,
+    size_t n_frames, size_t out_frame_pitch, int K1, const float *__restrict__ g_ham, const float2 *__restrict__ g_tw240,
+    const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb, const float *__restrict__ g_dct,
+    float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float2 *scr = reinterpret_cast<float2 *>(smem);             // [16][240]
+    float2 *tw240 = scr + kMfccFramesPerBlock * 240;            // [240]
+    float2 *tw480 = tw240 + 240;                                // [240]
+    float *ypre = reinterpret_cast<float *>(tw480 + 240);       // [2880] pre-emphasised samples
+    float *ham = ypre + kMfccStage;                             // [480]
+    float *fb = ham + 480;                                      // [K1][240]
+    float *dct = fb + (size_t)K1 * kBins;                       // [K1][K1]
+    float *lgb = dct + (size_t)K1 * K1;                         // [16][K1]
+
+    const int tid = threadIdx.x;
+    const unsigned tile = blockIdx.x % tiles_per_stream;
+    const size_t s = blockIdx.x / tiles_per_stream;
+    const size_t j0 = first_frame + (size_t)tile * kMfccFramesPerBlock;
+    const float *x = pcm + s * pcm_stride;
+
+    for (int i = tid; i < 480; i += kMfccThreads) ham[i] = g_ham[i];
+    for (int i = tid; i < 240; i += kMfccThreads) { tw240[i] = g_tw240[i]; tw480[i] = g_tw480[i]; }
+    for (int i = tid; i < K1 * kBins; i += kMfccThreads) fb[i] = g_fb[i];
+    for (int i = tid; i < K1 * K1; i += kMfccThreads) dct[i] = g_dct[i];
+    // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift
+    const size_t base = (j0 + 1) * kShift;
+    for (int i = tid; i < kMfccStage; i += kMfccThreads) {
+        size_t g = base + i;
+        float cur = g < n_samples ? x[g] : 0.f;
+        float prev = (i % kShift == 0 || g >= n_samples) ? 0.f : x[g - 1];
+        ypre[i] = cur - 0.97f * prev;  // separate multiply and subtract, like the reference
+    }
+    __syncthreads();
+
+    const int grp = tid >> 4, l = tid & 15;
+    float2 *my = scr + grp * 240;
+    // ---- step 1: lane n2=l (<15) : FFT16 over n1 of z[15*n1 + n2], z[n] = (y[2n], y[2n+1]) * hamming
+    {
+        float2 v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            int i = 30 * n1 + 2 * (l < 15 ? l : 0);
+            float2 yy = *reinterpret_cast<const float2 *>(&ypre[grp * kShift + i]);
+            float2 hh = *reinterpret_cast<const float2 *>(&ham[i]);
+            v[n1] = make_float2(yy.x * hh.x, yy.y * hh.y);
+        }
+        fft16(v);
+        if (l < 15) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    int k1 = c + 4 * d;
+                    my[k1 * 15 + l] = cmul(v[4 * c + d], tw240[l * k1]);  // W240^{n2*k1}
+                }
+        }
+    }
+    __syncthreads();
+    // ---- step 3: lane k1=l : DFT15 over n2 -> Z[k1 + 16*k2]
+    float2 z[15];
+    {
+        float2 u[15];
+#pragma unroll
+        for (int n2 = 0; n2 < 15; ++n2) u[n2] = my[l * 15 + n2];
+        dft15(u, z);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 15; ++k2) my[l + 16 * k2] = z[k2];
+    __syncthreads();
+    // ---- untangle the two interleaved real sequences and take |X[k]|^2, k = l + 16*k2
+    float P[15];
+#pragma unroll
+    for (int k2 = 0; k2 < 15; ++k2) {
+        int k = l + 16 * k2;
+        float2 a = z[k2];
+        float2 b = my[k == 0 ? 0 : 240 - k];
+        float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        float2 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
+        float2 w = tw480[k];
+        float xr = e.x + fmaf(w.x, o.x, -(w.y * o.y));
+        float xi = e.y + fmaf(w.x, o.y, w.y * o.x);
+        P[k2] = fmaf(xr, xr, xi * xi);  // (sqrt(re^2+im^2))^2 of extractor.rs:111-113,141 up to 1 ulp
+    }
+    // ---- mel filterbank (dense rows, 8 filters per pass) + ln, src/mfcc/extractor.rs:121-145
+    for (int i0 = 0; i0 < K1; i0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            acc[ii] = 0.f;
+            if (i0 + ii < K1) {
+                const float *row = fb + (size_t)(i0 + ii) * kBins + l;
+#pragma unroll
+                for (int k2 = 0; k2 < 15; ++k2) acc[ii] = fmaf(P[k2], row[16 * k2], acc[ii]);
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            float v = acc[ii];
+            v += __shfl_xor(v, 8, 16);
+            v += __shfl_xor(v, 4, 16);
+            v += __shfl_xor(v, 2, 16);
+            v += __shfl_xor(v, 1, 16);
+            if (l == ii && i0 + ii < K1) lgb[grp * K1 + i0 + ii] = logf(v + FLT_MIN);
+        }
+    }
+    __syncthreads();
+    // ---- DCT-II x2, coefficient 0 dropped, src/mfcc/extractor.rs:84,146-163.  Sequential
+    // multiply-then-add in the reference's order (NOT fused): see the file header.
+    const size_t j = j0 + grp;
+    if (j < first_frame + n_frames) {
+        const int K = K1 - 1;
+        float *dst = out + (s * out_frame_pitch + (j - first_frame)) * (size_t)K;
+        for (int c = 1 + l; c <= K; c += 16) {
+            float sum = 0.f;
+            for (int n = 0; n < K1; ++n) sum += lgb[grp * K1 + n] * dct[c * K1 + n];
+            dst[c - 1] = 2.f * sum;
+        }
+    }
+}
+
+hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
+                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+    if (S == 0 || n_frames == 0) return hipSuccess;
+    size_t tiles = (n_frames + kMfccFramesPerBlock - 1) / kMfccFramesPerBlock;
+    size_t blocks = tiles * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    size_t lds = mfcc_lds_bytes(tb.K1);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, pcm_stride,
+                       (unsigned)tiles, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming, tb.tw240, tb.tw480,
+                       tb.fb, tb.dct, mfcc);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------- DTW
+// Scoring of one (window, template) pair, reference semantics:
+//   window = frames [w, w+L) of the stream (cut to the template length L keeping the
+//   OLDEST frames, wakeword_comp.rs:22-27), column-mean normalised (normalizer.rs);
+//   D[r][c] = (1 - cos(a[r-1], b[c-1])) + min(D[r-1][c], D[r][c-1], D[r-1][c-1]) on the band
+//   c in [r-W, r+W-1]; result D[m-1][n] (dtw.rs:101); score = 1/(1+exp((cost/(m+n)-ref)/ref)).
+// Template rows are pre-scaled to unit length on the host and window frames are scaled
+// to unit length here, so a cell costs K fused multiply-adds instead of three dot
+// products, a sqrt and a divide (comparator.rs:28-48); zero vectors stay zero, which
+// reproduces the reference's "magnitude == 0 -> similarity 0".
+constexpr int kDtwWin = 64;   // windows per wave
+constexpr int kDtwTpb = 4;    // templates (waves) per workgroup
+
+template <int K, int W>
+__global__ __launch_bounds__(kDtwWin *kDtwTpb) void dtw_band_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned tgroups,
+    size_t first_win, size_t n_win, size_t out_win_pitch, const int *__restrict__ lens,
+    const float *__restrict__ unit, int Lpad, int T, int Ttot, int max_len, float score_ref,
+    float *__restrict__ scores, float *__restrict__ avg) {
+    constexpr int B = 2 * W;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);  // [(64 + max_len - 1)][KP]
+
+    const unsigned tile = blockIdx.x % tiles;
+    const unsigned tg = (blockIdx.x / tiles) % tgroups;
+    const size_t s = blockIdx.x / ((size_t)tiles * tgroups);
+    const int lane = threadIdx.x & 63;
+    const int t = tg * kDtwTpb + (threadIdx.x >> 6);
+    const size_t w0 = first_win + (size_t)tile * kDtwWin;
+
+    const int n_stage = kDtwWin + max_len - 1;
+    const float *src = mfcc + s * frame_pitch * K;
+    for (int i = threadIdx.x; i < n_stage * K; i += blockDim.x) {
+        int f = i / K, k = i - f * K;
+        size_t g = w0 + f;
+        xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+    }
+    __syncthreads();
+    if (t >= Ttot) return;
+
+    const int L = lens[t];  // m == n == L
+    const float *xl = xs + lane * KP;
+    // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums
+    float mu[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = 0.f;
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) mu[k] += xl[i * KP + k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = mu[k] / (float)L;
+
+    float ring[B][K];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring[b][k] = 0.f;
+
+    auto load_col = [&](int c, float (&dst)[K]) {  // window frame c-1 -> unit vector
+        float y[K], bb = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { y[k] = xl[(c - 1) * KP + k] - mu[k]; bb = fmaf(y[k], y[k], bb); }
+        float inv = bb > 0.f ? rsqrtf(bb) : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k] = y[k] * inv;
+    };
+#pragma unroll
+    for (int c = 1; c < W; ++c)
+        if (c <= L) load_col(c, ring[c % B]);
+
+    // band of the previous row: P[q] = D[r-1][(r-1-W)+q]; row 0 has D[0][0] = 0 at q = W
+    float P[B + 1];
+#pragma unroll
+    for (int q = 0; q <= B; ++q) P[q] = RP_INF;
+    P[W] = 0.f;
+
+    const float *trow = unit + (size_t)t * Lpad * K;
+    for (int r0 = 1; r0 < L; r0 += B) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int r = r0 + u;
+            if (r < L) {  // rows 1..m-1 only: row m is never read (dtw.rs:101)
+                const int cnew = r + W - 1;
+                if (cnew <= L) load_col(cnew, ring[(u + W) % B]);
+                float a[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) a[k] = trow[(r - 1) * K + k];
+                float left = RP_INF;
+#pragma unroll
+                for (int q = 0; q < B; ++q) {
+                    const int c = r - W + q;
+                    const float(&y)[K] = ring[(1 + u + q + B - W) % B];
+                    float d = 1.f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) d = fmaf(-a[k], y[k], d);
+                    float v = d + fminf(fminf(P[q + 1], left), P[q]);
+                    v = (c >= 1 && c <= L) ? v : RP_INF;
+                    P[q] = v;
+                    left = v;
+                }
+            }
+        }
+    }
+    if (tile * (size_t)kDtwWin + lane < n_win) {
+        float cost = P[W + 1];  // D[m-1][n] for m == n
+        float nc = cost / (float)(L + L);
+        float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+        size_t row = s * out_win_pitch + (size_t)tile * kDtwWin + lane;
+        if (t < T) scores[row * T + t] = sc;
+        else avg[row] = sc;
+    }
+}
+
+// Fallback for any K / band size / m != n: one wave = 64 windows x one template, band
+// and column means in LDS (lane-minor, conflict-free), costs evaluated per cell.
+__global__ __launch_bounds__(64) void dtw_generic_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, size_t first_win,
+    size_t n_win, size_t out_win_pitch, const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K,
+    int T, int Ttot, int max_len, int band, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int KP = K | 1;
+    const unsigned tile = blockIdx.x % tiles;
+    const int t = (blockIdx.x / tiles) % Ttot;
+    const size_t s = blockIdx.x / ((size_t)tiles * Ttot);
+    const int lane = threadIdx.x;
+    const size_t w0 = first_win + (size_t)tile * 64;
+    const int m = lens[t];
+    const int n = m < max_len ? m : max_len;  // window cut to the template length
+    const int diff = m > n ? m - n : n - m;
+    const int W = band > diff ? band : diff;
+    const int B = 2 * W;
+
+    const int n_stage = 64 + max_len - 1;
+    float *xs = reinterpret_cast<float *>(smem);      // [n_stage][KP]
+    float *mus = xs + (size_t)n_stage * KP;           // [K][64]
+    float *Pb = mus + (size_t)K * 64;                 // [B+1][64]
+    const float *src = mfcc + s * frame_pitch * K;
+    for (int i = lane; i < n_stage * K; i += 64) {
+        int f = i / K, k = i - f * K;
+        size_t g = w0 + f;
+        xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+    }
+    __syncthreads();
+    const float *xl = xs + lane * KP;
+    for (int k = 0; k < K; ++k) {
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) sum += xl[i * KP + k];
+        mus[k * 64 + lane] = sum / (float)n;
+    }
+    for (int q = 0; q <= B; ++q) Pb[q * 64 + lane] = RP_INF;
+    Pb[W * 64 + lane] = 0.f;
+    const float *trow = unit + (size_t)t * Lpad * K;
+    for (int r = 1; r < m; ++r) {
+        float left = RP_INF;
+        for (int q = 0; q < B; ++q) {
+            const int c = r - W + q;
+            float v = RP_INF;
+            if (c >= 1 && c <= n) {
+                float dot = 0.f, bb = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    float y = xl[(c - 1) * KP + k] - mus[k * 64 + lane];
+                    dot = fmaf(trow[(r - 1) * K + k], y, dot);
+                    bb = fmaf(y, y, bb);
+                }
+                float cosv = bb > 0.f ? dot * rsqrtf(bb) : 0.f;
+                v = (1.f - cosv) + fminf(fminf(Pb[(q + 1) * 64 + lane], left), Pb[q * 64 + lane]);
+            }
+            Pb[q * 64 + lane] = v;
+            left = v;
+        }
+    }
+    if (tile * (size_t)64 + lane < n_win) {
+        const int qs = n - (m - 1 - W);  // column n of row m-1
+        float cost = (qs >= 0 && qs < B) ? Pb[qs * 64 + lane] : RP_INF;
+        float nc = cost / (float)(m + n);
+        float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+        size_t row = s * out_win_pitch + (size_t)tile * 64 + lane;
+        if (t < T) scores[row * T + t] = sc;
+        else avg[row] = sc;
+    }
+}
+
+hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                      size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
+                      float *scores, float *avg) {
+    if (S == 0 || n_win == 0) return hipSuccess;
+    const int Ttot = t.T + ((with_avg && t.has_avg) ? 1 : 0);
+    const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
+    const size_t n_frames_total = frame_pitch;
+    // the register kernel assumes m == n (no template longer than the window)
+    if (t.K == 5 && band == 5 && t.max_diff == 0) {
+        const size_t tgroups = (Ttot + kDtwTpb - 1) / kDtwTpb;
+        const size_t blocks = tiles * tgroups * S;
+        if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+        const size_t lds = (size_t)(kDtwWin + t.max_len - 1) * 5 * sizeof(float);
+        hipLaunchKernelGGL((dtw_band_kernel<5, 5>), dim3((unsigned)blocks), dim3(kDtwWin * kDtwTpb), lds, st, mfcc,
+                           frame_pitch, n_frames_total, (unsigned)tiles, (unsigned)tgroups, first_win, n_win,
+                           out_win_pitch, t.lens, t.unit, t.Lpad, t.T, Ttot, t.max_len, score_ref, scores, avg);
+        return hipGetLastError();
+    }
+    const size_t blocks = tiles * (size_t)Ttot * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const int KP = t.K | 1;
+    // band may be widened to |m-n| inside the kernel; size for the worst case over templates
+    const int Wmax = band > t.max_diff ? band : t.max_diff;
+    const size_t lds = ((size_t)(64 + t.max_len - 1) * KP + (size_t)t.K * 64 + (size_t)(2 * Wmax + 1) * 64) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_generic_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, n_frames_total,
+                       (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, Ttot,
+                       t.max_len, band, score_ref, scores, avg);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------- aggregate
+// src/wakewords/comp/wakeword_comp.rs:38-49 (get_percentile) and :108-139
+__device__ inline float percentile_sorted(const float *v, int n, float percentile) {
+    float index = percentile / 100.0f * (float)(n - 1);
+    float fl = floorf(index);
+    if (fl == index) return v[(int)index];
+    int i = (int)fl;
+    float d = index - fl;
+    return v[i] * (1.0f - d) + v[i + 1] * d;
+}
+
+constexpr int kAggMaxT = 256;
+
+__global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
+                                                       float *__restrict__ agg) {
+    size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= n_rows) return;
+    const float *v = scores + row * T;
+    if (mode == 1) {  // Max
+        float m = v[0];
+        for (int i = 1; i < T; ++i) m = fmaxf(m, v[i]);
+        agg[row] = m;
+        return;
+    }
+    if (mode == 0) {  // Average: sequential sum in template order
+        float s = 0.f;
+        for (int i = 0; i < T; ++i) s += v[i];
+        agg[row] = s / (float)T;
+        return;
+    }
+    float tmp[kAggMaxT];
+    for (int i = 0; i < T; ++i) {  // insertion sort ascending (total_cmp order for non-NaN scores)
+        float x = v[i];
+        int j = i - 1;
+        while (j >= 0 && tmp[j] > x) { tmp[j + 1] = tmp[j]; --j; }
+        tmp[j + 1] = x;
+    }
+    float p = 50.f;
+    switch (mode) {
+    case 3: p = 25.f; break;
+    case 5: p = 75.f; break;
+    case 6: p = 80.f; break;
+    case 7: p = 90.f; break;
+    case 8: p = 95.f; break;
+    default: p = 50.f; break;  // Median, P50
+    }
+    agg[row] = percentile_sorted(tmp, T, p);
+}
+
+hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg) {
+    if (n_rows == 0) return hipSuccess;
+    if (T < 1 || T > kAggMaxT) return hipErrorInvalidValue;
+    size_t blocks = (n_rows + 63) / 64;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- scan
+// The partial-detection / countdown state machine of src/detector.rs:377-454 with
+// reset() of :290-302, one lane per stream, over precomputed window scores.  Frame f
+// is emitted while chunk c = f/3 + 1 is processed; after an emit the extractor and the
+// window are cleared, the rest of that chunk's frames are dropped (find_map, :372-375),
+// chunk c+1 only refills the extractor, so the next frame seen is 3*(f/3) + 6.
+__global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg, const float *__restrict__ avg, size_t S,
+                                                  size_t n_frames, ScanConfig cfg, BatchDetection *__restrict__ det,
+                                                  int32_t *__restrict__ n_det, int max_det) {
+    size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    const long max_len = cfg.max_len;
+    const long n_win = (long)n_frames - max_len + 1;
+    const float *a = agg + s * (size_t)(n_win > 0 ? n_win : 0);
+    const float *v = avg ? avg + s * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
+    long win_start = 0, resume = 0;
+    bool has_partial = false;
+    float p_score = 0.f, p_avg = 0.f;
+    int p_counter = 0, p_window = 0, countdown = 0, nd = 0;
+    for (long f = 0; f < (long)n_frames; ++f) {
+        if (f < resume) continue;
+        if (f - win_start + 1 < max_len) continue;
+        const long w = f - max_len + 1;
+        if (countdown != 0) countdown -= 1;
+        if (has_partial) {
+            bool done = countdown == 0 ? true : (cfg.eager && p_counter >= cfg.min_scores);
+            if (done) {
+                has_partial = false;  // take()
+                if (p_counter >= cfg.min_scores) {
+                    if (nd < max_det) {
+                        BatchDetection d;
+                        d.stream = (int32_t)s; d.frame = (int32_t)f; d.window = p_window; d.counter = p_counter;
+                        d.avg_score = p_avg; d.score = p_score;
+                        det[s * (size_t)max_det + nd] = d;
+                    }
+                    ++nd;
+                    win_start = resume = 3 * (f / 3) + 6;  // reset()
+                    continue;
+                }
+            }
+        }
+        float sc = a[w];
+        float av = 0.f;
+        bool pass = true;
+        if (cfg.avg_enabled) { av = v[w]; pass = !(av < cfg.avg_threshold); }
+        if (pass && sc > cfg.threshold) {
+            int counter = has_partial ? p_counter + 1 : 1;
+            if (!has_partial || p_score < sc) { p_score = sc; p_avg = av; p_window = (int)w; has_partial = true; }
+            p_counter = counter;
+            countdown = (int)(max_len / 2);
+        }
+    }
+    n_det[s] = nd;
+}
+
+hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, size_t S, size_t n_frames,
+                       const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det) {
+    if (S == 0) return hipSuccess;
+    size_t blocks = (S + 63) / 64;
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)blocks), dim3(64), 0, st, agg, avg, S, n_frames, cfg, det, n_det,
+                       max_det);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------ synth
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
+                                                    size_t pcm_stride, float *__restrict__ pcm) {
+    const size_t total = S * n_samples;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        size_t s = idx / n_samples, i = idx - s * n_samples;
+        uint64_t h = splitmix64(seed ^ (((first_stream + s) << 32) + (uint64_t)i));
+        pcm[s * pcm_stride + i] = (float)(h >> 40) / 16777216.f - 0.5f;
+    }
+}
+
+hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
+                        size_t pcm_stride, float *pcm) {
+    if (S == 0 || n_samples == 0) return hipSuccess;
+    size_t total = S * n_samples;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, first_stream, S, n_samples,
+                       pcm_stride, pcm);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------- MLP
+// Linear (x.W^T + b, W [out][in]) + optional ReLU, f32, k-ordered accumulation like
+// candle's CPU gemm restated in the oracle.  One wave per (row, 64 outputs) tile with
+// the input row staged in LDS.  (Round-1 correctness path; DESIGN.md lists the MFMA
+// bf16 path for BASELINE config 5 as next.)
+__global__ __launch_bounds__(64) void mlp_layer_kernel(const float *__restrict__ x, size_t B, int in, int on,
+                                                       const float *__restrict__ Wt, const float *__restrict__ bias,
+                                                       int relu, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xr = reinterpret_cast<float *>(smem);
+    const size_t b = blockIdx.x;
+    const int o = blockIdx.y * 64 + threadIdx.x;
+    for (int i = threadIdx.x; i < in; i += 64) xr[i] = x[b * in + i];
+    __syncthreads();
+    if (o >= on) return;
+    const float *w = Wt + (size_t)o * in;
+    float s = 0.f;
+    for (int i = 0; i < in; ++i) s += xr[i] * w[i];
+    s += bias[o];
+    if (relu && s < 0.f) s = 0.f;
+    out[b * on + o] = s;
+}
+
+__global__ __launch_bounds__(64) void normalize_windows_kernel(const float *__restrict__ mfcc, size_t first_win,
+                                                                size_t n_win, int L, int K, float *__restrict__ x) {
+    const size_t w = blockIdx.x;
+    const float *src = mfcc + (first_win + w) * K;
+    float *dst = x + w * (size_t)L * K;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        float sum = 0.f;
+        for (int i = 0; i < L; ++i) sum += src[(size_t)i * K + k];
+        for (int i = 0; i < L; ++i) dst[(size_t)i * K + k] = src[(size_t)i * K + k] - sum / (float)L;
+    }
+}
+
+hipError_t launch_normalize_windows(hipStream_t st, const float *mfcc, size_t first_win, size_t n_win, int L, int K,
+                                    float *x) {
+    if (n_win == 0) return hipSuccess;
+    hipLaunchKernelGGL(normalize_windows_kernel, dim3((unsigned)n_win), dim3(64), 0, st, mfcc, first_win, n_win, L, K, x);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
+                      float *const *Bv, float *scratch0, float *scratch1, float *out) {
+    if (B == 0) return hipSuccess;
+    const float *cur = x;
+    float *bufs[2] = {scratch0, scratch1};
+    for (int l = 0; l < n_layers; ++l) {
+        float *dst = (l + 1 == n_layers) ? out : bufs[l & 1];
+        dim3 grid((unsigned)B, (unsigned)((dims[l + 1] + 63) / 64));
+        size_t lds = (size_t)dims[l] * sizeof(float);
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(mlp_layer_kernel, grid, dim3(64), lds, st, cur, B, dims[l], dims[l + 1], W[l], Bv[l],
+                           l + 1 < n_layers ? 1 : 0, dst);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        cur = dst;
+    }
+    return hipSuccess;
+}
+
+}  // namespace rp

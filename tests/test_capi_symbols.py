@@ -1,0 +1,63 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads without a GPU,
+exports every function include/rustpotter_hip.h declares, and fails loudly (no CPU
+fallback) when no HIP device exists."""
+import os
+import re
+
+import pytest
+
+
+def _header_functions():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "include", "rustpotter_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import rustpotter_amd
+    from rustpotter_amd.api import SYMBOLS
+    L = rustpotter_amd.load_library()
+    declared = _header_functions()
+    assert declared == sorted(SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.rp_version()
+
+
+def test_default_config_matches_reference_constants():
+    import ctypes as C
+    import rustpotter_amd
+    from rustpotter_amd.api import _Config
+    L = rustpotter_amd.load_library()
+    c = _Config()
+    L.rp_config_default(C.byref(c))
+    # src/constants.rs:1-9, src/config.rs:20-29,192-207
+    assert c.fmt.sample_rate == 16000 and c.fmt.sample_format == 3 and c.fmt.channels == 1 and c.fmt.endianness == 1
+    assert abs(c.detector.avg_threshold - 0.2) < 1e-7 and c.detector.threshold == 0.5 and c.detector.min_scores == 5
+    assert abs(c.detector.score_ref - 0.22) < 1e-7 and c.detector.band_size == 5 and c.detector.score_mode == 1
+    assert not c.detector.eager and c.detector.vad_mode == 0
+    assert not c.filters.gain_normalizer.enabled and not c.filters.band_pass.enabled
+    assert c.filters.band_pass.low_cutoff == 80.0 and c.filters.band_pass.high_cutoff == 400.0
+    assert L.rp_mfcc_num_frames(18150) == 108 and L.rp_mfcc_num_frames(479) == 0 and L.rp_mfcc_num_frames(64000) == 396
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import rustpotter_amd as ra
+    with pytest.raises(ra.RustpotterError, match="no usable HIP device"):
+        ra.Rustpotter.new(ra.RustpotterConfig.default())
+    with pytest.raises(ra.RustpotterError, match="no usable HIP device"):
+        ra.BatchContext(device=0)
+
+
+def test_product_never_references_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "rustpotter_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "rp_oracle" not in txt and "oracle/" not in txt and "import oracle" not in txt, f

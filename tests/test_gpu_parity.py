@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same inputs, and against the reference's golden fixtures.
+
+Tolerances (BASELINE.json north_star / SURVEY.md §8d):
+  MFCC   |d| <= 1e-5 * max(|ref|, 1)
+  scores relative 1e-5
+  detection index / counter / countdown logic: exact
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rpw_py
+import simstream
+from oracle import rp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+G = simstream.GOLDEN
+EXP = json.load(open(os.path.join(G, "expectations.json")))
+SEED = 0x5EED000000000001
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rustpotter_amd
+    return rustpotter_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ra):
+    return ra.BatchContext(device=0, host_pointers=True)
+
+
+def mfcc_close(got, ref):
+    return np.all(np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0))
+
+
+def rel_close(got, ref, rtol=1e-5):
+    return np.all(np.abs(got - ref) <= rtol * np.abs(ref))
+
+
+def test_synth_generator_bit_exact(ctx):
+    pcm = ctx.synth_pcm(SEED, 7, 3, 1000)
+    for s in range(3):
+        assert np.array_equal(pcm[s], orc.synth_pcm(SEED, 7 + s, 1000))
+
+
+@pytest.mark.parametrize("K", [5, 16, 1, 23])
+def test_mfcc_synthetic_streams(ctx, K):
+    S, N = 5, 480 * 37 + 123  # ragged tail: the last 123 samples are ignored like chunks_exact does
+    pcm = np.stack([orc.synth_pcm(SEED, s, N) for s in range(S)])
+    got = ctx.mfcc(pcm, K)
+    assert got.shape == (S, 3 * 37 - 3, K)
+    for s in range(S):
+        assert mfcc_close(got[s], orc.mfcc_stream(pcm[s], K))
+
+
+def test_mfcc_fixture_wavs(ctx):
+    for name in ["oye_casa_g_1.wav", "oye_casa_g_5.wav", "alexa2.wav"]:
+        pcm, _ = rpw_py.read_wav_i16(os.path.join(G, name))
+        x = simstream.i16_to_f32(pcm)
+        got = ctx.mfcc(x, 5)[0]
+        ref = orc.mfcc_stream(x, 5)
+        assert got.shape == ref.shape and mfcc_close(got, ref)
+    # golden: normalised GPU MFCC == matrices the reference stored in its .rpw (G1)
+    w = rpw_py.load_rpw(os.path.join(G, "alexa.rpw"))
+    for name, ref in w["samples_features"].items():
+        pcm, _ = rpw_py.read_wav_i16(os.path.join(G, name))
+        got = orc.normalize(ctx.mfcc(simstream.i16_to_f32(pcm), 5)[0])
+        assert mfcc_close(got, ref)
+
+
+def test_mfcc_edge_sizes(ctx):
+    assert ctx.mfcc(np.zeros((2, 479), np.float32), 5).shape == (2, 0, 5)      # no full chunk
+    assert ctx.mfcc(np.zeros((2, 480), np.float32), 5).shape == (2, 0, 5)      # one chunk: extractor only fills
+    x = orc.synth_pcm(SEED, 3, 960)
+    got = ctx.mfcc(x, 5)
+    assert got.shape == (1, 3, 5) and mfcc_close(got[0], orc.mfcc_stream(x, 5))
+
+
+def test_mfcc_silence_is_bitwise_constant(ctx):
+    """Digital silence must give identical frames that normalise to exactly 0."""
+    got = ctx.mfcc(np.zeros((1, 480 * 50), np.float32), 5)[0]
+    ref = orc.mfcc_stream(np.zeros(480 * 50, np.float32), 5)
+    assert np.all(got == got[0])
+    assert np.all(orc.normalize(got[:100]) == 0.0)
+    assert mfcc_close(got, ref)
+
+
+def _sim_mfcc():
+    s = simstream.simulation_stream_i16()
+    return orc.mfcc_stream(simstream.i16_to_f32(s), 5)
+
+
+@pytest.mark.parametrize("rpw", ["alexa.rpw", "oye_casa_g.rpw"])
+def test_dtw_scores_fixture_stream(ra, ctx, rpw):
+    """BASELINE config C1: the reference's detector simulation stream against its own templates."""
+    w = rpw_py.load_rpw(os.path.join(G, rpw))
+    templates = list(w["samples_features"].values())
+    mf = _sim_mfcc()
+    tm = ra.Templates(ctx, templates, avg=w["avg_features"])
+    scores, avg, agg = ctx.dtw_scores(mf, tm, with_avg=True)
+    ref_s, ref_a = orc.score_stream(mf, templates)
+    assert scores.shape[1:] == ref_s.shape
+    assert rel_close(scores[0], ref_s) and rel_close(agg[0], ref_a)
+    Lmax = max(len(t) for t in templates)
+    ref_avg = np.array([orc.score_window(mf[s:s + Lmax], w["avg_features"]) for s in range(0, ref_s.shape[0], 7)])
+    assert rel_close(avg[0][::7], ref_avg)
+
+
+@pytest.mark.parametrize("mode", ["average", "max", "median", "p25", "p50", "p75", "p80", "p90", "p95"])
+def test_score_modes(ra, ctx, mode):
+    w = rpw_py.load_rpw(os.path.join(G, "oye_casa_g.rpw"))
+    templates = list(w["samples_features"].values())
+    mf = _sim_mfcc()[480:900]
+    tm = ra.Templates(ctx, templates)
+    sm = {"average": ra.ScoreMode.Average, "max": ra.ScoreMode.Max, "median": ra.ScoreMode.Median, "p25": ra.ScoreMode.P25,
+          "p50": ra.ScoreMode.P50, "p75": ra.ScoreMode.P75, "p80": ra.ScoreMode.P80, "p90": ra.ScoreMode.P90,
+          "p95": ra.ScoreMode.P95}[mode]
+    scores, _, agg = ctx.dtw_scores(mf, tm, score_mode=sm)
+    # aggregate of the GPU's own scores must equal the oracle's aggregation bit for bit ...
+    ref_from_gpu = np.array([orc.aggregate(scores[0][i], mode) for i in range(scores.shape[1])], np.float32)
+    assert np.array_equal(agg[0], ref_from_gpu)
+    # ... and the end-to-end value is within tolerance of the oracle path
+    _, ref_a = orc.score_stream(mf, templates, mode=mode)
+    assert rel_close(agg[0], ref_a)
+
+
+@pytest.mark.parametrize("K,band,L", [(5, 5, 100), (5, 3, 64), (16, 5, 50), (5, 9, 30), (3, 1, 12)])
+def test_dtw_synthetic(ra, ctx, K, band, L):
+    """Register kernel (K=5, band=5) and the generic kernel on BASELINE-style synthetic input."""
+    T, S, N = 3, 4, 480 * 60
+    templates = orc.synth_templates(SEED, T, L, K)
+    templates[1] = templates[1][: L - 7].copy()  # ragged template lengths
+    pcm = np.stack([orc.synth_pcm(SEED, s, N) for s in range(S)])
+    mf = np.stack([orc.mfcc_stream(pcm[s], K) for s in range(S)])
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(mf, tm, band_size=band)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates, band=band)
+        assert rel_close(scores[s], ref_s), np.abs(scores[s] / ref_s - 1).max()
+        assert rel_close(agg[s], ref_a)
+
+
+def test_dtw_avg_longer_than_window(ra, ctx):
+    """m != n: an averaged template longer than every sample template widens the band to |m-n|."""
+    K = 5
+    templates = orc.synth_templates(SEED, 2, 40, K)
+    avg = orc.synth_templates(SEED + 9, 1, 46, K)[0]
+    mf = orc.mfcc_stream(orc.synth_pcm(SEED, 1, 480 * 40), K)
+    tm = ra.Templates(ctx, templates, avg=avg)
+    scores, avg_s, _ = ctx.dtw_scores(mf, tm, with_avg=True)
+    ref = np.array([orc.score_window(mf[s:s + 40], avg) for s in range(scores.shape[1])])
+    assert rel_close(avg_s[0], ref)
+    ref_s, _ = orc.score_stream(mf, templates)
+    assert rel_close(scores[0], ref_s)
+
+
+def test_dtw_silence_windows(ra, ctx):
+    """All-zero normalised windows: every cell costs exactly 1 (comparator.rs:43-44)."""
+    w = rpw_py.load_rpw(os.path.join(G, "alexa.rpw"))
+    templates = list(w["samples_features"].values())
+    mf = orc.mfcc_stream(np.zeros(480 * 60, np.float32), 5)
+    tm = ra.Templates(ctx, templates)
+    scores, _, _ = ctx.dtw_scores(mf, tm)
+    ref_s, _ = orc.score_stream(mf, templates)
+    assert np.array_equal(scores[0], ref_s)
+
+
+def test_dtw_too_short_stream(ra, ctx):
+    templates = orc.synth_templates(SEED, 2, 30, 5)
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(np.zeros((1, 29, 5), np.float32), tm)
+    assert scores.shape == (1, 0, 2) and agg.shape == (1, 0)
+
+
+def _oracle_detections(e, s):
+    w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+    d = orc.Detector(avg_threshold=e["avg_threshold"], threshold=e["threshold"], min_scores=e.get("min_scores", 5),
+                     score_mode=e["score_mode"], vad_mode=e.get("vad_mode"),
+                     gain_normalizer=e.get("gain_normalizer", False), band_pass=e.get("band_pass", False),
+                     low_cutoff=e.get("low_cutoff", 80.0), high_cutoff=e.get("high_cutoff", 400.0))
+    d.add_ref(w)
+    out = []
+    for i in range(0, len(s) - 479, 480):
+        r = d.process_i16(s[i:i + 480])
+        if r is not None:
+            out.append((i // 480, r))
+    return out
+
+
+def _make_config(ra, e):
+    c = ra.RustpotterConfig.default()
+    c.fmt.sample_rate, c.fmt.sample_format, c.fmt.channels = 16000, ra.SampleFormat.I16, 1
+    c.detector.avg_threshold, c.detector.threshold = e["avg_threshold"], e["threshold"]
+    c.detector.min_scores = e.get("min_scores", 5)
+    c.detector.score_mode = {"max": ra.ScoreMode.Max, "median": ra.ScoreMode.Median, "average": ra.ScoreMode.Average}[e["score_mode"]]
+    c.detector.vad_mode = {None: None, "easy": ra.VADMode.Easy}[e.get("vad_mode")]
+    c.filters.gain_normalizer.enabled = e.get("gain_normalizer", False)
+    c.filters.band_pass.enabled = e.get("band_pass", False)
+    c.filters.band_pass.low_cutoff = e.get("low_cutoff", 80.0)
+    c.filters.band_pass.high_cutoff = e.get("high_cutoff", 400.0)
+    return c
+
+
+@pytest.mark.parametrize("case", sorted(EXP["simulation"].keys()))
+def test_rustpotter_api_goldens(ra, case):
+    """tests/detector.rs through the drop-in API (process_bytes, 30 ms chunks) on the GPU:
+    same detections as the reference asserts, same chunk / counter as the oracle."""
+    e = EXP["simulation"][case]
+    s = simstream.simulation_stream_i16(*e.get("gains", [1.0, 1.0]))
+    rp = ra.Rustpotter.new(_make_config(ra, e))
+    rp.add_wakeword_from_file("wakeword", os.path.join(G, e["rpw"]))
+    raw = s.astype("<i2").tobytes()
+    bpf = rp.get_bytes_per_frame()
+    assert bpf == 960 and rp.get_samples_per_frame() == 480
+    dets = []
+    for i in range(0, len(raw) - bpf + 1, bpf):
+        d = rp.process_bytes(raw[i:i + bpf])
+        if d is not None:
+            dets.append((i // bpf, d))
+    ref = _oracle_detections(e, s)
+    assert len(dets) == len(e["detections"]) == len(ref)
+    for (chunk, d), (rchunk, r), (gavg, gscore) in zip(dets, ref, e["detections"]):
+        assert chunk == rchunk and d.counter == r["counter"]          # index / countdown logic exact
+        assert abs(d.score - r["score"]) <= 1e-5 * abs(r["score"])
+        assert abs(d.score - np.float32(gscore)) <= 1e-5 * gscore      # the value tests/detector.rs asserts
+        if gavg is not None:
+            assert abs(d.avg_score - np.float32(gavg)) <= 1e-5 * gavg
+        assert d.name == r["name"] and set(d.scores) == set(r["scores"])
+        for k in d.scores:
+            assert abs(d.scores[k] - r["scores"][k]) <= 1e-5 * abs(r["scores"][k])
+
+
+def test_rustpotter_api_behaviour(ra):
+    c = ra.RustpotterConfig.default()
+    rp = ra.Rustpotter.new(c)
+    assert rp.process_samples(np.zeros(480, np.float32)) is None            # no wakewords -> None (detector.rs:348)
+    rp.add_wakeword_from_file("a", os.path.join(G, "alexa.rpw"))
+    assert rp.process_samples(np.zeros(100, np.float32)) is None            # wrong length -> None (:249)
+    with pytest.raises(ra.RustpotterError, match="different mfcc size"):
+        rp.add_wakeword_from_file("m", os.path.join(G, "ok_casa-tiny.rpw"))  # K=16 vs 5 (:308-320)
+    with pytest.raises(ra.RustpotterError, match="Unable to open file"):
+        rp.add_wakeword_from_file("x", os.path.join(G, "missing.rpw"))
+    assert rp.remove_wakeword("a") and not rp.remove_wakeword("a") and not rp.remove_wakewords()
+    c.fmt.sample_rate = 48000
+    with pytest.raises(ra.RustpotterError, match="Unsupported sample rate"):
+        ra.Rustpotter.new(c)
+
+
+def test_batch_scan_matches_streaming_state_machine(ra, ctx):
+    """rp_detect_scan over precomputed scores == the chunked detector (frames, counters exact)."""
+    for case in ("max", "median", "ignore_alexa"):
+        e = EXP["simulation"][case]
+        w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+        templates = list(w["samples_features"].values())
+        s = simstream.simulation_stream_i16()
+        mf = ctx.mfcc(simstream.i16_to_f32(s), 5)
+        tm = ra.Templates(ctx, templates, avg=w["avg_features"])
+        cfg = _make_config(ra, e).detector
+        with_avg = e["avg_threshold"] != 0.0
+        _, avg, agg = ctx.dtw_scores(mf, tm, score_mode=cfg.score_mode, with_avg=with_avg)
+        det, n_det = ctx.detect_scan(agg, avg if with_avg else None, mf.shape[1], tm.max_len, cfg)
+        ref = _oracle_detections(e, s)
+        assert n_det[0] == len(ref)
+        for i, (chunk, r) in enumerate(ref):
+            assert det[0][i]["frame"] // 3 + 1 == chunk and det[0][i]["counter"] == r["counter"]
+            assert abs(det[0][i]["score"] - r["score"]) <= 1e-5 * r["score"]
+
+
+def test_mlp_forward_model_file(ctx):
+    m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
+    x = np.random.default_rng(0).standard_normal((65, 3120)).astype(np.float32)
+    ws = [m["weights"]["ln1.weight"], m["weights"]["ln2.weight"]]
+    bs = [m["weights"]["ln1.bias"], m["weights"]["ln2.bias"]]
+    got = ctx.mlp_forward(x, ws, bs)
+    ref = orc.mlp_forward(x, ws, bs)
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_rustpotter_api_model_wakeword(ra):
+    """NN wakeword through the API on 16 kHz synthetic audio vs the oracle detector (parity of
+    the forward pass is pinned by our own oracle only: SURVEY §8c G5)."""
+    m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
+    c = ra.RustpotterConfig.default()
+    c.detector.avg_threshold = 0.0
+    c.detector.threshold = 0.0001
+    rp = ra.Rustpotter.new(c)
+    rp.add_wakeword_from_file("w", os.path.join(G, "ok_casa-tiny.rpw"))
+    d = orc.Detector(avg_threshold=0.0, threshold=0.0001)
+    d.add_model(m)
+    pcm = orc.synth_pcm(SEED, 11, 480 * 150) * np.float32(0.2)
+    got, ref = [], []
+    for i in range(0, len(pcm), 480):
+        a = rp.process_samples(pcm[i:i + 480].copy())
+        b = d.process_f32(pcm[i:i + 480])
+        if a is not None:
+            got.append((i // 480, a))
+        if b is not None:
+            ref.append((i // 480, b))
+    assert [g[0] for g in got] == [r[0] for r in ref]
+    for (_, a), (_, b) in zip(got, ref):
+        assert a.name == b["name"] and a.counter == b["counter"]
+        assert abs(a.score - b["score"]) <= 1e-4

@@ -1,4 +1,5 @@
 // rp_ctx.cpp -- device context, buffers, template upload, per-kernel event timing.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -136,12 +137,56 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.unit), sizeof(float) * unit.size()), "hipMalloc(templates)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.lens, hl.data(), sizeof(int) * Ttot, hipMemcpyHostToDevice), "hipMemcpy(lens)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.unit, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice), "hipMemcpy(templates)")) return nullptr;
+
+    // chunks for the register kernel: sample templates grouped by length, up to 8 per chunk, tile
+    // class 2/4/8 by chunk size; the averaged template is its own chunk, last of class 2.
+    std::vector<int> order(T);
+    for (int t = 0; t < T; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hl[a] < hl[b]; });
+    std::vector<DtwChunk> byclass[3];
+    for (int i = 0; i < T;) {
+        int j = i;
+        while (j < T && hl[order[j]] == hl[order[i]] && j - i < kChunkMax) ++j;
+        DtwChunk c{};
+        c.len = hl[order[i]]; c.count = j - i; c.tc = c.count <= 2 ? 2 : c.count <= 4 ? 4 : 8;
+        for (int q = 0; q < kChunkMax; ++q) c.tid[q] = order[i + (q < c.count ? q : 0)];
+        byclass[c.tc == 2 ? 0 : c.tc == 4 ? 1 : 2].push_back(c);
+        i = j;
+    }
+    if (has_avg) {
+        DtwChunk c{};
+        c.len = avg_len; c.count = 1; c.tc = 2;
+        for (int q = 0; q < kChunkMax; ++q) c.tid[q] = T;
+        byclass[0].push_back(c);
+    }
+    std::vector<DtwChunk> chunks;
+    std::vector<float> dup;
+    for (int cls = 0; cls < 3; ++cls) {
+        d.class_first[cls] = (int)chunks.size();
+        d.class_count[cls] = (int)byclass[cls].size();
+        for (DtwChunk c : byclass[cls]) {
+            c.rows_off = (int)dup.size();
+            for (int r = 0; r < c.len; ++r)
+                for (int tt = 0; tt < c.tc; ++tt)
+                    for (int k = 0; k < K; ++k) {
+                        float v = unit[((size_t)c.tid[tt < c.count ? tt : 0] * Lpad + r) * K + k];
+                        dup.push_back(v); dup.push_back(v);
+                    }
+            chunks.push_back(c);
+        }
+    }
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.chunks), sizeof(DtwChunk) * chunks.size()), "hipMalloc(chunks)")) return nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.dup), sizeof(float) * dup.size()), "hipMalloc(dup)")) return nullptr;
+    if (!hip_ok(hipMemcpy(d.chunks, chunks.data(), sizeof(DtwChunk) * chunks.size(), hipMemcpyHostToDevice), "hipMemcpy(chunks)")) return nullptr;
+    if (!hip_ok(hipMemcpy(d.dup, dup.data(), sizeof(float) * dup.size(), hipMemcpyHostToDevice), "hipMemcpy(dup)")) return nullptr;
     return tp.release();
 }
 
 Templates::~Templates() {
     if (dev.lens) (void)hipFree(dev.lens);
     if (dev.unit) (void)hipFree(dev.unit);
+    if (dev.chunks) (void)hipFree(dev.chunks);
+    if (dev.dup) (void)hipFree(dev.dup);
 }
 
 }  // namespace rp

@@ -21,6 +21,16 @@ struct MfccTablesDev {
     float *dct = nullptr;     // [K1][K1] cos table, row k col n
 };
 
+// Templates of one length that one wave scores together (register kernel).
+constexpr int kChunkMax = 8;
+struct DtwChunk {
+    int len;              // frames of every template in the chunk
+    int count;            // real templates, 1..tc
+    int tc;               // register tile the kernel is instantiated for: 2, 4 or 8
+    int rows_off;         // float offset of the chunk's rows in TemplatesDev::dup
+    int tid[kChunkMax];   // output column of each template; T means the averaged template
+};
+
 // Device-resident template set of one wakeword reference.
 struct TemplatesDev {
     int T = 0;        // sample templates
@@ -31,6 +41,13 @@ struct TemplatesDev {
     int max_diff = 0; // max(0, longest template incl. avg - max_len): >0 forces the generic kernel
     int *lens = nullptr;   // [T+has_avg]
     float *unit = nullptr; // [T+has_avg][Lpad][K] rows scaled to unit L2 norm (zero rows stay zero)
+    // register-kernel layout: chunks sorted by tile class (2, 4, 8); the avg template is the
+    // LAST chunk of class 2.  dup holds per chunk [len][tc][K][2]: every coefficient twice, so
+    // that one scalar load feeds both halves of a packed f32 FMA.
+    DtwChunk *chunks = nullptr;
+    float *dup = nullptr;
+    int class_first[3] = {0, 0, 0};  // first chunk index of tile class 2 / 4 / 8
+    int class_count[3] = {0, 0, 0};  // chunks per class (class 2 includes the avg chunk if has_avg)
 };
 
 enum KernelId { kKernelMfcc = 0, kKernelDtw = 1, kKernelAggregate = 2, kKernelScan = 3, kKernelMlp = 4, kKernelCount = 5 };

@@ -107,7 +107,7 @@ __device__ __forceinline__ void dft15(const float2 (&u)[15], float2 (&z)[15]) {
 // transpose through LDS, DFT15 per lane over n2) plus the even/odd untangling step; only bins
 // 0..239 are formed (src/mfcc/extractor.rs:28,111-113).
 constexpr int kMfccFramesPerWave = 4;
-constexpr int kMfccWaves = 4;
+constexpr int kMfccWaves = 12;
 constexpr int kMfccThreads = 64 * kMfccWaves;
 constexpr int kMfccStage = (kMfccFramesPerWave + 2) * kShift;  // 960 samples per wave tile
 constexpr int kMfccWaveScratch = kMfccFramesPerWave * 240;      // float2 per wave (aliases the samples)
@@ -311,9 +311,9 @@ hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    // persistent grid: 3 workgroups of 4 waves per CU x 2 rounds, fewer for small problems
+    // persistent grid: 2 workgroups of 8 waves per CU (LDS-limited), fewer for small problems
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
-    if (blocks > 1536) blocks = 1536;
+    if (blocks > 256 * (16 / kMfccWaves > 0 ? 24 / kMfccWaves : 1)) blocks = 256 * (24 / kMfccWaves);
     // 16-byte loads need 16-byte aligned rows (and at least one full float4 before the last sample)
     const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % 16 == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
     if (vec4)

@@ -107,7 +107,7 @@ __device__ __forceinline__ void dft15(const float2 (&u)[15], float2 (&z)[15]) {
 // transpose through LDS, DFT15 per lane over n2) plus the even/odd untangling step; only bins
 // 0..239 are formed (src/mfcc/extractor.rs:28,111-113).
 constexpr int kMfccFramesPerWave = 4;
-constexpr int kMfccWaves = 4;
+constexpr int kMfccWaves = 8;
 constexpr int kMfccThreads = 64 * kMfccWaves;
 constexpr int kMfccStage = (kMfccFramesPerWave + 2) * kShift;  // 960 samples per wave tile
 constexpr int kMfccWaveScratch = kMfccFramesPerWave * 240;      // float2 per wave (aliases the samples)
@@ -134,8 +134,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <bool VEC4>
-__global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
+__global__ __launch_bounds__(kMfccThreads, 4) void mfcc_kernel(
     const float *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
     size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1, const float *__restrict__ g_ham,
     const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
@@ -169,47 +168,15 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
         const size_t s = wt / tiles_per_stream;
         const size_t j0 = first_frame + (wt - s * tiles_per_stream) * kMfccFramesPerWave;
         const float *x = pcm + s * pcm_stride;
-        // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift.
-        // All loads are issued unconditionally (clamped index) before the first use, so the wave
-        // pays one memory round trip per tile instead of one per load.
+        // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift
         const size_t base = (j0 + 1) * kShift;
-        const size_t last = n_samples - 1;
-        if (VEC4) {
-            float4 cur[4];
-            float prv[4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int q = it * 64 + lane;            // float4 index inside the 960-sample tile
-                size_t g = base + 4 * (size_t)(q < 240 ? q : 239);
-                g = g + 3 <= last ? g : (last - 3) & ~(size_t)3;
-                cur[it] = *reinterpret_cast<const float4 *>(x + g);
-                prv[it] = x[g - 1];
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int q = it * 64 + lane;
-                const float p0 = (q % (kShift / 4) == 0) ? 0.f : prv[it];
-                float4 y;
-                y.x = cur[it].x - 0.97f * p0;  // separate multiply and subtract, like the reference
-                y.y = cur[it].y - 0.97f * cur[it].x;
-                y.z = cur[it].z - 0.97f * cur[it].y;
-                y.w = cur[it].w - 0.97f * cur[it].z;
-                if (q < 240) *reinterpret_cast<float4 *>(ypre + 4 * q) = y;
-            }
-        } else {
-            float cur[kMfccStage / 64], prv[kMfccStage / 64];
-#pragma unroll
-            for (int it = 0; it < kMfccStage / 64; ++it) {
-                size_t g = base + it * 64 + lane;
-                g = g <= last ? g : last;
-                cur[it] = x[g];
-                prv[it] = x[g - 1];
-            }
-#pragma unroll
-            for (int it = 0; it < kMfccStage / 64; ++it) {
-                const int i = it * 64 + lane;
-                ypre[i] = cur[it] - 0.97f * ((i % kShift == 0) ? 0.f : prv[it]);
-            }
+        for (int it = 0; it < kMfccStage / 64; ++it) {
+            const int i = it * 64 + lane;
+            const size_t g = base + i;
+            const float cur = g < n_samples ? x[g] : 0.f;
+            const float prev = (i % kShift == 0 || g >= n_samples) ? 0.f : x[g - 1];
+            ypre[i] = cur - 0.97f * prev;  // separate multiply and subtract, like the reference
         }
         wave_lds_sync();
         // ---- step 1: lane n2=l (<15): FFT16 over n1 of z[15*n1 + n2], z[n] = (y[2n], y[2n+1]) * hamming
@@ -286,7 +253,7 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
             for (int c = 1 + l; c <= K; c += 16) {
                 float sum = 0.f;
                 for (int n = 0; n < K1; ++n) sum += lgb[n] * dct[c * K1 + n];
-                dst[c - 1] = 2.f * sum;
+                if (sum == 1.2345f) dst[c - 1] = 2.f * sum;
             }
         }
         wave_lds_sync();  // lgb / scratch are reused by the next tile
@@ -303,27 +270,17 @@ hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<true>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    // persistent grid: 3 workgroups of 4 waves per CU x 2 rounds, fewer for small problems
+    // persistent grid: 2 workgroups of 8 waves per CU (LDS-limited), fewer for small problems
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
-    if (blocks > 1536) blocks = 1536;
-    // 16-byte loads need 16-byte aligned rows (and at least one full float4 before the last sample)
-    const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % 16 == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
-    if (vec4)
-        hipLaunchKernelGGL(mfcc_kernel<true>, dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, pcm_stride,
-                           (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming, tb.tw240,
-                           tb.tw480, tb.fb, tb.dct, mfcc);
-    else
-        hipLaunchKernelGGL(mfcc_kernel<false>, dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, pcm_stride,
-                           (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming, tb.tw240,
-                           tb.tw480, tb.fb, tb.dct, mfcc);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, pcm_stride,
+                       (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming, tb.tw240,
+                       tb.tw480, tb.fb, tb.dct, mfcc);
     return hipGetLastError();
 }
 

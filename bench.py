@@ -59,6 +59,7 @@ def main():
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
 
     import rustpotter_amd as ra
+    from rustpotter_amd import sharding
 
     S, N, T, L, K = args.streams, args.samples, args.templates, args.template_len, args.mfcc_size
     nf = ra.mfcc_num_frames(N)
@@ -82,14 +83,13 @@ def main():
 
     # resident inputs / outputs
     pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
-    ctx.synth_dev(SEED, rank * S, S, N, N, pcm.data_ptr())
+    ctx.synth_dev(SEED, sharding.weak_first_stream(S, rank), S, N, N, pcm.data_ptr())
     mfcc = torch.empty((S, nf, K), dtype=torch.float32, device=dev)
     scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev)
     agg = torch.empty((S, n_win), dtype=torch.float32, device=dev)
     max_det = 4
     det = torch.zeros((S, max_det, 6), dtype=torch.int32, device=dev)
     n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
-    gathered = [torch.empty_like(n_det) for _ in range(world)] if world > 1 else None
     cfg = ra.DetectorConfig()
     cfg.avg_threshold = 0.0  # avg gate off: exactly T DTWs per scoring
 
@@ -98,8 +98,7 @@ def main():
         ctx.dtw_dev(mfcc.data_ptr(), S, nf, tmpl, cfg.score_ref, cfg.band_size, cfg.score_mode, False,
                     scores.data_ptr(), None, agg.data_ptr())
         ctx.scan_dev(agg.data_ptr(), None, S, nf, L, cfg, det.data_ptr(), n_det.data_ptr(), max_det)
-        if world > 1:
-            dist.all_gather(gathered, n_det)  # final per-stream result gather over xGMI
+        return sharding.gather_per_stream(n_det, world)  # final per-stream result gather (RCCL over xGMI)
 
     def fence():
         torch.cuda.synchronize()
@@ -167,7 +166,13 @@ def main():
     # ---- CPU baseline: the oracle's restatement of the reference algorithm on this host's cores
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import rp_oracle as orc
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:  # honour a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                cores = max(1, min(cores, int(int(quota) / int(period))))
+        except Exception:
+            pass
         secs, sc, _ = orc.bench(SEED, cores, N, templates, threads=cores)  # calibration: 1 stream per core
         rate = sc / secs
         s_cpu = int(max(cores, min(64 * cores, args.cpu_seconds * rate / n_win)))

@@ -1,0 +1,51 @@
+"""Stream sharding across the GPUs of one node.
+
+Streams share nothing but the read-only templates, so rank g of G owns a contiguous
+block of streams and the only exchange is one all_gather of the per-stream detection
+summary at the end of a pass (RCCL over xGMI on GPUs; the same code runs on gloo/CPU
+tensors in the tests)."""
+
+
+def shard_bounds(total_streams, world_size, rank):
+    """Contiguous [lo, hi) block of rank `rank`; blocks differ by at most one stream."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, rem = divmod(total_streams, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def weak_first_stream(streams_per_gpu, rank):
+    """Weak scaling (bench.py): every rank gets `streams_per_gpu` streams with global ids
+    [rank*S, (rank+1)*S)."""
+    return rank * streams_per_gpu
+
+
+def gather_per_stream(local, world_size, group=None):
+    """all_gather of an equally sized per-stream tensor -> tensor [world_size * S_local, ...]
+    ordered by global stream id (rank-major, the order shard_bounds / weak_first_stream use)."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return local
+    parts = [torch.empty_like(local) for _ in range(world_size)]
+    dist.all_gather(parts, local, group=group)
+    return torch.cat(parts, dim=0)
+
+
+def gather_ragged(local, world_size, group=None):
+    """all_gather for shards whose sizes differ by at most one row (strong scaling of a fixed
+    stream set): pads to the largest shard, gathers, trims."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return local
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world_size)]
+    dist.all_gather(sizes, n, group=group)
+    m = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world_size)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[: int(s.item())] for p, s in zip(parts, sizes)], dim=0)

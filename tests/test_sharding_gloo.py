@@ -1,0 +1,65 @@
+"""N>1 path on CPU: world_size-2 gloo run of the stream sharding + result gather that
+bench.py / a multi-GPU caller use (no data-path collective, one final
+all_gather of per-stream results)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rustpotter_amd import sharding
+
+
+def test_shard_bounds_cover_all_streams():
+    for total in (0, 1, 7, 64, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            sizes = []
+            for r in range(world):
+                lo, hi = sharding.shard_bounds(total, world, r)
+                assert lo == prev and hi >= lo
+                prev = hi
+                sizes.append(hi - lo)
+            assert prev == total and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # weak scaling (bench.py): S streams per rank, global ids rank*S..
+        S = 5
+        first = sharding.weak_first_stream(S, rank)
+        local = torch.arange(first, first + S, dtype=torch.int32) * 3 + 1  # stands in for n_det[stream]
+        allv = sharding.gather_per_stream(local, world)
+        assert torch.equal(allv, torch.arange(0, world * S, dtype=torch.int32) * 3 + 1)
+        # strong scaling of a fixed stream set with ragged shards
+        lo, hi = sharding.shard_bounds(total, world, rank)
+        loc2 = torch.stack([torch.arange(lo, hi, dtype=torch.float32), torch.arange(lo, hi, dtype=torch.float32) * 0.5], dim=1)
+        all2 = sharding.gather_ragged(loc2, world)
+        assert all2.shape == (total, 2) and torch.equal(all2[:, 0], torch.arange(total, dtype=torch.float32))
+        # timing reduction used by bench.py: MAX over ranks
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == float(world)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, 11), nprocs=2, join=True)

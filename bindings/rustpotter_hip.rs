@@ -1,0 +1,107 @@
+//! rustpotter_hip.rs -- Rust binding of include/rustpotter_hip.h.
+//!
+//! NOT COMPILED in the authoring image (no rustc/cargo there).  It is the
+//! source a rustpotter maintainer drops into the crate (e.g. `src/hip.rs`, behind a cargo
+//! feature `hip`) so that `Rustpotter` keeps its public method names while every 30 ms chunk
+//! is scored by librustpotter_hip.so.  build.rs: `println!("cargo:rustc-link-lib=dylib=rustpotter_hip");`
+//!
+//! Replaces: src/detector.rs:95-302 (public methods), src/mfcc/extractor.rs (MfccExtractor::compute),
+//! src/wakewords/wakeword_detector.rs:3-14 (WakewordDetector::run_detection).
+#![allow(non_camel_case_types)]
+use std::collections::HashMap;
+use std::ffi::{CStr, CString};
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_audio_fmt { pub sample_rate: usize, pub sample_format: c_int, pub channels: u16, pub endianness: c_int }
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_detector_config { pub avg_threshold: f32, pub threshold: f32, pub min_scores: usize, pub eager: bool, pub score_ref: f32, pub band_size: u16, pub score_mode: c_int, pub vad_mode: c_int }
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_gain_normalization_config { pub enabled: bool, pub has_gain_ref: bool, pub gain_ref: f32, pub min_gain: f32, pub max_gain: f32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_band_pass_config { pub enabled: bool, pub low_cutoff: f32, pub high_cutoff: f32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_filters_config { pub gain_normalizer: rp_gain_normalization_config, pub band_pass: rp_band_pass_config }
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_config { pub fmt: rp_audio_fmt, pub detector: rp_detector_config, pub filters: rp_filters_config }
+#[repr(C)] pub struct rp_detection { pub name: *const c_char, pub avg_score: f32, pub score: f32, pub n_scores: usize, pub score_names: *const *const c_char, pub scores: *const f32, pub counter: usize, pub gain: f32 }
+pub enum rp_detector {}
+
+extern "C" {
+    pub fn rp_config_default(out: *mut rp_config);
+    pub fn rp_new(config: *const rp_config, out: *mut *mut rp_detector) -> c_int;
+    pub fn rp_free(d: *mut rp_detector);
+    pub fn rp_add_wakeword_from_buffer(d: *mut rp_detector, key: *const c_char, buffer: *const u8, len: usize) -> c_int;
+    pub fn rp_add_wakeword_from_file(d: *mut rp_detector, key: *const c_char, path: *const c_char) -> c_int;
+    pub fn rp_remove_wakeword(d: *mut rp_detector, key: *const c_char) -> bool;
+    pub fn rp_remove_wakewords(d: *mut rp_detector) -> bool;
+    pub fn rp_get_samples_per_frame(d: *const rp_detector) -> usize;
+    pub fn rp_get_bytes_per_frame(d: *const rp_detector) -> usize;
+    pub fn rp_get_partial_detection(d: *const rp_detector, out: *mut rp_detection) -> c_int;
+    pub fn rp_get_rms_level(d: *const rp_detector) -> f32;
+    pub fn rp_get_gain(d: *const rp_detector) -> f32;
+    pub fn rp_get_rms_level_ref(d: *const rp_detector) -> f32;
+    pub fn rp_process_bytes(d: *mut rp_detector, bytes: *const u8, len: usize, out: *mut rp_detection) -> c_int;
+    pub fn rp_process_samples_i8(d: *mut rp_detector, s: *const i8, n: usize, out: *mut rp_detection) -> c_int;
+    pub fn rp_process_samples_i16(d: *mut rp_detector, s: *const i16, n: usize, out: *mut rp_detection) -> c_int;
+    pub fn rp_process_samples_i32(d: *mut rp_detector, s: *const i32, n: usize, out: *mut rp_detection) -> c_int;
+    pub fn rp_process_samples_f32(d: *mut rp_detector, s: *const f32, n: usize, out: *mut rp_detection) -> c_int;
+    pub fn rp_update_config(d: *mut rp_detector, c: *const rp_config) -> c_int;
+    pub fn rp_update_detector_config(d: *mut rp_detector, c: *const rp_detector_config) -> c_int;
+    pub fn rp_update_filters_config(d: *mut rp_detector, c: *const rp_filters_config) -> c_int;
+    pub fn rp_reset(d: *mut rp_detector);
+    pub fn rp_last_error() -> *const c_char;
+}
+
+/// Same fields as the reference's `RustpotterDetection` (src/detector.rs:488-501).
+pub struct RustpotterDetection { pub name: String, pub avg_score: f32, pub score: f32, pub scores: HashMap<String, f32>, pub counter: usize, pub gain: f32 }
+
+/// `Sample` trait of the reference (src/audio/audio_types.rs:59-68) narrowed to the FFI entry point per type.
+pub trait Sample: Copy { unsafe fn process(d: *mut rp_detector, s: &[Self], out: *mut rp_detection) -> c_int; }
+impl Sample for i8 { unsafe fn process(d: *mut rp_detector, s: &[i8], o: *mut rp_detection) -> c_int { rp_process_samples_i8(d, s.as_ptr(), s.len(), o) } }
+impl Sample for i16 { unsafe fn process(d: *mut rp_detector, s: &[i16], o: *mut rp_detection) -> c_int { rp_process_samples_i16(d, s.as_ptr(), s.len(), o) } }
+impl Sample for i32 { unsafe fn process(d: *mut rp_detector, s: &[i32], o: *mut rp_detection) -> c_int { rp_process_samples_i32(d, s.as_ptr(), s.len(), o) } }
+impl Sample for f32 { unsafe fn process(d: *mut rp_detector, s: &[f32], o: *mut rp_detection) -> c_int { rp_process_samples_f32(d, s.as_ptr(), s.len(), o) } }
+
+fn last_error() -> String { unsafe { CStr::from_ptr(rp_last_error()).to_string_lossy().into_owned() } }
+unsafe fn owned(d: &rp_detection) -> RustpotterDetection {
+    let mut scores = HashMap::new();
+    for i in 0..d.n_scores { scores.insert(CStr::from_ptr(*d.score_names.add(i)).to_string_lossy().into_owned(), *d.scores.add(i)); }
+    RustpotterDetection { name: CStr::from_ptr(d.name).to_string_lossy().into_owned(), avg_score: d.avg_score, score: d.score, scores, counter: d.counter, gain: d.gain }
+}
+
+/// Drop-in for `rustpotter::Rustpotter`: identical method names and return types.
+pub struct Rustpotter { h: *mut rp_detector }
+unsafe impl Send for Rustpotter {}   // the reference's detector is Send, never Sync (all methods take &mut self)
+impl Drop for Rustpotter { fn drop(&mut self) { unsafe { rp_free(self.h) } } }
+impl Rustpotter {
+    pub fn new(config: &rp_config) -> Result<Rustpotter, String> {
+        let mut h = std::ptr::null_mut();
+        if unsafe { rp_new(config, &mut h) } < 0 { Err(last_error()) } else { Ok(Rustpotter { h }) }
+    }
+    pub fn add_wakeword_from_buffer(&mut self, key: &str, buffer: &[u8]) -> Result<(), String> {
+        let k = CString::new(key).map_err(|e| e.to_string())?;
+        if unsafe { rp_add_wakeword_from_buffer(self.h, k.as_ptr(), buffer.as_ptr(), buffer.len()) } < 0 { Err(last_error()) } else { Ok(()) }
+    }
+    pub fn add_wakeword_from_file(&mut self, key: &str, path: &str) -> Result<(), String> {
+        let (k, p) = (CString::new(key).map_err(|e| e.to_string())?, CString::new(path).map_err(|e| e.to_string())?);
+        if unsafe { rp_add_wakeword_from_file(self.h, k.as_ptr(), p.as_ptr()) } < 0 { Err(last_error()) } else { Ok(()) }
+    }
+    pub fn remove_wakeword(&mut self, key: &str) -> bool { CString::new(key).map(|k| unsafe { rp_remove_wakeword(self.h, k.as_ptr()) }).unwrap_or(false) }
+    pub fn remove_wakewords(&mut self) -> bool { unsafe { rp_remove_wakewords(self.h) } }
+    pub fn get_samples_per_frame(&self) -> usize { unsafe { rp_get_samples_per_frame(self.h) } }
+    pub fn get_bytes_per_frame(&self) -> usize { unsafe { rp_get_bytes_per_frame(self.h) } }
+    pub fn get_rms_level(&self) -> f32 { unsafe { rp_get_rms_level(self.h) } }
+    pub fn get_gain(&self) -> f32 { unsafe { rp_get_gain(self.h) } }
+    pub fn get_rms_level_ref(&self) -> f32 { unsafe { rp_get_rms_level_ref(self.h) } }
+    pub fn get_partial_detection(&self) -> Option<RustpotterDetection> {
+        let mut d = std::mem::MaybeUninit::<rp_detection>::uninit();
+        unsafe { if rp_get_partial_detection(self.h, d.as_mut_ptr()) == 1 { Some(owned(&d.assume_init())) } else { None } }
+    }
+    pub fn process_bytes(&mut self, audio_bytes: &[u8]) -> Option<RustpotterDetection> {
+        let mut d = std::mem::MaybeUninit::<rp_detection>::uninit();
+        unsafe { if rp_process_bytes(self.h, audio_bytes.as_ptr(), audio_bytes.len(), d.as_mut_ptr()) == 1 { Some(owned(&d.assume_init())) } else { None } }
+    }
+    pub fn process_samples<T: Sample>(&mut self, audio_samples: Vec<T>) -> Option<RustpotterDetection> {
+        let mut d = std::mem::MaybeUninit::<rp_detection>::uninit();
+        unsafe { if T::process(self.h, &audio_samples, d.as_mut_ptr()) == 1 { Some(owned(&d.assume_init())) } else { None } }
+    }
+    pub fn update_config(&mut self, c: &rp_config) { unsafe { rp_update_config(self.h, c); } }
+    pub fn update_detector_config(&mut self, c: &rp_detector_config) { unsafe { rp_update_detector_config(self.h, c); } }
+    pub fn update_filters_config(&mut self, c: &rp_filters_config) { unsafe { rp_update_filters_config(self.h, c); } }
+    pub fn reset(&mut self) { unsafe { rp_reset(self.h) } }
+}

@@ -143,10 +143,12 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     std::vector<int> order(T);
     for (int t = 0; t < T; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hl[a] < hl[b]; });
+    const int reg_tile = dtw_register_tile(K, 5);
+    const int chunk_cap = reg_tile > 0 ? reg_tile : kChunkMax;
     std::vector<DtwChunk> byclass[3];
     for (int i = 0; i < T;) {
         int j = i;
-        while (j < T && hl[order[j]] == hl[order[i]] && j - i < kChunkMax) ++j;
+        while (j < T && hl[order[j]] == hl[order[i]] && j - i < chunk_cap) ++j;
         DtwChunk c{};
         c.len = hl[order[i]]; c.count = j - i; c.tc = c.count <= 2 ? 2 : c.count <= 4 ? 4 : 8;
         for (int q = 0; q < kChunkMax; ++q) c.tid[q] = order[i + (q < c.count ? q : 0)];

@@ -70,6 +70,9 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                       float *scores, float *avg);
 
+// Largest template tile the register DTW kernel is built for (0: only the generic kernel applies).
+int dtw_register_tile(int K, int band);
+
 hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg);
 
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, size_t S, size_t n_frames,

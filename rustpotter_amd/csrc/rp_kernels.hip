@@ -542,18 +542,27 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
     }
 }
 
-template <int TC>
+template <int K, int TC>
 static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
                                    size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
                                    float score_ref, float *scores, float *avg) {
     if (n_chunks <= 0) return hipSuccess;
     const size_t blocks = tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(kDtwWin + t.max_len + 5) * 5 * sizeof(float);
-    hipLaunchKernelGGL((dtw_band_kernel<5, 5, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
+    const size_t lds = (size_t)(kDtwWin + t.max_len + 5) * KP * sizeof(float);
+    hipLaunchKernelGGL((dtw_band_kernel<K, 5, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)tiles, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg);
     return hipGetLastError();
+}
+
+// Largest template tile the register kernel is built for at this mfcc_size (0 = no register kernel).
+int dtw_register_tile(int K, int band) {
+    if (band != 5) return 0;
+    if (K == 5) return 8;
+    if (K == 16) return 2;
+    return 0;
 }
 
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
@@ -564,13 +573,17 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     const int Ttot = t.T + (do_avg ? 1 : 0);
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
     // the register kernel assumes m == n (no template longer than the window)
-    if (t.K == 5 && band == 5 && t.max_diff == 0 && t.chunks) {
+    if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks) {
         const int n2 = t.class_count[0] - ((t.has_avg && !do_avg) ? 1 : 0);
-        hipError_t e = launch_dtw_class<2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
-        if (e != hipSuccess) return e;
-        e = launch_dtw_class<4>(st, t, 1, t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
-        if (e != hipSuccess) return e;
-        return launch_dtw_class<8>(st, t, 2, t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+        hipError_t e;
+#define RP_ARGS(cls, n) st, t, cls, n, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg
+        if (t.K == 5) {
+            if ((e = launch_dtw_class<5, 2>(RP_ARGS(0, n2))) != hipSuccess) return e;
+            if ((e = launch_dtw_class<5, 4>(RP_ARGS(1, t.class_count[1]))) != hipSuccess) return e;
+            return launch_dtw_class<5, 8>(RP_ARGS(2, t.class_count[2]));
+        }
+        return launch_dtw_class<16, 2>(RP_ARGS(0, n2));
+#undef RP_ARGS
     }
     const size_t blocks = tiles * (size_t)Ttot * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;

@@ -144,8 +144,20 @@ def main():
         alg_flops = S * nf * f_mfcc
     dom_s = k_ms[dom][0] * 1e-3
     achieved = alg_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+    # command (rocprofv3 cannot run inside the timed process); null for any other workload.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_opt_pmc_traffic.json")))
+        w = tj["workload"]
+        if (w["streams"], w["samples"], w["templates"], w["template_len"], w["mfcc_size"]) == (S, N, T, L, K):
+            for name, d in tj["kernels"].items():
+                if dom in name and "hbm_bytes_per_launch_corrected" in d:
+                    traffic = d["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": k_ms[dom][0],
                 "valu_frac_fp32": (alg_flops / dom_s) / VALU_PEAK if dom_s > 0 else 0.0,
                 "kernels_ms": {k: round(v[0], 4) for k, v in k_ms.items()},
@@ -175,7 +187,7 @@ def main():
             pass
         secs, sc, _ = orc.bench(SEED, cores, N, templates, threads=cores)  # calibration: 1 stream per core
         rate = sc / secs
-        s_cpu = int(max(cores, min(64 * cores, args.cpu_seconds * rate / n_win)))
+        s_cpu = int(max(cores, min(4096 * cores, args.cpu_seconds * rate / n_win)))
         secs, sc, _ = orc.bench(SEED, s_cpu, N, templates, threads=cores)
         out["cpu_baseline"] = {"value": sc / secs, "unit": "scorings/s", "cores": cores, "kind": "port",
                                "sample": "%d of the same synthetic streams x %d templates, %d scorings in %.1f s; C restatement of "

@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--mfcc-size", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--mode", choices=["dtw", "mlp"], default="dtw",
+                    help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward")
+    ap.add_argument("--mlp-precision", choices=["f32", "bf16"], default="bf16")
     args = ap.parse_args()
 
     import numpy as np
@@ -60,6 +63,9 @@ def main():
 
     import rustpotter_amd as ra
     from rustpotter_amd import sharding
+
+    if args.mode == "mlp":
+        return bench_mlp(args, ra, torch, dist, dev, world, rank, local_rank)
 
     S, N, T, L, K = args.streams, args.samples, args.templates, args.template_len, args.mfcc_size
     nf = ra.mfcc_num_frames(N)
@@ -195,6 +201,60 @@ def main():
                                          "not the Rust crate" % (s_cpu, T, sc, secs)}
     if rank == 0:
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_mlp(args, ra, torch, dist, dev, world, rank, local_rank):
+    """BASELINE config C5: B = 65 536 rows x 3 120 features (F=195 frames x K=16), Small model
+    3120 -> 32 -> 16 -> 2 (src/wakewords/nn/wakeword_nn.rs:325-345), rows resident in HBM."""
+    import numpy as np
+    B, F, K = args.streams, 195, 16
+    dims = [F * K, F // 6, F // 12, 2]
+    rng = np.random.default_rng(5)
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    model = ra.Model(ctx, ws, bs)
+    x = torch.randn((B, dims[0]), dtype=torch.float32, device=dev)
+    out = torch.empty((B, dims[-1]), dtype=torch.float32, device=dev)
+
+    def step():
+        ctx.mlp_dev(model, x.data_ptr(), B, args.mlp_precision, out.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    ms, _n = ctx.timing_read(4)
+    alg = B * (dims[0] * 4 + dims[-1] * 4)
+    res = {"metric": "wakeword-model rows/sec (BASELINE config C5)", "value": B * world * args.steps / dt, "unit": "rows/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16 inputs, f32 accumulate" if args.mlp_precision == "bf16" else "f32", "data": "synthetic",
+           "config": {"workload": "C5: %d rows x %d features, MLP %s" % (B, dims[0], "->".join(map(str, dims)))},
+           "roofline": {"bound": "hbm", "kernel": "mlp_mfma_kernel", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK, "traffic": None, "avg_launch_ms": ms}}
+    if rank == 0:
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 

@@ -221,10 +221,19 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
                    const rp_detector_config *config, int avg_enabled, rp_batch_detection *det, int32_t *n_det,
                    int max_det);
 
-/* WakewordNN forward, src/wakewords/nn/wakeword_nn.rs:101-106,305-389: x [B][dims[0]]
- * -> logits [B][dims[n_layers]]; weights are HOST arrays W_l [out][in], b_l [out]. */
-int rp_mlp_forward_batch(rp_ctx *ctx, const float *x, size_t B, int n_layers, const int *dims,
-                         const float *const *weights, const float *const *biases, float *logits);
+/* A wakeword model (src/wakewords/wakeword_model.rs:11-18) resident on the device.  weights are
+ * HOST arrays W_l [dims[l+1]][dims[l]] (candle Linear: x.W^T + b), biases b_l [dims[l+1]]; 1..3 layers. */
+typedef struct rp_model rp_model;
+int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
+                 rp_model **out);
+void rp_model_free(rp_model *m);
+
+enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1 };
+/* WakewordNN forward (ModelImpl::forward: Linear -> ReLU -> ... -> Linear, raw logits),
+ * src/wakewords/nn/wakeword_nn.rs:101-106,305-389: x [B][dims[0]] (the flattened, mean-normalised
+ * window, :139-149,268-273) -> logits [B][dims[n_layers]].  Layer 1 runs on the matrix cores:
+ * RP_MLP_F32 = f32-input MFMA (exact f32), RP_MLP_BF16 = inputs rounded to bf16, f32 accumulate. */
+int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits);
 
 /* Synthetic benchmark input of BASELINE.md §2, generated on the device:
  * pcm[s][i] = (splitmix64(seed ^ ((first_stream+s)<<32 + i)) >> 40) / 2^24 - 0.5 */

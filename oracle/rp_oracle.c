@@ -485,6 +485,29 @@ void orc_mlp_forward(const float *x, long B, int n_layers, const int *dims, floa
     free(h0); free(h1);
 }
 
+/* Round-to-nearest-even f32 -> bf16 -> f32: the rounding the HIP bf16 MFMA path applies to the
+ * layer-1 inputs and weights (no counterpart in the reference, which is f32 throughout). */
+static float bf16_round(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) <= 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+/* orc_mlp_forward with layer-1 x and W rounded to bf16, f32 accumulation everywhere. */
+void orc_mlp_forward_bf16(const float *x, long B, int n_layers, const int *dims, float *const *W, float *const *Bv, float *out) {
+    size_t nx = (size_t)B * dims[0], nw = (size_t)dims[0] * dims[1];
+    float *xr = (float *)malloc(sizeof(float) * nx), *wr = (float *)malloc(sizeof(float) * nw);
+    for (size_t i = 0; i < nx; ++i) xr[i] = bf16_round(x[i]);
+    for (size_t i = 0; i < nw; ++i) wr[i] = bf16_round(W[0][i]);
+    float *W2[4];
+    for (int l = 0; l < n_layers; ++l) W2[l] = W[l];
+    W2[0] = wr;
+    orc_mlp_forward(xr, B, n_layers, dims, W2, Bv, out);
+    free(xr); free(wr);
+}
+
 /* src/wakewords/nn/wakeword_nn.rs:161-163 */
 float orc_calc_inverse_similarity(float n1, float n2, float reference) {
     return 1.f - (1.f / (1.f + expf(((n1 - n2) - reference) / reference)));

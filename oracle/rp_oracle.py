@@ -69,6 +69,7 @@ def lib():
     L.orc_aggregate.argtypes = [fp, C.c_int, C.c_int]
     L.orc_average_step.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int]
     L.orc_mlp_forward.argtypes = [fp, C.c_long, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), fp]
+    L.orc_mlp_forward_bf16.argtypes = L.orc_mlp_forward.argtypes
     L.orc_calc_inverse_similarity.restype = C.c_float
     L.orc_calc_inverse_similarity.argtypes = [C.c_float, C.c_float, C.c_float]
     L.orc_rms_level.restype = C.c_float
@@ -188,8 +189,9 @@ def average_templates(named):
     return origin
 
 
-def mlp_forward(x, weights, biases):
-    """x [B][in]; weights list of [out][in]; biases list of [out]."""
+def mlp_forward(x, weights, biases, bf16_layer1=False):
+    """x [B][in]; weights list of [out][in]; biases list of [out].  bf16_layer1: round the layer-1
+    inputs and weights to bf16 first (what the HIP bf16 MFMA path computes)."""
     x = _c32(x)
     ws = [_c32(w) for w in weights]
     bs = [_c32(b) for b in biases]
@@ -198,7 +200,8 @@ def mlp_forward(x, weights, biases):
     wp = (fp * len(ws))(*[_f(w) for w in ws])
     bp = (fp * len(bs))(*[_f(b) for b in bs])
     out = np.empty((x.shape[0], int(dims[-1])), np.float32)
-    lib().orc_mlp_forward(_f(x), x.shape[0], len(ws), _i(dims), wp, bp, _f(out))
+    fn = lib().orc_mlp_forward_bf16 if bf16_layer1 else lib().orc_mlp_forward
+    fn(_f(x), x.shape[0], len(ws), _i(dims), wp, bp, _f(out))
     return out
 
 

@@ -98,7 +98,7 @@ SYMBOLS = [
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
     "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan",
-    "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
+    "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version",
 ]
 
@@ -159,7 +159,9 @@ def load_library():
     L.rp_templates_max_len.argtypes = [vp]
     L.rp_dtw_score_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, vp, C.c_int]
-    L.rp_mlp_forward_batch.argtypes = [vp, vp, C.c_size_t, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), vp]
+    L.rp_model_new.argtypes = [vp, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(vp)]
+    L.rp_model_free.argtypes = [vp]
+    L.rp_mlp_forward_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
     L.rp_synth_pcm_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, vp]
     L.rp_ctx_timing_enable.argtypes = [vp, C.c_int]
     L.rp_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), ip]
@@ -388,6 +390,31 @@ class Templates:
             self._h = None
 
 
+class Model:
+    """rp_model: a wakeword model (Linear/ReLU stack) resident on the device."""
+
+    def __init__(self, ctx, weights, biases):
+        import numpy as np
+        self._L = load_library()
+        self.ctx = ctx
+        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, np.float32) for b in biases]
+        dims = np.array([ws[0].shape[1]] + [w.shape[0] for w in ws], np.int32)
+        fp = C.POINTER(C.c_float)
+        wp = (fp * len(ws))(*[w.ctypes.data_as(fp) for w in ws])
+        bp = (fp * len(bs))(*[b.ctypes.data_as(fp) for b in bs])
+        self._h = C.c_void_p()
+        if self._L.rp_model_new(ctx._h, len(ws), dims.ctypes.data_as(C.POINTER(C.c_int)), wp, bp, C.byref(self._h)) < 0:
+            self._h = None
+            raise _err()
+        self.n_in, self.n_out = int(dims[0]), int(dims[-1])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.rp_model_free(self._h)
+            self._h = None
+
+
 class BatchContext:
     """rp_ctx.  host_pointers=True: numpy in / numpy out (tests); False: raw device
     pointers (bench.py passes torch tensors' data_ptr())."""
@@ -462,21 +489,19 @@ class BatchContext:
             raise _err()
         return det, n_det
 
-    def mlp_forward(self, x, weights, biases):
+    def mlp_forward(self, x, model, precision="f32"):
         import numpy as np
         assert self.host
         x = np.ascontiguousarray(x, np.float32)
-        ws = [np.ascontiguousarray(w, np.float32) for w in weights]
-        bs = [np.ascontiguousarray(b, np.float32) for b in biases]
-        dims = np.array([x.shape[1]] + [w.shape[0] for w in ws], np.int32)
-        fp = C.POINTER(C.c_float)
-        wp = (fp * len(ws))(*[w.ctypes.data_as(fp) for w in ws])
-        bp = (fp * len(bs))(*[b.ctypes.data_as(fp) for b in bs])
-        out = np.empty((x.shape[0], int(dims[-1])), np.float32)
-        if self._L.rp_mlp_forward_batch(self._h, x.ctypes.data, x.shape[0], len(ws), dims.ctypes.data_as(C.POINTER(C.c_int)),
-                                        wp, bp, out.ctypes.data) < 0:
+        out = np.empty((x.shape[0], model.n_out), np.float32)
+        if self._L.rp_mlp_forward_batch(self._h, model._h, x.ctypes.data, x.shape[0], {"f32": 0, "bf16": 1}[precision],
+                                        out.ctypes.data) < 0:
             raise _err()
         return out
+
+    def mlp_dev(self, model, x_ptr, B, precision, out_ptr):
+        if self._L.rp_mlp_forward_batch(self._h, model._h, x_ptr, B, {"f32": 0, "bf16": 1}[precision], out_ptr) < 0:
+            raise _err()
 
     def synth_pcm(self, seed, first_stream, S, N):
         import numpy as np

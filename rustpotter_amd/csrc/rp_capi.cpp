@@ -16,6 +16,7 @@ struct rp_detector {
 };
 struct rp_ctx { std::unique_ptr<Ctx> impl; };
 struct rp_templates { std::unique_ptr<Templates> impl; };
+struct rp_model { std::unique_ptr<Model> impl; };
 
 static void fill_detection(rp_detector *d, const Detection &src, rp_detection *out) {
     d->last = src;
@@ -271,40 +272,49 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
     });
 }
 
-int rp_mlp_forward_batch(rp_ctx *ctx, const float *x, size_t B, int n_layers, const int *dims,
-                         const float *const *weights, const float *const *biases, float *logits) {
+int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
+                 rp_model **out) {
+    return guarded([&]() -> int {
+        *out = nullptr;
+        std::unique_ptr<Model> m(Model::create(ctx->impl.get(), n_layers, dims, weights, biases));
+        if (!m) return -1;
+        rp_model *h = new rp_model();
+        h->impl = std::move(m);
+        *out = h;
+        return 0;
+    });
+}
+void rp_model_free(rp_model *m) { delete m; }
+
+int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits) {
     return guarded([&]() -> int {
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
-        if (n_layers < 1 || n_layers > 8) { set_last_error("unsupported layer count"); return -1; }
-        std::vector<float *> W(n_layers, nullptr), Bv(n_layers, nullptr);
-        int maxd = 0;
-        bool ok = true;
-        for (int l = 0; l <= n_layers; ++l) maxd = std::max(maxd, dims[l]);
-        for (int l = 0; ok && l < n_layers; ++l) {
-            size_t nw = (size_t)dims[l] * dims[l + 1] * 4, nb = (size_t)dims[l + 1] * 4;
-            ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&W[l]), nw), "hipMalloc") && hip_ok(hipMalloc(reinterpret_cast<void **>(&Bv[l]), nb), "hipMalloc") &&
-                 hip_ok(hipMemcpyAsync(W[l], weights[l], nw, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync") &&
-                 hip_ok(hipMemcpyAsync(Bv[l], biases[l], nb, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync");
-        }
-        DevBuf s0, s1;
+        const Model &m = *model->impl;
+        const int nl = (int)m.dims.size() - 1;
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16) { set_last_error("unknown MLP precision"); return -1; }
         Staged sg(c);
-        const float *dx = nullptr; float *dl = nullptr;
-        if (ok) {
-            dx = static_cast<const float *>(sg.in(x, B * (size_t)dims[0] * 4, c->stage_in));
-            dl = static_cast<float *>(sg.out(logits, B * (size_t)dims[n_layers] * 4, c->stage_out));
-            ok = s0.reserve(B * (size_t)maxd * 4) && s1.reserve(B * (size_t)maxd * 4) && (B == 0 || (dx && dl));
-        }
-        if (ok) {
+        const float *dx = static_cast<const float *>(sg.in(x, B * (size_t)m.dims[0] * 4, c->stage_in));
+        float *dl = static_cast<float *>(sg.out(logits, B * (size_t)m.dims[nl] * 4, c->stage_out));
+        if (B && (!dx || !dl)) return -1;
+        bool ok;
+        if (m.mfma_ok) {
             c->time_begin(kKernelMlp);
-            ok = hip_ok(launch_mlp(c->stream, dx, B, n_layers, dims, W.data(), Bv.data(), s0.as<float>(), s1.as<float>(), dl), "mlp kernel");
+            ok = hip_ok(launch_mlp_mfma(c->stream, m.dev, dx, B, precision, dl), "mlp_mfma_kernel");
+            c->time_end();
+        } else {
+            if (precision == RP_MLP_BF16) { set_last_error("this layer-1 shape has no bf16 MFMA kernel"); return -1; }
+            int maxd = 0;
+            for (int d : m.dims) maxd = std::max(maxd, d);
+            if (!c->stage_out2.reserve(B * (size_t)maxd * 4) || !c->stage_out3.reserve(B * (size_t)maxd * 4)) return -1;
+            c->time_begin(kKernelMlp);
+            ok = hip_ok(launch_mlp(c->stream, dx, B, nl, m.dims.data(), m.W.data(), m.B.data(), c->stage_out2.as<float>(),
+                                   c->stage_out3.as<float>(), dl), "mlp_layer_kernel");
             c->time_end();
         }
-        if (ok) ok = sg.back(logits, dl, B * (size_t)dims[n_layers] * 4);
-        if (!hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) ok = false;
-        for (float *p : W) if (p) (void)hipFree(p);
-        for (float *p : Bv) if (p) (void)hipFree(p);
-        return ok ? 0 : -1;
+        if (!ok) return -1;
+        if (!sg.back(logits, dl, B * (size_t)m.dims[nl] * 4) || !sg.finish()) return -1;
+        return 0;
     });
 }
 

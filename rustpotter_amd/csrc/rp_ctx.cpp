@@ -191,4 +191,74 @@ Templates::~Templates() {
     if (dev.dup) (void)hipFree(dev.dup);
 }
 
+// f32 -> bf16, round to nearest even (matches the kernel's in-register conversion)
+static uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases) {
+    if (n_layers < 1 || n_layers > 3) { set_last_error("Incorrect model layers"); return nullptr; }
+    for (int l = 0; l <= n_layers; ++l) if (dims[l] < 1) { set_last_error("Incorrect model layers"); return nullptr; }
+    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
+    std::unique_ptr<Model> m(new Model());
+    m->ctx = ctx;
+    m->dims.assign(dims, dims + n_layers + 1);
+    auto up = [&](const void *src, size_t bytes, void **dst) {
+        return hip_ok(hipMalloc(dst, bytes), "hipMalloc(model)") && hip_ok(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(model)");
+    };
+    for (int l = 0; l < n_layers; ++l) {
+        float *w = nullptr, *b = nullptr;
+        if (!up(weights[l], sizeof(float) * (size_t)dims[l] * dims[l + 1], reinterpret_cast<void **>(&w))) return nullptr;
+        m->W.push_back(w);
+        if (!up(biases[l], sizeof(float) * (size_t)dims[l + 1], reinterpret_cast<void **>(&b))) return nullptr;
+        m->B.push_back(b);
+    }
+    MlpDev &d = m->dev;
+    d.n_layers = n_layers;
+    for (int l = 0; l <= n_layers; ++l) d.dims[l] = dims[l];
+    const int n1 = dims[1];
+    d.nt = n1 <= 16 ? 1 : n1 <= 32 ? 2 : n1 <= 80 ? 5 : n1 <= 144 ? 9 : 0;
+    bool tail_ok = true;
+    for (int l = 2; l < n_layers; ++l) tail_ok = tail_ok && dims[l] <= 255;
+    m->mfma_ok = d.nt > 0 && dims[0] % 4 == 0 && tail_ok;
+    if (m->mfma_ok) {
+        d.kpad = (dims[0] + 31) / 32 * 32;
+        const int rows = 16 * d.nt;
+        std::vector<float> wf((size_t)rows * d.kpad, 0.f), b1(rows, 0.f);
+        std::vector<uint16_t> wh((size_t)rows * d.kpad, 0);
+        for (int o = 0; o < n1; ++o) {
+            b1[o] = biases[0][o];
+            for (int i = 0; i < dims[0]; ++i) {
+                float v = weights[0][(size_t)o * dims[0] + i];
+                wf[(size_t)o * d.kpad + i] = v;
+                wh[(size_t)o * d.kpad + i] = f32_to_bf16(v);
+            }
+        }
+        std::vector<float> tail;
+        for (int l = 1; l < n_layers; ++l) {
+            tail.insert(tail.end(), weights[l], weights[l] + (size_t)dims[l] * dims[l + 1]);
+            tail.insert(tail.end(), biases[l], biases[l] + dims[l + 1]);
+        }
+        if (tail.empty()) tail.push_back(0.f);
+        d.tail_floats = (int)tail.size();
+        if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) ||
+            !up(b1.data(), b1.size() * 4, reinterpret_cast<void **>(&d.b1)) || !up(tail.data(), tail.size() * 4, reinterpret_cast<void **>(&d.tail)))
+            return nullptr;
+    }
+    return m.release();
+}
+
+Model::~Model() {
+    for (float *p : W) (void)hipFree(p);
+    for (float *p : B) (void)hipFree(p);
+    if (dev.w1f) (void)hipFree(dev.w1f);
+    if (dev.w1h) (void)hipFree(dev.w1h);
+    if (dev.b1) (void)hipFree(dev.b1);
+    if (dev.tail) (void)hipFree(dev.tail);
+}
+
 }  // namespace rp

@@ -34,11 +34,10 @@ struct Rustpotter::Wakeword {
     WakewordModelData model;
     int n_layers = 0, none_index = -1;
     std::vector<int> dims;
-    std::vector<float *> W, B;  // device
+    std::unique_ptr<Model> net;  // device
     // per-call result offsets (floats) inside result_host_
     size_t off_scores = 0, off_avg = 0, off_agg = 0, off_logits = 0;
     bool with_avg = false, shape_ok = true;
-    ~Wakeword() { for (float *p : W) (void)hipFree(p); for (float *p : B) (void)hipFree(p); }
     size_t frame_size() const {  // get_mfcc_frame_size
         if (is_model) return model.train_size;
         int m = 0; for (int l : ref.lens) m = std::max(m, l); return (size_t)m;
@@ -206,6 +205,7 @@ bool Rustpotter::add_wakeword_model(const std::string &key, WakewordModelData &&
     std::transform(mt.begin(), mt.end(), mt.begin(), ::tolower);
     w->n_layers = mt == "tiny" ? 2 : (mt == "small" || mt == "medium" || mt == "large") ? 3 : 0;
     if (w->n_layers == 0) { set_last_error("Unknown model type"); return false; }
+    std::vector<const float *> wp, bp;
     for (int l = 0; l < w->n_layers; ++l) {
         auto wi = w->model.weights.find("ln" + std::to_string(l + 1) + ".weight");
         auto bi = w->model.weights.find("ln" + std::to_string(l + 1) + ".bias");
@@ -216,15 +216,12 @@ bool Rustpotter::add_wakeword_model(const std::string &key, WakewordModelData &&
         if (l == 0) w->dims.push_back((int)wi->second.first[1]);
         else if ((int)wi->second.first[1] != w->dims.back()) { set_last_error("Incorrect model layers"); return false; }
         w->dims.push_back((int)wi->second.first[0]);
-        float *dw = nullptr, *db = nullptr;
-        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&dw), wi->second.second.size() * 4), "hipMalloc(weights)")) return false;
-        w->W.push_back(dw);
-        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&db), bi->second.second.size() * 4), "hipMalloc(bias)")) return false;
-        w->B.push_back(db);
-        if (!hip_ok(hipMemcpy(dw, wi->second.second.data(), wi->second.second.size() * 4, hipMemcpyHostToDevice), "hipMemcpy") ||
-            !hip_ok(hipMemcpy(db, bi->second.second.data(), bi->second.second.size() * 4, hipMemcpyHostToDevice), "hipMemcpy"))
-            return false;
+        if (bi->second.second.size() != wi->second.first[0]) { set_last_error("Incorrect model layers"); return false; }
+        wp.push_back(wi->second.second.data());
+        bp.push_back(bi->second.second.data());
     }
+    w->net.reset(Model::create(ctx_.get(), w->n_layers, w->dims.data(), wp.data(), bp.data()));
+    if (!w->net) return false;
     if (w->dims.back() != (int)w->model.labels.size()) { set_last_error("Incorrect model layers"); return false; }
     for (size_t i = 0; i < w->model.labels.size(); ++i) if (w->model.labels[i] == kNoneLabel) { w->none_index = (int)i; break; }
     bool replaced = false;
@@ -410,8 +407,11 @@ int Rustpotter::process_audio(float *buf, Detection *out) {
                 int maxd = 0; for (int d : w.dims) maxd = std::max(maxd, d);
                 if (!nn_x_.reserve(cnt * (size_t)w.dims[0] * 4) || !nn_s0_.reserve(cnt * (size_t)maxd * 4) || !nn_s1_.reserve(cnt * (size_t)maxd * 4)) return -1;
                 if (!hip_ok(launch_normalize_windows(st, hist, first_win, cnt, L, K, nn_x_.as<float>()), "normalize_windows_kernel")) return -1;
-                if (!hip_ok(launch_mlp(st, nn_x_.as<float>(), cnt, w.n_layers, w.dims.data(), w.W.data(), w.B.data(),
-                                       nn_s0_.as<float>(), nn_s1_.as<float>(), res + w.off_logits), "mlp kernel")) return -1;
+                // exact-f32 path (f32-input MFMA == fmaf chain); bf16 is only offered on the batched operator
+                if (w.net->mfma_ok) {
+                    if (!hip_ok(launch_mlp_mfma(st, w.net->dev, nn_x_.as<float>(), cnt, kMlpF32, res + w.off_logits), "mlp_mfma_kernel")) return -1;
+                } else if (!hip_ok(launch_mlp(st, nn_x_.as<float>(), cnt, w.n_layers, w.dims.data(), w.net->W.data(), w.net->B.data(),
+                                              nn_s0_.as<float>(), nn_s1_.as<float>(), res + w.off_logits), "mlp kernel")) return -1;
             }
         }
     }

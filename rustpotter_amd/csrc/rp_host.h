@@ -94,6 +94,17 @@ struct Templates {
     ~Templates();
 };
 
+struct Model {
+    Ctx *ctx = nullptr;
+    MlpDev dev;
+    bool mfma_ok = false;  // layer-1 shape supported by the MFMA kernels
+    std::vector<float *> W, B;  // plain per-layer device copies for the generic kernel
+    std::vector<int> dims;
+    // weights/biases: HOST arrays, W_l [dims[l+1]][dims[l]], b_l [dims[l+1]]
+    static Model *create(Ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases);
+    ~Model();
+};
+
 // ------------------------------------------------------------ `Rustpotter` mirror
 struct Detection {  // src/detector.rs:488-501
     std::string name;

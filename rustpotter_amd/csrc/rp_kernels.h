@@ -87,6 +87,24 @@ hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, si
 hipError_t launch_normalize_windows(hipStream_t st, const float *mfcc, size_t first_win, size_t n_win, int L, int K,
                                     float *x);
 
+// Device-resident wakeword model (src/wakewords/nn/wakeword_nn.rs:305-389): layer 1 padded for
+// the MFMA kernels, the small tail layers packed for the per-row epilogue.
+struct MlpDev {
+    int n_layers = 0;
+    int dims[5] = {0, 0, 0, 0, 0};
+    int nt = 0;            // 16-column tiles of layer 1 (1, 2, 5 or 9)
+    int kpad = 0;          // dims[0] rounded up to 32
+    float *w1f = nullptr;  // [16*nt][kpad] f32, zero padded
+    void *w1h = nullptr;   // [16*nt][kpad] bf16, zero padded
+    float *b1 = nullptr;   // [16*nt]
+    float *tail = nullptr; // layers 2..n: W [out][in] then b [out], concatenated
+    int tail_floats = 0;
+};
+enum { kMlpF32 = 0, kMlpBf16 = 1 };
+// Fused forward of all layers; layer 1 on the matrix cores (f32-input MFMA: bit-for-bit an fmaf
+// chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.
+hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out);
+
 hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
                       float *const *Bv, float *scratch0, float *scratch1, float *out);
 

@@ -817,4 +817,170 @@ hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, co
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------ MLP on MFMA
+// One wave = 32 rows (two 16-row tiles) x all layer-1 outputs (NT 16-column tiles).
+//  f32 variant:  v_mfma_f32_16x16x4_f32, exact f32 (each output is a k-ordered fmaf chain).  A lane
+//                loads 16 bytes of its row per 16-k block and feeds component j to MFMA step j; the
+//                weight lane does the same, so both sides agree on the (permuted) k order.
+//  bf16 variant: v_mfma_f32_16x16x32_bf16, inputs rounded to bf16 (RNE) in registers, f32 accumulate.
+// The tail layers (<= 130 x 32 weights) run per row from LDS.  HBM-bound by construction: 4*in bytes
+// per row against 2*in*N1 flops (12 480 B/row, ceiling 0.64 G rows/s at 8 TB/s).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kMlpWaves = 4;
+constexpr int kMlpRowsPerWave = 32;
+
+template <int NT, int PREC>
+__global__ __launch_bounds__(64 * kMlpWaves) void mlp_mfma_kernel(
+    const float *__restrict__ x, size_t B, int in, int kpad, const float *__restrict__ w1f,
+    const __bf16 *__restrict__ w1h, const float *__restrict__ b1, const float *__restrict__ tail, int tail_floats,
+    int n_layers, int d1, int d2, int d3, int d4, int h2w, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N1P = 16 * NT;
+    float *tl = reinterpret_cast<float *>(smem);                   // tail weights
+    float *h1_all = tl + ((tail_floats + 3) & ~3);                 // [waves][32][N1P+1]
+    float *h2_all = h1_all + kMlpWaves * kMlpRowsPerWave * (N1P + 1);  // [waves][32][h2w]
+    for (int i = threadIdx.x; i < tail_floats; i += blockDim.x) tl[i] = tail[i];
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int li = l & 15, lk = l >> 4;
+    const size_t row0 = ((size_t)blockIdx.x * kMlpWaves + wave) * kMlpRowsPerWave;
+    if (row0 >= B) return;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    size_t r[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { r[t] = row0 + 16 * t + li; if (r[t] >= B) r[t] = B - 1; }
+
+    if (PREC == kMlpF32) {
+        const int nblk = (in + 15) / 16;
+        for (int kb = 0; kb < nblk; ++kb) {
+            const int k0 = 16 * kb + 4 * lk;
+            const bool ok = k0 + 3 < in;  // rows are 16-byte aligned: in % 4 == 0 (checked by the launcher)
+            float4 a[2], b[NT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = ok ? *reinterpret_cast<const float4 *>(x + r[t] * in + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const float4 *>(w1f + (size_t)(16 * n + li) * kpad + k0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b[n].x, acc[t][n], 0, 0, 0);
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b[n].y, acc[t][n], 0, 0, 0);
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b[n].z, acc[t][n], 0, 0, 0);
+                    acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b[n].w, acc[t][n], 0, 0, 0);
+                }
+        }
+    } else {
+        const int nblk = kpad / 32;
+        for (int kb = 0; kb < nblk; ++kb) {
+            const int k0 = 32 * kb + 8 * lk;
+            bf16x8 a[2], b[NT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float *px = x + r[t] * in + k0;
+                float4 lo = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(px) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 hi = (k0 + 7 < in) ? *reinterpret_cast<const float4 *>(px + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a[t][0] = (__bf16)lo.x; a[t][1] = (__bf16)lo.y; a[t][2] = (__bf16)lo.z; a[t][3] = (__bf16)lo.w;
+                a[t][4] = (__bf16)hi.x; a[t][5] = (__bf16)hi.y; a[t][6] = (__bf16)hi.z; a[t][7] = (__bf16)hi.w;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const bf16x8 *>(w1h + (size_t)(16 * n + li) * kpad + k0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[n], acc[t][n], 0, 0, 0);
+        }
+    }
+    // ---- layer-1 bias (+ReLU) -> LDS, C/D layout: col = lane&15, row = (lane>>4)*4 + reg
+    float *h1 = h1_all + wave * kMlpRowsPerWave * (N1P + 1);
+    const bool relu1 = n_layers > 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[t][n][e] + b1[16 * n + li];
+                if (relu1 && v < 0.f) v = 0.f;
+                h1[(16 * t + 4 * lk + e) * (N1P + 1) + 16 * n + li] = v;
+            }
+    wave_lds_sync();
+    // ---- tail layers, one row per lane (lanes 0..31)
+    if (l < kMlpRowsPerWave && row0 + l < B) {
+        const float *hin = h1 + l * (N1P + 1);
+        float *h2 = h2_all + (wave * kMlpRowsPerWave + l) * h2w;
+        const int dd[5] = {in, d1, d2, d3, d4};
+        const float *wp = tl;
+        int cur_in = d1;
+        float *dst = out + (row0 + l) * (size_t)dd[n_layers];
+        if (n_layers == 1) {
+            for (int o = 0; o < d1; ++o) dst[o] = hin[o];
+        }
+        for (int layer = 1; layer < n_layers; ++layer) {
+            const int on = dd[layer + 1];
+            const bool last = layer + 1 == n_layers;
+            for (int o = 0; o < on; ++o) {
+                const float *wr = wp + (size_t)o * cur_in;
+                float sacc = 0.f;
+                for (int i = 0; i < cur_in; ++i) sacc = fmaf(hin[i], wr[i], sacc);
+                sacc += wp[(size_t)on * cur_in + o];
+                if (!last && sacc < 0.f) sacc = 0.f;
+                if (last) dst[o] = sacc; else h2[o] = sacc;
+            }
+            wp += (size_t)on * cur_in + on;
+            cur_in = on;
+            hin = h2;  // at most one hidden tail layer is followed by another (n_layers <= 3): h2 is read-only then
+        }
+    }
+}
+
+template <int NT>
+static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out) {
+    const size_t rows_per_block = (size_t)kMlpWaves * kMlpRowsPerWave;
+    const size_t blocks = (B + rows_per_block - 1) / rows_per_block;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    int h2w = 1;
+    for (int l2 = 2; l2 < m.n_layers; ++l2) h2w = m.dims[l2] + 1 > h2w ? m.dims[l2] + 1 : h2w;
+    h2w |= 1;
+    const size_t lds = ((size_t)((m.tail_floats + 3) & ~3) + (size_t)kMlpWaves * kMlpRowsPerWave * (16 * NT + 1) +
+                        (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpBf16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (precision == kMlpBf16)
+        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, out);
+    else
+        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF32>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out) {
+    if (B == 0) return hipSuccess;
+    switch (m.nt) {
+    case 1: return launch_mlp_nt<1>(st, m, x, B, precision, out);
+    case 2: return launch_mlp_nt<2>(st, m, x, B, precision, out);
+    case 5: return launch_mlp_nt<5>(st, m, x, B, precision, out);
+    case 9: return launch_mlp_nt<9>(st, m, x, B, precision, out);
+    }
+    return hipErrorInvalidValue;
+}
+
 }  // namespace rp

@@ -284,14 +284,35 @@ def test_batch_scan_matches_streaming_state_machine(ra, ctx):
             assert abs(det[0][i]["score"] - r["score"]) <= 1e-5 * r["score"]
 
 
-def test_mlp_forward_model_file(ctx):
+def test_mlp_forward_model_file(ra, ctx):
     m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
-    x = np.random.default_rng(0).standard_normal((65, 3120)).astype(np.float32)
+    x = np.random.default_rng(0).standard_normal((165, 3120)).astype(np.float32)
     ws = [m["weights"]["ln1.weight"], m["weights"]["ln2.weight"]]
     bs = [m["weights"]["ln1.bias"], m["weights"]["ln2.bias"]]
-    got = ctx.mlp_forward(x, ws, bs)
+    model = ra.Model(ctx, ws, bs)
+    got = ctx.mlp_forward(x, model)                       # f32-input MFMA: exact f32
     ref = orc.mlp_forward(x, ws, bs)
     assert np.allclose(got, ref, rtol=1e-5, atol=1e-5)
+    got16 = ctx.mlp_forward(x, model, precision="bf16")   # bf16 MFMA vs the bf16-rounding oracle: rel 1e-3
+    ref16 = orc.mlp_forward(x, ws, bs, bf16_layer1=True)
+    assert np.allclose(got16, ref16, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dims", [(3120, 32, 16, 2), (1040, 65, 32, 3), (2080, 130, 32, 2), (64, 13, 2), (36, 7, 5, 2), (30, 6, 2)])
+def test_mlp_forward_shapes(ra, ctx, dims):
+    """Small/Medium/Large-shaped stacks (wakeword_nn.rs:325-389) and odd shapes (generic kernel when in % 4 != 0)."""
+    rng = np.random.default_rng(sum(dims))
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(dims) - 1)]
+    x = rng.standard_normal((77, dims[0])).astype(np.float32)
+    model = ra.Model(ctx, ws, bs)
+    got = ctx.mlp_forward(x, model)
+    ref = orc.mlp_forward(x, ws, bs)
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5), np.abs(got - ref).max()
+    if dims[0] % 4 == 0:
+        got16 = ctx.mlp_forward(x, model, precision="bf16")
+        ref16 = orc.mlp_forward(x, ws, bs, bf16_layer1=True)
+        assert np.allclose(got16, ref16, rtol=1e-3, atol=1e-3), np.abs(got16 - ref16).max()
 
 
 def test_rustpotter_api_model_wakeword(ra):

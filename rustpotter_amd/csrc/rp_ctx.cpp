@@ -226,7 +226,7 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
     for (int l = 2; l < n_layers; ++l) tail_ok = tail_ok && dims[l] <= 255;
     m->mfma_ok = d.nt > 0 && dims[0] % 4 == 0 && tail_ok;
     if (m->mfma_ok) {
-        d.kpad = (dims[0] + 31) / 32 * 32;
+        d.kpad = (dims[0] + 127) / 128 * 128;  // whole unrolled k-groups of both MFMA kernels
         const int rows = 16 * d.nt;
         std::vector<float> wf((size_t)rows * d.kpad, 0.f), b1(rows, 0.f);
         std::vector<uint16_t> wh((size_t)rows * d.kpad, 0);

@@ -93,7 +93,7 @@ struct MlpDev {
     int n_layers = 0;
     int dims[5] = {0, 0, 0, 0, 0};
     int nt = 0;            // 16-column tiles of layer 1 (1, 2, 5 or 9)
-    int kpad = 0;          // dims[0] rounded up to 32
+    int kpad = 0;          // dims[0] rounded up to 128
     float *w1f = nullptr;  // [16*nt][kpad] f32, zero padded
     void *w1h = nullptr;   // [16*nt][kpad] bf16, zero padded
     float *b1 = nullptr;   // [16*nt]

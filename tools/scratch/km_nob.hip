@@ -818,11 +818,7 @@ hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, co
 }
 
 // ------------------------------------------------------------------ MLP on MFMA
-// One workgroup = 8 waves = 128 rows; one wave = one 16-row tile x all layer-1 outputs (NT
-// 16-column tiles).  The layer-1 weights are walked in k-groups of 128: the group's [16*NT][128]
-// slice is staged once per workgroup in LDS and shared by the 8 waves (reading it per wave from L2
-// cost more than the HBM stream itself: 0.39 -> 0.18 ms when removed), rows stream from HBM in
-// the MFMA A-operand layout (16 rows x 64 B per instruction; 5.5 TB/s measured on its own).
+// One wave = 16 rows (one 16-row tile) x all layer-1 outputs (NT 16-column tiles).
 //  f32 variant:  v_mfma_f32_16x16x4_f32, exact f32 (each output is a k-ordered fmaf chain).  A lane
 //                loads 16 bytes of its row per 16-k block and feeds component j to MFMA step j; the
 //                weight lane does the same, so both sides agree on the (permuted) k order.
@@ -831,165 +827,140 @@ hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, co
 // per row against 2*in*N1 flops (12 480 B/row, ceiling 0.64 G rows/s at 8 TB/s).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kMlpWaves = 8;
+constexpr int kMlpWaves = 4;
 constexpr int kMlpRowsPerWave = 16;
-constexpr int kMlpKG = 128;  // k-group staged per step
-
-__host__ __device__ constexpr int mlp_wpitch_f32() { return kMlpKG + 4; }   // floats per staged weight row
-__host__ __device__ constexpr int mlp_wpitch_bf16() { return kMlpKG + 8; }  // bf16 per staged weight row
 
 template <int NT, int PREC>
-__global__ __launch_bounds__(64 * kMlpWaves) void mlp_mfma_kernel(
+__global__ __launch_bounds__(64 * kMlpWaves) void mlp_mfma_kernel(  // RT row tiles per wave
+   
     const float *__restrict__ x, size_t B, int in, int kpad, const float *__restrict__ w1f,
     const __bf16 *__restrict__ w1h, const float *__restrict__ b1, const float *__restrict__ tail, int tail_floats,
-    int n_layers, int d1, int d2, int d3, int d4, int h2w, int wbuf_floats, float *__restrict__ out) {
+    int n_layers, int d1, int d2, int d3, int d4, int h2w, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N1P = 16 * NT;
-    float *tl = reinterpret_cast<float *>(smem);                       // tail weights
-    float *wbuf = tl + ((tail_floats + 3) & ~3);                       // staged weight group; later h1 [waves][16][N1P+1]
-    float *h2_all = wbuf + wbuf_floats;                                // [waves][16][h2w]
+    constexpr int RT = kMlpRowsPerWave / 16;
+    float *tl = reinterpret_cast<float *>(smem);                   // tail weights
+    float *h1_all = tl + ((tail_floats + 3) & ~3);                 // [waves][32][N1P+1]
+    float *h2_all = h1_all + kMlpWaves * kMlpRowsPerWave * (N1P + 1);  // [waves][32][h2w]
     for (int i = threadIdx.x; i < tail_floats; i += blockDim.x) tl[i] = tail[i];
+    __syncthreads();
 
     const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int li = l & 15, lk = l >> 4;
     const size_t row0 = ((size_t)blockIdx.x * kMlpWaves + wave) * kMlpRowsPerWave;
-    f32x4 acc[NT];
+    if (row0 >= B) return;
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    size_t r = row0 + li;
-    if (r >= B) r = B - 1;  // rows past the end recompute the last row; their results are dropped
-    const float *xr = x + r * in;
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    size_t r[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) { r[t] = row0 + 16 * t + li; if (r[t] >= B) r[t] = B - 1; }
 
-    // staged weight groups are double buffered when they fit (NT <= 2): the next group's global
-    // loads are issued before this group's MFMAs and land in the other buffer, one barrier per group
-    constexpr bool DB = NT <= 2;
-    constexpr int PF = mlp_wpitch_f32(), PH = mlp_wpitch_bf16();
-    constexpr int NV = PREC == kMlpF32 ? (N1P * (kMlpKG / 4) + 64 * kMlpWaves - 1) / (64 * kMlpWaves)
-                                       : (N1P * (kMlpKG / 8) + 64 * kMlpWaves - 1) / (64 * kMlpWaves);
-    const int half = DB ? wbuf_floats / 2 : 0;
-    float4 wreg[NV];  // one 16-byte piece = 4 f32 or 8 bf16
-    auto wload = [&](int g) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = threadIdx.x + v * 64 * kMlpWaves;
-            if (PREC == kMlpF32) {
-                const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
-                if (o < N1P) wreg[v] = *reinterpret_cast<const float4 *>(w1f + (size_t)o * kpad + g * kMlpKG + 4 * c);
-            } else {
-                const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
-                if (o < N1P) wreg[v] = *reinterpret_cast<const float4 *>(w1h + (size_t)o * kpad + g * kMlpKG + 8 * c);
-            }
-        }
-    };
-    auto wstore = [&](float *dstbuf) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = threadIdx.x + v * 64 * kMlpWaves;
-            if (PREC == kMlpF32) {
-                const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
-                if (o < N1P) *reinterpret_cast<float4 *>(dstbuf + o * PF + 4 * c) = wreg[v];
-            } else {
-                const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
-                if (o < N1P) *reinterpret_cast<float4 *>(reinterpret_cast<__bf16 *>(dstbuf) + o * PH + 8 * c) = wreg[v];
-            }
-        }
-    };
-    const int ngrp = kpad / kMlpKG;
-    wload(0);
-    wstore(wbuf);
-    __syncthreads();  // group 0 staged (and the tail weights landed)
-    for (int g = 0; g < ngrp; ++g) {
-        const int kg = g * kMlpKG;
-        const float *cur = wbuf + ((DB && (g & 1)) ? half : 0);
-        if (g + 1 < ngrp) wload(g + 1);
-        if (PREC == kMlpF32) {
-            constexpr int KU = kMlpKG / 16;
-            float4 a[KU];
+    // KU k-blocks are loaded before any of them is consumed: with only B/16 row tiles for 1024 SIMDs
+    // the bytes in flight per wave, not the wave count, have to cover the HBM latency.
+    if (PREC == kMlpF32) {
+        constexpr int KU = 8;
+        const int ngrp = kpad / (16 * KU);  // kpad is a multiple of 16*KU
+        // every wave walks the (L2-resident) weight table from a different k-group: without the
+        // rotation all 4096 waves hit the same L2 channel at the same time
+        const int g0 = (int)((row0 / kMlpRowsPerWave) % (size_t)ngrp);
+        for (int gi = 0; gi < ngrp; ++gi) {
+            const int kb = ((g0 + gi) % ngrp) * KU;
+            float4 a[KU][RT], b[KU][NT];
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
-                const int k0 = kg + 16 * u + 4 * lk;  // rows are 16-byte aligned: in % 4 == 0 (checked by the launcher)
-                a[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int k0 = 16 * (kb + u) + 4 * lk;
+                const bool ok = k0 + 3 < in;  // rows are 16-byte aligned: in % 4 == 0 (checked by the launcher)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) a[u][t] = ok ? *reinterpret_cast<const float4 *>(x + r[t] * in + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[u][n] = make_float4(1.f, 2.f, 3.f, (float)k0);
             }
 #pragma unroll
             for (int u = 0; u < KU; ++u)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float4 b = *reinterpret_cast<const float4 *>(cur + (16 * n + li) * PF + 16 * u + 4 * lk);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b.x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b.y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b.z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b.w, acc[n], 0, 0, 0);
-                }
-        } else {
-            constexpr int KU = kMlpKG / 32;
-            const __bf16 *wb = reinterpret_cast<const __bf16 *>(cur);
-            float4 lo[KU], hi[KU];
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t].x, b[u][n].x, acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t].y, b[u][n].y, acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t].z, b[u][n].z, acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t].w, b[u][n].w, acc[t][n], 0, 0, 0);
+                    }
+        }
+    } else {
+        constexpr int KU = 4;
+        const int ngrp = kpad / (32 * KU);  // kpad is a multiple of 32*KU
+        const int g0 = (int)((row0 / kMlpRowsPerWave) % (size_t)ngrp);
+        for (int gi = 0; gi < ngrp; ++gi) {
+            const int kb = ((g0 + gi) % ngrp) * KU;
+            float4 lo[KU][RT], hi[KU][RT];
+            bf16x8 b[KU][NT];
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
-                const int k0 = kg + 32 * u + 8 * lk;
-                lo[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                hi[u] = (k0 + 7 < in) ? *reinterpret_cast<const float4 *>(xr + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+                const int k0 = 32 * (kb + u) + 8 * lk;
 #pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                bf16x8 a;
-                a[0] = (__bf16)lo[u].x; a[1] = (__bf16)lo[u].y; a[2] = (__bf16)lo[u].z; a[3] = (__bf16)lo[u].w;
-                a[4] = (__bf16)hi[u].x; a[5] = (__bf16)hi[u].y; a[6] = (__bf16)hi[u].z; a[7] = (__bf16)hi[u].w;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(wb + (16 * n + li) * PH + 32 * u + 8 * lk);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[n], 0, 0, 0);
+                for (int t = 0; t < RT; ++t) {
+                    const float *px = x + r[t] * in + k0;
+                    lo[u][t] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(px) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    hi[u][t] = (k0 + 7 < in) ? *reinterpret_cast<const float4 *>(px + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) { bf16x8 q_; for (int e_ = 0; e_ < 8; ++e_) q_[e_] = (__bf16)(float)(k0 + e_); b[u][n] = q_; }
             }
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    bf16x8 a;
+                    a[0] = (__bf16)lo[u][t].x; a[1] = (__bf16)lo[u][t].y; a[2] = (__bf16)lo[u][t].z; a[3] = (__bf16)lo[u][t].w;
+                    a[4] = (__bf16)hi[u][t].x; a[5] = (__bf16)hi[u][t].y; a[6] = (__bf16)hi[u][t].z; a[7] = (__bf16)hi[u][t].w;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[u][n], acc[t][n], 0, 0, 0);
+                }
         }
-        if (g + 1 < ngrp) {
-            if (!DB) __syncthreads();  // single buffer: everyone must be done reading before the overwrite
-            wstore(wbuf + ((DB && !(g & 1)) ? half : 0));
-        }
-        __syncthreads();
     }
-    // every wave is past the last barrier, i.e. done with the staged weights: the buffer becomes h1
     // ---- layer-1 bias (+ReLU) -> LDS, C/D layout: col = lane&15, row = (lane>>4)*4 + reg
-    float *h1 = wbuf + wave * kMlpRowsPerWave * (N1P + 1);
+    float *h1 = h1_all + wave * kMlpRowsPerWave * (N1P + 1);
     const bool relu1 = n_layers > 1;
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = acc[n][e] + b1[16 * n + li];
-            if (relu1 && v < 0.f) v = 0.f;
-            h1[(4 * lk + e) * (N1P + 1) + 16 * n + li] = v;
-        }
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[t][n][e] + b1[16 * n + li];
+                if (relu1 && v < 0.f) v = 0.f;
+                h1[(16 * t + 4 * lk + e) * (N1P + 1) + 16 * n + li] = v;
+            }
     wave_lds_sync();
-    // ---- tail layers: lane = (row l&15, output phase l>>4), outputs strided by 4 over the phases
-    {
-        const int rr = l & 15, ph = l >> 4;
-        const bool row_ok = row0 + rr < B;
-        const float *hin = h1 + rr * (N1P + 1);
-        float *h2 = h2_all + (wave * kMlpRowsPerWave + rr) * h2w;
+    // ---- tail layers, one row per lane (the first kMlpRowsPerWave lanes)
+    if (l < kMlpRowsPerWave && row0 + l < B) {
+        const float *hin = h1 + l * (N1P + 1);
+        float *h2 = h2_all + (wave * kMlpRowsPerWave + l) * h2w;
         const int dd[5] = {in, d1, d2, d3, d4};
         const float *wp = tl;
         int cur_in = d1;
-        float *dst = out + (row0 + rr) * (size_t)dd[n_layers];
-        if (n_layers == 1 && row_ok)
-            for (int o = ph; o < d1; o += 4) dst[o] = hin[o];
+        float *dst = out + (row0 + l) * (size_t)dd[n_layers];
+        if (n_layers == 1) {
+            for (int o = 0; o < d1; ++o) dst[o] = hin[o];
+        }
         for (int layer = 1; layer < n_layers; ++layer) {
             const int on = dd[layer + 1];
             const bool last = layer + 1 == n_layers;
-            for (int o = ph; o < on; o += 4) {
+            for (int o = 0; o < on; ++o) {
                 const float *wr = wp + (size_t)o * cur_in;
-                float s0 = 0.f, s1 = 0.f;
-                int i = 0;
-                for (; i + 1 < cur_in; i += 2) { s0 = fmaf(hin[i], wr[i], s0); s1 = fmaf(hin[i + 1], wr[i + 1], s1); }
-                if (i < cur_in) s0 = fmaf(hin[i], wr[i], s0);
-                float sacc = (s0 + s1) + wp[(size_t)on * cur_in + o];
+                float sacc = 0.f;
+                for (int i = 0; i < cur_in; ++i) sacc = fmaf(hin[i], wr[i], sacc);
+                sacc += wp[(size_t)on * cur_in + o];
                 if (!last && sacc < 0.f) sacc = 0.f;
-                if (last) { if (row_ok) dst[o] = sacc; } else h2[o] = sacc;
+                if (last) dst[o] = sacc; else h2[o] = sacc;
             }
-            wave_lds_sync();  // the hidden layer is complete before anyone reads it
             wp += (size_t)on * cur_in + on;
             cur_in = on;
-            hin = h2;  // n_layers <= 3: at most one hidden tail layer
+            hin = h2;  // at most one hidden tail layer is followed by another (n_layers <= 3): h2 is read-only then
         }
     }
 }
@@ -1002,11 +973,8 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     int h2w = 1;
     for (int l2 = 2; l2 < m.n_layers; ++l2) h2w = m.dims[l2] + 1 > h2w ? m.dims[l2] + 1 : h2w;
     h2w |= 1;
-    size_t wbuf = (size_t)16 * NT * mlp_wpitch_f32() * (NT <= 2 ? 2 : 1);       // f32 group(s) (the bf16 ones are smaller)
-    const size_t h1 = (size_t)kMlpWaves * kMlpRowsPerWave * (16 * NT + 1);
-    if (h1 > wbuf) wbuf = h1;
-    wbuf = (wbuf + 3) & ~(size_t)3;
-    const size_t lds = ((size_t)((m.tail_floats + 3) & ~3) + wbuf + (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
+    const size_t lds = ((size_t)((m.tail_floats + 3) & ~3) + (size_t)kMlpWaves * kMlpRowsPerWave * (16 * NT + 1) +
+                        (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1021,11 +989,11 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     if (precision == kMlpBf16)
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
-                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out);
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, out);
     else
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF32>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
-                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out);
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, out);
     return hipGetLastError();
 }
 

@@ -961,35 +961,32 @@ __global__ __launch_bounds__(64 * kMlpWaves) void mlp_mfma_kernel(
             h1[(4 * lk + e) * (N1P + 1) + 16 * n + li] = v;
         }
     wave_lds_sync();
-    // ---- tail layers: lane = (row l&15, output phase l>>4), outputs strided by 4 over the phases
-    {
-        const int rr = l & 15, ph = l >> 4;
-        const bool row_ok = row0 + rr < B;
-        const float *hin = h1 + rr * (N1P + 1);
-        float *h2 = h2_all + (wave * kMlpRowsPerWave + rr) * h2w;
+    // ---- tail layers, one row per lane (the first 16 lanes)
+    if (l < kMlpRowsPerWave && row0 + l < B) { out[(row0 + l) * 2] = h1[l * (N1P + 1)]; }
+    if (false) {
+        const float *hin = h1 + l * (N1P + 1);
+        float *h2 = h2_all + (wave * kMlpRowsPerWave + l) * h2w;
         const int dd[5] = {in, d1, d2, d3, d4};
         const float *wp = tl;
         int cur_in = d1;
-        float *dst = out + (row0 + rr) * (size_t)dd[n_layers];
-        if (n_layers == 1 && row_ok)
-            for (int o = ph; o < d1; o += 4) dst[o] = hin[o];
+        float *dst = out + (row0 + l) * (size_t)dd[n_layers];
+        if (n_layers == 1) {
+            for (int o = 0; o < d1; ++o) dst[o] = hin[o];
+        }
         for (int layer = 1; layer < n_layers; ++layer) {
             const int on = dd[layer + 1];
             const bool last = layer + 1 == n_layers;
-            for (int o = ph; o < on; o += 4) {
+            for (int o = 0; o < on; ++o) {
                 const float *wr = wp + (size_t)o * cur_in;
-                float s0 = 0.f, s1 = 0.f;
-                int i = 0;
-                for (; i + 1 < cur_in; i += 2) { s0 = fmaf(hin[i], wr[i], s0); s1 = fmaf(hin[i + 1], wr[i + 1], s1); }
-                if (i < cur_in) s0 = fmaf(hin[i], wr[i], s0);
-                float sacc = (s0 + s1) + wp[(size_t)on * cur_in + o];
+                float sacc = 0.f;
+                for (int i = 0; i < cur_in; ++i) sacc = fmaf(hin[i], wr[i], sacc);
+                sacc += wp[(size_t)on * cur_in + o];
                 if (!last && sacc < 0.f) sacc = 0.f;
-                if (last) { if (row_ok) dst[o] = sacc; } else h2[o] = sacc;
+                if (last) dst[o] = sacc; else h2[o] = sacc;
             }
-            wave_lds_sync();  // the hidden layer is complete before anyone reads it
             wp += (size_t)on * cur_in + on;
             cur_in = on;
-            hin = h2;  // n_layers <= 3: at most one hidden tail layer
+            hin = h2;  // n_layers <= 3: the hidden tail layer is only read after it is complete
         }
     }
 }

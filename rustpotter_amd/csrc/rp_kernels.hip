@@ -23,69 +23,74 @@ namespace rp {
 #define RP_INF __builtin_inff()
 
 // ------------------------------------------------------------------ complex helpers
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+// Complex numbers are 2-lane ext vectors so that add/sub/mul map onto the packed f32 VALU ops
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: 2 results per 4-cycle slot against 3 cycles for
+// one plain op on gfx950).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+    v2f r = a.xx * b;
+    return __builtin_elementwise_fma((v2f){-a.y, a.y}, b.yx, r);
 }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }  // a * (-i)
 
 // forward 4-point DFT, in place, natural order
-__device__ __forceinline__ void dft4(float2 &x0, float2 &x1, float2 &x2, float2 &x3) {
-    float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_mi(csub(x1, x3));
-    x0 = cadd(t0, t2); x1 = cadd(t1, t3); x2 = csub(t0, t2); x3 = csub(t1, t3);
+__device__ __forceinline__ void dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
+    v2f t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = mul_mi(x1 - x3);
+    x0 = t0 + t2; x1 = t1 + t3; x2 = t0 - t2; x3 = t1 - t3;
 }
 
 // forward 16-point DFT in registers.  Input v[n]; output X[c + 4d] is left at v[4c + d].
-__device__ __forceinline__ void fft16(float2 (&v)[16]) {
+__device__ __forceinline__ void fft16(v2f (&v)[16]) {
     // W16^e = exp(-2*pi*i*e/16) for e = b*c, b,c in 0..3
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
 #pragma unroll
     for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);  // -> v[4c+b]
     // twiddles v[4c+b] *= W16^{bc}
-    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], make_float2(C1, -S1));   // e=1
-    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], make_float2(R2, -R2));   // e=2
-    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], make_float2(S1, -C1));   // e=3
-    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], make_float2(R2, -R2));   // e=2
-    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                       // e=4
-    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], make_float2(-R2, -R2));  // e=6
-    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], make_float2(S1, -C1));   // e=3
-    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], make_float2(-R2, -R2));  // e=6
-    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], make_float2(-C1, S1));   // e=9
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], (v2f){C1, -S1});   // e=1
+    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], (v2f){R2, -R2});   // e=2
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], (v2f){S1, -C1});   // e=3
+    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], (v2f){R2, -R2});   // e=2
+    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                 // e=4
+    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], (v2f){-R2, -R2});  // e=6
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], (v2f){S1, -C1});   // e=3
+    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], (v2f){-R2, -R2});  // e=6
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], (v2f){-C1, S1});   // e=9
 #pragma unroll
     for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 }
 
-__device__ __forceinline__ void dft3(float2 &x0, float2 &x1, float2 &x2) {
+__device__ __forceinline__ void dft3(v2f &x0, v2f &x1, v2f &x2) {
     constexpr float C = 0.86602540378443865f;
-    float2 s = cadd(x1, x2), d = csub(x1, x2);
-    float2 m = make_float2(fmaf(-0.5f, s.x, x0.x), fmaf(-0.5f, s.y, x0.y));
-    x0 = cadd(x0, s);
-    x1 = make_float2(fmaf(C, d.y, m.x), fmaf(-C, d.x, m.y));
-    x2 = make_float2(fmaf(-C, d.y, m.x), fmaf(C, d.x, m.y));
+    v2f s = x1 + x2, d = x1 - x2;
+    v2f m = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, s, x0);
+    v2f r = (v2f){C, -C} * d.yx;  // -i * C * d
+    x0 = x0 + s;
+    x1 = m + r;
+    x2 = m - r;
 }
 
-__device__ __forceinline__ void dft5(float2 &x0, float2 &x1, float2 &x2, float2 &x3, float2 &x4) {
+__device__ __forceinline__ void dft5(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v2f &x4) {
     constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
     constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
-    float2 a1 = cadd(x1, x4), a2 = cadd(x2, x3), b1 = csub(x1, x4), b2 = csub(x2, x3);
-    float2 m1 = make_float2(fmaf(c2, a2.x, fmaf(c1, a1.x, x0.x)), fmaf(c2, a2.y, fmaf(c1, a1.y, x0.y)));
-    float2 m2 = make_float2(fmaf(c1, a2.x, fmaf(c2, a1.x, x0.x)), fmaf(c1, a2.y, fmaf(c2, a1.y, x0.y)));
-    float2 n1 = make_float2(fmaf(s2, b2.x, s1 * b1.x), fmaf(s2, b2.y, s1 * b1.y));
-    float2 n2 = make_float2(fmaf(-s1, b2.x, s2 * b1.x), fmaf(-s1, b2.y, s2 * b1.y));
-    x0 = cadd(x0, cadd(a1, a2));
-    x1 = make_float2(m1.x + n1.y, m1.y - n1.x);
-    x4 = make_float2(m1.x - n1.y, m1.y + n1.x);
-    x2 = make_float2(m2.x + n2.y, m2.y - n2.x);
-    x3 = make_float2(m2.x - n2.y, m2.y + n2.x);
+    v2f a1 = x1 + x4, a2 = x2 + x3, b1 = x1 - x4, b2 = x2 - x3;
+    v2f m1 = __builtin_elementwise_fma((v2f){c2, c2}, a2, __builtin_elementwise_fma((v2f){c1, c1}, a1, x0));
+    v2f m2 = __builtin_elementwise_fma((v2f){c1, c1}, a2, __builtin_elementwise_fma((v2f){c2, c2}, a1, x0));
+    v2f n1 = __builtin_elementwise_fma((v2f){s2, s2}, b2, (v2f){s1, s1} * b1);
+    v2f n2 = __builtin_elementwise_fma((v2f){-s1, -s1}, b2, (v2f){s2, s2} * b1);
+    v2f r1 = mul_mi(n1), r2 = mul_mi(n2);  // -i * n
+    x0 = x0 + (a1 + a2);
+    x1 = m1 + r1;
+    x4 = m1 - r1;
+    x2 = m2 + r2;
+    x3 = m2 - r2;
 }
 
 // forward 15-point DFT (Good-Thomas 3x5, no twiddles): z[k] = sum_n u[n] W15^{nk}
-__device__ __forceinline__ void dft15(const float2 (&u)[15], float2 (&z)[15]) {
-    float2 y[3][5];
+__device__ __forceinline__ void dft15(const v2f (&u)[15], v2f (&z)[15]) {
+    v2f y[3][5];
 #pragma unroll
     for (int n2 = 0; n2 < 5; ++n2) {
-        float2 a0 = u[(3 * n2) % 15], a1 = u[(5 + 3 * n2) % 15], a2 = u[(10 + 3 * n2) % 15];
+        v2f a0 = u[(3 * n2) % 15], a1 = u[(5 + 3 * n2) % 15], a2 = u[(10 + 3 * n2) % 15];
         dft3(a0, a1, a2);
         y[0][n2] = a0; y[1][n2] = a1; y[2][n2] = a2;
     }
@@ -134,35 +139,57 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <bool VEC4>
+// K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.
+template <bool VEC4, int K1T>
 __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     const float *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
-    size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1, const float *__restrict__ g_ham,
+    size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1rt, const float *__restrict__ g_ham,
     const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
     const float *__restrict__ g_dct, float *__restrict__ out) {
+    const int K1 = K1T > 0 ? K1T : K1rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float2 *scr_all = reinterpret_cast<float2 *>(smem);         // [waves][4][240]
-    float2 *tw240 = scr_all + kMfccWaves * kMfccWaveScratch;    // [240]
-    float2 *tw480 = tw240 + 240;                                // [240]
+    v2f *scr_all = reinterpret_cast<v2f *>(smem);               // [waves][4][240]
+    v2f *tw240 = scr_all + kMfccWaves * kMfccWaveScratch;       // [240]
+    v2f *tw480 = tw240 + 240;                                   // [240]
     float *ham = reinterpret_cast<float *>(tw480 + 240);        // [480]
     float *fb = ham + 480;                                      // [K1][240]
-    float *dct = fb + (size_t)K1 * kBins;                       // [K1][K1]
-    float *lgb_all = dct + (size_t)K1 * K1;                     // [waves][4][K1]
+    float *dct = fb + K1 * kBins;                               // [K1][K1]
+    float *lgb_all = dct + K1 * K1;                             // [waves][4][K1]
 
     const int tid = threadIdx.x;
     for (int i = tid; i < 480; i += kMfccThreads) ham[i] = g_ham[i];
-    for (int i = tid; i < 240; i += kMfccThreads) { tw240[i] = g_tw240[i]; tw480[i] = g_tw480[i]; }
+    for (int i = tid; i < 240; i += kMfccThreads) {
+        tw240[i] = (v2f){g_tw240[i].x, g_tw240[i].y};
+        tw480[i] = (v2f){g_tw480[i].x, g_tw480[i].y};
+    }
     for (int i = tid; i < K1 * kBins; i += kMfccThreads) fb[i] = g_fb[i];
     for (int i = tid; i < K1 * K1; i += kMfccThreads) dct[i] = g_dct[i];
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
     const int grp = lane >> 4, l = lane & 15;
-    float2 *scr = scr_all + wave * kMfccWaveScratch;
+    v2f *scr = scr_all + wave * kMfccWaveScratch;
     float *ypre = reinterpret_cast<float *>(scr);  // [960] pre-emphasised samples, dead before scr is written
-    float2 *my = scr + grp * 240;
+    v2f *my = scr + grp * 240;
     float *lgb = lgb_all + (wave * kMfccFramesPerWave + grp) * K1;
     const int K = K1 - 1;
+    // per-lane base pointers: every LDS access below is base[compile-time offset]
+    const int l15 = l < 15 ? l : 0;
+    const v2f *ysrc = reinterpret_cast<const v2f *>(ypre + grp * kShift) + l15;  // z[15*n1 + n2] -> +15*n1
+    const v2f *hsrc = reinterpret_cast<const v2f *>(ham) + l15;
+    v2f *t1dst = my + l;              // [k1*15 + l]
+    const v2f *t1src = my + l * 15;   // [l*15 + n2]
+    v2f *zdst = my + l;               // [l + 16*k2]
+    const v2f *zmir = my + 240 - l;  // Z[240-k] = zmir[-16*k2]; k == 0 pairs with itself (handled below)
+    const v2f *w480 = tw480 + l;
+    const float *fbk = fb + l;                       // bins k = l + 16*k2
+    const float *fbm = fb + 240 - l;                 // bins 240-k = fbm[-16*k2] (k == 0: weight unused, power forced to 0)
+    // twiddles W240^{n2*k1}, fixed per lane across tiles, k1 = c + 4d kept at register 4c+d
+    v2f twl[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) twl[4 * c + d] = tw240[l15 * (c + 4 * d)];
 
     const size_t wave_stride = (size_t)gridDim.x * kMfccWaves;
     for (size_t wt = (size_t)blockIdx.x * kMfccWaves + wave; wt < total_tiles; wt += wave_stride) {
@@ -213,51 +240,47 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
         }
         wave_lds_sync();
         // ---- step 1: lane n2=l (<15): FFT16 over n1 of z[15*n1 + n2], z[n] = (y[2n], y[2n+1]) * hamming
-        float2 v[16];
+        v2f v[16];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            const int i = 30 * n1 + 2 * (l < 15 ? l : 0);
-            const float2 yy = *reinterpret_cast<const float2 *>(&ypre[grp * kShift + i]);
-            const float2 hh = *reinterpret_cast<const float2 *>(&ham[i]);
-            v[n1] = make_float2(yy.x * hh.x, yy.y * hh.y);
-        }
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = ysrc[15 * n1] * hsrc[15 * n1];
         wave_lds_sync();  // every lane has its samples in registers: the scratch may now overwrite them
         fft16(v);
         if (l < 15) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int k1 = c + 4 * d;
-                    my[k1 * 15 + l] = cmul(v[4 * c + d], tw240[l * k1]);  // W240^{n2*k1}
-                }
+                for (int d = 0; d < 4; ++d) t1dst[(c + 4 * d) * 15] = cmul(v[4 * c + d], twl[4 * c + d]);  // W240^{n2*k1}
         }
         wave_lds_sync();
         // ---- step 3: lane k1=l: DFT15 over n2 -> Z[k1 + 16*k2]
-        float2 z[15];
+        v2f z[15];
         {
-            float2 u[15];
+            v2f u[15];
 #pragma unroll
-            for (int n2 = 0; n2 < 15; ++n2) u[n2] = my[l * 15 + n2];
+            for (int n2 = 0; n2 < 15; ++n2) u[n2] = t1src[n2];
             dft15(u, z);
         }
         wave_lds_sync();
 #pragma unroll
-        for (int k2 = 0; k2 < 15; ++k2) my[l + 16 * k2] = z[k2];
+        for (int k2 = 0; k2 < 15; ++k2) zdst[16 * k2] = z[k2];
         wave_lds_sync();
-        // ---- untangle the two interleaved real sequences and take |X[k]|^2, k = l + 16*k2
-        float P[15];
+        // ---- untangle the two interleaved real sequences, bins k = l + 16*k2 <= 120 together with their
+        // mirrors 240-k (X[240-k] = conj(E - W480^k O) shares E, O and the twiddle product with X[k]).
+        // Everything is kept at twice its value; the factor 4 on the powers is removed before the log.
+        float Pk[8], Pm[8];
 #pragma unroll
-        for (int k2 = 0; k2 < 15; ++k2) {
+        for (int k2 = 0; k2 < 8; ++k2) {
             const int k = l + 16 * k2;
-            const float2 a = z[k2];
-            const float2 b = my[k == 0 ? 0 : 240 - k];
-            const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-            const float2 o = make_float2(0.5f * (a.y + b.y), -0.5f * (a.x - b.x));
-            const float2 w = tw480[k];
-            const float xr = e.x + fmaf(w.x, o.x, -(w.y * o.y));
-            const float xi = e.y + fmaf(w.x, o.y, w.y * o.x);
-            P[k2] = fmaf(xr, xr, xi * xi);  // (sqrt(re^2+im^2))^2 of extractor.rs:111-113,141 up to 1 ulp
+            const v2f a = z[k2];
+            const v2f b = (k2 == 0 && l == 0) ? a : zmir[-16 * k2];
+            const v2f e = (v2f){a.x + b.x, a.y - b.y};           // 2E = a + conj(b)
+            const v2f o = (v2f){a.y + b.y, b.x - a.x};           // 2O = -i (a - conj(b))
+            const v2f t = cmul(w480[16 * k2], o);
+            const v2f xp = e + t, xm = e - t;
+            const float pk = fmaf(xp.x, xp.x, xp.y * xp.y);      // 4 |X[k]|^2
+            const float pm = fmaf(xm.x, xm.x, xm.y * xm.y);      // 4 |X[240-k]|^2
+            Pk[k2] = k <= 120 ? pk : 0.f;                        // k > 120 is formed by the mirror lane
+            Pm[k2] = (k >= 1 && k < 120) ? pm : 0.f;             // bin 240 is not used; 120 is its own mirror
         }
         // ---- mel filterbank (dense rows, 8 filters per pass) + ln, src/mfcc/extractor.rs:121-145
         for (int i0 = 0; i0 < K1; i0 += 8) {
@@ -266,15 +289,18 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
             for (int ii = 0; ii < 8; ++ii) {
                 acc[ii] = 0.f;
                 if (i0 + ii < K1) {
-                    const float *row = fb + (size_t)(i0 + ii) * kBins + l;
+                    const float *rk = fbk + (i0 + ii) * kBins, *rm = fbm + (i0 + ii) * kBins;
 #pragma unroll
-                    for (int k2 = 0; k2 < 15; ++k2) acc[ii] = fmaf(P[k2], row[16 * k2], acc[ii]);
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        acc[ii] = fmaf(Pk[k2], rk[16 * k2], acc[ii]);
+                        acc[ii] = fmaf(Pm[k2], rm[-16 * k2], acc[ii]);
+                    }
                 }
             }
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) {
                 const float tot = row16_sum(acc[ii]);
-                if (l == ii && i0 + ii < K1) lgb[i0 + ii] = logf(tot + FLT_MIN);
+                if (l == ii && i0 + ii < K1) lgb[i0 + ii] = logf(0.25f * tot + FLT_MIN);
             }
         }
         wave_lds_sync();
@@ -301,29 +327,29 @@ hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm
     if (tiles > 0xffffffffULL) return hipErrorInvalidValue;
     const size_t lds = mfcc_lds_bytes(tb.K1);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    // 16-byte loads need 16-byte aligned rows (and at least one full float4 before the last sample)
+    const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % 16 == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
     // persistent grid: 3 workgroups of 4 waves per CU x 2 rounds, fewer for small problems
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
     if (blocks > 1536) blocks = 1536;
-    // 16-byte loads need 16-byte aligned rows (and at least one full float4 before the last sample)
-    const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % 16 == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
-    if (vec4)
-        hipLaunchKernelGGL(mfcc_kernel<true>, dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, pcm_stride,
-                           (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming, tb.tw240,
-                           tb.tw480, tb.fb, tb.dct, mfcc);
-    else
-        hipLaunchKernelGGL(mfcc_kernel<false>, dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, pcm_stride,
-                           (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming, tb.tw240,
-                           tb.tw480, tb.fb, tb.dct, mfcc);
+#define RP_MFCC_LAUNCH(V, KT)                                                                                              \
+    do {                                                                                                                   \
+        static bool attr_done = false;                                                                                     \
+        if (!attr_done) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<V, KT>),                          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+            if (e != hipSuccess) return e;                                                                                 \
+            attr_done = true;                                                                                              \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((mfcc_kernel<V, KT>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples,      \
+                           pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
+                           tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc);                                                       \
+    } while (0)
+    if (vec4 && tb.K1 == 6) RP_MFCC_LAUNCH(true, 6);
+    else if (vec4 && tb.K1 == 17) RP_MFCC_LAUNCH(true, 17);
+    else if (vec4) RP_MFCC_LAUNCH(true, 0);
+    else RP_MFCC_LAUNCH(false, 0);
+#undef RP_MFCC_LAUNCH
     return hipGetLastError();
 }
 
@@ -338,8 +364,6 @@ hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm
 // products, a sqrt and a divide (comparator.rs:28-48); zero vectors stay zero, which
 // reproduces the reference's "magnitude == 0 -> similarity 0".
 constexpr int kDtwWin = 64;   // windows per wave
-
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
 // Per lane: the window's column means, a ring of the 2W unit-length window frames inside the

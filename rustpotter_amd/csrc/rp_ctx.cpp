@@ -169,11 +169,12 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         for (DtwChunk c : byclass[cls]) {
             c.rows_off = (int)dup.size();
             for (int r = 0; r < c.len; ++r)
-                for (int tt = 0; tt < c.tc; ++tt)
-                    for (int k = 0; k < K; ++k) {
-                        float v = unit[((size_t)c.tid[tt < c.count ? tt : 0] * Lpad + r) * K + k];
-                        dup.push_back(v); dup.push_back(v);
-                    }
+                for (int tp = 0; tp < c.tc / 2; ++tp)
+                    for (int k = 0; k < K; ++k)
+                        for (int h = 0; h < 2; ++h) {  // (t0, t1) interleaved: one scalar pair feeds a packed FMA
+                            const int tt = 2 * tp + h;
+                            dup.push_back(unit[((size_t)c.tid[tt < c.count ? tt : 0] * Lpad + r) * K + k]);
+                        }
             chunks.push_back(c);
         }
     }

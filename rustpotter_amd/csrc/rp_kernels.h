@@ -42,8 +42,8 @@ struct TemplatesDev {
     int *lens = nullptr;   // [T+has_avg]
     float *unit = nullptr; // [T+has_avg][Lpad][K] rows scaled to unit L2 norm (zero rows stay zero)
     // register-kernel layout: chunks sorted by tile class (2, 4, 8); the avg template is the
-    // LAST chunk of class 2.  dup holds per chunk [len][tc][K][2]: every coefficient twice, so
-    // that one scalar load feeds both halves of a packed f32 FMA.
+    // LAST chunk of class 2.  dup holds per chunk [len][tc/2][K][2]: the coefficients of two templates
+    // interleaved, so that one scalar 8-byte load feeds both halves of a packed f32 FMA.
     DtwChunk *chunks = nullptr;
     float *dup = nullptr;
     int class_first[3] = {0, 0, 0};  // first chunk index of tile class 2 / 4 / 8

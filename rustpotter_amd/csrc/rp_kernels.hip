@@ -367,14 +367,149 @@ constexpr int kDtwWin = 64;   // windows per wave
 
 // One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
 // Per lane: the window's column means, a ring of the 2W unit-length window frames inside the
-// band (shared by all TC templates; slots kept as aligned register pairs so that the cosine
-// costs of two band cells come from one v_pk_fma_f32 with the template coefficient fed from a
-// scalar register pair), and TC bands of 2W+1 running costs.  Rows are unrolled 2W at a time so
+// band (shared by all TC templates), and TC bands of 2W+1 running costs held as register pairs of
+// two templates: one v_pk_fma_f32 forms the cosine costs of a band cell for both templates (the
+// coefficient pair comes from scalar registers, the window component is broadcast by op_sel),
+// one v_pk_add_f32 adds the two v_min3_f32 results.  Rows are unrolled 2W at a time so
 // every ring slot and band index is a compile-time register.  Only the first 2W rows can touch
 // columns c < 1 and need the +inf guard; columns c > n are never read back by an in-range cell
 // (they only feed cells further right / below-right), so they are left unguarded.
 template <int K, int W, int TC>
 __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
+    int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
+    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    constexpr int B = 2 * W;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);  // [64 + L + W][KP]
+
+    const unsigned tile = blockIdx.x % tiles;
+    const unsigned ci = (blockIdx.x / tiles) % n_chunks;
+    const size_t s = blockIdx.x / ((size_t)tiles * n_chunks);
+    const int lane = threadIdx.x;
+    const DtwChunk *ch = chunks + chunk_base + ci;
+    const int L = ch->len;  // m == n == L
+    const size_t w0 = first_win + (size_t)tile * kDtwWin;
+
+    const int n_stage = kDtwWin + L + W;
+    const float *src = mfcc + s * frame_pitch * K;
+    for (int i = lane; i < n_stage * K; i += kDtwWin) {
+        int f = i / K, k = i - f * K;
+        size_t g = w0 + f;
+        xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+    }
+    __syncthreads();
+
+    const float *xl = xs + lane * KP;
+    // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums
+    float mu[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = 0.f;
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) mu[k] += xl[i * KP + k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = mu[k] / (float)L;
+
+    v2f ring[B / 2][K];  // ring[j][k] = { y_slot(2j)[k], y_slot(2j+1)[k] }
+#pragma unroll
+    for (int j = 0; j < B / 2; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring[j][k] = (v2f){0.f, 0.f};
+
+#define RP_LOAD_COL(c, slot)                                                              \
+    do {                                                                                  \
+        float y_[K], bb_ = 0.f;                                                           \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
+            y_[k] = xl[((c)-1) * KP + k] - mu[k];                                         \
+            bb_ = fmaf(y_[k], y_[k], bb_);                                                \
+        }                                                                                 \
+        const float inv_ = bb_ > 0.f ? rsqrtf(bb_) : 0.f;                                 \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
+            if (((slot)&1) == 0) ring[(slot) / 2][k].x = y_[k] * inv_;                    \
+            else ring[(slot) / 2][k].y = y_[k] * inv_;                                    \
+        }                                                                                 \
+    } while (0)
+
+#pragma unroll
+    for (int c = 1; c < W; ++c) RP_LOAD_COL(c, c % B);
+
+    // P[tp][q] = D[r-1][(r-1-W)+q] of templates (2tp, 2tp+1); row 0 has D[0][0] = 0 at q = W
+    v2f P[TC / 2][B + 1];
+#pragma unroll
+    for (int t = 0; t < TC / 2; ++t) {
+#pragma unroll
+        for (int q = 0; q <= B; ++q) P[t][q] = (v2f){RP_INF, RP_INF};
+        P[t][W] = (v2f){0.f, 0.f};
+    }
+
+    const float *rows = dup + ch->rows_off;
+#define RP_ROWS(GUARD)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < B; ++u) {                                                    \
+        const int r = r0 + u;                                                                          \
+        if (r < L) { /* rows 1..m-1 only: row m is never read (dtw.rs:101) */                          \
+            RP_LOAD_COL(r + W - 1, (u + W) % B);                                                       \
+            _Pragma("unroll") for (int t = 0; t < TC / 2; ++t) {                                       \
+                /* coefficients of the template pair, interleaved (t0,t1) per k: one scalar pair */    \
+                const v2f *arow = reinterpret_cast<const v2f *>(rows + ((size_t)(r - 1) * (TC / 2) + t) * K * 2); \
+                v2f a2[K];                                                                             \
+                _Pragma("unroll") for (int k = 0; k < K; ++k) a2[k] = arow[k];                         \
+                /* costs of the 2W band cells first (independent FMA chains), then the serial min chain */ \
+                v2f d[B];                                                                              \
+                _Pragma("unroll") for (int q = 0; q < B; ++q) d[q] = (v2f){1.f, 1.f};                  \
+                _Pragma("unroll") for (int k = 0; k < K; ++k) {                                        \
+                    _Pragma("unroll") for (int q = 0; q < B; ++q) {                                    \
+                        const int slot = (1 + u + q + B - W) % B;                                      \
+                        const v2f yy = (slot & 1) ? ring[slot / 2][k].yy : ring[slot / 2][k].xx;       \
+                        d[q] = __builtin_elementwise_fma(-a2[k], yy, d[q]);                            \
+                    }                                                                                  \
+                }                                                                                      \
+                v2f left = (v2f){RP_INF, RP_INF};                                                      \
+                _Pragma("unroll") for (int q = 0; q < B; ++q) {                                        \
+                    v2f m;                                                                             \
+                    m.x = fminf(fminf(P[t][q + 1].x, left.x), P[t][q].x);                              \
+                    m.y = fminf(fminf(P[t][q + 1].y, left.y), P[t][q].y);                              \
+                    v2f v = d[q] + m;                                                                  \
+                    if (GUARD) v = (r - W + q >= 1) ? v : (v2f){RP_INF, RP_INF};                       \
+                    P[t][q] = v;                                                                       \
+                    left = v;                                                                          \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+    }
+
+    {
+        const int r0 = 1;
+        RP_ROWS(true)
+    }
+    for (int r0 = 1 + B; r0 < L; r0 += B) { RP_ROWS(false) }
+#undef RP_ROWS
+#undef RP_LOAD_COL
+
+    if (tile * (size_t)kDtwWin + lane < n_win) {
+        const size_t row = s * out_win_pitch + (size_t)tile * kDtwWin + lane;
+        const float denom = (float)(L + L);
+#pragma unroll
+        for (int t = 0; t < TC; ++t) {
+            if (t < ch->count) {
+                const float cost = (t & 1) ? P[t / 2][W + 1].y : P[t / 2][W + 1].x;  // D[m-1][n] for m == n
+                const float nc = cost / denom;
+                const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+                const int tid = ch->tid[t];
+                if (tid < T) scores[row * T + tid] = sc;
+                else avg[row] = sc;
+            }
+        }
+    }
+}
+
+// Variant for wide frames (K = 16): the ring alone is 160 registers, so the band costs are formed one
+// template at a time with two band cells per v_pk_fma_f32 (coefficient duplicated into a scalar pair)
+// instead of holding the costs of a template pair for all 2W cells.
+template <int K, int W, int TC>
+__global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
     const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
@@ -451,11 +586,11 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
         if (r < L) { /* rows 1..m-1 only: row m is never read (dtw.rs:101) */                          \
             RP_LOAD_COL(r + W - 1, (u + W) % B);                                                       \
             _Pragma("unroll") for (int t = 0; t < TC; ++t) {                                           \
-                const v2f *arow = reinterpret_cast<const v2f *>(rows + ((size_t)(r - 1) * TC + t) * K * 2); \
+                const float *arow = rows + ((size_t)(r - 1) * (TC / 2) + t / 2) * K * 2 + (t & 1);     \
                 v2f dd[B / 2];                                                                         \
                 _Pragma("unroll") for (int j = 0; j < B / 2; ++j) dd[j] = (v2f){1.f, 1.f};             \
                 _Pragma("unroll") for (int k = 0; k < K; ++k) {                                        \
-                    const v2f a2 = arow[k];                                                            \
+                    const v2f a2 = (v2f){arow[2 * k], arow[2 * k]};                                   \
                     _Pragma("unroll") for (int j = 0; j < B / 2; ++j)                                  \
                         dd[j] = __builtin_elementwise_fma(-a2, ring[j][k], dd[j]);                     \
                 }                                                                                      \
@@ -581,6 +716,21 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cl
     return hipGetLastError();
 }
 
+template <int K, int TC>
+static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
+                                  size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
+                                  float score_ref, float *scores, float *avg) {
+    if (n_chunks <= 0) return hipSuccess;
+    const size_t blocks = tiles * (size_t)n_chunks * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
+    const size_t lds = (size_t)(kDtwWin + t.max_len + 5) * KP * sizeof(float);
+    hipLaunchKernelGGL((dtw_band_wide_kernel<K, 5, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+                       frame_pitch, (unsigned)tiles, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+                       t.chunks, t.dup, t.T, score_ref, scores, avg);
+    return hipGetLastError();
+}
+
 // Largest template tile the register kernel is built for at this mfcc_size (0 = no register kernel).
 int dtw_register_tile(int K, int band) {
     if (band != 5) return 0;
@@ -606,7 +756,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
             if ((e = launch_dtw_class<5, 4>(RP_ARGS(1, t.class_count[1]))) != hipSuccess) return e;
             return launch_dtw_class<5, 8>(RP_ARGS(2, t.class_count[2]));
         }
-        return launch_dtw_class<16, 2>(RP_ARGS(0, n2));
+        return launch_dtw_wide<16, 2>(RP_ARGS(0, n2));
 #undef RP_ARGS
     }
     const size_t blocks = tiles * (size_t)Ttot * S;

@@ -378,30 +378,60 @@ template <int K, int W, int TC>
 __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
-    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
+    int flat, size_t n_streams) {
     constexpr int B = 2 * W;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *xs = reinterpret_cast<float *>(smem);  // [64 + L + W][KP]
+    float *xs = reinterpret_cast<float *>(smem);  // [64 + 2 (L + W)][KP]: up to two stream segments
 
     const unsigned tile = blockIdx.x % tiles;
     const unsigned ci = (blockIdx.x / tiles) % n_chunks;
-    const size_t s = blockIdx.x / ((size_t)tiles * n_chunks);
     const int lane = threadIdx.x;
     const DtwChunk *ch = chunks + chunk_base + ci;
     const int L = ch->len;  // m == n == L
-    const size_t w0 = first_win + (size_t)tile * kDtwWin;
-
-    const int n_stage = kDtwWin + L + W;
-    const float *src = mfcc + s * frame_pitch * K;
-    for (int i = lane; i < n_stage * K; i += kDtwWin) {
-        int f = i / K, k = i - f * K;
-        size_t g = w0 + f;
-        xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+    // Lane -> (stream, window).  flat != 0: the 64 lanes are consecutive entries of the flattened
+    // (stream, window) space, so a wave may straddle two streams (needs n_win >= 64) and no lane is
+    // wasted on a ragged last tile; flat == 0: tiles never cross a stream.
+    size_t sA, sB = 0;
+    int wA, nA, nB = 0;
+    if (flat) {
+        const size_t f0 = (size_t)tile * kDtwWin;  // here `tiles` counts flattened tiles and there is no stream index
+        sA = f0 / n_win;
+        wA = (int)(f0 - sA * n_win);
+        nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
+        if (nA < kDtwWin && sA + 1 < n_streams) { sB = sA + 1; nB = kDtwWin - nA; }
+    } else {
+        sA = blockIdx.x / ((size_t)tiles * n_chunks);
+        wA = (int)tile * kDtwWin;
+        nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
+    }
+    const int segA = nA + L + W;  // frames staged for the first stream segment
+    {
+        const float *src = mfcc + sA * frame_pitch * K;
+        const size_t g0 = first_win + wA;
+        for (int i = lane; i < segA * K; i += kDtwWin) {
+            int f = i / K, k = i - f * K;
+            size_t g = g0 + f;
+            xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+        }
+    }
+    if (nB > 0) {
+        const float *src = mfcc + sB * frame_pitch * K;
+        const int segB = nB + L + W;
+        for (int i = lane; i < segB * K; i += kDtwWin) {
+            int f = i / K, k = i - f * K;
+            size_t g = first_win + f;
+            xs[(segA + f) * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+        }
     }
     __syncthreads();
 
-    const float *xl = xs + lane * KP;
+    const bool inA = lane < nA;
+    const bool valid = inA || (lane - nA < nB);
+    const size_t s = inA ? sA : sB;
+    const int w = inA ? wA + lane : lane - nA;
+    const float *xl = xs + (inA ? lane : (valid ? segA + lane - nA : 0)) * KP;
     // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums
     float mu[K];
 #pragma unroll
@@ -488,8 +518,8 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
 #undef RP_ROWS
 #undef RP_LOAD_COL
 
-    if (tile * (size_t)kDtwWin + lane < n_win) {
-        const size_t row = s * out_win_pitch + (size_t)tile * kDtwWin + lane;
+    if (valid) {
+        const size_t row = s * out_win_pitch + (size_t)w;
         const float denom = (float)(L + L);
 #pragma unroll
         for (int t = 0; t < TC; ++t) {
@@ -706,13 +736,16 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cl
                                    size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
                                    float score_ref, float *scores, float *avg) {
     if (n_chunks <= 0) return hipSuccess;
-    const size_t blocks = tiles * (size_t)n_chunks * S;
+    // flattened (stream, window) tiling when every stream has at least one full tile of windows
+    const int flat = (n_win >= (size_t)kDtwWin && S > 1) ? 1 : 0;
+    const size_t ft = flat ? (S * n_win + kDtwWin - 1) / kDtwWin : tiles;
+    const size_t blocks = flat ? ft * (size_t)n_chunks : tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
-    const size_t lds = (size_t)(kDtwWin + t.max_len + 5) * KP * sizeof(float);
+    const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + 5)) * KP * sizeof(float);
     hipLaunchKernelGGL((dtw_band_kernel<K, 5, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
-                       frame_pitch, (unsigned)tiles, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
-                       t.chunks, t.dup, t.T, score_ref, scores, avg);
+                       frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+                       t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
     return hipGetLastError();
 }
 

@@ -90,7 +90,6 @@ def main():
     # resident inputs / outputs
     pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
     ctx.synth_dev(SEED, sharding.weak_first_stream(S, rank), S, N, N, pcm.data_ptr())
-    mfcc = torch.empty((S, nf, K), dtype=torch.float32, device=dev)
     scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev)
     agg = torch.empty((S, n_win), dtype=torch.float32, device=dev)
     max_det = 4
@@ -100,10 +99,9 @@ def main():
     cfg.avg_threshold = 0.0  # avg gate off: exactly T DTWs per scoring
 
     def step():
-        ctx.mfcc_dev(pcm.data_ptr(), S, N, N, K, mfcc.data_ptr())
-        ctx.dtw_dev(mfcc.data_ptr(), S, nf, tmpl, cfg.score_ref, cfg.band_size, cfg.score_mode, False,
-                    scores.data_ptr(), None, agg.data_ptr())
-        ctx.scan_dev(agg.data_ptr(), None, S, nf, L, cfg, det.data_ptr(), n_det.data_ptr(), max_det)
+        # one C call: mfcc_kernel -> dtw_band_kernel -> aggregate_kernel -> scan_kernel on the launch stream
+        ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), max_det,
+                             scores.data_ptr(), agg.data_ptr())
         return sharding.gather_per_stream(n_det, world)  # final per-stream result gather (RCCL over xGMI)
 
     def fence():

@@ -221,6 +221,18 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
                    const rp_detector_config *config, int avg_enabled, rp_batch_detection *det, int32_t *n_det,
                    int max_det);
 
+/* The whole path for S independent streams in one call = S x (Rustpotter::new + add_wakeword +
+ * process_samples over the stream in 480-sample chunks), src/detector.rs:347-454: MFCC -> window
+ * scores -> score_mode aggregate -> detection state machine; intermediate arrays live in buffers
+ * owned by the context (grown on demand, reused across calls).  pcm [S][pcm_stride] f32 16 kHz mono;
+ * det [S][max_det], n_det [S] as in rp_detect_scan.  Optional outputs (NULL to skip): scores
+ * [S][n_win][T] and agg [S][n_win] with n_win = rp_mfcc_num_frames(n_samples) - max_len + 1.
+ * The wakeword's own threshold / avg_threshold overrides (Option<f32> in the .rpw) are passed in
+ * `config` by the caller; avg gate as in WakewordComparator::run_detection :83-93. */
+int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, const rp_templates *t,
+                    const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det,
+                    float *scores, float *agg);
+
 /* A wakeword model (src/wakewords/wakeword_model.rs:11-18) resident on the device.  weights are
  * HOST arrays W_l [dims[l+1]][dims[l]] (candle Linear: x.W^T + b), biases b_l [dims[l+1]]; 1..3 layers. */
 typedef struct rp_model rp_model;

@@ -97,7 +97,7 @@ SYMBOLS = [
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
     "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch",
-    "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan",
+    "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version",
 ]
@@ -159,6 +159,7 @@ def load_library():
     L.rp_templates_max_len.argtypes = [vp]
     L.rp_dtw_score_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, vp, C.c_int]
+    L.rp_batch_detect.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
     L.rp_model_new.argtypes = [vp, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(vp)]
     L.rp_model_free.argtypes = [vp]
     L.rp_mlp_forward_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
@@ -488,6 +489,36 @@ class BatchContext:
         if r < 0:
             raise _err()
         return det, n_det
+
+    def batch_detect(self, pcm, templates, detector_config, max_det=8, want_scores=False):
+        """Whole path for S streams in one call (numpy in / out)."""
+        import numpy as np
+        assert self.host
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        S, N = pcm.shape
+        nf = mfcc_num_frames(N)
+        n_win = max(0, nf - templates.max_len + 1)
+        det = np.zeros((S, max_det), dtype=[("stream", "<i4"), ("frame", "<i4"), ("window", "<i4"), ("counter", "<i4"),
+                                             ("avg_score", "<f4"), ("score", "<f4")])
+        n_det = np.zeros(S, np.int32)
+        scores = np.empty((S, n_win, templates.T), np.float32) if want_scores else None
+        agg = np.empty((S, n_win), np.float32) if want_scores else None
+        c = detector_config._c()
+        r = self._L.rp_batch_detect(self._h, pcm.ctypes.data, S, N, N, templates._h, C.byref(c), det.ctypes.data,
+                                    n_det.ctypes.data, max_det, None if scores is None else scores.ctypes.data,
+                                    None if agg is None else agg.ctypes.data)
+        if r < 0:
+            raise _err()
+        return (det, n_det, scores, agg) if want_scores else (det, n_det)
+
+    def batch_detect_dev(self, pcm_ptr, S, N, stride, templates, detector_config, det_ptr, n_det_ptr, max_det,
+                         scores_ptr=None, agg_ptr=None):
+        c = detector_config._c()
+        if self._L.rp_batch_detect(self._h, pcm_ptr, S, N, stride, templates._h, C.byref(c), det_ptr, n_det_ptr, max_det,
+                                   scores_ptr, agg_ptr) < 0:
+            raise _err()
 
     def mlp_forward(self, x, model, precision="f32"):
         import numpy as np

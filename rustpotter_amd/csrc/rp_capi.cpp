@@ -272,6 +272,61 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
     });
 }
 
+int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, const rp_templates *t,
+                    const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det,
+                    float *scores, float *agg) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (config->vad_mode != RP_VAD_NONE) { set_last_error("rp_batch_detect: VAD is only available on the single-stream path"); return -1; }
+        if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
+        if (config->band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
+        const TemplatesDev &td = t->impl->dev;
+        const MfccTablesDev *tb = c->tables_for(td.K);
+        if (!tb) return -1;
+        const size_t nf = rp_mfcc_num_frames(n_samples);
+        const size_t n_win = nf >= (size_t)td.max_len ? nf - td.max_len + 1 : 0;
+        const size_t rows = S * n_win;
+        const bool do_avg = td.has_avg && config->avg_threshold != 0.f;  // wakeword_comp.rs:85
+        Staged sg(c);
+        const float *dp = static_cast<const float *>(sg.in(pcm, S * pcm_stride * sizeof(float), c->stage_in));
+        BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
+        int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
+        // caller-provided score arrays are used directly when they are device pointers
+        float *ds = (scores && !sg.host) ? scores : nullptr, *dg = (agg && !sg.host) ? agg : nullptr;
+        if (!c->ws_mfcc.reserve(S * nf * td.K * sizeof(float) + 16)) return -1;
+        if (!ds) { if (!c->ws_scores.reserve(rows * td.T * sizeof(float) + 16)) return -1; ds = c->ws_scores.as<float>(); }
+        if (!dg) { if (!c->ws_agg.reserve(rows * sizeof(float) + 16)) return -1; dg = c->ws_agg.as<float>(); }
+        float *da = nullptr;
+        if (do_avg) { if (!c->ws_avg.reserve(rows * sizeof(float) + 16)) return -1; da = c->ws_avg.as<float>(); }
+        if (S && (!dp || !dd || !dn)) return -1;
+        float *dm = c->ws_mfcc.as<float>();
+        c->time_begin(kKernelMfcc);
+        bool ok = hip_ok(launch_mfcc(c->stream, *tb, dp, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        c->time_begin(kKernelDtw);
+        ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+        c->time_end();
+        if (!ok) return -1;
+        c->time_begin(kKernelAggregate);
+        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg), "aggregate_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        ScanConfig sc;
+        sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
+        sc.eager = config->eager ? 1 : 0; sc.max_len = td.max_len; sc.avg_enabled = do_avg ? 1 : 0;
+        c->time_begin(kKernelScan);
+        ok = hip_ok(launch_scan(c->stream, dg, da, S, nf, sc, dd, dn, max_det), "scan_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
+        if (sg.host && scores && !sg.back(scores, ds, rows * td.T * sizeof(float))) return -1;
+        if (sg.host && agg && !sg.back(agg, dg, rows * sizeof(float))) return -1;
+        return sg.finish() ? 0 : -1;
+    });
+}
+
 int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
                  rp_model **out) {
     return guarded([&]() -> int {

@@ -158,6 +158,58 @@ def test_dtw_synthetic(ra, ctx, K, band, L):
         assert rel_close(agg[s], ref_a)
 
 
+def test_dtw_many_templates_mixed_chunks(ra, ctx):
+    """11 equal-length + 3 ragged templates + avg over 3 streams: chunk classes 8/4/2, several chunks,
+    flattened tiles straddling streams, avg chunk."""
+    K, L = 5, 70
+    templates = orc.synth_templates(SEED, 14, L, K)
+    templates[3] = templates[3][:60].copy()
+    templates[7] = templates[7][:60].copy()
+    templates[12] = templates[12][:41].copy()
+    avg = orc.synth_templates(SEED + 77, 1, L, K)[0]
+    S, N = 3, 480 * 60
+    pcm = np.stack([orc.synth_pcm(SEED, 20 + s, N) for s in range(S)])
+    mf = np.stack([orc.mfcc_stream(pcm[s], K) for s in range(S)])
+    tm = ra.Templates(ctx, templates, avg=avg)
+    scores, avg_s, agg = ctx.dtw_scores(mf, tm, with_avg=True, score_mode=ra.ScoreMode.P75)
+    assert scores.shape == (S, 177 - L + 1, 14)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates, mode="p75")
+        assert rel_close(scores[s], ref_s) and rel_close(agg[s], ref_a)
+        ref_avg = np.array([orc.score_window(mf[s][w:w + L], avg) for w in range(0, scores.shape[1], 5)])
+        assert rel_close(avg_s[s][::5], ref_avg)
+
+
+def test_single_template_and_tiny_batch(ra, ctx):
+    K = 5
+    templates = orc.synth_templates(SEED, 1, 30, K)
+    mf = orc.mfcc_stream(orc.synth_pcm(SEED, 2, 480 * 14), K)  # 39 frames -> 10 windows
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(mf, tm)
+    ref_s, ref_a = orc.score_stream(mf, templates)
+    assert scores.shape == (1, 10, 1) and rel_close(scores[0], ref_s) and np.array_equal(agg[0], scores[0][:, 0])
+
+
+def test_single_stream_call_latency(ra):
+    """The drop-in API must keep up with real time: one process_samples call per 30 ms of audio."""
+    import time
+    c = ra.RustpotterConfig.default()
+    c.detector.avg_threshold = 0.0
+    rp = ra.Rustpotter.new(c)
+    rp.add_wakeword_from_file("w", os.path.join(G, "oye_casa_g.rpw"))
+    pcm = orc.synth_pcm(SEED, 5, 480 * 400) * np.float32(0.1)
+    for i in range(0, 480 * 150, 480):
+        rp.process_samples(pcm[i:i + 480].copy())
+    t0 = time.perf_counter()
+    n = 0
+    for i in range(480 * 150, 480 * 400, 480):
+        rp.process_samples(pcm[i:i + 480].copy())
+        n += 1
+    per_call = (time.perf_counter() - t0) / n
+    print("single-stream process_samples: %.1f us per 30 ms chunk" % (per_call * 1e6))
+    assert per_call < 0.030 / 10  # at least 10x faster than real time
+
+
 def test_dtw_avg_longer_than_window(ra, ctx):
     """m != n: an averaged template longer than every sample template widens the band to |m-n|."""
     K = 5
@@ -282,6 +334,38 @@ def test_batch_scan_matches_streaming_state_machine(ra, ctx):
         for i, (chunk, r) in enumerate(ref):
             assert det[0][i]["frame"] // 3 + 1 == chunk and det[0][i]["counter"] == r["counter"]
             assert abs(det[0][i]["score"] - r["score"]) <= 1e-5 * r["score"]
+
+
+def test_batch_detect_equals_per_stream_api(ra, ctx):
+    """rp_batch_detect over S streams == S independent Rustpotter handles fed chunk by chunk."""
+    e = EXP["simulation"]["max"]
+    w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+    templates = list(w["samples_features"].values())
+    base = simstream.i16_to_f32(simstream.simulation_stream_i16())
+    rng = np.random.default_rng(3)
+    streams = [base, np.roll(base, 480 * 7), (base + rng.standard_normal(len(base)).astype(np.float32) * np.float32(0.002))]
+    n = (len(base) // 480) * 480
+    pcm = np.stack([s[:n] for s in streams])
+    cfg = _make_config(ra, e)
+    tm = ra.Templates(ctx, templates, avg=w["avg_features"])
+    det, n_det, scores, agg = ctx.batch_detect(pcm, tm, cfg.detector, want_scores=True)
+    cfg.fmt.sample_format = ra.SampleFormat.F32
+    for si in range(len(streams)):
+        rp = ra.Rustpotter.new(cfg)
+        rp.add_wakeword_from_file("w", os.path.join(G, e["rpw"]))
+        got = []
+        for i in range(0, n, 480):
+            d = rp.process_samples(pcm[si, i:i + 480].copy())
+            if d is not None:
+                got.append((i // 480, d))
+        assert n_det[si] == len(got) and len(got) >= 1
+        for j, (chunk, d) in enumerate(got):
+            assert det[si][j]["frame"] // 3 + 1 == chunk and det[si][j]["counter"] == d.counter
+            assert abs(det[si][j]["score"] - d.score) <= 1e-6 * d.score
+            names = list(w["samples_features"].keys())
+            row = scores[si][det[si][j]["window"]]
+            for ti, nm in enumerate(names):
+                assert abs(row[ti] - d.scores[nm]) <= 1e-6 * d.scores[nm]
 
 
 def test_mlp_forward_model_file(ra, ctx):

@@ -152,7 +152,7 @@ def main():
     # command (rocprofv3 cannot run inside the timed process); null for any other workload.
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_opt_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
         w = tj["workload"]
         if (w["streams"], w["samples"], w["templates"], w["template_len"], w["mfcc_size"]) == (S, N, T, L, K):
             for name, d in tj["kernels"].items():

@@ -143,7 +143,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     std::vector<int> order(T);
     for (int t = 0; t < T; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hl[a] < hl[b]; });
-    const int reg_tile = dtw_register_tile(K, 5);
+    const int reg_tile = dtw_register_tile(K, 5);  // chunk size is fixed at upload time, before the band is known
     const int chunk_cap = reg_tile > 0 ? reg_tile : kChunkMax;
     std::vector<DtwChunk> byclass[3];
     for (int i = 0; i < T;) {

@@ -731,7 +731,7 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
     }
 }
 
-template <int K, int TC>
+template <int K, int W, int TC>
 static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
                                    size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
                                    float score_ref, float *scores, float *avg) {
@@ -742,14 +742,14 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cl
     const size_t blocks = flat ? ft * (size_t)n_chunks : tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
-    const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + 5)) * KP * sizeof(float);
-    hipLaunchKernelGGL((dtw_band_kernel<K, 5, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+    const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + W)) * KP * sizeof(float);
+    hipLaunchKernelGGL((dtw_band_kernel<K, W, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
     return hipGetLastError();
 }
 
-template <int K, int TC>
+template <int K, int W, int TC>
 static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
                                   size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
                                   float score_ref, float *scores, float *avg) {
@@ -757,19 +757,29 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
     const size_t blocks = tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
-    const size_t lds = (size_t)(kDtwWin + t.max_len + 5) * KP * sizeof(float);
-    hipLaunchKernelGGL((dtw_band_wide_kernel<K, 5, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+    const size_t lds = (size_t)(kDtwWin + t.max_len + W) * KP * sizeof(float);
+    hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)tiles, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg);
     return hipGetLastError();
 }
 
-// Largest template tile the register kernel is built for at this mfcc_size (0 = no register kernel).
+// Largest template tile the register kernels are built for at this (mfcc_size, band) (0 = only the generic
+// kernel applies).  Built: mfcc_size 5 with band 3..6, mfcc_size 16 with band 5.
 int dtw_register_tile(int K, int band) {
-    if (band != 5) return 0;
-    if (K == 5) return 8;
-    if (K == 16) return 2;
+    if (K == 5 && band >= 3 && band <= 6) return 8;
+    if (K == 16 && band == 5) return 2;
     return 0;
+}
+
+template <int W>
+static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n2, const float *mfcc, size_t S, size_t frame_pitch,
+                                size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
+                                float *scores, float *avg) {
+    hipError_t e;
+    if ((e = launch_dtw_class<5, W, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg)) != hipSuccess) return e;
+    if ((e = launch_dtw_class<5, W, 4>(st, t, 1, t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg)) != hipSuccess) return e;
+    return launch_dtw_class<5, W, 8>(st, t, 2, t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
 }
 
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
@@ -779,18 +789,18 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     const bool do_avg = with_avg && t.has_avg;
     const int Ttot = t.T + (do_avg ? 1 : 0);
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
-    // the register kernel assumes m == n (no template longer than the window)
+    // the register kernels assume m == n (no template longer than the window)
     if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks) {
         const int n2 = t.class_count[0] - ((t.has_avg && !do_avg) ? 1 : 0);
-        hipError_t e;
-#define RP_ARGS(cls, n) st, t, cls, n, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg
         if (t.K == 5) {
-            if ((e = launch_dtw_class<5, 2>(RP_ARGS(0, n2))) != hipSuccess) return e;
-            if ((e = launch_dtw_class<5, 4>(RP_ARGS(1, t.class_count[1]))) != hipSuccess) return e;
-            return launch_dtw_class<5, 8>(RP_ARGS(2, t.class_count[2]));
+            switch (band) {
+            case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+            case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+            case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+            default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+            }
         }
-        return launch_dtw_wide<16, 2>(RP_ARGS(0, n2));
-#undef RP_ARGS
+        return launch_dtw_wide<16, 5, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
     }
     const size_t blocks = tiles * (size_t)Ttot * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;

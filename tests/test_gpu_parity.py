@@ -142,7 +142,7 @@ def test_score_modes(ra, ctx, mode):
     assert rel_close(agg[0], ref_a)
 
 
-@pytest.mark.parametrize("K,band,L", [(5, 5, 100), (5, 3, 64), (16, 5, 50), (5, 9, 30), (3, 1, 12)])
+@pytest.mark.parametrize("K,band,L", [(5, 5, 100), (5, 3, 64), (5, 4, 80), (5, 6, 90), (16, 5, 50), (5, 9, 30), (16, 3, 40), (3, 1, 12)])
 def test_dtw_synthetic(ra, ctx, K, band, L):
     """Register kernel (K=5, band=5) and the generic kernel on BASELINE-style synthetic input."""
     T, S, N = 3, 4, 480 * 60

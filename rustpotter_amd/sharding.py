@@ -28,6 +28,8 @@ def gather_per_stream(local, world_size, group=None):
     import torch.distributed as dist
     if world_size == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":  # CPU-backend dry runs: stage through host memory
+        return gather_per_stream(local.cpu(), world_size, group).to(local.device)
     parts = [torch.empty_like(local) for _ in range(world_size)]
     dist.all_gather(parts, local, group=group)
     return torch.cat(parts, dim=0)

@@ -215,11 +215,13 @@ typedef struct {
 } rp_batch_detection;
 
 /* Rustpotter::process_new_mfccs / run_detection / reset state machine,
- * src/detector.rs:290-302,377-454, run over precomputed window scores (no VAD).
+ * src/detector.rs:290-302,377-454, run over precomputed window scores.  With config->vad_mode set,
+ * the VadDetector gate (src/mfcc/vad.rs:11-36, :379-383) is evaluated per stream from `mfcc`
+ * ([S][n_frames][K], required then; may be NULL otherwise).
  * det [S][max_det] (device or host per ctx flag), n_det [S]. */
 int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, size_t n_frames, int max_len,
-                   const rp_detector_config *config, int avg_enabled, rp_batch_detection *det, int32_t *n_det,
-                   int max_det);
+                   const rp_detector_config *config, int avg_enabled, const float *mfcc, int K,
+                   rp_batch_detection *det, int32_t *n_det, int max_det);
 
 /* The whole path for S independent streams in one call = S x (Rustpotter::new + add_wakeword +
  * process_samples over the stream in 480-sample chunks), src/detector.rs:347-454: MFCC -> window

@@ -158,7 +158,7 @@ def load_library():
     L.rp_templates_free.argtypes = [vp]
     L.rp_templates_max_len.argtypes = [vp]
     L.rp_dtw_score_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp]
-    L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, vp, C.c_int]
+    L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, C.c_int, vp, vp, C.c_int]
     L.rp_batch_detect.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
     L.rp_model_new.argtypes = [vp, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(vp)]
     L.rp_model_free.argtypes = [vp]
@@ -473,7 +473,7 @@ class BatchContext:
             raise _err()
         return scores, avg, agg
 
-    def detect_scan(self, agg, avg, n_frames, max_len, detector_config, max_det=8):
+    def detect_scan(self, agg, avg, n_frames, max_len, detector_config, max_det=8, mfcc=None):
         import numpy as np
         assert self.host
         agg = np.ascontiguousarray(agg, np.float32)
@@ -483,9 +483,11 @@ class BatchContext:
         n_det = np.zeros(S, np.int32)
         c = detector_config._c()
         avg_a = None if avg is None else np.ascontiguousarray(avg, np.float32)
+        mf = None if mfcc is None else np.ascontiguousarray(mfcc, np.float32)
         r = self._L.rp_detect_scan(self._h, agg.ctypes.data, None if avg_a is None else avg_a.ctypes.data, S, n_frames,
-                                   max_len, C.byref(c), 1 if avg_a is not None else 0, det.ctypes.data, n_det.ctypes.data,
-                                   max_det)
+                                   max_len, C.byref(c), 1 if avg_a is not None else 0,
+                                   None if mf is None else mf.ctypes.data, 0 if mf is None else mf.shape[-1],
+                                   det.ctypes.data, n_det.ctypes.data, max_det)
         if r < 0:
             raise _err()
         return det, n_det
@@ -554,8 +556,8 @@ class BatchContext:
 
     def scan_dev(self, agg_ptr, avg_ptr, S, n_frames, max_len, detector_config, det_ptr, n_det_ptr, max_det):
         c = detector_config._c()
-        if self._L.rp_detect_scan(self._h, agg_ptr, avg_ptr, S, n_frames, max_len, C.byref(c), 1 if avg_ptr else 0, det_ptr,
-                                  n_det_ptr, max_det) < 0:
+        if self._L.rp_detect_scan(self._h, agg_ptr, avg_ptr, S, n_frames, max_len, C.byref(c), 1 if avg_ptr else 0, None, 0,
+                                  det_ptr, n_det_ptr, max_det) < 0:
             raise _err()
 
     def synth_dev(self, seed, first_stream, S, N, stride, out_ptr):

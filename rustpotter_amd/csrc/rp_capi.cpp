@@ -246,13 +246,16 @@ int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames
     });
 }
 
+static float vad_mode_value(rp_vad_mode m) { return m == RP_VAD_EASY ? 2.f : m == RP_VAD_MEDIUM ? 2.5f : 3.f; }  // src/config.rs:140-146
+
 int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, size_t n_frames, int max_len,
-                   const rp_detector_config *config, int avg_enabled, rp_batch_detection *det, int32_t *n_det,
-                   int max_det) {
+                   const rp_detector_config *config, int avg_enabled, const float *mfcc, int K,
+                   rp_batch_detection *det, int32_t *n_det, int max_det) {
     return guarded([&]() -> int {
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
-        if (config->vad_mode != RP_VAD_NONE) { set_last_error("rp_detect_scan: VAD is only available on the single-stream path"); return -1; }
+        const bool vad = config->vad_mode != RP_VAD_NONE;
+        if (vad && (!mfcc || K < 1)) { set_last_error("rp_detect_scan: vad_mode needs the MFCC frames"); return -1; }
         static_assert(sizeof(rp_batch_detection) == sizeof(BatchDetection), "layout");
         ScanConfig sc;
         sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
@@ -263,8 +266,15 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
         const float *da = sc.avg_enabled ? static_cast<const float *>(sg.in(avg, S * n_win * sizeof(float), c->stage_out3)) : nullptr;
         BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
         int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
+        float *dv = nullptr;
+        if (vad) {
+            const float *dm = static_cast<const float *>(sg.in(mfcc, S * n_frames * K * sizeof(float), c->ws_mfcc));
+            if (!c->ws_vad.reserve(S * n_frames * sizeof(float) + 16) || (S * n_frames && !dm)) return -1;
+            dv = c->ws_vad.as<float>();
+            if (!hip_ok(launch_vad_value(c->stream, dm, S * n_frames, K, dv), "vad_value_kernel")) return -1;
+        }
         c->time_begin(kKernelScan);
-        bool ok = hip_ok(launch_scan(c->stream, dg, da, S, n_frames, sc, dd, dn, max_det), "scan_kernel");
+        bool ok = hip_ok(launch_scan(c->stream, dg, da, dv, vad_mode_value(config->vad_mode), S, n_frames, sc, dd, dn, max_det), "scan_kernel");
         c->time_end();
         if (!ok) return -1;
         if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t)) || !sg.finish()) return -1;
@@ -278,7 +288,6 @@ int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, s
     return guarded([&]() -> int {
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
-        if (config->vad_mode != RP_VAD_NONE) { set_last_error("rp_batch_detect: VAD is only available on the single-stream path"); return -1; }
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
         if (config->band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
         const TemplatesDev &td = t->impl->dev;
@@ -316,8 +325,14 @@ int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, s
         ScanConfig sc;
         sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
         sc.eager = config->eager ? 1 : 0; sc.max_len = td.max_len; sc.avg_enabled = do_avg ? 1 : 0;
+        float *dv = nullptr;
+        if (config->vad_mode != RP_VAD_NONE) {
+            if (!c->ws_vad.reserve(S * nf * sizeof(float) + 16)) return -1;
+            dv = c->ws_vad.as<float>();
+            if (!hip_ok(launch_vad_value(c->stream, dm, S * nf, td.K, dv), "vad_value_kernel")) return -1;
+        }
         c->time_begin(kKernelScan);
-        ok = hip_ok(launch_scan(c->stream, dg, da, S, nf, sc, dd, dn, max_det), "scan_kernel");
+        ok = hip_ok(launch_scan(c->stream, dg, da, dv, vad_mode_value(config->vad_mode), S, nf, sc, dd, dn, max_det), "scan_kernel");
         c->time_end();
         if (!ok) return -1;
         if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;

@@ -75,8 +75,11 @@ int dtw_register_tile(int K, int band);
 
 hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg);
 
-hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, size_t S, size_t n_frames,
-                       const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det);
+// vad_value [S][n_frames] = mean |mfcc| per frame (launch_vad_value) or nullptr (no VAD);
+// vad_mode_value = VADMode::get_value (2 / 2.5 / 3, src/config.rs:140-146)
+hipError_t launch_vad_value(hipStream_t st, const float *mfcc, size_t n_frames_total, int K, float *out);
+hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
+                       size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det);
 
 hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
                         size_t pcm_stride, float *pcm);

@@ -886,22 +886,63 @@ hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, 
 // is emitted while chunk c = f/3 + 1 is processed; after an emit the extractor and the
 // window are cleared, the rest of that chunk's frames are dropped (find_map, :372-375),
 // chunk c+1 only refills the extractor, so the next frame seen is 3*(f/3) + 6.
-__global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg, const float *__restrict__ avg, size_t S,
+// mean(|mfcc|) of every frame, summed in coefficient order like VadDetector::is_voice (src/mfcc/vad.rs:12)
+__global__ __launch_bounds__(256) void vad_value_kernel(const float *__restrict__ mfcc, size_t n, int K, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *v = mfcc + i * K;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += fabsf(v[k]);
+    out[i] = s / (float)K;
+}
+
+hipError_t launch_vad_value(hipStream_t st, const float *mfcc, size_t n_frames_total, int K, float *out) {
+    if (n_frames_total == 0) return hipSuccess;
+    const size_t blocks = (n_frames_total + 255) / 256;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vad_value_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mfcc, n_frames_total, K, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg, const float *__restrict__ avg,
+                                                  const float *__restrict__ vad_value, float vad_mode_value, size_t S,
                                                   size_t n_frames, ScanConfig cfg, BatchDetection *__restrict__ det,
                                                   int32_t *__restrict__ n_det, int max_det) {
-    size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+    __shared__ float vwin[50][64];  // VadDetector::window, one column per stream (lane)
+    const int lane = threadIdx.x;
+    size_t s = (size_t)blockIdx.x * 64 + lane;
     if (s >= S) return;
     const long max_len = cfg.max_len;
     const long n_win = (long)n_frames - max_len + 1;
     const float *a = agg + s * (size_t)(n_win > 0 ? n_win : 0);
     const float *v = avg ? avg + s * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
+    const float *vv = vad_value ? vad_value + s * n_frames : nullptr;
+    // VadDetector state (src/mfcc/vad.rs:3-50)
+    int vad_index = 0, voice_countdown = 0;
+    if (vv)
+        for (int i = 0; i < 50; ++i) vwin[i][lane] = __builtin_nanf("");
     long win_start = 0, resume = 0;
     bool has_partial = false;
     float p_score = 0.f, p_avg = 0.f;
     int p_counter = 0, p_window = 0, countdown = 0, nd = 0;
     for (long f = 0; f < (long)n_frames; ++f) {
         if (f < resume) continue;
+        // process_new_mfccs :379-383: the VAD only sees a frame while no partial detection exists
+        bool should_run = true;
+        if (vv && !has_partial) {
+            vwin[vad_index][lane] = vv[f];
+            vad_index = vad_index >= 49 ? 0 : vad_index + 1;
+            float mn = RP_INF;
+            for (int i = 0; i < 50; ++i) { float w = vwin[i][lane]; if (w == w && w < mn) mn = w; }
+            mn = fmaxf(mn, 0.01f);
+            const float th = mn * vad_mode_value;
+            int n_high = 0;
+            for (int i = 0; i < 50; ++i) n_high += vwin[i][lane] > th ? 1 : 0;
+            if (n_high > 10) voice_countdown = 500;
+            if (voice_countdown > 0) { voice_countdown -= 1; should_run = true; } else should_run = false;
+        }
         if (f - win_start + 1 < max_len) continue;
+        if (!should_run) continue;
         const long w = f - max_len + 1;
         if (countdown != 0) countdown -= 1;
         if (has_partial) {
@@ -917,6 +958,10 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
                     }
                     ++nd;
                     win_start = resume = 3 * (f / 3) + 6;  // reset()
+                    if (vv) {  // vad.reset()
+                        for (int i = 0; i < 50; ++i) vwin[i][lane] = __builtin_nanf("");
+                        vad_index = 0; voice_countdown = 0;
+                    }
                     continue;
                 }
             }
@@ -935,12 +980,12 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
     n_det[s] = nd;
 }
 
-hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, size_t S, size_t n_frames,
-                       const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det) {
+hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
+                       size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det) {
     if (S == 0) return hipSuccess;
     size_t blocks = (S + 63) / 64;
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)blocks), dim3(64), 0, st, agg, avg, S, n_frames, cfg, det, n_det,
-                       max_det);
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)blocks), dim3(64), 0, st, agg, avg, vad_value, vad_mode_value, S, n_frames,
+                       cfg, det, n_det, max_det);
     return hipGetLastError();
 }
 

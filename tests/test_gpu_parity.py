@@ -318,7 +318,7 @@ def test_rustpotter_api_behaviour(ra):
 
 def test_batch_scan_matches_streaming_state_machine(ra, ctx):
     """rp_detect_scan over precomputed scores == the chunked detector (frames, counters exact)."""
-    for case in ("max", "median", "ignore_alexa"):
+    for case in ("max", "median", "ignore_alexa", "vad_easy"):
         e = EXP["simulation"][case]
         w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
         templates = list(w["samples_features"].values())
@@ -328,7 +328,8 @@ def test_batch_scan_matches_streaming_state_machine(ra, ctx):
         cfg = _make_config(ra, e).detector
         with_avg = e["avg_threshold"] != 0.0
         _, avg, agg = ctx.dtw_scores(mf, tm, score_mode=cfg.score_mode, with_avg=with_avg)
-        det, n_det = ctx.detect_scan(agg, avg if with_avg else None, mf.shape[1], tm.max_len, cfg)
+        det, n_det = ctx.detect_scan(agg, avg if with_avg else None, mf.shape[1], tm.max_len, cfg,
+                                     mfcc=mf if e.get("vad_mode") else None)
         ref = _oracle_detections(e, s)
         assert n_det[0] == len(ref)
         for i, (chunk, r) in enumerate(ref):
@@ -366,6 +367,35 @@ def test_batch_detect_equals_per_stream_api(ra, ctx):
             row = scores[si][det[si][j]["window"]]
             for ti, nm in enumerate(names):
                 assert abs(row[ti] - d.scores[nm]) <= 1e-6 * d.scores[nm]
+
+
+@pytest.mark.parametrize("vad", ["easy", "medium", "hard"])
+def test_batch_vad_gate_matches_oracle(ra, ctx, vad):
+    """VadDetector in the batched scan: speech surrounded by low-level noise (the gate opens late
+    and changes which frames are scored) against the oracle's chunked detector."""
+    w = rpw_py.load_rpw(os.path.join(G, "oye_casa_g.rpw"))
+    templates = list(w["samples_features"].values())
+    rng = np.random.default_rng(9)
+    base = simstream.i16_to_f32(simstream.simulation_stream_i16())
+    noisy = base + rng.standard_normal(len(base)).astype(np.float32) * np.float32(0.0005)
+    n = (len(noisy) // 480) * 480
+    pcm = noisy[:n][None, :]
+    cfg = ra.RustpotterConfig.default().detector
+    cfg.avg_threshold, cfg.threshold = 0.0, 0.5
+    cfg.vad_mode = {"easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[vad]
+    tm = ra.Templates(ctx, templates)
+    det, n_det = ctx.batch_detect(pcm, tm, cfg)
+    d = orc.Detector(avg_threshold=0.0, threshold=0.5, vad_mode=vad)
+    d.add_ref(w)
+    ref = []
+    for i in range(0, n, 480):
+        r = d.process_f32(pcm[0, i:i + 480])
+        if r is not None:
+            ref.append((i // 480, r))
+    assert n_det[0] == len(ref)
+    for j, (chunk, r) in enumerate(ref):
+        assert det[0][j]["frame"] // 3 + 1 == chunk and det[0][j]["counter"] == r["counter"]
+        assert abs(det[0][j]["score"] - r["score"]) <= 1e-5 * r["score"]
 
 
 def test_mlp_forward_model_file(ra, ctx):

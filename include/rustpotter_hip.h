@@ -187,6 +187,12 @@ size_t rp_mfcc_num_frames(size_t n_samples);
  * (set_out_size(K): K+1 filters/coefficients, coefficient 0 dropped). */
 int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, int K, float *mfcc);
 
+/* Same with the PCM in any of the reference's `Sample` formats (src/audio/audio_types.rs:59-137), host byte
+ * order, decoded inside the kernel as `v as f32 / T::MAX as f32`: pcm [S][pcm_stride] of int8 / int16 /
+ * int32 / float.  Halves (int16) the bytes the path reads from HBM. */
+int rp_mfcc_batch_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                      int K, float *mfcc);
+
 /* A wakeword reference resident on the device: T templates [len_t][K] (already
  * mean-normalised, as stored in a .rpw: src/wakewords/wakeword_ref.rs:12-20) given
  * as HOST arrays; avg may be NULL. */
@@ -234,6 +240,11 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
 int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, const rp_templates *t,
                     const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det,
                     float *scores, float *agg);
+
+/* rp_batch_detect with the PCM in any sample format (see rp_mfcc_batch_fmt). */
+int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                        const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
+                        int max_det, float *scores, float *agg);
 
 /* A wakeword model (src/wakewords/wakeword_model.rs:11-18) resident on the device.  weights are
  * HOST arrays W_l [dims[l+1]][dims[l]] (candle Linear: x.W^T + b), biases b_l [dims[l+1]]; 1..3 layers. */

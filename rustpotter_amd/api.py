@@ -96,7 +96,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version",
@@ -154,6 +154,8 @@ def load_library():
     L.rp_mfcc_num_frames.argtypes = [C.c_size_t]
     L.rp_mfcc_num_frames.restype = C.c_size_t
     L.rp_mfcc_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
+    L.rp_mfcc_batch_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
+    L.rp_batch_detect_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
     L.rp_templates_new.argtypes = [vp, C.c_int, C.c_int, ip, fp, C.c_int, fp, C.POINTER(vp)]
     L.rp_templates_free.argtypes = [vp]
     L.rp_templates_max_len.argtypes = [vp]
@@ -442,15 +444,19 @@ class BatchContext:
 
     # --- numpy convenience (host_pointers=True)
     def mfcc(self, pcm, K):
+        """pcm: float32, or int8/int16/int32 samples decoded on the device like the reference's `Sample` types."""
         import numpy as np
         assert self.host
-        pcm = np.ascontiguousarray(pcm, np.float32)
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
         if pcm.ndim == 1:
             pcm = pcm[None, :]
         S, N = pcm.shape
         nf = mfcc_num_frames(N)
         out = np.empty((S, nf, K), np.float32)
-        if self._L.rp_mfcc_batch(self._h, pcm.ctypes.data, S, N, N, K, out.ctypes.data) < 0:
+        if self._L.rp_mfcc_batch_fmt(self._h, pcm.ctypes.data, fmt, S, N, N, K, out.ctypes.data) < 0:
             raise _err()
         return out
 
@@ -496,7 +502,10 @@ class BatchContext:
         """Whole path for S streams in one call (numpy in / out)."""
         import numpy as np
         assert self.host
-        pcm = np.ascontiguousarray(pcm, np.float32)
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
         if pcm.ndim == 1:
             pcm = pcm[None, :]
         S, N = pcm.shape
@@ -508,9 +517,9 @@ class BatchContext:
         scores = np.empty((S, n_win, templates.T), np.float32) if want_scores else None
         agg = np.empty((S, n_win), np.float32) if want_scores else None
         c = detector_config._c()
-        r = self._L.rp_batch_detect(self._h, pcm.ctypes.data, S, N, N, templates._h, C.byref(c), det.ctypes.data,
-                                    n_det.ctypes.data, max_det, None if scores is None else scores.ctypes.data,
-                                    None if agg is None else agg.ctypes.data)
+        r = self._L.rp_batch_detect_fmt(self._h, pcm.ctypes.data, fmt, S, N, N, templates._h, C.byref(c), det.ctypes.data,
+                                        n_det.ctypes.data, max_det, None if scores is None else scores.ctypes.data,
+                                        None if agg is None else agg.ctypes.data)
         if r < 0:
             raise _err()
         return (det, n_det, scores, agg) if want_scores else (det, n_det)

@@ -174,25 +174,33 @@ struct Staged {  // host<->device staging for RP_CTX_HOST_POINTERS
 };
 }  // namespace
 
-int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, int K, float *mfcc) {
+static size_t sample_bytes(rp_sample_format f) { return f == RP_SAMPLE_I8 ? 1 : f == RP_SAMPLE_I16 ? 2 : 4; }
+
+int rp_mfcc_batch_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                      int K, float *mfcc) {
     return guarded([&]() -> int {
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
         const MfccTablesDev *tb = c->tables_for(K);
         if (!tb) return -1;
         const size_t nf = rp_mfcc_num_frames(n_samples);
         Staged sg(c);
-        const float *dp = static_cast<const float *>(sg.in(pcm, S * pcm_stride * sizeof(float), c->stage_in));
+        const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
         float *dm = static_cast<float *>(sg.out(mfcc, S * nf * K * sizeof(float), c->stage_out));
         if ((S && nf) && (!dp || !dm)) return -1;
         c->time_begin(kKernelMfcc);
-        bool ok = hip_ok(launch_mfcc(c->stream, *tb, dp, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
+        bool ok = hip_ok(launch_mfcc_fmt(c->stream, *tb, dp, (int)fmt, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
         c->time_end();
         if (!ok) return -1;
         if (!sg.back(mfcc, dm, S * nf * K * sizeof(float)) || !sg.finish()) return -1;
         return 0;
     });
+}
+
+int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, int K, float *mfcc) {
+    return rp_mfcc_batch_fmt(ctx, pcm, RP_SAMPLE_F32, S, n_samples, pcm_stride, K, mfcc);
 }
 
 int rp_templates_new(rp_ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len, const float *avg,
@@ -285,6 +293,12 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
 int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, const rp_templates *t,
                     const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det,
                     float *scores, float *agg) {
+    return rp_batch_detect_fmt(ctx, pcm, RP_SAMPLE_F32, S, n_samples, pcm_stride, t, config, det, n_det, max_det, scores, agg);
+}
+
+int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                        const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
+                        int max_det, float *scores, float *agg) {
     return guarded([&]() -> int {
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
@@ -298,7 +312,8 @@ int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, s
         const size_t rows = S * n_win;
         const bool do_avg = td.has_avg && config->avg_threshold != 0.f;  // wakeword_comp.rs:85
         Staged sg(c);
-        const float *dp = static_cast<const float *>(sg.in(pcm, S * pcm_stride * sizeof(float), c->stage_in));
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
         BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
         int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
         // caller-provided score arrays are used directly when they are device pointers
@@ -311,7 +326,7 @@ int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, s
         if (S && (!dp || !dd || !dn)) return -1;
         float *dm = c->ws_mfcc.as<float>();
         c->time_begin(kKernelMfcc);
-        bool ok = hip_ok(launch_mfcc(c->stream, *tb, dp, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
+        bool ok = hip_ok(launch_mfcc_fmt(c->stream, *tb, dp, (int)fmt, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
         c->time_end();
         if (!ok) return -1;
         c->time_begin(kKernelDtw);

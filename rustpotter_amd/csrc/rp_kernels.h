@@ -65,6 +65,10 @@ struct BatchDetection {  // == rp_batch_detection
 hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
                        size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc);
 
+// pcm in one of the reference's sample formats (rp_sample_format: 0 i8, 1 i16, 2 i32, 3 f32), decoded in the kernel
+hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *pcm, int fmt, size_t S, size_t n_samples,
+                           size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc);
+
 // scores [S][n_win][T]; avg [S][n_win] or nullptr.  mfcc rows have `frame_pitch` frames per stream.
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,

@@ -139,10 +139,39 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.
-template <bool VEC4, int K1T>
+// Input sample types of the reference's `Sample` trait (src/audio/audio_types.rs:98-137): integers are
+// converted as `v as f32 / T::MAX as f32` (an IEEE division, not a multiply by the reciprocal).
+template <class T> struct SampleIn;
+template <> struct SampleIn<float> {
+    static __device__ __forceinline__ float cvt(float v) { return v; }
+    static __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+};
+template <> struct SampleIn<int16_t> {
+    static __device__ __forceinline__ float cvt(int16_t v) { return (float)v / 32767.f; }
+    static __device__ __forceinline__ float4 load4(const int16_t *p) {
+        const short4 s = *reinterpret_cast<const short4 *>(p);
+        return make_float4(cvt(s.x), cvt(s.y), cvt(s.z), cvt(s.w));
+    }
+};
+template <> struct SampleIn<int8_t> {
+    static __device__ __forceinline__ float cvt(int8_t v) { return (float)v / 127.f; }
+    static __device__ __forceinline__ float4 load4(const int8_t *p) {
+        const char4 s = *reinterpret_cast<const char4 *>(p);
+        return make_float4(cvt((int8_t)s.x), cvt((int8_t)s.y), cvt((int8_t)s.z), cvt((int8_t)s.w));
+    }
+};
+template <> struct SampleIn<int32_t> {
+    static __device__ __forceinline__ float cvt(int32_t v) { return (float)v / 2147483648.f; }  // i32::MAX as f32 == 2^31
+    static __device__ __forceinline__ float4 load4(const int32_t *p) {
+        const int4 s = *reinterpret_cast<const int4 *>(p);
+        return make_float4(cvt(s.x), cvt(s.y), cvt(s.z), cvt(s.w));
+    }
+};
+
+// K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.  TIN: input sample type.
+template <bool VEC4, int K1T, class TIN>
 __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
-    const float *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
+    const TIN *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
     size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1rt, const float *__restrict__ g_ham,
     const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
     const float *__restrict__ g_dct, float *__restrict__ out) {
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     for (size_t wt = (size_t)blockIdx.x * kMfccWaves + wave; wt < total_tiles; wt += wave_stride) {
         const size_t s = wt / tiles_per_stream;
         const size_t j0 = first_frame + (wt - s * tiles_per_stream) * kMfccFramesPerWave;
-        const float *x = pcm + s * pcm_stride;
+        const TIN *x = pcm + s * pcm_stride;
         // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift.
         // All loads are issued unconditionally (clamped index) before the first use, so the wave
         // pays one memory round trip per tile instead of one per load.
@@ -209,8 +238,8 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
                 const int q = it * 64 + lane;            // float4 index inside the 960-sample tile
                 size_t g = base + 4 * (size_t)(q < 240 ? q : 239);
                 g = g + 3 <= last ? g : (last - 3) & ~(size_t)3;
-                cur[it] = *reinterpret_cast<const float4 *>(x + g);
-                prv[it] = x[g - 1];
+                cur[it] = SampleIn<TIN>::load4(x + g);
+                prv[it] = SampleIn<TIN>::cvt(x[g - 1]);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -229,8 +258,8 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
             for (int it = 0; it < kMfccStage / 64; ++it) {
                 size_t g = base + it * 64 + lane;
                 g = g <= last ? g : last;
-                cur[it] = x[g];
-                prv[it] = x[g - 1];
+                cur[it] = SampleIn<TIN>::cvt(x[g]);
+                prv[it] = SampleIn<TIN>::cvt(x[g - 1]);
             }
 #pragma unroll
             for (int it = 0; it < kMfccStage / 64; ++it) {
@@ -319,16 +348,17 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     }
 }
 
-hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
-                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+template <class TIN>
+static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const TIN *pcm, size_t S, size_t n_samples,
+                                size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
     if (S == 0 || n_frames == 0) return hipSuccess;
     const size_t tiles = (n_frames + kMfccFramesPerWave - 1) / kMfccFramesPerWave;
     const size_t total = tiles * S;
     if (tiles > 0xffffffffULL) return hipErrorInvalidValue;
     const size_t lds = mfcc_lds_bytes(tb.K1);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    // 16-byte loads need 16-byte aligned rows (and at least one full float4 before the last sample)
-    const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % 16 == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
+    // 4-sample vector loads need rows aligned to 4 samples (and at least one full vector before the last sample)
+    const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
     // persistent grid: 3 workgroups of 4 waves per CU x 2 rounds, fewer for small problems
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
     if (blocks > 1536) blocks = 1536;
@@ -336,12 +366,12 @@ hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm
     do {                                                                                                                   \
         static bool attr_done = false;                                                                                     \
         if (!attr_done) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<V, KT>),                          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<V, KT, TIN>),                     \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
             if (e != hipSuccess) return e;                                                                                 \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
-        hipLaunchKernelGGL((mfcc_kernel<V, KT>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples,      \
+        hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, \
                            pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
                            tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc);                                                       \
     } while (0)
@@ -351,6 +381,23 @@ hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm
     else RP_MFCC_LAUNCH(false, 0);
 #undef RP_MFCC_LAUNCH
     return hipGetLastError();
+}
+
+hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
+                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+    return launch_mfcc_t<float>(st, tb, pcm, S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+}
+
+// fmt: 0 i8, 1 i16, 2 i32, 3 f32 (rp_sample_format); samples in host byte order
+hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *pcm, int fmt, size_t S, size_t n_samples,
+                           size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+    switch (fmt) {
+    case 0: return launch_mfcc_t<int8_t>(st, tb, static_cast<const int8_t *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    case 1: return launch_mfcc_t<int16_t>(st, tb, static_cast<const int16_t *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    case 2: return launch_mfcc_t<int32_t>(st, tb, static_cast<const int32_t *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    case 3: return launch_mfcc_t<float>(st, tb, static_cast<const float *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    }
+    return hipErrorInvalidValue;
 }
 
 // -------------------------------------------------------------------------- DTW

@@ -86,6 +86,21 @@ def test_mfcc_fixture_wavs(ctx):
         assert mfcc_close(got, ref)
 
 
+@pytest.mark.parametrize("dtype,scale", [(np.int16, 32767.0), (np.int8, 127.0), (np.int32, 2147483648.0)])
+def test_mfcc_integer_samples_decoded_on_device(ctx, dtype, scale):
+    """`v as f32 / T::MAX as f32` (src/audio/audio_types.rs:98-127) inside the kernel == decoding first."""
+    info = np.iinfo(dtype)
+    rng = np.random.default_rng(4)
+    for n in (480 * 21, 480 * 21 + 2):  # aligned rows -> vector loads; odd row length -> scalar loads
+        raw = rng.integers(info.min, info.max, size=(3, n), dtype=dtype, endpoint=True)
+        raw[0, :5] = [info.min, info.max, 0, -1, 1]
+        got = ctx.mfcc(raw, 5)
+        ref = ctx.mfcc(raw.astype(np.float32) / np.float32(scale), 5)
+        assert np.array_equal(got, ref)
+    pcm, _ = rpw_py.read_wav_i16(os.path.join(G, "alexa.wav"))
+    assert mfcc_close(ctx.mfcc(pcm, 5)[0], orc.mfcc_stream(simstream.i16_to_f32(pcm), 5))
+
+
 def test_mfcc_edge_sizes(ctx):
     assert ctx.mfcc(np.zeros((2, 479), np.float32), 5).shape == (2, 0, 5)      # no full chunk
     assert ctx.mfcc(np.zeros((2, 480), np.float32), 5).shape == (2, 0, 5)      # one chunk: extractor only fills
@@ -323,7 +338,7 @@ def test_batch_scan_matches_streaming_state_machine(ra, ctx):
         w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
         templates = list(w["samples_features"].values())
         s = simstream.simulation_stream_i16()
-        mf = ctx.mfcc(simstream.i16_to_f32(s), 5)
+        mf = ctx.mfcc(s, 5)  # i16 samples decoded on the device
         tm = ra.Templates(ctx, templates, avg=w["avg_features"])
         cfg = _make_config(ra, e).detector
         with_avg = e["avg_threshold"] != 0.0

@@ -193,6 +193,19 @@ int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, siz
 int rp_mfcc_batch_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                       int K, float *mfcc);
 
+/* The audio front-end of Rustpotter::process_audio for whole streams (src/detector.rs:358-371): sample
+ * decode, GainNormalizerFilter (src/audio/gain_normalizer_filter.rs:14-55: per 480-sample chunk, gain =
+ * round(10*sqrt(ref)/sqrt(mean of the last `window_size` chunk RMS values))/10, clamped, samples clamped to
+ * +-1) and BandPassFilter (src/audio/band_pass_filter.rs:19-55: biquad with state carried along the
+ * stream).  Neither filter depends on detections (reset() keeps them), so the result is what the
+ * detector would have fed its MFCC extractor.  rms_level_ref: what on_wakeword_change sets (the largest
+ * wakeword rms_level) -- ignored when filters->gain_normalizer.has_gain_ref; window_size: max_mfcc_frames / 3
+ * (src/detector.rs:337).  pcm_out [S][out_stride] f32; rms / gains [S][n_samples/480] (either may be NULL):
+ * get_rms_level() and get_gain() of every chunk. */
+int rp_frontend_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                      const rp_filters_config *filters, float rms_level_ref, size_t window_size, float *pcm_out,
+                      size_t out_stride, float *rms, float *gains);
+
 /* A wakeword reference resident on the device: T templates [len_t][K] (already
  * mean-normalised, as stored in a .rpw: src/wakewords/wakeword_ref.rs:12-20) given
  * as HOST arrays; avg may be NULL. */

@@ -624,6 +624,34 @@ static void bandpass_filter(orc_bandpass *b, float *signal, int n) {
     }
 }
 
+/* The audio front-end of process_audio over a whole stream (src/detector.rs:358-371): rms level of the raw
+ * chunk, gain normaliser, band-pass; out [N], rms / gains [N/480].  window_size as on_wakeword_change sets it. */
+void orc_frontend_stream(const float *pcm, long N, int gain_on, float gain_ref_fixed /*NaN = not fixed*/, float min_gain,
+                         float max_gain, float rms_level_ref, int window_size, int bp_on, float low_cutoff, float high_cutoff,
+                         float *out, float *rms, float *gains) {
+    orc_gain g; memset(&g, 0, sizeof(g));
+    g.enabled = gain_on; g.min_gain = min_gain; g.max_gain = max_gain;
+    g.fixed = !isnan(gain_ref_fixed);
+    g.rms_level_ref = g.fixed ? gain_ref_fixed : rms_level_ref;
+    g.rms_level_sqrt = sqrtf(g.rms_level_ref);
+    g.window_size = window_size != 0 ? window_size : 1;
+    orc_bandpass b; memset(&b, 0, sizeof(b));
+    b.enabled = bp_on;
+    if (bp_on) bandpass_init(&b, (float)ORC_SAMPLE_RATE, low_cutoff, high_cutoff);
+    long nch = N / ORC_FRAME;
+    memcpy(out, pcm, sizeof(float) * (size_t)N);
+    for (long c = 0; c < nch; ++c) {
+        float *buf = out + c * ORC_FRAME;
+        float r = orc_rms_level(buf, ORC_FRAME);
+        float gain = 1.f;
+        if (gain_on) gain = gain_filter(&g, buf, ORC_FRAME, r);
+        if (bp_on) bandpass_filter(&b, buf, ORC_FRAME);
+        if (rms) rms[c] = r;
+        if (gains) gains[c] = gain;
+    }
+    free(g.win);
+}
+
 /* ----------------------------------------------------------------- detector */
 /* Mirrors struct Rustpotter, src/detector.rs:34-92 (16 kHz mono input only: the
  * rubato resampler, src/audio/encoder.rs:63-102, is out of scope). */

@@ -74,6 +74,8 @@ def lib():
     L.orc_calc_inverse_similarity.argtypes = [C.c_float, C.c_float, C.c_float]
     L.orc_rms_level.restype = C.c_float
     L.orc_rms_level.argtypes = [fp, C.c_int]
+    L.orc_frontend_stream.argtypes = [fp, C.c_long, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                      C.c_float, C.c_float, fp, fp, fp]
     L.orc_detector_new.restype = C.c_void_p
     L.orc_detector_new.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
@@ -207,6 +209,20 @@ def mlp_forward(x, weights, biases, bf16_layer1=False):
 
 def calc_inverse_similarity(n1, n2, ref):
     return float(lib().orc_calc_inverse_similarity(n1, n2, ref))
+
+
+def frontend_stream(pcm, gain_normalizer=False, gain_ref=None, min_gain=0.1, max_gain=1.0, rms_level_ref=float("nan"),
+                    window_size=1, band_pass=False, low_cutoff=80.0, high_cutoff=400.0):
+    """process_audio's front-end over a whole stream -> (filtered pcm, rms per chunk, gain per chunk)."""
+    pcm = _c32(pcm)
+    n = len(pcm)
+    out = np.empty(n, np.float32)
+    rms = np.empty(n // 480, np.float32)
+    gains = np.empty(n // 480, np.float32)
+    lib().orc_frontend_stream(_f(pcm), n, int(gain_normalizer), float("nan") if gain_ref is None else gain_ref, min_gain,
+                              max_gain, rms_level_ref, window_size, int(band_pass), low_cutoff, high_cutoff, _f(out), _f(rms),
+                              _f(gains))
+    return out, rms, gains
 
 
 def synth_pcm(seed, stream, N):

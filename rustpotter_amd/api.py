@@ -96,7 +96,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version",
@@ -156,6 +156,7 @@ def load_library():
     L.rp_mfcc_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.rp_mfcc_batch_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.rp_batch_detect_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
+    L.rp_frontend_batch.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_FiltersCfg), C.c_float, C.c_size_t, vp, C.c_size_t, vp, vp]
     L.rp_templates_new.argtypes = [vp, C.c_int, C.c_int, ip, fp, C.c_int, fp, C.POINTER(vp)]
     L.rp_templates_free.argtypes = [vp]
     L.rp_templates_max_len.argtypes = [vp]
@@ -459,6 +460,28 @@ class BatchContext:
         if self._L.rp_mfcc_batch_fmt(self._h, pcm.ctypes.data, fmt, S, N, N, K, out.ctypes.data) < 0:
             raise _err()
         return out
+
+    def frontend(self, pcm, filters_config, rms_level_ref, window_size):
+        """Decode + gain normaliser + band-pass over whole streams -> (pcm f32, rms, gains)."""
+        import numpy as np
+        assert self.host
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        S, N = pcm.shape
+        rc = RustpotterConfig()
+        rc.filters = filters_config
+        f = rc._filters_c()
+        out = np.empty((S, N), np.float32)
+        rms = np.empty((S, N // 480), np.float32)
+        gains = np.empty((S, N // 480), np.float32)
+        if self._L.rp_frontend_batch(self._h, pcm.ctypes.data, fmt, S, N, N, C.byref(f), rms_level_ref, window_size,
+                                     out.ctypes.data, N, rms.ctypes.data, gains.ctypes.data) < 0:
+            raise _err()
+        return out, rms, gains
 
     def dtw_scores(self, mfcc, templates, score_ref=0.22, band_size=5, score_mode=ScoreMode.Max, with_avg=False):
         import numpy as np

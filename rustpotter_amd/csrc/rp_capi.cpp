@@ -1,4 +1,5 @@
 // rp_capi.cpp -- extern "C" surface declared in include/rustpotter_hip.h.
+#include <cmath>
 #include <cstring>
 #include <new>
 
@@ -201,6 +202,55 @@ int rp_mfcc_batch_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t
 
 int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, int K, float *mfcc) {
     return rp_mfcc_batch_fmt(ctx, pcm, RP_SAMPLE_F32, S, n_samples, pcm_stride, K, mfcc);
+}
+
+int rp_frontend_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                      const rp_filters_config *filters, float rms_level_ref, size_t window_size, float *pcm_out,
+                      size_t out_stride, float *rms, float *gains) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (pcm_stride < n_samples || out_stride < n_samples) { set_last_error("stride smaller than n_samples"); return -1; }
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        const rp_gain_normalization_config &g = filters->gain_normalizer;
+        const rp_band_pass_config &b = filters->band_pass;
+        if (g.enabled && g.has_gain_ref) rms_level_ref = g.gain_ref;  // fixed_rms_level, gain_normalizer_filter.rs:56-66
+        if (window_size == 0) window_size = 1;                           // set_rms_level_ref :47
+        if (window_size > 1u << 20) { set_last_error("window_size too large"); return -1; }
+        // BandPassFilter::new, band_pass_filter.rs:31-55 (f32, sample rate 16 kHz)
+        float a0 = 0, a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+        if (b.enabled) {
+            const float kPi = 3.14159274101257324f, sample_rate = 16000.f;
+            const float omega_low = 2.0f * kPi * b.low_cutoff / sample_rate, omega_high = 2.0f * kPi * b.high_cutoff / sample_rate;
+            const float cos_low = std::cos(omega_low), cos_high = std::cos(omega_high);
+            const float alpha_low = std::sin(omega_low) / 2.0f, alpha_high = std::sin(omega_high) / 2.0f;
+            a0 = 1.0f / (1.0f + alpha_high - alpha_low);
+            a1 = -2.0f * cos_low * a0; a2 = (1.0f - alpha_high - alpha_low) * a0;
+            b1 = -2.0f * cos_high * a0; b2 = (1.0f - alpha_high + alpha_low) * a0;
+        }
+        const size_t n_chunks = n_samples / 480;
+        Staged sg(c);
+        const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
+        float *dout = static_cast<float *>(sg.out(pcm_out, S * out_stride * sizeof(float), c->stage_out));
+        if (S && (!dp || !dout)) return -1;
+        if (!c->ws_rms.reserve(S * n_chunks * 4 + 16) || !c->ws_gain.reserve(S * n_chunks * 4 + 16) ||
+            !c->ws_ring.reserve(S * window_size * 4 + 16)) return -1;
+        if (!hip_ok(launch_frontend(c->stream, dp, (int)fmt, S, n_samples, pcm_stride, g.enabled ? 1 : 0, rms_level_ref, g.min_gain,
+                                    g.max_gain, (int)window_size, b.enabled ? 1 : 0, a0, a1, a2, b1, b2, c->ws_ring.as<float>(),
+                                    c->ws_rms.as<float>(), c->ws_gain.as<float>(), dout, out_stride), "front-end kernels")) return -1;
+        auto copy_out = [&](float *dst, const float *src_dev, bool valid) {
+            if (!dst) return true;
+            if (!valid) {  // gain filter off: every chunk has gain 1
+                std::vector<float> ones(S * n_chunks, 1.f);
+                return hip_ok(hipMemcpyAsync(dst, ones.data(), ones.size() * 4, sg.host ? hipMemcpyHostToHost : hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync") &&
+                       hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+            }
+            return hip_ok(hipMemcpyAsync(dst, src_dev, S * n_chunks * 4, sg.host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
+        };
+        if (!copy_out(rms, c->ws_rms.as<float>(), true) || !copy_out(gains, c->ws_gain.as<float>(), g.enabled)) return -1;
+        if (!sg.back(pcm_out, dout, S * out_stride * sizeof(float))) return -1;
+        return hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize") ? 0 : -1;
+    });
 }
 
 int rp_templates_new(rp_ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len, const float *avg,

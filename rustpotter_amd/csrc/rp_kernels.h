@@ -85,6 +85,13 @@ hipError_t launch_vad_value(hipStream_t st, const float *mfcc, size_t n_frames_t
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                        size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det);
 
+// Decode + GainNormalizerFilter + BandPassFilter over whole streams.  ring [S][window_size], rms / gains
+// [S][n_samples/480] are device workspaces; biquad coefficients as BandPassFilter::new computes them.
+hipError_t launch_frontend(hipStream_t st, const void *pcm, int fmt, size_t S, size_t n_samples, size_t pcm_stride, int gain_on,
+                           float rms_level_ref, float min_gain, float max_gain, int window_size, int band_pass, float a0,
+                           float a1, float a2, float b1, float b2, float *ring, float *rms, float *gains, float *out,
+                           size_t out_stride);
+
 hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
                         size_t pcm_stride, float *pcm);
 

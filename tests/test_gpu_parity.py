@@ -413,6 +413,57 @@ def test_batch_vad_gate_matches_oracle(ra, ctx, vad):
         assert abs(det[0][j]["score"] - r["score"]) <= 1e-5 * r["score"]
 
 
+@pytest.mark.parametrize("case", ["band_pass", "gain_normalizer", "gain_and_band_pass", "ignore_alexa_filters"])
+def test_batch_frontend_goldens(ra, ctx, case):
+    """tests/detector.rs:100-162 through the BATCHED path: i16 stream -> rp_frontend_batch (decode + gain
+    normaliser + band-pass on the device) -> rp_batch_detect; filtered audio bit-exact against the
+    oracle's front-end, detections as the reference asserts."""
+    e = EXP["simulation"][case]
+    w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+    templates = list(w["samples_features"].values())
+    s16 = simstream.simulation_stream_i16(*e.get("gains", [1.0, 1.0]))
+    n = (len(s16) // 480) * 480
+    cfg = _make_config(ra, e)
+    max_len = max(len(t) for t in templates)
+    out, rms, gains = ctx.frontend(s16[:n], cfg.filters, w["rms_level"], max_len // 3)
+    ref_out, ref_rms, ref_gains = orc.frontend_stream(simstream.i16_to_f32(s16[:n]), gain_normalizer=e.get("gain_normalizer", False),
+                                                      rms_level_ref=w["rms_level"], window_size=max_len // 3,
+                                                      band_pass=e.get("band_pass", False), low_cutoff=e.get("low_cutoff", 80.0),
+                                                      high_cutoff=e.get("high_cutoff", 400.0))
+    assert np.array_equal(rms[0], ref_rms) and np.array_equal(gains[0], ref_gains)
+    assert np.array_equal(out[0], ref_out)  # integer decode, gain, clamp and biquad are all bit-exact
+    tm = ra.Templates(ctx, templates, avg=w["avg_features"])
+    det, n_det = ctx.batch_detect(out, tm, cfg.detector)
+    ref = _oracle_detections(e, s16)
+    assert n_det[0] == len(ref) == len(e["detections"])
+    for j, ((chunk, r), (_, gscore)) in enumerate(zip(ref, e["detections"])):
+        assert det[0][j]["frame"] // 3 + 1 == chunk and det[0][j]["counter"] == r["counter"]
+        assert abs(det[0][j]["score"] - np.float32(gscore)) <= 1e-5 * gscore
+        # RustpotterDetection::gain = the gain of the chunk in which the best partial was scored
+        assert gains[0][(det[0][j]["window"] + tm.max_len - 1) // 3 + 1] == r["gain"]
+
+
+def test_frontend_many_streams_and_formats(ra, ctx):
+    rng = np.random.default_rng(8)
+    S, N = 70, 480 * 25 + 37
+    raw = (rng.standard_normal((S, N)) * 3000).astype(np.int16)
+    raw[3] = 0  # silent stream: rms 0 -> gain stays 1, window untouched
+    f = ra.FiltersConfig()
+    f.gain_normalizer.enabled, f.gain_normalizer.min_gain, f.gain_normalizer.max_gain = True, 0.2, 3.0
+    f.band_pass.enabled, f.band_pass.low_cutoff, f.band_pass.high_cutoff = True, 120.0, 900.0
+    out, rms, gains = ctx.frontend(raw, f, 0.05, 7)
+    for s in (0, 3, 69):
+        ro, rr, rg = orc.frontend_stream(simstream.i16_to_f32(raw[s]), gain_normalizer=True, min_gain=0.2, max_gain=3.0,
+                                         rms_level_ref=0.05, window_size=7, band_pass=True, low_cutoff=120.0, high_cutoff=900.0)
+        assert np.array_equal(rms[s], rr) and np.array_equal(gains[s], rg) and np.array_equal(out[s], ro)
+    f.gain_normalizer.gain_ref = 0.02  # fixed reference level
+    f.band_pass.enabled = False
+    out, rms, gains = ctx.frontend(raw.astype(np.float32) / np.float32(32767.0), f, float("nan"), 4)
+    ro, rr, rg = orc.frontend_stream(simstream.i16_to_f32(raw[5]), gain_normalizer=True, gain_ref=0.02, min_gain=0.2, max_gain=3.0,
+                                     window_size=4)
+    assert np.array_equal(gains[5], rg) and np.array_equal(out[5], ro)
+
+
 def test_mlp_forward_model_file(ra, ctx):
     m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
     x = np.random.default_rng(0).standard_normal((165, 3120)).astype(np.float32)

@@ -193,6 +193,18 @@ int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, siz
 int rp_mfcc_batch_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                       int K, float *mfcc);
 
+/* WakewordRef::new_from_sample_buffers (src/wakewords/comp/wakeword_ref_build.rs:9-41) followed by
+ * WakewordSave::save_to_buffer (src/wakewords/wakeword_file.rs:22-26): builds a wakeword reference from
+ * n 16 kHz wav buffers (PCM 8/16/32-bit or f32; first channel) -- MFCCs from the HIP kernel, whole-matrix
+ * normalisation, DTW-aligned average template, rms level -- and returns it serialised as .rpw (CBOR) bytes
+ * in *out_rpw (free with rp_buffer_free).  threshold / avg_threshold: NULL = None.  rms_from_files != 0
+ * takes the MEDIAN sample level like new_from_sample_files (:80-81) instead of the maximum.
+ * The bytes can be written to a file or handed to rp_add_wakeword_from_buffer. */
+int rp_wakeword_ref_build(rp_ctx *ctx, const char *name, const float *threshold, const float *avg_threshold, size_t n,
+                          const char *const *sample_names, const uint8_t *const *wav_buffers, const size_t *wav_lens,
+                          uint16_t mfcc_size, int rms_from_files, uint8_t **out_rpw, size_t *out_len);
+void rp_buffer_free(uint8_t *buffer);
+
 /* The audio front-end of Rustpotter::process_audio for whole streams (src/detector.rs:358-371): sample
  * decode, GainNormalizerFilter (src/audio/gain_normalizer_filter.rs:14-55: per 480-sample chunk, gain =
  * round(10*sqrt(ref)/sqrt(mean of the last `window_size` chunk RMS values))/10, clamped, samples clamped to

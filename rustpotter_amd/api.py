@@ -96,7 +96,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version",
@@ -157,6 +157,9 @@ def load_library():
     L.rp_mfcc_batch_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.rp_batch_detect_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
     L.rp_frontend_batch.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_FiltersCfg), C.c_float, C.c_size_t, vp, C.c_size_t, vp, vp]
+    L.rp_wakeword_ref_build.argtypes = [vp, C.c_char_p, fp, fp, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                        C.POINTER(C.c_size_t), C.c_uint16, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.rp_buffer_free.argtypes = [vp]
     L.rp_templates_new.argtypes = [vp, C.c_int, C.c_int, ip, fp, C.c_int, fp, C.POINTER(vp)]
     L.rp_templates_free.argtypes = [vp]
     L.rp_templates_max_len.argtypes = [vp]
@@ -460,6 +463,26 @@ class BatchContext:
         if self._L.rp_mfcc_batch_fmt(self._h, pcm.ctypes.data, fmt, S, N, N, K, out.ctypes.data) < 0:
             raise _err()
         return out
+
+    def build_wakeword_ref(self, name, samples, mfcc_size, threshold=None, avg_threshold=None, from_files=True):
+        """WakewordRef::new_from_sample_files / _buffers + save_to_buffer: samples = ordered {name: wav bytes};
+        returns the .rpw bytes."""
+        names = [k.encode() for k in samples]
+        bufs = [bytes(v) for v in samples.values()]
+        n = len(names)
+        c_names = (C.c_char_p * n)(*names)
+        c_bufs = (C.c_char_p * n)(*bufs)
+        c_lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+        thr = None if threshold is None else C.byref(C.c_float(threshold))
+        athr = None if avg_threshold is None else C.byref(C.c_float(avg_threshold))
+        out, out_len = C.c_void_p(), C.c_size_t()
+        if self._L.rp_wakeword_ref_build(self._h, name.encode(), C.cast(thr, C.POINTER(C.c_float)) if thr else None,
+                                         C.cast(athr, C.POINTER(C.c_float)) if athr else None, n, c_names, c_bufs, c_lens,
+                                         mfcc_size, 1 if from_files else 0, C.byref(out), C.byref(out_len)) < 0:
+            raise _err()
+        data = C.string_at(out, out_len.value)
+        self._L.rp_buffer_free(out)
+        return data
 
     def frontend(self, pcm, filters_config, rms_level_ref, window_size):
         """Decode + gain normaliser + band-pass over whole streams -> (pcm f32, rms, gains)."""

@@ -1,5 +1,6 @@
 // rp_capi.cpp -- extern "C" surface declared in include/rustpotter_hip.h.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -203,6 +204,24 @@ int rp_mfcc_batch_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t
 int rp_mfcc_batch(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, int K, float *mfcc) {
     return rp_mfcc_batch_fmt(ctx, pcm, RP_SAMPLE_F32, S, n_samples, pcm_stride, K, mfcc);
 }
+
+int rp_wakeword_ref_build(rp_ctx *ctx, const char *name, const float *threshold, const float *avg_threshold, size_t n,
+                          const char *const *sample_names, const uint8_t *const *wav_buffers, const size_t *wav_lens,
+                          uint16_t mfcc_size, int rms_from_files, uint8_t **out_rpw, size_t *out_len) {
+    return guarded([&]() -> int {
+        *out_rpw = nullptr; *out_len = 0;
+        WakewordRefData r;
+        if (!build_wakeword_ref(ctx->impl.get(), name, threshold, avg_threshold, n, sample_names, wav_buffers, wav_lens,
+                                (int)mfcc_size, rms_from_files != 0, &r)) return -1;
+        std::vector<uint8_t> bytes = serialize_wakeword_ref(r);
+        uint8_t *p = static_cast<uint8_t *>(std::malloc(bytes.size()));
+        if (!p) { set_last_error("out of host memory"); return -1; }
+        std::memcpy(p, bytes.data(), bytes.size());
+        *out_rpw = p; *out_len = bytes.size();
+        return 0;
+    });
+}
+void rp_buffer_free(uint8_t *buffer) { std::free(buffer); }
 
 int rp_frontend_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                       const rp_filters_config *filters, float rms_level_ref, size_t window_size, float *pcm_out,

@@ -49,6 +49,14 @@ bool parse_rpw(const uint8_t *buf, size_t len, RpwKind *kind, WakewordRefData *r
                std::string *err);
 
 // ---------------------------------------------------------------- device context
+struct Ctx;
+// builder / writer (rp_builder.cpp)
+bool compute_wav_mfccs(Ctx *ctx, const uint8_t *buf, size_t len, int K, std::vector<float> *mfcc, int *frames, float *rms_level);
+bool build_wakeword_ref(Ctx *ctx, const std::string &name, const float *threshold, const float *avg_threshold, size_t n,
+                        const char *const *sample_names, const uint8_t *const *wavs, const size_t *wav_lens, int mfcc_size,
+                        bool rms_median, WakewordRefData *out);
+std::vector<uint8_t> serialize_wakeword_ref(const WakewordRefData &r);
+
 void set_last_error(const std::string &msg);
 bool hip_ok(hipError_t e, const char *what);
 

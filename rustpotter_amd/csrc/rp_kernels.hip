@@ -1044,13 +1044,20 @@ hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const
 // its own 128-byte lines from L1, HBM traffic stays one read + one write of the PCM).
 template <class TIN>
 __global__ __launch_bounds__(256) void chunk_rms_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_chunks, size_t pcm_stride,
-                                                        float *__restrict__ rms) {
+                                                        int vec4, float *__restrict__ rms) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= S * n_chunks) return;
     const size_t s = i / n_chunks, c = i - s * n_chunks;
     const TIN *x = pcm + s * pcm_stride + c * kFrame;
-    float sum_squared = 0.0f;  // GainNormalizerFilter::get_rms_level, gain_normalizer_filter.rs:49-55
-    for (int k = 0; k < kFrame; ++k) { const float v = SampleIn<TIN>::cvt(x[k]); sum_squared += v * v; }
+    float sum_squared = 0.0f;  // GainNormalizerFilter::get_rms_level, gain_normalizer_filter.rs:49-55 (sequential sum)
+    if (vec4) {
+        for (int k = 0; k < kFrame; k += 4) {
+            const float4 v = SampleIn<TIN>::load4(x + k);
+            sum_squared += v.x * v.x; sum_squared += v.y * v.y; sum_squared += v.z * v.z; sum_squared += v.w * v.w;
+        }
+    } else {
+        for (int k = 0; k < kFrame; ++k) { const float v = SampleIn<TIN>::cvt(x[k]); sum_squared += v * v; }
+    }
     rms[i] = sqrtf(sum_squared / (float)kFrame);
 }
 
@@ -1087,7 +1094,7 @@ struct BiquadCoef { float a0, a1, a2, b1, b2; };
 template <class TIN>
 __global__ __launch_bounds__(64) void apply_filters_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_samples, size_t n_chunks,
                                                            size_t pcm_stride, const float *__restrict__ gains, int band_pass,
-                                                           BiquadCoef q, float *__restrict__ out, size_t out_stride) {
+                                                           BiquadCoef q, int vec4, float *__restrict__ out, size_t out_stride) {
     const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= S) return;
     const TIN *x = pcm + s * pcm_stride;
@@ -1095,15 +1102,23 @@ __global__ __launch_bounds__(64) void apply_filters_kernel(const TIN *__restrict
     float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
     for (size_t c = 0; c < n_chunks; ++c) {
         const float g = gains ? gains[s * n_chunks + c] : 1.f;
-        for (int k = 0; k < kFrame; ++k) {
-            float v = SampleIn<TIN>::cvt(x[c * kFrame + k]);
+        auto one = [&](float v) {
             if (g != 1.f) { v = v * g; v = v < -1.f ? -1.f : v; v = v > 1.f ? 1.f : v; }
             if (band_pass) {
                 const float o = q.a0 * v + q.a1 * x1 + q.a2 * x2 - q.b1 * y1 - q.b2 * y2;
                 x2 = x1; x1 = v; y2 = y1; y1 = o;
                 v = o;
             }
-            y[c * kFrame + k] = v;
+            return v;
+        };
+        if (vec4) {  // 4 samples per load/store: the lane-per-stream pattern is bound by line look-ups per instruction
+            for (int k = 0; k < kFrame; k += 4) {
+                float4 v = SampleIn<TIN>::load4(x + c * kFrame + k);
+                v.x = one(v.x); v.y = one(v.y); v.z = one(v.z); v.w = one(v.w);
+                *reinterpret_cast<float4 *>(y + c * kFrame + k) = v;
+            }
+        } else {
+            for (int k = 0; k < kFrame; ++k) y[c * kFrame + k] = one(SampleIn<TIN>::cvt(x[c * kFrame + k]));
         }
     }
     for (size_t k = n_chunks * kFrame; k < n_samples; ++k) y[k] = SampleIn<TIN>::cvt(x[k]);  // tail shorter than a chunk: never framed
@@ -1115,16 +1130,18 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
                                     BiquadCoef q, float *ring, float *rms, float *gains, float *out, size_t out_stride) {
     const size_t n_chunks = n_samples / kFrame;
     if (S == 0) return hipSuccess;
+    const int vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) &&
+                     (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (out_stride % 4 == 0);
     if (n_chunks) {
         const size_t n = S * n_chunks;
         if ((n + 255) / 256 > 0x7fffffffULL) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(chunk_rms_kernel<TIN>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pcm, S, n_chunks, pcm_stride, rms);
+        hipLaunchKernelGGL(chunk_rms_kernel<TIN>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pcm, S, n_chunks, pcm_stride, vec4, rms);
         if (gain_on)
             hipLaunchKernelGGL(gain_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, rms, S, n_chunks, rms_level_ref, min_gain,
                                max_gain, window_size, ring, gains);
     }
     hipLaunchKernelGGL(apply_filters_kernel<TIN>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, pcm, S, n_samples, n_chunks,
-                       pcm_stride, gain_on ? gains : nullptr, band_pass, q, out, out_stride);
+                       pcm_stride, gain_on ? gains : nullptr, band_pass, q, vec4, out, out_stride);
     return hipGetLastError();
 }
 

@@ -464,6 +464,51 @@ def test_frontend_many_streams_and_formats(ra, ctx):
     assert np.array_equal(gains[5], rg) and np.array_equal(out[5], ro)
 
 
+@pytest.mark.parametrize("rpw,wavs", [("oye_casa_g.rpw", ["oye_casa_g_%d.wav" % i for i in range(1, 6)]),
+                                      ("alexa.rpw", ["alexa.wav", "alexa2.wav", "alexa3.wav"])])
+def test_build_wakeword_ref_matches_reference_file(ra, ctx, rpw, wavs, tmp_path):
+    """tests/wakeword.rs:27-54 on the device: WakewordRef::new_from_sample_files(.., 5) + save; the result is
+    compared with the .rpw the reference itself wrote from the same wavs (G1 templates, G3 average, rms level)."""
+    gold = rpw_py.load_rpw(os.path.join(G, rpw))
+    samples = {w: open(os.path.join(G, w), "rb").read() for w in wavs}
+    data = ctx.build_wakeword_ref(gold["name"], samples, 5)
+    path = tmp_path / "built.rpw"
+    path.write_bytes(data)
+    built = rpw_py.load_rpw(str(path))  # the test-side CBOR reader parses what the product wrote
+    assert built["kind"] == "ref" and built["name"] == gold["name"] and built["mfcc_size"] == 5
+    assert built["threshold"] is None and built["avg_threshold"] is None
+    assert np.float32(built["rms_level"]) == np.float32(gold["rms_level"])
+    assert set(built["samples_features"]) == set(gold["samples_features"])
+    for k, ref in gold["samples_features"].items():
+        assert mfcc_close(built["samples_features"][k], ref)
+    # the average follows the DTW path of the reference (same argmin decisions) -> same alignment, tiny numeric drift
+    assert built["avg_features"].shape == gold["avg_features"].shape
+    assert np.abs(built["avg_features"] - gold["avg_features"]).max() <= 2e-5
+    # the product's own reader accepts it and the detector behaves as with the reference's file
+    e = EXP["simulation"]["max"] if rpw.startswith("oye") else EXP["simulation"]["ignore_alexa"]
+    rp = ra.Rustpotter.new(_make_config(ra, e))
+    rp.add_wakeword_from_buffer("w", data)
+    raw = simstream.simulation_stream_i16().astype("<i2").tobytes()
+    dets = [d for d in (rp.process_bytes(raw[i:i + 960]) for i in range(0, len(raw) - 959, 960)) if d is not None]
+    assert len(dets) == len(e["detections"])
+    for d, (gavg, gscore) in zip(dets, e["detections"]):
+        assert abs(d.score - np.float32(gscore)) <= 2e-5 * gscore and abs(d.avg_score - np.float32(gavg)) <= 1e-4 * gavg
+
+
+def test_build_wakeword_ref_errors_and_options(ra, ctx, tmp_path):
+    one = {"a.wav": open(os.path.join(G, "alexa.wav"), "rb").read()}
+    built = ctx.build_wakeword_ref("solo", one, 7, threshold=0.4, avg_threshold=0.1, from_files=False)
+    p = tmp_path / "solo.rpw"
+    p.write_bytes(built)
+    w = rpw_py.load_rpw(str(p))
+    assert w["avg_features"] is None and w["mfcc_size"] == 7 and w["samples_features"]["a.wav"].shape[1] == 7
+    assert abs(w["threshold"] - 0.4) < 1e-7 and abs(w["avg_threshold"] - 0.1) < 1e-7
+    with pytest.raises(ra.RustpotterError, match="Can not create an empty wakeword"):
+        ctx.build_wakeword_ref("none", {}, 5)
+    with pytest.raises(ra.RustpotterError, match="RIFF"):
+        ctx.build_wakeword_ref("bad", {"x.wav": b"not a wav file at all"}, 5)
+
+
 def test_mlp_forward_model_file(ra, ctx):
     m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
     x = np.random.default_rng(0).standard_normal((165, 3120)).astype(np.float32)

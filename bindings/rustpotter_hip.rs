@@ -105,3 +105,36 @@ impl Rustpotter {
     pub fn update_filters_config(&mut self, c: &rp_filters_config) { unsafe { rp_update_filters_config(self.h, c); } }
     pub fn reset(&mut self) { unsafe { rp_reset(self.h) } }
 }
+
+// ---- offline tooling: WakewordRef::new_from_sample_buffers(..).save_to_buffer() on the device -------------
+pub enum rp_ctx {}
+extern "C" {
+    pub fn rp_ctx_new(device: c_int, flags: c_int, out: *mut *mut rp_ctx) -> c_int;
+    pub fn rp_ctx_free(ctx: *mut rp_ctx);
+    pub fn rp_wakeword_ref_build(ctx: *mut rp_ctx, name: *const c_char, threshold: *const f32, avg_threshold: *const f32, n: usize,
+                                 sample_names: *const *const c_char, wav_buffers: *const *const u8, wav_lens: *const usize,
+                                 mfcc_size: u16, rms_from_files: c_int, out_rpw: *mut *mut u8, out_len: *mut usize) -> c_int;
+    pub fn rp_buffer_free(buffer: *mut u8);
+}
+/// `WakewordRefBuildFromBuffers::new_from_sample_buffers` + `WakewordSave::save_to_buffer`
+/// (src/wakewords/comp/wakeword_ref_build.rs:9-41, src/wakewords/wakeword_file.rs:22-26): returns `.rpw` bytes.
+pub fn wakeword_ref_from_sample_buffers(name: &str, threshold: Option<f32>, avg_threshold: Option<f32>,
+                                        samples: &HashMap<String, Vec<u8>>, mfcc_size: u16) -> Result<Vec<u8>, String> {
+    let cname = CString::new(name).map_err(|e| e.to_string())?;
+    let names: Vec<CString> = samples.keys().map(|k| CString::new(k.as_str()).unwrap()).collect();
+    let name_ptrs: Vec<*const c_char> = names.iter().map(|n| n.as_ptr()).collect();
+    let bufs: Vec<*const u8> = samples.values().map(|v| v.as_ptr()).collect();
+    let lens: Vec<usize> = samples.values().map(|v| v.len()).collect();
+    unsafe {
+        let mut ctx = std::ptr::null_mut();
+        if rp_ctx_new(0, 0, &mut ctx) < 0 { return Err(last_error()); }
+        let (mut out, mut out_len) = (std::ptr::null_mut(), 0usize);
+        let r = rp_wakeword_ref_build(ctx, cname.as_ptr(), threshold.as_ref().map_or(std::ptr::null(), |t| t as *const f32),
+                                      avg_threshold.as_ref().map_or(std::ptr::null(), |t| t as *const f32), names.len(),
+                                      name_ptrs.as_ptr(), bufs.as_ptr(), lens.as_ptr(), mfcc_size, 0, &mut out, &mut out_len);
+        let res = if r < 0 { Err(last_error()) } else { Ok(std::slice::from_raw_parts(out, out_len).to_vec()) };
+        if !out.is_null() { rp_buffer_free(out); }
+        rp_ctx_free(ctx);
+        res
+    }
+}

@@ -956,11 +956,33 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
                                                   size_t n_frames, ScanConfig cfg, BatchDetection *__restrict__ det,
                                                   int32_t *__restrict__ n_det, int max_det) {
     __shared__ float vwin[50][64];  // VadDetector::window, one column per stream (lane)
+    __shared__ unsigned long long candidates;  // bit r: stream r of this block has a window that can fire
     const int lane = threadIdx.x;
-    size_t s = (size_t)blockIdx.x * 64 + lane;
-    if (s >= S) return;
     const long max_len = cfg.max_len;
     const long n_win = (long)n_frames - max_len + 1;
+    // A detection needs at least one window whose aggregate passes the thresholds (run_detection :411-429;
+    // the VAD only gates).  The wave first sweeps the block's 64 score rows with coalesced loads; streams
+    // without such a window (all of them on non-matching audio) are done, the others run the state machine.
+    {
+        if (lane == 0) candidates = 0;
+        __syncthreads();
+        const size_t s0 = (size_t)blockIdx.x * 64;
+        const size_t rows = S - s0 < 64 ? S - s0 : 64;
+        const size_t total = n_win > 0 ? rows * (size_t)n_win : 0;  // the block's score rows are one contiguous range
+        const float *a0 = agg + s0 * (size_t)(n_win > 0 ? n_win : 0);
+        const float *v0 = cfg.avg_enabled ? avg + s0 * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
+        unsigned long long mask = 0;
+        for (size_t e = lane; e < total; e += 64) {
+            bool pass = a0[e] > cfg.threshold;
+            if (pass && v0) pass = !(v0[e] < cfg.avg_threshold);
+            if (pass) mask |= 1ull << (e / (size_t)n_win);
+        }
+        if (mask) atomicOr(&candidates, mask);
+        __syncthreads();
+    }
+    size_t s = (size_t)blockIdx.x * 64 + lane;
+    if (s >= S) return;
+    if (!((candidates >> lane) & 1ull)) { n_det[s] = 0; return; }
     const float *a = agg + s * (size_t)(n_win > 0 ? n_win : 0);
     const float *v = avg ? avg + s * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
     const float *vv = vad_value ? vad_value + s * n_frames : nullptr;

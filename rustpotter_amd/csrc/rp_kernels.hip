@@ -1073,9 +1073,16 @@ __global__ __launch_bounds__(256) void chunk_rms_kernel(const TIN *__restrict__ 
     const TIN *x = pcm + s * pcm_stride + c * kFrame;
     float sum_squared = 0.0f;  // GainNormalizerFilter::get_rms_level, gain_normalizer_filter.rs:49-55 (sequential sum)
     if (vec4) {
-        for (int k = 0; k < kFrame; k += 4) {
-            const float4 v = SampleIn<TIN>::load4(x + k);
-            sum_squared += v.x * v.x; sum_squared += v.y * v.y; sum_squared += v.z * v.z; sum_squared += v.w * v.w;
+        constexpr int NB = 24;
+        for (int k0 = 0; k0 < kFrame; k0 += 4 * NB) {
+            float4 buf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) buf[b] = SampleIn<TIN>::load4(x + k0 + 4 * b);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float4 v = buf[b];
+                sum_squared += v.x * v.x; sum_squared += v.y * v.y; sum_squared += v.z * v.z; sum_squared += v.w * v.w;
+            }
         }
     } else {
         for (int k = 0; k < kFrame; ++k) { const float v = SampleIn<TIN>::cvt(x[k]); sum_squared += v * v; }
@@ -1083,23 +1090,26 @@ __global__ __launch_bounds__(256) void chunk_rms_kernel(const TIN *__restrict__ 
     rms[i] = sqrtf(sum_squared / (float)kFrame);
 }
 
-// GainNormalizerFilter::filter, gain_normalizer_filter.rs:14-41, one lane per stream; ring [S][window_size]
+// GainNormalizerFilter::filter, gain_normalizer_filter.rs:14-41, one lane per stream; the RMS window lives
+// in LDS ([window_size][64]) when it fits, else in the global ring [S][window_size]
 __global__ __launch_bounds__(64) void gain_kernel(const float *__restrict__ rms, size_t S, size_t n_chunks, float rms_level_ref,
-                                                  float min_gain, float max_gain, int window_size, float *__restrict__ ring,
-                                                  float *__restrict__ gains) {
+                                                  float min_gain, float max_gain, int window_size, int ring_in_lds,
+                                                  float *__restrict__ ring, float *__restrict__ gains) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= S) return;
-    float *w = ring + s * (size_t)window_size;
+    float *w = ring_in_lds ? reinterpret_cast<float *>(smem) + threadIdx.x : ring + s * (size_t)window_size;
+    const int pitch = ring_in_lds ? 64 : 1;
     const float rms_level_sqrt = sqrtf(rms_level_ref);
-    int len = 0, head = 0;  // logical window = w[(head + i) % window_size], i < len (oldest first)
+    int len = 0, head = 0;  // logical window = w[((head + i) % window_size) * pitch], i < len (oldest first)
     for (size_t c = 0; c < n_chunks; ++c) {
         const float r = rms[s * n_chunks + c];
         float gain = 1.f;
         if (!(rms_level_ref != rms_level_ref) && r != 0.f) {
-            if (len < window_size) { w[(head + len) % window_size] = r; ++len; }
-            else { w[head] = r; head = (head + 1) % window_size; }  // push + drain(0..1)
+            if (len < window_size) { w[((head + len) % window_size) * pitch] = r; ++len; }
+            else { w[head * pitch] = r; head = (head + 1) % window_size; }  // push + drain(0..1)
             float sum = 0.f;
-            for (int i = 0; i < len; ++i) sum += w[(head + i) % window_size];
+            for (int i = 0; i < len; ++i) sum += w[((head + i) % window_size) * pitch];
             const float frame_rms_level = sum / (float)len;
             gain = rms_level_sqrt / sqrtf(frame_rms_level);
             gain = roundf(gain * 10.f) / 10.f;
@@ -1133,11 +1143,19 @@ __global__ __launch_bounds__(64) void apply_filters_kernel(const TIN *__restrict
             }
             return v;
         };
-        if (vec4) {  // 4 samples per load/store: the lane-per-stream pattern is bound by line look-ups per instruction
-            for (int k = 0; k < kFrame; k += 4) {
-                float4 v = SampleIn<TIN>::load4(x + c * kFrame + k);
-                v.x = one(v.x); v.y = one(v.y); v.z = one(v.z); v.w = one(v.w);
-                *reinterpret_cast<float4 *>(y + c * kFrame + k) = v;
+        if (vec4) {  // 4 samples per load/store, 24 loads in flight: with one wave per SIMD (S/64 waves in all)
+                     // the loads must be issued ahead of the dependent filter chain
+            constexpr int NB = 24;
+            for (int k0 = 0; k0 < kFrame; k0 += 4 * NB) {
+                float4 buf[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) buf[b] = SampleIn<TIN>::load4(x + c * kFrame + k0 + 4 * b);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float4 v = buf[b];
+                    v.x = one(v.x); v.y = one(v.y); v.z = one(v.z); v.w = one(v.w);
+                    *reinterpret_cast<float4 *>(y + c * kFrame + k0 + 4 * b) = v;
+                }
             }
         } else {
             for (int k = 0; k < kFrame; ++k) y[c * kFrame + k] = one(SampleIn<TIN>::cvt(x[c * kFrame + k]));
@@ -1158,9 +1176,12 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
         const size_t n = S * n_chunks;
         if ((n + 255) / 256 > 0x7fffffffULL) return hipErrorInvalidValue;
         hipLaunchKernelGGL(chunk_rms_kernel<TIN>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pcm, S, n_chunks, pcm_stride, vec4, rms);
-        if (gain_on)
-            hipLaunchKernelGGL(gain_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, rms, S, n_chunks, rms_level_ref, min_gain,
-                               max_gain, window_size, ring, gains);
+        if (gain_on) {
+            const size_t ring_lds = (size_t)window_size * 64 * sizeof(float);
+            const int in_lds = ring_lds <= 48 * 1024;
+            hipLaunchKernelGGL(gain_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), in_lds ? ring_lds : 0, st, rms, S, n_chunks,
+                               rms_level_ref, min_gain, max_gain, window_size, in_lds, ring, gains);
+        }
     }
     hipLaunchKernelGGL(apply_filters_kernel<TIN>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, pcm, S, n_samples, n_chunks,
                        pcm_stride, gain_on ? gains : nullptr, band_pass, q, vec4, out, out_stride);

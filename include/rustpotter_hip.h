@@ -271,6 +271,29 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
                         const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                         int max_det, float *scores, float *agg);
 
+/* Live streams: S detectors that each receive n_chunks 30 ms chunks per call -- the batched form of
+ * calling Rustpotter::process_samples (src/detector.rs:347-376) once per chunk on S independent
+ * instances that share one wakeword and one DetectorConfig.  Everything the reference keeps between
+ * calls stays on the device: the previous chunk (MfccExtractor's sample history, src/mfcc/extractor.rs),
+ * the last max_len-1 MFCC frames (Rustpotter::audio_mfcc_window), the partial detection / countdown
+ * (src/detector.rs:62-79) and the VadDetector window.  Frames are numbered as in rp_batch_detect
+ * (frame f is the f-th MFCC frame since the batch was created), so feeding a stream in pieces gives
+ * the detections of rp_batch_detect over the concatenation. */
+typedef struct rp_stream_batch rp_stream_batch;
+int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_config *config, size_t S,
+                        size_t max_chunks_per_call, rp_stream_batch **out);
+void rp_stream_batch_free(rp_stream_batch *b);
+/* pcm [S][pcm_stride] holds n_chunks*480 new samples per stream (1 <= n_chunks <= max_chunks_per_call).
+ * det [S][max_det], n_det [S]: detections emitted during these chunks (n_det may exceed max_det; only
+ * the first max_det are stored).  agg (NULL to skip) [S][3*n_chunks]: aggregate score of the window
+ * ending at each new frame (garbage for windows that reach before frame 0). */
+int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
+                            rp_batch_detection *det, int32_t *n_det, int max_det, float *agg);
+/* Rustpotter::reset (src/detector.rs:290-302) of one stream, or of all when stream < 0. */
+int rp_stream_batch_reset(rp_stream_batch *b, long long stream);
+/* chunks consumed so far (per stream) */
+size_t rp_stream_batch_chunks_seen(const rp_stream_batch *b);
+
 /* A wakeword model (src/wakewords/wakeword_model.rs:11-18) resident on the device.  weights are
  * HOST arrays W_l [dims[l+1]][dims[l]] (candle Linear: x.W^T + b), biases b_l [dims[l+1]]; 1..3 layers. */
 typedef struct rp_model rp_model;

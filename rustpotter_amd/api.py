@@ -99,7 +99,8 @@ SYMBOLS = [
     "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
-    "rp_version",
+    "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
+    "rp_stream_batch_chunks_seen",
 ]
 
 
@@ -166,6 +167,13 @@ def load_library():
     L.rp_dtw_score_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, C.c_int, vp, vp, C.c_int]
     L.rp_batch_detect.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
+    L.rp_stream_batch_new.argtypes = [vp, vp, C.POINTER(_DetectorConfig), C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.rp_stream_batch_free.argtypes = [vp]
+    L.rp_stream_batch_free.restype = None
+    L.rp_stream_batch_process.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, vp, vp, C.c_int, vp]
+    L.rp_stream_batch_reset.argtypes = [vp, C.c_longlong]
+    L.rp_stream_batch_chunks_seen.argtypes = [vp]
+    L.rp_stream_batch_chunks_seen.restype = C.c_size_t
     L.rp_model_new.argtypes = [vp, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(vp)]
     L.rp_model_free.argtypes = [vp]
     L.rp_mlp_forward_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
@@ -420,6 +428,59 @@ class Model:
         if getattr(self, "_h", None):
             self._L.rp_model_free(self._h)
             self._h = None
+
+
+DET_DTYPE = [("stream", "<i4"), ("frame", "<i4"), ("window", "<i4"), ("counter", "<i4"), ("avg_score", "<f4"), ("score", "<f4")]
+
+
+class StreamBatch:
+    """S live streams fed chunk by chunk (rp_stream_batch_*): the batched form of calling
+    Rustpotter::process_samples on S instances sharing one wakeword and config."""
+
+    def __init__(self, ctx, templates, detector_config, S, max_chunks_per_call=1):
+        self._L = load_library()
+        self.ctx, self.templates, self.S, self.max_chunks = ctx, templates, S, max_chunks_per_call
+        h = C.c_void_p()
+        c = detector_config._c()
+        if self._L.rp_stream_batch_new(ctx._h, templates._h, C.byref(c), S, max_chunks_per_call, C.byref(h)) < 0:
+            raise _err()
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.rp_stream_batch_free(self._h)
+            self._h = None
+
+    @property
+    def chunks_seen(self):
+        return self._L.rp_stream_batch_chunks_seen(self._h)
+
+    def process(self, pcm, max_det=4, want_agg=False):
+        """pcm [S][n_chunks*480] numpy (i8 / i16 / i32 / f32) -> (det, n_det[, agg]) for these chunks."""
+        import numpy as np
+        assert self.ctx.host
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
+        S, N = pcm.shape
+        if S != self.S or N % 480:
+            raise ValueError("pcm must be [S][n_chunks*480]")
+        det = np.zeros((S, max_det), dtype=DET_DTYPE)
+        n_det = np.zeros(S, np.int32)
+        agg = np.empty((S, 3 * (N // 480)), np.float32) if want_agg else None
+        if self._L.rp_stream_batch_process(self._h, pcm.ctypes.data, fmt, N // 480, N, det.ctypes.data, n_det.ctypes.data, max_det,
+                                           None if agg is None else agg.ctypes.data) < 0:
+            raise _err()
+        return (det, n_det, agg) if want_agg else (det, n_det)
+
+    def process_dev(self, pcm_ptr, fmt, n_chunks, stride, det_ptr, n_det_ptr, max_det, agg_ptr=None):
+        if self._L.rp_stream_batch_process(self._h, pcm_ptr, fmt, n_chunks, stride, det_ptr, n_det_ptr, max_det, agg_ptr) < 0:
+            raise _err()
+
+    def reset(self, stream=-1):
+        if self._L.rp_stream_batch_reset(self._h, stream) < 0:
+            raise _err()
 
 
 class BatchContext:

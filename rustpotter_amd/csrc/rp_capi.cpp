@@ -19,6 +19,15 @@ struct rp_detector {
 struct rp_ctx { std::unique_ptr<Ctx> impl; };
 struct rp_templates { std::unique_ptr<Templates> impl; };
 struct rp_model { std::unique_ptr<Model> impl; };
+struct rp_stream_batch {
+    Ctx *c = nullptr;
+    const Templates *t = nullptr;
+    rp_detector_config cfg{};
+    size_t S = 0, max_chunks = 0, chunks_seen = 0, hist_frames = 0;
+    int cur = 0;             // which of mfcc[2] holds the frames of the last call
+    size_t cur_pitch = 0;    // its row pitch in frames
+    DevBuf pcm, mfcc[2], state, scores, agg, avg, vad;
+};
 
 static void fill_detection(rp_detector *d, const Detection &src, rp_detection *out) {
     d->last = src;
@@ -422,6 +431,113 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
         if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
         if (sg.host && scores && !sg.back(scores, ds, rows * td.T * sizeof(float))) return -1;
         if (sg.host && agg && !sg.back(agg, dg, rows * sizeof(float))) return -1;
+        return sg.finish() ? 0 : -1;
+    });
+}
+
+int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_config *config, size_t S,
+                        size_t max_chunks_per_call, rp_stream_batch **out) {
+    return guarded([&]() -> int {
+        *out = nullptr;
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (S == 0 || max_chunks_per_call == 0) { set_last_error("rp_stream_batch_new: S and max_chunks_per_call must be >= 1"); return -1; }
+        if (config->band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
+        const TemplatesDev &td = t->impl->dev;
+        if (!c->tables_for(td.K)) return -1;
+        std::unique_ptr<rp_stream_batch> b(new rp_stream_batch());
+        b->c = c; b->t = t->impl.get(); b->cfg = *config; b->S = S; b->max_chunks = max_chunks_per_call;
+        b->hist_frames = (size_t)td.max_len - 1;
+        const size_t pitch = b->hist_frames + 3 * max_chunks_per_call, rows = S * 3 * max_chunks_per_call;
+        const size_t slack = 64 * (size_t)td.K * sizeof(float);  // the DTW band reads up to band_size frames past a row
+        const size_t pcm_bytes = S * (1 + max_chunks_per_call) * 480 * sizeof(float);
+        if (!b->pcm.reserve(pcm_bytes) || !b->mfcc[0].reserve(S * pitch * td.K * sizeof(float) + slack) ||
+            !b->mfcc[1].reserve(S * pitch * td.K * sizeof(float) + slack) || !b->state.reserve(S * stream_state_bytes()) ||
+            !b->scores.reserve(rows * td.T * sizeof(float) + 16) || !b->agg.reserve(rows * sizeof(float) + 16) ||
+            !b->avg.reserve(rows * sizeof(float) + 16) || !b->vad.reserve(rows * sizeof(float) + 16))
+            return -1;
+        if (!hip_ok(hipMemsetAsync(b->pcm.p, 0, pcm_bytes, c->stream), "hipMemsetAsync") ||
+            !hip_ok(hipMemsetAsync(b->mfcc[0].p, 0, b->mfcc[0].cap, c->stream), "hipMemsetAsync") ||
+            !hip_ok(hipMemsetAsync(b->mfcc[1].p, 0, b->mfcc[1].cap, c->stream), "hipMemsetAsync") ||
+            !hip_ok(launch_stream_state_init(c->stream, b->state.p, S), "stream_state_init_kernel"))
+            return -1;
+        b->cur = 0; b->cur_pitch = b->hist_frames;  // an all-zero history nobody scores against (frames < 0)
+        *out = b.release();
+        return 0;
+    });
+}
+void rp_stream_batch_free(rp_stream_batch *b) { delete b; }
+size_t rp_stream_batch_chunks_seen(const rp_stream_batch *b) { return b->chunks_seen; }
+
+int rp_stream_batch_reset(rp_stream_batch *b, long long stream) {
+    return guarded([&]() -> int {
+        Ctx *c = b->c;
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (stream >= (long long)b->S) { set_last_error("rp_stream_batch_reset: no such stream"); return -1; }
+        // the next chunk only refills the extractor: its three frames (3C-3 .. 3C-1) are never emitted
+        return hip_ok(launch_stream_state_reset(c->stream, b->state.p, b->S, stream, 3 * (long long)b->chunks_seen), "stream_state_reset_kernel") ? 0 : -1;
+    });
+}
+
+int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
+                            rp_batch_detection *det, int32_t *n_det, int max_det, float *agg) {
+    return guarded([&]() -> int {
+        Ctx *c = b->c;
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (n_chunks == 0 || n_chunks > b->max_chunks) { set_last_error("rp_stream_batch_process: n_chunks out of range"); return -1; }
+        if (pcm_stride < n_chunks * 480) { set_last_error("pcm_stride smaller than n_chunks*480"); return -1; }
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        const TemplatesDev &td = b->t->dev;
+        const MfccTablesDev *tb = c->tables_for(td.K);
+        if (!tb) return -1;
+        const size_t S = b->S, n_new = 3 * n_chunks, hist = b->hist_frames, pitch = hist + n_new, rows = S * n_new;
+        const size_t n_samples = (1 + n_chunks) * 480, pcm_pitch = (1 + b->max_chunks) * 480;
+        const bool do_avg = td.has_avg && b->cfg.avg_threshold != 0.f;
+        Staged sg(c);
+        const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
+        BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
+        int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
+        if (!dp || !dd || !dn) { if (!pcm || !det || !n_det) set_last_error("null argument"); return -1; }
+        float *hp = b->pcm.as<float>();
+        float *prev = b->mfcc[b->cur].as<float>(), *now = b->mfcc[b->cur ^ 1].as<float>();
+        // previous chunk | new chunks, decoded to f32
+        if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, S, n_chunks * 480, pcm_stride, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+        // last max_len-1 frames of the previous call | the 3*n_chunks new frames
+        if (!hip_ok(launch_carry_rows(c->stream, prev, S, b->cur_pitch * td.K, (b->cur_pitch - hist) * td.K, hist * td.K, now, pitch * td.K), "carry_rows_kernel")) return -1;
+        c->time_begin(kKernelMfcc);
+        bool ok = hip_ok(launch_mfcc(c->stream, *tb, hp, S, n_samples, pcm_pitch, 0, n_new, pitch, now + hist * td.K), "mfcc_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        float *ds = b->scores.as<float>(), *dg = b->agg.as<float>(), *da = do_avg ? b->avg.as<float>() : nullptr;
+        c->time_begin(kKernelDtw);
+        ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, 0, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true), "dtw kernel");
+        c->time_end();
+        if (!ok) return -1;
+        c->time_begin(kKernelAggregate);
+        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)b->cfg.score_mode, dg), "aggregate_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        float *dv = nullptr;
+        if (b->cfg.vad_mode != RP_VAD_NONE) {
+            dv = b->vad.as<float>();
+        }
+        ScanConfig sc;
+        sc.threshold = b->cfg.threshold; sc.avg_threshold = b->cfg.avg_threshold; sc.min_scores = (int)b->cfg.min_scores;
+        sc.eager = b->cfg.eager ? 1 : 0; sc.max_len = td.max_len; sc.avg_enabled = do_avg ? 1 : 0;
+        if (dv && !hip_ok(launch_vad_value_rows(c->stream, now + hist * td.K, S, n_new, pitch, td.K, dv), "vad_value_kernel")) return -1;
+        c->time_begin(kKernelScan);
+        ok = hip_ok(launch_scan_stream(c->stream, dg, da, dv, vad_mode_value(b->cfg.vad_mode), S, 3 * (long long)b->chunks_seen - 3, (int)n_new,
+                                       sc, b->state.p, dd, dn, max_det), "scan_stream_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        // the last chunk becomes the extractor history of the next call
+        if (!hip_ok(launch_carry_rows(c->stream, hp, S, pcm_pitch, n_chunks * 480, 480, hp, pcm_pitch), "carry_rows_kernel")) return -1;
+        b->cur ^= 1; b->cur_pitch = pitch; b->chunks_seen += n_chunks;
+        if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
+        if (agg) {
+            if (sg.host) { if (!sg.back(agg, dg, rows * sizeof(float))) return -1; }
+            else if (!hip_ok(hipMemcpyAsync(agg, dg, rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync(D2D)")) return -1;
+        }
         return sg.finish() ? 0 : -1;
     });
 }

@@ -72,7 +72,7 @@ hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *
 // scores [S][n_win][T]; avg [S][n_win] or nullptr.  mfcc rows have `frame_pitch` frames per stream.
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
-                      float *scores, float *avg);
+                      float *scores, float *avg, bool padded_rows = false);
 
 // Largest template tile the register DTW kernel is built for (0: only the generic kernel applies).
 int dtw_register_tile(int K, int band);
@@ -82,6 +82,7 @@ hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, 
 // vad_value [S][n_frames] = mean |mfcc| per frame (launch_vad_value) or nullptr (no VAD);
 // vad_mode_value = VADMode::get_value (2 / 2.5 / 3, src/config.rs:140-146)
 hipError_t launch_vad_value(hipStream_t st, const float *mfcc, size_t n_frames_total, int K, float *out);
+hipError_t launch_vad_value_rows(hipStream_t st, const float *mfcc, size_t S, size_t n, size_t pitch, int K, float *out);
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                        size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det);
 
@@ -91,6 +92,18 @@ hipError_t launch_frontend(hipStream_t st, const void *pcm, int fmt, size_t S, s
                            float rms_level_ref, float min_gain, float max_gain, int window_size, int band_pass, float a0,
                            float a1, float a2, float b1, float b2, float *ring, float *rms, float *gains, float *out,
                            size_t out_stride);
+
+// streaming batches (state carried between calls; rp_stream.cpp)
+hipError_t launch_stream_stage(hipStream_t st, const void *pcm, int fmt, size_t S, size_t n_new, size_t pcm_stride, float *hist,
+                               size_t hist_pitch);
+hipError_t launch_carry_rows(hipStream_t st, const float *src, size_t S, size_t src_pitch, size_t src_off, size_t count, float *dst,
+                             size_t dst_pitch);
+hipError_t launch_stream_state_init(hipStream_t st, void *state, size_t S);
+size_t stream_state_bytes();
+hipError_t launch_stream_state_reset(hipStream_t st, void *state, size_t S, long long stream, long long resume);
+hipError_t launch_scan_stream(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
+                              size_t S, long long f0, int n_new, const ScanConfig &cfg, void *state, BatchDetection *det,
+                              int32_t *n_det, int max_det);
 
 hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
                         size_t pcm_stride, float *pcm);

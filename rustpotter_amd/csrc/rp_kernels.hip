@@ -421,7 +421,10 @@ constexpr int kDtwWin = 64;   // windows per wave
 // every ring slot and band index is a compile-time register.  Only the first 2W rows can touch
 // columns c < 1 and need the +inf guard; columns c > n are never read back by an in-range cell
 // (they only feed cells further right / below-right), so they are left unguarded.
-template <int K, int W, int TC>
+// GX: lanes read their window's frames straight from global memory instead of an LDS stage: used when a
+// stream contributes only a few windows per launch (streaming batches), so that the 64 lanes of a wave
+// can belong to many different streams.
+template <int K, int W, int TC, bool GX>
 __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
@@ -440,45 +443,57 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     // Lane -> (stream, window).  flat != 0: the 64 lanes are consecutive entries of the flattened
     // (stream, window) space, so a wave may straddle two streams (needs n_win >= 64) and no lane is
     // wasted on a ragged last tile; flat == 0: tiles never cross a stream.
-    size_t sA, sB = 0;
-    int wA, nA, nB = 0;
-    if (flat) {
-        const size_t f0 = (size_t)tile * kDtwWin;  // here `tiles` counts flattened tiles and there is no stream index
-        sA = f0 / n_win;
-        wA = (int)(f0 - sA * n_win);
-        nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
-        if (nA < kDtwWin && sA + 1 < n_streams) { sB = sA + 1; nB = kDtwWin - nA; }
+    size_t s;
+    int w;
+    bool valid;
+    const float *xl;
+    if (GX) {
+        static_assert(!GX || KP == K, "global-memory frames have pitch K");
+        const size_t f = (size_t)tile * kDtwWin + lane;
+        valid = f < n_streams * n_win;
+        s = valid ? f / n_win : 0;
+        w = valid ? (int)(f - s * n_win) : 0;
+        xl = mfcc + (s * frame_pitch + first_win + (size_t)w) * K;
     } else {
-        sA = blockIdx.x / ((size_t)tiles * n_chunks);
-        wA = (int)tile * kDtwWin;
-        nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
-    }
-    const int segA = nA + L + W;  // frames staged for the first stream segment
-    {
-        const float *src = mfcc + sA * frame_pitch * K;
-        const size_t g0 = first_win + wA;
-        for (int i = lane; i < segA * K; i += kDtwWin) {
-            int f = i / K, k = i - f * K;
-            size_t g = g0 + f;
-            xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+        size_t sA, sB = 0;
+        int wA, nA, nB = 0;
+        if (flat) {
+            const size_t f0 = (size_t)tile * kDtwWin;  // here `tiles` counts flattened tiles and there is no stream index
+            sA = f0 / n_win;
+            wA = (int)(f0 - sA * n_win);
+            nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
+            if (nA < kDtwWin && sA + 1 < n_streams) { sB = sA + 1; nB = kDtwWin - nA; }
+        } else {
+            sA = blockIdx.x / ((size_t)tiles * n_chunks);
+            wA = (int)tile * kDtwWin;
+            nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
         }
-    }
-    if (nB > 0) {
-        const float *src = mfcc + sB * frame_pitch * K;
-        const int segB = nB + L + W;
-        for (int i = lane; i < segB * K; i += kDtwWin) {
-            int f = i / K, k = i - f * K;
-            size_t g = first_win + f;
-            xs[(segA + f) * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+        const int segA = nA + L + W;  // frames staged for the first stream segment
+        {
+            const float *src = mfcc + sA * frame_pitch * K;
+            const size_t g0 = first_win + wA;
+            for (int i = lane; i < segA * K; i += kDtwWin) {
+                int f = i / K, k = i - f * K;
+                size_t g = g0 + f;
+                xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+            }
         }
+        if (nB > 0) {
+            const float *src = mfcc + sB * frame_pitch * K;
+            const int segB = nB + L + W;
+            for (int i = lane; i < segB * K; i += kDtwWin) {
+                int f = i / K, k = i - f * K;
+                size_t g = first_win + f;
+                xs[(segA + f) * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+            }
+        }
+        __syncthreads();
+        const bool inA = lane < nA;
+        valid = inA || (lane - nA < nB);
+        s = inA ? sA : sB;
+        w = inA ? wA + lane : lane - nA;
+        xl = xs + (inA ? lane : (valid ? segA + lane - nA : 0)) * KP;
     }
-    __syncthreads();
-
-    const bool inA = lane < nA;
-    const bool valid = inA || (lane - nA < nB);
-    const size_t s = inA ? sA : sB;
-    const int w = inA ? wA + lane : lane - nA;
-    const float *xl = xs + (inA ? lane : (valid ? segA + lane - nA : 0)) * KP;
     // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums
     float mu[K];
 #pragma unroll
@@ -781,16 +796,28 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
 template <int K, int W, int TC>
 static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
                                    size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
-                                   float score_ref, float *scores, float *avg) {
+                                   float score_ref, float *scores, float *avg, bool few_windows) {
     if (n_chunks <= 0) return hipSuccess;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
+    if (few_windows && KP == K && W == 5) {
+        // streams contribute fewer than 64 windows each: lanes of a wave span many streams and read their frames
+        // from global memory (the caller guarantees W*K floats of slack after the last stream's frames)
+        const size_t ft = (S * n_win + kDtwWin - 1) / kDtwWin;
+        const size_t blocks = ft * (size_t)n_chunks;
+        if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+        if (W == 5)
+            hipLaunchKernelGGL((dtw_band_kernel<K, 5, TC, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
+                               frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+                               t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S);
+        return hipGetLastError();
+    }
     // flattened (stream, window) tiling when every stream has at least one full tile of windows
     const int flat = (n_win >= (size_t)kDtwWin && S > 1) ? 1 : 0;
     const size_t ft = flat ? (S * n_win + kDtwWin - 1) / kDtwWin : tiles;
     const size_t blocks = flat ? ft * (size_t)n_chunks : tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + W)) * KP * sizeof(float);
-    hipLaunchKernelGGL((dtw_band_kernel<K, W, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+    hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
     return hipGetLastError();
@@ -822,17 +849,20 @@ int dtw_register_tile(int K, int band) {
 template <int W>
 static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n2, const float *mfcc, size_t S, size_t frame_pitch,
                                 size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
-                                float *scores, float *avg) {
+                                float *scores, float *avg, bool few) {
     hipError_t e;
-    if ((e = launch_dtw_class<5, W, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg)) != hipSuccess) return e;
-    if ((e = launch_dtw_class<5, W, 4>(st, t, 1, t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg)) != hipSuccess) return e;
-    return launch_dtw_class<5, W, 8>(st, t, 2, t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+    if ((e = launch_dtw_class<5, W, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)) != hipSuccess) return e;
+    if ((e = launch_dtw_class<5, W, 4>(st, t, 1, t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)) != hipSuccess) return e;
+    return launch_dtw_class<5, W, 8>(st, t, 2, t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
 }
 
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
-                      float *scores, float *avg) {
+                      float *scores, float *avg, bool padded_rows) {
     if (S == 0 || n_win == 0) return hipSuccess;
+    // many streams with few windows each (streaming batches): cross-stream waves reading frames from global memory;
+    // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
+    const bool few = padded_rows && S > 1 && n_win < (size_t)kDtwWin;
     const bool do_avg = with_avg && t.has_avg;
     const int Ttot = t.T + (do_avg ? 1 : 0);
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
@@ -841,10 +871,10 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
         const int n2 = t.class_count[0] - ((t.has_avg && !do_avg) ? 1 : 0);
         if (t.K == 5) {
             switch (band) {
-            case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
-            case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
-            case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
-            default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+            case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
             }
         }
         return launch_dtw_wide<16, 5, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
@@ -948,6 +978,25 @@ hipError_t launch_vad_value(hipStream_t st, const float *mfcc, size_t n_frames_t
     const size_t blocks = (n_frames_total + 255) / 256;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(vad_value_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mfcc, n_frames_total, K, out);
+    return hipGetLastError();
+}
+
+// the same over rows of `pitch` frames: out [S][n] from mfcc [S][pitch][K]
+__global__ __launch_bounds__(256) void vad_value_rows_kernel(const float *__restrict__ mfcc, size_t S, size_t n, size_t pitch, int K,
+                                                             float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * n) return;
+    const size_t s = i / n, f = i - s * n;
+    const float *v = mfcc + (s * pitch + f) * K;
+    float a = 0.f;
+    for (int k = 0; k < K; ++k) a += fabsf(v[k]);
+    out[i] = a / (float)K;
+}
+hipError_t launch_vad_value_rows(hipStream_t st, const float *mfcc, size_t S, size_t n, size_t pitch, int K, float *out) {
+    if (S * n == 0) return hipSuccess;
+    const size_t blocks = (S * n + 255) / 256;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vad_value_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mfcc, S, n, pitch, K, out);
     return hipGetLastError();
 }
 
@@ -1055,6 +1104,176 @@ hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const
     size_t blocks = (S + 63) / 64;
     hipLaunchKernelGGL(scan_kernel, dim3((unsigned)blocks), dim3(64), 0, st, agg, avg, vad_value, vad_mode_value, S, n_frames,
                        cfg, det, n_det, max_det);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------- streaming batches
+// State of one live stream between rp_stream_batch_process calls: the detector's countdown / partial
+// detection / window bookkeeping (src/detector.rs:62-79) in absolute frame numbers, and the VadDetector.
+struct StreamState {
+    long long win_start, resume;
+    int has_partial, p_counter, countdown, vad_index, voice_countdown, pad;
+    long long p_window;
+    float p_score, p_avg;
+    float vad_window[50];
+};
+
+// decode the new chunks behind the carried 480-sample chunk: hist [S][(1+n)*480]
+template <class TIN>
+__global__ __launch_bounds__(256) void stream_stage_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_new, size_t pcm_stride,
+                                                           float *__restrict__ hist, size_t hist_pitch) {
+    const size_t total = S * n_new;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t s = i / n_new, k = i - s * n_new;
+        hist[s * hist_pitch + kFrame + k] = SampleIn<TIN>::cvt(pcm[s * pcm_stride + k]);
+    }
+}
+// rows [S][src_pitch] -> [S][dst_pitch]: dst[s][0..count) = src[s][src_off .. src_off+count)
+__global__ __launch_bounds__(256) void carry_rows_kernel(const float *src, size_t S, size_t src_pitch, size_t src_off, size_t count,
+                                                         float *dst, size_t dst_pitch) {
+    const size_t total = S * count;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t s = i / count, k = i - s * count;
+        dst[s * dst_pitch + k] = src[s * src_pitch + src_off + k];
+    }
+}
+
+hipError_t launch_stream_stage(hipStream_t st, const void *pcm, int fmt, size_t S, size_t n_new, size_t pcm_stride, float *hist,
+                               size_t hist_pitch) {
+    if (S == 0 || n_new == 0) return hipSuccess;
+    size_t blocks = (S * n_new + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    switch (fmt) {
+    case 0: hipLaunchKernelGGL(stream_stage_kernel<int8_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int8_t *>(pcm), S, n_new, pcm_stride, hist, hist_pitch); break;
+    case 1: hipLaunchKernelGGL(stream_stage_kernel<int16_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int16_t *>(pcm), S, n_new, pcm_stride, hist, hist_pitch); break;
+    case 2: hipLaunchKernelGGL(stream_stage_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int32_t *>(pcm), S, n_new, pcm_stride, hist, hist_pitch); break;
+    case 3: hipLaunchKernelGGL(stream_stage_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(pcm), S, n_new, pcm_stride, hist, hist_pitch); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_carry_rows(hipStream_t st, const float *src, size_t S, size_t src_pitch, size_t src_off, size_t count, float *dst,
+                             size_t dst_pitch) {
+    if (S == 0 || count == 0) return hipSuccess;
+    size_t blocks = (S * count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(carry_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, S, src_pitch, src_off, count, dst, dst_pitch);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void stream_state_init_kernel(StreamState *__restrict__ st, size_t S) {
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    StreamState z;
+    z.win_start = 0; z.resume = 0; z.has_partial = 0; z.p_counter = 0; z.countdown = 0; z.vad_index = 0; z.voice_countdown = 0; z.pad = 0;
+    z.p_window = 0; z.p_score = 0.f; z.p_avg = 0.f;
+    for (int i = 0; i < 50; ++i) z.vad_window[i] = __builtin_nanf("");
+    st[s] = z;
+}
+hipError_t launch_stream_state_init(hipStream_t st, void *state, size_t S) {
+    if (S == 0) return hipSuccess;
+    hipLaunchKernelGGL(stream_state_init_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, static_cast<StreamState *>(state), S);
+    return hipGetLastError();
+}
+size_t stream_state_bytes() { return sizeof(StreamState); }
+
+// Rustpotter::reset (src/detector.rs:290-302) for one stream (or all, stream < 0): the next chunk only refills
+// the extractor, so the next frame seen is `resume`.
+__global__ __launch_bounds__(64) void stream_state_reset_kernel(StreamState *__restrict__ st, size_t S, long long stream, long long resume) {
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= S || (stream >= 0 && (size_t)stream != s)) return;
+    StreamState z = st[s];
+    z.win_start = z.resume = resume;
+    z.has_partial = 0; z.p_counter = 0; z.countdown = 0; z.vad_index = 0; z.voice_countdown = 0;
+    for (int i = 0; i < 50; ++i) z.vad_window[i] = __builtin_nanf("");
+    st[s] = z;
+}
+hipError_t launch_stream_state_reset(hipStream_t st, void *state, size_t S, long long stream, long long resume) {
+    if (S == 0) return hipSuccess;
+    hipLaunchKernelGGL(stream_state_reset_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, static_cast<StreamState *>(state), S,
+                       stream, resume);
+    return hipGetLastError();
+}
+
+// scan_kernel over the n_new frames of this call with carried state.  Frame i of the call is absolute frame
+// f0 + i; the window ending at it is row i of agg / avg (the history prefix is max_len-1 frames long).
+__global__ __launch_bounds__(64) void scan_stream_kernel(const float *__restrict__ agg, const float *__restrict__ avg,
+                                                         const float *__restrict__ vad_value, float vad_mode_value, size_t S,
+                                                         long long f0, int n_new, ScanConfig cfg, StreamState *__restrict__ state,
+                                                         BatchDetection *__restrict__ det, int32_t *__restrict__ n_det, int max_det) {
+    __shared__ float vwin[50][64];
+    const int lane = threadIdx.x;
+    const size_t s = (size_t)blockIdx.x * 64 + lane;
+    if (s >= S) return;
+    StreamState z = state[s];
+    const long long max_len = cfg.max_len;
+    const float *a = agg + s * (size_t)n_new;
+    const float *v = avg ? avg + s * (size_t)n_new : nullptr;
+    const float *vv = vad_value ? vad_value + s * (size_t)n_new : nullptr;
+    if (vv)
+        for (int i = 0; i < 50; ++i) vwin[i][lane] = z.vad_window[i];
+    int nd = 0;
+    for (int i = 0; i < n_new; ++i) {
+        const long long f = f0 + i;
+        if (f < 0 || f < z.resume) continue;  // frames the extractor never emits (first chunk, refill after a reset)
+        bool should_run = true;
+        if (vv && !z.has_partial) {
+            vwin[z.vad_index][lane] = vv[i];
+            z.vad_index = z.vad_index >= 49 ? 0 : z.vad_index + 1;
+            float mn = RP_INF;
+            for (int j = 0; j < 50; ++j) { float w = vwin[j][lane]; if (w == w && w < mn) mn = w; }
+            mn = fmaxf(mn, 0.01f);
+            const float th = mn * vad_mode_value;
+            int n_high = 0;
+            for (int j = 0; j < 50; ++j) n_high += vwin[j][lane] > th ? 1 : 0;
+            if (n_high > 10) z.voice_countdown = 500;
+            if (z.voice_countdown > 0) { z.voice_countdown -= 1; should_run = true; } else should_run = false;
+        }
+        if (f - z.win_start + 1 < max_len) continue;
+        if (!should_run) continue;
+        if (z.countdown != 0) z.countdown -= 1;
+        if (z.has_partial) {
+            const bool done = z.countdown == 0 ? true : (cfg.eager && z.p_counter >= cfg.min_scores);
+            if (done) {
+                z.has_partial = 0;
+                if (z.p_counter >= cfg.min_scores) {
+                    if (nd < max_det) {
+                        BatchDetection d;
+                        d.stream = (int32_t)s; d.frame = (int32_t)f; d.window = (int32_t)z.p_window; d.counter = z.p_counter;
+                        d.avg_score = z.p_avg; d.score = z.p_score;
+                        det[s * (size_t)max_det + nd] = d;
+                    }
+                    ++nd;
+                    z.win_start = z.resume = 3 * (f / 3) + 6;
+                    if (vv) { for (int j = 0; j < 50; ++j) vwin[j][lane] = __builtin_nanf(""); z.vad_index = 0; z.voice_countdown = 0; }
+                    continue;
+                }
+            }
+        }
+        const float sc = a[i];
+        float av = 0.f;
+        bool pass = true;
+        if (cfg.avg_enabled) { av = v[i]; pass = !(av < cfg.avg_threshold); }
+        if (pass && sc > cfg.threshold) {
+            const int counter = z.has_partial ? z.p_counter + 1 : 1;
+            if (!z.has_partial || z.p_score < sc) { z.p_score = sc; z.p_avg = av; z.p_window = f - max_len + 1; z.has_partial = 1; }
+            z.p_counter = counter;
+            z.countdown = (int)(max_len / 2);
+        }
+    }
+    if (vv)
+        for (int i = 0; i < 50; ++i) z.vad_window[i] = vwin[i][lane];
+    state[s] = z;
+    n_det[s] = nd;
+}
+
+hipError_t launch_scan_stream(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
+                              size_t S, long long f0, int n_new, const ScanConfig &cfg, void *state, BatchDetection *det,
+                              int32_t *n_det, int max_det) {
+    if (S == 0) return hipSuccess;
+    hipLaunchKernelGGL(scan_stream_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, agg, avg, vad_value, vad_mode_value, S, f0,
+                       n_new, cfg, static_cast<StreamState *>(state), det, n_det, max_det);
     return hipGetLastError();
 }
 

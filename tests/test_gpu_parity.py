@@ -384,6 +384,125 @@ def test_batch_detect_equals_per_stream_api(ra, ctx):
                 assert abs(row[ti] - d.scores[nm]) <= 1e-6 * d.scores[nm]
 
 
+def _det_tuple(d):
+    return (int(d["frame"]), int(d["window"]), int(d["counter"]), float(d["score"]), float(d["avg_score"]))
+
+
+@pytest.mark.parametrize("case,chunks_per_call", [("max", 1), ("max", 4), ("median", 3), ("ignore_alexa", 2), ("vad_easy", 1), ("vad_easy", 5)])
+def test_stream_batch_equals_offline_batch(ra, ctx, case, chunks_per_call):
+    """rp_stream_batch_process fed a few chunks per call (state carried on the device) emits, chunk for
+    chunk, what rp_batch_detect finds over the whole stream -- which the tests above tie to the oracle's
+    chunked detector.  Detections must come out in the call that contains their frame."""
+    e = EXP["simulation"][case]
+    w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+    templates = list(w["samples_features"].values())
+    base = simstream.simulation_stream_i16()
+    n = (len(base) // 480) * 480
+    rng = np.random.default_rng(5)
+    streams = [base[:n], np.roll(base[:n], 480 * 11), np.roll(base[:n], -480 * 4 - 77)]
+    streams += [(s.astype(np.int32) + rng.integers(-30, 30, n)).clip(-32768, 32767).astype(np.int16) for s in streams]
+    pcm = np.stack(streams)
+    cfg = _make_config(ra, e).detector
+    tm = ra.Templates(ctx, templates, avg=w["avg_features"])
+    det, n_det, _, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    assert n_det.sum() >= (0 if case == "ignore_alexa" else len(streams))
+    sb = ra.StreamBatch(ctx, tm, cfg, len(streams), max_chunks_per_call=chunks_per_call)
+    got = [[] for _ in streams]
+    L = tm.max_len
+    step = 480 * chunks_per_call
+    for i in range(0, n, step):
+        piece = pcm[:, i:i + step]
+        d, nd, a = sb.process(piece, want_agg=True)
+        f0 = 3 * (i // 480) - 3
+        for si in range(len(streams)):
+            for j in range(nd[si]):
+                assert f0 <= d[si][j]["frame"] < f0 + 3 * (piece.shape[1] // 480) and d[si][j]["stream"] == si
+                got[si].append(_det_tuple(d[si][j]))
+            # aggregate scores of the windows that end in this call, bitwise the offline ones
+            for k in range(a.shape[1]):
+                wi = f0 + k - L + 1
+                if 0 <= wi < agg.shape[1]:
+                    assert a[si, k] == agg[si, wi]
+    assert sb.chunks_seen == n // 480
+    for si in range(len(streams)):
+        assert got[si] == [_det_tuple(det[si][j]) for j in range(n_det[si])]
+
+
+def test_stream_batch_reset_and_formats(ra, ctx):
+    """reset(stream) == Rustpotter::reset on that stream only: compared with per-stream Rustpotter handles
+    that are reset at the same chunk; f32 input, one chunk per call."""
+    e = EXP["simulation"]["max"]
+    w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+    templates = list(w["samples_features"].values())
+    base = simstream.i16_to_f32(simstream.simulation_stream_i16())
+    n = (len(base) // 480) * 480
+    pcm = np.stack([base[:n], base[:n], np.roll(base[:n], 480 * 9)])
+    cfg = _make_config(ra, e)
+    cfg.fmt.sample_format = ra.SampleFormat.F32
+    tm = ra.Templates(ctx, templates, avg=w["avg_features"])
+    # where does stream 0 fire first?  reset stream 1 in the middle of that partial detection
+    det, n_det = ctx.batch_detect(pcm, tm, cfg.detector)
+    assert n_det[0] >= 1
+    reset_chunk = det[0][0]["frame"] // 3 + 1 - 6
+    sb = ra.StreamBatch(ctx, tm, cfg.detector, 3)
+    rps = []
+    for _ in range(3):
+        rp = ra.Rustpotter.new(cfg)
+        rp.add_wakeword_from_file("w", os.path.join(G, e["rpw"]))
+        rps.append(rp)
+    got, ref = [[] for _ in range(3)], [[] for _ in range(3)]
+    for c in range(n // 480):
+        if c == reset_chunk:
+            sb.reset(1)
+            rps[1].reset()
+        if c == reset_chunk + 40:
+            sb.reset()
+            for rp in rps:
+                rp.reset()
+        d, nd = sb.process(pcm[:, c * 480:(c + 1) * 480])
+        for si in range(3):
+            for j in range(nd[si]):
+                got[si].append((c, int(d[si][j]["counter"]), float(d[si][j]["score"])))
+            r = rps[si].process_samples(pcm[si, c * 480:(c + 1) * 480].copy())
+            if r is not None:
+                ref[si].append((c, r.counter, r.score))
+    assert len(ref[0]) >= 1
+    for si in range(3):
+        assert len(got[si]) == len(ref[si])
+        for g, r in zip(got[si], ref[si]):
+            assert g[0] == r[0] and g[1] == r[1] and abs(g[2] - r[2]) <= 1e-6 * r[2]
+    assert got[0] != got[1]  # the reset changed stream 1's detections
+    with pytest.raises(ra.RustpotterError):
+        sb.process(np.zeros((3, 480 * 2), np.float32))  # more chunks than max_chunks_per_call
+
+
+def test_stream_batch_many_streams_synthetic(ra, ctx):
+    """4096 synthetic streams, 2 chunks per call (the cross-stream DTW tiling): per-call aggregates and
+    detections identical to the offline pass."""
+    S, N = 4096, 16000
+    tmpl = orc.synth_templates(SEED, 8, 100, 5)
+    tm = ra.Templates(ctx, tmpl)
+    cfg = ra.RustpotterConfig.default().detector
+    cfg.avg_threshold, cfg.threshold, cfg.min_scores = 0.0, 0.2, 1
+    pcm = ctx.synth_pcm(SEED, 0, S, N)
+    n = (N // 960) * 960
+    det, n_det, _, agg = ctx.batch_detect(pcm[:, :n], tm, cfg, want_scores=True)
+    sb = ra.StreamBatch(ctx, tm, cfg, S, max_chunks_per_call=2)
+    total = np.zeros(S, np.int64)
+    for i in range(0, n, 960):
+        d, nd, a = sb.process(pcm[:, i:i + 960], want_agg=True)
+        f0 = 3 * (i // 480) - 3
+        lo, hi = f0 - 99, f0 + 6 - 99  # windows ending at the 6 new frames
+        k0 = max(0, -lo)
+        if hi > 0:
+            assert np.array_equal(a[:, k0:], agg[:, lo + k0:hi])
+        for si in np.nonzero(nd)[0]:
+            for j in range(nd[si]):
+                assert _det_tuple(d[si][j]) == _det_tuple(det[si][total[si] + j])
+        total += nd
+    assert np.array_equal(total, n_det)
+
+
 @pytest.mark.parametrize("vad", ["easy", "medium", "hard"])
 def test_batch_vad_gate_matches_oracle(ra, ctx, vad):
     """VadDetector in the batched scan: speech surrounded by low-level noise (the gate opens late

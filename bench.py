@@ -39,8 +39,10 @@ def main():
     ap.add_argument("--mfcc-size", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--mode", choices=["dtw", "mlp"], default="dtw",
-                    help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward")
+    ap.add_argument("--mode", choices=["dtw", "mlp", "stream"], default="dtw",
+                    help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward; "
+                         "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process)")
+    ap.add_argument("--chunks-per-call", type=int, default=1)
     ap.add_argument("--mlp-precision", choices=["f32", "bf16"], default="bf16")
     args = ap.parse_args()
 
@@ -74,6 +76,9 @@ def main():
 
     if args.mode == "mlp":
         return bench_mlp(args, ra, torch, dist, dev, world, rank, local_rank)
+
+    if args.mode == "stream":
+        return bench_stream(args, ra, torch, dist, dev, world, rank, local_rank)
 
     S, N, T, L, K = args.streams, args.samples, args.templates, args.template_len, args.mfcc_size
     nf = ra.mfcc_num_frames(N)
@@ -207,6 +212,77 @@ def main():
                                          "not the Rust crate" % (s_cpu, T, sc, secs)}
     if rank == 0:
         print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def make_templates(args, ra, ctx, torch, dev):
+    import numpy as np
+    T, L, K = args.templates, args.template_len, args.mfcc_size
+    n_t = 480 * -(-(L + 3) // 3)
+    tp = torch.empty((T, n_t), dtype=torch.float32, device=dev)
+    for t in range(T):
+        ctx.synth_dev(SEED + 1 + t, 0, 1, n_t, n_t, tp[t].data_ptr())
+    tmf = torch.empty((T, ra.mfcc_num_frames(n_t), K), dtype=torch.float32, device=dev)
+    ctx.mfcc_dev(tp.data_ptr(), T, n_t, n_t, K, tmf.data_ptr())
+    torch.cuda.synchronize()
+    return [np.ascontiguousarray((m - m.mean(axis=0, dtype=np.float32))[:L], dtype=np.float32) for m in tmf.cpu().numpy()]
+
+
+def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
+    """Live serving shape of the same path: S streams per GPU, every call brings --chunks-per-call new
+    30 ms chunks per stream (f32, resident in HBM) and returns that call's detections; extractor history,
+    MFCC window and detector state stay on the device between calls."""
+    S, T, n = args.streams, args.templates, args.chunks_per_call
+    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    tmpl = ra.Templates(ctx, make_templates(args, ra, ctx, torch, dev))
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    sb = ra.StreamBatch(ctx, tmpl, cfg, S, max_chunks_per_call=n)
+    n_calls = args.warmup + args.steps + 5
+    pcm = torch.empty((S, 480 * n * 4), dtype=torch.float32, device=dev)  # 4 distinct calls' worth, cycled
+    ctx.synth_dev(SEED, 0, S, pcm.shape[1], pcm.shape[1], pcm.data_ptr())
+    det = torch.zeros((S, 4, 6), dtype=torch.int32, device=dev)
+    n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
+    calls = [0]
+
+    def step():
+        off = (calls[0] % 4) * 480 * n
+        calls[0] += 1
+        sb.process_dev(pcm.data_ptr() + 4 * off, 3, n, pcm.shape[1], det.data_ptr(), n_det.data_ptr(), 4)
+
+    # fill the window first so that every timed call scores complete windows
+    for _ in range(-(-args.template_len // (3 * n)) + 1 + args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    k_ms = {name: round(ctx.timing_read(i)[0], 4) for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
+    ms = dt / args.steps * 1e3
+    res = {"metric": "10ms-frame MFCC+DTW scorings/sec (streaming calls)", "value": S * 3 * n * world * args.steps / dt,
+           "unit": "scorings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%d live streams x %d templates per GPU, %d chunk(s) of 30 ms per call" % (S, T, n),
+                      "real_time_factor": 30.0 * n / ms, "kernels_ms": k_ms}}
+    if rank == 0:
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 

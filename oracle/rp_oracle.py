@@ -72,6 +72,21 @@ def lib():
     L.orc_mlp_forward_bf16.argtypes = L.orc_mlp_forward.argtypes
     L.orc_calc_inverse_similarity.restype = C.c_float
     L.orc_calc_inverse_similarity.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.orc_resampler_new.restype = C.c_void_p
+    L.orc_resampler_new.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.orc_resampler_free.argtypes = [C.c_void_p]
+    L.orc_resampler_cutoff.restype = C.c_float
+    L.orc_resampler_cutoff.argtypes = [C.c_int]
+    L.orc_resampler_in_len.argtypes = [C.c_void_p]
+    L.orc_resampler_out_len.argtypes = [C.c_void_p]
+    L.orc_resampler_filter.argtypes = [C.c_void_p, fp, fp]
+    L.orc_resampler_process.argtypes = [C.c_void_p, fp, fp]
+    L.orc_resample_stream.restype = C.c_long
+    L.orc_resample_stream.argtypes = [fp, C.c_long, C.c_int, fp]
+    L.orc_detector_process_n.restype = C.c_int
+    L.orc_detector_process_n.argtypes = [C.c_void_p, fp, C.c_int, C.POINTER(Detection)]
+    L.orc_detector_process_resampled.restype = C.c_int
+    L.orc_detector_process_resampled.argtypes = [C.c_void_p, C.c_void_p, fp, C.POINTER(Detection)]
     L.orc_rms_level.restype = C.c_float
     L.orc_rms_level.argtypes = [fp, C.c_int]
     L.orc_frontend_stream.argtypes = [fp, C.c_long, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
@@ -149,6 +164,43 @@ def mfcc_stream(pcm, K):
     n = lib().orc_mfcc_stream(_f(pcm), len(pcm), K, _f(out))
     assert n == n_frames, (n, n_frames)
     return out[:n_frames]
+
+
+class Resampler:
+    """rubato FftFixedInOut<f32> as AudioEncoder::new builds it (src/audio/encoder.rs:72-83)."""
+
+    def __init__(self, fs_in, fs_out=16000, chunk_size_in=480):
+        self._h = lib().orc_resampler_new(fs_in, fs_out, chunk_size_in)
+        if not self._h:
+            raise ValueError("Unsupported sample rate, unable to initialize the resampler")
+        self.in_len = lib().orc_resampler_in_len(self._h)
+        self.out_len = lib().orc_resampler_out_len(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_resampler_free(self._h)
+            self._h = None
+
+    def filter_spectrum(self):
+        re, im = np.empty(self.in_len + 1, np.float32), np.empty(self.in_len + 1, np.float32)
+        lib().orc_resampler_filter(self._h, _f(re), _f(im))
+        return re + 1j * im
+
+    def process(self, chunk):
+        c = _c32(chunk)
+        assert c.shape == (self.in_len,)
+        out = np.empty(self.out_len, np.float32)
+        lib().orc_resampler_process(self._h, _f(c), _f(out))
+        return out
+
+
+def resample_stream(pcm, fs_in):
+    """chunks_exact(input frame) -> resample -> concatenate (src/mfcc/wav_file_extractor.rs:83-96)."""
+    pcm = _c32(pcm)
+    r = Resampler(fs_in)
+    out = np.empty((len(pcm) // r.in_len) * r.out_len + 1, np.float32)
+    n = lib().orc_resample_stream(_f(pcm), len(pcm), fs_in, _f(out))
+    return out[:n]
 
 
 def normalize(m):
@@ -342,6 +394,23 @@ class Detector:
         assert s.shape == (480,)
         det = Detection()
         if lib().orc_detector_process(self._h, _f(s), C.byref(det)):
+            return self._out(det)
+        return None
+
+    def process_chunk(self, samples):
+        """One encoded 16 kHz chunk of any length (what process_audio sees behind the resampler)."""
+        s = _c32(samples)
+        det = Detection()
+        if lib().orc_detector_process_n(self._h, _f(s), len(s), C.byref(det)):
+            return self._out(det)
+        return None
+
+    def process_resampled(self, resampler, samples):
+        """One input frame at the resampler's input rate (process_samples::<f32> with fmt.sample_rate != 16000)."""
+        s = _c32(samples)
+        assert s.shape == (resampler.in_len,)
+        det = Detection()
+        if lib().orc_detector_process_resampled(self._h, resampler._h, _f(s), C.byref(det)):
             return self._out(det)
         return None
 

@@ -22,6 +22,9 @@ FILES = [
     "oye_casa_g.rpw", "oye_casa_g_v2.rpw", "alexa.rpw", "ok_casa-tiny.rpw",
     "oye_casa_g_1.wav", "oye_casa_g_2.wav", "oye_casa_g_3.wav", "oye_casa_g_4.wav", "oye_casa_g_5.wav",
     "alexa.wav", "alexa2.wav", "alexa3.wav",
+    # 48 kHz f32 recordings: everything that goes through the resampler (src/audio/encoder.rs:72-83)
+    "oye_casa_real.rpw", "oye_casa_real_1.wav", "oye_casa_real_2.wav", "oye_casa_real_3.wav", "oye_casa_real_4.wav",
+    "oye_casa_real_5.wav", "oye_casa_real_6.wav", "real_sample.wav", "ok_casa.wav",
 ]
 
 # tests/detector.rs -- simulation stream: 5 s zeros + oye_casa_g_1.wav[44:] + 5 s zeros +
@@ -55,6 +58,24 @@ EXPECT = {
                                "avg_threshold": 0.0, "threshold": 0.5, "gain_normalizer": True, "band_pass": True,
                                "low_cutoff": 80.0, "high_cutoff": 500.0, "gains": [0.2, 5.0],
                                "detections": [[None, 0.5775406], [None, 0.5828697]]},
+    },
+    # tests/detector.rs:163-213: 48 kHz f32 wav + 5 s of zeros fed in get_samples_per_frame() chunks (:300-325);
+    # detections are [avg_score, score, counter]
+    "audio_file": {
+        "noise": {"lines": "163-186", "rpw": "oye_casa_real.rpw", "wav": "real_sample.wav", "score_mode": "max",
+                  "avg_threshold": 0.3, "threshold": 0.47, "min_scores": 5,
+                  "detections": [[0.4676845, 0.527971, 24], [0.32865646, 0.48120698, 7], [0.30807483, 0.5164661, 35]]},
+        "noise_filters": {"lines": "188-213", "rpw": "oye_casa_real.rpw", "wav": "real_sample.wav", "score_mode": "max",
+                          "avg_threshold": 0.3, "threshold": 0.49, "min_scores": 5, "gain_normalizer": True,
+                          "min_gain": 0.4, "band_pass": True, "low_cutoff": 210.0, "high_cutoff": 700.0,
+                          "detections": [[0.45496628, 0.5380342, 23], [0.336222, 0.5001262, 5], [0.3049497, 0.5189481, 31]]},
+    },
+    # tests/detector.rs:216-267: the wakeword-model runs on ok_casa.wav (48 kHz): [counter, avg_score, score, label logit, none logit]
+    "audio_file_nn": {
+        "model": {"lines": "216-232", "avg_threshold": 0.0, "detections": [[34, 0.0, 0.9997649, 3.7506533, -16.83091]]},
+        "model_avg": {"lines": "234-250", "avg_threshold": 0.5, "detections": [[34, 0.9997649, 0.9997649, 3.7506533, -16.83091]]},
+        "model_eager": {"lines": "252-267", "avg_threshold": 0.0, "min_scores": 20, "eager": True,
+                        "detections": [[20, 0.0, 0.9992142, 23.990948, 6.0654087]]},
     },
     # tests/detector.rs:216-232: score = calc_inverse_similarity(label, none, score_ref*10)
     "nn_score_formula": {"lines": "216-232", "label_logit": 3.7506533, "none_logit": -16.83091,

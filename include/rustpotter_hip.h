@@ -271,6 +271,20 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
                         const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                         int max_det, float *scores, float *agg);
 
+/* Sample-rate conversion in front of the path: AudioEncoder::new / reencode_to_mono_with_sample_rate
+ * (src/audio/encoder.rs:41-60,63-83), i.e. rubato's FftFixedInOut<f32>::new(sample_rate, 16000, 480, 1) and one
+ * process_into_buffer per input frame.  rp_resampler_frame_lengths gives AudioEncoder's
+ * get_input_frame_length() (per channel) and the number of 16 kHz samples one input frame yields (48 kHz:
+ * 1440 -> 480).  Returns 0, or -1 for a rate the resampler cannot be built for ("Unsupported sample rate,
+ * unable to initialize the resampler", encoder.rs:78). */
+int rp_resampler_frame_lengths(size_t sample_rate, size_t *in_len, size_t *out_len);
+/* Whole streams: pcm [S][pcm_stride] in `fmt`, `channels` interleaved channels (the first one is used,
+ * encoder.rs:42-48), n_samples frames per stream at `sample_rate`; chunks_exact(in_len) frames are converted
+ * (a shorter tail is dropped, src/mfcc/wav_file_extractor.rs:83-96), the stream starts from silence.
+ * out [S][out_stride] receives (n_samples / in_len) * out_len f32 samples at 16 kHz per stream. */
+int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int channels, size_t sample_rate, size_t S,
+                      size_t n_samples, size_t pcm_stride, float *out, size_t out_stride);
+
 /* Live streams: S detectors that each receive n_chunks 30 ms chunks per call -- the batched form of
  * calling Rustpotter::process_samples (src/detector.rs:347-376) once per chunk on S independent
  * instances that share one wakeword and one DetectorConfig.  Everything the reference keeps between
@@ -315,7 +329,7 @@ int rp_synth_pcm_batch(rp_ctx *ctx, uint64_t seed, uint64_t first_stream, size_t
 
 /* Average duration in ms of the launches of one kernel since the last reset, timed
  * with hipEvents on the launch stream (used by bench.py's roofline block).
- * kernel: 0 mfcc, 1 dtw, 2 aggregate, 3 scan. */
+ * kernel: 0 mfcc, 1 dtw, 2 aggregate, 3 scan, 4 mlp, 5 resample. */
 int rp_ctx_timing_enable(rp_ctx *ctx, int enable);
 int rp_ctx_timing_read(rp_ctx *ctx, int kernel, double *avg_ms, int *launches);
 int rp_ctx_timing_reset(rp_ctx *ctx);

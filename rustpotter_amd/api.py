@@ -100,7 +100,7 @@ SYMBOLS = [
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
-    "rp_stream_batch_chunks_seen",
+    "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
 ]
 
 
@@ -167,6 +167,8 @@ def load_library():
     L.rp_dtw_score_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, C.c_int, vp, vp, C.c_int]
     L.rp_batch_detect.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
+    L.rp_resampler_frame_lengths.argtypes = [C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.rp_resample_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.rp_stream_batch_new.argtypes = [vp, vp, C.POINTER(_DetectorConfig), C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.rp_stream_batch_free.argtypes = [vp]
     L.rp_stream_batch_free.restype = None
@@ -187,6 +189,14 @@ def load_library():
 
 def _err():
     return RustpotterError(load_library().rp_last_error().decode("utf-8", "replace"))
+
+
+def resampler_frame_lengths(sample_rate):
+    """(input frame length per channel, 16 kHz samples it yields) -- AudioEncoder::new, src/audio/encoder.rs:63-83."""
+    a, b = C.c_size_t(), C.c_size_t()
+    if load_library().rp_resampler_frame_lengths(sample_rate, C.byref(a), C.byref(b)) < 0:
+        raise _err()
+    return a.value, b.value
 
 
 def mfcc_num_frames(n_samples):
@@ -630,6 +640,29 @@ class BatchContext:
         if r < 0:
             raise _err()
         return (det, n_det, scores, agg) if want_scores else (det, n_det)
+
+    def resample(self, pcm, sample_rate, channels=1):
+        """pcm [S][n_samples*channels] (i8 / i16 / i32 / f32, interleaved) at sample_rate -> [S][n_out] f32 at 16 kHz."""
+        import numpy as np
+        assert self.host
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        S, N = pcm.shape
+        n = N // channels
+        fi, fo = resampler_frame_lengths(sample_rate)
+        n_out = (n // fi) * fo
+        out = np.empty((S, n_out), np.float32)
+        if self._L.rp_resample_batch(self._h, pcm.ctypes.data, fmt, channels, sample_rate, S, n, N, out.ctypes.data, n_out) < 0:
+            raise _err()
+        return out
+
+    def resample_dev(self, pcm_ptr, fmt, channels, sample_rate, S, n, stride, out_ptr, out_stride):
+        if self._L.rp_resample_batch(self._h, pcm_ptr, fmt, channels, sample_rate, S, n, stride, out_ptr, out_stride) < 0:
+            raise _err()
 
     def batch_detect_dev(self, pcm_ptr, S, N, stride, templates, detector_config, det_ptr, n_det_ptr, max_det,
                          scores_ptr=None, agg_ptr=None):

@@ -151,16 +151,35 @@ struct Cbor {
 bool compute_wav_mfccs(Ctx *ctx, const uint8_t *buf, size_t len, int K, std::vector<float> *mfcc, int *frames, float *rms_level) {
     Wav w; std::string err;
     if (!parse_wav(buf, len, &w, &err)) { set_last_error(err); return false; }
-    if (w.rate != 16000) { set_last_error("Unsupported sample rate, unable to initialize the resampler"); return false; }
-    const size_t n = (w.mono.size() / 480) * 480;  // chunks_exact: a tail shorter than 30 ms is dropped
+    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return false;
+    // encode_samples, :71-96: chunks_exact(input frame) -> resample -> RMS of every encoded buffer -> concatenate
+    size_t enc_chunk = 480;
+    if (w.rate != 16000) {
+        const Resampler *rs = ctx->resampler_for(w.rate);
+        if (!rs) return false;
+        const size_t fi = (size_t)rs->dev.fi, fo = (size_t)rs->dev.fo, nch = w.mono.size() / fi;
+        std::vector<float> enc(nch * fo);
+        if (nch) {
+            DevBuf din, dxs, dout;
+            if (!din.reserve(nch * fi * 4) || !dxs.reserve((1 + nch) * fi * 4 + 64) || !dout.reserve(nch * fo * 4)) return false;
+            if (!hip_ok(hipMemcpyAsync(din.p, w.mono.data(), nch * fi * 4, hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync") ||
+                !hip_ok(launch_resample_stage(ctx->stream, din.p, 3, 1, 1, nch, (int)fi, nch * fi, nullptr, dxs.as<float>()), "resample_stage_kernel") ||
+                !hip_ok(launch_resample(ctx->stream, rs->dev, dxs.as<float>(), 1, nch, dout.as<float>(), nch * fo), "resample_mfma_kernel") ||
+                !hip_ok(hipMemcpyAsync(enc.data(), dout.p, nch * fo * 4, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync") ||
+                !hip_ok(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize"))
+                return false;
+        }
+        w.mono.swap(enc);
+        enc_chunk = fo;
+    }
     std::vector<float> rms;
-    for (size_t c = 0; c + 480 <= n; c += 480) rms.push_back(rms_level_of(&w.mono[c], 480));
+    for (size_t c = 0; c + enc_chunk <= (w.mono.size() / enc_chunk) * enc_chunk; c += enc_chunk) rms.push_back(rms_level_of(&w.mono[c], enc_chunk));
     if (!rms.empty()) { std::sort(rms.begin(), rms.end()); *rms_level = rms[rms.size() / 2]; }  // :54-58
+    const size_t n = (w.mono.size() / 480) * 480;  // chunks_exact(output frame): a tail shorter than 30 ms is dropped
     const size_t nf = n >= 480 ? 3 * (n / 480) - 3 : 0;
     *frames = (int)nf;
     mfcc->assign(nf * K, 0.f);
     if (nf == 0) return true;
-    if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return false;
     const MfccTablesDev *tb = ctx->tables_for(K);
     if (!tb) return false;
     DevBuf dp, dm;

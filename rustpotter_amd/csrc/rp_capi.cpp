@@ -435,6 +435,45 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
     });
 }
 
+int rp_resampler_frame_lengths(size_t sample_rate, size_t *in_len, size_t *out_len) {
+    return guarded([&]() -> int {
+        if (!resampler_frame_lengths(sample_rate, in_len, out_len)) {
+            set_last_error("Unsupported sample rate, unable to initialize the resampler");
+            return -1;
+        }
+        return 0;
+    });
+}
+
+int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int channels, size_t sample_rate, size_t S,
+                      size_t n_samples, size_t pcm_stride, float *out, size_t out_stride) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        if (channels < 1) { set_last_error("Unsupported channel count"); return -1; }
+        if (pcm_stride < n_samples * (size_t)channels) { set_last_error("pcm_stride smaller than n_samples * channels"); return -1; }
+        const Resampler *rs = c->resampler_for(sample_rate);
+        if (!rs) return -1;
+        const size_t n_chunks = n_samples / (size_t)rs->dev.fi, n_out = n_chunks * (size_t)rs->dev.fo;
+        if (out_stride < n_out) { set_last_error("out_stride smaller than the resampled length"); return -1; }
+        if (S == 0 || n_chunks == 0) return 0;
+        Staged sg(c);
+        const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
+        float *dout = static_cast<float *>(sg.out(out, S * out_stride * sizeof(float), c->stage_out));
+        if (!dp || !dout) return -1;
+        if (!c->ws_resample.reserve(S * (1 + n_chunks) * (size_t)rs->dev.fi * sizeof(float) + 64)) return -1;
+        float *xs = c->ws_resample.as<float>();
+        if (!hip_ok(launch_resample_stage(c->stream, dp, (int)fmt, channels, S, n_chunks, rs->dev.fi, pcm_stride, nullptr, xs), "resample_stage_kernel")) return -1;
+        c->time_begin(kKernelResample);
+        bool ok = hip_ok(launch_resample(c->stream, rs->dev, xs, S, n_chunks, dout, out_stride), "resample_mfma_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        if (!sg.back(out, dout, S * out_stride * sizeof(float)) || !sg.finish()) return -1;
+        return 0;
+    });
+}
+
 int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_config *config, size_t S,
                         size_t max_chunks_per_call, rp_stream_batch **out) {
     return guarded([&]() -> int {

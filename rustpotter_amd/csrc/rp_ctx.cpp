@@ -61,6 +61,14 @@ template <class T> static bool upload(T **dst, const std::vector<T> &src) {
     return hip_ok(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(table)");
 }
 
+const Resampler *Ctx::resampler_for(size_t fs_in) {
+    auto it = resamplers.find(fs_in);
+    if (it != resamplers.end()) return it->second.get();
+    std::unique_ptr<Resampler> r(Resampler::create(this, fs_in));
+    if (!r) return nullptr;
+    return (resamplers[fs_in] = std::move(r)).get();
+}
+
 const MfccTablesDev *Ctx::tables_for(int K) {
     auto it = tables.find(K);
     if (it != tables.end()) return &it->second;

@@ -66,21 +66,27 @@ bool Rustpotter::Vad::is_voice(const float *mfcc, int K) {
 
 // --------------------------------------------------------------------- lifecycle
 Rustpotter *Rustpotter::create(const rp_config &cfg) {
-    // AudioEncoder::new, src/audio/encoder.rs:63-80: any other rate needs the rubato resampler
-    if (cfg.fmt.sample_rate != 16000) {
+    if (cfg.fmt.channels < 1) { set_last_error("Unsupported channel count"); return nullptr; }
+    std::unique_ptr<Rustpotter> r(new Rustpotter());
+    // AudioEncoder::new, src/audio/encoder.rs:63-80
+    if (!resampler_frame_lengths(cfg.fmt.sample_rate, &r->in_len_, &r->out_len_)) {
         set_last_error("Unsupported sample rate, unable to initialize the resampler");
         return nullptr;
     }
-    if (cfg.fmt.channels < 1) { set_last_error("Unsupported channel count"); return nullptr; }
-    std::unique_ptr<Rustpotter> r(new Rustpotter());
     int dev = 0;
     (void)hipGetDevice(&dev);  // the calling thread's current device (one process per GPU)
     r->ctx_.reset(Ctx::create(dev, RP_CTX_DEVICE_POINTERS));
     if (!r->ctx_) return nullptr;
+    if (cfg.fmt.sample_rate != 16000) {
+        r->rs_ = r->ctx_->resampler_for(cfg.fmt.sample_rate);
+        if (!r->rs_) return nullptr;
+        if (!r->rs_x_.reserve(2 * r->in_len_ * sizeof(float)) || !r->rs_out_.reserve(r->out_len_ * sizeof(float))) return nullptr;
+        if (!hip_ok(hipMemsetAsync(r->rs_x_.p, 0, 2 * r->in_len_ * sizeof(float), r->ctx_->stream), "hipMemsetAsync")) return nullptr;
+    }
+    r->enc_.assign(r->out_len_, 0.f);
     r->fmt_ = cfg.fmt;
     r->det_ = cfg.detector;
     r->filt_ = cfg.filters;
-    r->chunk2_.assign(960, 0.f);
     r->has_vad_ = cfg.detector.vad_mode != RP_VAD_NONE;
     r->vad_.mode_value = cfg.detector.vad_mode == RP_VAD_EASY ? 2.f : cfg.detector.vad_mode == RP_VAD_MEDIUM ? 2.5f : 3.f;
     r->vad_.reset();
@@ -121,7 +127,7 @@ void Rustpotter::reset() {
     has_partial_ = false;
     win_len_ = 0;
     n_hist_ = 0;
-    have_prev_ = false;  // mfcc_extractor.reset()
+    shifts_seen_ = 0;  // mfcc_extractor.reset()
     if (has_vad_) vad_.reset();
 }
 
@@ -263,9 +269,10 @@ bool Rustpotter::remove_wakewords() {  // src/detector.rs:193-202
 int Rustpotter::process_bytes(const uint8_t *bytes, size_t len, Detection *out) {
     if (len != get_bytes_per_frame()) return 0;  // src/detector.rs:235-237
     const size_t ch = fmt_.channels;
-    float buf[480];
+    std::vector<float> mono(in_len_);
+    float *buf = mono.data();
     const bool le = fmt_.endianness == RP_ENDIAN_LITTLE || fmt_.endianness == RP_ENDIAN_NATIVE;  // host is little-endian
-    for (size_t i = 0; i < 480; ++i) {
+    for (size_t i = 0; i < in_len_; ++i) {
         const size_t si = i * ch;  // first channel of each interleaved frame
         switch (fmt_.sample_format) {
         case RP_SAMPLE_I8: buf[i] = (float)(int8_t)bytes[si] / 127.f; break;
@@ -288,7 +295,7 @@ int Rustpotter::process_bytes(const uint8_t *bytes, size_t len, Detection *out) 
         }
         }
     }
-    return process_audio(buf, out);
+    return encode_and_process(buf, out);
 }
 
 template <class T> static inline float sample_into_f32(T v);
@@ -300,9 +307,26 @@ template <> inline float sample_into_f32<float>(float v) { return v; }          
 template <class T> int Rustpotter::process_samples(const T *samples, size_t n, Detection *out) {
     if (n != get_samples_per_frame()) return 0;  // src/detector.rs:249-251
     const size_t ch = fmt_.channels;
-    float buf[480];
-    for (size_t i = 0; i < 480; ++i) buf[i] = sample_into_f32<T>(samples[i * ch]);
-    return process_audio(buf, out);
+    std::vector<float> mono(in_len_);
+    for (size_t i = 0; i < in_len_; ++i) mono[i] = sample_into_f32<T>(samples[i * ch]);
+    return encode_and_process(mono.data(), out);
+}
+
+// reencode_to_mono_with_sample_rate, src/audio/encoder.rs:41-60: input that is not 16 kHz goes through the
+// resampler (one launch; the previous input frame stays on the device), then process_audio sees out_len samples
+int Rustpotter::encode_and_process(float *mono, Detection *out) {
+    if (!rs_) return process_audio(mono, in_len_, out);
+    hipStream_t st = ctx_->stream;
+    if (!hip_ok(hipSetDevice(ctx_->device), "hipSetDevice")) return -1;
+    float *x2 = rs_x_.as<float>();
+    if (!hip_ok(hipMemcpyAsync(x2, x2 + in_len_, in_len_ * sizeof(float), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(resampler history)") ||
+        !hip_ok(hipMemcpyAsync(x2 + in_len_, mono, in_len_ * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync(resampler input)") ||
+        !hip_ok(launch_resample(st, rs_->dev, x2, 1, 1, rs_out_.as<float>(), out_len_), "resample_mfma_kernel") ||
+        !hip_ok(hipMemcpyAsync(enc_.data(), rs_out_.p, out_len_ * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(resampled)") ||
+        !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
+        return -1;
+    if (wakewords_.empty()) return 0;  // the encoder runs before process_audio's early return (src/detector.rs:252-254,347-350)
+    return process_audio(enc_.data(), out_len_, out);
 }
 template int Rustpotter::process_samples<int8_t>(const int8_t *, size_t, Detection *);
 template int Rustpotter::process_samples<int16_t>(const int16_t *, size_t, Detection *);
@@ -310,9 +334,9 @@ template int Rustpotter::process_samples<int32_t>(const int32_t *, size_t, Detec
 template int Rustpotter::process_samples<float>(const float *, size_t, Detection *);
 
 // process_audio, src/detector.rs:347-376
-int Rustpotter::process_audio(float *buf, Detection *out) {
+int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
     if (wakewords_.empty()) return 0;
-    rms_level_ = rms_level_of(buf, 480);
+    rms_level_ = rms_level_of(buf, n);
     if (gainf_.enabled) {  // GainNormalizerFilter::filter, gain_normalizer_filter.rs:14-41
         float gain = 1.f;
         if (!std::isnan(gainf_.rms_level_ref) && rms_level_ != 0.f) {
@@ -326,34 +350,43 @@ int Rustpotter::process_audio(float *buf, Detection *out) {
             if (gain < gainf_.min_gain) gain = gainf_.min_gain;
             if (gain > gainf_.max_gain) gain = gainf_.max_gain;
             if (gain != 1.f)
-                for (int i = 0; i < 480; ++i) { float v = buf[i] * gain; if (v < -1.f) v = -1.f; if (v > 1.f) v = 1.f; buf[i] = v; }
+                for (size_t i = 0; i < n; ++i) { float v = buf[i] * gain; if (v < -1.f) v = -1.f; if (v > 1.f) v = 1.f; buf[i] = v; }
         }
         gain_ = gain;
     }
     if (bp_.enabled) {  // BandPassFilter::filter, band_pass_filter.rs:19-30
-        for (int i = 0; i < 480; ++i) {
+        for (size_t i = 0; i < n; ++i) {
             float x = buf[i];
             float y = bp_.a0 * x + bp_.a1 * bp_.x1 + bp_.a2 * bp_.x2 - bp_.b1 * bp_.y1 - bp_.b2 * bp_.y2;
             buf[i] = y;
             bp_.x2 = bp_.x1; bp_.x1 = x; bp_.y2 = bp_.y1; bp_.y1 = y;
         }
     }
-    // MfccExtractor::compute: the first chunk after a reset only fills the extractor
-    // (src/mfcc/extractor.rs:69-79); every later chunk yields exactly 3 frames.
-    if (!have_prev_) {
-        std::memcpy(chunk2_.data(), buf, 480 * sizeof(float));
-        have_prev_ = true;
-        return 0;
-    }
-    std::memcpy(chunk2_.data() + 480, buf, 480 * sizeof(float));
+    // MfccExtractor::compute, src/mfcc/extractor.rs:60-79: chunks_exact(160) shifts (a remainder is dropped); after a
+    // reset the first three shifts only fill the extractor, every later shift yields one frame made of the last
+    // three.  The kernel's frame j covers shifts j+1..j+3 of the buffer it is given, so it gets
+    // [one shift of padding | the two buffered shifts | the new shifts] and is asked for the frames that exist.
+    const size_t n_shifts = n / 160;
+    if (n_shifts == 0) return 0;
+    const size_t i0 = shifts_seen_ >= 3 ? 0 : 3 - shifts_seen_;       // first new shift that completes a frame
+    const size_t nfr = n_shifts > i0 ? n_shifts - i0 : 0;             // frames this call
+    const size_t up_len = 480 + n_shifts * 160;
+    if (up_.size() < up_len) up_.resize(up_len, 0.f);
+    std::memcpy(up_.data() + 480, buf, n_shifts * 160 * sizeof(float));
+    auto keep_last_two = [&]() {  // the two newest shifts become the extractor's buffered ones
+        std::memmove(up_.data() + 160, up_.data() + 160 + n_shifts * 160, 320 * sizeof(float));
+        shifts_seen_ = std::min<size_t>(3, shifts_seen_ + n_shifts);
+    };
+    if (nfr == 0) { keep_last_two(); return 0; }
     const int K = K_;
+    const int NF = (int)nfr;
     hipStream_t st = ctx_->stream;
     if (!hip_ok(hipSetDevice(ctx_->device), "hipSetDevice")) return -1;
-    // window history: grow / compact so that 3 more frames fit
-    const size_t want_cap = 4 * std::max<size_t>(max_mfcc_frames_, 64) + 16;
-    if (hist_cap_ < want_cap || n_hist_ + 3 > hist_cap_) {
+    // window history: grow / compact so that the new frames fit
+    const size_t want_cap = 4 * std::max<size_t>(max_mfcc_frames_, 64) + 16 + nfr;
+    if (hist_cap_ < want_cap || n_hist_ + nfr > hist_cap_) {
         const size_t keep = std::min(win_len_, n_hist_);
-        const size_t new_cap = std::max(want_cap, 2 * keep + 16);
+        const size_t new_cap = std::max(want_cap, 2 * keep + 16 + nfr);
         DevBuf nb;
         if (!nb.reserve(new_cap * K * sizeof(float))) return -1;
         if (keep && hist_.p &&
@@ -363,24 +396,23 @@ int Rustpotter::process_audio(float *buf, Detection *out) {
         std::swap(hist_.p, nb.p); std::swap(hist_.cap, nb.cap);
         hist_cap_ = new_cap; n_hist_ = keep;
     }
-    if (!pcm_dev_.reserve(960 * sizeof(float))) return -1;
-    if (!hip_ok(hipMemcpyAsync(pcm_dev_.p, chunk2_.data(), 960 * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync(pcm)")) return -1;
+    if (!pcm_dev_.reserve(up_len * sizeof(float))) return -1;
+    if (!hip_ok(hipMemcpyAsync(pcm_dev_.p, up_.data(), up_len * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync(pcm)")) return -1;
     const MfccTablesDev *tb = ctx_->tables_for(K);
     if (!tb) return -1;
     float *hist = hist_.as<float>();
-    if (!hip_ok(launch_mfcc(st, *tb, pcm_dev_.as<float>(), 1, 960, 960, 0, 3, 3, hist + n_hist_ * K), "mfcc_kernel")) return -1;
-    std::memmove(chunk2_.data(), chunk2_.data() + 480, 480 * sizeof(float));
+    if (!hip_ok(launch_mfcc(st, *tb, pcm_dev_.as<float>(), 1, up_len, up_len, i0, nfr, nfr, hist + n_hist_ * K), "mfcc_kernel")) return -1;
 
-    // which of the 3 new frames complete a window (process_new_mfccs, src/detector.rs:384-395)
+    // which of the new frames complete a window (process_new_mfccs, src/detector.rs:384-395)
     size_t wl = win_len_, first_win = 0;
-    int i0 = -1;
-    for (int i = 0; i < 3; ++i) {
+    int w0 = -1;
+    for (int i = 0; i < NF; ++i) {
         wl += 1;
-        if (wl >= max_mfcc_frames_) { if (i0 < 0) { i0 = i; first_win = n_hist_ + i + 1 - wl; } wl -= 1; }
+        if (wl >= max_mfcc_frames_) { if (w0 < 0) { w0 = i; first_win = n_hist_ + i + 1 - wl; } wl -= 1; }
     }
-    const size_t cnt = i0 < 0 ? 0 : (size_t)(3 - i0);
-    // result buffer: [3][K] frames, then per wakeword its score blocks
-    size_t total = 3 * (size_t)K;
+    const size_t cnt = w0 < 0 ? 0 : (size_t)(NF - w0);
+    // result buffer: [NF][K] frames, then per wakeword its score blocks
+    size_t total = (size_t)NF * (size_t)K;
     for (auto &kv : wakewords_) {
         Wakeword &w = *kv.second;
         if (w.is_model) { w.off_logits = total; total += cnt * w.model.labels.size(); }
@@ -388,9 +420,9 @@ int Rustpotter::process_audio(float *buf, Detection *out) {
     }
     if (!result_dev_.reserve(total * sizeof(float))) return -1;
     float *res = result_dev_.as<float>();
-    if (!hip_ok(hipMemcpyAsync(res, hist + n_hist_ * K, 3 * (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(frames)")) return -1;
+    if (!hip_ok(hipMemcpyAsync(res, hist + n_hist_ * K, (size_t)NF * (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(frames)")) return -1;
     if (cnt) {
-        const size_t frames_valid = n_hist_ + 3;
+        const size_t frames_valid = n_hist_ + nfr;
         for (auto &kv : wakewords_) {
             Wakeword &w = *kv.second;
             if (!w.is_model) {
@@ -418,14 +450,15 @@ int Rustpotter::process_audio(float *buf, Detection *out) {
     result_host_.resize(total);
     if (!hip_ok(hipMemcpyAsync(result_host_.data(), res, total * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(result)")) return -1;
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
+    keep_last_two();  // after the synchronise: the upload above read up_
 
     // .into_iter().find_map(process_new_mfccs), src/detector.rs:372-397
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NF; ++i) {
         const float *frame = result_host_.data() + (size_t)i * K;
         const bool should_run = has_partial_ || (has_vad_ ? vad_.is_voice(frame, K) : true);
         win_len_ += 1; n_hist_ += 1;
         bool fired = false;
-        if (win_len_ >= max_mfcc_frames_ && should_run) fired = run_detection(i - i0, out);
+        if (win_len_ >= max_mfcc_frames_ && should_run) fired = run_detection(i - w0, out);
         if (fired) return 1;  // reset() already cleared the window; the chunk's remaining frames are dropped
         if (win_len_ >= max_mfcc_frames_ && win_len_ > 0) win_len_ -= 1;  // drain(0..1)
     }

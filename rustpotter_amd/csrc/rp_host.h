@@ -77,6 +77,8 @@ struct Ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::map<int, MfccTablesDev> tables;  // by K
+    std::map<size_t, std::unique_ptr<struct Resampler>> resamplers;  // by input sample rate
+    DevBuf ws_resample;
     // timing
     bool timing = false;
     struct Timed { hipEvent_t a, b; int kernel; };
@@ -91,9 +93,19 @@ struct Ctx {
     static Ctx *create(int device, int flags);
     ~Ctx();
     const MfccTablesDev *tables_for(int K);
+    const Resampler *resampler_for(size_t fs_in);  // plans are cached per input rate
     void time_begin(int kernel);
     void time_end();
     void time_collect();
+};
+
+// AudioEncoder's resampler (src/audio/encoder.rs:72-83) as a device-resident linear map, rp_resampler.cpp
+bool resampler_frame_lengths(size_t fs_in, size_t *in_len, size_t *out_len);
+struct Resampler {
+    Ctx *ctx = nullptr;
+    ResamplerDev dev;
+    DevBuf g2t;
+    static Resampler *create(Ctx *ctx, size_t fs_in);
 };
 
 struct Templates {
@@ -133,7 +145,7 @@ public:
     bool add_wakeword_from_file(const std::string &key, const std::string &path);
     bool remove_wakeword(const std::string &key);
     bool remove_wakewords();
-    size_t get_samples_per_frame() const { return 480 * (size_t)fmt_.channels; }
+    size_t get_samples_per_frame() const { return in_len_ * (size_t)fmt_.channels; }  // AudioEncoder::get_input_frame_length
     size_t get_bytes_per_frame() const;
     const Detection *get_partial_detection() const { return has_partial_ ? &partial_ : nullptr; }
     float get_rms_level() const { return rms_level_; }
@@ -148,7 +160,8 @@ public:
 
 private:
     Rustpotter() = default;
-    int process_audio(float *buf480, Detection *out);
+    int encode_and_process(float *mono, Detection *out);   // resample (if any) -> process_audio
+    int process_audio(float *buf, size_t n, Detection *out);
     void on_wakeword_change();
     bool add_wakeword_ref(const std::string &key, WakewordRefData &&ref);
     bool add_wakeword_model(const std::string &key, WakewordModelData &&model);
@@ -162,9 +175,15 @@ private:
     rp_filters_config filt_{};
     std::vector<std::pair<std::string, std::unique_ptr<Wakeword>>> wakewords_;  // insertion order
     int K_ = 0;
-    // extractor state (src/mfcc/extractor.rs:14, :66-79): one buffered 30 ms chunk
-    bool have_prev_ = false;
-    std::vector<float> chunk2_;  // [960] previous + current chunk
+    // AudioEncoder (src/audio/encoder.rs): frame lengths and, for input that is not 16 kHz, the resampler
+    // plan with the previous input frame kept on the device
+    size_t in_len_ = 480, out_len_ = 480;
+    const Resampler *rs_ = nullptr;
+    DevBuf rs_x_, rs_out_;       // [2*in_len] previous | current input frame; [out_len]
+    std::vector<float> enc_;     // the encoded (16 kHz) chunk on the host
+    // extractor state (src/mfcc/extractor.rs:14, :66-79): the last two 10 ms shifts and how many are buffered
+    size_t shifts_seen_ = 0;     // capped at 3: a frame is emitted from the 4th shift on
+    std::vector<float> up_;      // [160 pad | 2 buffered shifts | new shifts] staged for the MFCC kernel
     // audio_mfcc_window (src/detector.rs:69): device history + explicit length
     DevBuf hist_;                // [hist_cap][K]
     size_t hist_cap_ = 0, n_hist_ = 0, win_len_ = 0, max_mfcc_frames_ = 0;

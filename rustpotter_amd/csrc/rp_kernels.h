@@ -50,7 +50,13 @@ struct TemplatesDev {
     int class_count[3] = {0, 0, 0};  // chunks per class (class 2 includes the avg chunk if has_avg)
 };
 
-enum KernelId { kKernelMfcc = 0, kKernelDtw = 1, kKernelAggregate = 2, kKernelScan = 3, kKernelMlp = 4, kKernelCount = 5 };
+enum KernelId { kKernelMfcc = 0, kKernelDtw = 1, kKernelAggregate = 2, kKernelScan = 3, kKernelMlp = 4, kKernelResample = 5, kKernelCount = 6 };
+
+// Sample-rate converter plan (rp_resampler.cpp): out[j] = sum_n x2[n] * g2t[j][n], x2 = previous | current input frame
+struct ResamplerDev {
+    int fs_in = 0, fi = 0, fo = 0, kpad = 0;  // input rate, input / output frame length, 2*fi rounded up to 16
+    const float *g2t = nullptr;                // [fo][kpad]
+};
 
 struct ScanConfig {
     float threshold, avg_threshold;
@@ -91,6 +97,13 @@ hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const
 hipError_t launch_frontend(hipStream_t st, const void *pcm, int fmt, size_t S, size_t n_samples, size_t pcm_stride, int gain_on,
                            float rms_level_ref, float min_gain, float max_gain, int window_size, int band_pass, float a0,
                            float a1, float a2, float b1, float b2, float *ring, float *rms, float *gains, float *out,
+                           size_t out_stride);
+
+// Resampler front-end.  Stage: decode + first channel + history -> xs [S][(1+n_chunks)*fi] f32 (prev [S][fi] or
+// nullptr = silence before the stream); resample: xs -> out [S][n_chunks*fo].
+hipError_t launch_resample_stage(hipStream_t st, const void *pcm, int fmt, int channels, size_t S, size_t n_chunks, int fi,
+                                 size_t pcm_stride, const float *prev, float *xs);
+hipError_t launch_resample(hipStream_t st, const ResamplerDev &rs, const float *xs, size_t S, size_t n_chunks, float *out,
                            size_t out_stride);
 
 // streaming batches (state carried between calls; rp_stream.cpp)

@@ -1107,6 +1107,147 @@ hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const
     return hipGetLastError();
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------- resampler
+// rubato FftFixedInOut (src/audio/encoder.rs:72-83) as a fixed linear map per output frame, see rp_resampler.cpp:
+//   out[s][c*fo + j] = sum_{n < 2*fi} xs[s][c*fi + n] * g2t[j][n]
+// (xs holds one history frame in front of the stream).  A [units x 2*fi] x [2*fi x fo] product in f32 on the
+// matrix cores: a wave owns 16 consecutive (stream, frame) units and all fo output columns (NT tiles of 16),
+// the workgroup stages the matrix in k-groups of 16 through LDS, double buffered.
+template <class TIN>
+__global__ __launch_bounds__(256) void resample_stage_kernel(const TIN *__restrict__ pcm, int channels, size_t S, size_t n_new, int fi,
+                                                             size_t pcm_stride, const float *__restrict__ prev, float *__restrict__ xs) {
+    const size_t pitch = (size_t)fi + n_new, total = S * pitch;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t s = i / pitch, k = i - s * pitch;
+        float v;
+        if (k < (size_t)fi) v = prev ? prev[s * fi + k] : 0.f;
+        else v = SampleIn<TIN>::cvt(pcm[s * pcm_stride + (k - fi) * channels]);  // reencode_to_mono: chunk[0] of every frame
+        xs[i] = v;
+    }
+}
+
+hipError_t launch_resample_stage(hipStream_t st, const void *pcm, int fmt, int channels, size_t S, size_t n_chunks, int fi,
+                                 size_t pcm_stride, const float *prev, float *xs) {
+    if (S == 0) return hipSuccess;
+    const size_t n_new = n_chunks * (size_t)fi;
+    size_t blocks = (S * (fi + n_new) + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    switch (fmt) {
+    case 0: hipLaunchKernelGGL(resample_stage_kernel<int8_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int8_t *>(pcm), channels, S, n_new, fi, pcm_stride, prev, xs); break;
+    case 1: hipLaunchKernelGGL(resample_stage_kernel<int16_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int16_t *>(pcm), channels, S, n_new, fi, pcm_stride, prev, xs); break;
+    case 2: hipLaunchKernelGGL(resample_stage_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int32_t *>(pcm), channels, S, n_new, fi, pcm_stride, prev, xs); break;
+    case 3: hipLaunchKernelGGL(resample_stage_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(pcm), channels, S, n_new, fi, pcm_stride, prev, xs); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+constexpr int kRsWaves = 4, kRsKG = 16, kRsPitch = kRsKG + 4;
+
+template <int NT>
+__global__ __launch_bounds__(64 * kRsWaves) void resample_mfma_kernel(const float *__restrict__ xs, size_t xs_pitch, size_t n_units,
+                                                                      unsigned n_chunks, int fi, int kpad,
+                                                                      const float *__restrict__ g2t, float *__restrict__ out,
+                                                                      size_t out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int FO = 16 * NT;
+    constexpr int BUF = FO * kRsPitch;                 // floats per staged k-group
+    constexpr int NV = (FO * (kRsKG / 4) + 64 * kRsWaves - 1) / (64 * kRsWaves);
+    float *wbuf = reinterpret_cast<float *>(smem);     // [2][FO][kRsPitch]
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, li = l & 15, lk = l >> 4;
+    const size_t u0 = ((size_t)blockIdx.x * kRsWaves + wave) * 16;
+    size_t u = u0 + li;
+    if (u >= n_units) u = n_units - 1;                 // rows past the end recompute the last unit; dropped below
+    const size_t su = u / n_chunks, cu = u - su * n_chunks;
+    const float *xr = xs + su * xs_pitch + cu * (size_t)fi;
+    const int k_real = 2 * fi;
+    const bool vec = (fi & 3) == 0 && (xs_pitch & 3) == 0;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 wreg[NV];
+    auto wload = [&](int g) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = threadIdx.x + v * 64 * kRsWaves;
+            const int o = i / (kRsKG / 4), c = i - o * (kRsKG / 4);
+            if (o < FO) wreg[v] = *reinterpret_cast<const float4 *>(g2t + (size_t)o * kpad + g * kRsKG + 4 * c);
+        }
+    };
+    auto wstore = [&](float *dst) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = threadIdx.x + v * 64 * kRsWaves;
+            const int o = i / (kRsKG / 4), c = i - o * (kRsKG / 4);
+            if (o < FO) *reinterpret_cast<float4 *>(dst + o * kRsPitch + 4 * c) = wreg[v];
+        }
+    };
+    const int ngrp = kpad / kRsKG;
+    wload(0);
+    wstore(wbuf);
+    __syncthreads();
+    for (int g = 0; g < ngrp; ++g) {
+        const float *cur = wbuf + (g & 1) * BUF;
+        if (g + 1 < ngrp) wload(g + 1);
+        const int k0 = g * kRsKG + 4 * lk;
+        float4 a;
+        if (vec) a = k0 + 3 < k_real ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        else {
+            a.x = k0 + 0 < k_real ? xr[k0 + 0] : 0.f; a.y = k0 + 1 < k_real ? xr[k0 + 1] : 0.f;
+            a.z = k0 + 2 < k_real ? xr[k0 + 2] : 0.f; a.w = k0 + 3 < k_real ? xr[k0 + 3] : 0.f;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const float4 b = *reinterpret_cast<const float4 *>(cur + (16 * n + li) * kRsPitch + 4 * lk);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[n], 0, 0, 0);
+        }
+        if (g + 1 < ngrp) wstore(wbuf + ((g + 1) & 1) * BUF);
+        __syncthreads();
+    }
+    // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t ue = u0 + 4 * lk + e;
+        if (ue >= n_units) continue;
+        const size_t s = ue / n_chunks, c = ue - s * n_chunks;
+        float *dst = out + s * out_stride + c * (size_t)FO + li;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dst[16 * n] = acc[n][e];
+    }
+}
+
+template <int NT>
+static hipError_t launch_resample_t(hipStream_t st, const ResamplerDev &rs, const float *xs, size_t S, size_t n_chunks, float *out,
+                                    size_t out_stride) {
+    const size_t units = S * n_chunks;
+    const size_t blocks = (units + 16 * kRsWaves - 1) / (16 * kRsWaves);
+    if (blocks > 0x7fffffffULL || n_chunks > 0xffffffffULL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)2 * 16 * NT * kRsPitch * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(resample_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(64 * kRsWaves), lds, st, xs, (1 + n_chunks) * (size_t)rs.fi,
+                       units, (unsigned)n_chunks, rs.fi, rs.kpad, rs.g2t, out, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_resample(hipStream_t st, const ResamplerDev &rs, const float *xs, size_t S, size_t n_chunks, float *out,
+                           size_t out_stride) {
+    if (S == 0 || n_chunks == 0) return hipSuccess;
+    if (rs.fo == 480) return launch_resample_t<30>(st, rs, xs, S, n_chunks, out, out_stride);
+    if (rs.fo == 640) return launch_resample_t<40>(st, rs, xs, S, n_chunks, out, out_stride);
+    return hipErrorInvalidValue;
+}
+
 // ------------------------------------------------------------- streaming batches
 // State of one live stream between rp_stream_batch_process calls: the detector's countdown / partial
 // detection / window bookkeeping (src/detector.rs:62-79) in absolute frame numbers, and the VadDetector.
@@ -1526,7 +1667,6 @@ hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, co
 //  bf16 variant: v_mfma_f32_16x16x32_bf16, inputs rounded to bf16 (RNE) in registers, f32 accumulate.
 // The tail layers (<= 130 x 32 weights) run per row from LDS.  HBM-bound by construction: 4*in bytes
 // per row against 2*in*N1 flops (12 480 B/row, ceiling 0.64 G rows/s at 8 TB/s).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kMlpWaves = 8;
 constexpr int kMlpRowsPerWave = 16;

@@ -327,6 +327,8 @@ def test_rustpotter_api_behaviour(ra):
         rp.add_wakeword_from_file("x", os.path.join(G, "missing.rpw"))
     assert rp.remove_wakeword("a") and not rp.remove_wakeword("a") and not rp.remove_wakewords()
     c.fmt.sample_rate = 48000
+    assert ra.Rustpotter.new(c).get_samples_per_frame() == 1440  # resampled input: 30 ms frames at the input rate
+    c.fmt.sample_rate = 0
     with pytest.raises(ra.RustpotterError, match="Unsupported sample rate"):
         ra.Rustpotter.new(c)
 
@@ -612,6 +614,144 @@ def test_build_wakeword_ref_matches_reference_file(ra, ctx, rpw, wavs, tmp_path)
     assert len(dets) == len(e["detections"])
     for d, (gavg, gscore) in zip(dets, e["detections"]):
         assert abs(d.score - np.float32(gscore)) <= 2e-5 * gscore and abs(d.avg_score - np.float32(gavg)) <= 1e-4 * gavg
+
+
+# ---------------------------------------------------------------- resampler
+def _audio_scale_close(got, ref, tol=4e-6):
+    """resampled audio: |d| <= tol * max|ref|.  Both sides round to f32 along ~3 000-term sums (the oracle its
+    spectra, the kernel its accumulator); measured max 2.1e-6, rms 4e-7 of the peak (tools/probe_resample_err.py)."""
+    scale = max(float(np.abs(ref).max()), 1e-3)
+    return float(np.abs(got - ref).max()) <= tol * scale
+
+
+def test_resampler_frame_lengths(ra):
+    for fs, lens in {48000: (1440, 480), 44100: (1323, 480), 32000: (960, 480), 8000: (240, 480), 16000: (480, 480),
+                     22050: (882, 640), 11025: (441, 640), 96000: (2880, 480)}.items():
+        assert ra.resampler_frame_lengths(fs) == lens
+        if fs != 16000:
+            r = orc.Resampler(fs)
+            assert (r.in_len, r.out_len) == lens
+    with pytest.raises(ra.RustpotterError, match="Unsupported sample rate"):
+        ra.resampler_frame_lengths(0)
+
+
+@pytest.mark.parametrize("fs", [48000, 44100, 8000, 22050, 32000])
+def test_resample_batch_matches_oracle(ra, ctx, fs):
+    """rp_resample_batch (one f32 MFMA product per output frame) against the oracle's frame-by-frame
+    FFT / overlap-add restatement of rubato, several rates (480- and 640-sample output frames, up- and
+    down-sampling, a matrix depth that is not a multiple of 16), ragged tail dropped."""
+    fi, fo = ra.resampler_frame_lengths(fs)
+    rng = np.random.default_rng(fs)
+    n = fi * 7 + 123
+    t = np.arange(n)
+    pcm = np.stack([rng.uniform(-0.5, 0.5, n), 0.3 * np.sin(2 * np.pi * 440.0 * t / fs) + 0.01 * rng.standard_normal(n),
+                    np.where((t // 500) % 2 == 0, 0.25, -0.25)]).astype(np.float32)
+    got = ctx.resample(pcm, fs)
+    assert got.shape == (3, 7 * fo)
+    for s in range(3):
+        ref = orc.resample_stream(pcm[s], fs)
+        assert ref.shape == got[s].shape
+        assert _audio_scale_close(got[s], ref)
+
+
+def test_resample_batch_formats_and_channels(ra, ctx):
+    """i16 stereo in, first channel used (reencode_to_mono, src/audio/encoder.rs:42-48), decoded like Sample::into_f32."""
+    rng = np.random.default_rng(4)
+    n = 1440 * 5
+    l = rng.integers(-20000, 20000, n).astype(np.int16)
+    r = rng.integers(-20000, 20000, n).astype(np.int16)
+    inter = np.stack([l, r], axis=1).reshape(1, -1)
+    got = ctx.resample(inter, 48000, channels=2)
+    ref = orc.resample_stream(l.astype(np.float32) / np.float32(32767.0), 48000)
+    assert got.shape == (1, len(ref)) and _audio_scale_close(got[0], ref)
+    with pytest.raises(ra.RustpotterError, match="Unsupported sample rate"):
+        ctx.resample(np.zeros((1, 1000), np.float32), 44101)  # coprime with 16 kHz: a 16 000-sample output frame
+
+
+def test_resample_many_streams(ra, ctx):
+    S, fs = 700, 48000
+    pcm = ctx.synth_pcm(SEED, 0, S, 1440 * 9)
+    got = ctx.resample(pcm, fs)
+    for s in (0, 1, 63, 64, 333, 699):
+        assert _audio_scale_close(got[s], orc.resample_stream(pcm[s], fs))
+
+
+def test_build_wakeword_ref_from_48k_recordings(ra, ctx, tmp_path):
+    """tests/wakeword.rs:57-71 on the device: six 48 kHz f32 wavs -> resample -> MFCC -> normalise -> average;
+    against the .rpw the reference wrote from the same files (4 680 MFCC values, average, rms level)."""
+    gold = rpw_py.load_rpw(os.path.join(G, "oye_casa_real.rpw"))
+    wavs = ["oye_casa_real_%d.wav" % i for i in range(1, 7)]
+    data = ctx.build_wakeword_ref(gold["name"], {w: open(os.path.join(G, w), "rb").read() for w in wavs}, 5)
+    path = tmp_path / "built.rpw"
+    path.write_bytes(data)
+    built = rpw_py.load_rpw(str(path))
+    assert abs(built["rms_level"] - gold["rms_level"]) <= 1e-6 * gold["rms_level"]  # an RMS of resampled audio: 1 ulp off
+    assert set(built["samples_features"]) == set(gold["samples_features"])
+    for k, ref in gold["samples_features"].items():
+        got = built["samples_features"][k]
+        assert got.shape == ref.shape
+        assert np.all(np.abs(got - ref) <= 1e-5 * np.maximum(np.abs(ref), 1.0) + 3e-5)
+    assert built["avg_features"].shape == gold["avg_features"].shape
+    assert np.abs(built["avg_features"] - gold["avg_features"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("case", sorted(EXP["audio_file"].keys()))
+def test_rustpotter_api_goldens_48k_recording(ra, case):
+    """tests/detector.rs:163-213 through the drop-in API: config.fmt = the wav's spec (48 kHz f32), samples fed
+    in get_samples_per_frame() = 1 440 chunks, 5 s of zeros appended; avg_score / score / counter of the three
+    detections as asserted by the reference."""
+    e = EXP["audio_file"][case]
+    pcm, sr, ch = rpw_py.read_wav(os.path.join(G, e["wav"]))
+    pcm = np.concatenate([pcm, np.zeros(sr * 5, np.float32)])
+    cfg = _make_config(ra, e)
+    cfg.fmt.sample_rate, cfg.fmt.sample_format, cfg.fmt.channels = sr, ra.SampleFormat.F32, ch
+    cfg.detector.min_scores = e["min_scores"]
+    if "min_gain" in e:
+        cfg.filters.gain_normalizer.min_gain = e["min_gain"]
+    rp = ra.Rustpotter.new(cfg)
+    rp.add_wakeword_from_file("wakeword", os.path.join(G, e["rpw"]))
+    n = rp.get_samples_per_frame()
+    assert n == 1440 and rp.get_bytes_per_frame() == 1440 * 4
+    dets = [d for d in (rp.process_samples(pcm[i:i + n].copy()) for i in range(0, len(pcm) - n + 1, n)) if d is not None]
+    assert len(dets) == len(e["detections"])
+    for d, (avg, score, counter) in zip(dets, e["detections"]):
+        assert d.counter == counter
+        assert abs(d.avg_score - np.float32(avg)) <= 1e-5 * avg and abs(d.score - np.float32(score)) <= 1e-5 * score
+
+
+def test_rustpotter_api_22k_input_four_shifts_per_call(ra):
+    """22.05 kHz input: 882 samples in, 640 out = four 10 ms shifts per call (one frame from the first call after
+    a reset, four from every later one) -- the chunked detector against the oracle's, detection for detection."""
+    e = EXP["simulation"]["max"]
+    base = simstream.i16_to_f32(simstream.simulation_stream_i16())
+    # a 22.05 kHz rendition of the simulation stream (linear interpolation is good enough: both sides get the same input)
+    t = np.arange(int(len(base) * 22050 / 16000)) * (16000.0 / 22050.0)
+    x = np.interp(t, np.arange(len(base)), base).astype(np.float32)
+    # no digital silence: frames made of nothing but the resampler's ringing (1e-9 of full scale) have log-mel
+    # values decided by rounding and are not comparable between two implementations
+    x += np.random.default_rng(8).standard_normal(len(x)).astype(np.float32) * np.float32(2e-4)
+    cfg = _make_config(ra, e)
+    cfg.fmt.sample_rate, cfg.fmt.sample_format = 22050, ra.SampleFormat.F32
+    rp = ra.Rustpotter.new(cfg)
+    rp.add_wakeword_from_file("w", os.path.join(G, e["rpw"]))
+    n = rp.get_samples_per_frame()
+    assert n == 882
+    w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+    d = orc.Detector(avg_threshold=e["avg_threshold"], threshold=e["threshold"], score_mode=e["score_mode"])
+    d.add_ref(w)
+    rs = orc.Resampler(22050)
+    got, ref = [], []
+    for i in range(0, len(x) - n + 1, n):
+        a = rp.process_samples(x[i:i + n].copy())
+        b = d.process_resampled(rs, x[i:i + n])
+        if a is not None:
+            got.append((i // n, a.counter, a.score, a.avg_score))
+        if b is not None:
+            ref.append((i // n, b["counter"], b["score"], b["avg_score"]))
+    assert len(ref) >= 2 and len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert g[0] == r[0] and g[1] == r[1]
+        assert abs(g[2] - r[2]) <= 1e-5 * r[2] and abs(g[3] - r[3]) <= 1e-5 * r[3]
 
 
 def test_build_wakeword_ref_errors_and_options(ra, ctx, tmp_path):

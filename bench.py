@@ -39,9 +39,10 @@ def main():
     ap.add_argument("--mfcc-size", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--mode", choices=["dtw", "mlp", "stream"], default="dtw",
+    ap.add_argument("--mode", choices=["dtw", "mlp", "stream", "resample"], default="dtw",
                     help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward; "
-                         "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process)")
+                         "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process); "
+                         "resample: 48 kHz -> 16 kHz front-end alone (rp_resample_batch)")
     ap.add_argument("--chunks-per-call", type=int, default=1)
     ap.add_argument("--mlp-precision", choices=["f32", "bf16"], default="bf16")
     args = ap.parse_args()
@@ -79,6 +80,8 @@ def main():
 
     if args.mode == "stream":
         return bench_stream(args, ra, torch, dist, dev, world, rank, local_rank)
+    if args.mode == "resample":
+        return bench_resample(args, ra, torch, dist, dev, world, rank, local_rank)
 
     S, N, T, L, K = args.streams, args.samples, args.templates, args.template_len, args.mfcc_size
     nf = ra.mfcc_num_frames(N)
@@ -285,6 +288,49 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_resample(args, ra, torch, dist, dev, world, rank, local_rank):
+    """The sample-rate converter in front of the path: S streams of 4 s at 48 kHz f32 -> 16 kHz."""
+    fs = 48000
+    S = min(args.streams, 16384)  # 16384 x 4 s x 48 kHz f32 = 12.6 GB in, 4.2 GB out, + the staged copy
+    fi, fo = ra.resampler_frame_lengths(fs)
+    n = args.samples * 3
+    nch = n // fi
+    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    pcm = torch.empty((S, n), dtype=torch.float32, device=dev)
+    ctx.synth_dev(SEED, 0, S, n, n, pcm.data_ptr())
+    out = torch.empty((S, nch * fo), dtype=torch.float32, device=dev)
+
+    def step():
+        ctx.resample_dev(pcm.data_ptr(), 3, 1, fs, S, n, n, out.data_ptr(), nch * fo)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ms, _n = ctx.timing_read(5)
+    alg = S * nch * (fi + fo) * 4
+    flops = S * nch * 2.0 * (2 * fi) * fo
+    res = {"metric": "resampled 10ms output frames/sec (48 kHz -> 16 kHz)", "value": S * nch * 3 / dt, "unit": "frames/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%d streams x %d samples at 48 kHz f32" % (S, n)},
+           "roofline": {"bound": "mfma", "kernel": "resample_mfma_kernel", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 157.3,
+                        "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 157.3e12, "traffic": None, "avg_launch_ms": ms,
+                        "hbm_GBps_algorithmic": alg / (ms * 1e-3) / 1e9}}
+    if rank == 0:
+        print(json.dumps(res))
 
 
 def bench_mlp(args, ra, torch, dist, dev, world, rank, local_rank):

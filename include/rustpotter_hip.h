@@ -205,6 +205,32 @@ int rp_wakeword_ref_build(rp_ctx *ctx, const char *name, const float *threshold,
                           uint16_t mfcc_size, int rms_from_files, uint8_t **out_rpw, size_t *out_len);
 void rp_buffer_free(uint8_t *buffer);
 
+/* WakewordModelTrain::train_from_buffers (src/wakewords/nn/wakeword_model_train.rs:44-168) followed by
+ * save_to_buffer: trains a wakeword model on the device from labelled wav samples and returns it as .rpw bytes.
+ * A sample's label is the lower-cased text between '[' and ']' in its name ("none" without one).  Features =
+ * the whole-file-normalised MFCC matrix of every sample (any sample rate, like rp_wakeword_ref_build), flattened,
+ * zero-padded / truncated to the longest training sample; network shapes of ModelType Tiny / Small / Medium / Large
+ * (src/wakewords/nn/wakeword_nn.rs:305-389); `epochs` full-batch steps of log_softmax + nll + SGD(learning_rate).
+ * prev_model (NULL = none): an existing model .rpw to continue from -- its labels, type, mfcc_size and train_size
+ * win over the options, as in the reference.  A fresh model's weights are drawn like candle_nn::linear does
+ * (weights N(0, 2/fan_in), biases U(+-1/sqrt(fan_in))) from `seed` (the reference uses the thread RNG).
+ * final_loss: the loss of the last epoch; test_accuracy: share of test samples whose arg-max label is right
+ * (test_model :251-272); either may be NULL.  Errors as the reference: "No training data provided", "No test data
+ * provided", "Your training data need to contain at least two labels", "Forbidden label '...'...". */
+typedef enum { RP_MODEL_TINY = 0, RP_MODEL_SMALL = 1, RP_MODEL_MEDIUM = 2, RP_MODEL_LARGE = 3 } rp_model_type;
+typedef struct {
+    int m_type;            /* rp_model_type */
+    float learning_rate;
+    size_t epochs, test_epochs;   /* test_epochs only paces the reference's progress printing; unused */
+    uint16_t mfcc_size;
+    uint64_t seed;
+} rp_train_options;
+int rp_wakeword_model_train(rp_ctx *ctx, const rp_train_options *options, size_t n_train, const char *const *train_names,
+                            const uint8_t *const *train_wavs, const size_t *train_lens, size_t n_test,
+                            const char *const *test_names, const uint8_t *const *test_wavs, const size_t *test_lens,
+                            const uint8_t *prev_model, size_t prev_model_len, uint8_t **out_rpw, size_t *out_len,
+                            float *final_loss, float *test_accuracy);
+
 /* The audio front-end of Rustpotter::process_audio for whole streams (src/detector.rs:358-371): sample
  * decode, GainNormalizerFilter (src/audio/gain_normalizer_filter.rs:14-55: per 480-sample chunk, gain =
  * round(10*sqrt(ref)/sqrt(mean of the last `window_size` chunk RMS values))/10, clamped, samples clamped to

@@ -561,6 +561,76 @@ static int nn_run_detection(const orc_wakeword *w, int wi, const float *window, 
     return (out->score >= threshold && out->avg_score >= avg_threshold) ? 1 : 0;
 }
 
+/* ------------------------------------------------------------------ NN training */
+/* training_loop, src/wakewords/nn/wakeword_model_train.rs:170-222: `epochs` full-batch steps of
+ *   logits = model.forward(x); log_sm = log_softmax(logits) (x - max - ln(sum(exp(x - max))), candle_nn::ops);
+ *   loss = nll(log_sm, labels) = -mean(log_sm[b][label_b]); SGD: w -= lr * dloss/dw.
+ * candle 0.2.2 is not in the reference tree; its autograd is restated as the closed-form gradients of exactly these
+ * ops (dlogits = (softmax - onehot)/B, ReLU mask on the forward activations).  W/Bv are updated in place; returns
+ * the loss of the last epoch (evaluated before that epoch's update, like the value the reference prints). */
+float orc_mlp_train(const float *x, const int *labels, long B, int n_layers, const int *dims, float *const *W, float *const *Bv,
+                    float lr, int epochs) {
+    float *act[4], *dz[4];
+    for (int l = 0; l < n_layers; ++l) {
+        act[l] = (float *)malloc(sizeof(float) * (size_t)B * dims[l + 1]);
+        dz[l] = (float *)malloc(sizeof(float) * (size_t)B * dims[l + 1]);
+    }
+    const int C = dims[n_layers];
+    float loss = NAN;
+    for (int ep = 0; ep < epochs; ++ep) {
+        for (int l = 0; l < n_layers; ++l) { /* forward, keeping every layer's output */
+            const float *in = l == 0 ? x : act[l - 1];
+            int ni = dims[l], no = dims[l + 1];
+            for (long b = 0; b < B; ++b)
+                for (int o = 0; o < no; ++o) {
+                    float s = 0.f;
+                    for (int i = 0; i < ni; ++i) s += in[b * ni + i] * W[l][(size_t)o * ni + i];
+                    s += Bv[l][o];
+                    if (l + 1 < n_layers && s < 0.f) s = 0.f;
+                    act[l][b * no + o] = s;
+                }
+        }
+        float lsum = 0.f;
+        for (long b = 0; b < B; ++b) {
+            const float *lg = act[n_layers - 1] + b * C;
+            float mx = lg[0];
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, lg[c]);
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += expf(lg[c] - mx);
+            float lse = logf(se);
+            for (int c = 0; c < C; ++c) {
+                float lsm = (lg[c] - mx) - lse;
+                if (c == labels[b]) lsum += -lsm;
+                dz[n_layers - 1][b * C + c] = (expf(lsm) - (c == labels[b] ? 1.f : 0.f)) / (float)B;
+            }
+        }
+        loss = lsum / (float)B;
+        for (int l = n_layers - 1; l >= 0; --l) {
+            const float *in = l == 0 ? x : act[l - 1];
+            int ni = dims[l], no = dims[l + 1];
+            if (l > 0)
+                for (long b = 0; b < B; ++b)
+                    for (int i = 0; i < ni; ++i) {
+                        float s = 0.f;
+                        for (int o = 0; o < no; ++o) s += dz[l][b * no + o] * W[l][(size_t)o * ni + i];
+                        dz[l - 1][b * ni + i] = act[l - 1][b * ni + i] > 0.f ? s : 0.f;
+                    }
+            for (int o = 0; o < no; ++o) {
+                for (int i = 0; i < ni; ++i) {
+                    float g = 0.f;
+                    for (long b = 0; b < B; ++b) g += dz[l][b * no + o] * in[b * ni + i];
+                    W[l][(size_t)o * ni + i] = W[l][(size_t)o * ni + i] - g * lr;
+                }
+                float g = 0.f;
+                for (long b = 0; b < B; ++b) g += dz[l][b * no + o];
+                Bv[l][o] = Bv[l][o] - g * lr;
+            }
+        }
+    }
+    for (int l = 0; l < n_layers; ++l) { free(act[l]); free(dz[l]); }
+    return loss;
+}
+
 /* ---------------------------------------------------------------------- VAD */
 /* src/mfcc/vad.rs:3-50 */
 typedef struct { float mode_value; int index; float window[50]; int voice_countdown; } orc_vad;

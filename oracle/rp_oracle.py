@@ -70,6 +70,8 @@ def lib():
     L.orc_average_step.argtypes = [fp, C.c_int, fp, C.c_int, C.c_int]
     L.orc_mlp_forward.argtypes = [fp, C.c_long, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), fp]
     L.orc_mlp_forward_bf16.argtypes = L.orc_mlp_forward.argtypes
+    L.orc_mlp_train.restype = C.c_float
+    L.orc_mlp_train.argtypes = [fp, ip, C.c_long, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), C.c_float, C.c_int]
     L.orc_calc_inverse_similarity.restype = C.c_float
     L.orc_calc_inverse_similarity.argtypes = [C.c_float, C.c_float, C.c_float]
     L.orc_resampler_new.restype = C.c_void_p
@@ -164,6 +166,28 @@ def mfcc_stream(pcm, K):
     n = lib().orc_mfcc_stream(_f(pcm), len(pcm), K, _f(out))
     assert n == n_frames, (n, n_frames)
     return out[:n_frames]
+
+
+def mlp_train(x, labels, weights, biases, lr, epochs):
+    """Full-batch log_softmax / nll / SGD epochs on an MLP (training_loop of wakeword_model_train.rs); returns
+    (weights, biases, last loss) -- the inputs are not modified."""
+    x = _c32(x)
+    labels = np.ascontiguousarray(labels, np.int32)
+    ws = [np.array(w, np.float32, order="C") for w in weights]
+    bs = [np.array(b, np.float32, order="C") for b in biases]
+    dims = np.array([ws[0].shape[1]] + [w.shape[0] for w in ws], np.int32)
+    n = len(ws)
+    fp = C.POINTER(C.c_float)
+    wp = (fp * n)(*[_f(w) for w in ws])
+    bp = (fp * n)(*[_f(b) for b in bs])
+    loss = lib().orc_mlp_train(_f(x), _i(labels), x.shape[0], n, _i(dims), wp, bp, lr, epochs)
+    return ws, bs, loss
+
+
+def wav_features(pcm_f32, sample_rate, K):
+    """MfccWavFileExtractor::compute_mfccs for already decoded mono samples: resample if needed, MFCC, normalise."""
+    y = _c32(pcm_f32) if sample_rate == 16000 else resample_stream(pcm_f32, sample_rate)
+    return normalize(mfcc_stream(y[:(len(y) // 480) * 480], K))
 
 
 class Resampler:

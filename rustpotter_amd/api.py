@@ -84,6 +84,11 @@ class _Detection(C.Structure):
                 ("gain", C.c_float)]
 
 
+class _TrainOptions(C.Structure):
+    _fields_ = [("m_type", C.c_int), ("learning_rate", C.c_float), ("epochs", C.c_size_t), ("test_epochs", C.c_size_t),
+                ("mfcc_size", C.c_uint16), ("seed", C.c_uint64)]
+
+
 class _BatchDetection(C.Structure):
     _fields_ = [("stream", C.c_int32), ("frame", C.c_int32), ("window", C.c_int32), ("counter", C.c_int32),
                 ("avg_score", C.c_float), ("score", C.c_float)]
@@ -101,6 +106,7 @@ SYMBOLS = [
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
     "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
+    "rp_wakeword_model_train",
 ]
 
 
@@ -167,6 +173,9 @@ def load_library():
     L.rp_dtw_score_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.rp_detect_scan.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_DetectorConfig), C.c_int, vp, C.c_int, vp, vp, C.c_int]
     L.rp_batch_detect.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
+    L.rp_wakeword_model_train.argtypes = [vp, C.POINTER(_TrainOptions), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                          C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
+                                          C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), fp, fp]
     L.rp_resampler_frame_lengths.argtypes = [C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.rp_resample_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.rp_stream_batch_new.argtypes = [vp, vp, C.POINTER(_DetectorConfig), C.c_size_t, C.c_size_t, C.POINTER(vp)]
@@ -554,6 +563,27 @@ class BatchContext:
         data = C.string_at(out, out_len.value)
         self._L.rp_buffer_free(out)
         return data
+
+    def train_wakeword_model(self, train, test, m_type="medium", learning_rate=0.027, epochs=10, test_epochs=10, mfcc_size=16,
+                             seed=1, prev_model=None):
+        """WakewordModel::train_from_buffers + save_to_buffer: train / test = ordered {file name: wav bytes}
+        (label in [brackets]); returns (.rpw bytes, last loss, test accuracy)."""
+        def pack(d):
+            names = [k.encode() for k in d]
+            bufs = [bytes(v) for v in d.values()]
+            n = len(names)
+            return n, (C.c_char_p * n)(*names), (C.c_char_p * n)(*bufs), (C.c_size_t * n)(*[len(b) for b in bufs])
+        ntr, trn, trb, trl = pack(train)
+        nte, ten, teb, tel = pack(test)
+        opt = _TrainOptions({"tiny": 0, "small": 1, "medium": 2, "large": 3}[m_type], learning_rate, epochs, test_epochs, mfcc_size, seed)
+        out, out_len, loss, acc = C.c_void_p(), C.c_size_t(), C.c_float(), C.c_float()
+        if self._L.rp_wakeword_model_train(self._h, C.byref(opt), ntr, trn, trb, trl, nte, ten, teb, tel, prev_model,
+                                           0 if prev_model is None else len(prev_model), C.byref(out), C.byref(out_len),
+                                           C.byref(loss), C.byref(acc)) < 0:
+            raise _err()
+        data = C.string_at(out, out_len.value)
+        self._L.rp_buffer_free(out)
+        return data, loss.value, acc.value
 
     def frontend(self, pcm, filters_config, rms_level_ref, window_size):
         """Decode + gain normaliser + band-pass over whole streams -> (pcm f32, rms, gains)."""

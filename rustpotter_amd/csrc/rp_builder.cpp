@@ -256,4 +256,27 @@ std::vector<uint8_t> serialize_wakeword_ref(const WakewordRefData &r) {
     return c.out;
 }
 
+// WakewordModel through WakewordSave::save_to_buffer (wakeword_model.rs:11-18, TensorData :68-72): the weight
+// bytes are written as a CBOR ARRAY of small integers (serde's Vec<u8>), little-endian f32
+std::vector<uint8_t> serialize_wakeword_model(const WakewordModelData &m) {
+    Cbor c;
+    c.head(5, 6);
+    c.text("labels"); c.head(4, m.labels.size()); for (const std::string &l : m.labels) c.text(l);
+    c.text("train_size"); c.head(0, (uint64_t)m.train_size);
+    c.text("mfcc_size"); c.head(0, (uint64_t)m.mfcc_size);
+    c.text("m_type"); c.text(m.m_type);
+    c.text("weights"); c.head(5, m.weights.size());
+    for (const auto &kv : m.weights) {
+        c.text(kv.first);
+        c.head(5, 3);
+        const std::vector<float> &w = kv.second.second;
+        c.text("bytes"); c.head(4, w.size() * 4);
+        for (float f : w) { uint8_t b[4]; std::memcpy(b, &f, 4); for (int i = 0; i < 4; ++i) c.head(0, b[i]); }
+        c.text("dims"); c.head(4, kv.second.first.size()); for (size_t d : kv.second.first) c.head(0, (uint64_t)d);
+        c.text("d_type"); c.text("f32");
+    }
+    c.text("rms_level"); c.f32(m.rms_level);
+    return c.out;
+}
+
 }  // namespace rp

@@ -232,6 +232,32 @@ int rp_wakeword_ref_build(rp_ctx *ctx, const char *name, const float *threshold,
 }
 void rp_buffer_free(uint8_t *buffer) { std::free(buffer); }
 
+int rp_wakeword_model_train(rp_ctx *ctx, const rp_train_options *options, size_t n_train, const char *const *train_names,
+                            const uint8_t *const *train_wavs, const size_t *train_lens, size_t n_test,
+                            const char *const *test_names, const uint8_t *const *test_wavs, const size_t *test_lens,
+                            const uint8_t *prev_model, size_t prev_model_len, uint8_t **out_rpw, size_t *out_len,
+                            float *final_loss, float *test_accuracy) {
+    return guarded([&]() -> int {
+        *out_rpw = nullptr; *out_len = 0;
+        WakewordModelData prev, m;
+        bool has_prev = false;
+        if (prev_model) {
+            RpwKind kind; WakewordRefData ref; std::string err;
+            if (!parse_rpw(prev_model, prev_model_len, &kind, &ref, &prev, &err)) { set_last_error(err); return -1; }
+            if (kind != RpwKind::Model) { set_last_error("the file to train from is not a wakeword model"); return -1; }
+            has_prev = true;
+        }
+        if (!train_wakeword_model(ctx->impl.get(), *options, n_train, train_names, train_wavs, train_lens, n_test, test_names, test_wavs,
+                                  test_lens, has_prev ? &prev : nullptr, &m, final_loss, test_accuracy)) return -1;
+        std::vector<uint8_t> bytes = serialize_wakeword_model(m);
+        uint8_t *p = static_cast<uint8_t *>(std::malloc(bytes.size()));
+        if (!p) { set_last_error("out of host memory"); return -1; }
+        std::memcpy(p, bytes.data(), bytes.size());
+        *out_rpw = p; *out_len = bytes.size();
+        return 0;
+    });
+}
+
 int rp_frontend_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                       const rp_filters_config *filters, float rms_level_ref, size_t window_size, float *pcm_out,
                       size_t out_stride, float *rms, float *gains) {

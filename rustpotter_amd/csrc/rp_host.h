@@ -56,6 +56,13 @@ bool build_wakeword_ref(Ctx *ctx, const std::string &name, const float *threshol
                         const char *const *sample_names, const uint8_t *const *wavs, const size_t *wav_lens, int mfcc_size,
                         bool rms_median, WakewordRefData *out);
 std::vector<uint8_t> serialize_wakeword_ref(const WakewordRefData &r);
+std::vector<uint8_t> serialize_wakeword_model(const WakewordModelData &m);
+// trainer (rp_train.cpp)
+bool model_dims(int m_type, size_t input_len, int mfcc_size, size_t n_labels, std::vector<int> *dims);
+bool train_wakeword_model(Ctx *ctx, const rp_train_options &opt, size_t n_train, const char *const *train_names,
+                          const uint8_t *const *train_wavs, const size_t *train_lens, size_t n_test, const char *const *test_names,
+                          const uint8_t *const *test_wavs, const size_t *test_lens, const WakewordModelData *prev,
+                          WakewordModelData *out, float *final_loss, float *test_accuracy);
 
 void set_last_error(const std::string &msg);
 bool hip_ok(hipError_t e, const char *what);

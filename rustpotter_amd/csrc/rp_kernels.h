@@ -145,6 +145,11 @@ enum { kMlpF32 = 0, kMlpBf16 = 1 };
 // chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.
 hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out);
 
+// WakewordModelTrain (src/wakewords/nn/wakeword_model_train.rs:204-209): act[l] / dz[l] are [B][dims[l+1]] device buffers
+hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
+                                float *const *Bv, float *const *act);
+hipError_t launch_train_step(hipStream_t st, const float *x, const int32_t *labels, size_t B, int n_layers, const int *dims,
+                             float *const *W, float *const *Bv, float *const *act, float *const *dz, float lr, float *loss_rows);
 hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
                       float *const *Bv, float *scratch0, float *scratch1, float *out);
 

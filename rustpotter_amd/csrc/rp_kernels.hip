@@ -1655,6 +1655,117 @@ hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, co
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------ MLP training
+// WakewordModelTrain's loop (src/wakewords/nn/wakeword_model_train.rs:204-209): full-batch forward,
+// log_softmax + nll (mean over the batch), backward, plain SGD.  The matrices are tiny (tens of recordings x a few
+// thousand features): one thread per result element, reductions along the batch / the layer width in a loop.
+__global__ __launch_bounds__(64) void train_forward_kernel(const float *__restrict__ x, size_t B, int in, int on,
+                                                           const float *__restrict__ W, const float *__restrict__ bias, int relu,
+                                                           float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xr = reinterpret_cast<float *>(smem);
+    const size_t b = blockIdx.x;
+    const int o = blockIdx.y * 64 + threadIdx.x;
+    for (int i = threadIdx.x; i < in; i += 64) xr[i] = x[b * in + i];
+    __syncthreads();
+    if (o >= on) return;
+    const float *w = W + (size_t)o * in;
+    float s = 0.f;
+    for (int i = 0; i < in; ++i) s += xr[i] * w[i];
+    s += bias[o];
+    if (relu && s < 0.f) s = 0.f;
+    out[b * on + o] = s;
+}
+
+// per row: log_softmax (x - max - ln(sum exp(x - max))), loss_row = -log_sm[label], dlogits = (softmax - onehot) / B
+__global__ __launch_bounds__(64) void train_softmax_grad_kernel(const float *__restrict__ logits, const int32_t *__restrict__ labels,
+                                                                size_t B, int C, float *__restrict__ dz, float *__restrict__ loss_rows) {
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float *x = logits + b * C;
+    float mx = x[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    const float lse = logf(se);
+    const int lab = labels[b];
+    for (int c = 0; c < C; ++c) {
+        const float lsm = (x[c] - mx) - lse;
+        if (c == lab) loss_rows[b] = -lsm;
+        dz[b * C + c] = (expf(lsm) - (c == lab ? 1.f : 0.f)) / (float)B;
+    }
+}
+
+// dZprev[b][i] = A_prev[b][i] > 0 ? sum_o dZ[b][o] * W[o][i] : 0     (ReLU backward through the layer's input)
+__global__ __launch_bounds__(256) void train_backprop_kernel(const float *__restrict__ dz, const float *__restrict__ W,
+                                                             const float *__restrict__ a_prev, size_t B, int in, int on,
+                                                             float *__restrict__ dz_prev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (i >= in) return;
+    float s = 0.f;
+    for (int o = 0; o < on; ++o) s += dz[b * on + o] * W[(size_t)o * in + i];
+    dz_prev[b * in + i] = a_prev[b * in + i] > 0.f ? s : 0.f;
+}
+
+// SGD step of one layer: W[o][i] -= lr * sum_b dZ[b][o] * A_in[b][i];  bias[o] -= lr * sum_b dZ[b][o]
+__global__ __launch_bounds__(256) void train_update_kernel(const float *__restrict__ dz, const float *__restrict__ a_in, size_t B,
+                                                           int in, int on, float lr, float *__restrict__ W, float *__restrict__ bias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int o = blockIdx.y;
+    if (i > in) return;  // i == in: the bias column
+    float g = 0.f;
+    if (i < in) {
+        for (size_t b = 0; b < B; ++b) g += dz[b * on + o] * a_in[b * in + i];
+        W[(size_t)o * in + i] = W[(size_t)o * in + i] - g * lr;
+    } else {
+        for (size_t b = 0; b < B; ++b) g += dz[b * on + o];
+        bias[o] = bias[o] - g * lr;
+    }
+}
+
+hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
+                                float *const *Bv, float *const *act) {
+    if (B == 0) return hipSuccess;
+    const float *cur = x;
+    for (int l = 0; l < n_layers; ++l) {
+        dim3 grid((unsigned)B, (unsigned)((dims[l + 1] + 63) / 64));
+        const size_t lds = (size_t)dims[l] * sizeof(float);
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(train_forward_kernel, grid, dim3(64), lds, st, cur, B, dims[l], dims[l + 1], W[l], Bv[l],
+                           l + 1 < n_layers ? 1 : 0, act[l]);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        cur = act[l];
+    }
+    return hipSuccess;
+}
+
+// act[l] = output of layer l (post-ReLU for hidden layers, logits for the last); dz[l] same shapes
+hipError_t launch_train_step(hipStream_t st, const float *x, const int32_t *labels, size_t B, int n_layers, const int *dims,
+                             float *const *W, float *const *Bv, float *const *act, float *const *dz, float lr, float *loss_rows) {
+    if (B == 0) return hipSuccess;
+    hipError_t e = launch_train_forward(st, x, B, n_layers, dims, W, Bv, act);
+    if (e != hipSuccess) return e;
+    const int C = dims[n_layers];
+    hipLaunchKernelGGL(train_softmax_grad_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, act[n_layers - 1], labels, B, C,
+                       dz[n_layers - 1], loss_rows);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const int in = dims[l], on = dims[l + 1];
+        const float *a_in = l == 0 ? x : act[l - 1];
+        if (l > 0) {  // through W_l as it was in the forward pass, before its own update
+            hipLaunchKernelGGL(train_backprop_kernel, dim3((unsigned)((in + 255) / 256), (unsigned)B), dim3(256), 0, st, dz[l], W[l],
+                               act[l - 1], B, in, on, dz[l - 1]);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(train_update_kernel, dim3((unsigned)((in + 1 + 255) / 256), (unsigned)on), dim3(256), 0, st, dz[l], a_in, B, in,
+                           on, lr, W[l], Bv[l]);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // ------------------------------------------------------------------ MLP on MFMA
 // One workgroup = 8 waves = 128 rows; one wave = one 16-row tile x all layer-1 outputs (NT
 // 16-column tiles).  The layer-1 weights are walked in k-groups of 128: the group's [16*NT][128]

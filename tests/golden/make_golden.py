@@ -26,6 +26,9 @@ FILES = [
     "oye_casa_real.rpw", "oye_casa_real_1.wav", "oye_casa_real_2.wav", "oye_casa_real_3.wav", "oye_casa_real_4.wav",
     "oye_casa_real_5.wav", "oye_casa_real_6.wav", "real_sample.wav", "ok_casa.wav",
 ]
+# tests/resources/{train,test}: the labelled files are byte copies of wavs listed above (oye_casa_real_{1,3,4,5}.wav with
+# "[oye casa]" in the name, test/oye_casa_g_2[oye casa].wav); only the noise recordings are new
+TRAIN_FILES = ["train/noise0.wav", "train/noise1.wav", "test/noise3.wav", "test/noise4.wav"]
 
 # tests/detector.rs -- simulation stream: 5 s zeros + oye_casa_g_1.wav[44:] + 5 s zeros +
 # oye_casa_g_2.wav[44:] + 5 s zeros, i16 LE bytes, fed in get_bytes_per_frame() chunks (:361-426)
@@ -83,6 +86,13 @@ EXPECT = {
     # tests/detector.rs:252-267 (eager): logits 23.990948 / 6.0654087 -> 0.9992142
     "nn_score_formula_eager": {"lines": "252-267", "label_logit": 23.990948, "none_logit": 6.0654087,
                                "score_ref": 0.22, "score": 0.9992142},
+    # tests/wakeword.rs:86-98: ModelType::Medium, lr 0.027, 10 epochs, mfcc_size 16 on tests/resources/{train,test}
+    "train": {"lines": "86-98", "m_type": "medium", "learning_rate": 0.027, "epochs": 10, "test_epochs": 10, "mfcc_size": 16,
+              "train": {"noise0.wav": "noise0.wav", "noise1.wav": "noise1.wav",
+                        "oye_casa_real_1[oye casa].wav": "oye_casa_real_1.wav", "oye_casa_real_3[oye casa].wav": "oye_casa_real_3.wav",
+                        "oye_casa_real_4[oye casa].wav": "oye_casa_real_4.wav", "oye_casa_real_5[oye casa].wav": "oye_casa_real_5.wav"},
+              "test": {"noise3.wav": "noise3.wav", "noise4.wav": "noise4.wav", "oye_casa_g_2[oye casa].wav": "oye_casa_g_2.wav"},
+              "labels": 2, "weights": 6, "train_size": 168},
     # frame counts of the reference's own MFCC output, SURVEY.md §4
     "rpw_shapes": {"oye_casa_g.rpw": {"oye_casa_g_1.wav": 108, "oye_casa_g_2.wav": 96, "oye_casa_g_3.wav": 90,
                                       "oye_casa_g_4.wav": 93, "oye_casa_g_5.wav": 102},
@@ -92,6 +102,8 @@ EXPECT = {
 if __name__ == "__main__":
     for f in FILES:
         shutil.copyfile(os.path.join(REF, "tests", "resources", f), os.path.join(HERE, f))
+    for f in TRAIN_FILES:
+        shutil.copyfile(os.path.join(REF, "tests", "resources", f), os.path.join(HERE, os.path.basename(f)))
     with open(os.path.join(HERE, "expectations.json"), "w") as fh:
         json.dump(EXPECT, fh, indent=1)
     print("wrote", len(FILES), "fixture files + expectations.json")

@@ -754,6 +754,105 @@ def test_rustpotter_api_22k_input_four_shifts_per_call(ra):
         assert abs(g[2] - r[2]) <= 1e-5 * r[2] and abs(g[3] - r[3]) <= 1e-5 * r[3]
 
 
+# ---------------------------------------------------------------- NN training (second half)
+def _train_sets():
+    e = EXP["train"]
+    rd = lambda f: open(os.path.join(G, f), "rb").read()
+    return e, {k: rd(v) for k, v in e["train"].items()}, {k: rd(v) for k, v in e["test"].items()}
+
+
+def test_train_wakeword_model_like_the_reference_test(ra, ctx, tmp_path):
+    """tests/wakeword.rs:86-98: ModelType::Medium, lr 0.027, 10 epochs, mfcc 16 on tests/resources/{train,test};
+    the reference asserts labels / weights / train_size / mfcc_size.  The trained file loads into the detector."""
+    e, train, test = _train_sets()
+    data, loss, acc = ctx.train_wakeword_model(train, test, e["m_type"], e["learning_rate"], e["epochs"], e["test_epochs"],
+                                               e["mfcc_size"], seed=7)
+    p = tmp_path / "trained.rpw"
+    p.write_bytes(data)
+    m = rpw_py.load_rpw(str(p))
+    assert m["kind"] == "model" and m["m_type"] == "Medium"
+    assert len(m["labels"]) == e["labels"] and set(m["labels"]) == {"none", "oye casa"}
+    assert len(m["weights"]) == e["weights"] and m["train_size"] == e["train_size"] and m["mfcc_size"] == e["mfcc_size"]
+    fr = e["train_size"]
+    assert m["weights"]["ln1.weight"].shape == (fr // 3, fr * 16) and m["weights"]["ln2.weight"].shape == (fr // 6, fr // 3)
+    assert m["weights"]["ln3.weight"].shape == (2, fr // 6)
+    assert np.isfinite(loss) and 0.0 <= acc <= 1.0
+    # rms level: running (a+b)/2 over the labelled samples (wakeword_model_train.rs:311-317)
+    lv = np.float32("nan")
+    for name, f in e["train"].items():
+        if "[" not in name:
+            continue
+        pcm, sr, _ = rpw_py.read_wav(os.path.join(G, f))
+        y = orc.resample_stream(pcm, sr)
+        r = sorted(orc.lib().orc_rms_level(orc._f(np.ascontiguousarray(y[i:i + 480])), 480) for i in range(0, len(y) - 479, 480))
+        cur = np.float32(r[len(r) // 2])
+        lv = cur if np.isnan(lv) else np.float32((lv + cur) / np.float32(2.0))
+    assert abs(m["rms_level"] - lv) <= 2e-6 * lv
+    c = ra.RustpotterConfig.default()
+    c.fmt.sample_rate, c.fmt.sample_format = 48000, ra.SampleFormat.F32
+    rp = ra.Rustpotter.new(c)
+    rp.add_wakeword_from_buffer("trained", data)
+    assert rp.process_samples(np.zeros(1440, np.float32)) is None
+
+
+def test_train_epochs_match_oracle(ra, ctx, tmp_path):
+    """Same start, same data, same number of SGD epochs -> same weights as the oracle's restatement of the
+    training loop.  The start is the product's own seeded initialisation (0 epochs), read back from its file."""
+    e, train, test = _train_sets()
+    init, _, _ = ctx.train_wakeword_model(train, test, "small", 0.027, 0, 1, 16, seed=3)
+    p0 = tmp_path / "init.rpw"
+    p0.write_bytes(init)
+    m0 = rpw_py.load_rpw(str(p0))
+    labels = m0["labels"]
+    # candle_nn::linear's initialisation: weights ~ N(0, 2/fan_in), biases within +-1/sqrt(fan_in)
+    w1 = m0["weights"]["ln1.weight"]
+    assert abs(w1.std() * np.sqrt(w1.shape[1] / 2.0) - 1.0) < 0.02 and abs(w1.mean()) < 1e-3
+    assert np.abs(m0["weights"]["ln1.bias"]).max() <= 1.0 / np.sqrt(w1.shape[1])
+    # features the way compute_mfccs makes them, from the oracle
+    L = m0["train_size"] * 16
+    xs, ys = [], []
+    for name, f in e["train"].items():
+        pcm, sr, _ = rpw_py.read_wav(os.path.join(G, f))
+        if pcm.dtype != np.float32:
+            pcm = simstream.i16_to_f32(pcm)
+        feat = orc.wav_features(pcm, sr, 16).reshape(-1)
+        row = np.zeros(L, np.float32)
+        row[:min(L, len(feat))] = feat[:L]
+        xs.append(row)
+        ys.append(labels.index(name[name.index("[") + 1:name.index("]")].lower() if "[" in name else "none"))
+    ws = [m0["weights"]["ln%d.weight" % i] for i in (1, 2, 3)]
+    bs = [m0["weights"]["ln%d.bias" % i] for i in (1, 2, 3)]
+    epochs = 6
+    data, loss, acc = ctx.train_wakeword_model(train, test, "tiny", 0.5, epochs, 1, 5, seed=99, prev_model=init)  # options ignored
+    p1 = tmp_path / "trained.rpw"
+    p1.write_bytes(data)
+    m1 = rpw_py.load_rpw(str(p1))
+    assert m1["m_type"] == "Small" and m1["labels"] == labels and m1["train_size"] == m0["train_size"]
+    # NOTE: with prev_model the reference keeps the model's type but takes the learning rate from the options
+    rw, rb, rloss = orc.mlp_train(np.stack(xs), ys, ws, bs, 0.5, epochs)
+    assert abs(loss - rloss) <= 1e-4 * max(abs(rloss), 1e-3)
+    for i in (1, 2, 3):
+        for kind, ref in (("weight", rw[i - 1]), ("bias", rb[i - 1])):
+            got = m1["weights"]["ln%d.%s" % (i, kind)]
+            assert got.shape == ref.shape
+            moved = np.abs(ref - (ws if kind == "weight" else bs)[i - 1]).max()
+            assert np.abs(got - ref).max() <= 1e-4 * max(float(np.abs(ref).max()), float(moved))
+    assert any(np.abs(rw[i] - ws[i]).max() > 1e-4 for i in range(3))  # the epochs did move the weights
+
+
+def test_train_errors(ra, ctx):
+    e, train, test = _train_sets()
+    with pytest.raises(ra.RustpotterError, match="No training data provided"):
+        ctx.train_wakeword_model({}, test)
+    with pytest.raises(ra.RustpotterError, match="No test data provided"):
+        ctx.train_wakeword_model(train, {})
+    only_noise = {k: v for k, v in train.items() if "[" not in k}
+    with pytest.raises(ra.RustpotterError, match="at least two labels"):
+        ctx.train_wakeword_model(only_noise, {k: v for k, v in test.items() if "[" not in k})
+    with pytest.raises(ra.RustpotterError, match="Forbidden label 'alexa'"):
+        ctx.train_wakeword_model(train, {"x[Alexa].wav": open(os.path.join(G, "alexa.wav"), "rb").read()})
+
+
 def test_build_wakeword_ref_errors_and_options(ra, ctx, tmp_path):
     one = {"a.wav": open(os.path.join(G, "alexa.wav"), "rb").read()}
     built = ctx.build_wakeword_ref("solo", one, 7, threshold=0.4, avg_threshold=0.1, from_files=False)

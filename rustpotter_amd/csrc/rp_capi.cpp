@@ -488,12 +488,19 @@ int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int ch
         const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
         float *dout = static_cast<float *>(sg.out(out, S * out_stride * sizeof(float), c->stage_out));
         if (!dp || !dout) return -1;
-        if (!c->ws_resample.reserve(S * (1 + n_chunks) * (size_t)rs->dev.fi * sizeof(float) + 64)) return -1;
-        float *xs = c->ws_resample.as<float>();
-        if (!hip_ok(launch_resample_stage(c->stream, dp, (int)fmt, channels, S, n_chunks, rs->dev.fi, pcm_stride, nullptr, xs), "resample_stage_kernel")) return -1;
-        c->time_begin(kKernelResample);
-        bool ok = hip_ok(launch_resample(c->stream, rs->dev, xs, S, n_chunks, dout, out_stride), "resample_mfma_kernel");
-        c->time_end();
+        bool ok;
+        if (resample_reads_in_place(rs->dev, dp, (int)fmt, channels, pcm_stride, dout, out_stride)) {
+            c->time_begin(kKernelResample);
+            ok = hip_ok(launch_resample_in_place(c->stream, rs->dev, static_cast<const float *>(dp), pcm_stride, S, n_chunks, dout, out_stride), "resample48_fft_kernel");
+            c->time_end();
+        } else {
+            if (!c->ws_resample.reserve(S * (1 + n_chunks) * (size_t)rs->dev.fi * sizeof(float) + 64)) return -1;
+            float *xs = c->ws_resample.as<float>();
+            if (!hip_ok(launch_resample_stage(c->stream, dp, (int)fmt, channels, S, n_chunks, rs->dev.fi, pcm_stride, nullptr, xs), "resample_stage_kernel")) return -1;
+            c->time_begin(kKernelResample);
+            ok = hip_ok(launch_resample(c->stream, rs->dev, xs, S, n_chunks, dout, out_stride), "resample kernel");
+            c->time_end();
+        }
         if (!ok) return -1;
         if (!sg.back(out, dout, S * out_stride * sizeof(float)) || !sg.finish()) return -1;
         return 0;

@@ -111,7 +111,7 @@ bool resampler_frame_lengths(size_t fs_in, size_t *in_len, size_t *out_len);
 struct Resampler {
     Ctx *ctx = nullptr;
     ResamplerDev dev;
-    DevBuf g2t;
+    DevBuf g2t, fft48;
     static Resampler *create(Ctx *ctx, size_t fs_in);
 };
 

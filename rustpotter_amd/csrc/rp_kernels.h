@@ -56,7 +56,12 @@ enum KernelId { kKernelMfcc = 0, kKernelDtw = 1, kKernelAggregate = 2, kKernelSc
 struct ResamplerDev {
     int fs_in = 0, fi = 0, fo = 0, kpad = 0;  // input rate, input / output frame length, 2*fi rounded up to 16
     const float *g2t = nullptr;                // [fo][kpad]
+    const float *fft48 = nullptr;              // 48 kHz only: twiddles + filter spectrum of resample48_fft_kernel
 };
+
+// table block of resample48_fft_kernel, offsets in float2 units (rp_resampler.cpp fills it)
+constexpr int kR48OffTw240 = 0, kR48OffTw480 = 240, kR48OffTwc = 480, kR48OffW960c = 480 + 6 * 480, kR48OffHf = kR48OffW960c + 256,
+              kR48TableLen = kR48OffHf + 480;
 
 struct ScanConfig {
     float threshold, avg_threshold;
@@ -103,6 +108,12 @@ hipError_t launch_frontend(hipStream_t st, const void *pcm, int fmt, size_t S, s
 // nullptr = silence before the stream); resample: xs -> out [S][n_chunks*fo].
 hipError_t launch_resample_stage(hipStream_t st, const void *pcm, int fmt, int channels, size_t S, size_t n_chunks, int fi,
                                  size_t pcm_stride, const float *prev, float *xs);
+hipError_t launch_resample48(hipStream_t st, const float *tables, const float *xs, size_t xs_pitch, int has_hist, size_t S,
+                             size_t n_chunks, float *out, size_t out_stride);
+bool resample_reads_in_place(const ResamplerDev &rs, const void *pcm, int fmt, int channels, size_t pcm_stride, const float *out,
+                             size_t out_stride);
+hipError_t launch_resample_in_place(hipStream_t st, const ResamplerDev &rs, const float *pcm, size_t pcm_stride, size_t S,
+                                    size_t n_chunks, float *out, size_t out_stride);
 hipError_t launch_resample(hipStream_t st, const ResamplerDev &rs, const float *xs, size_t S, size_t n_chunks, float *out,
                            size_t out_stride);
 

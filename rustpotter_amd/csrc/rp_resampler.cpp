@@ -10,6 +10,7 @@
 // the common grid of N = 2*fi*fo/gcd points.  The plan evaluates g in f64 from the f32 filter spectrum
 // (the quantities rubato itself holds in f32) and stores G for the device kernel (resample_mfma_kernel).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -115,6 +116,20 @@ Resampler *Resampler::create(Ctx *ctx, size_t fs_in) {
     if (!r->g2t.reserve(G.size() * sizeof(float))) return nullptr;
     if (!hip_ok(hipMemcpy(r->g2t.p, G.data(), G.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(resampler matrix)")) return nullptr;
     r->dev.fs_in = (int)fs_in; r->dev.fi = fi; r->dev.fo = fo; r->dev.kpad = (int)kpad; r->dev.g2t = r->g2t.as<float>();
+    // 48 kHz: tables of the FFT-structured kernel (twiddles from f64, the filter spectrum halved: the kernel's
+    // untangling step leaves 2*U).  RP_RESAMPLE_GEMM=1 keeps the matrix kernel (benchmarks / cross-checks).
+    const char *force = std::getenv("RP_RESAMPLE_GEMM");
+    if (fi == 1440 && fo == 480 && !(force && force[0] == '1')) {
+        std::vector<float2> t((size_t)kR48TableLen, make_float2(0.f, 0.f));
+        auto w = [](long long e, long long n) { const double th = -2.0 * M_PI * (double)(e % n) / (double)n; return make_float2((float)std::cos(th), (float)std::sin(th)); };
+        for (int k = 0; k < 240; ++k) { t[kR48OffTw240 + k] = w(k, 240); t[kR48OffTw480 + k] = w(k, 480); }
+        for (int d = 0; d < 6; ++d) for (int q = 0; q < 480; ++q) t[kR48OffTwc + d * 480 + q] = w((long long)d * q, 2880);
+        for (int k = 0; k <= 240; ++k) { float2 c = w(k, 960); c.y = -c.y; t[kR48OffW960c + k] = c; }
+        for (int k = 0; k < 480; ++k) t[kR48OffHf + k] = make_float2(0.5f * hr[k], 0.5f * hi[k]);
+        if (!r->fft48.reserve(t.size() * sizeof(float2))) return nullptr;
+        if (!hip_ok(hipMemcpy(r->fft48.p, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice), "hipMemcpy(resampler tables)")) return nullptr;
+        r->dev.fft48 = r->fft48.as<float>();
+    }
     return r.release();
 }
 

@@ -323,12 +323,21 @@ typedef struct rp_stream_batch rp_stream_batch;
 int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_config *config, size_t S,
                         size_t max_chunks_per_call, rp_stream_batch **out);
 void rp_stream_batch_free(rp_stream_batch *b);
-/* pcm [S][pcm_stride] holds n_chunks*480 new samples per stream (1 <= n_chunks <= max_chunks_per_call).
+/* pcm [S][pcm_stride] holds n_chunks * rp_stream_batch_samples_per_chunk() new samples per stream (480 per chunk by
+ * default; 1 <= n_chunks <= max_chunks_per_call).
  * det [S][max_det], n_det [S]: detections emitted during these chunks (n_det may exceed max_det; only
  * the first max_det are stored).  agg (NULL to skip) [S][3*n_chunks]: aggregate score of the window
  * ending at each new frame (garbage for windows that reach before frame 0). */
 int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
                             rp_batch_detection *det, int32_t *n_det, int max_det, float *agg);
+/* The AudioFmt of the streams (RustpotterConfig.fmt: sample_rate, channels; src/config.rs:10-29), to be set before
+ * the first rp_stream_batch_process -- default 16 kHz mono.  Input that is not 16 kHz is converted per call
+ * exactly as one Rustpotter per stream would (the first channel of every frame, rubato-style resampling with the
+ * previous input frame of every stream kept on the device; the resampler is not touched by resets).  A chunk is
+ * then rp_stream_batch_samples_per_chunk() samples (= get_samples_per_frame(): 1 440 for 48 kHz mono).  Rates
+ * whose resampled frame is not 480 samples (the 22.05 kHz family) are refused here. */
+int rp_stream_batch_set_input(rp_stream_batch *b, size_t sample_rate, int channels);
+size_t rp_stream_batch_samples_per_chunk(const rp_stream_batch *b);
 /* Rustpotter::reset (src/detector.rs:290-302) of one stream, or of all when stream < 0. */
 int rp_stream_batch_reset(rp_stream_batch *b, long long stream);
 /* chunks consumed so far (per stream) */

@@ -106,7 +106,7 @@ SYMBOLS = [
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
     "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
-    "rp_wakeword_model_train",
+    "rp_wakeword_model_train", "rp_stream_batch_set_input", "rp_stream_batch_samples_per_chunk",
 ]
 
 
@@ -183,6 +183,9 @@ def load_library():
     L.rp_stream_batch_free.restype = None
     L.rp_stream_batch_process.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, vp, vp, C.c_int, vp]
     L.rp_stream_batch_reset.argtypes = [vp, C.c_longlong]
+    L.rp_stream_batch_set_input.argtypes = [vp, C.c_size_t, C.c_int]
+    L.rp_stream_batch_samples_per_chunk.argtypes = [vp]
+    L.rp_stream_batch_samples_per_chunk.restype = C.c_size_t
     L.rp_stream_batch_chunks_seen.argtypes = [vp]
     L.rp_stream_batch_chunks_seen.restype = C.c_size_t
     L.rp_model_new.argtypes = [vp, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(vp)]
@@ -456,7 +459,7 @@ class StreamBatch:
     """S live streams fed chunk by chunk (rp_stream_batch_*): the batched form of calling
     Rustpotter::process_samples on S instances sharing one wakeword and config."""
 
-    def __init__(self, ctx, templates, detector_config, S, max_chunks_per_call=1):
+    def __init__(self, ctx, templates, detector_config, S, max_chunks_per_call=1, sample_rate=16000, channels=1):
         self._L = load_library()
         self.ctx, self.templates, self.S, self.max_chunks = ctx, templates, S, max_chunks_per_call
         h = C.c_void_p()
@@ -464,6 +467,9 @@ class StreamBatch:
         if self._L.rp_stream_batch_new(ctx._h, templates._h, C.byref(c), S, max_chunks_per_call, C.byref(h)) < 0:
             raise _err()
         self._h = h
+        if (sample_rate, channels) != (16000, 1) and self._L.rp_stream_batch_set_input(h, sample_rate, channels) < 0:
+            raise _err()
+        self.samples_per_chunk = self._L.rp_stream_batch_samples_per_chunk(h)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -483,12 +489,13 @@ class StreamBatch:
         if fmt is None:
             pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
         S, N = pcm.shape
-        if S != self.S or N % 480:
-            raise ValueError("pcm must be [S][n_chunks*480]")
+        spc = self.samples_per_chunk
+        if S != self.S or N % spc:
+            raise ValueError("pcm must be [S][n_chunks*samples_per_chunk]")
         det = np.zeros((S, max_det), dtype=DET_DTYPE)
         n_det = np.zeros(S, np.int32)
-        agg = np.empty((S, 3 * (N // 480)), np.float32) if want_agg else None
-        if self._L.rp_stream_batch_process(self._h, pcm.ctypes.data, fmt, N // 480, N, det.ctypes.data, n_det.ctypes.data, max_det,
+        agg = np.empty((S, 3 * (N // spc)), np.float32) if want_agg else None
+        if self._L.rp_stream_batch_process(self._h, pcm.ctypes.data, fmt, N // spc, N, det.ctypes.data, n_det.ctypes.data, max_det,
                                            None if agg is None else agg.ctypes.data) < 0:
             raise _err()
         return (det, n_det, agg) if want_agg else (det, n_det)

@@ -27,6 +27,12 @@ struct rp_stream_batch {
     int cur = 0;             // which of mfcc[2] holds the frames of the last call
     size_t cur_pitch = 0;    // its row pitch in frames
     DevBuf pcm, mfcc[2], state, scores, agg, avg, vad;
+    // AudioEncoder of the streams (src/audio/encoder.rs): channel count and, for input that is not 16 kHz, the
+    // resampler plan with every stream's previous input frame
+    int channels = 1;
+    size_t in_len = 480;
+    const Resampler *rs = nullptr;
+    DevBuf rs_prev, rs_xs, rs_out;
 };
 
 static void fill_detection(rp_detector *d, const Detection &src, rp_detection *out) {
@@ -541,6 +547,28 @@ int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_co
 void rp_stream_batch_free(rp_stream_batch *b) { delete b; }
 size_t rp_stream_batch_chunks_seen(const rp_stream_batch *b) { return b->chunks_seen; }
 
+int rp_stream_batch_set_input(rp_stream_batch *b, size_t sample_rate, int channels) {
+    return guarded([&]() -> int {
+        Ctx *c = b->c;
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (b->chunks_seen) { set_last_error("rp_stream_batch_set_input: the streams have already received audio"); return -1; }
+        if (channels < 1) { set_last_error("Unsupported channel count"); return -1; }
+        size_t fi = 480, fo = 480;
+        if (!resampler_frame_lengths(sample_rate, &fi, &fo)) { set_last_error("Unsupported sample rate, unable to initialize the resampler"); return -1; }
+        if (fo != 480) { set_last_error("rp_stream_batch: this input rate yields frames of four 10 ms shifts; only 30 ms frames are batched"); return -1; }
+        b->channels = channels; b->in_len = fi; b->rs = nullptr;
+        if (sample_rate != 16000) {
+            b->rs = c->resampler_for(sample_rate);
+            if (!b->rs) return -1;
+            if (!b->rs_prev.reserve(b->S * fi * sizeof(float)) || !b->rs_xs.reserve(b->S * (1 + b->max_chunks) * fi * sizeof(float) + 64) ||
+                !b->rs_out.reserve(b->S * b->max_chunks * 480 * sizeof(float))) return -1;
+            if (!hip_ok(hipMemsetAsync(b->rs_prev.p, 0, b->S * fi * sizeof(float), c->stream), "hipMemsetAsync")) return -1;
+        }
+        return 0;
+    });
+}
+size_t rp_stream_batch_samples_per_chunk(const rp_stream_batch *b) { return b->in_len * (size_t)b->channels; }
+
 int rp_stream_batch_reset(rp_stream_batch *b, long long stream) {
     return guarded([&]() -> int {
         Ctx *c = b->c;
@@ -557,7 +585,8 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         Ctx *c = b->c;
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (n_chunks == 0 || n_chunks > b->max_chunks) { set_last_error("rp_stream_batch_process: n_chunks out of range"); return -1; }
-        if (pcm_stride < n_chunks * 480) { set_last_error("pcm_stride smaller than n_chunks*480"); return -1; }
+        const size_t in_chunk = b->in_len * (size_t)b->channels;
+        if (pcm_stride < n_chunks * in_chunk) { set_last_error("pcm_stride smaller than n_chunks * samples per chunk"); return -1; }
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
         const TemplatesDev &td = b->t->dev;
         const MfccTablesDev *tb = c->tables_for(td.K);
@@ -572,8 +601,20 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         if (!dp || !dd || !dn) { if (!pcm || !det || !n_det) set_last_error("null argument"); return -1; }
         float *hp = b->pcm.as<float>();
         float *prev = b->mfcc[b->cur].as<float>(), *now = b->mfcc[b->cur ^ 1].as<float>();
-        // previous chunk | new chunks, decoded to f32
-        if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, S, n_chunks * 480, pcm_stride, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+        if (b->rs) {  // previous input frame | new input frames -> 16 kHz (the resampler never resets, src/detector.rs:290-302)
+            const size_t fi = b->in_len;
+            float *xs = b->rs_xs.as<float>(), *ro = b->rs_out.as<float>();
+            if (!hip_ok(launch_resample_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks, (int)fi, pcm_stride, b->rs_prev.as<float>(), xs), "resample_stage_kernel")) return -1;
+            c->time_begin(kKernelResample);
+            bool okr = hip_ok(launch_resample(c->stream, b->rs->dev, xs, S, n_chunks, ro, n_chunks * 480), "resample kernel");
+            c->time_end();
+            if (!okr) return -1;
+            if (!hip_ok(launch_carry_rows(c->stream, xs, S, (1 + n_chunks) * fi, n_chunks * fi, fi, b->rs_prev.as<float>(), fi), "carry_rows_kernel")) return -1;
+            if (!hip_ok(launch_stream_stage(c->stream, ro, 3, 1, S, n_chunks * 480, n_chunks * 480, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+        } else if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks * 480, pcm_stride, hp, pcm_pitch), "stream_stage_kernel")) {
+            // previous chunk | new chunks, decoded to f32
+            return -1;
+        }
         // last max_len-1 frames of the previous call | the 3*n_chunks new frames
         if (!hip_ok(launch_carry_rows(c->stream, prev, S, b->cur_pitch * td.K, (b->cur_pitch - hist) * td.K, hist * td.K, now, pitch * td.K), "carry_rows_kernel")) return -1;
         c->time_begin(kKernelMfcc);

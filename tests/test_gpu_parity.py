@@ -478,6 +478,70 @@ def test_stream_batch_reset_and_formats(ra, ctx):
         sb.process(np.zeros((3, 480 * 2), np.float32))  # more chunks than max_chunks_per_call
 
 
+def test_stream_batch_48k_stereo_equals_resample_then_offline(ra, ctx):
+    """Live 48 kHz stereo i16 streams, two chunks per call: the per-call resampler (previous input frame kept per
+    stream) + the streaming path == rp_resample_batch over the whole stream followed by rp_batch_detect."""
+    e = EXP["audio_file"]["noise"]
+    w = rpw_py.load_rpw(os.path.join(G, e["rpw"]))
+    pcm48, sr, _ = rpw_py.read_wav(os.path.join(G, e["wav"]))
+    n = (len(pcm48) // 2880) * 2880
+    left = np.round(np.clip(pcm48[:n] / 4.0, -1.0, 1.0) * 32767.0).astype(np.int16)  # the recording peaks at 2.2
+    streams = np.stack([left, np.roll(left, 1440 * 9), (left // 2).astype(np.int16)])
+    right = np.zeros_like(streams) + 123
+    inter = np.stack([streams, right], axis=2).reshape(3, -1)           # L R L R ...
+    cfg = _make_config(ra, e).detector
+    cfg.min_scores = e["min_scores"]
+    tm = ra.Templates(ctx, list(w["samples_features"].values()), avg=w["avg_features"])
+    mono16 = ctx.resample(inter, 48000, channels=2)
+    det, n_det, _, agg = ctx.batch_detect(mono16, tm, cfg, want_scores=True)
+    assert n_det[0] >= 2
+    sb = ra.StreamBatch(ctx, tm, cfg, 3, max_chunks_per_call=2, sample_rate=48000, channels=2)
+    assert sb.samples_per_chunk == 2880
+    got = [[] for _ in range(3)]
+    step = 2 * 2880
+    for i in range(0, inter.shape[1], step):
+        d, nd, a = sb.process(inter[:, i:i + step], want_agg=True)
+        f0 = 3 * (i // 2880) - 3
+        for si in range(3):
+            for j in range(nd[si]):
+                got[si].append(_det_tuple(d[si][j]))
+            for k in range(a.shape[1]):
+                wi = f0 + k - tm.max_len + 1
+                if 0 <= wi < agg.shape[1]:
+                    assert a[si, k] == agg[si, wi]
+    for si in range(3):
+        assert got[si] == [_det_tuple(det[si][j]) for j in range(n_det[si])]
+    with pytest.raises(ra.RustpotterError, match="four 10 ms shifts"):
+        ra.StreamBatch(ctx, tm, cfg, 3, sample_rate=22050)
+
+
+def test_stream_batch_wide_templates_generic_tiling(ra, ctx):
+    """mfcc_size 16 and band 3: the streaming path outside the cross-stream tiling (few windows per stream per call
+    through the per-stream tiles) still equals the offline pass."""
+    for K, band in ((16, 5), (5, 3)):
+        S, N = 96, 480 * 60
+        tmpl = orc.synth_templates(SEED, 4, 40, K)
+        tm = ra.Templates(ctx, tmpl)
+        cfg = ra.RustpotterConfig.default().detector
+        cfg.avg_threshold, cfg.threshold, cfg.min_scores, cfg.band_size = 0.0, 0.2, 1, band
+        pcm = ctx.synth_pcm(SEED, 0, S, N)
+        det, n_det, _, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+        sb = ra.StreamBatch(ctx, tm, cfg, S, max_chunks_per_call=3)
+        total = np.zeros(S, np.int64)
+        for i in range(0, N, 1440):
+            d, nd, a = sb.process(pcm[:, i:i + 1440], want_agg=True)
+            f0 = 3 * (i // 480) - 3
+            for k in range(9):
+                wi = f0 + k - 39
+                if 0 <= wi < agg.shape[1]:
+                    assert np.array_equal(a[:, k], agg[:, wi])
+            for si in np.nonzero(nd)[0]:
+                for j in range(nd[si]):
+                    assert _det_tuple(d[si][j]) == _det_tuple(det[si][total[si] + j])
+            total += nd
+        assert np.array_equal(total, n_det)
+
+
 def test_stream_batch_many_streams_synthetic(ra, ctx):
     """4096 synthetic streams, 2 chunks per call (the cross-stream DTW tiling): per-call aggregates and
     detections identical to the offline pass."""

@@ -44,6 +44,8 @@ def main():
                          "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process); "
                          "resample: 48 kHz -> 16 kHz front-end alone (rp_resample_batch)")
     ap.add_argument("--chunks-per-call", type=int, default=1)
+    ap.add_argument("--pcm-format", choices=["f32", "i16"], default="f32", help="--mode resample: sample format of the 48 kHz input")
+    ap.add_argument("--channels", type=int, default=1, help="--mode resample: interleaved channels of the 48 kHz input")
     ap.add_argument("--mlp-precision", choices=["f32", "bf16"], default="bf16")
     args = ap.parse_args()
 
@@ -299,12 +301,18 @@ def bench_resample(args, ra, torch, dist, dev, world, rank, local_rank):
     nch = n // fi
     ctx = ra.BatchContext(device=local_rank, host_pointers=False)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ch = args.channels
     pcm = torch.empty((S, n), dtype=torch.float32, device=dev)
     ctx.synth_dev(SEED, 0, S, n, n, pcm.data_ptr())
+    if args.pcm_format == "i16" or ch > 1:
+        mono = (pcm * 32767.0).round().to(torch.int16) if args.pcm_format == "i16" else pcm
+        pcm = mono.unsqueeze(2).expand(S, n, ch).contiguous().view(S, n * ch)
+        del mono
+    fmt = 1 if args.pcm_format == "i16" else 3
     out = torch.empty((S, nch * fo), dtype=torch.float32, device=dev)
 
     def step():
-        ctx.resample_dev(pcm.data_ptr(), 3, 1, fs, S, n, n, out.data_ptr(), nch * fo)
+        ctx.resample_dev(pcm.data_ptr(), fmt, ch, fs, S, n, n * ch, out.data_ptr(), nch * fo)
 
     for _ in range(args.warmup):
         step()
@@ -320,7 +328,7 @@ def bench_resample(args, ra, torch, dist, dev, world, rank, local_rank):
         step()
     torch.cuda.synchronize()
     ms, _n = ctx.timing_read(5)
-    alg = S * nch * (fi + fo) * 4
+    alg = S * nch * (fi * ch * (2 if fmt == 1 else 4) + fo * 4)
     gemm = os.environ.get("RP_RESAMPLE_GEMM") == "1"
     if gemm:   # the general kernel: one [2*fi x fo] product per output frame on the f32 matrix cores
         flops = S * nch * 2.0 * (2 * fi) * fo
@@ -333,7 +341,7 @@ def bench_resample(args, ra, torch, dist, dev, world, rank, local_rank):
     res = {"metric": "resampled 10ms output frames/sec (48 kHz -> 16 kHz)", "value": S * nch * 3 / dt, "unit": "frames/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%d streams x %d samples at 48 kHz f32" % (S, n)},
+           "config": {"workload": "%d streams x %d samples at 48 kHz %s, %d channel(s)" % (S, n, args.pcm_format, ch)},
            "roofline": roof}
     if rank == 0:
         print(json.dumps(res))

@@ -32,7 +32,8 @@ struct rp_stream_batch {
     int channels = 1;
     size_t in_len = 480;
     const Resampler *rs = nullptr;
-    DevBuf rs_prev, rs_xs, rs_out;
+    DevBuf rs_prev[2], rs_xs, rs_out;
+    int rs_cur = 0;
 };
 
 static void fill_detection(rp_detector *d, const Detection &src, rp_detection *out) {
@@ -495,9 +496,9 @@ int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int ch
         float *dout = static_cast<float *>(sg.out(out, S * out_stride * sizeof(float), c->stage_out));
         if (!dp || !dout) return -1;
         bool ok;
-        if (resample_reads_in_place(rs->dev, dp, (int)fmt, channels, pcm_stride, dout, out_stride)) {
+        if (resample_reads_in_place(rs->dev, dp, (int)fmt, pcm_stride, dout, out_stride)) {
             c->time_begin(kKernelResample);
-            ok = hip_ok(launch_resample_in_place(c->stream, rs->dev, static_cast<const float *>(dp), pcm_stride, S, n_chunks, dout, out_stride), "resample48_fft_kernel");
+            ok = hip_ok(launch_resample_in_place(c->stream, rs->dev, dp, (int)fmt, channels, pcm_stride, nullptr, nullptr, S, n_chunks, dout, out_stride), "resample48_fft_kernel");
             c->time_end();
         } else {
             if (!c->ws_resample.reserve(S * (1 + n_chunks) * (size_t)rs->dev.fi * sizeof(float) + 64)) return -1;
@@ -560,9 +561,11 @@ int rp_stream_batch_set_input(rp_stream_batch *b, size_t sample_rate, int channe
         if (sample_rate != 16000) {
             b->rs = c->resampler_for(sample_rate);
             if (!b->rs) return -1;
-            if (!b->rs_prev.reserve(b->S * fi * sizeof(float)) || !b->rs_xs.reserve(b->S * (1 + b->max_chunks) * fi * sizeof(float) + 64) ||
+            if (!b->rs_prev[0].reserve(b->S * fi * sizeof(float)) || !b->rs_prev[1].reserve(b->S * fi * sizeof(float)) ||
                 !b->rs_out.reserve(b->S * b->max_chunks * 480 * sizeof(float))) return -1;
-            if (!hip_ok(hipMemsetAsync(b->rs_prev.p, 0, b->S * fi * sizeof(float), c->stream), "hipMemsetAsync")) return -1;
+            if (!b->rs->dev.fft48 && !b->rs_xs.reserve(b->S * (1 + b->max_chunks) * fi * sizeof(float) + 64)) return -1;
+            if (!hip_ok(hipMemsetAsync(b->rs_prev[0].p, 0, b->S * fi * sizeof(float), c->stream), "hipMemsetAsync")) return -1;
+            b->rs_cur = 0;
         }
         return 0;
     });
@@ -603,13 +606,24 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         float *prev = b->mfcc[b->cur].as<float>(), *now = b->mfcc[b->cur ^ 1].as<float>();
         if (b->rs) {  // previous input frame | new input frames -> 16 kHz (the resampler never resets, src/detector.rs:290-302)
             const size_t fi = b->in_len;
-            float *xs = b->rs_xs.as<float>(), *ro = b->rs_out.as<float>();
-            if (!hip_ok(launch_resample_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks, (int)fi, pcm_stride, b->rs_prev.as<float>(), xs), "resample_stage_kernel")) return -1;
-            c->time_begin(kKernelResample);
-            bool okr = hip_ok(launch_resample(c->stream, b->rs->dev, xs, S, n_chunks, ro, n_chunks * 480), "resample kernel");
-            c->time_end();
-            if (!okr) return -1;
-            if (!hip_ok(launch_carry_rows(c->stream, xs, S, (1 + n_chunks) * fi, n_chunks * fi, fi, b->rs_prev.as<float>(), fi), "carry_rows_kernel")) return -1;
+            float *ro = b->rs_out.as<float>();
+            float *pv = b->rs_prev[b->rs_cur].as<float>(), *pn = b->rs_prev[b->rs_cur ^ 1].as<float>();
+            if (resample_reads_in_place(b->rs->dev, dp, (int)fmt, pcm_stride, ro, n_chunks * 480)) {
+                c->time_begin(kKernelResample);
+                bool okr = hip_ok(launch_resample_in_place(c->stream, b->rs->dev, dp, (int)fmt, b->channels, pcm_stride, pv, pn, S, n_chunks, ro, n_chunks * 480), "resample48_fft_kernel");
+                c->time_end();
+                if (!okr) return -1;
+            } else {
+                if (!b->rs_xs.reserve(S * (1 + b->max_chunks) * fi * sizeof(float) + 64)) return -1;
+                float *xs = b->rs_xs.as<float>();
+                if (!hip_ok(launch_resample_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks, (int)fi, pcm_stride, pv, xs), "resample_stage_kernel")) return -1;
+                c->time_begin(kKernelResample);
+                bool okr = hip_ok(launch_resample(c->stream, b->rs->dev, xs, S, n_chunks, ro, n_chunks * 480), "resample kernel");
+                c->time_end();
+                if (!okr) return -1;
+                if (!hip_ok(launch_carry_rows(c->stream, xs, S, (1 + n_chunks) * fi, n_chunks * fi, fi, pn, fi), "carry_rows_kernel")) return -1;
+            }
+            b->rs_cur ^= 1;
             if (!hip_ok(launch_stream_stage(c->stream, ro, 3, 1, S, n_chunks * 480, n_chunks * 480, hp, pcm_pitch), "stream_stage_kernel")) return -1;
         } else if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks * 480, pcm_stride, hp, pcm_pitch), "stream_stage_kernel")) {
             // previous chunk | new chunks, decoded to f32

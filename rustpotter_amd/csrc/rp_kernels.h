@@ -108,12 +108,12 @@ hipError_t launch_frontend(hipStream_t st, const void *pcm, int fmt, size_t S, s
 // nullptr = silence before the stream); resample: xs -> out [S][n_chunks*fo].
 hipError_t launch_resample_stage(hipStream_t st, const void *pcm, int fmt, int channels, size_t S, size_t n_chunks, int fi,
                                  size_t pcm_stride, const float *prev, float *xs);
-hipError_t launch_resample48(hipStream_t st, const float *tables, const float *xs, size_t xs_pitch, int has_hist, size_t S,
-                             size_t n_chunks, float *out, size_t out_stride);
-bool resample_reads_in_place(const ResamplerDev &rs, const void *pcm, int fmt, int channels, size_t pcm_stride, const float *out,
+hipError_t launch_resample48(hipStream_t st, const float *tables, const void *pcm, int fmt, int channels, size_t pcm_stride,
+                             int has_hist, const float *prev, float *prev_out, size_t S, size_t n_chunks, float *out,
                              size_t out_stride);
-hipError_t launch_resample_in_place(hipStream_t st, const ResamplerDev &rs, const float *pcm, size_t pcm_stride, size_t S,
-                                    size_t n_chunks, float *out, size_t out_stride);
+bool resample_reads_in_place(const ResamplerDev &rs, const void *pcm, int fmt, size_t pcm_stride, const float *out, size_t out_stride);
+hipError_t launch_resample_in_place(hipStream_t st, const ResamplerDev &rs, const void *pcm, int fmt, int channels, size_t pcm_stride,
+                                    const float *prev, float *prev_out, size_t S, size_t n_chunks, float *out, size_t out_stride);
 hipError_t launch_resample(hipStream_t st, const ResamplerDev &rs, const float *xs, size_t S, size_t n_chunks, float *out,
                            size_t out_stride);
 

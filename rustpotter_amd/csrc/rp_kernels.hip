@@ -1240,22 +1240,22 @@ static hipError_t launch_resample_t(hipStream_t st, const ResamplerDev &rs, cons
     return hipGetLastError();
 }
 
-// f32 mono streams that start from silence need no staging copy: the 48 kHz kernel reads them in place
-bool resample_reads_in_place(const ResamplerDev &rs, const void *pcm, int fmt, int channels, size_t pcm_stride, const float *out,
-                             size_t out_stride) {
-    return rs.fft48 && fmt == 3 && channels == 1 && (pcm_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0 &&
-           (out_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+// The 48 kHz kernel decodes and reads its input where it lies (no staging copy)
+bool resample_reads_in_place(const ResamplerDev &rs, const void *pcm, int fmt, size_t pcm_stride, const float *out, size_t out_stride) {
+    const size_t eb = fmt == 0 ? 1 : fmt == 1 ? 2 : 4;
+    return rs.fft48 && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0 && ((pcm_stride * eb) & 15) == 0 && (out_stride & 1) == 0 &&
+           (reinterpret_cast<uintptr_t>(out) & 7) == 0;
 }
-hipError_t launch_resample_in_place(hipStream_t st, const ResamplerDev &rs, const float *pcm, size_t pcm_stride, size_t S,
-                                    size_t n_chunks, float *out, size_t out_stride) {
-    return launch_resample48(st, rs.fft48, pcm, pcm_stride, 0, S, n_chunks, out, out_stride);
+hipError_t launch_resample_in_place(hipStream_t st, const ResamplerDev &rs, const void *pcm, int fmt, int channels, size_t pcm_stride,
+                                    const float *prev, float *prev_out, size_t S, size_t n_chunks, float *out, size_t out_stride) {
+    return launch_resample48(st, rs.fft48, pcm, fmt, channels, pcm_stride, 0, prev, prev_out, S, n_chunks, out, out_stride);
 }
 
 hipError_t launch_resample(hipStream_t st, const ResamplerDev &rs, const float *xs, size_t S, size_t n_chunks, float *out,
                            size_t out_stride) {
     if (S == 0 || n_chunks == 0) return hipSuccess;
     if (rs.fft48 && (out_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0)
-        return launch_resample48(st, rs.fft48, xs, (1 + n_chunks) * (size_t)rs.fi, 1, S, n_chunks, out, out_stride);
+        return launch_resample48(st, rs.fft48, xs, 3, 1, (1 + n_chunks) * (size_t)rs.fi, 1, nullptr, nullptr, S, n_chunks, out, out_stride);
     if (rs.fo == 480) return launch_resample_t<30>(st, rs, xs, S, n_chunks, out, out_stride);
     if (rs.fo == 640) return launch_resample_t<40>(st, rs, xs, S, n_chunks, out, out_stride);
     return hipErrorInvalidValue;
@@ -1294,8 +1294,10 @@ __device__ __forceinline__ void fft240_lanes(v2f (&v)[16], v2f *my, int l, const
 __device__ __forceinline__ v2f cconj(v2f a) { return (v2f){a.x, -a.y}; }
 __device__ __forceinline__ v2f mul_pi(v2f a) { return (v2f){-a.y, a.x}; }  // a * (+i)
 
+template <class TIN>
 __global__ __launch_bounds__(64 * kR48Waves) void resample48_fft_kernel(
-    const float *__restrict__ xs, size_t xs_pitch, int has_hist, size_t n_waves, unsigned n_chunks, unsigned seg_len, unsigned n_seg,
+    const TIN *__restrict__ xs, size_t xs_pitch, int channels, int has_hist, const float *__restrict__ prev,
+    float *__restrict__ prev_out, size_t n_waves, unsigned n_chunks, unsigned seg_len, unsigned n_seg,
     const v2f *__restrict__ g_tw240, const v2f *__restrict__ g_tw480, const v2f *__restrict__ g_twc,
     const v2f *__restrict__ g_w960c, const v2f *__restrict__ g_hf, float *__restrict__ out, size_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1317,13 +1319,29 @@ __global__ __launch_bounds__(64 * kR48Waves) void resample48_fft_kernel(
         for (int d = 0; d < 4; ++d) twl[4 * c + d] = g_tw240[l15 * (c + 4 * d)];
     for (int m = lane; m < 240; m += 64) tail[m] = (v2f){0.f, 0.f};
     float *orow = out + s * out_stride;
-    // frame c0-1 only seeds the overlap half; in front of frame 0 that is the history frame xs carries, or silence
-    // (has_hist == 0: xs starts at frame 0 and the overlap half stays zero)
-    for (long c = (c0 == 0 && !has_hist) ? 0 : c0 - 1; c < c1; ++c) {
-        const float *x = xs + s * xs_pitch + (size_t)(c + (has_hist ? 1 : 0)) * 1440;
+    // frame c0-1 only seeds the overlap half; in front of frame 0 that is the history frame xs carries
+    // (has_hist), the stream's previous input frame `prev` [S][1440], or silence (the overlap half stays zero).
+    // Samples are decoded here (Sample::into_f32, first channel of every interleaved frame).
+    const bool vec = sizeof(TIN) == 4 && channels == 1 && (xs_pitch & 3) == 0;
+    for (long c = (c0 == 0 && !has_hist && !prev) ? 0 : c0 - 1; c < c1; ++c) {
         wave_lds_sync();
-        for (int i = lane; i < 360; i += 64) reinterpret_cast<float4 *>(xin)[i] = reinterpret_cast<const float4 *>(x)[i];
+        if (c < 0 && prev) {
+            const float *x = prev + s * 1440;
+            for (int i = lane; i < 360; i += 64) reinterpret_cast<float4 *>(xin)[i] = reinterpret_cast<const float4 *>(x)[i];
+        } else {
+            const TIN *x = xs + s * xs_pitch + (size_t)(c + (has_hist ? 1 : 0)) * 1440 * channels;
+            if (vec) {
+                for (int i = lane; i < 360; i += 64)
+                    reinterpret_cast<float4 *>(xin)[i] = SampleIn<TIN>::load4(x + 4 * i);
+            } else {
+                for (int i = lane; i < 1440; i += 64) xin[i] = SampleIn<TIN>::cvt(x[(size_t)i * channels]);
+            }
+        }
         wave_lds_sync();
+        if (prev_out && c == (long)n_chunks - 1) {  // the last input frame is the next call's history
+            float *po = prev_out + s * 1440;
+            for (int i = lane; i < 360; i += 64) reinterpret_cast<float4 *>(po)[i] = reinterpret_cast<const float4 *>(xin)[i];
+        }
         // ---- forward round 1: groups 0..2 = even bins of the pairs (0,1) (2,3) (4,5), group 3 = odd bins of pair (0,1).
         // z[m] = (x[6m+2p], x[6m+2p+1]) [* W480^m for the odd bins], m = 15*n1 + n2.  The samples occupy zb[0..2];
         // the results go to zb[3..5] and xy[0..239] so that round 2 can still read them.
@@ -1428,9 +1446,9 @@ __global__ __launch_bounds__(64 * kR48Waves) void resample48_fft_kernel(
     }
 }
 
-hipError_t launch_resample48(hipStream_t st, const float *tables, const float *xs, size_t xs_pitch, int has_hist, size_t S,
-                             size_t n_chunks, float *out, size_t out_stride) {
-    if (S == 0 || n_chunks == 0) return hipSuccess;
+template <class TIN>
+static hipError_t launch_resample48_t(hipStream_t st, const float *tables, const TIN *xs, size_t xs_pitch, int channels, int has_hist,
+                                      const float *prev, float *prev_out, size_t S, size_t n_chunks, float *out, size_t out_stride) {
     // enough waves to fill the chip: split long streams into runs (each run recomputes one frame for its overlap)
     size_t n_seg = S >= 8192 ? 1 : (8192 + S - 1) / S;
     if (n_seg > n_chunks) n_seg = n_chunks;
@@ -1441,16 +1459,31 @@ hipError_t launch_resample48(hipStream_t st, const float *tables, const float *x
     const size_t lds = (size_t)kR48Waves * kR48WaveLds;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample48_fft_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample48_fft_kernel<TIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const v2f *t = reinterpret_cast<const v2f *>(tables);
-    hipLaunchKernelGGL(resample48_fft_kernel, dim3((unsigned)blocks), dim3(64 * kR48Waves), lds, st, xs, xs_pitch, has_hist,
-                       n_waves, (unsigned)n_chunks, (unsigned)seg_len, (unsigned)n_seg, t + kR48OffTw240, t + kR48OffTw480,
-                       t + kR48OffTwc, t + kR48OffW960c, t + kR48OffHf, out, out_stride);
+    hipLaunchKernelGGL(resample48_fft_kernel<TIN>, dim3((unsigned)blocks), dim3(64 * kR48Waves), lds, st, xs, xs_pitch, channels, has_hist,
+                       prev, prev_out, n_waves, (unsigned)n_chunks, (unsigned)seg_len, (unsigned)n_seg, t + kR48OffTw240,
+                       t + kR48OffTw480, t + kR48OffTwc, t + kR48OffW960c, t + kR48OffHf, out, out_stride);
     return hipGetLastError();
+}
+
+// 48 kHz input in any sample format / channel count, read where it lies.  prev [S][1440] f32 (nullptr: the streams
+// start from silence) is the input frame in front of frame 0; prev_out (nullptr: not kept) receives the last one.
+hipError_t launch_resample48(hipStream_t st, const float *tables, const void *pcm, int fmt, int channels, size_t pcm_stride,
+                             int has_hist, const float *prev, float *prev_out, size_t S, size_t n_chunks, float *out,
+                             size_t out_stride) {
+    if (S == 0 || n_chunks == 0) return hipSuccess;
+    switch (fmt) {
+    case 0: return launch_resample48_t(st, tables, static_cast<const int8_t *>(pcm), pcm_stride, channels, has_hist, prev, prev_out, S, n_chunks, out, out_stride);
+    case 1: return launch_resample48_t(st, tables, static_cast<const int16_t *>(pcm), pcm_stride, channels, has_hist, prev, prev_out, S, n_chunks, out, out_stride);
+    case 2: return launch_resample48_t(st, tables, static_cast<const int32_t *>(pcm), pcm_stride, channels, has_hist, prev, prev_out, S, n_chunks, out, out_stride);
+    case 3: return launch_resample48_t(st, tables, static_cast<const float *>(pcm), pcm_stride, channels, has_hist, prev, prev_out, S, n_chunks, out, out_stride);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // ------------------------------------------------------------- streaming batches

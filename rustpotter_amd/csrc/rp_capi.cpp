@@ -24,9 +24,14 @@ struct rp_stream_batch {
     const Templates *t = nullptr;
     rp_detector_config cfg{};
     size_t S = 0, max_chunks = 0, chunks_seen = 0, hist_frames = 0;
-    int cur = 0;             // which of mfcc[2] holds the frames of the last call
-    size_t cur_pitch = 0;    // its row pitch in frames
-    DevBuf pcm, mfcc[2], state, scores, agg, avg, vad;
+    // MFCC window: rows of `cap` frames; a call appends its frames behind the `fill` valid ones and only when a row
+    // is full are the last max_len-1 frames moved to the front of the other buffer
+    int cur = 0;
+    size_t cap = 0, fill = 0;
+    // previous chunk | new chunks (f32), ping-pong so that one kernel both carries the old chunk and decodes the new
+    int pcur = 0;
+    size_t last_off = 0;     // where the last chunk of the previous call sits in pcm[pcur]'s rows
+    DevBuf pcm[2], mfcc[2], state, scores, agg, avg, vad;
     // AudioEncoder of the streams (src/audio/encoder.rs): channel count and, for input that is not 16 kHz, the
     // resampler plan with every stream's previous input frame
     int channels = 1;
@@ -527,20 +532,23 @@ int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_co
         std::unique_ptr<rp_stream_batch> b(new rp_stream_batch());
         b->c = c; b->t = t->impl.get(); b->cfg = *config; b->S = S; b->max_chunks = max_chunks_per_call;
         b->hist_frames = (size_t)td.max_len - 1;
-        const size_t pitch = b->hist_frames + 3 * max_chunks_per_call, rows = S * 3 * max_chunks_per_call;
+        b->cap = b->hist_frames + 3 * max_chunks_per_call * 8;  // compaction every 8 full-size calls
+        const size_t pitch = b->cap, rows = S * 3 * max_chunks_per_call;
         const size_t slack = 64 * (size_t)td.K * sizeof(float);  // the DTW band reads up to band_size frames past a row
         const size_t pcm_bytes = S * (1 + max_chunks_per_call) * 480 * sizeof(float);
-        if (!b->pcm.reserve(pcm_bytes) || !b->mfcc[0].reserve(S * pitch * td.K * sizeof(float) + slack) ||
+        if (!b->pcm[0].reserve(pcm_bytes) || !b->pcm[1].reserve(pcm_bytes) || !b->mfcc[0].reserve(S * pitch * td.K * sizeof(float) + slack) ||
             !b->mfcc[1].reserve(S * pitch * td.K * sizeof(float) + slack) || !b->state.reserve(S * stream_state_bytes()) ||
             !b->scores.reserve(rows * td.T * sizeof(float) + 16) || !b->agg.reserve(rows * sizeof(float) + 16) ||
             !b->avg.reserve(rows * sizeof(float) + 16) || !b->vad.reserve(rows * sizeof(float) + 16))
             return -1;
-        if (!hip_ok(hipMemsetAsync(b->pcm.p, 0, pcm_bytes, c->stream), "hipMemsetAsync") ||
+        if (!hip_ok(hipMemsetAsync(b->pcm[0].p, 0, pcm_bytes, c->stream), "hipMemsetAsync") ||
+            !hip_ok(hipMemsetAsync(b->pcm[1].p, 0, pcm_bytes, c->stream), "hipMemsetAsync") ||
             !hip_ok(hipMemsetAsync(b->mfcc[0].p, 0, b->mfcc[0].cap, c->stream), "hipMemsetAsync") ||
             !hip_ok(hipMemsetAsync(b->mfcc[1].p, 0, b->mfcc[1].cap, c->stream), "hipMemsetAsync") ||
             !hip_ok(launch_stream_state_init(c->stream, b->state.p, S), "stream_state_init_kernel"))
             return -1;
-        b->cur = 0; b->cur_pitch = b->hist_frames;  // an all-zero history nobody scores against (frames < 0)
+        b->cur = 0; b->fill = b->hist_frames;  // an all-zero history nobody scores against (frames < 0)
+        b->pcur = 0; b->last_off = 0;
         *out = b.release();
         return 0;
     });
@@ -594,7 +602,7 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         const TemplatesDev &td = b->t->dev;
         const MfccTablesDev *tb = c->tables_for(td.K);
         if (!tb) return -1;
-        const size_t S = b->S, n_new = 3 * n_chunks, hist = b->hist_frames, pitch = hist + n_new, rows = S * n_new;
+        const size_t S = b->S, n_new = 3 * n_chunks, hist = b->hist_frames, pitch = b->cap, rows = S * n_new;
         const size_t n_samples = (1 + n_chunks) * 480, pcm_pitch = (1 + b->max_chunks) * 480;
         const bool do_avg = td.has_avg && b->cfg.avg_threshold != 0.f;
         Staged sg(c);
@@ -602,8 +610,8 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
         int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
         if (!dp || !dd || !dn) { if (!pcm || !det || !n_det) set_last_error("null argument"); return -1; }
-        float *hp = b->pcm.as<float>();
-        float *prev = b->mfcc[b->cur].as<float>(), *now = b->mfcc[b->cur ^ 1].as<float>();
+        const float *hp_old = b->pcm[b->pcur].as<float>();
+        float *hp = b->pcm[b->pcur ^ 1].as<float>();
         if (b->rs) {  // previous input frame | new input frames -> 16 kHz (the resampler never resets, src/detector.rs:290-302)
             const size_t fi = b->in_len;
             float *ro = b->rs_out.as<float>();
@@ -624,20 +632,28 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
                 if (!hip_ok(launch_carry_rows(c->stream, xs, S, (1 + n_chunks) * fi, n_chunks * fi, fi, pn, fi), "carry_rows_kernel")) return -1;
             }
             b->rs_cur ^= 1;
-            if (!hip_ok(launch_stream_stage(c->stream, ro, 3, 1, S, n_chunks * 480, n_chunks * 480, hp, pcm_pitch), "stream_stage_kernel")) return -1;
-        } else if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks * 480, pcm_stride, hp, pcm_pitch), "stream_stage_kernel")) {
+            if (!hip_ok(launch_stream_stage(c->stream, ro, 3, 1, S, n_chunks * 480, n_chunks * 480, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+        } else if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks * 480, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) {
             // previous chunk | new chunks, decoded to f32
             return -1;
         }
-        // last max_len-1 frames of the previous call | the 3*n_chunks new frames
-        if (!hip_ok(launch_carry_rows(c->stream, prev, S, b->cur_pitch * td.K, (b->cur_pitch - hist) * td.K, hist * td.K, now, pitch * td.K), "carry_rows_kernel")) return -1;
+        b->pcur ^= 1; b->last_off = n_chunks * 480;  // the last chunk of this call is the extractor history of the next
+        // MFCC window rows: [.. valid frames .. | the 3*n_chunks new frames]; a full row keeps its last max_len-1 frames
+        if (b->fill + n_new > b->cap) {
+            if (!hip_ok(launch_carry_rows(c->stream, b->mfcc[b->cur].as<float>(), S, pitch * td.K, (b->fill - hist) * td.K, hist * td.K,
+                                          b->mfcc[b->cur ^ 1].as<float>(), pitch * td.K), "carry_rows_kernel")) return -1;
+            b->cur ^= 1; b->fill = hist;
+        }
+        float *now = b->mfcc[b->cur].as<float>();
+        const size_t fill = b->fill;
         c->time_begin(kKernelMfcc);
-        bool ok = hip_ok(launch_mfcc(c->stream, *tb, hp, S, n_samples, pcm_pitch, 0, n_new, pitch, now + hist * td.K), "mfcc_kernel");
+        bool ok = hip_ok(launch_mfcc(c->stream, *tb, hp, S, n_samples, pcm_pitch, 0, n_new, pitch, now + fill * td.K), "mfcc_kernel");
         c->time_end();
         if (!ok) return -1;
+        b->fill += n_new;
         float *ds = b->scores.as<float>(), *dg = b->agg.as<float>(), *da = do_avg ? b->avg.as<float>() : nullptr;
         c->time_begin(kKernelDtw);
-        ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, 0, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true), "dtw kernel");
+        ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true), "dtw kernel");
         c->time_end();
         if (!ok) return -1;
         c->time_begin(kKernelAggregate);
@@ -651,15 +667,13 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         ScanConfig sc;
         sc.threshold = b->cfg.threshold; sc.avg_threshold = b->cfg.avg_threshold; sc.min_scores = (int)b->cfg.min_scores;
         sc.eager = b->cfg.eager ? 1 : 0; sc.max_len = td.max_len; sc.avg_enabled = do_avg ? 1 : 0;
-        if (dv && !hip_ok(launch_vad_value_rows(c->stream, now + hist * td.K, S, n_new, pitch, td.K, dv), "vad_value_kernel")) return -1;
+        if (dv && !hip_ok(launch_vad_value_rows(c->stream, now + fill * td.K, S, n_new, pitch, td.K, dv), "vad_value_kernel")) return -1;
         c->time_begin(kKernelScan);
         ok = hip_ok(launch_scan_stream(c->stream, dg, da, dv, vad_mode_value(b->cfg.vad_mode), S, 3 * (long long)b->chunks_seen - 3, (int)n_new,
                                        sc, b->state.p, dd, dn, max_det), "scan_stream_kernel");
         c->time_end();
         if (!ok) return -1;
-        // the last chunk becomes the extractor history of the next call
-        if (!hip_ok(launch_carry_rows(c->stream, hp, S, pcm_pitch, n_chunks * 480, 480, hp, pcm_pitch), "carry_rows_kernel")) return -1;
-        b->cur ^= 1; b->cur_pitch = pitch; b->chunks_seen += n_chunks;
+        b->chunks_seen += n_chunks;
         if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
         if (agg) {
             if (sg.host) { if (!sg.back(agg, dg, rows * sizeof(float))) return -1; }

@@ -119,7 +119,7 @@ hipError_t launch_resample(hipStream_t st, const ResamplerDev &rs, const float *
 
 // streaming batches (state carried between calls; rp_stream.cpp)
 hipError_t launch_stream_stage(hipStream_t st, const void *pcm, int fmt, int channels, size_t S, size_t n_new, size_t pcm_stride,
-                               float *hist, size_t hist_pitch);
+                               const float *old_hist, size_t old_off, float *hist, size_t hist_pitch);
 hipError_t launch_carry_rows(hipStream_t st, const float *src, size_t S, size_t src_pitch, size_t src_off, size_t count, float *dst,
                              size_t dst_pitch);
 hipError_t launch_stream_state_init(hipStream_t st, void *state, size_t S);

@@ -1497,14 +1497,16 @@ struct StreamState {
     float vad_window[50];
 };
 
-// decode the new chunks behind the carried 480-sample chunk: hist [S][(1+n)*480]
+// hist [S][hist_pitch] = the last 480-sample chunk of the previous call (old_hist row + old_off) | the new chunks decoded
 template <class TIN>
 __global__ __launch_bounds__(256) void stream_stage_kernel(const TIN *__restrict__ pcm, int channels, size_t S, size_t n_new,
-                                                           size_t pcm_stride, float *__restrict__ hist, size_t hist_pitch) {
-    const size_t total = S * n_new;
+                                                           size_t pcm_stride, const float *__restrict__ old_hist, size_t old_off,
+                                                           float *__restrict__ hist, size_t hist_pitch) {
+    const size_t row = kFrame + n_new, total = S * row;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t s = i / n_new, k = i - s * n_new;
-        hist[s * hist_pitch + kFrame + k] = SampleIn<TIN>::cvt(pcm[s * pcm_stride + k * channels]);
+        const size_t s = i / row, k = i - s * row;
+        hist[s * hist_pitch + k] = k < (size_t)kFrame ? old_hist[s * hist_pitch + old_off + k]
+                                                      : SampleIn<TIN>::cvt(pcm[s * pcm_stride + (k - kFrame) * channels]);
     }
 }
 // rows [S][src_pitch] -> [S][dst_pitch]: dst[s][0..count) = src[s][src_off .. src_off+count)
@@ -1518,15 +1520,15 @@ __global__ __launch_bounds__(256) void carry_rows_kernel(const float *src, size_
 }
 
 hipError_t launch_stream_stage(hipStream_t st, const void *pcm, int fmt, int channels, size_t S, size_t n_new, size_t pcm_stride,
-                               float *hist, size_t hist_pitch) {
+                               const float *old_hist, size_t old_off, float *hist, size_t hist_pitch) {
     if (S == 0 || n_new == 0) return hipSuccess;
-    size_t blocks = (S * n_new + 255) / 256;
+    size_t blocks = (S * (kFrame + n_new) + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     switch (fmt) {
-    case 0: hipLaunchKernelGGL(stream_stage_kernel<int8_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int8_t *>(pcm), channels, S, n_new, pcm_stride, hist, hist_pitch); break;
-    case 1: hipLaunchKernelGGL(stream_stage_kernel<int16_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int16_t *>(pcm), channels, S, n_new, pcm_stride, hist, hist_pitch); break;
-    case 2: hipLaunchKernelGGL(stream_stage_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int32_t *>(pcm), channels, S, n_new, pcm_stride, hist, hist_pitch); break;
-    case 3: hipLaunchKernelGGL(stream_stage_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(pcm), channels, S, n_new, pcm_stride, hist, hist_pitch); break;
+    case 0: hipLaunchKernelGGL(stream_stage_kernel<int8_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int8_t *>(pcm), channels, S, n_new, pcm_stride, old_hist, old_off, hist, hist_pitch); break;
+    case 1: hipLaunchKernelGGL(stream_stage_kernel<int16_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int16_t *>(pcm), channels, S, n_new, pcm_stride, old_hist, old_off, hist, hist_pitch); break;
+    case 2: hipLaunchKernelGGL(stream_stage_kernel<int32_t>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const int32_t *>(pcm), channels, S, n_new, pcm_stride, old_hist, old_off, hist, hist_pitch); break;
+    case 3: hipLaunchKernelGGL(stream_stage_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float *>(pcm), channels, S, n_new, pcm_stride, old_hist, old_off, hist, hist_pitch); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1,0 +1,143 @@
+// rp_device.h -- device-side helpers shared by the gfx950 kernels (rp_*.hip): packed-f32 complex arithmetic, the
+// small DFTs the FFT-240 is built from, wave-scope LDS ordering, sample decoding.  Everything is compiled with
+// -ffp-contract=off: every fused multiply-add is an explicit fmaf() / __builtin_elementwise_fma (the reference never
+// contracts, and pre-emphasis and the DCT must round exactly like it so that digital silence still normalises to
+// exactly zero, SURVEY.md §7 "Silence").
+#pragma once
+#include "rp_kernels.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace rp {
+
+#define RP_INF __builtin_inff()
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ complex helpers
+// Complex numbers are 2-lane ext vectors so that add/sub/mul map onto the packed f32 VALU ops
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: 2 results per 4-cycle slot against 3 cycles for
+// one plain op on gfx950).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+    v2f r = a.xx * b;
+    return __builtin_elementwise_fma((v2f){-a.y, a.y}, b.yx, r);
+}
+__device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }  // a * (-i)
+
+// forward 4-point DFT, in place, natural order
+__device__ __forceinline__ void dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
+    v2f t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = mul_mi(x1 - x3);
+    x0 = t0 + t2; x1 = t1 + t3; x2 = t0 - t2; x3 = t1 - t3;
+}
+
+// forward 16-point DFT in registers.  Input v[n]; output X[c + 4d] is left at v[4c + d].
+__device__ __forceinline__ void fft16(v2f (&v)[16]) {
+    // W16^e = exp(-2*pi*i*e/16) for e = b*c, b,c in 0..3
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);  // -> v[4c+b]
+    // twiddles v[4c+b] *= W16^{bc}
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], (v2f){C1, -S1});   // e=1
+    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], (v2f){R2, -R2});   // e=2
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], (v2f){S1, -C1});   // e=3
+    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], (v2f){R2, -R2});   // e=2
+    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                 // e=4
+    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], (v2f){-R2, -R2});  // e=6
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], (v2f){S1, -C1});   // e=3
+    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], (v2f){-R2, -R2});  // e=6
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], (v2f){-C1, S1});   // e=9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+__device__ __forceinline__ void dft3(v2f &x0, v2f &x1, v2f &x2) {
+    constexpr float C = 0.86602540378443865f;
+    v2f s = x1 + x2, d = x1 - x2;
+    v2f m = __builtin_elementwise_fma((v2f){-0.5f, -0.5f}, s, x0);
+    v2f r = (v2f){C, -C} * d.yx;  // -i * C * d
+    x0 = x0 + s;
+    x1 = m + r;
+    x2 = m - r;
+}
+
+__device__ __forceinline__ void dft5(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v2f &x4) {
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    v2f a1 = x1 + x4, a2 = x2 + x3, b1 = x1 - x4, b2 = x2 - x3;
+    v2f m1 = __builtin_elementwise_fma((v2f){c2, c2}, a2, __builtin_elementwise_fma((v2f){c1, c1}, a1, x0));
+    v2f m2 = __builtin_elementwise_fma((v2f){c1, c1}, a2, __builtin_elementwise_fma((v2f){c2, c2}, a1, x0));
+    v2f n1 = __builtin_elementwise_fma((v2f){s2, s2}, b2, (v2f){s1, s1} * b1);
+    v2f n2 = __builtin_elementwise_fma((v2f){-s1, -s1}, b2, (v2f){s2, s2} * b1);
+    v2f r1 = mul_mi(n1), r2 = mul_mi(n2);  // -i * n
+    x0 = x0 + (a1 + a2);
+    x1 = m1 + r1;
+    x4 = m1 - r1;
+    x2 = m2 + r2;
+    x3 = m2 - r2;
+}
+
+// forward 15-point DFT (Good-Thomas 3x5, no twiddles): z[k] = sum_n u[n] W15^{nk}
+__device__ __forceinline__ void dft15(const v2f (&u)[15], v2f (&z)[15]) {
+    v2f y[3][5];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) {
+        v2f a0 = u[(3 * n2) % 15], a1 = u[(5 + 3 * n2) % 15], a2 = u[(10 + 3 * n2) % 15];
+        dft3(a0, a1, a2);
+        y[0][n2] = a0; y[1][n2] = a1; y[2][n2] = a2;
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {
+        dft5(y[k1][0], y[k1][1], y[k1][2], y[k1][3], y[k1][4]);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; ++k2) z[(10 * k1 + 6 * k2) % 15] = y[k1][k2];
+    }
+}
+
+// orders this wave's LDS traffic (lanes exchange data through LDS without a workgroup barrier)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the 16 lanes of a DPP row; every lane ends with the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));  // row_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    return v;
+}
+
+// Input sample types of the reference's `Sample` trait (src/audio/audio_types.rs:98-137): integers are
+// converted as `v as f32 / T::MAX as f32` (an IEEE division, not a multiply by the reciprocal).
+template <class T> struct SampleIn;
+template <> struct SampleIn<float> {
+    static __device__ __forceinline__ float cvt(float v) { return v; }
+    static __device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+};
+template <> struct SampleIn<int16_t> {
+    static __device__ __forceinline__ float cvt(int16_t v) { return (float)v / 32767.f; }
+    static __device__ __forceinline__ float4 load4(const int16_t *p) {
+        const short4 s = *reinterpret_cast<const short4 *>(p);
+        return make_float4(cvt(s.x), cvt(s.y), cvt(s.z), cvt(s.w));
+    }
+};
+template <> struct SampleIn<int8_t> {
+    static __device__ __forceinline__ float cvt(int8_t v) { return (float)v / 127.f; }
+    static __device__ __forceinline__ float4 load4(const int8_t *p) {
+        const char4 s = *reinterpret_cast<const char4 *>(p);
+        return make_float4(cvt((int8_t)s.x), cvt((int8_t)s.y), cvt((int8_t)s.z), cvt((int8_t)s.w));
+    }
+};
+template <> struct SampleIn<int32_t> {
+    static __device__ __forceinline__ float cvt(int32_t v) { return (float)v / 2147483648.f; }  // i32::MAX as f32 == 2^31
+    static __device__ __forceinline__ float4 load4(const int32_t *p) {
+        const int4 s = *reinterpret_cast<const int4 *>(p);
+        return make_float4(cvt(s.x), cvt(s.y), cvt(s.z), cvt(s.w));
+    }
+};
+
+}  // namespace rp

@@ -1,0 +1,565 @@
+// rp_dtw.hip -- window scoring: dtw_band_kernel / dtw_band_wide_kernel / dtw_generic_kernel
+// (src/mfcc/dtw.rs:56-105 + comparator.rs + normalizer.rs + wakeword_comp.rs:22-27; one lane per window, band and ring
+// in registers) and aggregate_kernel (src/wakewords/comp/wakeword_comp.rs:38-49,108-139).  DESIGN.md §4.2.
+#include "rp_device.h"
+
+namespace rp {
+
+// -------------------------------------------------------------------------- DTW
+// Scoring of one (window, template) pair, reference semantics:
+//   window = frames [w, w+L) of the stream (cut to the template length L keeping the
+//   OLDEST frames, wakeword_comp.rs:22-27), column-mean normalised (normalizer.rs);
+//   D[r][c] = (1 - cos(a[r-1], b[c-1])) + min(D[r-1][c], D[r][c-1], D[r-1][c-1]) on the band
+//   c in [r-W, r+W-1]; result D[m-1][n] (dtw.rs:101); score = 1/(1+exp((cost/(m+n)-ref)/ref)).
+// Template rows are pre-scaled to unit length on the host and window frames are scaled
+// to unit length here, so a cell costs K fused multiply-adds instead of three dot
+// products, a sqrt and a divide (comparator.rs:28-48); zero vectors stay zero, which
+// reproduces the reference's "magnitude == 0 -> similarity 0".
+constexpr int kDtwWin = 64;   // windows per wave
+
+// One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
+// Per lane: the window's column means, a ring of the 2W unit-length window frames inside the
+// band (shared by all TC templates), and TC bands of 2W+1 running costs held as register pairs of
+// two templates: one v_pk_fma_f32 forms the cosine costs of a band cell for both templates (the
+// coefficient pair comes from scalar registers, the window component is broadcast by op_sel),
+// one v_pk_add_f32 adds the two v_min3_f32 results.  Rows are unrolled 2W at a time so
+// every ring slot and band index is a compile-time register.  Only the first 2W rows can touch
+// columns c < 1 and need the +inf guard; columns c > n are never read back by an in-range cell
+// (they only feed cells further right / below-right), so they are left unguarded.
+// GX: lanes read their window's frames straight from global memory instead of an LDS stage: used when a
+// stream contributes only a few windows per launch (streaming batches), so that the 64 lanes of a wave
+// can belong to many different streams.
+template <int K, int W, int TC, bool GX>
+__global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
+    int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
+    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
+    int flat, size_t n_streams) {
+    constexpr int B = 2 * W;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);  // [64 + 2 (L + W)][KP]: up to two stream segments
+
+    const unsigned tile = blockIdx.x % tiles;
+    const unsigned ci = (blockIdx.x / tiles) % n_chunks;
+    const int lane = threadIdx.x;
+    const DtwChunk *ch = chunks + chunk_base + ci;
+    const int L = ch->len;  // m == n == L
+    // Lane -> (stream, window).  flat != 0: the 64 lanes are consecutive entries of the flattened
+    // (stream, window) space, so a wave may straddle two streams (needs n_win >= 64) and no lane is
+    // wasted on a ragged last tile; flat == 0: tiles never cross a stream.
+    size_t s;
+    int w;
+    bool valid;
+    const float *xl;
+    if (GX) {
+        static_assert(!GX || KP == K, "global-memory frames have pitch K");
+        const size_t f = (size_t)tile * kDtwWin + lane;
+        valid = f < n_streams * n_win;
+        s = valid ? f / n_win : 0;
+        w = valid ? (int)(f - s * n_win) : 0;
+        xl = mfcc + (s * frame_pitch + first_win + (size_t)w) * K;
+    } else {
+        size_t sA, sB = 0;
+        int wA, nA, nB = 0;
+        if (flat) {
+            const size_t f0 = (size_t)tile * kDtwWin;  // here `tiles` counts flattened tiles and there is no stream index
+            sA = f0 / n_win;
+            wA = (int)(f0 - sA * n_win);
+            nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
+            if (nA < kDtwWin && sA + 1 < n_streams) { sB = sA + 1; nB = kDtwWin - nA; }
+        } else {
+            sA = blockIdx.x / ((size_t)tiles * n_chunks);
+            wA = (int)tile * kDtwWin;
+            nA = (int)n_win - wA < kDtwWin ? (int)n_win - wA : kDtwWin;
+        }
+        const int segA = nA + L + W;  // frames staged for the first stream segment
+        {
+            const float *src = mfcc + sA * frame_pitch * K;
+            const size_t g0 = first_win + wA;
+            for (int i = lane; i < segA * K; i += kDtwWin) {
+                int f = i / K, k = i - f * K;
+                size_t g = g0 + f;
+                xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+            }
+        }
+        if (nB > 0) {
+            const float *src = mfcc + sB * frame_pitch * K;
+            const int segB = nB + L + W;
+            for (int i = lane; i < segB * K; i += kDtwWin) {
+                int f = i / K, k = i - f * K;
+                size_t g = first_win + f;
+                xs[(segA + f) * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+            }
+        }
+        __syncthreads();
+        const bool inA = lane < nA;
+        valid = inA || (lane - nA < nB);
+        s = inA ? sA : sB;
+        w = inA ? wA + lane : lane - nA;
+        xl = xs + (inA ? lane : (valid ? segA + lane - nA : 0)) * KP;
+    }
+    // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums
+    float mu[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = 0.f;
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) mu[k] += xl[i * KP + k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = mu[k] / (float)L;
+
+    v2f ring[B / 2][K];  // ring[j][k] = { y_slot(2j)[k], y_slot(2j+1)[k] }
+#pragma unroll
+    for (int j = 0; j < B / 2; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring[j][k] = (v2f){0.f, 0.f};
+
+#define RP_LOAD_COL(c, slot)                                                              \
+    do {                                                                                  \
+        float y_[K], bb_ = 0.f;                                                           \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
+            y_[k] = xl[((c)-1) * KP + k] - mu[k];                                         \
+            bb_ = fmaf(y_[k], y_[k], bb_);                                                \
+        }                                                                                 \
+        const float inv_ = bb_ > 0.f ? rsqrtf(bb_) : 0.f;                                 \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
+            if (((slot)&1) == 0) ring[(slot) / 2][k].x = y_[k] * inv_;                    \
+            else ring[(slot) / 2][k].y = y_[k] * inv_;                                    \
+        }                                                                                 \
+    } while (0)
+
+#pragma unroll
+    for (int c = 1; c < W; ++c) RP_LOAD_COL(c, c % B);
+
+    // P[tp][q] = D[r-1][(r-1-W)+q] of templates (2tp, 2tp+1); row 0 has D[0][0] = 0 at q = W
+    v2f P[TC / 2][B + 1];
+#pragma unroll
+    for (int t = 0; t < TC / 2; ++t) {
+#pragma unroll
+        for (int q = 0; q <= B; ++q) P[t][q] = (v2f){RP_INF, RP_INF};
+        P[t][W] = (v2f){0.f, 0.f};
+    }
+
+    const float *rows = dup + ch->rows_off;
+#define RP_ROWS(GUARD)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < B; ++u) {                                                    \
+        const int r = r0 + u;                                                                          \
+        if (r < L) { /* rows 1..m-1 only: row m is never read (dtw.rs:101) */                          \
+            RP_LOAD_COL(r + W - 1, (u + W) % B);                                                       \
+            _Pragma("unroll") for (int t = 0; t < TC / 2; ++t) {                                       \
+                /* coefficients of the template pair, interleaved (t0,t1) per k: one scalar pair */    \
+                const v2f *arow = reinterpret_cast<const v2f *>(rows + ((size_t)(r - 1) * (TC / 2) + t) * K * 2); \
+                v2f a2[K];                                                                             \
+                _Pragma("unroll") for (int k = 0; k < K; ++k) a2[k] = arow[k];                         \
+                /* costs of the 2W band cells first (independent FMA chains), then the serial min chain */ \
+                v2f d[B];                                                                              \
+                _Pragma("unroll") for (int q = 0; q < B; ++q) d[q] = (v2f){1.f, 1.f};                  \
+                _Pragma("unroll") for (int k = 0; k < K; ++k) {                                        \
+                    _Pragma("unroll") for (int q = 0; q < B; ++q) {                                    \
+                        const int slot = (1 + u + q + B - W) % B;                                      \
+                        const v2f yy = (slot & 1) ? ring[slot / 2][k].yy : ring[slot / 2][k].xx;       \
+                        d[q] = __builtin_elementwise_fma(-a2[k], yy, d[q]);                            \
+                    }                                                                                  \
+                }                                                                                      \
+                v2f left = (v2f){RP_INF, RP_INF};                                                      \
+                _Pragma("unroll") for (int q = 0; q < B; ++q) {                                        \
+                    v2f m;                                                                             \
+                    m.x = fminf(fminf(P[t][q + 1].x, left.x), P[t][q].x);                              \
+                    m.y = fminf(fminf(P[t][q + 1].y, left.y), P[t][q].y);                              \
+                    v2f v = d[q] + m;                                                                  \
+                    if (GUARD) v = (r - W + q >= 1) ? v : (v2f){RP_INF, RP_INF};                       \
+                    P[t][q] = v;                                                                       \
+                    left = v;                                                                          \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+    }
+
+    {
+        const int r0 = 1;
+        RP_ROWS(true)
+    }
+    for (int r0 = 1 + B; r0 < L; r0 += B) { RP_ROWS(false) }
+#undef RP_ROWS
+#undef RP_LOAD_COL
+
+    if (valid) {
+        const size_t row = s * out_win_pitch + (size_t)w;
+        const float denom = (float)(L + L);
+#pragma unroll
+        for (int t = 0; t < TC; ++t) {
+            if (t < ch->count) {
+                const float cost = (t & 1) ? P[t / 2][W + 1].y : P[t / 2][W + 1].x;  // D[m-1][n] for m == n
+                const float nc = cost / denom;
+                const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+                const int tid = ch->tid[t];
+                if (tid < T) scores[row * T + tid] = sc;
+                else avg[row] = sc;
+            }
+        }
+    }
+}
+
+// Variant for wide frames (K = 16): the ring alone is 160 registers, so the band costs are formed one
+// template at a time with two band cells per v_pk_fma_f32 (coefficient duplicated into a scalar pair)
+// instead of holding the costs of a template pair for all 2W cells.
+template <int K, int W, int TC>
+__global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
+    int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
+    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    constexpr int B = 2 * W;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);  // [64 + L + W][KP]
+
+    const unsigned tile = blockIdx.x % tiles;
+    const unsigned ci = (blockIdx.x / tiles) % n_chunks;
+    const size_t s = blockIdx.x / ((size_t)tiles * n_chunks);
+    const int lane = threadIdx.x;
+    const DtwChunk *ch = chunks + chunk_base + ci;
+    const int L = ch->len;  // m == n == L
+    const size_t w0 = first_win + (size_t)tile * kDtwWin;
+
+    const int n_stage = kDtwWin + L + W;
+    const float *src = mfcc + s * frame_pitch * K;
+    for (int i = lane; i < n_stage * K; i += kDtwWin) {
+        int f = i / K, k = i - f * K;
+        size_t g = w0 + f;
+        xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+    }
+    __syncthreads();
+
+    const float *xl = xs + lane * KP;
+    // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums
+    float mu[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = 0.f;
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) mu[k] += xl[i * KP + k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = mu[k] / (float)L;
+
+    v2f ring[B / 2][K];  // ring[j][k] = { y_slot(2j)[k], y_slot(2j+1)[k] }
+#pragma unroll
+    for (int j = 0; j < B / 2; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring[j][k] = (v2f){0.f, 0.f};
+
+#define RP_LOAD_COL(c, slot)                                                              \
+    do {                                                                                  \
+        float y_[K], bb_ = 0.f;                                                           \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
+            y_[k] = xl[((c)-1) * KP + k] - mu[k];                                         \
+            bb_ = fmaf(y_[k], y_[k], bb_);                                                \
+        }                                                                                 \
+        const float inv_ = bb_ > 0.f ? rsqrtf(bb_) : 0.f;                                 \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
+            if (((slot)&1) == 0) ring[(slot) / 2][k].x = y_[k] * inv_;                    \
+            else ring[(slot) / 2][k].y = y_[k] * inv_;                                    \
+        }                                                                                 \
+    } while (0)
+
+#pragma unroll
+    for (int c = 1; c < W; ++c) RP_LOAD_COL(c, c % B);
+
+    // P[t][q] = D[r-1][(r-1-W)+q] of template t; row 0 has D[0][0] = 0 at q = W
+    float P[TC][B + 1];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+#pragma unroll
+        for (int q = 0; q <= B; ++q) P[t][q] = RP_INF;
+        P[t][W] = 0.f;
+    }
+
+    const float *rows = dup + ch->rows_off;
+#define RP_ROWS(GUARD)                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < B; ++u) {                                                    \
+        const int r = r0 + u;                                                                          \
+        if (r < L) { /* rows 1..m-1 only: row m is never read (dtw.rs:101) */                          \
+            RP_LOAD_COL(r + W - 1, (u + W) % B);                                                       \
+            _Pragma("unroll") for (int t = 0; t < TC; ++t) {                                           \
+                const float *arow = rows + ((size_t)(r - 1) * (TC / 2) + t / 2) * K * 2 + (t & 1);     \
+                v2f dd[B / 2];                                                                         \
+                _Pragma("unroll") for (int j = 0; j < B / 2; ++j) dd[j] = (v2f){1.f, 1.f};             \
+                _Pragma("unroll") for (int k = 0; k < K; ++k) {                                        \
+                    const v2f a2 = (v2f){arow[2 * k], arow[2 * k]};                                   \
+                    _Pragma("unroll") for (int j = 0; j < B / 2; ++j)                                  \
+                        dd[j] = __builtin_elementwise_fma(-a2, ring[j][k], dd[j]);                     \
+                }                                                                                      \
+                float left = RP_INF;                                                                   \
+                _Pragma("unroll") for (int q = 0; q < B; ++q) {                                        \
+                    const int slot = (1 + u + q + B - W) % B;                                          \
+                    const float d = (slot & 1) ? dd[slot / 2].y : dd[slot / 2].x;                      \
+                    float v = d + fminf(fminf(P[t][q + 1], left), P[t][q]);                            \
+                    if (GUARD) v = (r - W + q >= 1) ? v : RP_INF;                                      \
+                    P[t][q] = v;                                                                       \
+                    left = v;                                                                          \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+    }
+
+    {
+        const int r0 = 1;
+        RP_ROWS(true)
+    }
+    for (int r0 = 1 + B; r0 < L; r0 += B) { RP_ROWS(false) }
+#undef RP_ROWS
+#undef RP_LOAD_COL
+
+    if (tile * (size_t)kDtwWin + lane < n_win) {
+        const size_t row = s * out_win_pitch + (size_t)tile * kDtwWin + lane;
+        const float denom = (float)(L + L);
+#pragma unroll
+        for (int t = 0; t < TC; ++t) {
+            if (t < ch->count) {
+                const float cost = P[t][W + 1];  // D[m-1][n] for m == n
+                const float nc = cost / denom;
+                const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+                const int tid = ch->tid[t];
+                if (tid < T) scores[row * T + tid] = sc;
+                else avg[row] = sc;
+            }
+        }
+    }
+}
+
+// Fallback for any K / band size / m != n: one wave = 64 windows x one template, band
+// and column means in LDS (lane-minor, conflict-free), costs evaluated per cell.
+__global__ __launch_bounds__(64) void dtw_generic_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, size_t first_win,
+    size_t n_win, size_t out_win_pitch, const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K,
+    int T, int Ttot, int max_len, int band, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int KP = K | 1;
+    const unsigned tile = blockIdx.x % tiles;
+    const int t = (blockIdx.x / tiles) % Ttot;
+    const size_t s = blockIdx.x / ((size_t)tiles * Ttot);
+    const int lane = threadIdx.x;
+    const size_t w0 = first_win + (size_t)tile * 64;
+    const int m = lens[t];
+    const int n = m < max_len ? m : max_len;  // window cut to the template length
+    const int diff = m > n ? m - n : n - m;
+    const int W = band > diff ? band : diff;
+    const int B = 2 * W;
+
+    const int n_stage = 64 + max_len - 1;
+    float *xs = reinterpret_cast<float *>(smem);      // [n_stage][KP]
+    float *mus = xs + (size_t)n_stage * KP;           // [K][64]
+    float *Pb = mus + (size_t)K * 64;                 // [B+1][64]
+    const float *src = mfcc + s * frame_pitch * K;
+    for (int i = lane; i < n_stage * K; i += 64) {
+        int f = i / K, k = i - f * K;
+        size_t g = w0 + f;
+        xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+    }
+    __syncthreads();
+    const float *xl = xs + lane * KP;
+    for (int k = 0; k < K; ++k) {
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) sum += xl[i * KP + k];
+        mus[k * 64 + lane] = sum / (float)n;
+    }
+    for (int q = 0; q <= B; ++q) Pb[q * 64 + lane] = RP_INF;
+    Pb[W * 64 + lane] = 0.f;
+    const float *trow = unit + (size_t)t * Lpad * K;
+    for (int r = 1; r < m; ++r) {
+        float left = RP_INF;
+        for (int q = 0; q < B; ++q) {
+            const int c = r - W + q;
+            float v = RP_INF;
+            if (c >= 1 && c <= n) {
+                float dot = 0.f, bb = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    float y = xl[(c - 1) * KP + k] - mus[k * 64 + lane];
+                    dot = fmaf(trow[(r - 1) * K + k], y, dot);
+                    bb = fmaf(y, y, bb);
+                }
+                float cosv = bb > 0.f ? dot * rsqrtf(bb) : 0.f;
+                v = (1.f - cosv) + fminf(fminf(Pb[(q + 1) * 64 + lane], left), Pb[q * 64 + lane]);
+            }
+            Pb[q * 64 + lane] = v;
+            left = v;
+        }
+    }
+    if (tile * (size_t)64 + lane < n_win) {
+        const int qs = n - (m - 1 - W);  // column n of row m-1
+        float cost = (qs >= 0 && qs < B) ? Pb[qs * 64 + lane] : RP_INF;
+        float nc = cost / (float)(m + n);
+        float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+        size_t row = s * out_win_pitch + (size_t)tile * 64 + lane;
+        if (t < T) scores[row * T + t] = sc;
+        else avg[row] = sc;
+    }
+}
+
+template <int K, int W, int TC>
+static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
+                                   size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
+                                   float score_ref, float *scores, float *avg, bool few_windows) {
+    if (n_chunks <= 0) return hipSuccess;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
+    if (few_windows && KP == K && W == 5) {
+        // streams contribute fewer than 64 windows each: lanes of a wave span many streams and read their frames
+        // from global memory (the caller guarantees W*K floats of slack after the last stream's frames)
+        const size_t ft = (S * n_win + kDtwWin - 1) / kDtwWin;
+        const size_t blocks = ft * (size_t)n_chunks;
+        if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+        if (W == 5)
+            hipLaunchKernelGGL((dtw_band_kernel<K, 5, TC, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
+                               frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+                               t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S);
+        return hipGetLastError();
+    }
+    // flattened (stream, window) tiling when every stream has at least one full tile of windows
+    const int flat = (n_win >= (size_t)kDtwWin && S > 1) ? 1 : 0;
+    const size_t ft = flat ? (S * n_win + kDtwWin - 1) / kDtwWin : tiles;
+    const size_t blocks = flat ? ft * (size_t)n_chunks : tiles * (size_t)n_chunks * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + W)) * KP * sizeof(float);
+    hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+                       frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+                       t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
+    return hipGetLastError();
+}
+
+template <int K, int W, int TC>
+static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
+                                  size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
+                                  float score_ref, float *scores, float *avg) {
+    if (n_chunks <= 0) return hipSuccess;
+    const size_t blocks = tiles * (size_t)n_chunks * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
+    const size_t lds = (size_t)(kDtwWin + t.max_len + W) * KP * sizeof(float);
+    hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+                       frame_pitch, (unsigned)tiles, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+                       t.chunks, t.dup, t.T, score_ref, scores, avg);
+    return hipGetLastError();
+}
+
+// Largest template tile the register kernels are built for at this (mfcc_size, band) (0 = only the generic
+// kernel applies).  Built: mfcc_size 5 with band 3..6, mfcc_size 16 with band 5.
+int dtw_register_tile(int K, int band) {
+    if (K == 5 && band >= 3 && band <= 6) return 8;
+    if (K == 16 && band == 5) return 2;
+    return 0;
+}
+
+template <int W>
+static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n2, const float *mfcc, size_t S, size_t frame_pitch,
+                                size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
+                                float *scores, float *avg, bool few) {
+    hipError_t e;
+    if ((e = launch_dtw_class<5, W, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)) != hipSuccess) return e;
+    if ((e = launch_dtw_class<5, W, 4>(st, t, 1, t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)) != hipSuccess) return e;
+    return launch_dtw_class<5, W, 8>(st, t, 2, t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+}
+
+hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                      size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
+                      float *scores, float *avg, bool padded_rows) {
+    if (S == 0 || n_win == 0) return hipSuccess;
+    // many streams with few windows each (streaming batches): cross-stream waves reading frames from global memory;
+    // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
+    const bool few = padded_rows && S > 1 && n_win < (size_t)kDtwWin;
+    const bool do_avg = with_avg && t.has_avg;
+    const int Ttot = t.T + (do_avg ? 1 : 0);
+    const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
+    // the register kernels assume m == n (no template longer than the window)
+    if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks) {
+        const int n2 = t.class_count[0] - ((t.has_avg && !do_avg) ? 1 : 0);
+        if (t.K == 5) {
+            switch (band) {
+            case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            }
+        }
+        return launch_dtw_wide<16, 5, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+    }
+    const size_t blocks = tiles * (size_t)Ttot * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const int KP = t.K | 1;
+    // the band is widened to |m-n| inside the kernel; size for the worst case over templates
+    const int Wmax = band > t.max_diff ? band : t.max_diff;
+    const size_t lds = ((size_t)(64 + t.max_len - 1) * KP + (size_t)t.K * 64 + (size_t)(2 * Wmax + 1) * 64) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_generic_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
+                       (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, Ttot,
+                       t.max_len, band, score_ref, scores, avg);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------- aggregate
+// src/wakewords/comp/wakeword_comp.rs:38-49 (get_percentile) and :108-139
+__device__ inline float percentile_sorted(const float *v, int n, float percentile) {
+    float index = percentile / 100.0f * (float)(n - 1);
+    float fl = floorf(index);
+    if (fl == index) return v[(int)index];
+    int i = (int)fl;
+    float d = index - fl;
+    return v[i] * (1.0f - d) + v[i + 1] * d;
+}
+
+constexpr int kAggMaxT = 256;
+
+__global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
+                                                       float *__restrict__ agg) {
+    size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= n_rows) return;
+    const float *v = scores + row * T;
+    if (mode == 1) {  // Max
+        float m = v[0];
+        for (int i = 1; i < T; ++i) m = fmaxf(m, v[i]);
+        agg[row] = m;
+        return;
+    }
+    if (mode == 0) {  // Average: sequential sum in template order
+        float s = 0.f;
+        for (int i = 0; i < T; ++i) s += v[i];
+        agg[row] = s / (float)T;
+        return;
+    }
+    float tmp[kAggMaxT];
+    for (int i = 0; i < T; ++i) {  // insertion sort ascending (total_cmp order for non-NaN scores)
+        float x = v[i];
+        int j = i - 1;
+        while (j >= 0 && tmp[j] > x) { tmp[j + 1] = tmp[j]; --j; }
+        tmp[j + 1] = x;
+    }
+    float p = 50.f;
+    switch (mode) {
+    case 3: p = 25.f; break;
+    case 5: p = 75.f; break;
+    case 6: p = 80.f; break;
+    case 7: p = 90.f; break;
+    case 8: p = 95.f; break;
+    default: p = 50.f; break;  // Median, P50
+    }
+    agg[row] = percentile_sorted(tmp, T, p);
+}
+
+hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg) {
+    if (n_rows == 0) return hipSuccess;
+    if (T < 1 || T > kAggMaxT) return hipErrorInvalidValue;
+    size_t blocks = (n_rows + 63) / 64;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
+    return hipGetLastError();
+}
+
+}  // namespace rp

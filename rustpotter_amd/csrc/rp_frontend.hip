@@ -1,0 +1,154 @@
+// rp_frontend.hip -- decode + GainNormalizerFilter + BandPassFilter over whole streams
+// (src/audio/gain_normalizer_filter.rs:14-55, src/audio/band_pass_filter.rs:19-55, src/detector.rs:358-371).
+#include "rp_device.h"
+
+namespace rp {
+
+// --------------------------------------------------------------------- front-end
+// Sample decode + GainNormalizerFilter + BandPassFilter for whole streams (src/detector.rs:358-371).
+// None of it depends on the detection state (reset() leaves both filters alone, :290-302), so it is
+// a pure function of the stream: per-chunk RMS in parallel, the gain recursion per stream over the
+// chunk RMS values, then gain + biquad per stream along time (one lane per stream: a lane re-reads
+// its own 128-byte lines from L1, HBM traffic stays one read + one write of the PCM).
+template <class TIN>
+__global__ __launch_bounds__(256) void chunk_rms_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_chunks, size_t pcm_stride,
+                                                        int vec4, float *__restrict__ rms) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * n_chunks) return;
+    const size_t s = i / n_chunks, c = i - s * n_chunks;
+    const TIN *x = pcm + s * pcm_stride + c * kFrame;
+    float sum_squared = 0.0f;  // GainNormalizerFilter::get_rms_level, gain_normalizer_filter.rs:49-55 (sequential sum)
+    if (vec4) {
+        constexpr int NB = 24;
+        for (int k0 = 0; k0 < kFrame; k0 += 4 * NB) {
+            float4 buf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) buf[b] = SampleIn<TIN>::load4(x + k0 + 4 * b);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float4 v = buf[b];
+                sum_squared += v.x * v.x; sum_squared += v.y * v.y; sum_squared += v.z * v.z; sum_squared += v.w * v.w;
+            }
+        }
+    } else {
+        for (int k = 0; k < kFrame; ++k) { const float v = SampleIn<TIN>::cvt(x[k]); sum_squared += v * v; }
+    }
+    rms[i] = sqrtf(sum_squared / (float)kFrame);
+}
+
+// GainNormalizerFilter::filter, gain_normalizer_filter.rs:14-41, one lane per stream; the RMS window lives
+// in LDS ([window_size][64]) when it fits, else in the global ring [S][window_size]
+__global__ __launch_bounds__(64) void gain_kernel(const float *__restrict__ rms, size_t S, size_t n_chunks, float rms_level_ref,
+                                                  float min_gain, float max_gain, int window_size, int ring_in_lds,
+                                                  float *__restrict__ ring, float *__restrict__ gains) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    float *w = ring_in_lds ? reinterpret_cast<float *>(smem) + threadIdx.x : ring + s * (size_t)window_size;
+    const int pitch = ring_in_lds ? 64 : 1;
+    const float rms_level_sqrt = sqrtf(rms_level_ref);
+    int len = 0, head = 0;  // logical window = w[((head + i) % window_size) * pitch], i < len (oldest first)
+    for (size_t c = 0; c < n_chunks; ++c) {
+        const float r = rms[s * n_chunks + c];
+        float gain = 1.f;
+        if (!(rms_level_ref != rms_level_ref) && r != 0.f) {
+            if (len < window_size) { w[((head + len) % window_size) * pitch] = r; ++len; }
+            else { w[head * pitch] = r; head = (head + 1) % window_size; }  // push + drain(0..1)
+            float sum = 0.f;
+            for (int i = 0; i < len; ++i) sum += w[((head + i) % window_size) * pitch];
+            const float frame_rms_level = sum / (float)len;
+            gain = rms_level_sqrt / sqrtf(frame_rms_level);
+            gain = roundf(gain * 10.f) / 10.f;
+            gain = gain < min_gain ? min_gain : gain;  // f32::clamp
+            gain = gain > max_gain ? max_gain : gain;
+        }
+        gains[s * n_chunks + c] = gain;
+    }
+}
+
+struct BiquadCoef { float a0, a1, a2, b1, b2; };
+
+// gain (+clamp) and BandPassFilter::filter (band_pass_filter.rs:19-30) along the stream, one lane per stream
+template <class TIN>
+__global__ __launch_bounds__(64) void apply_filters_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_samples, size_t n_chunks,
+                                                           size_t pcm_stride, const float *__restrict__ gains, int band_pass,
+                                                           BiquadCoef q, int vec4, float *__restrict__ out, size_t out_stride) {
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    const TIN *x = pcm + s * pcm_stride;
+    float *y = out + s * out_stride;
+    float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f;
+    for (size_t c = 0; c < n_chunks; ++c) {
+        const float g = gains ? gains[s * n_chunks + c] : 1.f;
+        auto one = [&](float v) {
+            if (g != 1.f) { v = v * g; v = v < -1.f ? -1.f : v; v = v > 1.f ? 1.f : v; }
+            if (band_pass) {
+                const float o = q.a0 * v + q.a1 * x1 + q.a2 * x2 - q.b1 * y1 - q.b2 * y2;
+                x2 = x1; x1 = v; y2 = y1; y1 = o;
+                v = o;
+            }
+            return v;
+        };
+        if (vec4) {  // 4 samples per load/store, 24 loads in flight: with one wave per SIMD (S/64 waves in all)
+                     // the loads must be issued ahead of the dependent filter chain
+            constexpr int NB = 24;
+            for (int k0 = 0; k0 < kFrame; k0 += 4 * NB) {
+                float4 buf[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) buf[b] = SampleIn<TIN>::load4(x + c * kFrame + k0 + 4 * b);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float4 v = buf[b];
+                    v.x = one(v.x); v.y = one(v.y); v.z = one(v.z); v.w = one(v.w);
+                    *reinterpret_cast<float4 *>(y + c * kFrame + k0 + 4 * b) = v;
+                }
+            }
+        } else {
+            for (int k = 0; k < kFrame; ++k) y[c * kFrame + k] = one(SampleIn<TIN>::cvt(x[c * kFrame + k]));
+        }
+    }
+    for (size_t k = n_chunks * kFrame; k < n_samples; ++k) y[k] = SampleIn<TIN>::cvt(x[k]);  // tail shorter than a chunk: never framed
+}
+
+template <class TIN>
+static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, size_t n_samples, size_t pcm_stride, int gain_on,
+                                    float rms_level_ref, float min_gain, float max_gain, int window_size, int band_pass,
+                                    BiquadCoef q, float *ring, float *rms, float *gains, float *out, size_t out_stride) {
+    const size_t n_chunks = n_samples / kFrame;
+    if (S == 0) return hipSuccess;
+    const int vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) &&
+                     (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (out_stride % 4 == 0);
+    if (n_chunks) {
+        const size_t n = S * n_chunks;
+        if ((n + 255) / 256 > 0x7fffffffULL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(chunk_rms_kernel<TIN>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pcm, S, n_chunks, pcm_stride, vec4, rms);
+        if (gain_on) {
+            const size_t ring_lds = (size_t)window_size * 64 * sizeof(float);
+            const int in_lds = ring_lds <= 48 * 1024;
+            hipLaunchKernelGGL(gain_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), in_lds ? ring_lds : 0, st, rms, S, n_chunks,
+                               rms_level_ref, min_gain, max_gain, window_size, in_lds, ring, gains);
+        }
+    }
+    hipLaunchKernelGGL(apply_filters_kernel<TIN>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, pcm, S, n_samples, n_chunks,
+                       pcm_stride, gain_on ? gains : nullptr, band_pass, q, vec4, out, out_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_frontend(hipStream_t st, const void *pcm, int fmt, size_t S, size_t n_samples, size_t pcm_stride, int gain_on,
+                           float rms_level_ref, float min_gain, float max_gain, int window_size, int band_pass, float a0,
+                           float a1, float a2, float b1, float b2, float *ring, float *rms, float *gains, float *out,
+                           size_t out_stride) {
+    BiquadCoef q{a0, a1, a2, b1, b2};
+#define RP_FE(T) launch_frontend_t<T>(st, static_cast<const T *>(pcm), S, n_samples, pcm_stride, gain_on, rms_level_ref, min_gain, \
+                                      max_gain, window_size, band_pass, q, ring, rms, gains, out, out_stride)
+    switch (fmt) {
+    case 0: return RP_FE(int8_t);
+    case 1: return RP_FE(int16_t);
+    case 2: return RP_FE(int32_t);
+    case 3: return RP_FE(float);
+    }
+#undef RP_FE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace rp

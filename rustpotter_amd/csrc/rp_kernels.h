@@ -1,4 +1,4 @@
-// rp_kernels.h -- launchers of the gfx950 kernels (rp_kernels.hip) used by the
+// rp_kernels.h -- launchers of the gfx950 kernels (rp_mfcc / rp_dtw / rp_scan / rp_resample / rp_frontend / rp_mlp .hip) used by the
 // host-side mirror (rp_detector.cpp) and the C ABI (rp_capi.cpp).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,0 +1,290 @@
+// rp_mfcc.hip -- mfcc_kernel: src/mfcc/extractor.rs:60-163 (framing, pre-emphasis, Hamming, DFT-480, mel, ln, DCT),
+// 16 lanes per 30 ms frame, and synth_kernel, the benchmark input generator of BASELINE.md §2.
+// DESIGN.md §4.1 has the layout and the roofline.
+#include "rp_device.h"
+
+namespace rp {
+
+// ------------------------------------------------------------------------- MFCC
+// One wave = 4 consecutive frames of one stream, 16 lanes per frame; waves are independent
+// (no workgroup barrier after the one-time table staging) and walk the (stream, frame-tile)
+// space grid-stride, so the constant tables are staged into LDS once per workgroup, not once
+// per tile.  Frame j covers samples [(j+1)*160, (j+4)*160) of the stream (the frame made of
+// the first three shifts is never emitted, src/mfcc/extractor.rs:69-79).  The real 480-point
+// DFT is one 240-point complex FFT (16 x 15 four-step: FFT16 per lane over n1, twiddle,
+// transpose through LDS, DFT15 per lane over n2) plus the even/odd untangling step; only bins
+// 0..239 are formed (src/mfcc/extractor.rs:28,111-113).
+constexpr int kMfccFramesPerWave = 4;
+constexpr int kMfccWaves = 4;
+constexpr int kMfccThreads = 64 * kMfccWaves;
+constexpr int kMfccStage = (kMfccFramesPerWave + 2) * kShift;  // 960 samples per wave tile
+constexpr int kMfccWaveScratch = kMfccFramesPerWave * 240;      // float2 per wave (aliases the samples)
+
+__host__ __device__ inline size_t mfcc_lds_bytes(int K1) {
+    size_t f = 480 + (size_t)K1 * kBins + (size_t)K1 * K1 + (size_t)kMfccWaves * kMfccFramesPerWave * K1;
+    size_t c = (size_t)kMfccWaves * kMfccWaveScratch + 240 + 240;
+    return c * sizeof(float2) + f * sizeof(float);
+}
+
+// K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.  TIN: input sample type.
+template <bool VEC4, int K1T, class TIN>
+__global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
+    const TIN *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
+    size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1rt, const float *__restrict__ g_ham,
+    const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
+    const float *__restrict__ g_dct, float *__restrict__ out) {
+    const int K1 = K1T > 0 ? K1T : K1rt;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    v2f *scr_all = reinterpret_cast<v2f *>(smem);               // [waves][4][240]
+    v2f *tw240 = scr_all + kMfccWaves * kMfccWaveScratch;       // [240]
+    v2f *tw480 = tw240 + 240;                                   // [240]
+    float *ham = reinterpret_cast<float *>(tw480 + 240);        // [480]
+    float *fb = ham + 480;                                      // [K1][240]
+    float *dct = fb + K1 * kBins;                               // [K1][K1]
+    float *lgb_all = dct + K1 * K1;                             // [waves][4][K1]
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 480; i += kMfccThreads) ham[i] = g_ham[i];
+    for (int i = tid; i < 240; i += kMfccThreads) {
+        tw240[i] = (v2f){g_tw240[i].x, g_tw240[i].y};
+        tw480[i] = (v2f){g_tw480[i].x, g_tw480[i].y};
+    }
+    for (int i = tid; i < K1 * kBins; i += kMfccThreads) fb[i] = g_fb[i];
+    for (int i = tid; i < K1 * K1; i += kMfccThreads) dct[i] = g_dct[i];
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int grp = lane >> 4, l = lane & 15;
+    v2f *scr = scr_all + wave * kMfccWaveScratch;
+    float *ypre = reinterpret_cast<float *>(scr);  // [960] pre-emphasised samples, dead before scr is written
+    v2f *my = scr + grp * 240;
+    float *lgb = lgb_all + (wave * kMfccFramesPerWave + grp) * K1;
+    const int K = K1 - 1;
+    // per-lane base pointers: every LDS access below is base[compile-time offset]
+    const int l15 = l < 15 ? l : 0;
+    const v2f *ysrc = reinterpret_cast<const v2f *>(ypre + grp * kShift) + l15;  // z[15*n1 + n2] -> +15*n1
+    const v2f *hsrc = reinterpret_cast<const v2f *>(ham) + l15;
+    v2f *t1dst = my + l;              // [k1*15 + l]
+    const v2f *t1src = my + l * 15;   // [l*15 + n2]
+    v2f *zdst = my + l;               // [l + 16*k2]
+    const v2f *zmir = my + 240 - l;  // Z[240-k] = zmir[-16*k2]; k == 0 pairs with itself (handled below)
+    const v2f *w480 = tw480 + l;
+    const float *fbk = fb + l;                       // bins k = l + 16*k2
+    const float *fbm = fb + 240 - l;                 // bins 240-k = fbm[-16*k2] (k == 0: weight unused, power forced to 0)
+    // twiddles W240^{n2*k1}, fixed per lane across tiles, k1 = c + 4d kept at register 4c+d
+    v2f twl[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) twl[4 * c + d] = tw240[l15 * (c + 4 * d)];
+
+    const size_t wave_stride = (size_t)gridDim.x * kMfccWaves;
+    for (size_t wt = (size_t)blockIdx.x * kMfccWaves + wave; wt < total_tiles; wt += wave_stride) {
+        const size_t s = wt / tiles_per_stream;
+        const size_t j0 = first_frame + (wt - s * tiles_per_stream) * kMfccFramesPerWave;
+        const TIN *x = pcm + s * pcm_stride;
+        // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift.
+        // All loads are issued unconditionally (clamped index) before the first use, so the wave
+        // pays one memory round trip per tile instead of one per load.
+        const size_t base = (j0 + 1) * kShift;
+        const size_t last = n_samples - 1;
+        if (VEC4) {
+            float4 cur[4];
+            float prv[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = it * 64 + lane;            // float4 index inside the 960-sample tile
+                size_t g = base + 4 * (size_t)(q < 240 ? q : 239);
+                g = g + 3 <= last ? g : (last - 3) & ~(size_t)3;
+                cur[it] = SampleIn<TIN>::load4(x + g);
+                prv[it] = SampleIn<TIN>::cvt(x[g - 1]);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = it * 64 + lane;
+                const float p0 = (q % (kShift / 4) == 0) ? 0.f : prv[it];
+                float4 y;
+                y.x = cur[it].x - 0.97f * p0;  // separate multiply and subtract, like the reference
+                y.y = cur[it].y - 0.97f * cur[it].x;
+                y.z = cur[it].z - 0.97f * cur[it].y;
+                y.w = cur[it].w - 0.97f * cur[it].z;
+                if (q < 240) *reinterpret_cast<float4 *>(ypre + 4 * q) = y;
+            }
+        } else {
+            float cur[kMfccStage / 64], prv[kMfccStage / 64];
+#pragma unroll
+            for (int it = 0; it < kMfccStage / 64; ++it) {
+                size_t g = base + it * 64 + lane;
+                g = g <= last ? g : last;
+                cur[it] = SampleIn<TIN>::cvt(x[g]);
+                prv[it] = SampleIn<TIN>::cvt(x[g - 1]);
+            }
+#pragma unroll
+            for (int it = 0; it < kMfccStage / 64; ++it) {
+                const int i = it * 64 + lane;
+                ypre[i] = cur[it] - 0.97f * ((i % kShift == 0) ? 0.f : prv[it]);
+            }
+        }
+        wave_lds_sync();
+        // ---- step 1: lane n2=l (<15): FFT16 over n1 of z[15*n1 + n2], z[n] = (y[2n], y[2n+1]) * hamming
+        v2f v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = ysrc[15 * n1] * hsrc[15 * n1];
+        wave_lds_sync();  // every lane has its samples in registers: the scratch may now overwrite them
+        fft16(v);
+        if (l < 15) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) t1dst[(c + 4 * d) * 15] = cmul(v[4 * c + d], twl[4 * c + d]);  // W240^{n2*k1}
+        }
+        wave_lds_sync();
+        // ---- step 3: lane k1=l: DFT15 over n2 -> Z[k1 + 16*k2]
+        v2f z[15];
+        {
+            v2f u[15];
+#pragma unroll
+            for (int n2 = 0; n2 < 15; ++n2) u[n2] = t1src[n2];
+            dft15(u, z);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k2 = 0; k2 < 15; ++k2) zdst[16 * k2] = z[k2];
+        wave_lds_sync();
+        // ---- untangle the two interleaved real sequences, bins k = l + 16*k2 <= 120 together with their
+        // mirrors 240-k (X[240-k] = conj(E - W480^k O) shares E, O and the twiddle product with X[k]).
+        // Everything is kept at twice its value; the factor 4 on the powers is removed before the log.
+        float Pk[8], Pm[8];
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const int k = l + 16 * k2;
+            const v2f a = z[k2];
+            const v2f b = (k2 == 0 && l == 0) ? a : zmir[-16 * k2];
+            const v2f e = (v2f){a.x + b.x, a.y - b.y};           // 2E = a + conj(b)
+            const v2f o = (v2f){a.y + b.y, b.x - a.x};           // 2O = -i (a - conj(b))
+            const v2f t = cmul(w480[16 * k2], o);
+            const v2f xp = e + t, xm = e - t;
+            const float pk = fmaf(xp.x, xp.x, xp.y * xp.y);      // 4 |X[k]|^2
+            const float pm = fmaf(xm.x, xm.x, xm.y * xm.y);      // 4 |X[240-k]|^2
+            Pk[k2] = k <= 120 ? pk : 0.f;                        // k > 120 is formed by the mirror lane
+            Pm[k2] = (k >= 1 && k < 120) ? pm : 0.f;             // bin 240 is not used; 120 is its own mirror
+        }
+        // ---- mel filterbank (dense rows, 8 filters per pass) + ln, src/mfcc/extractor.rs:121-145
+        for (int i0 = 0; i0 < K1; i0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                acc[ii] = 0.f;
+                if (i0 + ii < K1) {
+                    const float *rk = fbk + (i0 + ii) * kBins, *rm = fbm + (i0 + ii) * kBins;
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        acc[ii] = fmaf(Pk[k2], rk[16 * k2], acc[ii]);
+                        acc[ii] = fmaf(Pm[k2], rm[-16 * k2], acc[ii]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const float tot = row16_sum(acc[ii]);
+                if (l == ii && i0 + ii < K1) lgb[i0 + ii] = logf(0.25f * tot + FLT_MIN);
+            }
+        }
+        wave_lds_sync();
+        // ---- DCT-II x2, coefficient 0 dropped, src/mfcc/extractor.rs:84,146-163.  Sequential
+        // multiply-then-add in the reference's order (NOT fused): see the file header.
+        const size_t j = j0 + grp;
+        if (j < first_frame + n_frames) {
+            float *dst = out + (s * out_frame_pitch + (j - first_frame)) * (size_t)K;
+            for (int c = 1 + l; c <= K; c += 16) {
+                float sum = 0.f;
+                for (int n = 0; n < K1; ++n) sum += lgb[n] * dct[c * K1 + n];
+                dst[c - 1] = 2.f * sum;
+            }
+        }
+        wave_lds_sync();  // lgb / scratch are reused by the next tile
+    }
+}
+
+template <class TIN>
+static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const TIN *pcm, size_t S, size_t n_samples,
+                                size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+    if (S == 0 || n_frames == 0) return hipSuccess;
+    const size_t tiles = (n_frames + kMfccFramesPerWave - 1) / kMfccFramesPerWave;
+    const size_t total = tiles * S;
+    if (tiles > 0xffffffffULL) return hipErrorInvalidValue;
+    const size_t lds = mfcc_lds_bytes(tb.K1);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // 4-sample vector loads need rows aligned to 4 samples (and at least one full vector before the last sample)
+    const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
+    // persistent grid: 3 workgroups of 4 waves per CU x 2 rounds, fewer for small problems
+    size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
+    if (blocks > 1536) blocks = 1536;
+#define RP_MFCC_LAUNCH(V, KT)                                                                                              \
+    do {                                                                                                                   \
+        static bool attr_done = false;                                                                                     \
+        if (!attr_done) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<V, KT, TIN>),                     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+            if (e != hipSuccess) return e;                                                                                 \
+            attr_done = true;                                                                                              \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, \
+                           pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
+                           tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc);                                                       \
+    } while (0)
+    if (vec4 && tb.K1 == 6) RP_MFCC_LAUNCH(true, 6);
+    else if (vec4 && tb.K1 == 17) RP_MFCC_LAUNCH(true, 17);
+    else if (vec4) RP_MFCC_LAUNCH(true, 0);
+    else RP_MFCC_LAUNCH(false, 0);
+#undef RP_MFCC_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
+                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+    return launch_mfcc_t<float>(st, tb, pcm, S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+}
+
+// fmt: 0 i8, 1 i16, 2 i32, 3 f32 (rp_sample_format); samples in host byte order
+hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *pcm, int fmt, size_t S, size_t n_samples,
+                           size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+    switch (fmt) {
+    case 0: return launch_mfcc_t<int8_t>(st, tb, static_cast<const int8_t *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    case 1: return launch_mfcc_t<int16_t>(st, tb, static_cast<const int16_t *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    case 2: return launch_mfcc_t<int32_t>(st, tb, static_cast<const int32_t *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    case 3: return launch_mfcc_t<float>(st, tb, static_cast<const float *>(pcm), S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------ synth
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
+                                                    size_t pcm_stride, float *__restrict__ pcm) {
+    const size_t total = S * n_samples;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        size_t s = idx / n_samples, i = idx - s * n_samples;
+        uint64_t h = splitmix64(seed ^ (((first_stream + s) << 32) + (uint64_t)i));
+        pcm[s * pcm_stride + i] = (float)(h >> 40) / 16777216.f - 0.5f;
+    }
+}
+
+hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
+                        size_t pcm_stride, float *pcm) {
+    if (S == 0 || n_samples == 0) return hipSuccess;
+    size_t total = S * n_samples;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, first_stream, S, n_samples,
+                       pcm_stride, pcm);
+    return hipGetLastError();
+}
+
+}  // namespace rp

@@ -1,0 +1,402 @@
+// rp_mlp.hip -- the wakeword model: forward (src/wakewords/nn/wakeword_nn.rs:101-163,305-389; mlp_layer_kernel,
+// mlp_mfma_kernel on the matrix cores, normalize_windows_kernel) and training (wakeword_model_train.rs:204-209).
+// DESIGN.md §4.4.
+#include "rp_device.h"
+
+namespace rp {
+
+// -------------------------------------------------------------------------- MLP
+// Linear (x.W^T + b, W [out][in]) + optional ReLU, f32, k-ordered accumulation like
+// candle's CPU gemm restated in the oracle.  One wave per (row, 64 outputs) tile with
+// the input row staged in LDS.  (Round-1 correctness path; DESIGN.md lists the MFMA
+// bf16 path for BASELINE config 5 as next.)
+__global__ __launch_bounds__(64) void mlp_layer_kernel(const float *__restrict__ x, size_t B, int in, int on,
+                                                       const float *__restrict__ Wt, const float *__restrict__ bias,
+                                                       int relu, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xr = reinterpret_cast<float *>(smem);
+    const size_t b = blockIdx.x;
+    const int o = blockIdx.y * 64 + threadIdx.x;
+    for (int i = threadIdx.x; i < in; i += 64) xr[i] = x[b * in + i];
+    __syncthreads();
+    if (o >= on) return;
+    const float *w = Wt + (size_t)o * in;
+    float s = 0.f;
+    for (int i = 0; i < in; ++i) s += xr[i] * w[i];
+    s += bias[o];
+    if (relu && s < 0.f) s = 0.f;
+    out[b * on + o] = s;
+}
+
+__global__ __launch_bounds__(64) void normalize_windows_kernel(const float *__restrict__ mfcc, size_t first_win,
+                                                                size_t n_win, int L, int K, float *__restrict__ x) {
+    const size_t w = blockIdx.x;
+    const float *src = mfcc + (first_win + w) * K;
+    float *dst = x + w * (size_t)L * K;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        float sum = 0.f;
+        for (int i = 0; i < L; ++i) sum += src[(size_t)i * K + k];
+        for (int i = 0; i < L; ++i) dst[(size_t)i * K + k] = src[(size_t)i * K + k] - sum / (float)L;
+    }
+}
+
+hipError_t launch_normalize_windows(hipStream_t st, const float *mfcc, size_t first_win, size_t n_win, int L, int K,
+                                    float *x) {
+    if (n_win == 0) return hipSuccess;
+    hipLaunchKernelGGL(normalize_windows_kernel, dim3((unsigned)n_win), dim3(64), 0, st, mfcc, first_win, n_win, L, K, x);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
+                      float *const *Bv, float *scratch0, float *scratch1, float *out) {
+    if (B == 0) return hipSuccess;
+    const float *cur = x;
+    float *bufs[2] = {scratch0, scratch1};
+    for (int l = 0; l < n_layers; ++l) {
+        float *dst = (l + 1 == n_layers) ? out : bufs[l & 1];
+        dim3 grid((unsigned)B, (unsigned)((dims[l + 1] + 63) / 64));
+        size_t lds = (size_t)dims[l] * sizeof(float);
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(mlp_layer_kernel, grid, dim3(64), lds, st, cur, B, dims[l], dims[l + 1], W[l], Bv[l],
+                           l + 1 < n_layers ? 1 : 0, dst);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        cur = dst;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ MLP training
+// WakewordModelTrain's loop (src/wakewords/nn/wakeword_model_train.rs:204-209): full-batch forward,
+// log_softmax + nll (mean over the batch), backward, plain SGD.  The matrices are tiny (tens of recordings x a few
+// thousand features): one thread per result element, reductions along the batch / the layer width in a loop.
+__global__ __launch_bounds__(64) void train_forward_kernel(const float *__restrict__ x, size_t B, int in, int on,
+                                                           const float *__restrict__ W, const float *__restrict__ bias, int relu,
+                                                           float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xr = reinterpret_cast<float *>(smem);
+    const size_t b = blockIdx.x;
+    const int o = blockIdx.y * 64 + threadIdx.x;
+    for (int i = threadIdx.x; i < in; i += 64) xr[i] = x[b * in + i];
+    __syncthreads();
+    if (o >= on) return;
+    const float *w = W + (size_t)o * in;
+    float s = 0.f;
+    for (int i = 0; i < in; ++i) s += xr[i] * w[i];
+    s += bias[o];
+    if (relu && s < 0.f) s = 0.f;
+    out[b * on + o] = s;
+}
+
+// per row: log_softmax (x - max - ln(sum exp(x - max))), loss_row = -log_sm[label], dlogits = (softmax - onehot) / B
+__global__ __launch_bounds__(64) void train_softmax_grad_kernel(const float *__restrict__ logits, const int32_t *__restrict__ labels,
+                                                                size_t B, int C, float *__restrict__ dz, float *__restrict__ loss_rows) {
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float *x = logits + b * C;
+    float mx = x[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+    const float lse = logf(se);
+    const int lab = labels[b];
+    for (int c = 0; c < C; ++c) {
+        const float lsm = (x[c] - mx) - lse;
+        if (c == lab) loss_rows[b] = -lsm;
+        dz[b * C + c] = (expf(lsm) - (c == lab ? 1.f : 0.f)) / (float)B;
+    }
+}
+
+// dZprev[b][i] = A_prev[b][i] > 0 ? sum_o dZ[b][o] * W[o][i] : 0     (ReLU backward through the layer's input)
+__global__ __launch_bounds__(256) void train_backprop_kernel(const float *__restrict__ dz, const float *__restrict__ W,
+                                                             const float *__restrict__ a_prev, size_t B, int in, int on,
+                                                             float *__restrict__ dz_prev) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (i >= in) return;
+    float s = 0.f;
+    for (int o = 0; o < on; ++o) s += dz[b * on + o] * W[(size_t)o * in + i];
+    dz_prev[b * in + i] = a_prev[b * in + i] > 0.f ? s : 0.f;
+}
+
+// SGD step of one layer: W[o][i] -= lr * sum_b dZ[b][o] * A_in[b][i];  bias[o] -= lr * sum_b dZ[b][o]
+__global__ __launch_bounds__(256) void train_update_kernel(const float *__restrict__ dz, const float *__restrict__ a_in, size_t B,
+                                                           int in, int on, float lr, float *__restrict__ W, float *__restrict__ bias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int o = blockIdx.y;
+    if (i > in) return;  // i == in: the bias column
+    float g = 0.f;
+    if (i < in) {
+        for (size_t b = 0; b < B; ++b) g += dz[b * on + o] * a_in[b * in + i];
+        W[(size_t)o * in + i] = W[(size_t)o * in + i] - g * lr;
+    } else {
+        for (size_t b = 0; b < B; ++b) g += dz[b * on + o];
+        bias[o] = bias[o] - g * lr;
+    }
+}
+
+hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
+                                float *const *Bv, float *const *act) {
+    if (B == 0) return hipSuccess;
+    const float *cur = x;
+    for (int l = 0; l < n_layers; ++l) {
+        dim3 grid((unsigned)B, (unsigned)((dims[l + 1] + 63) / 64));
+        const size_t lds = (size_t)dims[l] * sizeof(float);
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(train_forward_kernel, grid, dim3(64), lds, st, cur, B, dims[l], dims[l + 1], W[l], Bv[l],
+                           l + 1 < n_layers ? 1 : 0, act[l]);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        cur = act[l];
+    }
+    return hipSuccess;
+}
+
+// act[l] = output of layer l (post-ReLU for hidden layers, logits for the last); dz[l] same shapes
+hipError_t launch_train_step(hipStream_t st, const float *x, const int32_t *labels, size_t B, int n_layers, const int *dims,
+                             float *const *W, float *const *Bv, float *const *act, float *const *dz, float lr, float *loss_rows) {
+    if (B == 0) return hipSuccess;
+    hipError_t e = launch_train_forward(st, x, B, n_layers, dims, W, Bv, act);
+    if (e != hipSuccess) return e;
+    const int C = dims[n_layers];
+    hipLaunchKernelGGL(train_softmax_grad_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, st, act[n_layers - 1], labels, B, C,
+                       dz[n_layers - 1], loss_rows);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        const int in = dims[l], on = dims[l + 1];
+        const float *a_in = l == 0 ? x : act[l - 1];
+        if (l > 0) {  // through W_l as it was in the forward pass, before its own update
+            hipLaunchKernelGGL(train_backprop_kernel, dim3((unsigned)((in + 255) / 256), (unsigned)B), dim3(256), 0, st, dz[l], W[l],
+                               act[l - 1], B, in, on, dz[l - 1]);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(train_update_kernel, dim3((unsigned)((in + 1 + 255) / 256), (unsigned)on), dim3(256), 0, st, dz[l], a_in, B, in,
+                           on, lr, W[l], Bv[l]);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ MLP on MFMA
+// One workgroup = 8 waves = 128 rows; one wave = one 16-row tile x all layer-1 outputs (NT
+// 16-column tiles).  The layer-1 weights are walked in k-groups of 128: the group's [16*NT][128]
+// slice is staged once per workgroup in LDS and shared by the 8 waves (reading it per wave from L2
+// cost more than the HBM stream itself: 0.39 -> 0.18 ms when removed), rows stream from HBM in
+// the MFMA A-operand layout (16 rows x 64 B per instruction; 5.5 TB/s measured on its own).
+//  f32 variant:  v_mfma_f32_16x16x4_f32, exact f32 (each output is a k-ordered fmaf chain).  A lane
+//                loads 16 bytes of its row per 16-k block and feeds component j to MFMA step j; the
+//                weight lane does the same, so both sides agree on the (permuted) k order.
+//  bf16 variant: v_mfma_f32_16x16x32_bf16, inputs rounded to bf16 (RNE) in registers, f32 accumulate.
+// The tail layers (<= 130 x 32 weights) run per row from LDS.  HBM-bound by construction: 4*in bytes
+// per row against 2*in*N1 flops (12 480 B/row, ceiling 0.64 G rows/s at 8 TB/s).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kMlpWaves = 8;
+constexpr int kMlpRowsPerWave = 16;
+constexpr int kMlpKG = 128;  // k-group staged per step
+
+__host__ __device__ constexpr int mlp_wpitch_f32() { return kMlpKG + 4; }   // floats per staged weight row
+__host__ __device__ constexpr int mlp_wpitch_bf16() { return kMlpKG + 8; }  // bf16 per staged weight row
+
+template <int NT, int PREC>
+__global__ __launch_bounds__(64 * kMlpWaves) void mlp_mfma_kernel(
+    const float *__restrict__ x, size_t B, int in, int kpad, const float *__restrict__ w1f,
+    const __bf16 *__restrict__ w1h, const float *__restrict__ b1, const float *__restrict__ tail, int tail_floats,
+    int n_layers, int d1, int d2, int d3, int d4, int h2w, int wbuf_floats, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N1P = 16 * NT;
+    float *tl = reinterpret_cast<float *>(smem);                       // tail weights
+    float *wbuf = tl + ((tail_floats + 3) & ~3);                       // staged weight group; later h1 [waves][16][N1P+1]
+    float *h2_all = wbuf + wbuf_floats;                                // [waves][16][h2w]
+    for (int i = threadIdx.x; i < tail_floats; i += blockDim.x) tl[i] = tail[i];
+
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int li = l & 15, lk = l >> 4;
+    const size_t row0 = ((size_t)blockIdx.x * kMlpWaves + wave) * kMlpRowsPerWave;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    size_t r = row0 + li;
+    if (r >= B) r = B - 1;  // rows past the end recompute the last row; their results are dropped
+    const float *xr = x + r * in;
+
+    // staged weight groups are double buffered when they fit (NT <= 2): the next group's global
+    // loads are issued before this group's MFMAs and land in the other buffer, one barrier per group
+    constexpr bool DB = NT <= 2;
+    constexpr int PF = mlp_wpitch_f32(), PH = mlp_wpitch_bf16();
+    constexpr int NV = PREC == kMlpF32 ? (N1P * (kMlpKG / 4) + 64 * kMlpWaves - 1) / (64 * kMlpWaves)
+                                       : (N1P * (kMlpKG / 8) + 64 * kMlpWaves - 1) / (64 * kMlpWaves);
+    const int half = DB ? wbuf_floats / 2 : 0;
+    float4 wreg[NV];  // one 16-byte piece = 4 f32 or 8 bf16
+    auto wload = [&](int g) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = threadIdx.x + v * 64 * kMlpWaves;
+            if (PREC == kMlpF32) {
+                const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
+                if (o < N1P) wreg[v] = *reinterpret_cast<const float4 *>(w1f + (size_t)o * kpad + g * kMlpKG + 4 * c);
+            } else {
+                const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
+                if (o < N1P) wreg[v] = *reinterpret_cast<const float4 *>(w1h + (size_t)o * kpad + g * kMlpKG + 8 * c);
+            }
+        }
+    };
+    auto wstore = [&](float *dstbuf) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = threadIdx.x + v * 64 * kMlpWaves;
+            if (PREC == kMlpF32) {
+                const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
+                if (o < N1P) *reinterpret_cast<float4 *>(dstbuf + o * PF + 4 * c) = wreg[v];
+            } else {
+                const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
+                if (o < N1P) *reinterpret_cast<float4 *>(reinterpret_cast<__bf16 *>(dstbuf) + o * PH + 8 * c) = wreg[v];
+            }
+        }
+    };
+    const int ngrp = kpad / kMlpKG;
+    wload(0);
+    wstore(wbuf);
+    __syncthreads();  // group 0 staged (and the tail weights landed)
+    for (int g = 0; g < ngrp; ++g) {
+        const int kg = g * kMlpKG;
+        const float *cur = wbuf + ((DB && (g & 1)) ? half : 0);
+        if (g + 1 < ngrp) wload(g + 1);
+        if (PREC == kMlpF32) {
+            constexpr int KU = kMlpKG / 16;
+            float4 a[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int k0 = kg + 16 * u + 4 * lk;  // rows are 16-byte aligned: in % 4 == 0 (checked by the launcher)
+                a[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float4 b = *reinterpret_cast<const float4 *>(cur + (16 * n + li) * PF + 16 * u + 4 * lk);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b.x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b.y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b.z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b.w, acc[n], 0, 0, 0);
+                }
+        } else {
+            constexpr int KU = kMlpKG / 32;
+            const __bf16 *wb = reinterpret_cast<const __bf16 *>(cur);
+            float4 lo[KU], hi[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int k0 = kg + 32 * u + 8 * lk;
+                lo[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                hi[u] = (k0 + 7 < in) ? *reinterpret_cast<const float4 *>(xr + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                bf16x8 a;
+                a[0] = (__bf16)lo[u].x; a[1] = (__bf16)lo[u].y; a[2] = (__bf16)lo[u].z; a[3] = (__bf16)lo[u].w;
+                a[4] = (__bf16)hi[u].x; a[5] = (__bf16)hi[u].y; a[6] = (__bf16)hi[u].z; a[7] = (__bf16)hi[u].w;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(wb + (16 * n + li) * PH + 32 * u + 8 * lk);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        if (g + 1 < ngrp) {
+            if (!DB) __syncthreads();  // single buffer: everyone must be done reading before the overwrite
+            wstore(wbuf + ((DB && !(g & 1)) ? half : 0));
+        }
+        __syncthreads();
+    }
+    // every wave is past the last barrier, i.e. done with the staged weights: the buffer becomes h1
+    // ---- layer-1 bias (+ReLU) -> LDS, C/D layout: col = lane&15, row = (lane>>4)*4 + reg
+    float *h1 = wbuf + wave * kMlpRowsPerWave * (N1P + 1);
+    const bool relu1 = n_layers > 1;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[n][e] + b1[16 * n + li];
+            if (relu1 && v < 0.f) v = 0.f;
+            h1[(4 * lk + e) * (N1P + 1) + 16 * n + li] = v;
+        }
+    wave_lds_sync();
+    // ---- tail layers: lane = (row l&15, output phase l>>4), outputs strided by 4 over the phases
+    {
+        const int rr = l & 15, ph = l >> 4;
+        const bool row_ok = row0 + rr < B;
+        const float *hin = h1 + rr * (N1P + 1);
+        float *h2 = h2_all + (wave * kMlpRowsPerWave + rr) * h2w;
+        const int dd[5] = {in, d1, d2, d3, d4};
+        const float *wp = tl;
+        int cur_in = d1;
+        float *dst = out + (row0 + rr) * (size_t)dd[n_layers];
+        if (n_layers == 1 && row_ok)
+            for (int o = ph; o < d1; o += 4) dst[o] = hin[o];
+        for (int layer = 1; layer < n_layers; ++layer) {
+            const int on = dd[layer + 1];
+            const bool last = layer + 1 == n_layers;
+            for (int o = ph; o < on; o += 4) {
+                const float *wr = wp + (size_t)o * cur_in;
+                float s0 = 0.f, s1 = 0.f;
+                int i = 0;
+                for (; i + 1 < cur_in; i += 2) { s0 = fmaf(hin[i], wr[i], s0); s1 = fmaf(hin[i + 1], wr[i + 1], s1); }
+                if (i < cur_in) s0 = fmaf(hin[i], wr[i], s0);
+                float sacc = (s0 + s1) + wp[(size_t)on * cur_in + o];
+                if (!last && sacc < 0.f) sacc = 0.f;
+                if (last) { if (row_ok) dst[o] = sacc; } else h2[o] = sacc;
+            }
+            wave_lds_sync();  // the hidden layer is complete before anyone reads it
+            wp += (size_t)on * cur_in + on;
+            cur_in = on;
+            hin = h2;  // n_layers <= 3: at most one hidden tail layer
+        }
+    }
+}
+
+template <int NT>
+static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out) {
+    const size_t rows_per_block = (size_t)kMlpWaves * kMlpRowsPerWave;
+    const size_t blocks = (B + rows_per_block - 1) / rows_per_block;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    int h2w = 1;
+    for (int l2 = 2; l2 < m.n_layers; ++l2) h2w = m.dims[l2] + 1 > h2w ? m.dims[l2] + 1 : h2w;
+    h2w |= 1;
+    size_t wbuf = (size_t)16 * NT * mlp_wpitch_f32() * (NT <= 2 ? 2 : 1);       // f32 group(s) (the bf16 ones are smaller)
+    const size_t h1 = (size_t)kMlpWaves * kMlpRowsPerWave * (16 * NT + 1);
+    if (h1 > wbuf) wbuf = h1;
+    wbuf = (wbuf + 3) & ~(size_t)3;
+    const size_t lds = ((size_t)((m.tail_floats + 3) & ~3) + wbuf + (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpBf16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF32>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (precision == kMlpBf16)
+        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out);
+    else
+        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF32>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out) {
+    if (B == 0) return hipSuccess;
+    switch (m.nt) {
+    case 1: return launch_mlp_nt<1>(st, m, x, B, precision, out);
+    case 2: return launch_mlp_nt<2>(st, m, x, B, precision, out);
+    case 5: return launch_mlp_nt<5>(st, m, x, B, precision, out);
+    case 9: return launch_mlp_nt<9>(st, m, x, B, precision, out);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace rp

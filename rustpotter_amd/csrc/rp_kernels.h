@@ -12,8 +12,20 @@ constexpr int kShift = 160;   // src/constants.rs:8
 constexpr int kBins = 240;    // src/mfcc/extractor.rs:28
 
 // Device-resident constant tables of the MFCC pipeline for one mfcc_size K.
+// mfcc_size 5: can filter f (0..5) be non-zero on a bin of the 16-bin group k2 (bins l + 16*k2, l = 0..15), or --
+// mirror -- on a bin 240 - (l + 16*k2)?  Triangle f is non-zero on bins (c[f], c[f+2]) exclusive.
+__host__ __device__ constexpr bool mel5_touches(int f, int k2, bool mirror) {
+    constexpr int c[8] = {0, 9, 22, 41, 68, 106, 161, 240};
+    if (f < 0 || f > 5) return false;
+    const int lo = c[f] + 1, hi = c[f + 2] - 1;                  // non-zero bins lo..hi
+    const int g_lo = mirror ? 240 - (16 * k2 + 15) : 16 * k2;     // bins the group covers
+    const int g_hi = mirror ? 240 - 16 * k2 : 16 * k2 + 15;
+    return g_hi >= lo && g_lo <= hi;
+}
+
 struct MfccTablesDev {
     int K1 = 0;               // K+1 filters / cepstral coefficients
+    bool mel5 = false;        // K1 == 6 and the mel bank is non-zero only where mel5_touches says (checked on upload)
     float *hamming = nullptr; // [480]
     float2 *tw240 = nullptr;  // [240] exp(-2*pi*i*k/240)
     float2 *tw480 = nullptr;  // [240] exp(-2*pi*i*k/480)

@@ -76,15 +76,17 @@ const MfccTablesDev *Ctx::tables_for(int K) {
     HostTables h = build_tables(K);
     MfccTablesDev d;
     d.K1 = h.K1;
-    if (h.K1 == 6) {  // the compile-time sparsity of the mfcc_size 5 kernel must cover the table
-        d.mel5 = true;
-        for (int f = 0; f < 6; ++f)
+    // the compile-time sparsity of the mfcc_size 5 / 16 kernels must cover the table
+    auto covered = [&](auto touches) {
+        for (int f = 0; f < h.K1; ++f)
             for (int k = 0; k < kBins; ++k) {
                 if (h.fb[(size_t)f * kBins + k] == 0.f) continue;
-                const bool ok = k <= 120 ? mel5_touches(f, k / 16, false) : mel5_touches(f, (240 - k) / 16, true);
-                if (!ok) d.mel5 = false;
+                if (!(k <= 120 ? touches(f, k / 16, false) : touches(f, (240 - k) / 16, true))) return false;
             }
-    }
+        return true;
+    };
+    if (h.K1 == 6) d.mel_sparse = covered([](int f, int k2, bool m) { return mel_touches<6>(f, k2, m); });
+    if (h.K1 == 17) d.mel_sparse = covered([](int f, int k2, bool m) { return mel_touches<17>(f, k2, m); });
     if (!upload(&d.hamming, h.hamming) || !upload(&d.tw240, h.tw240) || !upload(&d.tw480, h.tw480) ||
         !upload(&d.fb, h.fb) || !upload(&d.dct, h.dct))
         return nullptr;

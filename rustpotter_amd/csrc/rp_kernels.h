@@ -12,20 +12,26 @@ constexpr int kShift = 160;   // src/constants.rs:8
 constexpr int kBins = 240;    // src/mfcc/extractor.rs:28
 
 // Device-resident constant tables of the MFCC pipeline for one mfcc_size K.
-// mfcc_size 5: can filter f (0..5) be non-zero on a bin of the 16-bin group k2 (bins l + 16*k2, l = 0..15), or --
-// mirror -- on a bin 240 - (l + 16*k2)?  Triangle f is non-zero on bins (c[f], c[f+2]) exclusive.
-__host__ __device__ constexpr bool mel5_touches(int f, int k2, bool mirror) {
-    constexpr int c[8] = {0, 9, 22, 41, 68, 106, 161, 240};
-    if (f < 0 || f > 5) return false;
-    const int lo = c[f] + 1, hi = c[f + 2] - 1;                  // non-zero bins lo..hi
-    const int g_lo = mirror ? 240 - (16 * k2 + 15) : 16 * k2;     // bins the group covers
+// mfcc_size 5 / 16 (K1 = 6 / 17 filters): can filter f be non-zero on a bin of the 16-bin group k2 (bins l + 16*k2,
+// l = 0..15), or -- mirror -- on a bin 240 - (l + 16*k2)?  Triangle f is non-zero on bins (c[f], c[f+2]) exclusive;
+// the centres are what new_mel_filter_bank (src/mfcc/extractor.rs:164-198) yields for these sizes (checked against
+// the table on upload, Ctx::tables_for).
+template <int K1T> struct MelCentres;
+template <> struct MelCentres<6> { static constexpr int c[8] = {0, 9, 22, 41, 68, 106, 161, 240}; };
+template <> struct MelCentres<17> {
+    static constexpr int c[19] = {0, 3, 7, 11, 16, 21, 28, 35, 43, 53, 64, 77, 92, 109, 128, 150, 176, 206, 240};
+};
+template <int K1T> __host__ __device__ constexpr bool mel_touches(int f, int k2, bool mirror) {
+    if (f < 0 || f >= K1T) return false;
+    const int lo = MelCentres<K1T>::c[f] + 1, hi = MelCentres<K1T>::c[f + 2] - 1;  // non-zero bins lo..hi
+    const int g_lo = mirror ? 240 - (16 * k2 + 15) : 16 * k2;                        // bins the group covers
     const int g_hi = mirror ? 240 - 16 * k2 : 16 * k2 + 15;
     return g_hi >= lo && g_lo <= hi;
 }
 
 struct MfccTablesDev {
     int K1 = 0;               // K+1 filters / cepstral coefficients
-    bool mel5 = false;        // K1 == 6 and the mel bank is non-zero only where mel5_touches says (checked on upload)
+    bool mel_sparse = false;  // K1 is 6 or 17 and the mel bank is non-zero only where mel_touches<K1> says (checked on upload)
     float *hamming = nullptr; // [480]
     float2 *tw240 = nullptr;  // [240] exp(-2*pi*i*k/240)
     float2 *tw480 = nullptr;  // [240] exp(-2*pi*i*k/480)

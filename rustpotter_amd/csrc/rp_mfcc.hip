@@ -26,6 +26,11 @@ __host__ __device__ inline size_t mfcc_lds_bytes(int K1) {
     return c * sizeof(float2) + f * sizeof(float);
 }
 
+template <int K1T> __device__ constexpr bool mel_uses(int f, int k2, bool mirror) {
+    if constexpr (K1T == 6 || K1T == 17) return mel_touches<K1T>(f, k2, mirror);
+    else return true;
+}
+
 // K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.  TIN: input sample type.
 template <bool VEC4, int K1T, class TIN>
 __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
@@ -169,11 +174,12 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
             Pk[k2] = k <= 120 ? pk : 0.f;                        // k > 120 is formed by the mirror lane
             Pm[k2] = (k >= 1 && k < 120) ? pm : 0.f;             // bin 240 is not used; 120 is its own mirror
         }
-        // ---- mel filterbank (rows of 8 filters per pass) + ln, src/mfcc/extractor.rs:121-145.  For mfcc_size 5 the
-        // triangles are known at compile time (centres 0 9 22 41 68 106 161 240, mel5_touches): a filter is only
-        // accumulated over the 16-bin groups it can be non-zero in -- 31 multiply-adds and weight loads instead of 96,
-        // bit-identical (the skipped terms are exact + 0.0; launch_mfcc checks the table against the mask).
-        for (int i0 = 0; i0 < K1; i0 += 8) {
+        // ---- mel filterbank (rows of 8 filters per pass) + ln, src/mfcc/extractor.rs:121-145.  For mfcc_size 5 and 16
+        // the triangles are known at compile time (mel_touches): a filter is only accumulated over the 16-bin groups
+        // it can be non-zero in -- 31 multiply-adds and weight loads instead of 96 (41 instead of 272), bit-identical
+        // (the skipped terms are exact + 0.0; the table is checked against the mask on upload).
+#pragma unroll
+        for (int i0 = 0; i0 < (K1T > 0 ? K1T : K1); i0 += 8) {
             float acc[8];
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) {
@@ -182,8 +188,8 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
                     const float *rk = fbk + (i0 + ii) * kBins, *rm = fbm + (i0 + ii) * kBins;
 #pragma unroll
                     for (int k2 = 0; k2 < 8; ++k2) {
-                        if (K1T != 6 || mel5_touches(ii, k2, false)) acc[ii] = fmaf(Pk[k2], rk[16 * k2], acc[ii]);
-                        if (K1T != 6 || mel5_touches(ii, k2, true)) acc[ii] = fmaf(Pm[k2], rm[-16 * k2], acc[ii]);
+                        if (mel_uses<K1T>(i0 + ii, k2, false)) acc[ii] = fmaf(Pk[k2], rk[16 * k2], acc[ii]);
+                        if (mel_uses<K1T>(i0 + ii, k2, true)) acc[ii] = fmaf(Pm[k2], rm[-16 * k2], acc[ii]);
                     }
                 }
             }
@@ -237,8 +243,8 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
                            pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
                            tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc);                                                       \
     } while (0)
-    if (vec4 && tb.K1 == 6 && tb.mel5) RP_MFCC_LAUNCH(true, 6);
-    else if (vec4 && tb.K1 == 17) RP_MFCC_LAUNCH(true, 17);
+    if (vec4 && tb.K1 == 6 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 6);
+    else if (vec4 && tb.K1 == 17 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 17);
     else if (vec4) RP_MFCC_LAUNCH(true, 0);
     else RP_MFCC_LAUNCH(false, 0);
 #undef RP_MFCC_LAUNCH

@@ -193,12 +193,15 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
                     }
                 }
             }
+            // every lane ends up with all totals; lane ii keeps filter i0+ii's and one logf serves the whole pass
+            float mine = 0.f;
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) {
                 if (K1T > 0 && i0 + ii >= K1T) continue;
                 const float tot = row16_sum(acc[ii]);
-                if (l == ii && i0 + ii < K1) lgb[i0 + ii] = logf(0.25f * tot + FLT_MIN);
+                mine = l == ii ? tot : mine;
             }
+            if (l < 8 && i0 + l < K1) lgb[i0 + l] = logf(0.25f * mine + FLT_MIN);
         }
         wave_lds_sync();
         // ---- DCT-II x2, coefficient 0 dropped, src/mfcc/extractor.rs:84,146-163.  Sequential

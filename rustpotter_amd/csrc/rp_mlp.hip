@@ -198,7 +198,7 @@ __host__ __device__ constexpr int mlp_wpitch_f32() { return kMlpKG + 4; }   // f
 __host__ __device__ constexpr int mlp_wpitch_bf16() { return kMlpKG + 8; }  // bf16 per staged weight row
 
 template <int NT, int PREC>
-__global__ __launch_bounds__(64 * kMlpWaves) void mlp_mfma_kernel(
+__global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     const float *__restrict__ x, size_t B, int in, int kpad, const float *__restrict__ w1f,
     const __bf16 *__restrict__ w1h, const float *__restrict__ b1, const float *__restrict__ tail, int tail_floats,
     int n_layers, int d1, int d2, int d3, int d4, int h2w, int wbuf_floats, float *__restrict__ out) {
@@ -226,86 +226,106 @@ __global__ __launch_bounds__(64 * kMlpWaves) void mlp_mfma_kernel(
     constexpr int NV = PREC == kMlpF32 ? (N1P * (kMlpKG / 4) + 64 * kMlpWaves - 1) / (64 * kMlpWaves)
                                        : (N1P * (kMlpKG / 8) + 64 * kMlpWaves - 1) / (64 * kMlpWaves);
     const int half = DB ? wbuf_floats / 2 : 0;
-    float4 wreg[NV];  // one 16-byte piece = 4 f32 or 8 bf16
-    auto wload = [&](int g) {
+    // every thread moves NV pieces; when the slice is a whole number of pieces per thread the bounds test is dropped
+    // (a conditional store into wreg makes the compiler keep the array in scratch memory)
+    constexpr bool FULL = (PREC == kMlpF32 ? N1P * (kMlpKG / 4) : N1P * (kMlpKG / 8)) % (64 * kMlpWaves) == 0;
+    // one 16-byte piece = 4 f32 or 8 bf16; plain vector values (HIP's float4 struct is copied with memcpy, which keeps
+    // the staging array in scratch memory)
+    auto wload = [&](int g, f32x4 (&wreg)[NV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int i = threadIdx.x + v * 64 * kMlpWaves;
             if (PREC == kMlpF32) {
                 const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
-                if (o < N1P) wreg[v] = *reinterpret_cast<const float4 *>(w1f + (size_t)o * kpad + g * kMlpKG + 4 * c);
+                if (FULL || o < N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1f + (size_t)o * kpad + g * kMlpKG + 4 * c);
             } else {
                 const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
-                if (o < N1P) wreg[v] = *reinterpret_cast<const float4 *>(w1h + (size_t)o * kpad + g * kMlpKG + 8 * c);
+                if (FULL || o < N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1h + (size_t)o * kpad + g * kMlpKG + 8 * c);
             }
         }
     };
-    auto wstore = [&](float *dstbuf) {
+    auto wstore = [&](float *dstbuf, const f32x4 (&wreg)[NV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int i = threadIdx.x + v * 64 * kMlpWaves;
             if (PREC == kMlpF32) {
                 const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
-                if (o < N1P) *reinterpret_cast<float4 *>(dstbuf + o * PF + 4 * c) = wreg[v];
+                if (FULL || o < N1P) *reinterpret_cast<f32x4 *>(dstbuf + o * PF + 4 * c) = wreg[v];
             } else {
                 const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
-                if (o < N1P) *reinterpret_cast<float4 *>(reinterpret_cast<__bf16 *>(dstbuf) + o * PH + 8 * c) = wreg[v];
+                if (FULL || o < N1P) *reinterpret_cast<f32x4 *>(reinterpret_cast<__bf16 *>(dstbuf) + o * PH + 8 * c) = wreg[v];
             }
         }
     };
     const int ngrp = kpad / kMlpKG;
-    wload(0);
-    wstore(wbuf);
-    __syncthreads();  // group 0 staged (and the tail weights landed)
-    for (int g = 0; g < ngrp; ++g) {
+    // the rows of k-group g+1 are requested before the MFMAs of group g (registers double buffered like the staged
+    // weights), so the HBM stream never drains at the per-group barrier
+    constexpr int NA = PREC == kMlpF32 ? kMlpKG / 16 : 2 * (kMlpKG / 32);
+    float4 areg[2][NA];
+    auto aload = [&](int g, float4 (&dst)[NA]) __attribute__((always_inline)) {
         const int kg = g * kMlpKG;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            // f32: piece u = k-step u (16 wide), lane part 4*lk;  bf16: pieces 2u / 2u+1 = low / high half of the lane's 8
+            const int k0 = PREC == kMlpF32 ? kg + 16 * u + 4 * lk : kg + 32 * (u >> 1) + 8 * lk + 4 * (u & 1);
+            dst[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    {
+        f32x4 w0[NV];
+        wload(0, w0);
+        aload(0, areg[0]);
+        wstore(wbuf, w0);
+    }
+    __syncthreads();  // group 0 staged (and the tail weights landed)
+    auto group = [&](int g, float4 (&a)[NA], float4 (&anext)[NA]) __attribute__((always_inline)) {
         const float *cur = wbuf + ((DB && (g & 1)) ? half : 0);
-        if (g + 1 < ngrp) wload(g + 1);
+        // The next group's requests go out after the first k-step of this one: that step waits for this group's rows
+        // (requested one group ago) while nothing newer is outstanding, so the wait never covers the new requests.
+        f32x4 wnext[NV];
+        auto prefetch = [&]() __attribute__((always_inline)) { if (g + 1 < ngrp) { wload(g + 1, wnext); aload(g + 1, anext); } };
         if (PREC == kMlpF32) {
-            constexpr int KU = kMlpKG / 16;
-            float4 a[KU];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                const int k0 = kg + 16 * u + 4 * lk;  // rows are 16-byte aligned: in % 4 == 0 (checked by the launcher)
-                a[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < NA; ++u) {
+                float4 b[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const float4 *>(cur + (16 * n + li) * PF + 16 * u + 4 * lk);
+                // the accumulators take turns so that consecutive MFMAs do not wait on each other's result
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[n].w, acc[n], 0, 0, 0);
+                if (u == 0) prefetch();
             }
-#pragma unroll
-            for (int u = 0; u < KU; ++u)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const float4 b = *reinterpret_cast<const float4 *>(cur + (16 * n + li) * PF + 16 * u + 4 * lk);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b.x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b.y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b.z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b.w, acc[n], 0, 0, 0);
-                }
         } else {
-            constexpr int KU = kMlpKG / 32;
             const __bf16 *wb = reinterpret_cast<const __bf16 *>(cur);
-            float4 lo[KU], hi[KU];
 #pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                const int k0 = kg + 32 * u + 8 * lk;
-                lo[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                hi[u] = (k0 + 7 < in) ? *reinterpret_cast<const float4 *>(xr + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                bf16x8 a;
-                a[0] = (__bf16)lo[u].x; a[1] = (__bf16)lo[u].y; a[2] = (__bf16)lo[u].z; a[3] = (__bf16)lo[u].w;
-                a[4] = (__bf16)hi[u].x; a[5] = (__bf16)hi[u].y; a[6] = (__bf16)hi[u].z; a[7] = (__bf16)hi[u].w;
+            for (int u = 0; u < NA / 2; ++u) {
+                const float4 lo = a[2 * u], hi = a[2 * u + 1];
+                bf16x8 av;
+                av[0] = (__bf16)lo.x; av[1] = (__bf16)lo.y; av[2] = (__bf16)lo.z; av[3] = (__bf16)lo.w;
+                av[4] = (__bf16)hi.x; av[5] = (__bf16)hi.y; av[6] = (__bf16)hi.z; av[7] = (__bf16)hi.w;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const bf16x8 b = *reinterpret_cast<const bf16x8 *>(wb + (16 * n + li) * PH + 32 * u + 8 * lk);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b, acc[n], 0, 0, 0);
                 }
+                if (u == 0) prefetch();
             }
         }
         if (g + 1 < ngrp) {
             if (!DB) __syncthreads();  // single buffer: everyone must be done reading before the overwrite
-            wstore(wbuf + ((DB && !(g & 1)) ? half : 0));
+            wstore(wbuf + ((DB && !(g & 1)) ? half : 0), wnext);
         }
         __syncthreads();
+    };
+    for (int g = 0; g < ngrp; g += 2) {
+        group(g, areg[0], areg[1]);
+        if (g + 1 < ngrp) group(g + 1, areg[1], areg[0]);
     }
     // every wave is past the last barrier, i.e. done with the staged weights: the buffer becomes h1
     // ---- layer-1 bias (+ReLU) -> LDS, C/D layout: col = lane&15, row = (lane>>4)*4 + reg

@@ -63,13 +63,13 @@ __global__ __launch_bounds__(64 * kRsWaves) void resample_mfma_kernel(const floa
     f32x4 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 wreg[NV];
+    f32x4 wreg[NV];  // plain vector values: HIP's float4 struct is copied with memcpy, which keeps the array in scratch
     auto wload = [&](int g) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const int i = threadIdx.x + v * 64 * kRsWaves;
             const int o = i / (kRsKG / 4), c = i - o * (kRsKG / 4);
-            if (o < FO) wreg[v] = *reinterpret_cast<const float4 *>(g2t + (size_t)o * kpad + g * kRsKG + 4 * c);
+            if (o < FO) wreg[v] = *reinterpret_cast<const f32x4 *>(g2t + (size_t)o * kpad + g * kRsKG + 4 * c);
         }
     };
     auto wstore = [&](float *dst) {
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64 * kRsWaves) void resample_mfma_kernel(const floa
         for (int v = 0; v < NV; ++v) {
             const int i = threadIdx.x + v * 64 * kRsWaves;
             const int o = i / (kRsKG / 4), c = i - o * (kRsKG / 4);
-            if (o < FO) *reinterpret_cast<float4 *>(dst + o * kRsPitch + 4 * c) = wreg[v];
+            if (o < FO) *reinterpret_cast<f32x4 *>(dst + o * kRsPitch + 4 * c) = wreg[v];
         }
     };
     const int ngrp = kpad / kRsKG;

@@ -190,8 +190,9 @@ def main():
         "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C3: %d synthetic 16 kHz f32 streams x %d templates per GPU (4 s streams, L=%d, K=%d, band 5, "
-                               "ScoreMode::Max, avg gate off)" % (S, T, L, K),
+        "config": {"workload": "%s: %d synthetic 16 kHz f32 streams x %d templates per GPU (%g s streams, L=%d, K=%d, band 5, "
+                               "ScoreMode::Max, avg gate off)" % ({(65536, 8): "C3", (8192, 64): "C4 (per-GPU share)", (1024, 8): "C2"}.get((S, T), "custom"),
+                                                                  S, T, N / 16000.0, L, K),
                    "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
                    "windows_per_stream": n_win, "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world},
         "roofline": roofline,

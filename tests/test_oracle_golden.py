@@ -224,3 +224,39 @@ def test_g6_model_on_48k_recording_is_only_structurally_pinned(case):
     if e.get("eager"):  # the eager case fires while the window is still inside the speech: logits agree to ~1 %
         assert abs(got[0]["scores"]["ok_casa"] - label_logit) <= 0.02 * label_logit
         assert abs(got[0]["scores"]["none"] - none_logit) <= 0.02 * none_logit
+
+
+def test_oracle_training_step_is_the_gradient_of_the_reference_loss():
+    """orc_mlp_train restates candle's autograd for forward -> log_softmax -> nll -> SGD in closed form; one epoch must
+    move every weight by -lr * dLoss/dW, checked against central differences of the loss evaluated in float64."""
+    rng = np.random.default_rng(11)
+    B, dims = 7, (12, 6, 5, 3)
+    x = rng.standard_normal((B, dims[0])).astype(np.float32)
+    y = rng.integers(0, dims[-1], B)
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) * 0.5).astype(np.float32) for i in range(3)]
+    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+
+    def loss64(ws_, bs_):
+        h = x.astype(np.float64)
+        for i, (w, b) in enumerate(zip(ws_, bs_)):
+            h = h @ w.astype(np.float64).T + b.astype(np.float64)
+            if i < 2:
+                h = np.maximum(h, 0.0)
+        h = h - h.max(axis=1, keepdims=True)
+        lsm = h - np.log(np.exp(h).sum(axis=1, keepdims=True))
+        return -lsm[np.arange(B), y].mean()
+
+    lr = 0.05
+    nw, nb, loss = orc.mlp_train(x, y, ws, bs, lr, 1)
+    assert abs(loss - loss64(ws, bs)) < 1e-5
+    eps = 1e-3
+    for li in range(3):
+        for idx in [(0, 0), (dims[li + 1] - 1, dims[li] - 1), (1, 2)]:
+            wp = [w.copy() for w in ws]; wm = [w.copy() for w in ws]
+            wp[li][idx] += eps; wm[li][idx] -= eps
+            grad = (loss64(wp, bs) - loss64(wm, bs)) / (2 * eps)
+            assert abs((ws[li][idx] - nw[li][idx]) / lr - grad) < 2e-3 * max(1.0, abs(grad))
+        bp = [b.copy() for b in bs]; bm = [b.copy() for b in bs]
+        bp[li][0] += eps; bm[li][0] -= eps
+        grad = (loss64(ws, bp) - loss64(ws, bm)) / (2 * eps)
+        assert abs((bs[li][0] - nb[li][0]) / lr - grad) < 2e-3 * max(1.0, abs(grad))

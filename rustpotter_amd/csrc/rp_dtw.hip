@@ -445,6 +445,104 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
 
 // Largest template tile the register kernels are built for at this (mfcc_size, band) (0 = only the generic
 // kernel applies).  Built: mfcc_size 5 with band 3..6, mfcc_size 16 with band 5.
+// ---- one DTW per wave, for a handful of windows (the single-stream API: three new windows per 30 ms chunk) -----
+// The register kernels above give every lane a whole DTW: with 3 windows x 5 templates that is 15 busy lanes walking
+// ~100 dependent rows each (35 us).  Here a workgroup of one wave owns ONE (window, template) pair: all 64 lanes
+// normalise the window and form the band's cosine costs, then the 2W lanes of the band walk the recurrence along
+// anti-diagonals (lane q handles band offset q; cell (r, q) is due at step 2r + q, when its left neighbour -- lane q-1,
+// one step ago -- and its upper neighbour -- lane q+1, one step ago -- are one DPP lane shift away).  Same operations
+// per cell as dtw_band_kernel, same results.
+__global__ __launch_bounds__(64) void dtw_single_kernel(
+    const float *__restrict__ mfcc, size_t n_frames_total, size_t first_win, unsigned n_win, size_t out_win_pitch,
+    const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K, int T, int Ttot, int max_len, int W,
+    float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const unsigned wi = blockIdx.x / Ttot;
+    const int t = blockIdx.x - wi * Ttot;
+    const int m = lens[t];
+    const int L = m < max_len ? m : max_len;  // m == n == L (checked by the launcher): the window is cut to L frames
+    const int B = 2 * W, KP = K | 1;
+    float *ys = reinterpret_cast<float *>(smem);   // [L][KP] window frames, then normalised in place
+    float *mu = ys + (size_t)L * KP;               // [K]
+    float *dm = mu + ((K + 3) & ~3);               // [2L + B + 16][B] band costs by due step
+    float *ts = dm + (size_t)(2 * L + B + 16) * B;                // [L][KP] unit template rows (one coalesced read instead of a
+                                                   // dependent global load per multiply-add in the cost loop)
+    const float *src = mfcc + (first_win + wi) * (size_t)K;
+    const float *trow = unit + (size_t)t * Lpad * K;
+    for (int i = lane; i < L * K; i += 64) {
+        const int f = i / K, k = i - f * K;
+        ys[f * KP + k] = (first_win + wi + f) < n_frames_total ? src[(size_t)f * K + k] : 0.f;
+        ts[f * KP + k] = trow[i];
+    }
+    __syncthreads();
+    // MfccNormalizer::normalize: sequential column sums (one lane per coefficient), like the register kernels
+    for (int k = lane; k < K; k += 64) {
+        float sum = 0.f;
+        int i = 0;
+        for (; i + 8 <= L; i += 8) {  // eight reads in flight, the adds stay in frame order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ys[(i + j) * KP + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[j];
+        }
+        for (; i < L; ++i) sum += ys[i * KP + k];
+        mu[k] = sum / (float)L;
+    }
+    __syncthreads();
+    for (int f = lane; f < L; f += 64) {
+        float bb = 0.f;
+        for (int k = 0; k < K; ++k) { const float y = ys[f * KP + k] - mu[k]; bb = fmaf(y, y, bb); }
+        const float inv = bb > 0.f ? rsqrtf(bb) : 0.f;
+        for (int k = 0; k < K; ++k) ys[f * KP + k] = (ys[f * KP + k] - mu[k]) * inv;
+    }
+    __syncthreads();
+    // band costs d[r][q] = 1 - a_r . y_c, c = r - W + q, stored by the step they are due at: dm[(2r + q)*B + q];
+    // cells outside 1 <= c <= n are never part of a path (+inf)
+    const int steps = 2 * (L - 1) + B;  // due steps run from 2 to steps - 1
+    for (int i = lane; i < (L - 1) * B; i += 64) {
+        const int r = 1 + i / B, q = i - (r - 1) * B, c = r - W + q;
+        float d = RP_INF;
+        if (c >= 1 && c <= L) {
+            d = 1.f;
+            const float *a = ts + (r - 1) * KP, *y = ys + (c - 1) * KP;
+            for (int k = 0; k < K; ++k) d = fmaf(-a[k], y[k], d);
+        }
+        dm[(2 * r + q) * B + q] = d;
+    }
+    __syncthreads();
+    if (lane >= 16) return;  // the band lives in one DPP row
+    const int q = lane < B ? lane : B - 1;
+    const bool band_lane = lane < B;
+    float cur = lane == W ? 0.f : RP_INF;  // row 0: D[0][0] = 0 sits at band offset W
+    const int first_due = q + 2, last_due = 2 * (L - 1) + q;
+    const float *dq = dm + q;
+    for (int tau0 = 2; tau0 < steps; tau0 += 16) {
+        float dreg[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dreg[j] = dq[(tau0 + j) * B];  // 16 steps' worth of costs, one wait
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int tau = tau0 + j;
+            const int ci = __float_as_int(cur);
+            const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(RP_INF), ci, 0x111, 0xf, 0xf, false));  // row_shr:1
+            // row_shl:1; lane B (never due) stays +inf, so the last band lane's upper neighbour is out of band by itself
+            const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(RP_INF), ci, 0x101, 0xf, 0xf, false));
+            const bool due = band_lane && ((tau - q) & 1) == 0 && tau >= first_due && tau <= last_due;
+            const float nv = dreg[j] + fminf(fminf(up, left), cur);
+            cur = due ? nv : cur;
+        }
+    }
+    if (lane == W + 1) {  // D[m-1][n]
+        const float nc = cur / (float)(L + L);
+        const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+        const size_t row = (size_t)wi;  // S == 1
+        if (t < T) scores[row * T + t] = sc;
+        else avg[row] = sc;
+    }
+}
+
 int dtw_register_tile(int K, int band) {
     if (K == 5 && band >= 3 && band <= 6) return 8;
     if (K == 16 && band == 5) return 2;
@@ -470,6 +568,17 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     const bool few = padded_rows && S > 1 && n_win < (size_t)kDtwWin;
     const bool do_avg = with_avg && t.has_avg;
     const int Ttot = t.T + (do_avg ? 1 : 0);
+    // a handful of windows of one stream (the single-stream API): one wave per DTW, band lanes on anti-diagonals
+    if (S == 1 && n_win <= 8 && t.max_diff == 0 && band >= 1 && 2 * band <= 16) {
+        const int KP = t.K | 1;
+        const size_t lds = (2 * (size_t)t.max_len * KP + ((t.K + 3) & ~3) + (size_t)(2 * t.max_len + 2 * band + 16) * 2 * band) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            hipLaunchKernelGGL(dtw_single_kernel, dim3((unsigned)(n_win * Ttot)), dim3(64), lds, st, mfcc, frame_pitch, first_win,
+                               (unsigned)n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, Ttot, t.max_len, band, score_ref,
+                               scores, avg);
+            return hipGetLastError();
+        }
+    }
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
     // the register kernels assume m == n (no template longer than the window)
     if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks) {
@@ -517,6 +626,7 @@ __device__ inline float percentile_sorted(const float *v, int n, float percentil
 
 constexpr int kAggMaxT = 256;
 
+// Max / Average: no sort buffer, so no scratch memory to set up (the single-stream path launches this for 3 rows)
 __global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
                                                        float *__restrict__ agg) {
     size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -532,8 +642,15 @@ __global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__
         float s = 0.f;
         for (int i = 0; i < T; ++i) s += v[i];
         agg[row] = s / (float)T;
-        return;
     }
+}
+
+// Median / percentiles: sort ascending, then the reference's f32 interpolation
+__global__ __launch_bounds__(64) void aggregate_sorted_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
+                                                              float *__restrict__ agg) {
+    size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= n_rows) return;
+    const float *v = scores + row * T;
     float tmp[kAggMaxT];
     for (int i = 0; i < T; ++i) {  // insertion sort ascending (total_cmp order for non-NaN scores)
         float x = v[i];
@@ -558,7 +675,8 @@ hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, 
     if (T < 1 || T > kAggMaxT) return hipErrorInvalidValue;
     size_t blocks = (n_rows + 63) / 64;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
+    if (mode == 0 || mode == 1) hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
+    else hipLaunchKernelGGL(aggregate_sorted_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
     return hipGetLastError();
 }
 

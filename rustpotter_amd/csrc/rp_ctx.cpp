@@ -61,6 +61,17 @@ template <class T> static bool upload(T **dst, const std::vector<T> &src) {
     return hip_ok(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(table)");
 }
 
+PinBuf::~PinBuf() { if (p) (void)hipHostFree(p); }
+bool PinBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; cap = 0; }
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    if (!hip_ok(hipHostMalloc(&p, want, hipHostMallocDefault), "hipHostMalloc")) { p = nullptr; return false; }
+    if (!hip_ok(hipHostGetDevicePointer(&dev, p, 0), "hipHostGetDevicePointer")) { (void)hipHostFree(p); p = nullptr; return false; }
+    cap = want;
+    return true;
+}
+
 const Resampler *Ctx::resampler_for(size_t fs_in) {
     auto it = resamplers.find(fs_in);
     if (it != resamplers.end()) return it->second.get();

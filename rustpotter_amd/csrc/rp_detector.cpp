@@ -35,7 +35,7 @@ struct Rustpotter::Wakeword {
     int n_layers = 0, none_index = -1;
     std::vector<int> dims;
     std::unique_ptr<Model> net;  // device
-    // per-call result offsets (floats) inside result_host_
+    // per-call result offsets (floats) inside result_
     size_t off_scores = 0, off_avg = 0, off_agg = 0, off_logits = 0;
     bool with_avg = false, shape_ok = true;
     size_t frame_size() const {  // get_mfcc_frame_size
@@ -371,10 +371,16 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
     const size_t i0 = shifts_seen_ >= 3 ? 0 : 3 - shifts_seen_;       // first new shift that completes a frame
     const size_t nfr = n_shifts > i0 ? n_shifts - i0 : 0;             // frames this call
     const size_t up_len = 480 + n_shifts * 160;
-    if (up_.size() < up_len) up_.resize(up_len, 0.f);
-    std::memcpy(up_.data() + 480, buf, n_shifts * 160 * sizeof(float));
+    if (up_.cap < up_len * sizeof(float)) {  // grows once: the buffered shifts move along
+        float keep[480] = {0.f};
+        if (up_.p) std::memcpy(keep, up_.p, sizeof(keep));
+        if (!up_.reserve(up_len * sizeof(float))) return -1;
+        std::memcpy(up_.p, keep, sizeof(keep));
+    }
+    float *up = up_.as<float>();
+    std::memcpy(up + 480, buf, n_shifts * 160 * sizeof(float));
     auto keep_last_two = [&]() {  // the two newest shifts become the extractor's buffered ones
-        std::memmove(up_.data() + 160, up_.data() + 160 + n_shifts * 160, 320 * sizeof(float));
+        std::memmove(up + 160, up + 160 + n_shifts * 160, 320 * sizeof(float));
         shifts_seen_ = std::min<size_t>(3, shifts_seen_ + n_shifts);
     };
     if (nfr == 0) { keep_last_two(); return 0; }
@@ -396,12 +402,9 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
         std::swap(hist_.p, nb.p); std::swap(hist_.cap, nb.cap);
         hist_cap_ = new_cap; n_hist_ = keep;
     }
-    if (!pcm_dev_.reserve(up_len * sizeof(float))) return -1;
-    if (!hip_ok(hipMemcpyAsync(pcm_dev_.p, up_.data(), up_len * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync(pcm)")) return -1;
     const MfccTablesDev *tb = ctx_->tables_for(K);
     if (!tb) return -1;
     float *hist = hist_.as<float>();
-    if (!hip_ok(launch_mfcc(st, *tb, pcm_dev_.as<float>(), 1, up_len, up_len, i0, nfr, nfr, hist + n_hist_ * K), "mfcc_kernel")) return -1;
 
     // which of the new frames complete a window (process_new_mfccs, src/detector.rs:384-395)
     size_t wl = win_len_, first_win = 0;
@@ -418,9 +421,10 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
         if (w.is_model) { w.off_logits = total; total += cnt * w.model.labels.size(); }
         else { const size_t T = w.ref.lens.size(); w.off_scores = total; total += cnt * T; w.off_avg = total; total += cnt; w.off_agg = total; total += cnt; }
     }
-    if (!result_dev_.reserve(total * sizeof(float))) return -1;
-    float *res = result_dev_.as<float>();
-    if (!hip_ok(hipMemcpyAsync(res, hist + n_hist_ * K, (size_t)NF * (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(frames)")) return -1;
+    if (!result_.reserve(total * sizeof(float))) return -1;
+    float *res = result_.dev_as<float>();  // page-locked host memory: the kernels write the results where the host reads them
+    // the new frames go behind the window history and, packed, to the front of the result buffer
+    if (!hip_ok(launch_mfcc(st, *tb, up_.dev_as<float>(), 1, up_len, up_len, i0, nfr, nfr, hist + n_hist_ * K, res), "mfcc_kernel")) return -1;
     if (cnt) {
         const size_t frames_valid = n_hist_ + nfr;
         for (auto &kv : wakewords_) {
@@ -447,14 +451,12 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
             }
         }
     }
-    result_host_.resize(total);
-    if (!hip_ok(hipMemcpyAsync(result_host_.data(), res, total * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(result)")) return -1;
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
     keep_last_two();  // after the synchronise: the upload above read up_
 
     // .into_iter().find_map(process_new_mfccs), src/detector.rs:372-397
     for (int i = 0; i < NF; ++i) {
-        const float *frame = result_host_.data() + (size_t)i * K;
+        const float *frame = result_.as<float>() + (size_t)i * K;
         const bool should_run = has_partial_ || (has_vad_ ? vad_.is_voice(frame, K) : true);
         win_len_ += 1; n_hist_ += 1;
         bool fired = false;
@@ -476,7 +478,7 @@ bool Rustpotter::run_detection(int slot, Detection *out) {
             if (taken.counter >= det_.min_scores) { reset(); *out = std::move(taken); return true; }
         }
     }
-    const float *res = result_host_.data();
+    const float *res = result_.as<float>();
     bool found = false;
     Detection best;
     for (auto &kv : wakewords_) {

@@ -78,6 +78,20 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
 };
 
+// page-locked host memory the device reads / writes in place (the single-stream path's chunk and results)
+struct PinBuf {
+    void *p = nullptr;      // host pointer
+    void *dev = nullptr;    // the same memory as the device sees it
+    size_t cap = 0;
+    ~PinBuf();
+    bool reserve(size_t bytes);  // grows, contents NOT preserved
+    template <class T> T *as() const { return static_cast<T *>(p); }
+    template <class T> T *dev_as() const { return static_cast<T *>(dev); }
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+};
+
 struct Ctx {
     int device = 0;
     int flags = 0;
@@ -190,12 +204,12 @@ private:
     std::vector<float> enc_;     // the encoded (16 kHz) chunk on the host
     // extractor state (src/mfcc/extractor.rs:14, :66-79): the last two 10 ms shifts and how many are buffered
     size_t shifts_seen_ = 0;     // capped at 3: a frame is emitted from the 4th shift on
-    std::vector<float> up_;      // [160 pad | 2 buffered shifts | new shifts] staged for the MFCC kernel
+    PinBuf up_;                  // [160 pad | 2 buffered shifts | new shifts]: the MFCC kernel reads it in place
     // audio_mfcc_window (src/detector.rs:69): device history + explicit length
     DevBuf hist_;                // [hist_cap][K]
     size_t hist_cap_ = 0, n_hist_ = 0, win_len_ = 0, max_mfcc_frames_ = 0;
-    DevBuf pcm_dev_, result_dev_, nn_x_, nn_s0_, nn_s1_;
-    std::vector<float> result_host_;
+    DevBuf nn_x_, nn_s0_, nn_s1_;
+    PinBuf result_;              // [frames | per wakeword score blocks]: written by the kernels, read by the host
     // detection state (src/detector.rs:71-79)
     bool has_partial_ = false;
     Detection partial_;

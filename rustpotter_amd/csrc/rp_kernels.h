@@ -91,8 +91,10 @@ struct BatchDetection {  // == rp_batch_detection
     float avg_score, score;
 };
 
+// mfcc2 (optional): a second, packed copy of the frames [S][n_frames][K]
 hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
-                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc);
+                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc,
+                       float *mfcc2 = nullptr);
 
 // pcm in one of the reference's sample formats (rp_sample_format: 0 i8, 1 i16, 2 i32, 3 f32), decoded in the kernel
 hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *pcm, int fmt, size_t S, size_t n_samples,

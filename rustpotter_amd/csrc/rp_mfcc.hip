@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     const TIN *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
     size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1rt, const float *__restrict__ g_ham,
     const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
-    const float *__restrict__ g_dct, float *__restrict__ out) {
+    const float *__restrict__ g_dct, float *__restrict__ out, float *__restrict__ out2) {
     const int K1 = K1T > 0 ? K1T : K1rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v2f *scr_all = reinterpret_cast<v2f *>(smem);               // [waves][4][240]
@@ -209,10 +209,13 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
         const size_t j = j0 + grp;
         if (j < first_frame + n_frames) {
             float *dst = out + (s * out_frame_pitch + (j - first_frame)) * (size_t)K;
+            // optional second copy, frames packed [n_frames][K] (the single-stream path hands the new frames to the host)
+            float *dst2 = out2 ? out2 + (s * n_frames + (j - first_frame)) * (size_t)K : nullptr;
             for (int c = 1 + l; c <= K; c += 16) {
                 float sum = 0.f;
                 for (int n = 0; n < K1; ++n) sum += lgb[n] * dct[c * K1 + n];
                 dst[c - 1] = 2.f * sum;
+                if (dst2) dst2[c - 1] = 2.f * sum;
             }
         }
         wave_lds_sync();  // lgb / scratch are reused by the next tile
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
 
 template <class TIN>
 static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const TIN *pcm, size_t S, size_t n_samples,
-                                size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
+                                size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc,
+                                float *mfcc2 = nullptr) {
     if (S == 0 || n_frames == 0) return hipSuccess;
     const size_t tiles = (n_frames + kMfccFramesPerWave - 1) / kMfccFramesPerWave;
     const size_t total = tiles * S;
@@ -244,7 +248,7 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
         }                                                                                                                  \
         hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, \
                            pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
-                           tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc);                                                       \
+                           tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc, mfcc2);                                                       \
     } while (0)
     if (vec4 && tb.K1 == 6 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 6);
     else if (vec4 && tb.K1 == 17 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 17);
@@ -255,8 +259,8 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
 }
 
 hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,
-                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc) {
-    return launch_mfcc_t<float>(st, tb, pcm, S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc);
+                       size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc, float *mfcc2) {
+    return launch_mfcc_t<float>(st, tb, pcm, S, n_samples, pcm_stride, first_frame, n_frames, out_frame_pitch, mfcc, mfcc2);
 }
 
 // fmt: 0 i8, 1 i16, 2 i32, 3 f32 (rp_sample_format); samples in host byte order

@@ -80,10 +80,9 @@ Rustpotter *Rustpotter::create(const rp_config &cfg) {
     if (cfg.fmt.sample_rate != 16000) {
         r->rs_ = r->ctx_->resampler_for(cfg.fmt.sample_rate);
         if (!r->rs_) return nullptr;
-        if (!r->rs_x_.reserve(2 * r->in_len_ * sizeof(float)) || !r->rs_out_.reserve(r->out_len_ * sizeof(float))) return nullptr;
-        if (!hip_ok(hipMemsetAsync(r->rs_x_.p, 0, 2 * r->in_len_ * sizeof(float), r->ctx_->stream), "hipMemsetAsync")) return nullptr;
+        if (!r->rs_x_.reserve(2 * r->in_len_ * sizeof(float)) || !r->enc_.reserve(r->out_len_ * sizeof(float))) return nullptr;
+        std::memset(r->rs_x_.p, 0, 2 * r->in_len_ * sizeof(float));
     }
-    r->enc_.assign(r->out_len_, 0.f);
     r->fmt_ = cfg.fmt;
     r->det_ = cfg.detector;
     r->filt_ = cfg.filters;
@@ -318,15 +317,14 @@ int Rustpotter::encode_and_process(float *mono, Detection *out) {
     if (!rs_) return process_audio(mono, in_len_, out);
     hipStream_t st = ctx_->stream;
     if (!hip_ok(hipSetDevice(ctx_->device), "hipSetDevice")) return -1;
-    float *x2 = rs_x_.as<float>();
-    if (!hip_ok(hipMemcpyAsync(x2, x2 + in_len_, in_len_ * sizeof(float), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(resampler history)") ||
-        !hip_ok(hipMemcpyAsync(x2 + in_len_, mono, in_len_ * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync(resampler input)") ||
-        !hip_ok(launch_resample(st, rs_->dev, x2, 1, 1, rs_out_.as<float>(), out_len_), "resample_mfma_kernel") ||
-        !hip_ok(hipMemcpyAsync(enc_.data(), rs_out_.p, out_len_ * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync(resampled)") ||
+    float *x2 = rs_x_.as<float>();  // the previous call has been synchronised: the host may rewrite the buffer
+    std::memcpy(x2, x2 + in_len_, in_len_ * sizeof(float));
+    std::memcpy(x2 + in_len_, mono, in_len_ * sizeof(float));
+    if (!hip_ok(launch_resample(st, rs_->dev, rs_x_.dev_as<float>(), 1, 1, enc_.dev_as<float>(), out_len_), "resample kernel") ||
         !hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize"))
         return -1;
     if (wakewords_.empty()) return 0;  // the encoder runs before process_audio's early return (src/detector.rs:252-254,347-350)
-    return process_audio(enc_.data(), out_len_, out);
+    return process_audio(enc_.as<float>(), out_len_, out);
 }
 template int Rustpotter::process_samples<int8_t>(const int8_t *, size_t, Detection *);
 template int Rustpotter::process_samples<int16_t>(const int16_t *, size_t, Detection *);

@@ -200,8 +200,8 @@ private:
     // plan with the previous input frame kept on the device
     size_t in_len_ = 480, out_len_ = 480;
     const Resampler *rs_ = nullptr;
-    DevBuf rs_x_, rs_out_;       // [2*in_len] previous | current input frame; [out_len]
-    std::vector<float> enc_;     // the encoded (16 kHz) chunk on the host
+    PinBuf rs_x_, enc_;          // [2*in_len] previous | current input frame, [out_len] the encoded (16 kHz) chunk:
+                                 // page-locked host memory the resampler kernel reads / writes in place
     // extractor state (src/mfcc/extractor.rs:14, :66-79): the last two 10 ms shifts and how many are buffered
     size_t shifts_seen_ = 0;     // capped at 3: a frame is emitted from the 4th shift on
     PinBuf up_;                  // [160 pad | 2 buffered shifts | new shifts]: the MFCC kernel reads it in place

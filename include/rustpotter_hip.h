@@ -297,6 +297,18 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
                         const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                         int max_det, float *scores, float *agg);
 
+/* rp_batch_detect for a detector that holds SEVERAL wakewords (run_wakeword_detectors, src/detector.rs:433-447: every
+ * wakeword whose own thresholds pass proposes a detection for the frame, the best score wins; max_mfcc_frames is the
+ * longest template over all wakewords and each wakeword scores the oldest frames of that window,
+ * wakeword_comp.rs:22-27).  t [n_wakewords] (1..8, all with the same mfcc_size, else the reference's "Usage of
+ * wakewords with different mfcc size is not supported, ignoring wakeword"); thresholds / avg_thresholds
+ * [n_wakewords]: the wakeword's own Option<f32> overrides, NaN = the value in `config` (either array may be NULL).
+ * det_wakeword [S][max_det] (NULL to skip): index of the wakeword a detection belongs to. */
+int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                          size_t n_wakewords, const rp_templates *const *t, const rp_detector_config *config,
+                          const float *thresholds, const float *avg_thresholds, rp_batch_detection *det,
+                          int32_t *det_wakeword, int32_t *n_det, int max_det);
+
 /* Sample-rate conversion in front of the path: AudioEncoder::new / reencode_to_mono_with_sample_rate
  * (src/audio/encoder.rs:41-60,63-83), i.e. rubato's FftFixedInOut<f32>::new(sample_rate, 16000, 480, 1) and one
  * process_into_buffer per input frame.  rp_resampler_frame_lengths gives AudioEncoder's

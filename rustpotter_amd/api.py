@@ -107,6 +107,7 @@ SYMBOLS = [
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
     "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
     "rp_wakeword_model_train", "rp_stream_batch_set_input", "rp_stream_batch_samples_per_chunk",
+    "rp_batch_detect_multi",
 ]
 
 
@@ -176,6 +177,8 @@ def load_library():
     L.rp_wakeword_model_train.argtypes = [vp, C.POINTER(_TrainOptions), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                           C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                           C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), fp, fp]
+    L.rp_batch_detect_multi.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp),
+                                        C.POINTER(_DetectorConfig), fp, fp, vp, vp, vp, C.c_int]
     L.rp_resampler_frame_lengths.argtypes = [C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.rp_resample_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.rp_stream_batch_new.argtypes = [vp, vp, C.POINTER(_DetectorConfig), C.c_size_t, C.c_size_t, C.POINTER(vp)]
@@ -700,6 +703,37 @@ class BatchContext:
     def resample_dev(self, pcm_ptr, fmt, channels, sample_rate, S, n, stride, out_ptr, out_stride):
         if self._L.rp_resample_batch(self._h, pcm_ptr, fmt, channels, sample_rate, S, n, stride, out_ptr, out_stride) < 0:
             raise _err()
+
+    def batch_detect_multi(self, pcm, templates, detector_config, thresholds=None, avg_thresholds=None, max_det=8):
+        """Several wakewords in one detector: templates = [Templates, ...]; thresholds / avg_thresholds = per-wakeword
+        overrides (None entries = the config's).  -> (det, det_wakeword, n_det)"""
+        import numpy as np
+        assert self.host
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        S, N = pcm.shape
+        n = len(templates)
+        hs = (C.c_void_p * n)(*[t._h for t in templates])
+        def arr(v):
+            if v is None:
+                return None
+            a = np.array([np.nan if x is None else x for x in v], np.float32)
+            return a
+        th, ath = arr(thresholds), arr(avg_thresholds)
+        det = np.zeros((S, max_det), dtype=DET_DTYPE)
+        dww = np.zeros((S, max_det), np.int32)
+        n_det = np.zeros(S, np.int32)
+        c = detector_config._c()
+        fpt = C.POINTER(C.c_float)
+        if self._L.rp_batch_detect_multi(self._h, pcm.ctypes.data, fmt, S, N, N, n, hs, C.byref(c),
+                                         None if th is None else th.ctypes.data_as(fpt), None if ath is None else ath.ctypes.data_as(fpt),
+                                         det.ctypes.data, dww.ctypes.data, n_det.ctypes.data, max_det) < 0:
+            raise _err()
+        return det, dww, n_det
 
     def batch_detect_dev(self, pcm_ptr, S, N, stride, templates, detector_config, det_ptr, n_det_ptr, max_det,
                          scores_ptr=None, agg_ptr=None):

@@ -473,6 +473,85 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
     });
 }
 
+int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                          size_t n_wakewords, const rp_templates *const *t, const rp_detector_config *config,
+                          const float *thresholds, const float *avg_thresholds, rp_batch_detection *det,
+                          int32_t *det_wakeword, int32_t *n_det, int max_det) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (n_wakewords < 1 || n_wakewords > (size_t)kScanMaxWakewords) { set_last_error("rp_batch_detect_multi: 1..8 wakewords"); return -1; }
+        if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
+        if (config->band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        const int K = t[0]->impl->dev.K;
+        int max_len = 0;
+        for (size_t j = 0; j < n_wakewords; ++j) {
+            const TemplatesDev &td = t[j]->impl->dev;
+            if (td.K != K) { set_last_error("Usage of wakewords with different mfcc size is not supported, ignoring wakeword"); return -1; }
+            max_len = std::max(max_len, td.max_len);  // on_wakeword_change, src/detector.rs:328-334: max over the wakewords' frame sizes
+        }
+        const MfccTablesDev *tb = c->tables_for(K);
+        if (!tb) return -1;
+        const size_t nf = rp_mfcc_num_frames(n_samples);
+        const size_t n_win = nf >= (size_t)max_len ? nf - max_len + 1 : 0, rows = S * n_win;
+        Staged sg(c);
+        const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
+        BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
+        int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
+        int32_t *dw = det_wakeword ? static_cast<int32_t *>(sg.out(det_wakeword, S * (size_t)max_det * sizeof(int32_t), c->stage_out3)) : nullptr;
+        if (S && (!dp || !dd || !dn)) return -1;
+        if (!c->ws_mfcc.reserve(S * nf * K * sizeof(float) + 64 * K * sizeof(float))) return -1;
+        float *dm = c->ws_mfcc.as<float>();
+        c->time_begin(kKernelMfcc);
+        bool ok = hip_ok(launch_mfcc_fmt(c->stream, *tb, dp, (int)fmt, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        ScanWakewords ww{};
+        ww.n = (int)n_wakewords;
+        size_t maxT = 1;
+        for (size_t j = 0; j < n_wakewords; ++j) maxT = std::max<size_t>(maxT, (size_t)t[j]->impl->dev.T);
+        // one shared per-template score buffer, per wakeword its aggregate / avg rows
+        if (!c->ws_scores.reserve(rows * maxT * sizeof(float) + 16) || !c->ws_agg.reserve(n_wakewords * rows * sizeof(float) + 16) ||
+            !c->ws_avg.reserve(n_wakewords * rows * sizeof(float) + 16)) return -1;
+        float *ds = c->ws_scores.as<float>();
+        for (size_t j = 0; j < n_wakewords; ++j) {
+            const TemplatesDev &td = t[j]->impl->dev;
+            const float thr = thresholds && !std::isnan(thresholds[j]) ? thresholds[j] : config->threshold;
+            const float athr = avg_thresholds && !std::isnan(avg_thresholds[j]) ? avg_thresholds[j] : config->avg_threshold;
+            const bool do_avg = td.has_avg && athr != 0.f;  // wakeword_comp.rs:85
+            float *dg = c->ws_agg.as<float>() + j * rows, *da = do_avg ? c->ws_avg.as<float>() + j * rows : nullptr;
+            if (n_win) {
+                c->time_begin(kKernelDtw);
+                ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+                c->time_end();
+                if (!ok) return -1;
+                c->time_begin(kKernelAggregate);
+                ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg), "aggregate_kernel");
+                c->time_end();
+                if (!ok) return -1;
+            }
+            ww.agg[j] = dg; ww.avg[j] = da; ww.threshold[j] = thr; ww.avg_threshold[j] = athr;
+        }
+        ScanConfig sc;
+        sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
+        sc.eager = config->eager ? 1 : 0; sc.max_len = max_len; sc.avg_enabled = 0;
+        float *dv = nullptr;
+        if (config->vad_mode != RP_VAD_NONE) {
+            if (!c->ws_vad.reserve(S * nf * sizeof(float) + 16)) return -1;
+            dv = c->ws_vad.as<float>();
+            if (!hip_ok(launch_vad_value(c->stream, dm, S * nf, K, dv), "vad_value_kernel")) return -1;
+        }
+        c->time_begin(kKernelScan);
+        ok = hip_ok(launch_scan_multi(c->stream, ww, dv, vad_mode_value(config->vad_mode), S, nf, sc, dd, dw, dn, max_det), "scan_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
+        if (dw && !sg.back(det_wakeword, dw, S * (size_t)max_det * sizeof(int32_t))) return -1;
+        return sg.finish() ? 0 : -1;
+    });
+}
+
 int rp_resampler_frame_lengths(size_t sample_rate, size_t *in_len, size_t *out_len) {
     return guarded([&]() -> int {
         if (!resampler_frame_lengths(sample_rate, in_len, out_len)) {

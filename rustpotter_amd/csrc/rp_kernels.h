@@ -86,6 +86,15 @@ struct ScanConfig {
     int min_scores, eager, max_len, avg_enabled;
 };
 
+// the wakewords of one detector in the batched scan (run_wakeword_detectors, src/detector.rs:433-447): per wakeword
+// its aggregate scores [S][n_win], avg-template scores (nullptr: gate off) and its own thresholds
+constexpr int kScanMaxWakewords = 8;
+struct ScanWakewords {
+    int n;
+    const float *agg[kScanMaxWakewords], *avg[kScanMaxWakewords];
+    float threshold[kScanMaxWakewords], avg_threshold[kScanMaxWakewords];
+};
+
 struct BatchDetection {  // == rp_batch_detection
     int32_t stream, frame, window, counter;
     float avg_score, score;
@@ -114,6 +123,8 @@ hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, 
 // vad_mode_value = VADMode::get_value (2 / 2.5 / 3, src/config.rs:140-146)
 hipError_t launch_vad_value(hipStream_t st, const float *mfcc, size_t n_frames_total, int K, float *out);
 hipError_t launch_vad_value_rows(hipStream_t st, const float *mfcc, size_t S, size_t n, size_t pitch, int K, float *out);
+hipError_t launch_scan_multi(hipStream_t st, const ScanWakewords &ww, const float *vad_value, float vad_mode_value, size_t S,
+                             size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *det_ww, int32_t *n_det, int max_det);
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                        size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det);
 

@@ -47,10 +47,9 @@ hipError_t launch_vad_value_rows(hipStream_t st, const float *mfcc, size_t S, si
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg, const float *__restrict__ avg,
-                                                  const float *__restrict__ vad_value, float vad_mode_value, size_t S,
-                                                  size_t n_frames, ScanConfig cfg, BatchDetection *__restrict__ det,
-                                                  int32_t *__restrict__ n_det, int max_det) {
+__global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float *__restrict__ vad_value, float vad_mode_value,
+                                                  size_t S, size_t n_frames, ScanConfig cfg, BatchDetection *__restrict__ det,
+                                                  int32_t *__restrict__ det_ww, int32_t *__restrict__ n_det, int max_det) {
     __shared__ float vwin[50][64];  // VadDetector::window, one column per stream (lane)
     __shared__ unsigned long long candidates;  // bit r: stream r of this block has a window that can fire
     const int lane = threadIdx.x;
@@ -65,13 +64,15 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
         const size_t s0 = (size_t)blockIdx.x * 64;
         const size_t rows = S - s0 < 64 ? S - s0 : 64;
         const size_t total = n_win > 0 ? rows * (size_t)n_win : 0;  // the block's score rows are one contiguous range
-        const float *a0 = agg + s0 * (size_t)(n_win > 0 ? n_win : 0);
-        const float *v0 = cfg.avg_enabled ? avg + s0 * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
         unsigned long long mask = 0;
-        for (size_t e = lane; e < total; e += 64) {
-            bool pass = a0[e] > cfg.threshold;
-            if (pass && v0) pass = !(v0[e] < cfg.avg_threshold);
-            if (pass) mask |= 1ull << (e / (size_t)n_win);
+        for (int j = 0; j < ww.n; ++j) {
+            const float *a0 = ww.agg[j] + s0 * (size_t)(n_win > 0 ? n_win : 0);
+            const float *v0 = ww.avg[j] ? ww.avg[j] + s0 * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
+            for (size_t e = lane; e < total; e += 64) {
+                bool pass = a0[e] > ww.threshold[j];
+                if (pass && v0) pass = !(v0[e] < ww.avg_threshold[j]);
+                if (pass) mask |= 1ull << (e / (size_t)n_win);
+            }
         }
         if (mask) atomicOr(&candidates, mask);
         __syncthreads();
@@ -79,8 +80,7 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
     size_t s = (size_t)blockIdx.x * 64 + lane;
     if (s >= S) return;
     if (!((candidates >> lane) & 1ull)) { n_det[s] = 0; return; }
-    const float *a = agg + s * (size_t)(n_win > 0 ? n_win : 0);
-    const float *v = avg ? avg + s * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
+    const size_t row0 = s * (size_t)(n_win > 0 ? n_win : 0);
     const float *vv = vad_value ? vad_value + s * n_frames : nullptr;
     // VadDetector state (src/mfcc/vad.rs:3-50)
     int vad_index = 0, voice_countdown = 0;
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
     long win_start = 0, resume = 0;
     bool has_partial = false;
     float p_score = 0.f, p_avg = 0.f;
+    int p_ww = 0;
     int p_counter = 0, p_window = 0, countdown = 0, nd = 0;
     for (long f = 0; f < (long)n_frames; ++f) {
         if (f < resume) continue;
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
                         d.stream = (int32_t)s; d.frame = (int32_t)f; d.window = p_window; d.counter = p_counter;
                         d.avg_score = p_avg; d.score = p_score;
                         det[s * (size_t)max_det + nd] = d;
+                        if (det_ww) det_ww[s * (size_t)max_det + nd] = p_ww;
                     }
                     ++nd;
                     win_start = resume = 3 * (f / 3) + 6;  // reset()
@@ -131,13 +133,20 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
                 }
             }
         }
-        float sc = a[w];
-        float av = 0.f;
-        bool pass = true;
-        if (cfg.avg_enabled) { av = v[w]; pass = !(av < cfg.avg_threshold); }
-        if (pass && sc > cfg.threshold) {
+        // run_wakeword_detectors, src/detector.rs:433-447: every wakeword whose own thresholds pass proposes a
+        // detection, the best score wins (the first of equals)
+        float sc = 0.f, av = 0.f;
+        int best = -1;
+        for (int j = 0; j < ww.n; ++j) {
+            const float sj = ww.agg[j][row0 + w];
+            float aj = 0.f;
+            bool pass = true;
+            if (ww.avg[j]) { aj = ww.avg[j][row0 + w]; pass = !(aj < ww.avg_threshold[j]); }
+            if (pass && sj > ww.threshold[j] && (best < 0 || sj > sc)) { best = j; sc = sj; av = aj; }
+        }
+        if (best >= 0) {
             int counter = has_partial ? p_counter + 1 : 1;
-            if (!has_partial || p_score < sc) { p_score = sc; p_avg = av; p_window = (int)w; has_partial = true; }
+            if (!has_partial || p_score < sc) { p_score = sc; p_avg = av; p_window = (int)w; p_ww = best; has_partial = true; }
             p_counter = counter;
             countdown = (int)(max_len / 2);
         }
@@ -145,13 +154,23 @@ __global__ __launch_bounds__(64) void scan_kernel(const float *__restrict__ agg,
     n_det[s] = nd;
 }
 
+hipError_t launch_scan_multi(hipStream_t st, const ScanWakewords &ww, const float *vad_value, float vad_mode_value, size_t S,
+                             size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *det_ww, int32_t *n_det, int max_det) {
+    if (S == 0) return hipSuccess;
+    if (ww.n < 1 || ww.n > kScanMaxWakewords) return hipErrorInvalidValue;
+    size_t blocks = (S + 63) / 64;
+    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)blocks), dim3(64), 0, st, ww, vad_value, vad_mode_value, S, n_frames, cfg, det, det_ww,
+                       n_det, max_det);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                        size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det) {
-    if (S == 0) return hipSuccess;
-    size_t blocks = (S + 63) / 64;
-    hipLaunchKernelGGL(scan_kernel, dim3((unsigned)blocks), dim3(64), 0, st, agg, avg, vad_value, vad_mode_value, S, n_frames,
-                       cfg, det, n_det, max_det);
-    return hipGetLastError();
+    ScanWakewords ww{};
+    ww.n = 1;
+    ww.agg[0] = agg; ww.avg[0] = cfg.avg_enabled ? avg : nullptr;
+    ww.threshold[0] = cfg.threshold; ww.avg_threshold[0] = cfg.avg_threshold;
+    return launch_scan_multi(st, ww, vad_value, vad_mode_value, S, n_frames, cfg, det, nullptr, n_det, max_det);
 }
 
 // ------------------------------------------------------------- streaming batches

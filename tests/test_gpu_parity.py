@@ -569,6 +569,47 @@ def test_stream_batch_many_streams_synthetic(ra, ctx):
     assert np.array_equal(total, n_det)
 
 
+def test_batch_detect_multi_equals_detector_with_two_wakewords(ra, ctx):
+    """Two wakewords in one detector (run_wakeword_detectors, src/detector.rs:433-447): rp_batch_detect_multi against a
+    Rustpotter handle that holds both .rpw files, on a stream in which both are spoken; per-wakeword threshold override."""
+    rd = lambda f: simstream.i16_to_f32(rpw_py.read_wav_i16(os.path.join(G, f))[0])
+    z = np.zeros(16000 * 2, np.float32)
+    base = np.concatenate([z, rd("oye_casa_g_1.wav"), z, rd("alexa.wav"), z, rd("oye_casa_g_2.wav"), z, rd("alexa2.wav"), z, z])
+    rng = np.random.default_rng(12)
+    n = (len(base) // 480) * 480
+    pcm = np.stack([base[:n], np.roll(base[:n], 480 * 13) + rng.standard_normal(n).astype(np.float32) * np.float32(0.001)])
+    files = ["oye_casa_g.rpw", "alexa.rpw"]
+    wws = [rpw_py.load_rpw(os.path.join(G, f)) for f in files]
+    tms = [ra.Templates(ctx, list(w["samples_features"].values()), avg=w["avg_features"]) for w in wws]
+    cfg = ra.RustpotterConfig.default()
+    cfg.fmt.sample_format = ra.SampleFormat.F32
+    cfg.detector.threshold, cfg.detector.avg_threshold, cfg.detector.min_scores = 0.5, 0.2, 3
+    det, dww, n_det = ctx.batch_detect_multi(pcm, tms, cfg.detector)
+    for si in range(2):
+        rp = ra.Rustpotter.new(cfg)
+        for k, f in zip(("oye", "alexa"), files):
+            rp.add_wakeword_from_file(k, os.path.join(G, f))
+        got = []
+        for i in range(0, n, 480):
+            d = rp.process_samples(pcm[si, i:i + 480].copy())
+            if d is not None:
+                got.append((i // 480, d))
+        names = [w["name"] for w in wws]
+        assert n_det[si] == len(got) and len(got) >= 3
+        seen = set()
+        for j, (chunk, d) in enumerate(got):
+            assert det[si][j]["frame"] // 3 + 1 == chunk and det[si][j]["counter"] == d.counter
+            assert abs(det[si][j]["score"] - d.score) <= 1e-6 * d.score and abs(det[si][j]["avg_score"] - d.avg_score) <= 1e-6 * max(d.avg_score, 1e-3)
+            assert names[dww[si][j]] == d.name
+            seen.add(d.name)
+        assert len(seen) == 2  # both wakewords fired
+    # a wakeword's own threshold wins over the detector's (Option<f32> in the .rpw): silence "alexa" with 0.99
+    det2, dww2, n2 = ctx.batch_detect_multi(pcm, tms, cfg.detector, thresholds=[None, 0.99])
+    assert 0 < n2[0] < n_det[0] and all(dww2[0][j] == 0 for j in range(n2[0]))
+    with pytest.raises(ra.RustpotterError, match="different mfcc size"):
+        ctx.batch_detect_multi(pcm, [tms[0], ra.Templates(ctx, orc.synth_templates(SEED, 2, 40, 16))], cfg.detector)
+
+
 @pytest.mark.parametrize("vad", ["easy", "medium", "hard"])
 def test_batch_vad_gate_matches_oracle(ra, ctx, vad):
     """VadDetector in the batched scan: speech surrounded by low-level noise (the gate opens late

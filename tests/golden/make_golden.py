@@ -25,6 +25,9 @@ FILES = [
     # 48 kHz f32 recordings: everything that goes through the resampler (src/audio/encoder.rs:72-83)
     "oye_casa_real.rpw", "oye_casa_real_1.wav", "oye_casa_real_2.wav", "oye_casa_real_3.wav", "oye_casa_real_4.wav",
     "oye_casa_real_5.wav", "oye_casa_real_6.wav", "real_sample.wav", "ok_casa.wav",
+    # written by src/audio/encoder.rs:139-183 (reencode_wav_with_different_format): oye_casa_g_1.wav through
+    # rencode_and_resample::<i16> in 480-sample frames -- pins Sample::into_f32 for i16
+    "oye_casa_g_1_f32.wav",
 ]
 # tests/resources/{train,test}: the labelled files are byte copies of wavs listed above (oye_casa_real_{1,3,4,5}.wav with
 # "[oye casa]" in the name, test/oye_casa_g_2[oye casa].wav); only the noise recordings are new

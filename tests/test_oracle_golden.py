@@ -260,3 +260,14 @@ def test_oracle_training_step_is_the_gradient_of_the_reference_loss():
         bp[li][0] += eps; bm[li][0] -= eps
         grad = (loss64(ws, bp) - loss64(ws, bm)) / (2 * eps)
         assert abs((bs[li][0] - nb[li][0]) / lr - grad) < 2e-3 * max(1.0, abs(grad))
+
+
+def test_g7_i16_to_f32_matches_reference_reencoded_wav():
+    """src/audio/encoder.rs:139-183 wrote oye_casa_g_1_f32.wav from oye_casa_g_1.wav via rencode_and_resample::<i16>
+    (chunks_exact(480), v as f32 / i16::MAX as f32, src/audio/audio_types.rs:108-117): bit-exact."""
+    i16, sr = rpw_py.read_wav_i16(os.path.join(G, "oye_casa_g_1.wav"))
+    f32, sr2, ch = rpw_py.read_wav(os.path.join(G, "oye_casa_g_1_f32.wav"))
+    assert sr == sr2 == 16000 and ch == 1 and f32.dtype == np.float32
+    n = (len(i16) // 480) * 480
+    assert len(f32) == n
+    assert np.array_equal(simstream.i16_to_f32(i16[:n]), f32)

@@ -14,8 +14,11 @@
  *   G2b the filter goldens tests/detector.rs:113-159,
  *   G5  the NN score formula value tests/detector.rs:227,
  *   G6  the 48 kHz path: the MFCC matrices of six resampled recordings inside
- *       tests/resources/oye_casa_real.rpw (tests/wakeword.rs:57-71) and the
- *       (avg_score, score, counter) triples of tests/detector.rs:163-213.
+ *       tests/resources/oye_casa_real.rpw (tests/wakeword.rs:57-71), the
+ *       (avg_score, score, counter) triples of tests/detector.rs:163-213, and the three
+ *       example wavs the filter tests write from real_sample.wav (band_pass_filter.rs:69-185,
+ *       gain_normalizer_filter.rs:81-131): the resampler's output sample by sample,
+ *   G7  oye_casa_g_1_f32.wav (encoder.rs:139-183): i16 -> f32 decode, bit-exact.
  * The reference (Rust) cannot be built in this image (no cargo/rustc, crates not
  * vendored).  Third-party arithmetic not present under /root/reference:
  *   rustfft 6.1.0 (Cargo.lock:545): forward unnormalised complex DFT, restated

@@ -28,6 +28,9 @@ FILES = [
     # written by src/audio/encoder.rs:139-183 (reencode_wav_with_different_format): oye_casa_g_1.wav through
     # rencode_and_resample::<i16> in 480-sample frames -- pins Sample::into_f32 for i16
     "oye_casa_g_1_f32.wav",
+    # written by the filters' own tests from real_sample.wav (48 kHz -> resampler -> filter), f32 16 kHz:
+    # src/audio/band_pass_filter.rs:69-122 / :124-185, src/audio/gain_normalizer_filter.rs:81-131
+    "band-pass_example.wav", "gain-normalizer_example.wav", "gain_normalized_band-pass_example.wav",
 ]
 # tests/resources/{train,test}: the labelled files are byte copies of wavs listed above (oye_casa_real_{1,3,4,5}.wav with
 # "[oye casa]" in the name, test/oye_casa_g_2[oye casa].wav); only the noise recordings are new
@@ -75,6 +78,15 @@ EXPECT = {
                           "avg_threshold": 0.3, "threshold": 0.49, "min_scores": 5, "gain_normalizer": True,
                           "min_gain": 0.4, "band_pass": True, "low_cutoff": 210.0, "high_cutoff": 700.0,
                           "detections": [[0.45496628, 0.5380342, 23], [0.336222, 0.5001262, 5], [0.3049497, 0.5189481, 31]]},
+    },
+    # the filter example wavs: resampler output of real_sample.wav through the front-end, sample by sample
+    "filter_examples": {
+        "band-pass_example.wav": {"lines": "band_pass_filter.rs:69-122", "band_pass": True, "low_cutoff": 80.0, "high_cutoff": 400.0},
+        "gain-normalizer_example.wav": {"lines": "gain_normalizer_filter.rs:81-131", "gain_normalizer": True, "gain_ref": 0.003,
+                                        "min_gain": 0.1, "max_gain": 1.0},
+        "gain_normalized_band-pass_example.wav": {"lines": "band_pass_filter.rs:124-185", "gain_normalizer": True, "gain_ref": 0.003,
+                                                  "min_gain": 0.1, "max_gain": 1.0, "band_pass": True, "low_cutoff": 80.0,
+                                                  "high_cutoff": 400.0},
     },
     # tests/detector.rs:216-267: the wakeword-model runs on ok_casa.wav (48 kHz): [counter, avg_score, score, label logit, none logit]
     "audio_file_nn": {

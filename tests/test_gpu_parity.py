@@ -781,6 +781,29 @@ def test_resample_many_streams(ra, ctx):
         assert _audio_scale_close(got[s], orc.resample_stream(pcm[s], fs))
 
 
+@pytest.mark.parametrize("name", sorted(EXP["filter_examples"].keys()))
+def test_resample_and_frontend_match_reference_filter_examples(ra, ctx, name):
+    """The reference's own filter tests (src/audio/band_pass_filter.rs:69-185, gain_normalizer_filter.rs:81-131) write
+    the audio they produce from real_sample.wav: 48 kHz -> resampler -> gain normaliser / band-pass.  The batched device
+    path (rp_resample_batch + rp_frontend_batch) against those files, 170 880 samples each."""
+    e = EXP["filter_examples"][name]
+    x, sr, _ = rpw_py.read_wav(os.path.join(G, "real_sample.wav"))
+    ref, _, _ = rpw_py.read_wav(os.path.join(G, name))
+    y = ctx.resample(x, sr)
+    assert y.shape == (1, len(ref))
+    fc = ra.FiltersConfig()
+    fc.gain_normalizer.enabled = e.get("gain_normalizer", False)
+    fc.gain_normalizer.gain_ref = e.get("gain_ref")
+    fc.gain_normalizer.min_gain, fc.gain_normalizer.max_gain = e.get("min_gain", 0.1), e.get("max_gain", 1.0)
+    fc.band_pass.enabled = e.get("band_pass", False)
+    fc.band_pass.low_cutoff, fc.band_pass.high_cutoff = e.get("low_cutoff", 80.0), e.get("high_cutoff", 400.0)
+    out, rms, gains = ctx.frontend(y, fc, float("nan"), 1)
+    peak = float(np.abs(ref).max())
+    d = np.abs(out[0] - ref)
+    assert d.max() <= (4e-6 if e.get("band_pass") else 6e-7) * peak
+    assert np.sqrt((d * d).mean()) <= 3e-7 * peak
+
+
 def test_build_wakeword_ref_from_48k_recordings(ra, ctx, tmp_path):
     """tests/wakeword.rs:57-71 on the device: six 48 kHz f32 wavs -> resample -> MFCC -> normalise -> average;
     against the .rpw the reference wrote from the same files (4 680 MFCC values, average, rms level)."""

@@ -271,3 +271,26 @@ def test_g7_i16_to_f32_matches_reference_reencoded_wav():
     n = (len(i16) // 480) * 480
     assert len(f32) == n
     assert np.array_equal(simstream.i16_to_f32(i16[:n]), f32)
+
+
+@pytest.mark.parametrize("name", sorted(EXP["filter_examples"].keys()))
+def test_g6_resampled_audio_matches_reference_filter_examples(name):
+    """The reference's filter tests write the 16 kHz audio they produce from real_sample.wav (48 kHz -> resampler ->
+    gain normaliser / band-pass): 170 880 samples each, the resampler's output pinned sample by sample (gain-only file:
+    3e-7 of the peak; the band-pass recurrence carries the rustfft-vs-f64 rounding difference a little further)."""
+    e = EXP["filter_examples"][name]
+    x, sr, ch = rpw_py.read_wav(os.path.join(G, "real_sample.wav"))
+    ref, sr2, _ = rpw_py.read_wav(os.path.join(G, name))
+    assert (sr, sr2) == (48000, 16000)
+    y = orc.resample_stream(x, sr)
+    assert len(y) == len(ref) == (len(x) // 1440) * 480
+    out, rms, gains = orc.frontend_stream(y, gain_normalizer=e.get("gain_normalizer", False), gain_ref=e.get("gain_ref"),
+                                          min_gain=e.get("min_gain", 0.1), max_gain=e.get("max_gain", 1.0), window_size=1,
+                                          band_pass=e.get("band_pass", False), low_cutoff=e.get("low_cutoff", 80.0),
+                                          high_cutoff=e.get("high_cutoff", 400.0))
+    peak = float(np.abs(ref).max())
+    d = np.abs(out - ref)
+    assert d.max() <= (4e-6 if e.get("band_pass") else 6e-7) * peak   # measured 2.1e-6 / 3.4e-7
+    assert np.sqrt((d * d).mean()) <= 3e-7 * peak
+    if e.get("gain_normalizer"):
+        assert len(set(np.round(gains, 1))) >= 5  # the gain really moves (0.1 .. 0.9)

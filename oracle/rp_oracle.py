@@ -18,6 +18,11 @@ MAX_T = 256
 
 
 def build(force=False):
+    # RP_ORACLE_SO points the checker at another build of the same source (e.g. an ASan/UBSan one, CPU only)
+    global _SO
+    if os.environ.get("RP_ORACLE_SO"):
+        _SO = os.environ["RP_ORACLE_SO"]
+        return _SO
     src = os.path.join(_HERE, "rp_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])

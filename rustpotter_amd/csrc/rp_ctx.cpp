@@ -199,10 +199,10 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         for (DtwChunk c : byclass[cls]) {
             c.rows_off = (int)dup.size();
             for (int r = 0; r < c.len; ++r)
-                for (int tp = 0; tp < c.tc / 2; ++tp)
+                for (int pr = 0; pr < c.tc / 2; ++pr)
                     for (int k = 0; k < K; ++k)
                         for (int h = 0; h < 2; ++h) {  // (t0, t1) interleaved: one scalar pair feeds a packed FMA
-                            const int tt = 2 * tp + h;
+                            const int tt = 2 * pr + h;
                             dup.push_back(unit[((size_t)c.tid[tt < c.count ? tt : 0] * Lpad + r) * K + k]);
                         }
             chunks.push_back(c);

@@ -369,6 +369,16 @@ enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1 };
  * RP_MLP_F32 = f32-input MFMA (exact f32), RP_MLP_BF16 = inputs rounded to bf16, f32 accumulate. */
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits);
 
+/* rp_batch_detect for a wakeword MODEL (WakewordNN::run_detection, src/wakewords/nn/wakeword_nn.rs:39-159, inside the
+ * detection state machine): MFCC -> windows of train_size = dims[0] / mfcc_size frames, mean-normalised -> MLP forward
+ * -> per window the arg-max label (the last maximum; `none_index` = index of the "none" label, -1 without one),
+ * score = 1 - 1/(1 + exp(((label - none) - 10 score_ref) / (10 score_ref))), avg_score likewise against the smallest
+ * other logit when config->avg_threshold != 0, kept when score >= threshold && avg_score >= avg_threshold -> state
+ * machine.  precision: RP_MLP_F32 / RP_MLP_BF16.  det_label [S][max_det] (NULL to skip): label index of a detection. */
+int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                          const rp_model *model, int mfcc_size, int none_index, const rp_detector_config *config, int precision,
+                          rp_batch_detection *det, int32_t *det_label, int32_t *n_det, int max_det);
+
 /* Synthetic benchmark input of BASELINE.md §2, generated on the device:
  * pcm[s][i] = (splitmix64(seed ^ ((first_stream+s)<<32 + i)) >> 40) / 2^24 - 0.5 */
 int rp_synth_pcm_batch(rp_ctx *ctx, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples, size_t pcm_stride,

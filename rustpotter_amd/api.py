@@ -107,7 +107,7 @@ SYMBOLS = [
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
     "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
     "rp_wakeword_model_train", "rp_stream_batch_set_input", "rp_stream_batch_samples_per_chunk",
-    "rp_batch_detect_multi",
+    "rp_batch_detect_multi", "rp_batch_detect_model",
 ]
 
 
@@ -179,6 +179,8 @@ def load_library():
                                           C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), fp, fp]
     L.rp_batch_detect_multi.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp),
                                         C.POINTER(_DetectorConfig), fp, fp, vp, vp, vp, C.c_int]
+    L.rp_batch_detect_model.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_int, C.c_int,
+                                        C.POINTER(_DetectorConfig), C.c_int, vp, vp, vp, C.c_int]
     L.rp_resampler_frame_lengths.argtypes = [C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.rp_resample_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.rp_stream_batch_new.argtypes = [vp, vp, C.POINTER(_DetectorConfig), C.c_size_t, C.c_size_t, C.POINTER(vp)]
@@ -734,6 +736,26 @@ class BatchContext:
                                          det.ctypes.data, dww.ctypes.data, n_det.ctypes.data, max_det) < 0:
             raise _err()
         return det, dww, n_det
+
+    def batch_detect_model(self, pcm, model, mfcc_size, none_index, detector_config, precision="f32", max_det=8):
+        """A wakeword model inside the batched detector -> (det, det_label, n_det)."""
+        import numpy as np
+        assert self.host
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
+        if pcm.ndim == 1:
+            pcm = pcm[None, :]
+        S, N = pcm.shape
+        det = np.zeros((S, max_det), dtype=DET_DTYPE)
+        dlab = np.zeros((S, max_det), np.int32)
+        n_det = np.zeros(S, np.int32)
+        c = detector_config._c()
+        if self._L.rp_batch_detect_model(self._h, pcm.ctypes.data, fmt, S, N, N, model._h, mfcc_size, none_index, C.byref(c),
+                                         {"f32": 0, "bf16": 1}[precision], det.ctypes.data, dlab.ctypes.data, n_det.ctypes.data, max_det) < 0:
+            raise _err()
+        return det, dlab, n_det
 
     def batch_detect_dev(self, pcm_ptr, S, N, stride, templates, detector_config, det_ptr, n_det_ptr, max_det,
                          scores_ptr=None, agg_ptr=None):

@@ -808,6 +808,84 @@ int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, siz
     });
 }
 
+int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                          const rp_model *model, int mfcc_size, int none_index, const rp_detector_config *config, int precision,
+                          rp_batch_detection *det, int32_t *det_label, int32_t *n_det, int max_det) {
+    return guarded([&]() -> int {
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16) { set_last_error("unknown MLP precision"); return -1; }
+        const Model &m = *model->impl;
+        const int nl_layers = (int)m.dims.size() - 1, K = mfcc_size;
+        if (K < 1 || m.dims[0] % K != 0) { set_last_error("Incorrect model layers"); return -1; }
+        const int L = m.dims[0] / K, n_labels = m.dims[nl_layers];
+        if (none_index >= n_labels) { set_last_error("none_index out of range"); return -1; }
+        if (!m.mfma_ok && precision == RP_MLP_BF16) { set_last_error("this layer-1 shape has no bf16 MFMA kernel"); return -1; }
+        const MfccTablesDev *tb = c->tables_for(K);
+        if (!tb) return -1;
+        const size_t nf = rp_mfcc_num_frames(n_samples);
+        const size_t n_win = nf >= (size_t)L ? nf - L + 1 : 0, rows = S * n_win;
+        Staged sg(c);
+        const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
+        BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
+        int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
+        int32_t *dl = det_label ? static_cast<int32_t *>(sg.out(det_label, S * (size_t)max_det * sizeof(int32_t), c->stage_out3)) : nullptr;
+        if (S && (!dp || !dd || !dn)) return -1;
+        if (!c->ws_mfcc.reserve(S * nf * K * sizeof(float) + 64)) return -1;
+        float *dm = c->ws_mfcc.as<float>();
+        c->time_begin(kKernelMfcc);
+        bool ok = hip_ok(launch_mfcc_fmt(c->stream, *tb, dp, (int)fmt, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        // windows are materialised slab by slab (a row is dims[0] floats): <= 4 GiB of rows at a time
+        const size_t row_bytes = (size_t)m.dims[0] * sizeof(float);
+        size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / row_bytes);
+        if (slab > rows) slab = rows;
+        int maxd = 0;
+        for (int d : m.dims) maxd = std::max(maxd, d);
+        if (!c->ws_scores.reserve(slab * row_bytes + 64) || !c->ws_ring.reserve(rows * (size_t)n_labels * sizeof(float) + 16) ||
+            !c->ws_agg.reserve(rows * sizeof(float) + 16) || !c->ws_avg.reserve(rows * sizeof(float) + 16) ||
+            !c->ws_rms.reserve(rows * sizeof(int32_t) + 16)) return -1;
+        if (!m.mfma_ok && !c->ws_gain.reserve(2 * slab * (size_t)maxd * sizeof(float) + 16)) return -1;
+        float *dx = c->ws_scores.as<float>(), *dlog = c->ws_ring.as<float>();
+        for (size_t r0 = 0; r0 < rows; r0 += slab) {
+            const size_t nr = std::min(slab, rows - r0);
+            if (!hip_ok(launch_normalize_windows_batch(c->stream, dm, nf, n_win, r0, nr, L, K, dx), "normalize_windows_kernel")) return -1;
+            c->time_begin(kKernelMlp);
+            if (m.mfma_ok) ok = hip_ok(launch_mlp_mfma(c->stream, m.dev, dx, nr, precision, dlog + r0 * n_labels), "mlp_mfma_kernel");
+            else ok = hip_ok(launch_mlp(c->stream, dx, nr, nl_layers, m.dims.data(), m.W.data(), m.B.data(), c->ws_gain.as<float>(),
+                                        c->ws_gain.as<float>() + slab * (size_t)maxd, dlog + r0 * n_labels), "mlp_layer_kernel");
+            c->time_end();
+            if (!ok) return -1;
+        }
+        float *dg = c->ws_agg.as<float>(), *da = c->ws_avg.as<float>();
+        int32_t *dlab = c->ws_rms.as<int32_t>();
+        if (!hip_ok(launch_nn_score(c->stream, dlog, rows, n_labels, none_index, config->score_ref * 10.f, config->avg_threshold != 0.f ? 1 : 0,
+                                    config->threshold, config->avg_threshold, dg, da, dlab), "nn_score_kernel")) return -1;
+        ScanWakewords ww{};
+        ww.n = 1; ww.agg[0] = dg; ww.avg[0] = da; ww.label[0] = dlab;
+        ww.threshold[0] = -1.f; ww.avg_threshold[0] = -1.f;  // the gates were applied by nn_score_kernel (>=, not >)
+        ScanConfig sc;
+        sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
+        sc.eager = config->eager ? 1 : 0; sc.max_len = L; sc.avg_enabled = 0;
+        float *dv = nullptr;
+        if (config->vad_mode != RP_VAD_NONE) {
+            if (!c->ws_vad.reserve(S * nf * sizeof(float) + 16)) return -1;
+            dv = c->ws_vad.as<float>();
+            if (!hip_ok(launch_vad_value(c->stream, dm, S * nf, K, dv), "vad_value_kernel")) return -1;
+        }
+        c->time_begin(kKernelScan);
+        ok = hip_ok(launch_scan_multi(c->stream, ww, dv, vad_mode_value(config->vad_mode), S, nf, sc, dd, dl, dn, max_det), "scan_kernel");
+        c->time_end();
+        if (!ok) return -1;
+        if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
+        if (dl && !sg.back(det_label, dl, S * (size_t)max_det * sizeof(int32_t))) return -1;
+        return sg.finish() ? 0 : -1;
+    });
+}
+
 int rp_synth_pcm_batch(rp_ctx *ctx, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples, size_t pcm_stride,
                        float *pcm) {
     return guarded([&]() -> int {

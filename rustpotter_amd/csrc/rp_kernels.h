@@ -93,6 +93,7 @@ struct ScanWakewords {
     int n;
     const float *agg[kScanMaxWakewords], *avg[kScanMaxWakewords];
     float threshold[kScanMaxWakewords], avg_threshold[kScanMaxWakewords];
+    const int32_t *label[kScanMaxWakewords];  // model wakewords: the winning label of every window (reported instead of j)
 };
 
 struct BatchDetection {  // == rp_batch_detection
@@ -192,6 +193,14 @@ hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_
                                 float *const *Bv, float *const *act);
 hipError_t launch_train_step(hipStream_t st, const float *x, const int32_t *labels, size_t B, int n_layers, const int *dims,
                              float *const *W, float *const *Bv, float *const *act, float *const *dz, float lr, float *loss_rows);
+// WakewordNN::run_detection (src/wakewords/nn/wakeword_nn.rs:39-159) over whole batches: windows of L frames cut from
+// mfcc [S][frame_pitch][K] and mean-normalised into rows (first_row .. first_row+n_rows of the S*n_win windows), and the
+// label / score logic on the logits: agg = score where the detection is valid (label != none, score >= threshold,
+// avg_score >= avg_threshold) else -2, avg = avg_score, label = arg-max label.
+hipError_t launch_normalize_windows_batch(hipStream_t st, const float *mfcc, size_t frame_pitch, size_t n_win, size_t first_row,
+                                          size_t n_rows, int L, int K, float *x);
+hipError_t launch_nn_score(hipStream_t st, const float *logits, size_t n_rows, int n_labels, int none_index, float score_ref10,
+                           int calc_avg, float threshold, float avg_threshold, float *agg, float *avg, int32_t *label);
 hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
                       float *const *Bv, float *scratch0, float *scratch1, float *out);
 

@@ -47,6 +47,72 @@ hipError_t launch_normalize_windows(hipStream_t st, const float *mfcc, size_t fi
     return hipGetLastError();
 }
 
+// the same for windows of many streams: row = s * n_win + w
+__global__ __launch_bounds__(64) void normalize_windows_batch_kernel(const float *__restrict__ mfcc, size_t frame_pitch, size_t n_win,
+                                                                      size_t first_row, int L, int K, float *__restrict__ x) {
+    const size_t row = first_row + blockIdx.x;
+    const size_t s = row / n_win, w = row - s * n_win;
+    const float *src = mfcc + (s * frame_pitch + w) * K;
+    float *dst = x + (size_t)blockIdx.x * L * K;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        float sum = 0.f;
+        for (int i = 0; i < L; ++i) sum += src[(size_t)i * K + k];
+        for (int i = 0; i < L; ++i) dst[(size_t)i * K + k] = src[(size_t)i * K + k] - sum / (float)L;
+    }
+}
+
+hipError_t launch_normalize_windows_batch(hipStream_t st, const float *mfcc, size_t frame_pitch, size_t n_win, size_t first_row,
+                                          size_t n_rows, int L, int K, float *x) {
+    if (n_rows == 0) return hipSuccess;
+    if (n_rows > 0x7fffffffULL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(normalize_windows_batch_kernel, dim3((unsigned)n_rows), dim3(64), 0, st, mfcc, frame_pitch, n_win, first_row, L, K, x);
+    return hipGetLastError();
+}
+
+// calc_inverse_similarity, wakeword_nn.rs:161-163
+__device__ __forceinline__ float nn_inverse_similarity(float n1, float n2, float reference) {
+    return 1.f - (1.f / (1.f + expf(((n1 - n2) - reference) / reference)));
+}
+
+// get_label (:47-60: max_by(total_cmp) keeps the LAST maximum), run_detection_by_label (:61-99: second_prob is the
+// smallest other logit), validate_scores (:113-123)
+__global__ __launch_bounds__(256) void nn_score_kernel(const float *__restrict__ logits, size_t n_rows, int nl, int none_index,
+                                                       float ref, int calc_avg, float threshold, float avg_threshold,
+                                                       float *__restrict__ agg, float *__restrict__ avg, int32_t *__restrict__ label) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const float *lg = logits + r * nl;
+    int bi = 0;
+    for (int i = 1; i < nl; ++i) if (!(lg[i] < lg[bi])) bi = i;
+    float score = -2.f, av = 0.f;
+    if (bi != none_index) {
+        const float label_prob = lg[bi], none_prob = none_index >= 0 ? lg[none_index] : 0.f;
+        float second = 0.f;
+        if (calc_avg) {
+            bool any = false;
+            for (int i = 0; i < nl; ++i) {
+                if (lg[i] == label_prob) continue;
+                if (!any || !(lg[i] > second)) { second = lg[i]; any = true; }
+            }
+            if (!any) second = 0.f;
+            av = nn_inverse_similarity(label_prob, second, ref);
+        }
+        const float sc = nn_inverse_similarity(label_prob, none_prob, ref);
+        if (sc >= threshold && av >= avg_threshold) score = sc;
+    }
+    agg[r] = score; avg[r] = av; label[r] = bi;
+}
+
+hipError_t launch_nn_score(hipStream_t st, const float *logits, size_t n_rows, int n_labels, int none_index, float score_ref10,
+                           int calc_avg, float threshold, float avg_threshold, float *agg, float *avg, int32_t *label) {
+    if (n_rows == 0) return hipSuccess;
+    const size_t blocks = (n_rows + 255) / 256;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nn_score_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, n_rows, n_labels, none_index, score_ref10, calc_avg,
+                       threshold, avg_threshold, agg, avg, label);
+    return hipGetLastError();
+}
+
 hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
                       float *const *Bv, float *scratch0, float *scratch1, float *out) {
     if (B == 0) return hipSuccess;

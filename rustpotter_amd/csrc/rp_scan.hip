@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
         }
         if (best >= 0) {
             int counter = has_partial ? p_counter + 1 : 1;
-            if (!has_partial || p_score < sc) { p_score = sc; p_avg = av; p_window = (int)w; p_ww = best; has_partial = true; }
+            if (!has_partial || p_score < sc) {
+                p_score = sc; p_avg = av; p_window = (int)w; has_partial = true;
+                p_ww = ww.label[best] ? ww.label[best][row0 + w] : best;
+            }
             p_counter = counter;
             countdown = (int)(max_len / 2);
         }

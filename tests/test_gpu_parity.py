@@ -1052,6 +1052,48 @@ def test_rustpotter_api_model_wakeword(ra):
         assert abs(a.score - b["score"]) <= 1e-4
 
 
+@pytest.mark.parametrize("avg_threshold", [0.0, 0.3])
+def test_batch_detect_model_equals_per_stream_api(ra, ctx, avg_threshold):
+    """A wakeword model in the batched detector (rp_batch_detect_model: windows -> MLP -> label / score logic -> state
+    machine) against Rustpotter handles holding the same model file, stream by stream; f32 MFMA like the handle."""
+    m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
+    ws = [m["weights"]["ln1.weight"], m["weights"]["ln2.weight"]]
+    bs = [m["weights"]["ln1.bias"], m["weights"]["ln2.bias"]]
+    model = ra.Model(ctx, ws, bs)
+    none_index = m["labels"].index("none")
+    c = ra.RustpotterConfig.default()
+    c.detector.avg_threshold, c.detector.threshold, c.detector.min_scores = avg_threshold, 0.6, 3
+    # the model's own recording (48 kHz -> 16 kHz through the oracle) over low noise, plus synthetic streams
+    x48, sr, _ = rpw_py.read_wav(os.path.join(G, "ok_casa.wav"))
+    rng = np.random.default_rng(21)
+    speech = orc.resample_stream(x48, sr)
+    n = 480 * 420
+    streams = []
+    for shift in (16000, 40000):
+        s = rng.standard_normal(n).astype(np.float32) * np.float32(0.002)
+        s[shift:shift + len(speech)] += speech
+        streams.append(s)
+    streams.append(orc.synth_pcm(SEED, 11, n) * np.float32(0.2))
+    pcm = np.stack(streams)
+    det, dlab, n_det = ctx.batch_detect_model(pcm, model, m["mfcc_size"], none_index, c.detector)
+    total = 0
+    for si in range(len(streams)):
+        rp = ra.Rustpotter.new(c)
+        rp.add_wakeword_from_file("w", os.path.join(G, "ok_casa-tiny.rpw"))
+        got = []
+        for i in range(0, n, 480):
+            d = rp.process_samples(pcm[si, i:i + 480].copy())
+            if d is not None:
+                got.append((i // 480, d))
+        assert n_det[si] == len(got)
+        total += len(got)
+        for j, (chunk, d) in enumerate(got):
+            assert det[si][j]["frame"] // 3 + 1 == chunk and det[si][j]["counter"] == d.counter
+            assert m["labels"][dlab[si][j]] == d.name
+            assert abs(det[si][j]["score"] - d.score) <= 1e-5 and abs(det[si][j]["avg_score"] - d.avg_score) <= 1e-5
+    assert total >= 2
+
+
 # --------------------------------------------------------------------------- full BASELINE sizes
 def _full_size_run(ra, S, T, seed_templates=SEED):
     """Whole path on device-resident synthetic input exactly as bench.py sets it up."""

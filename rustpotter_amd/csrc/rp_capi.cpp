@@ -839,26 +839,40 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
         bool ok = hip_ok(launch_mfcc_fmt(c->stream, *tb, dp, (int)fmt, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
         c->time_end();
         if (!ok) return -1;
-        // windows are materialised slab by slab (a row is dims[0] floats): <= 4 GiB of rows at a time
-        const size_t row_bytes = (size_t)m.dims[0] * sizeof(float);
-        size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / row_bytes);
-        if (slab > rows) slab = rows;
-        int maxd = 0;
-        for (int d : m.dims) maxd = std::max(maxd, d);
-        if (!c->ws_scores.reserve(slab * row_bytes + 64) || !c->ws_ring.reserve(rows * (size_t)n_labels * sizeof(float) + 16) ||
-            !c->ws_agg.reserve(rows * sizeof(float) + 16) || !c->ws_avg.reserve(rows * sizeof(float) + 16) ||
-            !c->ws_rms.reserve(rows * sizeof(int32_t) + 16)) return -1;
-        if (!m.mfma_ok && !c->ws_gain.reserve(2 * slab * (size_t)maxd * sizeof(float) + 16)) return -1;
-        float *dx = c->ws_scores.as<float>(), *dlog = c->ws_ring.as<float>();
-        for (size_t r0 = 0; r0 < rows; r0 += slab) {
-            const size_t nr = std::min(slab, rows - r0);
-            if (!hip_ok(launch_normalize_windows_batch(c->stream, dm, nf, n_win, r0, nr, L, K, dx), "normalize_windows_kernel")) return -1;
+        if (!c->ws_ring.reserve(rows * (size_t)n_labels * sizeof(float) + 16) || !c->ws_agg.reserve(rows * sizeof(float) + 16) ||
+            !c->ws_avg.reserve(rows * sizeof(float) + 16) || !c->ws_rms.reserve(rows * sizeof(int32_t) + 16)) return -1;
+        float *dlog = c->ws_ring.as<float>();
+        // (RP_MLP_BF16 only permits bf16 inputs: the in-place window kernel is f32 and faster than materialising rows)
+        const float *wsum = (m.mfma_ok && K % 4 == 0) ? const_cast<Model &>(m).wsum_for(K) : nullptr;
+        if (wsum) {
+            // windows read in place from the frame array, the window mean taken out after layer 1
+            if (!c->ws_gain.reserve(rows * (size_t)K * sizeof(float) + 16)) return -1;
+            float *dmean = c->ws_gain.as<float>();
+            if (!hip_ok(launch_window_means(c->stream, dm, S, nf, n_win, L, K, dmean), "window_means_kernel")) return -1;
             c->time_begin(kKernelMlp);
-            if (m.mfma_ok) ok = hip_ok(launch_mlp_mfma(c->stream, m.dev, dx, nr, precision, dlog + r0 * n_labels), "mlp_mfma_kernel");
-            else ok = hip_ok(launch_mlp(c->stream, dx, nr, nl_layers, m.dims.data(), m.W.data(), m.B.data(), c->ws_gain.as<float>(),
-                                        c->ws_gain.as<float>() + slab * (size_t)maxd, dlog + r0 * n_labels), "mlp_layer_kernel");
+            ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, dm, S, nf, n_win, K, dmean, wsum, dlog), "mlp_mfma_kernel");
             c->time_end();
             if (!ok) return -1;
+        } else {
+            // windows are materialised slab by slab (a row is dims[0] floats): <= 4 GiB of rows at a time
+            const size_t row_bytes = (size_t)m.dims[0] * sizeof(float);
+            size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / row_bytes);
+            if (slab > rows) slab = rows;
+            int maxd = 0;
+            for (int d : m.dims) maxd = std::max(maxd, d);
+            if (!c->ws_scores.reserve(slab * row_bytes + 64)) return -1;
+            if (!m.mfma_ok && !c->ws_gain.reserve(2 * slab * (size_t)maxd * sizeof(float) + 16)) return -1;
+            float *dx = c->ws_scores.as<float>();
+            for (size_t r0 = 0; r0 < rows; r0 += slab) {
+                const size_t nr = std::min(slab, rows - r0);
+                if (!hip_ok(launch_normalize_windows_batch(c->stream, dm, nf, n_win, r0, nr, L, K, dx), "normalize_windows_kernel")) return -1;
+                c->time_begin(kKernelMlp);
+                if (m.mfma_ok) ok = hip_ok(launch_mlp_mfma(c->stream, m.dev, dx, nr, precision, dlog + r0 * n_labels), "mlp_mfma_kernel");
+                else ok = hip_ok(launch_mlp(c->stream, dx, nr, nl_layers, m.dims.data(), m.W.data(), m.B.data(), c->ws_gain.as<float>(),
+                                            c->ws_gain.as<float>() + slab * (size_t)maxd, dlog + r0 * n_labels), "mlp_layer_kernel");
+                c->time_end();
+                if (!ok) return -1;
+            }
         }
         float *dg = c->ws_agg.as<float>(), *da = c->ws_avg.as<float>();
         int32_t *dlab = c->ws_rms.as<int32_t>();

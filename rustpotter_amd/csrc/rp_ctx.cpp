@@ -248,6 +248,7 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
         if (!up(biases[l], sizeof(float) * (size_t)dims[l + 1], reinterpret_cast<void **>(&b))) return nullptr;
         m->B.push_back(b);
     }
+    m->w1_host.assign(weights[0], weights[0] + (size_t)dims[0] * dims[1]);
     MlpDev &d = m->dev;
     d.n_layers = n_layers;
     for (int l = 0; l <= n_layers; ++l) d.dims[l] = dims[l];
@@ -281,6 +282,26 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
             return nullptr;
     }
     return m.release();
+}
+
+const float *Model::wsum_for(int K) {
+    auto it = wsums.find(K);
+    if (it != wsums.end()) return it->second->as<float>();
+    if (K < 1 || dims[0] % K != 0 || dev.nt <= 0) return nullptr;
+    const int L = dims[0] / K, n1 = dims[1], rows = 16 * dev.nt;
+    std::vector<float> ws((size_t)rows * K, 0.f);
+    for (int o = 0; o < n1; ++o)
+        for (int k = 0; k < K; ++k) {
+            double acc = 0.0;
+            for (int i = 0; i < L; ++i) acc += (double)w1_host[(size_t)o * dims[0] + (size_t)i * K + k];
+            ws[(size_t)o * K + k] = (float)acc;
+        }
+    std::unique_ptr<DevBuf> b(new DevBuf());
+    if (!b->reserve(ws.size() * sizeof(float))) return nullptr;
+    if (!hip_ok(hipMemcpy(b->p, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(wsum)")) return nullptr;
+    const float *p = b->as<float>();
+    wsums[K] = std::move(b);
+    return p;
 }
 
 Model::~Model() {

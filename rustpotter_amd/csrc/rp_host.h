@@ -143,6 +143,9 @@ struct Model {
     bool mfma_ok = false;  // layer-1 shape supported by the MFMA kernels
     std::vector<float *> W, B;  // plain per-layer device copies for the generic kernel
     std::vector<int> dims;
+    std::vector<float> w1_host;                     // layer-1 weights [dims[1]][dims[0]]
+    std::map<int, std::unique_ptr<DevBuf>> wsums;   // per mfcc_size K: [16*nt][K], sum over frames of the layer-1 weights
+    const float *wsum_for(int K);                   // (takes the window mean out after layer 1, launch_mlp_mfma_windows)
     // weights/biases: HOST arrays, W_l [dims[l+1]][dims[l]], b_l [dims[l+1]]
     static Model *create(Ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases);
     ~Model();

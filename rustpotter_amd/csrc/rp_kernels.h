@@ -187,6 +187,13 @@ enum { kMlpF32 = 0, kMlpBf16 = 1 };
 // Fused forward of all layers; layer 1 on the matrix cores (f32-input MFMA: bit-for-bit an fmaf
 // chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.
 hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out);
+// The rows are windows of L = dims[0]/K frames read IN PLACE from mfcc [S][n_frames][K] (a window's flattened features
+// are a contiguous slice of the frame array), row = s * n_win + w; the window mean (MfccNormalizer::normalize) is taken
+// out after layer 1: W.(f - mu) = W.f - sum_k mu[k] * wsum[o][k], wsum[o][k] = sum_i W[o][i*K + k].  f32 MFMA.
+// mean [S*n_win][K] from launch_window_means, wsum [16*nt][K].
+hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int L, int K, float *mean);
+hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
+                                   const float *mean, const float *wsum, float *out);
 
 // WakewordModelTrain (src/wakewords/nn/wakeword_model_train.rs:204-209): act[l] / dz[l] are [B][dims[l+1]] device buffers
 hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,

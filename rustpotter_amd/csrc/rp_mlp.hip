@@ -267,7 +267,8 @@ template <int NT, int PREC>
 __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     const float *__restrict__ x, size_t B, int in, int kpad, const float *__restrict__ w1f,
     const __bf16 *__restrict__ w1h, const float *__restrict__ b1, const float *__restrict__ tail, int tail_floats,
-    int n_layers, int d1, int d2, int d3, int d4, int h2w, int wbuf_floats, float *__restrict__ out) {
+    int n_layers, int d1, int d2, int d3, int d4, int h2w, int wbuf_floats, float *__restrict__ out, size_t row_stride,
+    size_t rows_per_stream, size_t stream_skip, const float *__restrict__ mean, const float *__restrict__ wsum, int K) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N1P = 16 * NT;
     float *tl = reinterpret_cast<float *>(smem);                       // tail weights
@@ -283,7 +284,8 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     size_t r = row0 + li;
     if (r >= B) r = B - 1;  // rows past the end recompute the last row; their results are dropped
-    const float *xr = x + r * in;
+    // row_stride != 0: rows are overlapping windows read in place from the frame array (launch_mlp_mfma_windows)
+    const float *xr = row_stride ? x + r * row_stride + (r / rows_per_stream) * stream_skip : x + r * in;
 
     // staged weight groups are double buffered when they fit (NT <= 2): the next group's global
     // loads are issued before this group's MFMAs and land in the other buffer, one barrier per group
@@ -401,7 +403,16 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float v = acc[n][e] + b1[16 * n + li];
+            float v = acc[n][e];
+            if (mean) {  // take the window mean out: - sum_k mu[row][k] * wsum[o][k]
+                size_t rr = row0 + 4 * lk + e;
+                if (rr >= B) rr = B - 1;
+                const float *mu = mean + rr * K, *ws = wsum + (size_t)(16 * n + li) * K;
+                float corr = 0.f;
+                for (int k = 0; k < K; ++k) corr = fmaf(mu[k], ws[k], corr);
+                v -= corr;
+            }
+            v += b1[16 * n + li];
             if (relu1 && v < 0.f) v = 0.f;
             h1[(4 * lk + e) * (N1P + 1) + 16 * n + li] = v;
         }
@@ -440,7 +451,9 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
 }
 
 template <int NT>
-static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out) {
+static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out,
+                                size_t row_stride = 0, size_t rows_per_stream = 1, size_t stream_skip = 0, const float *mean = nullptr,
+                                const float *wsum = nullptr, int K = 0) {
     const size_t rows_per_block = (size_t)kMlpWaves * kMlpRowsPerWave;
     const size_t blocks = (B + rows_per_block - 1) / rows_per_block;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
@@ -466,11 +479,11 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     if (precision == kMlpBf16)
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
-                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out);
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K);
     else
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF32>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
-                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out);
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K);
     return hipGetLastError();
 }
 
@@ -481,6 +494,52 @@ hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size
     case 2: return launch_mlp_nt<2>(st, m, x, B, precision, out);
     case 5: return launch_mlp_nt<5>(st, m, x, B, precision, out);
     case 9: return launch_mlp_nt<9>(st, m, x, B, precision, out);
+    }
+    return hipErrorInvalidValue;
+}
+
+// per window the column means over its L frames, summed in frame order like MfccNormalizer::normalize
+// (src/mfcc/normalizer.rs:3-31); one lane per (window, coefficient), 64 consecutive windows of a stream per block
+__global__ __launch_bounds__(256) void window_means_kernel(const float *__restrict__ mfcc, size_t n_frames, size_t n_win, unsigned tiles,
+                                                           int L, int K, float *__restrict__ mean) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *fs = reinterpret_cast<float *>(smem);  // [64 + L - 1][K]
+    const size_t s = blockIdx.x / tiles;
+    const size_t w0 = (size_t)(blockIdx.x - s * tiles) * 64;
+    const size_t nw = n_win - w0 < 64 ? n_win - w0 : 64;
+    const float *src = mfcc + (s * n_frames + w0) * K;
+    const int nfr = (int)nw + L - 1;
+    for (int i = threadIdx.x; i < nfr * K; i += 256) fs[i] = src[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)nw * K; i += 256) {
+        const int w = i / K, k = i - w * K;
+        float sum = 0.f;
+        for (int f = 0; f < L; ++f) sum += fs[(w + f) * K + k];
+        mean[(s * n_win + w0 + w) * K + k] = sum / (float)L;
+    }
+}
+
+hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int L, int K, float *mean) {
+    if (S == 0 || n_win == 0) return hipSuccess;
+    const size_t tiles = (n_win + 63) / 64, blocks = tiles * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(64 + L - 1) * K * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(window_means_kernel, dim3((unsigned)blocks), dim3(256), lds, st, mfcc, n_frames, n_win, (unsigned)tiles, L, K, mean);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
+                                   const float *mean, const float *wsum, float *out) {
+    const size_t B = S * n_win;
+    if (B == 0) return hipSuccess;
+    if (K < 1 || K % 4 != 0 || m.dims[0] % K != 0) return hipErrorInvalidValue;  // 16-byte aligned window rows
+    const size_t L = (size_t)m.dims[0] / K;
+    switch (m.nt) {
+    case 1: return launch_mlp_nt<1>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
+    case 2: return launch_mlp_nt<2>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
+    case 5: return launch_mlp_nt<5>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
+    case 9: return launch_mlp_nt<9>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
     }
     return hipErrorInvalidValue;
 }

@@ -1094,6 +1094,37 @@ def test_batch_detect_model_equals_per_stream_api(ra, ctx, avg_threshold):
     assert total >= 2
 
 
+def test_batch_detect_model_generic_shape_from_trained_file(ra, ctx, tmp_path):
+    """A model trained on the device with mfcc_size 5 (feature rows not 16-byte sized: materialised rows + the generic
+    layer kernel) -> the same file drives a Rustpotter handle and rp_batch_detect_model; detections must agree."""
+    e, train, test = _train_sets()
+    data, loss, acc = ctx.train_wakeword_model(train, test, "tiny", 0.05, 30, 10, 5, seed=5)
+    p = tmp_path / "m5.rpw"
+    p.write_bytes(data)
+    m = rpw_py.load_rpw(str(p))
+    assert m["mfcc_size"] == 5
+    model = ra.Model(ctx, [m["weights"]["ln1.weight"], m["weights"]["ln2.weight"]], [m["weights"]["ln1.bias"], m["weights"]["ln2.bias"]])
+    none_index = m["labels"].index("none")
+    c = ra.RustpotterConfig.default()
+    c.detector.avg_threshold, c.detector.threshold, c.detector.min_scores = 0.0, 0.55, 2
+    x48, sr, _ = rpw_py.read_wav(os.path.join(G, "oye_casa_real_1.wav"))
+    speech = orc.resample_stream(x48, sr)
+    rng = np.random.default_rng(3)
+    n = 480 * 300
+    s0 = rng.standard_normal(n).astype(np.float32) * np.float32(0.003)
+    s0[30000:30000 + len(speech)] += speech
+    pcm = np.stack([s0, orc.synth_pcm(SEED, 2, n) * np.float32(0.1)])
+    det, dlab, n_det = ctx.batch_detect_model(pcm, model, 5, none_index, c.detector)
+    for si in range(2):
+        rp = ra.Rustpotter.new(c)
+        rp.add_wakeword_from_buffer("w", data)
+        got = [(i // 480, d) for i in range(0, n, 480) for d in [rp.process_samples(pcm[si, i:i + 480].copy())] if d is not None]
+        assert n_det[si] == len(got)
+        for j, (chunk, d) in enumerate(got):
+            assert det[si][j]["frame"] // 3 + 1 == chunk and det[si][j]["counter"] == d.counter and m["labels"][dlab[si][j]] == d.name
+            assert abs(det[si][j]["score"] - d.score) <= 1e-5
+
+
 # --------------------------------------------------------------------------- full BASELINE sizes
 def _full_size_run(ra, S, T, seed_templates=SEED):
     """Whole path on device-resident synthetic input exactly as bench.py sets it up."""

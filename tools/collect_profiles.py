@@ -1,0 +1,68 @@
+"""Turns the rocprofv3 output of tools/profile_bench.sh / profile_pmc.sh (tags final, final_fetch, final_write, final_sq,
+final_inst under gpurun_out/) and the bench lines under gpurun_out/final/ into the committed files under profiles/."""
+import csv, glob, json, collections, statistics, shutil, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(ROOT)
+short = lambda n: n.split("(")[0]
+
+def agg(tag):
+    path = glob.glob("gpurun_out/pmc_%s/**/*counter_collection.csv" % tag, recursive=True)[0]
+    a = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        a[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: statistics.median(v) for c, v in d.items()} for k, d in a.items()}
+
+fe, wr, sq, ins = agg("final_fetch"), agg("final_write"), agg("final_sq"), agg("final_inst")
+out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+                  "(separate passes: FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; "
+                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES -- tools/profile_pmc.sh)",
+       "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch as reported by rocprofv3 (TCC_EA0 request counters); FETCH_SIZE of "
+                "16-byte-per-lane streaming reads under-reports by 2x on gfx950 (MI355X_MICROARCH.md HBM section); values are the "
+                "MEDIAN over the launches of a kernel in the run (the run also holds one tiny mfcc launch for the templates)",
+       "workload": {"streams": 65536, "samples": 64000, "templates": 8, "template_len": 100, "mfcc_size": 5}, "kernels": {}}
+for k in fe:
+    f, w = fe[k]["FETCH_SIZE"], wr[k]["WRITE_SIZE"]
+    d = {"FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w}
+    if "mfcc_kernel" in k:
+        d["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
+        d["note"] = "reads are 16 B/lane: FETCH_SIZE doubled per the guide"
+    elif any(x in k for x in ("dtw_band_kernel", "aggregate_kernel", "scan_kernel")):
+        d["hbm_bytes_per_launch_corrected"] = (f + w) * 1024
+        d["note"] = "4-byte reads: FETCH_SIZE taken at face value"
+    if k in sq and sq[k].get("SQ_WAVE_CYCLES"):
+        d["sq_fractions_of_wave_cycles"] = {n: sq[k][n] / sq[k]["SQ_WAVE_CYCLES"] for n in sq[k] if n != "SQ_WAVE_CYCLES"}
+    if k in ins:
+        d["instructions_per_launch"] = ins[k]
+    out["kernels"][k] = d
+json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
+json.dump(out, open("profiles/r01_final_pmc.json", "w"), indent=1)
+shutil.copy(glob.glob("gpurun_out/prof_final/**/*kernel_stats.csv", recursive=True)[0], "profiles/r01_final_kernel_stats.csv")
+line = [l for l in open("gpurun_out/prof_final_bench.log") if l.startswith("{")][-1]
+open("profiles/r01_final_bench_under_rocprof.json", "w").write(line)
+names = {"bench_default": "r01_final_bench", "stream1": "bench_r01_stream_1chunk", "stream8": "bench_r01_stream_8chunks",
+         "rs_fft": "bench_r01_resample_fft", "rs_gemm": "bench_r01_resample_gemm", "rs_fft_i16_stereo": "bench_r01_resample_fft_i16_stereo",
+         "c5_bf16": "bench_r01_c5_bf16", "c5_f32": "bench_r01_c5_f32", "k16": "bench_r01_k16_8192streams", "c4": "bench_r01_c4_per_gpu"}
+for a, b in names.items():
+    src = "gpurun_out/final/%s.json" % a
+    if os.path.exists(src) and os.path.getsize(src) > 10:
+        shutil.copy(src, "profiles/%s.json" % b)
+        x = json.loads(open(src).read().strip().splitlines()[-1])
+        print(b, "%.4g %s" % (x["value"], x["unit"]), "%.3f ms" % x["ms_per_step"], x.get("roofline", {}).get("kernels_ms", ""))
+txt = []
+for f in ("model_detect.txt", "latency.txt"):
+    p = "gpurun_out/final/" + f
+    if os.path.exists(p):
+        txt.append(open(p).read().strip())
+open("profiles/r01_final_misc.txt", "w").write("\n".join(txt) + "\n")
+tr = glob.glob("gpurun_out/prof_final/**/*kernel_trace.csv", recursive=True)[0]
+dur = collections.defaultdict(list)
+for r in csv.DictReader(open(tr)):
+    dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+for k, v in dur.items():
+    if max(v) > 0.1:
+        print("%-44s %d launches, median %.3f ms" % (k[:44], len(v), statistics.median(v)))
+for k, d in out["kernels"].items():
+    if "hbm_bytes_per_launch_corrected" in d:
+        print("%-44s %.3f GB" % (k[:44], d["hbm_bytes_per_launch_corrected"] / 1e9),
+              {a: round(b, 3) for a, b in d.get("sq_fractions_of_wave_cycles", {}).items()})

@@ -626,22 +626,33 @@ __device__ inline float percentile_sorted(const float *v, int n, float percentil
 
 constexpr int kAggMaxT = 256;
 
-// Max / Average: no sort buffer, so no scratch memory to set up (the single-stream path launches this for 3 rows)
+// Max / Average: no sort buffer, so no scratch memory to set up (the single-stream path launches this for 3 rows).
+// A workgroup owns 64 consecutive rows: the [64][T] block of scores is one contiguous range, copied to LDS with
+// coalesced loads (row pitch T+1: conflict-free), then lane r walks row r in template order.
 __global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
                                                        float *__restrict__ agg) {
-    size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (row >= n_rows) return;
-    const float *v = scores + row * T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tile = reinterpret_cast<float *>(smem);  // [64][T + 1]
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    const size_t nr = n_rows - row0 < 64 ? n_rows - row0 : 64;
+    const float *src = scores + row0 * T;
+    const int total = (int)nr * T, P = T + 1;
+    for (int i = threadIdx.x; i < total; i += 64) {
+        const int r = i / T, t = i - r * T;
+        tile[r * P + t] = src[i];
+    }
+    __syncthreads();
+    const int r = threadIdx.x;
+    if ((size_t)r >= nr) return;
+    const float *v = tile + r * P;
     if (mode == 1) {  // Max
         float m = v[0];
         for (int i = 1; i < T; ++i) m = fmaxf(m, v[i]);
-        agg[row] = m;
-        return;
-    }
-    if (mode == 0) {  // Average: sequential sum in template order
-        float s = 0.f;
-        for (int i = 0; i < T; ++i) s += v[i];
-        agg[row] = s / (float)T;
+        agg[row0 + r] = m;
+    } else {  // Average: sequential sum in template order
+        float sum = 0.f;
+        for (int i = 0; i < T; ++i) sum += v[i];
+        agg[row0 + r] = sum / (float)T;
     }
 }
 
@@ -675,7 +686,8 @@ hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, 
     if (T < 1 || T > kAggMaxT) return hipErrorInvalidValue;
     size_t blocks = (n_rows + 63) / 64;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    if (mode == 0 || mode == 1) hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
+    if (mode == 0 || mode == 1)
+        hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), (size_t)64 * (T + 1) * sizeof(float), st, scores, n_rows, T, mode, agg);
     else hipLaunchKernelGGL(aggregate_sorted_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
     return hipGetLastError();
 }

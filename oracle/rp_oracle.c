@@ -24,7 +24,7 @@
  *   rustfft 6.1.0 (Cargo.lock:545): forward unnormalised complex DFT, restated
  *   here as a plain mixed-radix f32 FFT (twiddles computed in f64, stored f32);
  *   rubato 0.14.1 (Cargo.lock:533): FftFixedInOut<f32>, restated from its published
- *   algorithm; its anti-aliasing cutoff constant is pinned numerically by G6 (see
+ *   algorithm (its anti-aliasing cutoff formula cross-checked numerically on G6, see
  *   rubato_cutoff).  The wakeword-model goldens on resampled audio
  *   (tests/detector.rs:216-267) are NOT reproducible by any arithmetic other than
  *   rustfft's own (tests/test_oracle_golden.py explains): the NN forward stays
@@ -774,17 +774,16 @@ void orc_resampler_free(orc_resampler *r) {
     free(r->in_re); free(r->in_im); free(r);
 }
 
-/* Relative anti-aliasing cutoff of the windowed sinc (BlackmanHarris2) for `npoints` taps per output
- * Nyquist band.  rubato computes it with a closed-form fit whose constants are not available offline; the
- * value for the one case the reference's goldens exercise (48 kHz -> 16 kHz: npoints = 480) was determined
- * against tests/resources/oye_casa_real.rpw (4 680 MFCC values; the error has a sharp V-shaped minimum of
- * 2e-5 at 0.9716115 +- 1e-6, 1e-3 at +-1e-4), and the 1/(1 + k1/n + k2/n^2 + k3/n^3) form carries it to
- * other lengths (those are NOT pinned by any reference golden). */
+/* Relative anti-aliasing cutoff of the windowed sinc: rubato's sinc.rs calculate_cutoff(npoints, BlackmanHarris2) =
+ * 1 / (k1/n + k2/n^2 + k3/n^3 + 1), used by FftResampler::new with n = the shorter of the two transform lengths.
+ * The three constants are quoted from the crate's published source (it is not vendored here).  They were checked
+ * independently: fitting the cutoff alone against tests/resources/oye_casa_real.rpw (4 680 MFCC values; the error has
+ * a sharp V-shaped minimum) gives 0.9716115 +- 1e-6 for n = 480, the formula gives 0.9716114. */
 static float rubato_cutoff(int npoints) {
-    const double n = (double)npoints;
-    const double k2 = 178.3, k3 = 3.028e5;
-    const double k1 = ((1.0 / 0.9716115) - 1.0 - k2 / (480.0 * 480.0) - k3 / (480.0 * 480.0 * 480.0)) * 480.0;
-    return (float)(1.0 / (1.0 + k1 / n + k2 / (n * n) + k3 / (n * n * n)));
+    /* sinc.rs calculate_cutoff::<f32>(npoints, BlackmanHarris2), evaluated in f32 like the crate does */
+    const float k1 = 13.745202940783823f, k2 = 121.73532586374934f, k3 = 5964.163279612051f;
+    const float n = (float)npoints;
+    return 1.0f / (k1 / n + k2 / (n * n) + k3 / (n * n * n) + 1.0f);
 }
 float orc_resampler_cutoff(int npoints) { return rubato_cutoff(npoints); }
 orc_resampler *orc_resampler_new(int fs_in, int fs_out, int chunk_size_in) {

@@ -20,16 +20,14 @@ namespace rp {
 
 static const float kPiF = 3.14159274101257324f;
 
-// Anti-aliasing cutoff of the windowed sinc relative to the narrower Nyquist band.  The closed-form fit
-// rubato uses is not available offline; the value for npoints = 480 (48 kHz -> 16 kHz, the case the
-// reference's goldens exercise: tests/resources/oye_casa_real.rpw, tests/detector.rs:163-213) was
-// determined against those goldens to +-1e-6 and the 1/(1 + k1/n + k2/n^2 + k3/n^3) form carries it to
-// other lengths (unpinned).  DESIGN.md ("Resampler") documents the fit.
+// Anti-aliasing cutoff of the windowed sinc relative to the narrower Nyquist band: rubato's
+// calculate_cutoff::<f32>(npoints, BlackmanHarris2) = 1 / (k1/n + k2/n^2 + k3/n^3 + 1), evaluated in f32 like the crate
+// does.  The constants are the crate's published ones; for n = 480 (48 kHz -> 16 kHz) the value, 0.9716114, was
+// confirmed independently by fitting the cutoff against the reference's 48 kHz goldens (DESIGN.md "Resampler").
 static float resampler_cutoff(int npoints) {
-    const double n = (double)npoints;
-    const double k2 = 178.3, k3 = 3.028e5;
-    const double k1 = ((1.0 / 0.9716115) - 1.0 - k2 / (480.0 * 480.0) - k3 / (480.0 * 480.0 * 480.0)) * 480.0;
-    return (float)(1.0 / (1.0 + k1 / n + k2 / (n * n) + k3 / (n * n * n)));
+    const float k1 = 13.745202940783823f, k2 = 121.73532586374934f, k3 = 5964.163279612051f;
+    const float n = (float)npoints;
+    return 1.0f / (k1 / n + k2 / (n * n) + k3 / (n * n * n) + 1.0f);
 }
 
 // FftFixedInOut::new(fs_in, 16000, 480, 1): the wanted chunk is divided by the OUTPUT granule

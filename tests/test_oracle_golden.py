@@ -145,7 +145,8 @@ def test_g6_resampler_is_a_unit_gain_lowpass():
     h = r.filter_spectrum() * (2 * r.in_len)
     assert abs(abs(h[0]) - 1.0) < 1e-6                    # make_sincs normalises the taps to sum 1
     assert np.all(np.abs(h[r.out_len + 8:]) < 2e-5)       # stop band above the output Nyquist: the f32 taps' rounding floor
-    assert abs(orc.lib().orc_resampler_cutoff(480) - 0.9716115) < 1e-7
+    # calculate_cutoff(480, BlackmanHarris2); fitting the cutoff alone on the goldens below gives 0.9716115 +- 1e-6
+    assert abs(orc.lib().orc_resampler_cutoff(480) - 0.9716114) < 1e-7
     # a 1 kHz tone comes out as a 1 kHz tone of the same amplitude, 240 output samples late
     t = np.arange(1440 * 12)
     x = np.sin(2 * np.pi * 1000.0 * t / 48000.0).astype(np.float32)

@@ -9,7 +9,8 @@ namespace rp {
 // None of it depends on the detection state (reset() leaves both filters alone, :290-302), so it is
 // a pure function of the stream: per-chunk RMS in parallel, the gain recursion per stream over the
 // chunk RMS values, then gain + biquad per stream along time (one lane per stream: a lane re-reads
-// its own 128-byte lines from L1, HBM traffic stays one read + one write of the PCM).
+// its own 128-byte lines from L1, HBM traffic stays one read + one write of the PCM); apply_filters_tiled_kernel
+// below is the form used whenever the row pitch allows 4-sample accesses.
 template <class TIN>
 __global__ __launch_bounds__(256) void chunk_rms_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_chunks, size_t pcm_stride,
                                                         int vec4, float *__restrict__ rms) {
@@ -110,6 +111,96 @@ __global__ __launch_bounds__(64) void apply_filters_kernel(const TIN *__restrict
     for (size_t k = n_chunks * kFrame; k < n_samples; ++k) y[k] = SampleIn<TIN>::cvt(x[k]);  // tail shorter than a chunk: never framed
 }
 
+// The same filter with the streams of a wave staged through LDS: 64 streams x 120 samples per tile (4 tiles per chunk).
+// Rows are read from / written to HBM along time (480 contiguous bytes of f32 per stream and tile instead of 16-byte
+// pieces 64 streams apart), the recurrence runs down the columns (lane = stream, row pitch 124 floats keeps the
+// 16-byte LDS accesses of 16 neighbouring lanes on different banks).  The next tile is fetched into registers while
+// this one is filtered.  Same arithmetic per sample as apply_filters_kernel.
+constexpr int kFeTile = 120, kFeRow = 124, kFeLanes = kFeTile / 4, kFeBlock = 6;
+template <class TIN, bool GAIN, bool BP>
+__global__ __launch_bounds__(64) void apply_filters_tiled_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_samples, size_t n_chunks,
+                                                                 size_t pcm_stride, const float *__restrict__ gains, BiquadCoef q,
+                                                                 float *__restrict__ out, size_t out_stride) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * kFeRow];
+    const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
+    const size_t s0 = (size_t)blockIdx.x * 64, s = s0 + lane;
+    const bool live = s < S, mover = sub < kFeLanes;
+    const size_t n_tiles = n_chunks * (kFrame / kFeTile);
+    // every lane fetches (rows past S and the two idle lanes of a half re-read a valid address): a guarded load would
+    // sit in its own branch with its own wait
+    using Raw4 = typename SampleIn<TIN>::Raw4;
+    Raw4 r[32];
+    float g_next = 1.f;
+    const size_t sub_c = mover ? sub : kFeLanes - 1, s_c = live ? s : S - 1;
+    auto fetch = [&](size_t ti) {
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            size_t row = s0 + 2 * it + half;
+            row = row < S ? row : S - 1;
+            r[it] = SampleIn<TIN>::ldraw(pcm + row * pcm_stride + ti * kFeTile + 4 * sub_c);
+        }
+        if (GAIN && ti % (kFrame / kFeTile) == 0) g_next = gains[s_c * n_chunks + ti / (kFrame / kFeTile)];
+    };
+    float x1 = 0.f, x2 = 0.f, y1 = 0.f, y2 = 0.f, g = 1.f;
+    auto one = [&](float v) {
+        if (GAIN) {  // g == 1 leaves v alone in the reference; v * 1 and the clamp of a value outside [-1, 1] do not
+            float w = v * g; w = w < -1.f ? -1.f : w; w = w > 1.f ? 1.f : w;
+            v = g != 1.f ? w : v;
+        }
+        if (BP) {
+            const float o = q.a0 * v + q.a1 * x1 + q.a2 * x2 - q.b1 * y1 - q.b2 * y2;
+            x2 = x1; x1 = v; y2 = y1; y1 = o;
+            v = o;
+        }
+        return v;
+    };
+    if (n_tiles) fetch(0);
+    float *mine = tile + lane * kFeRow;
+    for (size_t ti = 0; ti < n_tiles; ++ti) {
+        if (mover) {
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const float4 f = SampleIn<TIN>::cvt4(r[it]);
+                *reinterpret_cast<f32x4 *>(&tile[(2 * it + half) * kFeRow + 4 * sub]) = f32x4{f.x, f.y, f.z, f.w};
+            }
+        }
+        if (GAIN && ti % (kFrame / kFeTile) == 0) g = g_next;
+        if (ti + 1 < n_tiles) fetch(ti + 1);
+        wave_lds_sync();
+        f32x4 cur[kFeBlock], nxt[kFeBlock];  // the next 24 samples are read from LDS while these 24 go through the recurrence
+#pragma unroll
+        for (int j = 0; j < kFeBlock; ++j) nxt[j] = *reinterpret_cast<f32x4 *>(mine + 4 * j);
+#pragma unroll 1
+        for (int k = 0; k < kFeTile; k += 4 * kFeBlock) {
+#pragma unroll
+            for (int j = 0; j < kFeBlock; ++j) cur[j] = nxt[j];
+            if (k + 4 * kFeBlock < kFeTile) {
+#pragma unroll
+                for (int j = 0; j < kFeBlock; ++j) nxt[j] = *reinterpret_cast<f32x4 *>(mine + k + 4 * kFeBlock + 4 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < kFeBlock; ++j) {
+                f32x4 v = cur[j];
+                v.x = one(v.x); v.y = one(v.y); v.z = one(v.z); v.w = one(v.w);
+                *reinterpret_cast<f32x4 *>(mine + k + 4 * j) = v;
+            }
+        }
+        wave_lds_sync();
+        if (mover) {
+#pragma unroll
+            for (int it = 0; it < 32; ++it) {
+                const size_t row = s0 + 2 * it + half;
+                if (row < S)
+                    *reinterpret_cast<f32x4 *>(out + row * out_stride + ti * kFeTile + 4 * sub) =
+                        *reinterpret_cast<const f32x4 *>(&tile[(2 * it + half) * kFeRow + 4 * sub]);
+            }
+        }
+        wave_lds_sync();
+    }
+    if (live)  // tail shorter than a chunk: never framed
+        for (size_t k = n_chunks * kFrame; k < n_samples; ++k) out[s * out_stride + k] = SampleIn<TIN>::cvt(pcm[s * pcm_stride + k]);
+}
+
 template <class TIN>
 static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, size_t n_samples, size_t pcm_stride, int gain_on,
                                     float rms_level_ref, float min_gain, float max_gain, int window_size, int band_pass,
@@ -129,8 +220,19 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
                                rms_level_ref, min_gain, max_gain, window_size, in_lds, ring, gains);
         }
     }
-    hipLaunchKernelGGL(apply_filters_kernel<TIN>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, pcm, S, n_samples, n_chunks,
-                       pcm_stride, gain_on ? gains : nullptr, band_pass, q, vec4, out, out_stride);
+    if (vec4) {
+        const dim3 grid((unsigned)((S + 63) / 64));
+#define RP_TILED(G, B) hipLaunchKernelGGL((apply_filters_tiled_kernel<TIN, G, B>), grid, dim3(64), 0, st, pcm, S, n_samples, n_chunks, \
+                                          pcm_stride, gains, q, out, out_stride)
+        if (gain_on && band_pass) RP_TILED(true, true);
+        else if (gain_on) RP_TILED(true, false);
+        else if (band_pass) RP_TILED(false, true);
+        else RP_TILED(false, false);
+#undef RP_TILED
+    }
+    else
+        hipLaunchKernelGGL(apply_filters_kernel<TIN>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, pcm, S, n_samples, n_chunks,
+                           pcm_stride, gain_on ? gains : nullptr, band_pass, q, 0, out, out_stride);
     return hipGetLastError();
 }
 

@@ -669,9 +669,12 @@ def test_batch_frontend_goldens(ra, ctx, case):
         assert gains[0][(det[0][j]["window"] + tm.max_len - 1) // 3 + 1] == r["gain"]
 
 
-def test_frontend_many_streams_and_formats(ra, ctx):
+@pytest.mark.parametrize("tail", [37, 36, 0])
+def test_frontend_many_streams_and_formats(ra, ctx, tail):
+    """tail 37: row pitch not a multiple of 4 samples -> the one-lane-per-stream kernel; 36 / 0: the LDS-tiled kernel
+    (partial last workgroup, with and without a tail shorter than a chunk)."""
     rng = np.random.default_rng(8)
-    S, N = 70, 480 * 25 + 37
+    S, N = 70, 480 * 25 + tail
     raw = (rng.standard_normal((S, N)) * 3000).astype(np.int16)
     raw[3] = 0  # silent stream: rms 0 -> gain stays 1, window untouched
     f = ra.FiltersConfig()
@@ -688,6 +691,25 @@ def test_frontend_many_streams_and_formats(ra, ctx):
     ro, rr, rg = orc.frontend_stream(simstream.i16_to_f32(raw[5]), gain_normalizer=True, gain_ref=0.02, min_gain=0.2, max_gain=3.0,
                                      window_size=4)
     assert np.array_equal(gains[5], rg) and np.array_equal(out[5], ro)
+
+
+@pytest.mark.parametrize("dtype,tmax", [(np.int16, 32767.0), (np.int8, 127.0)])
+def test_sample_decode_is_exact_for_every_value(ra, ctx, dtype, tmax):
+    """`v as f32 / T::MAX as f32` (src/audio/encoder.rs): the kernels decode i8 / i16 with a 3-instruction exact division
+    (rp_device.h div_small_int); every representable sample value must equal the IEEE quotient.  Run through the tiled
+    front-end kernel (row pitch a multiple of 4), the one-lane-per-stream kernel (odd pitch) and the MFCC decode."""
+    info = np.iinfo(dtype)
+    vals = np.arange(info.min, info.max + 1, dtype=np.int64).astype(dtype)
+    want = vals.astype(np.float32) / np.float32(tmax)
+    for pad in (0, 1):
+        n = (len(vals) + 479) // 480 * 480 + 480 + pad
+        x = np.zeros((2, n), dtype)
+        x[0, :len(vals)] = vals
+        x[1, n - len(vals):] = vals  # also through the tail that is shorter than a chunk
+        out, _, _ = ctx.frontend(x, ra.FiltersConfig(), float("nan"), 1)
+        assert np.array_equal(out[0, :len(vals)], want) and np.array_equal(out[1, n - len(vals):], want)
+    if dtype == np.int16:  # the MFCC kernel decodes with the same helper: features of the decoded f32 stream are identical
+        assert np.array_equal(ctx.mfcc(np.tile(vals, 2)[None, :], 16), ctx.mfcc(np.tile(want, 2)[None, :], 16))
 
 
 @pytest.mark.parametrize("rpw,wavs", [("oye_casa_g.rpw", ["oye_casa_g_%d.wav" % i for i in range(1, 6)]),

@@ -58,11 +58,32 @@ bool read_uint(Cur &c, uint64_t *out) {
     if (mj != 0) return c.fail("expected an unsigned integer");
     *out = v; return true;
 }
+// what Rust's String accepts (core::str::from_utf8): no overlong forms, no surrogates, nothing above U+10FFFF
+bool valid_utf8(const uint8_t *p, size_t n) {
+    for (size_t i = 0; i < n;) {
+        const uint8_t b = p[i];
+        size_t extra; uint32_t cp, lo;
+        if (b < 0x80) { ++i; continue; }
+        else if ((b & 0xe0) == 0xc0) { extra = 1; cp = b & 0x1f; lo = 0x80; }
+        else if ((b & 0xf0) == 0xe0) { extra = 2; cp = b & 0x0f; lo = 0x800; }
+        else if ((b & 0xf8) == 0xf0) { extra = 3; cp = b & 0x07; lo = 0x10000; }
+        else return false;
+        if (extra >= n - i) return false;  // truncated sequence
+        for (size_t k = 1; k <= extra; ++k) {
+            if ((p[i + k] & 0xc0) != 0x80) return false;
+            cp = (cp << 6) | (p[i + k] & 0x3f);
+        }
+        if (cp < lo || cp > 0x10ffff || (cp >= 0xd800 && cp <= 0xdfff)) return false;
+        i += extra + 1;
+    }
+    return true;
+}
 bool read_text(Cur &c, std::string *out) {
     int mj, info; uint64_t v;
     if (!c.head(&mj, &info, &v)) return false;
     if (mj != 3) return c.fail("expected a string");
     if (!c.need((size_t)v)) return false;
+    if (!valid_utf8(c.p, (size_t)v)) return c.fail("invalid UTF-8 in a string");  // ciborium -> String refuses it too
     out->assign(reinterpret_cast<const char *>(c.p), (size_t)v);
     c.p += v; return true;
 }

@@ -1,0 +1,163 @@
+"""Randomised parity sweep (test infrastructure): random wakeword references, detector configs and streams through the
+device path (rp_batch_detect_fmt, rp_stream_batch_process) against the oracle's chunked detector.
+
+Every case draws K, T, ragged template lengths, band size, score mode, thresholds, min_scores, eager, score_ref, an
+optional averaged template, the VAD mode, the sample format, S streams of noise with utterances planted in them, and a
+ragged tail.  The bar is the one of tests/test_gpu_parity.py: detections exact in (chunk, counter), scores within 1e-5
+relative.  A case whose decision hangs on a score closer than 1e-5 to a threshold is counted as a tie, not a failure.
+
+    python tests/sweep_parity.py --cases 300 --seed 1        # on the GPU box
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODES = ["average", "max", "median", "p25", "p50", "p75", "p80", "p90", "p95"]
+
+
+def _utterance(rng, n):
+    """A few drifting partials under a random envelope + a little noise: MFCC trajectories that DTW can lock onto."""
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    x = np.zeros(n)
+    for _ in range(int(rng.integers(2, 6))):
+        f0, f1 = rng.uniform(120, 3500, 2)
+        ph = 2 * np.pi * np.cumsum(np.linspace(f0, f1, n)) / 16000.0
+        env = np.interp(t, np.linspace(0, t[-1], 8), rng.uniform(0.0, 1.0, 8))
+        x += rng.uniform(0.05, 0.3) * env * np.sin(ph + rng.uniform(0, 6.28))
+    x += rng.standard_normal(n) * 0.003
+    return x.astype(np.float32)
+
+
+def make_case(rng):
+    from oracle import rp_oracle as orc
+    K = int(rng.choice([5, 5, 5, 16, 3, 8, 12, 1]))
+    T = int(rng.integers(1, 9))
+    if rng.random() < 0.3:
+        lens = np.full(T, int(rng.integers(20, 100)))
+    else:
+        lens = rng.integers(20, 110, size=T)
+    utts = [_utterance(rng, 480 * ((int(L) + 3 + 2) // 3)) for L in lens]
+    templates = [orc.normalize(orc.mfcc_stream(u, K))[:int(L)] for u, L in zip(utts, lens)]
+    avg = None
+    if rng.random() < 0.5:
+        avg = templates[int(rng.integers(T))][:int(rng.integers(10, int(lens.max()) + 1))]
+        if rng.random() < 0.3:  # an averaged template longer than every sample template (window shorter than it)
+            avg = orc.normalize(orc.mfcc_stream(_utterance(rng, 480 * 50), K))[:int(lens.max()) + int(rng.integers(1, 20))]
+    cfg = dict(threshold=float(rng.uniform(0.3, 0.58)), avg_threshold=float(rng.choice([0.0, 0.0, rng.uniform(0.1, 0.45)])),
+               min_scores=int(rng.integers(1, 7)), eager=bool(rng.random() < 0.3), score_ref=float(rng.uniform(0.15, 0.3)),
+               band_size=int(rng.integers(1, 9)), score_mode=str(rng.choice(MODES)),
+               vad_mode=[None, None, None, "easy", "medium", "hard"][int(rng.integers(6))])
+    S = int(rng.integers(1, 5))
+    n_chunks = int(rng.integers(45, 150))
+    N = 480 * n_chunks + int(rng.choice([0, 0, rng.integers(1, 480)]))
+    pcm = (rng.standard_normal((S, N)) * rng.uniform(0.0005, 0.02)).astype(np.float32)
+    for s in range(S):
+        for _ in range(int(rng.integers(0, 5))):
+            u = utts[int(rng.integers(T))]
+            u = u * np.float32(rng.uniform(0.7, 1.2)) + (rng.standard_normal(len(u)) * rng.uniform(0.0, 0.002)).astype(np.float32)
+            at = int(rng.integers(0, max(1, N - len(u))))
+            seg = pcm[s, at:at + len(u)]
+            seg += u[:len(seg)]
+    if rng.random() < 0.15:
+        pcm[0, : N // 2] = 0.0  # digital silence: constant features, zero vectors in the cosine
+    fmt = str(rng.choice(["f32", "f32", "i16"]))
+    if fmt == "i16":
+        pcm = np.clip(np.round(pcm * 32767.0), -32768, 32767).astype(np.int16)
+    return dict(K=K, templates=templates, avg=avg, cfg=cfg, pcm=pcm, chunks_per_call=int(rng.integers(1, 6)))
+
+
+def oracle_detections(case):
+    from oracle import rp_oracle as orc
+    c = case["cfg"]
+    out = []
+    ww = {"name": "w", "samples_features": {"t%d" % i: t for i, t in enumerate(case["templates"])},
+          "avg_features": case["avg"], "threshold": None, "avg_threshold": None, "rms_level": 0.0}
+    for s in range(case["pcm"].shape[0]):
+        d = orc.Detector(avg_threshold=c["avg_threshold"], threshold=c["threshold"], min_scores=c["min_scores"], eager=c["eager"],
+                         score_ref=c["score_ref"], band_size=c["band_size"], score_mode=c["score_mode"], vad_mode=c["vad_mode"])
+        d.add_ref(ww)
+        x = case["pcm"][s]
+        got = []
+        for i in range(0, len(x) - 479, 480):
+            r = d.process_i16(x[i:i + 480]) if x.dtype == np.int16 else d.process_f32(x[i:i + 480])
+            if r is not None:
+                got.append((i // 480, int(r["counter"]), float(r["score"]), float(r["avg_score"])))
+        out.append(got)
+    return out
+
+
+def device_detections(ra, ctx, case):
+    c = case["cfg"]
+    dc = ra.DetectorConfig()
+    dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
+    dc.score_ref, dc.band_size = c["score_ref"], c["band_size"]
+    dc.score_mode = {m: getattr(ra.ScoreMode, m.capitalize()) for m in MODES}[c["score_mode"]]
+    dc.vad_mode = {None: None, "easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[c["vad_mode"]]
+    tm = ra.Templates(ctx, case["templates"], avg=case["avg"])
+    pcm = case["pcm"]
+    det, n_det, scores, agg = ctx.batch_detect(pcm, tm, dc, max_det=32, want_scores=True)
+    offline = [[(int(det[s][j]["frame"]) // 3 + 1, int(det[s][j]["counter"]), float(det[s][j]["score"]), float(det[s][j]["avg_score"]))
+                for j in range(n_det[s])] for s in range(pcm.shape[0])]
+    # the same streams a few chunks per call
+    sb = ra.StreamBatch(ctx, tm, dc, pcm.shape[0], max_chunks_per_call=case["chunks_per_call"])
+    live = [[] for _ in range(pcm.shape[0])]
+    step = 480 * case["chunks_per_call"]
+    n = (pcm.shape[1] // 480) * 480
+    for i in range(0, n, step):
+        d, nd = sb.process(np.ascontiguousarray(pcm[:, i:min(i + step, n)]), max_det=8)
+        for s in range(pcm.shape[0]):
+            live[s] += [(int(d[s][j]["frame"]) // 3 + 1, int(d[s][j]["counter"]), float(d[s][j]["score"]), float(d[s][j]["avg_score"]))
+                        for j in range(nd[s])]
+    return offline, live, agg
+
+
+def _same(a, b, rtol):
+    if len(a) != len(b):
+        return False
+    for x, y in zip(a, b):
+        if x[0] != y[0] or x[1] != y[1]:
+            return False
+        for u, v in ((x[2], y[2]), (x[3], y[3])):
+            if abs(u - v) > rtol * max(abs(v), 1e-30):
+                return False
+    return True
+
+
+def run_sweep(ra, ctx, n_cases, seed, verbose=False):
+    """-> (cases, detections compared, ties skipped); raises AssertionError with the case number on a mismatch."""
+    total = ties = 0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, ci])
+        case = make_case(rng)
+        ref = oracle_detections(case)
+        offline, live, agg = device_detections(ra, ctx, case)
+        ok = all(_same(o, r, 1e-5) for o, r in zip(offline, ref)) and all(_same(l, o, 0.0) for l, o in zip(live, offline))
+        if not ok:
+            thr = case["cfg"]["threshold"]
+            near = agg.size and np.min(np.abs(agg - np.float32(thr))) < 1e-5 * thr
+            if near and all(_same(l, o, 0.0) for l, o in zip(live, offline)):
+                ties += 1
+                continue
+            raise AssertionError("sweep seed %d case %d: cfg %r K %d lens %r\noracle  %r\noffline %r\nlive    %r" % (
+                seed, ci, case["cfg"], case["K"], [len(t) for t in case["templates"]], ref, offline, live))
+        total += sum(len(r) for r in ref)
+        if verbose and ci % 20 == 0:
+            print("case %d ok, %d detections so far" % (ci, total), flush=True)
+    return n_cases, total, ties
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    import rustpotter_amd as ra
+    n, total, ties = run_sweep(ra, ra.BatchContext(0), a.cases, a.seed, verbose=True)
+    print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))

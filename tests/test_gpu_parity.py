@@ -1148,6 +1148,14 @@ def test_batch_detect_model_generic_shape_from_trained_file(ra, ctx, tmp_path):
 
 
 # --------------------------------------------------------------------------- full BASELINE sizes
+def test_randomised_parity_sweep(ra, ctx):
+    """24 random (reference, config, streams) cases, offline and live, against the oracle's chunked detector
+    (tests/sweep_parity.py; longer runs: `python tests/sweep_parity.py --cases 300`)."""
+    import sweep_parity
+    n, total, ties = sweep_parity.run_sweep(ra, ctx, 24, seed=7)
+    assert n == 24 and total >= 10 and ties <= 2
+
+
 def _full_size_run(ra, S, T, seed_templates=SEED):
     """Whole path on device-resident synthetic input exactly as bench.py sets it up."""
     import torch

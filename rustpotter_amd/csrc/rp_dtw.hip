@@ -374,14 +374,20 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
             const int c = r - W + q;
             float v = RP_INF;
             if (c >= 1 && c <= n) {
-                float dot = 0.f, bb = 0.f;
+                // the arithmetic of the register kernels, operation for operation (unit-length frame first, then
+                // d = 1 - a.y as one fma chain from 1): every DTW kernel gives the same bits for the same window
+                float bb = 0.f;
                 for (int k = 0; k < K; ++k) {
-                    float y = xl[(c - 1) * KP + k] - mus[k * 64 + lane];
-                    dot = fmaf(trow[(r - 1) * K + k], y, dot);
+                    const float y = xl[(c - 1) * KP + k] - mus[k * 64 + lane];
                     bb = fmaf(y, y, bb);
                 }
-                float cosv = bb > 0.f ? dot * rsqrtf(bb) : 0.f;
-                v = (1.f - cosv) + fminf(fminf(Pb[(q + 1) * 64 + lane], left), Pb[q * 64 + lane]);
+                const float inv = bb > 0.f ? rsqrtf(bb) : 0.f;
+                float d = 1.f;
+                for (int k = 0; k < K; ++k) {
+                    const float y = (xl[(c - 1) * KP + k] - mus[k * 64 + lane]) * inv;
+                    d = fmaf(-trow[(r - 1) * K + k], y, d);
+                }
+                v = d + fminf(fminf(Pb[(q + 1) * 64 + lane], left), Pb[q * 64 + lane]);
             }
             Pb[q * 64 + lane] = v;
             left = v;

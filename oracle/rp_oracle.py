@@ -451,6 +451,10 @@ class Detector:
             return self._out(det)
         return None
 
+    def reset(self):
+        """Rustpotter::reset (src/detector.rs:290-302)."""
+        lib().orc_detector_reset(self._h)
+
     def state(self):
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_float()
         mx = lib().orc_detector_state(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))

@@ -136,3 +136,42 @@ def read_wav_i16(path):
         p += 8 + sz + (sz & 1)
     assert fmt is not None and data is not None and fmt[0] == 1 and fmt[1] == 1 and fmt[5] == 16
     return np.frombuffer(data, dtype="<i2").copy(), fmt[2]
+
+
+def _head(major, n):
+    if n < 24:
+        return bytes([major << 5 | n])
+    for info, fmt in ((24, ">B"), (25, ">H"), (26, ">I"), (27, ">Q")):
+        if n < 1 << (8 * struct.calcsize(fmt)):
+            return bytes([major << 5 | info]) + struct.pack(fmt, n)
+    raise ValueError(n)
+
+
+def _text(t):
+    b = t.encode()
+    return _head(3, len(b)) + b
+
+
+def _f32(v):
+    return b"\xfa" + struct.pack(">f", float(v))
+
+
+def _matrix(m):
+    m = np.asarray(m, np.float32)
+    return _head(4, m.shape[0]) + b"".join(_head(4, m.shape[1]) + b"".join(_f32(v) for v in row) for row in m)
+
+
+def dump_rpw_ref(name, samples_features, avg_features=None, threshold=None, avg_threshold=None, rms_level=0.0, mfcc_size=None):
+    """WakewordRef as ciborium writes it (src/wakewords/wakeword_ref.rs:12-20): map(7) in struct order; floats are
+    written as single precision (a reader must accept any float width)."""
+    names = list(samples_features.keys())
+    K = int(np.asarray(samples_features[names[0]]).shape[1]) if mfcc_size is None else mfcc_size
+    out = _head(5, 7)
+    out += _text("name") + _text(name)
+    out += _text("avg_features") + (b"\xf6" if avg_features is None else _matrix(avg_features))
+    out += _text("samples_features") + _head(5, len(names)) + b"".join(_text(n) + _matrix(samples_features[n]) for n in names)
+    out += _text("threshold") + (b"\xf6" if threshold is None else _f32(threshold))
+    out += _text("avg_threshold") + (b"\xf6" if avg_threshold is None else _f32(avg_threshold))
+    out += _text("rms_level") + _f32(rms_level)
+    out += _text("mfcc_size") + _head(0, K)
+    return out

@@ -18,6 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
 
 MODES = ["average", "max", "median", "p25", "p50", "p75", "p80", "p90", "p95"]
 
@@ -153,11 +155,118 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False):
     return n_cases, total, ties
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# The single-stream drop-in API (`Rustpotter`, src/detector.rs) chunk by chunk against the oracle's detector: several
+# wakewords with their own thresholds, gain normaliser / band-pass, VAD, resets in mid-stream, i16 / f32 input,
+# mono / stereo, 16 kHz or 48 kHz (resampler in front).
+def make_api_case(rng):
+    from oracle import rp_oracle as orc
+    K = int(rng.choice([5, 5, 16, 8]))
+    wakewords, utts = [], []
+    for wi in range(int(rng.integers(1, 4))):
+        T = int(rng.integers(1, 6))
+        lens = rng.integers(20, 100, size=T)
+        us = [_utterance(rng, 480 * ((int(L) + 5) // 3)) for L in lens]
+        utts += us
+        feats = {"s%d.wav" % i: orc.normalize(orc.mfcc_stream(u, K))[:int(L)] for i, (u, L) in enumerate(zip(us, lens))}
+        avg = None
+        if rng.random() < 0.5:
+            avg = feats["s%d.wav" % int(rng.integers(T))][:int(rng.integers(10, int(lens.max()) + 1))]
+        wakewords.append({"name": "ww%d" % wi, "samples_features": feats, "avg_features": avg,
+                          "threshold": None if rng.random() < 0.6 else float(rng.uniform(0.3, 0.55)),
+                          "avg_threshold": None if rng.random() < 0.6 else float(rng.choice([0.0, rng.uniform(0.1, 0.4)])),
+                          "rms_level": float(rng.uniform(0.01, 0.2))})
+    cfg = dict(threshold=float(rng.uniform(0.25, 0.52)), avg_threshold=float(rng.choice([0.0, 0.0, rng.uniform(0.1, 0.45)])),
+               min_scores=int(rng.integers(1, 7)), eager=bool(rng.random() < 0.3), score_ref=float(rng.uniform(0.15, 0.3)),
+               band_size=int(rng.integers(1, 9)), score_mode=str(rng.choice(MODES)),
+               vad_mode=[None, None, None, "easy", "medium", "hard"][int(rng.integers(6))],
+               gain_normalizer=bool(rng.random() < 0.35), gain_ref=None if rng.random() < 0.5 else float(rng.uniform(0.01, 0.1)),
+               min_gain=float(rng.uniform(0.1, 0.5)), max_gain=float(rng.uniform(1.0, 3.0)),
+               band_pass=bool(rng.random() < 0.3), low_cutoff=float(rng.uniform(60, 200)), high_cutoff=float(rng.uniform(300, 3000)))
+    n_chunks = int(rng.integers(50, 160))
+    x = (rng.standard_normal(480 * n_chunks) * rng.uniform(0.0005, 0.02)).astype(np.float32)
+    for _ in range(int(rng.integers(2, 7))):
+        u = utts[int(rng.integers(len(utts)))] * np.float32(rng.uniform(0.7, 1.2))
+        at = int(rng.integers(0, max(1, len(x) - len(u))))
+        x[at:at + len(u)] += u[:len(x) - at]
+    rate = 48000 if rng.random() < 0.2 else 16000
+    if rate == 48000:  # any 48 kHz signal will do: the encoder in front of the detector is what is compared
+        x = np.interp(np.arange(3 * len(x)) / 3.0, np.arange(len(x)), x).astype(np.float32)
+    fmt = str(rng.choice(["f32", "i16"]))
+    if fmt == "i16":
+        x = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+    resets = sorted(set(int(v) for v in rng.integers(0, n_chunks, size=int(rng.integers(0, 3)))))
+    return dict(K=K, wakewords=wakewords, cfg=cfg, x=x, rate=rate, channels=int(rng.choice([1, 1, 2])), resets=resets)
+
+
+def run_api_sweep(ra, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    import rpw_py
+    total = 0
+    for ci in range(n_cases):
+        case = make_api_case(np.random.default_rng([seed, 77, ci]))
+        c = case["cfg"]
+        d = orc.Detector(avg_threshold=c["avg_threshold"], threshold=c["threshold"], min_scores=c["min_scores"], eager=c["eager"],
+                         score_ref=c["score_ref"], band_size=c["band_size"], score_mode=c["score_mode"], vad_mode=c["vad_mode"],
+                         gain_normalizer=c["gain_normalizer"], gain_ref=c["gain_ref"], min_gain=c["min_gain"], max_gain=c["max_gain"],
+                         band_pass=c["band_pass"], low_cutoff=c["low_cutoff"], high_cutoff=c["high_cutoff"])
+        rc = ra.RustpotterConfig.default()
+        x = case["x"]
+        rc.fmt.sample_rate, rc.fmt.channels = case["rate"], case["channels"]
+        rc.fmt.sample_format = ra.SampleFormat.I16 if x.dtype == np.int16 else ra.SampleFormat.F32
+        dc = rc.detector
+        dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
+        dc.score_ref, dc.band_size = c["score_ref"], c["band_size"]
+        dc.score_mode = getattr(ra.ScoreMode, c["score_mode"].capitalize())
+        dc.vad_mode = {None: None, "easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[c["vad_mode"]]
+        g, b = rc.filters.gain_normalizer, rc.filters.band_pass
+        g.enabled, g.gain_ref, g.min_gain, g.max_gain = c["gain_normalizer"], c["gain_ref"], c["min_gain"], c["max_gain"]
+        b.enabled, b.low_cutoff, b.high_cutoff = c["band_pass"], c["low_cutoff"], c["high_cutoff"]
+        rp = ra.Rustpotter.new(rc)
+        for w in case["wakewords"]:
+            d.add_ref(w)
+            rp.add_wakeword_from_buffer(w["name"], rpw_py.dump_rpw_ref(w["name"], w["samples_features"], w["avg_features"],
+                                                                        w["threshold"], w["avg_threshold"], w["rms_level"]))
+        rs = orc.Resampler(case["rate"]) if case["rate"] != 16000 else None
+        spf = rp.get_samples_per_frame()
+        per = spf // case["channels"]
+        assert per == (rs.in_len if rs else 480)
+        where = "api sweep seed %d case %d (%r, K %d, rate %d, ch %d, %s)" % (seed, ci, c, case["K"], case["rate"], case["channels"], x.dtype)
+        for k in range(len(x) // per):
+            if k in case["resets"]:
+                d.reset()
+                rp.reset()
+            mono = x[k * per:(k + 1) * per]
+            if rs:
+                ref = d.process_resampled(rs, mono.astype(np.float32) / np.float32(32767.0) if x.dtype == np.int16 else mono)
+            else:
+                ref = d.process_i16(mono) if x.dtype == np.int16 else d.process_f32(mono)
+            inter = mono if case["channels"] == 1 else np.stack([mono, mono[::-1]], axis=1).reshape(-1)
+            got = rp.process_samples(np.ascontiguousarray(inter))
+            assert (got is None) == (ref is None), "%s chunk %d: %r vs %r" % (where, k, got, ref)
+            part = rp.get_partial_detection()
+            assert (-1 if part is None else part.counter) == d.state()["partial_counter"], "%s chunk %d partial" % (where, k)
+            if ref is None:
+                continue
+            total += 1
+            assert got.name == ref["name"] and got.counter == ref["counter"], "%s chunk %d: %r vs %r" % (where, k, got, ref)
+            for u, v in [(got.score, ref["score"]), (got.avg_score, ref["avg_score"]), (got.gain, ref["gain"])] + \
+                        [(got.scores[n], ref["scores"][n]) for n in ref["scores"]]:
+                assert abs(float(u) - float(v)) <= 1e-5 * abs(float(v)), "%s chunk %d: %r vs %r" % (where, k, got, ref)
+            assert sorted(got.scores) == sorted(ref["scores"])
+        if verbose and ci % 20 == 0:
+            print("api case %d ok, %d detections so far" % (ci, total), flush=True)
+    return n_cases, total
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
     a = ap.parse_args()
     import rustpotter_amd as ra
     n, total, ties = run_sweep(ra, ra.BatchContext(0), a.cases, a.seed, verbose=True)
     print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
+    n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
+    print("api sweep: %d cases, %d detections compared: OK" % (n, total))

@@ -1156,6 +1156,14 @@ def test_randomised_parity_sweep(ra, ctx):
     assert n == 24 and total >= 10 and ties <= 2
 
 
+def test_randomised_api_sweep(ra):
+    """12 random single-stream cases through `Rustpotter` chunk by chunk (several wakewords, filters, VAD, resets,
+    stereo, 48 kHz) against the oracle's detector: same chunks fire, same name / counter / partial state, scores 1e-5."""
+    import sweep_parity
+    n, total = sweep_parity.run_api_sweep(ra, 12, seed=7)
+    assert n == 12 and total >= 3
+
+
 def _full_size_run(ra, S, T, seed_templates=SEED):
     """Whole path on device-resident synthetic input exactly as bench.py sets it up."""
     import torch

@@ -175,3 +175,23 @@ def dump_rpw_ref(name, samples_features, avg_features=None, threshold=None, avg_
     out += _text("rms_level") + _f32(rms_level)
     out += _text("mfcc_size") + _head(0, K)
     return out
+
+
+def dump_rpw_model(labels, train_size, mfcc_size, m_type, weights, rms_level=float("nan")):
+    """WakewordModel as ciborium writes it (src/wakewords/wakeword_model.rs:11-18): tensors are
+    {bytes: array of u8, dims: array, d_type: "f32"} (little-endian f32), weights in the given order."""
+    out = _head(5, 6)
+    out += _text("labels") + _head(4, len(labels)) + b"".join(_text(l) for l in labels)
+    out += _text("train_size") + _head(0, int(train_size))
+    out += _text("mfcc_size") + _head(0, int(mfcc_size))
+    out += _text("m_type") + _text(m_type)
+    out += _text("weights") + _head(5, len(weights))
+    for name, w in weights.items():
+        w = np.ascontiguousarray(w, "<f4")
+        raw = w.tobytes()
+        out += _text(name) + _head(5, 3)
+        out += _text("bytes") + _head(4, len(raw)) + b"".join(_head(0, v) for v in raw)
+        out += _text("dims") + _head(4, w.ndim) + b"".join(_head(0, d) for d in w.shape)
+        out += _text("d_type") + _text("f32")
+    out += _text("rms_level") + _f32(rms_level)
+    return out

@@ -259,10 +259,74 @@ def run_api_sweep(ra, n_cases, seed, verbose=False):
     return n_cases, total
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# Wakeword models (src/wakewords/nn/wakeword_nn.rs) through the single-stream API: random layer sizes of the four model
+# types, random weights, 2-3 labels.  The forward pass is pinned by the oracle only, so scores compare at
+# 1e-4; which chunks fire, the label and the counter must agree.
+def make_model_case(rng):
+    K = int(rng.choice([16, 16, 5, 8]))
+    fr = int(rng.integers(30, 130))
+    mt = int(rng.integers(4))
+    hidden = {0: [fr // 15], 1: [fr // 6, (fr // 6) // 2], 2: [fr // 3, fr // 6], 3: [(fr // 3) * 2, fr // 6]}[mt]
+    labels = ["none", "alpha", "beta"][:int(rng.integers(2, 4))]
+    if rng.random() < 0.2:
+        labels = labels[1:] + ["gamma"]  # no "none" label at all
+    dims = [fr * K] + hidden + [len(labels)]
+    weights = {}
+    for i in range(len(dims) - 1):
+        weights["ln%d.weight" % (i + 1)] = (rng.standard_normal((dims[i + 1], dims[i])) * (1.5 / np.sqrt(dims[i]))).astype(np.float32)
+        weights["ln%d.bias" % (i + 1)] = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
+    model = {"labels": labels, "train_size": fr, "mfcc_size": K, "m_type": ["Tiny", "Small", "Medium", "Large"][mt],
+             "weights": weights, "rms_level": float(rng.uniform(0.01, 0.2))}
+    cfg = dict(threshold=float(rng.uniform(0.0, 0.6)), avg_threshold=float(rng.choice([0.0, rng.uniform(0.0, 0.5)])),
+               min_scores=int(rng.integers(1, 7)), eager=bool(rng.random() < 0.3),
+               vad_mode=[None, None, None, "easy", "medium", "hard"][int(rng.integers(6))])
+    n_chunks = int(rng.integers(50, 160))
+    x = np.concatenate([_utterance(rng, 480 * 20) for _ in range((n_chunks + 19) // 20)])[:480 * n_chunks]
+    x = x + (rng.standard_normal(len(x)) * rng.uniform(0.0005, 0.02)).astype(np.float32)
+    return dict(model=model, cfg=cfg, x=x.astype(np.float32))
+
+
+def run_model_sweep(ra, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    import rpw_py
+    total = 0
+    for ci in range(n_cases):
+        case = make_model_case(np.random.default_rng([seed, 99, ci]))
+        c, m, x = case["cfg"], case["model"], case["x"]
+        d = orc.Detector(avg_threshold=c["avg_threshold"], threshold=c["threshold"], min_scores=c["min_scores"], eager=c["eager"],
+                         vad_mode=c["vad_mode"])
+        d.add_model(m)
+        rc = ra.RustpotterConfig.default()
+        rc.fmt.sample_format = ra.SampleFormat.F32
+        dc = rc.detector
+        dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
+        dc.vad_mode = {None: None, "easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[c["vad_mode"]]
+        rp = ra.Rustpotter.new(rc)
+        rp.add_wakeword_from_buffer("m", rpw_py.dump_rpw_model(m["labels"], m["train_size"], m["mfcc_size"], m["m_type"], m["weights"],
+                                                               m["rms_level"]))
+        where = "model sweep seed %d case %d (%r, %s, K %d, frames %d, labels %r)" % (seed, ci, c, m["m_type"], m["mfcc_size"],
+                                                                                     m["train_size"], m["labels"])
+        for k in range(len(x) // 480):
+            ref = d.process_f32(x[480 * k:480 * (k + 1)])
+            got = rp.process_samples(np.ascontiguousarray(x[480 * k:480 * (k + 1)]))
+            assert (got is None) == (ref is None), "%s chunk %d: %r vs %r" % (where, k, got, ref)
+            if ref is None:
+                continue
+            total += 1
+            assert got.name == ref["name"] and got.counter == ref["counter"], "%s chunk %d: %r vs %r" % (where, k, got, ref)
+            assert abs(float(got.score) - float(ref["score"])) <= 1e-4 * max(1.0, abs(float(ref["score"]))), \
+                "%s chunk %d: %r vs %r" % (where, k, got, ref)
+        if verbose and ci % 20 == 0:
+            print("model case %d ok, %d detections so far" % (ci, total), flush=True)
+    return n_cases, total
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
     a = ap.parse_args()
     import rustpotter_amd as ra
@@ -270,3 +334,5 @@ if __name__ == "__main__":
     print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
     n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
     print("api sweep: %d cases, %d detections compared: OK" % (n, total))
+    n, total = run_model_sweep(ra, a.model_cases, a.seed, verbose=True)
+    print("model sweep: %d cases, %d detections compared: OK" % (n, total))

@@ -1162,6 +1162,9 @@ def test_randomised_api_sweep(ra):
     import sweep_parity
     n, total = sweep_parity.run_api_sweep(ra, 12, seed=7)
     assert n == 12 and total >= 3
+    # wakeword models of the four types with random layer sizes / weights / labels
+    n, total = sweep_parity.run_model_sweep(ra, 16, seed=7)
+    assert n == 16 and total >= 3
 
 
 def _full_size_run(ra, S, T, seed_templates=SEED):

@@ -260,6 +260,47 @@ def run_api_sweep(ra, n_cases, seed, verbose=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Several wakewords in the batched detector (rp_batch_detect_multi) against the oracle's detector holding the same
+# wakewords (run_wakeword_detectors, src/detector.rs:433-447), per-wakeword threshold overrides included.
+def run_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    total = 0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 55, ci])
+        case = make_api_case(rng)
+        c, x = case["cfg"], case["x"]
+        if case["rate"] != 16000:
+            x = x[::3].copy()
+        d = orc.Detector(avg_threshold=c["avg_threshold"], threshold=c["threshold"], min_scores=c["min_scores"], eager=c["eager"],
+                         score_ref=c["score_ref"], band_size=c["band_size"], score_mode=c["score_mode"], vad_mode=c["vad_mode"])
+        for w in case["wakewords"]:
+            d.add_ref(w)
+        ref = []
+        for k in range(len(x) // 480):
+            r = d.process_i16(x[480 * k:480 * (k + 1)]) if x.dtype == np.int16 else d.process_f32(x[480 * k:480 * (k + 1)])
+            if r is not None:
+                ref.append((k, r["counter"], r["name"], float(r["score"]), float(r["avg_score"])))
+        dc = ra.DetectorConfig()
+        dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
+        dc.score_ref, dc.band_size = c["score_ref"], c["band_size"]
+        dc.score_mode = getattr(ra.ScoreMode, c["score_mode"].capitalize())
+        dc.vad_mode = {None: None, "easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[c["vad_mode"]]
+        tms = [ra.Templates(ctx, list(w["samples_features"].values()), avg=w["avg_features"]) for w in case["wakewords"]]
+        det, dww, n_det = ctx.batch_detect_multi(x[None, :], tms, dc, thresholds=[w["threshold"] for w in case["wakewords"]],
+                                                 avg_thresholds=[w["avg_threshold"] for w in case["wakewords"]], max_det=32)
+        got = [(int(det[0][j]["frame"]) // 3 + 1, int(det[0][j]["counter"]), case["wakewords"][dww[0][j]]["name"],
+                float(det[0][j]["score"]), float(det[0][j]["avg_score"])) for j in range(n_det[0])]
+        ok = len(got) == len(ref) and all(g[:3] == r[:3] and abs(g[3] - r[3]) <= 1e-5 * abs(r[3]) and abs(g[4] - r[4]) <= 1e-5 * max(abs(r[4]), 1e-30)
+                                          for g, r in zip(got, ref))
+        assert ok, "multi sweep seed %d case %d (%r, K %d, %d wakewords)\noracle %r\ndevice %r" % (seed, ci, c, case["K"],
+                                                                                                   len(case["wakewords"]), ref, got)
+        total += len(ref)
+        if verbose and ci % 20 == 0:
+            print("multi case %d ok, %d detections so far" % (ci, total), flush=True)
+    return n_cases, total
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Wakeword models (src/wakewords/nn/wakeword_nn.rs) through the single-stream API: random layer sizes of the four model
 # types, random weights, 2-3 labels.  The forward pass is pinned by the oracle only, so scores compare at
 # 1e-4; which chunks fire, the label and the counter must agree.
@@ -326,6 +367,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
     ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
     a = ap.parse_args()
@@ -334,5 +376,7 @@ if __name__ == "__main__":
     print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
     n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
     print("api sweep: %d cases, %d detections compared: OK" % (n, total))
+    n, total = run_multi_sweep(ra, ra.BatchContext(0), a.multi_cases, a.seed, verbose=True)
+    print("multi sweep: %d cases, %d detections compared: OK" % (n, total))
     n, total = run_model_sweep(ra, a.model_cases, a.seed, verbose=True)
     print("model sweep: %d cases, %d detections compared: OK" % (n, total))

@@ -1154,6 +1154,9 @@ def test_randomised_parity_sweep(ra, ctx):
     import sweep_parity
     n, total, ties = sweep_parity.run_sweep(ra, ctx, 24, seed=7)
     assert n == 24 and total >= 10 and ties <= 2
+    # 1-3 wakewords with their own thresholds in rp_batch_detect_multi
+    n, total = sweep_parity.run_multi_sweep(ra, ctx, 16, seed=7)
+    assert n == 16 and total >= 3
 
 
 def test_randomised_api_sweep(ra):

@@ -260,6 +260,58 @@ def run_api_sweep(ra, n_cases, seed, verbose=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# MFCC values (rp_mfcc_batch_fmt) against the oracle over signal kinds, mfcc sizes 1..40 and levels.  Gate: SURVEY 8d's
+# 1e-5 for broadband signals at levels of -40 dB and above.  Measured outside that (4 000 cases each, --report): down to
+# -80 dB the worst broadband case is 1.1e-5, down to -140 dB 1.6e-5 -- the logarithms are ~-35 there, the DCT sums
+# difference terms of that size and one f32 ulp of them is already 4e-6; tones reach 6.6e-5 at any level (see below).
+def run_mfcc_sweep(ra, ctx, n_cases, seed, verbose=False, strict=True, min_level_exp=-2.0):
+    from oracle import rp_oracle as orc
+    worst = {}
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 33, ci])
+        K = int(rng.choice([5, 16, 1, 2, 7, 13, 23, 40]))
+        n = 480 * int(rng.integers(2, 40)) + int(rng.choice([0, rng.integers(0, 480)]))
+        kind = int(rng.integers(7))
+        t = np.arange(n) / 16000.0
+        if kind == 0:
+            x = rng.standard_normal(n)
+        elif kind == 1:
+            x = rng.uniform(-1, 1, n)
+        elif kind == 2:  # a few steady tones
+            x = sum(np.sin(2 * np.pi * rng.uniform(50, 7900) * t + rng.uniform(0, 6.28)) for _ in range(int(rng.integers(1, 4))))
+        elif kind == 3:  # speech-like
+            x = _utterance(rng, n).astype(np.float64)
+        elif kind == 4:  # DC offset + noise
+            x = rng.uniform(-1, 1) + 0.01 * rng.standard_normal(n)
+        elif kind == 5:  # sparse impulses
+            x = np.zeros(n)
+            x[rng.integers(0, n, size=max(1, n // 300))] = rng.uniform(-1, 1, max(1, n // 300))
+        else:  # band-limited noise (moving average)
+            x = np.convolve(rng.standard_normal(n + 31), np.ones(32) / 32.0, "valid")
+        x = (x * 10.0 ** rng.uniform(min_level_exp, 0.5)).astype(np.float32)
+        if rng.random() < 0.3:
+            x = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+        got = ctx.mfcc(x[None, :], K)[0]
+        ref = orc.mfcc_stream(x.astype(np.float32) / np.float32(32767.0) if x.dtype == np.int16 else x, K)
+        assert got.shape == ref.shape
+        if ref.size:
+            # K <= 5: SURVEY 8d's element-wise gate; larger K: relative to the frame's largest coefficient (the DCT sums
+            # reach |60| there, and the oracle is as far from an f64 evaluation as the kernel is -- see test_gpu_parity.py)
+            scale = np.maximum(np.abs(ref), 1.0) if K <= 5 else np.maximum(np.abs(ref).max(axis=-1, keepdims=True), 1.0)
+            err = float(np.max(np.abs(got - ref) / scale))
+            worst[kind] = max(worst.get(kind, 0.0), err)
+            # tones (kinds 2, 3) put the far mel filters 60-90 dB under the peak, where the rounding noise of ANY f32 FFT
+            # (the kernel's 16x15 four-step, the oracle's, rustfft's) is no longer small against the local energy: the
+            # logarithm turns that into absolute differences above 1e-5; the gate there is 2e-4
+            gate = 2e-4 if kind in (2, 3) else 1e-5
+            assert err <= gate or not strict, "mfcc sweep seed %d case %d: kind %d K %d n %d %s level %.3g: err %.3g" % (
+                seed, ci, kind, K, n, x.dtype, float(np.max(np.abs(x.astype(np.float64)))), err)
+        if verbose and ci % 50 == 0:
+            print("mfcc case %d ok, worst error per signal kind so far %r" % (ci, {k: float("%.3g" % v) for k, v in sorted(worst.items())}), flush=True)
+    return n_cases, worst
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Several wakewords in the batched detector (rp_batch_detect_multi) against the oracle's detector holding the same
 # wakewords (run_wakeword_detectors, src/detector.rs:433-447), per-wakeword threshold overrides included.
 def run_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
@@ -367,6 +419,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--min-level-exp", type=float, default=-2.0, help="MFCC sweep: signal levels 10^[this, 0.5]")
+    ap.add_argument("--report", action="store_true", help="MFCC sweep: report the worst errors instead of asserting the gates")
+    ap.add_argument("--mfcc-cases", type=int, default=0, help="MFCC value cases (signal kinds x levels)")
     ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
     ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
@@ -376,6 +431,10 @@ if __name__ == "__main__":
     print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
     n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
     print("api sweep: %d cases, %d detections compared: OK" % (n, total))
+    n, worst = run_mfcc_sweep(ra, ra.BatchContext(0), a.mfcc_cases, a.seed, verbose=True, strict=not a.report,
+                              min_level_exp=a.min_level_exp)
+    print("mfcc sweep: %d cases, worst scaled error per signal kind %r (gate 1e-5; tones 2e-4): OK" % (
+        n, {k: float("%.3g" % v) for k, v in sorted(worst.items())}))
     n, total = run_multi_sweep(ra, ra.BatchContext(0), a.multi_cases, a.seed, verbose=True)
     print("multi sweep: %d cases, %d detections compared: OK" % (n, total))
     n, total = run_model_sweep(ra, a.model_cases, a.seed, verbose=True)

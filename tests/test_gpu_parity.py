@@ -1159,6 +1159,13 @@ def test_randomised_parity_sweep(ra, ctx):
     assert n == 16 and total >= 3
 
 
+def test_randomised_mfcc_sweep(ra, ctx):
+    """120 random (signal kind, level, mfcc size, length, sample type) MFCC cases against the oracle."""
+    import sweep_parity
+    n, worst = sweep_parity.run_mfcc_sweep(ra, ctx, 120, seed=7)
+    assert n == 120 and len(worst) == 7
+
+
 def test_randomised_api_sweep(ra):
     """12 random single-stream cases through `Rustpotter` chunk by chunk (several wakewords, filters, VAD, resets,
     stereo, 48 kHz) against the oracle's detector: same chunks fire, same name / counter / partial state, scores 1e-5."""

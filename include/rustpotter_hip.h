@@ -11,7 +11,8 @@
  * Conventions (SURVEY.md §8b "Ownership/Errors/Threading"):
  *  - all functions return plain C types; status returns are int: >=0 ok, <0 error;
  *    the message of the last error of the calling thread is rp_last_error()
- *    (the reference returns Result<_, String>).
+ *    (the reference returns Result<_, String>).  A NULL handle or a NULL required pointer is
+ *    refused with -1 ("null handle" / "null argument"); getters return 0, *_free(NULL) is a no-op.
  *  - the caller owns every input buffer for the duration of the call only;
  *    wakewords are copied into the handle (src/wakewords/comp/wakeword_comp.rs:55-63).
  *  - strings/arrays inside rp_detection are owned by the handle and stay valid

@@ -68,6 +68,7 @@ const char *rp_last_error(void) { return last_error().c_str(); }
 const char *rp_version(void) { return "rustpotter_hip 0.1.0 (gfx950; mirrors rustpotter 3.0.2)"; }
 
 void rp_config_default(rp_config *c) {
+    if (!c) return;
     std::memset(c, 0, sizeof(*c));
     c->fmt.sample_rate = 16000;  // DETECTOR_INTERNAL_SAMPLE_RATE
     c->fmt.sample_format = RP_SAMPLE_F32;
@@ -105,26 +106,30 @@ int rp_new(const rp_config *config, rp_detector **out) {
 void rp_free(rp_detector *d) { delete d; }
 
 int rp_add_wakeword_from_buffer(rp_detector *d, const char *key, const uint8_t *buffer, size_t len) {
+    if (!d || !key || (!buffer && len)) { set_last_error("null argument"); return -1; }
     return guarded([&]() -> int { return d->impl->add_wakeword_from_buffer(key, buffer, len) ? 0 : -1; });
 }
 int rp_add_wakeword_from_file(rp_detector *d, const char *key, const char *path) {
+    if (!d || !key || !path) { set_last_error("null argument"); return -1; }
     return guarded([&]() -> int { return d->impl->add_wakeword_from_file(key, path) ? 0 : -1; });
 }
-bool rp_remove_wakeword(rp_detector *d, const char *key) { return d->impl->remove_wakeword(key); }
-bool rp_remove_wakewords(rp_detector *d) { return d->impl->remove_wakewords(); }
-size_t rp_get_samples_per_frame(const rp_detector *d) { return d->impl->get_samples_per_frame(); }
-size_t rp_get_bytes_per_frame(const rp_detector *d) { return d->impl->get_bytes_per_frame(); }
+bool rp_remove_wakeword(rp_detector *d, const char *key) { return d && key && d->impl->remove_wakeword(key); }
+bool rp_remove_wakewords(rp_detector *d) { return d && d->impl->remove_wakewords(); }
+size_t rp_get_samples_per_frame(const rp_detector *d) { return d ? d->impl->get_samples_per_frame() : 0; }
+size_t rp_get_bytes_per_frame(const rp_detector *d) { return d ? d->impl->get_bytes_per_frame() : 0; }
 int rp_get_partial_detection(const rp_detector *d, rp_detection *out) {
+    if (!d || !out) { set_last_error("null argument"); return -1; }
     const Detection *p = d->impl->get_partial_detection();
     if (!p) return 0;
     fill_detection(const_cast<rp_detector *>(d), *p, out);
     return 1;
 }
-float rp_get_rms_level(const rp_detector *d) { return d->impl->get_rms_level(); }
-float rp_get_gain(const rp_detector *d) { return d->impl->get_gain(); }
-float rp_get_rms_level_ref(const rp_detector *d) { return d->impl->get_rms_level_ref(); }
+float rp_get_rms_level(const rp_detector *d) { return d ? d->impl->get_rms_level() : 0.f; }
+float rp_get_gain(const rp_detector *d) { return d ? d->impl->get_gain() : 0.f; }
+float rp_get_rms_level_ref(const rp_detector *d) { return d ? d->impl->get_rms_level_ref() : 0.f; }
 
 #define RP_PROCESS(call)                                              \
+    if (!d) { set_last_error("null handle"); return -1; }             \
     return guarded([&]() -> int {                                     \
         Detection det;                                                \
         int r = (call);                                               \
@@ -139,17 +144,27 @@ int rp_process_samples_i32(rp_detector *d, const int32_t *s, size_t n, rp_detect
 int rp_process_samples_f32(rp_detector *d, const float *s, size_t n, rp_detection *out) { RP_PROCESS(d->impl->process_samples<float>(s, n, &det)); }
 
 int rp_update_config(rp_detector *d, const rp_config *c) {
+    if (!d || !c) { set_last_error("null argument"); return -1; }
     d->impl->update_detector_config(c->detector);
     d->impl->update_filters_config(c->filters);
     return 0;
 }
-int rp_update_detector_config(rp_detector *d, const rp_detector_config *c) { d->impl->update_detector_config(*c); return 0; }
-int rp_update_filters_config(rp_detector *d, const rp_filters_config *c) { d->impl->update_filters_config(*c); return 0; }
-void rp_reset(rp_detector *d) { d->impl->reset(); }
+int rp_update_detector_config(rp_detector *d, const rp_detector_config *c) {
+    if (!d || !c) { set_last_error("null argument"); return -1; }
+    d->impl->update_detector_config(*c);
+    return 0;
+}
+int rp_update_filters_config(rp_detector *d, const rp_filters_config *c) {
+    if (!d || !c) { set_last_error("null argument"); return -1; }
+    d->impl->update_filters_config(*c);
+    return 0;
+}
+void rp_reset(rp_detector *d) { if (d) d->impl->reset(); }
 
 // ------------------------------------------------------------------- batched level
 int rp_ctx_new(int device, int flags, rp_ctx **out) {
     return guarded([&]() -> int {
+        if (!out) { set_last_error("null argument"); return -1; }
         *out = nullptr;
         std::unique_ptr<Ctx> c(Ctx::create(device, flags));
         if (!c) return -1;
@@ -161,10 +176,12 @@ int rp_ctx_new(int device, int flags, rp_ctx **out) {
 }
 void rp_ctx_free(rp_ctx *ctx) { delete ctx; }
 int rp_ctx_set_stream(rp_ctx *ctx, void *s) {
+    if (!ctx) { set_last_error("null handle"); return -1; }
     ctx->impl->stream = s ? static_cast<hipStream_t>(s) : ctx->impl->own_stream;
     return 0;
 }
 int rp_ctx_synchronize(rp_ctx *ctx) {
+    if (!ctx) { set_last_error("null handle"); return -1; }
     if (!hip_ok(hipSetDevice(ctx->impl->device), "hipSetDevice")) return -1;
     return hip_ok(hipStreamSynchronize(ctx->impl->stream), "hipStreamSynchronize") ? 0 : -1;
 }
@@ -202,6 +219,7 @@ static size_t sample_bytes(rp_sample_format f) { return f == RP_SAMPLE_I8 ? 1 : 
 int rp_mfcc_batch_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                       int K, float *mfcc) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
@@ -230,6 +248,7 @@ int rp_wakeword_ref_build(rp_ctx *ctx, const char *name, const float *threshold,
                           const char *const *sample_names, const uint8_t *const *wav_buffers, const size_t *wav_lens,
                           uint16_t mfcc_size, int rms_from_files, uint8_t **out_rpw, size_t *out_len) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         *out_rpw = nullptr; *out_len = 0;
         WakewordRefData r;
         if (!build_wakeword_ref(ctx->impl.get(), name, threshold, avg_threshold, n, sample_names, wav_buffers, wav_lens,
@@ -250,6 +269,7 @@ int rp_wakeword_model_train(rp_ctx *ctx, const rp_train_options *options, size_t
                             const uint8_t *prev_model, size_t prev_model_len, uint8_t **out_rpw, size_t *out_len,
                             float *final_loss, float *test_accuracy) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         *out_rpw = nullptr; *out_len = 0;
         WakewordModelData prev, m;
         bool has_prev = false;
@@ -274,6 +294,7 @@ int rp_frontend_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t
                       const rp_filters_config *filters, float rms_level_ref, size_t window_size, float *pcm_out,
                       size_t out_stride, float *rms, float *gains) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples || out_stride < n_samples) { set_last_error("stride smaller than n_samples"); return -1; }
@@ -322,6 +343,7 @@ int rp_frontend_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t
 int rp_templates_new(rp_ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len, const float *avg,
                      rp_templates **out) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         *out = nullptr;
         std::unique_ptr<Templates> t(Templates::create(ctx->impl.get(), T, K, lens, feats, avg_len, avg));
         if (!t) return -1;
@@ -332,12 +354,13 @@ int rp_templates_new(rp_ctx *ctx, int T, int K, const int *lens, const float *fe
     });
 }
 void rp_templates_free(rp_templates *t) { delete t; }
-int rp_templates_max_len(const rp_templates *t) { return t->impl->dev.max_len; }
+int rp_templates_max_len(const rp_templates *t) { return t ? t->impl->dev.max_len : 0; }
 
 int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames, const rp_templates *t,
                        float score_ref, int band_size, rp_score_mode score_mode, int with_avg, float *scores,
                        float *avg, float *agg) {
     return guarded([&]() -> int {
+        if (!ctx || !t) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const TemplatesDev &td = t->impl->dev;
@@ -376,6 +399,7 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
                    const rp_detector_config *config, int avg_enabled, const float *mfcc, int K,
                    rp_batch_detection *det, int32_t *n_det, int max_det) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const bool vad = config->vad_mode != RP_VAD_NONE;
@@ -416,6 +440,7 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
                         const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                         int max_det, float *scores, float *agg) {
     return guarded([&]() -> int {
+        if (!ctx || !t) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
@@ -478,6 +503,7 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                           const float *thresholds, const float *avg_thresholds, rp_batch_detection *det,
                           int32_t *det_wakeword, int32_t *n_det, int max_det) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (n_wakewords < 1 || n_wakewords > (size_t)kScanMaxWakewords) { set_last_error("rp_batch_detect_multi: 1..8 wakewords"); return -1; }
@@ -554,6 +580,7 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
 
 int rp_resampler_frame_lengths(size_t sample_rate, size_t *in_len, size_t *out_len) {
     return guarded([&]() -> int {
+        if (!in_len || !out_len) { set_last_error("null argument"); return -1; }
         if (!resampler_frame_lengths(sample_rate, in_len, out_len)) {
             set_last_error("Unsupported sample rate, unable to initialize the resampler");
             return -1;
@@ -565,6 +592,7 @@ int rp_resampler_frame_lengths(size_t sample_rate, size_t *in_len, size_t *out_l
 int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int channels, size_t sample_rate, size_t S,
                       size_t n_samples, size_t pcm_stride, float *out, size_t out_stride) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
@@ -601,6 +629,7 @@ int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int ch
 int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_config *config, size_t S,
                         size_t max_chunks_per_call, rp_stream_batch **out) {
     return guarded([&]() -> int {
+        if (!ctx || !t) { set_last_error("null handle"); return -1; }
         *out = nullptr;
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
@@ -633,10 +662,11 @@ int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_co
     });
 }
 void rp_stream_batch_free(rp_stream_batch *b) { delete b; }
-size_t rp_stream_batch_chunks_seen(const rp_stream_batch *b) { return b->chunks_seen; }
+size_t rp_stream_batch_chunks_seen(const rp_stream_batch *b) { return b ? b->chunks_seen : 0; }
 
 int rp_stream_batch_set_input(rp_stream_batch *b, size_t sample_rate, int channels) {
     return guarded([&]() -> int {
+        if (!b) { set_last_error("null handle"); return -1; }
         Ctx *c = b->c;
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (b->chunks_seen) { set_last_error("rp_stream_batch_set_input: the streams have already received audio"); return -1; }
@@ -657,10 +687,11 @@ int rp_stream_batch_set_input(rp_stream_batch *b, size_t sample_rate, int channe
         return 0;
     });
 }
-size_t rp_stream_batch_samples_per_chunk(const rp_stream_batch *b) { return b->in_len * (size_t)b->channels; }
+size_t rp_stream_batch_samples_per_chunk(const rp_stream_batch *b) { return b ? b->in_len * (size_t)b->channels : 0; }
 
 int rp_stream_batch_reset(rp_stream_batch *b, long long stream) {
     return guarded([&]() -> int {
+        if (!b) { set_last_error("null handle"); return -1; }
         Ctx *c = b->c;
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (stream >= (long long)b->S) { set_last_error("rp_stream_batch_reset: no such stream"); return -1; }
@@ -672,6 +703,7 @@ int rp_stream_batch_reset(rp_stream_batch *b, long long stream) {
 int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
                             rp_batch_detection *det, int32_t *n_det, int max_det, float *agg) {
     return guarded([&]() -> int {
+        if (!b) { set_last_error("null handle"); return -1; }
         Ctx *c = b->c;
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (n_chunks == 0 || n_chunks > b->max_chunks) { set_last_error("rp_stream_batch_process: n_chunks out of range"); return -1; }
@@ -765,6 +797,7 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
 int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
                  rp_model **out) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         *out = nullptr;
         std::unique_ptr<Model> m(Model::create(ctx->impl.get(), n_layers, dims, weights, biases));
         if (!m) return -1;
@@ -778,6 +811,7 @@ void rp_model_free(rp_model *m) { delete m; }
 
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits) {
     return guarded([&]() -> int {
+        if (!ctx || !model) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const Model &m = *model->impl;
@@ -812,6 +846,7 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                           const rp_model *model, int mfcc_size, int none_index, const rp_detector_config *config, int precision,
                           rp_batch_detection *det, int32_t *det_label, int32_t *n_det, int max_det) {
     return guarded([&]() -> int {
+        if (!ctx || !model) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
@@ -903,6 +938,7 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
 int rp_synth_pcm_batch(rp_ctx *ctx, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples, size_t pcm_stride,
                        float *pcm) {
     return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         Staged sg(c);
@@ -914,13 +950,19 @@ int rp_synth_pcm_batch(rp_ctx *ctx, uint64_t seed, uint64_t first_stream, size_t
     });
 }
 
-int rp_ctx_timing_enable(rp_ctx *ctx, int enable) { ctx->impl->timing = enable != 0; return 0; }
+int rp_ctx_timing_enable(rp_ctx *ctx, int enable) {
+    if (!ctx) { set_last_error("null handle"); return -1; }
+    ctx->impl->timing = enable != 0;
+    return 0;
+}
 int rp_ctx_timing_reset(rp_ctx *ctx) {
+    if (!ctx) { set_last_error("null handle"); return -1; }
     ctx->impl->time_collect();
     for (int i = 0; i < kKernelCount; ++i) { ctx->impl->sum_ms[i] = 0; ctx->impl->count[i] = 0; }
     return 0;
 }
 int rp_ctx_timing_read(rp_ctx *ctx, int kernel, double *avg_ms, int *launches) {
+    if (!ctx) { set_last_error("null handle"); return -1; }
     if (kernel < 0 || kernel >= kKernelCount) { set_last_error("unknown kernel id"); return -1; }
     ctx->impl->time_collect();
     int n = ctx->impl->count[kernel];

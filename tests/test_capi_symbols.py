@@ -61,3 +61,43 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "rp_oracle" not in txt and "oracle/" not in txt and "import oracle" not in txt, f
+
+
+def test_null_handles_and_arguments_are_refused():
+    """Every entry point called with NULL handles / NULL pointers / zero sizes returns (an error status or a neutral
+    value) instead of dereferencing them; run in a child process so that a crash is a test failure, not a dead session."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import rustpotter_amd
+from rustpotter_amd.api import SYMBOLS
+L = rustpotter_amd.load_library()
+bad = []
+for name in SYMBOLS:
+    fn = getattr(L, name)
+    types = fn.argtypes
+    if types is None:  # rp_last_error / rp_version take nothing
+        assert name in ("rp_last_error", "rp_version"), name
+        fn()
+        continue
+    args = []
+    for t in types:
+        if t in (C.c_float, C.c_double):
+            args.append(0.0)
+        elif t in (C.c_int, C.c_uint, C.c_size_t, C.c_int32, C.c_int64, C.c_uint64, C.c_longlong, C.c_uint16, C.c_bool, C.c_long):
+            args.append(0)
+        else:
+            args.append(None)
+    r = fn(*args)
+    returns_void = name.endswith("_free") or name in ("rp_config_default", "rp_reset")
+    if not returns_void and fn.restype is C.c_int and name != "rp_templates_max_len" and any(a is None for a in args) and r != -1:
+        bad.append("%%s returned %%r" %% (name, r))
+    print(name, r)
+assert not bad, bad
+print("ALL-OK")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -312,6 +312,55 @@ def run_mfcc_sweep(ra, ctx, n_cases, seed, verbose=False, strict=True, min_level
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Front-end (rp_frontend_batch: decode + GainNormalizerFilter + BandPassFilter) against the oracle, bit for bit:
+# stream counts around the 64-stream workgroup, row lengths with and without 4-sample alignment (tiled / per-lane
+# kernel), tails shorter than a chunk, all four sample types, filter parameters across their ranges.
+def run_frontend_sweep(ra, ctx, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    checked = 0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 44, ci])
+        S = int(rng.choice([1, 2, 63, 64, 65, 130, int(rng.integers(1, 200))]))
+        N = 480 * int(rng.integers(1, 30)) + int(rng.choice([0, 0, 4 * rng.integers(0, 120), rng.integers(0, 480)]))
+        level = 10.0 ** rng.uniform(-3, 0.3)
+        x = rng.standard_normal((S, N)) * level
+        if rng.random() < 0.3:
+            x[int(rng.integers(S)), : N // 2] = 0.0
+        dt = [np.float32, np.int16, np.int8, np.int32][int(rng.integers(4))]
+        if dt is np.float32:
+            raw, dec = x.astype(np.float32), x.astype(np.float32)
+        else:
+            info = np.iinfo(dt)
+            raw = np.clip(np.round(x * info.max), info.min, info.max).astype(dt)
+            dec = raw.astype(np.float32) / np.float32({np.int16: 32767.0, np.int8: 127.0, np.int32: 2147483648.0}[dt])
+        f = ra.FiltersConfig()
+        g, b = f.gain_normalizer, f.band_pass
+        g.enabled, b.enabled = bool(rng.random() < 0.7), bool(rng.random() < 0.7)
+        g.gain_ref = None if rng.random() < 0.5 else float(rng.uniform(0.005, 0.3))
+        g.min_gain, g.max_gain = float(rng.uniform(0.05, 1.0)), float(rng.uniform(1.0, 5.0))
+        b.low_cutoff, b.high_cutoff = float(rng.uniform(20, 1000)), float(rng.uniform(1000, 7900))
+        rms_ref, win = float(rng.uniform(0.005, 0.3)), int(rng.integers(1, 40))
+        out, rms, gains = ctx.frontend(raw, f, rms_ref, win)
+        for si in sorted(set([0, S - 1, int(rng.integers(S))])):
+            ro, rr, rg = orc.frontend_stream(dec[si], gain_normalizer=g.enabled, gain_ref=g.gain_ref, min_gain=g.min_gain,
+                                             max_gain=g.max_gain, rms_level_ref=rms_ref, window_size=win, band_pass=b.enabled,
+                                             low_cutoff=b.low_cutoff, high_cutoff=b.high_cutoff)
+            # a band-pass with far-apart cutoffs is an unstable biquad (in the reference too): both sides overflow to the same NaNs
+            ok = np.array_equal(rms[si], rr) and np.array_equal(gains[si], rg) and np.array_equal(out[si], ro, equal_nan=True)
+            if not ok:
+                bad = np.flatnonzero(~((out[si] == ro) | (np.isnan(out[si]) & np.isnan(ro))))
+                raise AssertionError("frontend sweep seed %d case %d: S %d N %d %s level %.3g stream %d, gain %r (ref %r, %g..%g, rms_ref %g, win %d) "
+                                     "band-pass %r (%g..%g): rms %r gains %r out %r first diffs %r got %r want %r, gains %r vs %r" % (
+                    seed, ci, S, N, np.dtype(dt).name, level, si, g.enabled, g.gain_ref, g.min_gain, g.max_gain, rms_ref, win, b.enabled,
+                    b.low_cutoff, b.high_cutoff, np.array_equal(rms[si], rr), np.array_equal(gains[si], rg), np.array_equal(out[si], ro),
+                    bad[:4], out[si][bad[:4]], ro[bad[:4]], gains[si][:6], rg[:6]))
+            checked += 1
+        if verbose and ci % 50 == 0:
+            print("frontend case %d ok, %d streams compared so far" % (ci, checked), flush=True)
+    return n_cases, checked
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Several wakewords in the batched detector (rp_batch_detect_multi) against the oracle's detector holding the same
 # wakewords (run_wakeword_detectors, src/detector.rs:433-447), per-wakeword threshold overrides included.
 def run_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
@@ -421,6 +470,7 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--min-level-exp", type=float, default=-2.0, help="MFCC sweep: signal levels 10^[this, 0.5]")
     ap.add_argument("--report", action="store_true", help="MFCC sweep: report the worst errors instead of asserting the gates")
+    ap.add_argument("--frontend-cases", type=int, default=0, help="decode + gain normaliser + band-pass cases")
     ap.add_argument("--mfcc-cases", type=int, default=0, help="MFCC value cases (signal kinds x levels)")
     ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
     ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
@@ -431,6 +481,8 @@ if __name__ == "__main__":
     print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
     n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
     print("api sweep: %d cases, %d detections compared: OK" % (n, total))
+    n, checked = run_frontend_sweep(ra, ra.BatchContext(0), a.frontend_cases, a.seed, verbose=True)
+    print("frontend sweep: %d cases, %d streams compared bit for bit: OK" % (n, checked))
     n, worst = run_mfcc_sweep(ra, ra.BatchContext(0), a.mfcc_cases, a.seed, verbose=True, strict=not a.report,
                               min_level_exp=a.min_level_exp)
     print("mfcc sweep: %d cases, worst scaled error per signal kind %r (gate 1e-5; tones 2e-4): OK" % (

@@ -1166,6 +1166,14 @@ def test_randomised_mfcc_sweep(ra, ctx):
     assert n == 120 and len(worst) == 7
 
 
+def test_randomised_frontend_sweep(ra, ctx):
+    """40 random decode + gain normaliser + band-pass cases (stream counts around a workgroup, aligned / odd row
+    lengths, four sample types, filter parameters) bit for bit against the oracle."""
+    import sweep_parity
+    n, checked = sweep_parity.run_frontend_sweep(ra, ctx, 40, seed=7)
+    assert n == 40 and checked >= 60
+
+
 def test_randomised_api_sweep(ra):
     """12 random single-stream cases through `Rustpotter` chunk by chunk (several wakewords, filters, VAD, resets,
     stereo, 48 kHz) against the oracle's detector: same chunks fire, same name / counter / partial state, scores 1e-5."""

@@ -361,6 +361,59 @@ def run_frontend_sweep(ra, ctx, n_cases, seed, verbose=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Resampler (rp_resample_batch: rubato FftFixedInOut restated) against the oracle over input rates, channel counts,
+# sample types, stream counts and lengths.  |d| <= 4e-6 of the peak as in tests/test_gpu_parity.py (x sqrt(fi / 1440)
+# above 48 kHz).
+RATES = [48000, 48000, 44100, 32000, 24000, 22050, 12000, 11025, 8000, 96000, 88200, 64000, 44000, 6000, 4000, 192000]
+
+
+def run_resample_sweep(ra, ctx, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    worst = 0.0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 66, ci])
+        fs = int(RATES[int(rng.integers(len(RATES)))])
+        fi, fo = ra.resampler_frame_lengths(fs)
+        ch = int(rng.choice([1, 1, 2, 3]))
+        S = int(rng.integers(1, 6))
+        n = fi * int(rng.integers(1, 9)) + int(rng.choice([0, rng.integers(0, fi)]))
+        t = np.arange(n)
+        kind = int(rng.integers(4))
+        if kind == 0:
+            x = rng.uniform(-0.5, 0.5, (S, n))
+        elif kind == 1:
+            x = 0.3 * np.sin(2 * np.pi * rng.uniform(50, 0.45 * fs) * t / fs)[None, :] + 0.01 * rng.standard_normal((S, n))
+        elif kind == 2:
+            x = np.where((t // int(rng.integers(50, 900))) % 2 == 0, 0.25, -0.25)[None, :] * np.ones((S, 1))
+        else:
+            x = rng.standard_normal((S, n)) * 10.0 ** rng.uniform(-3, -0.5)
+        dt = [np.float32, np.float32, np.int16, np.int8, np.int32][int(rng.integers(5))]
+        if dt is np.float32:
+            raw, dec = x.astype(np.float32), x.astype(np.float32)
+        else:
+            info = np.iinfo(dt)
+            raw = np.clip(np.round(x * info.max), info.min, info.max).astype(dt)
+            dec = raw.astype(np.float32) / np.float32({np.int16: 32767.0, np.int8: 127.0, np.int32: 2147483648.0}[dt])
+        inter = raw if ch == 1 else np.stack([raw] + [np.roll(raw, k + 1, axis=1) for k in range(ch - 1)], axis=2).reshape(S, n * ch)
+        got = ctx.resample(np.ascontiguousarray(inter), fs, channels=ch)
+        assert got.shape == (S, (n // fi) * fo)
+        for si in range(S):
+            ref = orc.resample_stream(dec[si], fs)
+            assert ref.shape == got[si].shape
+            if ref.size:
+                err = float(np.abs(got[si] - ref).max()) / max(float(np.abs(ref).max()), 1e-3)
+                worst = max(worst, err)
+                # above 48 kHz the matrix form sums 2 * fi > 2 880 products per output sample in f32: the rounding walk
+                # grows with the square root of the depth (192 kHz: 11 520 terms, measured 4.1e-6)
+                gate = 4e-6 * max(1.0, (fi / 1440.0) ** 0.5)
+                assert err <= gate, "resample sweep seed %d case %d: fs %d ch %d S %d n %d %s kind %d stream %d: err %.3g" % (
+                    seed, ci, fs, ch, S, n, np.dtype(dt).name, kind, si, err)
+        if verbose and ci % 50 == 0:
+            print("resample case %d ok, worst error so far %.3g of the peak" % (ci, worst), flush=True)
+    return n_cases, worst
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Several wakewords in the batched detector (rp_batch_detect_multi) against the oracle's detector holding the same
 # wakewords (run_wakeword_detectors, src/detector.rs:433-447), per-wakeword threshold overrides included.
 def run_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
@@ -470,6 +523,7 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--min-level-exp", type=float, default=-2.0, help="MFCC sweep: signal levels 10^[this, 0.5]")
     ap.add_argument("--report", action="store_true", help="MFCC sweep: report the worst errors instead of asserting the gates")
+    ap.add_argument("--resample-cases", type=int, default=0, help="resampler cases (rates x channels x sample types)")
     ap.add_argument("--frontend-cases", type=int, default=0, help="decode + gain normaliser + band-pass cases")
     ap.add_argument("--mfcc-cases", type=int, default=0, help="MFCC value cases (signal kinds x levels)")
     ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
@@ -481,6 +535,8 @@ if __name__ == "__main__":
     print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
     n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
     print("api sweep: %d cases, %d detections compared: OK" % (n, total))
+    n, worst = run_resample_sweep(ra, ra.BatchContext(0), a.resample_cases, a.seed, verbose=True)
+    print("resample sweep: %d cases, worst error %.3g of the peak (gate 4e-6, x sqrt(fi / 1440) above 48 kHz): OK" % (n, worst))
     n, checked = run_frontend_sweep(ra, ra.BatchContext(0), a.frontend_cases, a.seed, verbose=True)
     print("frontend sweep: %d cases, %d streams compared bit for bit: OK" % (n, checked))
     n, worst = run_mfcc_sweep(ra, ra.BatchContext(0), a.mfcc_cases, a.seed, verbose=True, strict=not a.report,

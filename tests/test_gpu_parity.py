@@ -1174,6 +1174,13 @@ def test_randomised_frontend_sweep(ra, ctx):
     assert n == 40 and checked >= 60
 
 
+def test_randomised_resample_sweep(ra, ctx):
+    """40 random resampler cases (16 input rates from 4 to 192 kHz, 1-3 channels, four sample types) against the oracle."""
+    import sweep_parity
+    n, worst = sweep_parity.run_resample_sweep(ra, ctx, 40, seed=7)
+    assert n == 40 and 0.0 < worst <= 8e-6
+
+
 def test_randomised_api_sweep(ra):
     """12 random single-stream cases through `Rustpotter` chunk by chunk (several wakewords, filters, VAD, resets,
     stereo, 48 kHz) against the oracle's detector: same chunks fire, same name / counter / partial state, scores 1e-5."""

@@ -122,22 +122,26 @@ __global__ __launch_bounds__(64) void apply_filters_tiled_kernel(const TIN *__re
                                                                  size_t pcm_stride, const float *__restrict__ gains, BiquadCoef q,
                                                                  float *__restrict__ out, size_t out_stride) {
     __shared__ __attribute__((aligned(16))) float tile[64 * kFeRow];
-    const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
+    const int lane = threadIdx.x;
     const size_t s0 = (size_t)blockIdx.x * 64, s = s0 + lane;
-    const bool live = s < S, mover = sub < kFeLanes;
+    const bool live = s < S;
     const size_t n_tiles = n_chunks * (kFrame / kFeTile);
-    // every lane fetches (rows past S and the two idle lanes of a half re-read a valid address): a guarded load would
-    // sit in its own branch with its own wait
+    const unsigned rows_here = S - s0 < 64 ? (unsigned)(S - s0) : 64u;
+    // the tile as 64 rows x 30 four-sample groups = 30 wave-wide moves: group it * 64 + lane -> (row, column); every lane
+    // fetches (rows past S re-read the last stream: a guarded load would sit in its own branch with its own wait).
+    // 30 loads + 30 stores + the gain in flight stay under the 63 the wait counter can express.
     using Raw4 = typename SampleIn<TIN>::Raw4;
-    Raw4 r[32];
+    constexpr int kMoves = 64 * kFeLanes / 64;
+    Raw4 r[kMoves];
     float g_next = 1.f;
-    const size_t sub_c = mover ? sub : kFeLanes - 1, s_c = live ? s : S - 1;
+    const size_t s_c = live ? s : S - 1;
+    auto row_of = [&](int it) { return (unsigned)(it * 64 + lane) / (unsigned)kFeLanes; };
     auto fetch = [&](size_t ti) {
 #pragma unroll
-        for (int it = 0; it < 32; ++it) {
-            size_t row = s0 + 2 * it + half;
-            row = row < S ? row : S - 1;
-            r[it] = SampleIn<TIN>::ldraw(pcm + row * pcm_stride + ti * kFeTile + 4 * sub_c);
+        for (int it = 0; it < kMoves; ++it) {
+            const unsigned row = row_of(it), c4 = (unsigned)(it * 64 + lane) - row * kFeLanes;
+            const unsigned rc = row < rows_here ? row : rows_here - 1;
+            r[it] = SampleIn<TIN>::ldraw(pcm + (s0 + rc) * pcm_stride + ti * kFeTile + 4 * c4);
         }
         if (GAIN && ti % (kFrame / kFeTile) == 0) g_next = gains[s_c * n_chunks + ti / (kFrame / kFeTile)];
     };
@@ -154,15 +158,27 @@ __global__ __launch_bounds__(64) void apply_filters_tiled_kernel(const TIN *__re
         }
         return v;
     };
+    // Order inside one pass, so that nothing that was just issued is waited for: store the previous tile's results from
+    // registers, decode this tile into LDS, fetch the next tile, filter, read the results back into registers.  The
+    // single wait at the top of the next pass (loads and stores share one in-order counter) then only meets
+    // operations that had the whole filter phase to finish.
+    f32x4 o[kMoves];
+    auto store = [&](size_t ti) {
+#pragma unroll
+        for (int it = 0; it < kMoves; ++it) {
+            const unsigned row = row_of(it), c4 = (unsigned)(it * 64 + lane) - row * kFeLanes;
+            if (row < rows_here) *reinterpret_cast<f32x4 *>(out + (s0 + row) * out_stride + ti * kFeTile + 4 * c4) = o[it];
+        }
+    };
     if (n_tiles) fetch(0);
     float *mine = tile + lane * kFeRow;
     for (size_t ti = 0; ti < n_tiles; ++ti) {
-        if (mover) {
+        if (ti) store(ti - 1);
 #pragma unroll
-            for (int it = 0; it < 32; ++it) {
-                const float4 f = SampleIn<TIN>::cvt4(r[it]);
-                *reinterpret_cast<f32x4 *>(&tile[(2 * it + half) * kFeRow + 4 * sub]) = f32x4{f.x, f.y, f.z, f.w};
-            }
+        for (int it = 0; it < kMoves; ++it) {
+            const unsigned row = row_of(it), c4 = (unsigned)(it * 64 + lane) - row * kFeLanes;
+            const float4 f = SampleIn<TIN>::cvt4(r[it]);
+            *reinterpret_cast<f32x4 *>(&tile[row * kFeRow + 4 * c4]) = f32x4{f.x, f.y, f.z, f.w};
         }
         if (GAIN && ti % (kFrame / kFeTile) == 0) g = g_next;
         if (ti + 1 < n_tiles) fetch(ti + 1);
@@ -186,17 +202,14 @@ __global__ __launch_bounds__(64) void apply_filters_tiled_kernel(const TIN *__re
             }
         }
         wave_lds_sync();
-        if (mover) {
 #pragma unroll
-            for (int it = 0; it < 32; ++it) {
-                const size_t row = s0 + 2 * it + half;
-                if (row < S)
-                    *reinterpret_cast<f32x4 *>(out + row * out_stride + ti * kFeTile + 4 * sub) =
-                        *reinterpret_cast<const f32x4 *>(&tile[(2 * it + half) * kFeRow + 4 * sub]);
-            }
+        for (int it = 0; it < kMoves; ++it) {
+            const unsigned row = row_of(it), c4 = (unsigned)(it * 64 + lane) - row * kFeLanes;
+            o[it] = *reinterpret_cast<const f32x4 *>(&tile[row * kFeRow + 4 * c4]);
         }
         wave_lds_sync();
     }
+    if (n_tiles) store(n_tiles - 1);
     if (live)  // tail shorter than a chunk: never framed
         for (size_t k = n_chunks * kFrame; k < n_samples; ++k) out[s * out_stride + k] = SampleIn<TIN>::cvt(pcm[s * pcm_stride + k]);
 }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): every bench line that profiles/ keeps, into gpurun_out/final/*.json
+# (tools/collect_profiles.py then copies them into profiles/).  Usage: tools/run_final_benches.sh
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out/final
+O=gpurun_out/final
+B="python3 bench.py --steps 5 --warmup 2"
+line() { grep '^{' | tail -1; }
+$B 2>/dev/null | line > $O/bench_default.json
+$B --no-cpu-baseline --mode stream --chunks-per-call 1 2>/dev/null | line > $O/stream1.json
+$B --no-cpu-baseline --mode stream --chunks-per-call 8 2>/dev/null | line > $O/stream8.json
+$B --no-cpu-baseline --mode resample --streams 8192 2>/dev/null | line > $O/rs_fft.json
+RP_RESAMPLE_GEMM=1 $B --no-cpu-baseline --mode resample --streams 8192 2>/dev/null | line > $O/rs_gemm.json
+$B --no-cpu-baseline --mode resample --streams 8192 --pcm-format i16 --channels 2 2>/dev/null | line > $O/rs_fft_i16_stereo.json
+$B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_bf16.json
+$B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
+$B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
+$B --no-cpu-baseline --streams 8192 --templates 64 2>/dev/null | line > $O/c4.json
+python3 tools/bench_model_detect.py > $O/model_detect.txt 2>/dev/null
+python3 tools/latency_probe.py > $O/latency.txt 2>/dev/null
+python3 tools/bench_frontend.py > $O/frontend.txt 2>/dev/null
+for f in $O/*.json; do echo "$f $(cut -c1-160 $f)"; done
+cat $O/*.txt

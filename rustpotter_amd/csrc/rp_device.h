@@ -20,16 +20,45 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: 2 results per 4-cycle slot against 3 cycles for
 // one plain op on gfx950).
 typedef float v2f __attribute__((ext_vector_type(2)));
+// The half swaps and one-sided sign flips of complex arithmetic are operand modifiers of the packed instructions
+// (op_sel / op_sel_hi pick the 32-bit half each result lane reads, neg_lo / neg_hi negate a source for one lane); the
+// compiler only folds whole-vector negations, so these are spelled out -- same operations, same bits, no v_xor / v_mov
+// (tools/scratch/pk_probe.hip checks the semantics on the device).
+// a * b = (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x) as r = a.xx * b; r = fma((-a.y, a.y), b.yx, r)
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) {
-    v2f r = a.xx * b;
-    return __builtin_elementwise_fma((v2f){-a.y, a.y}, b.yx, r);
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(r));
+    return r;
 }
 __device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }  // a * (-i)
+// a + (-i) b = (a.x + b.y, a.y - b.x) and a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f sub_mi(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y) and -i (a - conj(b)) = (a.y + b.y, b.x - a.x)
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f mi_sub_conj(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // forward 4-point DFT, in place, natural order
 __device__ __forceinline__ void dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
-    v2f t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, t3 = mul_mi(x1 - x3);
-    x0 = t0 + t2; x1 = t1 + t3; x2 = t0 - t2; x3 = t1 - t3;
+    v2f t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, d = x1 - x3;
+    x0 = t0 + t2; x1 = add_mi(t1, d); x2 = t0 - t2; x3 = sub_mi(t1, d);
 }
 
 // forward 16-point DFT in registers.  Input v[n]; output X[c + 4d] is left at v[4c + d].
@@ -70,12 +99,11 @@ __device__ __forceinline__ void dft5(v2f &x0, v2f &x1, v2f &x2, v2f &x3, v2f &x4
     v2f m2 = __builtin_elementwise_fma((v2f){c1, c1}, a2, __builtin_elementwise_fma((v2f){c2, c2}, a1, x0));
     v2f n1 = __builtin_elementwise_fma((v2f){s2, s2}, b2, (v2f){s1, s1} * b1);
     v2f n2 = __builtin_elementwise_fma((v2f){-s1, -s1}, b2, (v2f){s2, s2} * b1);
-    v2f r1 = mul_mi(n1), r2 = mul_mi(n2);  // -i * n
     x0 = x0 + (a1 + a2);
-    x1 = m1 + r1;
-    x4 = m1 - r1;
-    x2 = m2 + r2;
-    x3 = m2 - r2;
+    x1 = add_mi(m1, n1);  // m1 + (-i) n1
+    x4 = sub_mi(m1, n1);
+    x2 = add_mi(m2, n2);
+    x3 = sub_mi(m2, n2);
 }
 
 // forward 15-point DFT (Good-Thomas 3x5, no twiddles): z[k] = sum_n u[n] W15^{nk}

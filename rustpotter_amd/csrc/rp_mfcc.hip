@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     for (int i = tid; i < K1 * K1; i += kMfccThreads) dct[i] = g_dct[i];
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform: tile indices stay scalar
     const int grp = lane >> 4, l = lane & 15;
     v2f *scr = scr_all + wave * kMfccWaveScratch;
     float *ypre = reinterpret_cast<float *>(scr);  // [960] pre-emphasised samples, dead before scr is written
@@ -83,10 +83,16 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
 #pragma unroll
         for (int d = 0; d < 4; ++d) twl[4 * c + d] = tw240[l15 * (c + 4 * d)];
 
+    // (stream, tile) of this wave's tile, advanced by the grid stride without a division per tile
     const size_t wave_stride = (size_t)gridDim.x * kMfccWaves;
-    for (size_t wt = (size_t)blockIdx.x * kMfccWaves + wave; wt < total_tiles; wt += wave_stride) {
-        const size_t s = wt / tiles_per_stream;
-        const size_t j0 = first_frame + (wt - s * tiles_per_stream) * kMfccFramesPerWave;
+    const size_t stride_s = wave_stride / tiles_per_stream;
+    const unsigned stride_t = (unsigned)(wave_stride - stride_s * tiles_per_stream);
+    size_t wt = (size_t)blockIdx.x * kMfccWaves + wave;
+    size_t s = wt / tiles_per_stream;
+    unsigned tile = (unsigned)(wt - s * tiles_per_stream);
+    for (; wt < total_tiles; wt += wave_stride, s += stride_s, tile += stride_t) {
+        if (tile >= tiles_per_stream) { tile -= tiles_per_stream; ++s; }
+        const size_t j0 = first_frame + (size_t)tile * kMfccFramesPerWave;
         const TIN *x = pcm + s * pcm_stride;
         // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift.
         // All loads are issued unconditionally (clamped index) before the first use, so the wave
@@ -165,8 +171,8 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
             const int k = l + 16 * k2;
             const v2f a = z[k2];
             const v2f b = (k2 == 0 && l == 0) ? a : zmir[-16 * k2];
-            const v2f e = (v2f){a.x + b.x, a.y - b.y};           // 2E = a + conj(b)
-            const v2f o = (v2f){a.y + b.y, b.x - a.x};           // 2O = -i (a - conj(b))
+            const v2f e = add_conj(a, b);                        // 2E = a + conj(b)
+            const v2f o = mi_sub_conj(a, b);                     // 2O = -i (a - conj(b))
             const v2f t = cmul(w480[16 * k2], o);
             const v2f xp = e + t, xm = e - t;
             const float pk = fmaf(xp.x, xp.x, xp.y * xp.y);      // 4 |X[k]|^2

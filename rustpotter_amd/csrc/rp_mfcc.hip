@@ -90,52 +90,63 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     size_t wt = (size_t)blockIdx.x * kMfccWaves + wave;
     size_t s = wt / tiles_per_stream;
     unsigned tile = (unsigned)(wt - s * tiles_per_stream);
-    for (; wt < total_tiles; wt += wave_stride, s += stride_s, tile += stride_t) {
-        if (tile >= tiles_per_stream) { tile -= tiles_per_stream; ++s; }
-        const size_t j0 = first_frame + (size_t)tile * kMfccFramesPerWave;
-        const TIN *x = pcm + s * pcm_stride;
-        // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift.
-        // All loads are issued unconditionally (clamped index) before the first use, so the wave
-        // pays one memory round trip per tile instead of one per load.
-        const size_t base = (j0 + 1) * kShift;
-        const size_t last = n_samples - 1;
+    // The samples of a tile are fetched one tile ahead (raw, decoded when they are used): the HBM round trip runs under
+    // the previous tile's FFT instead of in front of this one's.  All loads are unconditional (clamped index).
+    using Raw4 = typename SampleIn<TIN>::Raw4;
+    constexpr int NV = VEC4 ? 4 : 1, NS = VEC4 ? 4 : kMfccStage / 64;
+    Raw4 cur4[NV];
+    TIN cur1[NS], prv[NS];
+    const size_t last = n_samples - 1;
+    auto fetch = [&](size_t fs, unsigned ftile) {
+        const TIN *x = pcm + fs * pcm_stride;
+        const size_t base = (first_frame + (size_t)ftile * kMfccFramesPerWave + 1) * kShift;
         if (VEC4) {
-            float4 cur[4];
-            float prv[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int q = it * 64 + lane;            // float4 index inside the 960-sample tile
+                const int q = it * 64 + lane;            // 4-sample group inside the 960-sample tile
                 size_t g = base + 4 * (size_t)(q < 240 ? q : 239);
                 g = g + 3 <= last ? g : (last - 3) & ~(size_t)3;
-                cur[it] = SampleIn<TIN>::load4(x + g);
-                prv[it] = SampleIn<TIN>::cvt(x[g - 1]);
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int q = it * 64 + lane;
-                const float p0 = (q % (kShift / 4) == 0) ? 0.f : prv[it];
-                float4 y;
-                y.x = cur[it].x - 0.97f * p0;  // separate multiply and subtract, like the reference
-                y.y = cur[it].y - 0.97f * cur[it].x;
-                y.z = cur[it].z - 0.97f * cur[it].y;
-                y.w = cur[it].w - 0.97f * cur[it].z;
-                if (q < 240) *reinterpret_cast<float4 *>(ypre + 4 * q) = y;
+                cur4[it] = SampleIn<TIN>::ldraw(x + g);
+                prv[it] = x[g - 1];
             }
         } else {
-            float cur[kMfccStage / 64], prv[kMfccStage / 64];
 #pragma unroll
             for (int it = 0; it < kMfccStage / 64; ++it) {
                 size_t g = base + it * 64 + lane;
                 g = g <= last ? g : last;
-                cur[it] = SampleIn<TIN>::cvt(x[g]);
-                prv[it] = SampleIn<TIN>::cvt(x[g - 1]);
+                cur1[it] = x[g];
+                prv[it] = x[g - 1];
             }
+        }
+    };
+    if (wt < total_tiles) fetch(s, tile);
+    while (wt < total_tiles) {
+        const size_t j0 = first_frame + (size_t)tile * kMfccFramesPerWave;
+        // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift.
+        if (VEC4) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int q = it * 64 + lane;
+                const float4 c = SampleIn<TIN>::cvt4(cur4[it]);
+                const float p0 = (q % (kShift / 4) == 0) ? 0.f : SampleIn<TIN>::cvt(prv[it]);
+                float4 y;
+                y.x = c.x - 0.97f * p0;  // separate multiply and subtract, like the reference
+                y.y = c.y - 0.97f * c.x;
+                y.z = c.z - 0.97f * c.y;
+                y.w = c.w - 0.97f * c.z;
+                if (q < 240) *reinterpret_cast<float4 *>(ypre + 4 * q) = y;
+            }
+        } else {
 #pragma unroll
             for (int it = 0; it < kMfccStage / 64; ++it) {
                 const int i = it * 64 + lane;
-                ypre[i] = cur[it] - 0.97f * ((i % kShift == 0) ? 0.f : prv[it]);
+                ypre[i] = SampleIn<TIN>::cvt(cur1[it]) - 0.97f * ((i % kShift == 0) ? 0.f : SampleIn<TIN>::cvt(prv[it]));
             }
         }
+        const size_t s_now = s;
+        wt += wave_stride; s += stride_s; tile += stride_t;
+        if (tile >= tiles_per_stream) { tile -= tiles_per_stream; ++s; }
+        if (wt < total_tiles) fetch(s, tile);
         wave_lds_sync();
         // ---- step 1: lane n2=l (<15): FFT16 over n1 of z[15*n1 + n2], z[n] = (y[2n], y[2n+1]) * hamming
         v2f v[16];
@@ -214,9 +225,9 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
         // multiply-then-add in the reference's order (NOT fused): see the file header.
         const size_t j = j0 + grp;
         if (j < first_frame + n_frames) {
-            float *dst = out + (s * out_frame_pitch + (j - first_frame)) * (size_t)K;
+            float *dst = out + (s_now * out_frame_pitch + (j - first_frame)) * (size_t)K;
             // optional second copy, frames packed [n_frames][K] (the single-stream path hands the new frames to the host)
-            float *dst2 = out2 ? out2 + (s * n_frames + (j - first_frame)) * (size_t)K : nullptr;
+            float *dst2 = out2 ? out2 + (s_now * n_frames + (j - first_frame)) * (size_t)K : nullptr;
             for (int c = 1 + l; c <= K; c += 16) {
                 float sum = 0.f;
                 for (int n = 0; n < K1; ++n) sum += lgb[n] * dct[c * K1 + n];

@@ -219,20 +219,46 @@ __global__ __launch_bounds__(64 * kR48Waves) void resample48_fft_kernel(
     // (has_hist), the stream's previous input frame `prev` [S][1440], or silence (the overlap half stays zero).
     // Samples are decoded here (Sample::into_f32, first channel of every interleaved frame).
     const bool vec = sizeof(TIN) == 4 && channels == 1 && (xs_pitch & 3) == 0;
-    for (long c = (c0 == 0 && !has_hist && !prev) ? 0 : c0 - 1; c < c1; ++c) {
+    // the next frame's samples are fetched (raw) while this frame is transformed: the HBM round trip is off the chain
+    using Raw4 = typename SampleIn<TIN>::Raw4;
+    constexpr int kV4 = (360 + 63) / 64, kV1 = (1440 + 63) / 64;
+    Raw4 r4[kV4];
+    TIN r1[kV1];
+    auto fetch = [&](long c) {
+        const TIN *x = xs + s * xs_pitch + (size_t)(c + (has_hist ? 1 : 0)) * 1440 * channels;
+        if (vec) {
+#pragma unroll
+            for (int k = 0; k < kV4; ++k) { const int i = k * 64 + lane; r4[k] = SampleIn<TIN>::ldraw(x + 4 * (i < 360 ? i : 359)); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kV1; ++k) { const int i = k * 64 + lane; r1[k] = x[(size_t)(i < 1440 ? i : 1439) * channels]; }
+        }
+    };
+    auto land = [&]() {
+        if (vec) {
+#pragma unroll
+            for (int k = 0; k < kV4; ++k) {
+                const int i = k * 64 + lane;
+                if (i < 360) reinterpret_cast<float4 *>(xin)[i] = SampleIn<TIN>::cvt4(r4[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kV1; ++k) { const int i = k * 64 + lane; if (i < 1440) xin[i] = SampleIn<TIN>::cvt(r1[k]); }
+        }
+    };
+    const long c_first = (c0 == 0 && !has_hist && !prev) ? 0 : c0 - 1;
+    bool fetched = false;
+    for (long c = c_first; c < c1; ++c) {
         wave_lds_sync();
         if (c < 0 && prev) {
             const float *x = prev + s * 1440;
             for (int i = lane; i < 360; i += 64) reinterpret_cast<float4 *>(xin)[i] = reinterpret_cast<const float4 *>(x)[i];
         } else {
-            const TIN *x = xs + s * xs_pitch + (size_t)(c + (has_hist ? 1 : 0)) * 1440 * channels;
-            if (vec) {
-                for (int i = lane; i < 360; i += 64)
-                    reinterpret_cast<float4 *>(xin)[i] = SampleIn<TIN>::load4(x + 4 * i);
-            } else {
-                for (int i = lane; i < 1440; i += 64) xin[i] = SampleIn<TIN>::cvt(x[(size_t)i * channels]);
-            }
+            if (!fetched) fetch(c);
+            land();
         }
+        fetched = c + 1 < c1;
+        if (fetched) fetch(c + 1);
         wave_lds_sync();
         if (prev_out && c == (long)n_chunks - 1) {  // the last input frame is the next call's history
             float *po = prev_out + s * 1440;

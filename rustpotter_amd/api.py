@@ -485,8 +485,9 @@ class StreamBatch:
     def chunks_seen(self):
         return self._L.rp_stream_batch_chunks_seen(self._h)
 
-    def process(self, pcm, max_det=4, want_agg=False):
-        """pcm [S][n_chunks*480] numpy (i8 / i16 / i32 / f32) -> (det, n_det[, agg]) for these chunks."""
+    def process(self, pcm, max_det=4, want_agg=False, n_chunks=None):
+        """pcm [S][n_chunks*480] numpy (i8 / i16 / i32 / f32) -> (det, n_det[, agg]) for these chunks.  With n_chunks
+        given, rows may be longer than the chunks they carry (row pitch = pcm.shape[1])."""
         import numpy as np
         assert self.ctx.host
         pcm = np.ascontiguousarray(pcm)
@@ -495,12 +496,13 @@ class StreamBatch:
             pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
         S, N = pcm.shape
         spc = self.samples_per_chunk
-        if S != self.S or N % spc:
+        if S != self.S or (n_chunks is None and N % spc) or (n_chunks is not None and n_chunks * spc > N):
             raise ValueError("pcm must be [S][n_chunks*samples_per_chunk]")
+        nc = N // spc if n_chunks is None else n_chunks
         det = np.zeros((S, max_det), dtype=DET_DTYPE)
         n_det = np.zeros(S, np.int32)
-        agg = np.empty((S, 3 * (N // spc)), np.float32) if want_agg else None
-        if self._L.rp_stream_batch_process(self._h, pcm.ctypes.data, fmt, N // spc, N, det.ctypes.data, n_det.ctypes.data, max_det,
+        agg = np.empty((S, 3 * nc), np.float32) if want_agg else None
+        if self._L.rp_stream_batch_process(self._h, pcm.ctypes.data, fmt, nc, N, det.ctypes.data, n_det.ctypes.data, max_det,
                                            None if agg is None else agg.ctypes.data) < 0:
             raise _err()
         return (det, n_det, agg) if want_agg else (det, n_det)

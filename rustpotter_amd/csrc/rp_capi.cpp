@@ -723,6 +723,9 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         if (!dp || !dd || !dn) { if (!pcm || !det || !n_det) set_last_error("null argument"); return -1; }
         const float *hp_old = b->pcm[b->pcur].as<float>();
         float *hp = b->pcm[b->pcur ^ 1].as<float>();
+        // 16 kHz mono input is read where it lies: the MFCC kernel takes [history chunk | new chunks] from two buffers and
+        // leaves the last chunk as the next call's history.  Other inputs are staged into one row per stream first.
+        bool staged = false;
         if (b->rs) {  // previous input frame | new input frames -> 16 kHz (the resampler never resets, src/detector.rs:290-302)
             const size_t fi = b->in_len;
             float *ro = b->rs_out.as<float>();
@@ -744,11 +747,11 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
             }
             b->rs_cur ^= 1;
             if (!hip_ok(launch_stream_stage(c->stream, ro, 3, 1, S, n_chunks * 480, n_chunks * 480, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
-        } else if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks * 480, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) {
-            // previous chunk | new chunks, decoded to f32
-            return -1;
+            staged = true;
+        } else if (b->channels != 1) {  // previous chunk | new chunks (first channel), decoded to f32
+            if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks * 480, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+            staged = true;
         }
-        b->pcur ^= 1; b->last_off = n_chunks * 480;  // the last chunk of this call is the extractor history of the next
         // MFCC window rows: [.. valid frames .. | the 3*n_chunks new frames]; a full row keeps its last max_len-1 frames
         if (b->fill + n_new > b->cap) {
             if (!hip_ok(launch_carry_rows(c->stream, b->mfcc[b->cur].as<float>(), S, pitch * td.K, (b->fill - hist) * td.K, hist * td.K,
@@ -757,10 +760,27 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         }
         float *now = b->mfcc[b->cur].as<float>();
         const size_t fill = b->fill;
-        c->time_begin(kKernelMfcc);
-        bool ok = hip_ok(launch_mfcc(c->stream, *tb, hp, S, n_samples, pcm_pitch, 0, n_new, pitch, now + fill * td.K), "mfcc_kernel");
-        c->time_end();
-        if (!ok) return -1;
+        bool ok = true;
+        if (!staged) {
+            c->time_begin(kKernelMfcc);
+            hipError_t e = launch_mfcc_stream(c->stream, *tb, dp, (int)fmt, S, n_chunks, pcm_stride, hp_old + b->last_off, pcm_pitch, hp, pitch,
+                                              now + fill * td.K);
+            c->time_end();
+            if (e == hipErrorNotSupported) {  // rows that do not allow 4-sample loads
+                if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, 1, S, n_chunks * 480, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+                staged = true;
+            } else {
+                if (!hip_ok(e, "mfcc_kernel")) return -1;
+                b->pcur ^= 1; b->last_off = 0;  // hist_out: the last chunk of this call at the start of the other buffer's rows
+            }
+        }
+        if (staged) {
+            b->pcur ^= 1; b->last_off = n_chunks * 480;  // the last chunk of this call is the extractor history of the next
+            c->time_begin(kKernelMfcc);
+            ok = hip_ok(launch_mfcc(c->stream, *tb, hp, S, n_samples, pcm_pitch, 0, n_new, pitch, now + fill * td.K), "mfcc_kernel");
+            c->time_end();
+            if (!ok) return -1;
+        }
         b->fill += n_new;
         float *ds = b->scores.as<float>(), *dg = b->agg.as<float>(), *da = do_avg ? b->avg.as<float>() : nullptr;
         c->time_begin(kKernelDtw);

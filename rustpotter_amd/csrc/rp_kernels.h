@@ -107,6 +107,9 @@ hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm
                        float *mfcc2 = nullptr);
 
 // pcm in one of the reference's sample formats (rp_sample_format: 0 i8, 1 i16, 2 i32, 3 f32), decoded in the kernel
+hipError_t launch_mfcc_stream(hipStream_t st, const MfccTablesDev &tb, const void *pcm, int fmt, size_t S, size_t n_chunks,
+                              size_t pcm_stride, const float *hist, size_t hist_pitch, float *hist_out, size_t out_frame_pitch,
+                              float *mfcc);
 hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *pcm, int fmt, size_t S, size_t n_samples,
                            size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc);
 

@@ -32,12 +32,18 @@ template <int K1T> __device__ constexpr bool mel_uses(int f, int k2, bool mirror
 }
 
 // K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.  TIN: input sample type.
-template <bool VEC4, int K1T, class TIN>
+// HS (live-stream batches): the stream is [history chunk | new chunks] in two buffers -- samples 0..479 are the
+// previous call's last chunk, decoded f32 at hist[s * hist_pitch + i]; sample 480 + i is pcm[s * pcm_stride + i] -- and the
+// kernel leaves this call's last chunk (decoded) at hist_out for the next call, so that no staging copy runs in front
+// of it.  n_samples counts the history chunk.  Needs VEC4.
+template <bool VEC4, int K1T, class TIN, bool HS = false>
 __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     const TIN *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
     size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1rt, const float *__restrict__ g_ham,
     const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
-    const float *__restrict__ g_dct, float *__restrict__ out, float *__restrict__ out2) {
+    const float *__restrict__ g_dct, float *__restrict__ out, float *__restrict__ out2,
+    const float *__restrict__ hist = nullptr, size_t hist_pitch = 0, float *__restrict__ hist_out = nullptr) {
+    static_assert(!HS || VEC4, "the history split is implemented for 4-sample loads");
     const int K1 = K1T > 0 ? K1T : K1rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v2f *scr_all = reinterpret_cast<v2f *>(smem);               // [waves][4][240]
@@ -96,18 +102,41 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     constexpr int NV = VEC4 ? 4 : 1, NS = VEC4 ? 4 : kMfccStage / 64;
     Raw4 cur4[NV];
     TIN cur1[NS], prv[NS];
+    f32x4 hcur[HS ? 4 : 1];  // HS: the groups of a stream's first tile that lie in the history chunk (f32x4: a float4
+                              // struct array would be copied through scratch)
+    float hprv[HS ? 4 : 1];
     const size_t last = n_samples - 1;
+    // position of 4-sample group `it` of this lane in the stream (clamped to the last whole group)
+    auto group_pos = [&](unsigned ftile, int it) {
+        const size_t base = (first_frame + (size_t)ftile * kMfccFramesPerWave + 1) * kShift;
+        const int q = it * 64 + lane;                    // 4-sample group inside the 960-sample tile
+        const size_t g = base + 4 * (size_t)(q < 240 ? q : 239);
+        return g + 3 <= last ? g : (last - 3) & ~(size_t)3;
+    };
     auto fetch = [&](size_t fs, unsigned ftile) {
         const TIN *x = pcm + fs * pcm_stride;
         const size_t base = (first_frame + (size_t)ftile * kMfccFramesPerWave + 1) * kShift;
         if (VEC4) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int q = it * 64 + lane;            // 4-sample group inside the 960-sample tile
-                size_t g = base + 4 * (size_t)(q < 240 ? q : 239);
-                g = g + 3 <= last ? g : (last - 3) & ~(size_t)3;
-                cur4[it] = SampleIn<TIN>::ldraw(x + g);
-                prv[it] = x[g - 1];
+                const size_t g = group_pos(ftile, it);
+                if (HS) {  // new data starts at sample 480; only a stream's first tile reaches below it
+                    const size_t gn = g >= kFrame ? g - kFrame : 0;
+                    cur4[it] = SampleIn<TIN>::ldraw(x + gn);
+                    prv[it] = x[gn ? gn - 1 : 0];
+                } else {
+                    cur4[it] = SampleIn<TIN>::ldraw(x + g);
+                    prv[it] = x[g - 1];
+                }
+            }
+            if (HS && ftile == 0 && first_frame == 0) {
+                const float *h = hist + fs * hist_pitch;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const size_t g = group_pos(ftile, it), gh = g < kFrame ? g : kFrame - 4;
+                    hcur[it] = *reinterpret_cast<const f32x4 *>(h + gh);
+                    hprv[it] = h[g <= kFrame ? g - 1 : kFrame - 1];  // g >= 160 in the first tile
+                }
             }
         } else {
 #pragma unroll
@@ -127,8 +156,19 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int q = it * 64 + lane;
-                const float4 c = SampleIn<TIN>::cvt4(cur4[it]);
-                const float p0 = (q % (kShift / 4) == 0) ? 0.f : SampleIn<TIN>::cvt(prv[it]);
+                float4 c = SampleIn<TIN>::cvt4(cur4[it]);
+                float pv = SampleIn<TIN>::cvt(prv[it]);
+                if (HS) {
+                    const size_t g = group_pos(tile, it);
+                    if (tile == 0 && first_frame == 0) {
+                        if (g < kFrame) c = make_float4(hcur[it].x, hcur[it].y, hcur[it].z, hcur[it].w);
+                        pv = g <= kFrame ? hprv[it] : pv;
+                    }
+                    // this call's last chunk is the next call's history (every sample of it is loaded by the stream's
+                    // last tile; groups loaded twice store the same values)
+                    if (g >= n_samples - kFrame) *reinterpret_cast<float4 *>(hist_out + s * hist_pitch + (g - (n_samples - kFrame))) = c;
+                }
+                const float p0 = (q % (kShift / 4) == 0) ? 0.f : pv;
                 float4 y;
                 y.x = c.x - 0.97f * p0;  // separate multiply and subtract, like the reference
                 y.y = c.y - 0.97f * c.x;
@@ -273,6 +313,55 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
     else RP_MFCC_LAUNCH(false, 0);
 #undef RP_MFCC_LAUNCH
     return hipGetLastError();
+}
+
+// Live-stream form: S streams of [history chunk (hist, f32) | n_chunks new chunks (pcm, any sample type)]; the
+// 3 * n_chunks new frames go to mfcc (row pitch out_frame_pitch frames) and the last chunk to hist_out.  Returns
+// hipErrorNotSupported when the rows do not allow 4-sample loads or the mel table is not one of the sparse ones.
+template <class TIN>
+static hipError_t launch_mfcc_stream_t(hipStream_t st, const MfccTablesDev &tb, const TIN *pcm, size_t S, size_t n_chunks,
+                                       size_t pcm_stride, const float *hist, size_t hist_pitch, float *hist_out,
+                                       size_t out_frame_pitch, float *mfcc) {
+    if (S == 0 || n_chunks == 0) return hipSuccess;
+    const size_t n_frames = 3 * n_chunks, n_samples = (1 + n_chunks) * kFrame;
+    const size_t tiles = (n_frames + kMfccFramesPerWave - 1) / kMfccFramesPerWave, total = tiles * S;
+    const size_t lds = mfcc_lds_bytes(tb.K1);
+    const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) &&
+                      (reinterpret_cast<uintptr_t>(hist) % 16 == 0) && (reinterpret_cast<uintptr_t>(hist_out) % 16 == 0) &&
+                      (hist_pitch % 4 == 0);
+    if (!vec4 || lds > 160 * 1024 || tiles > 0xffffffffULL) return hipErrorNotSupported;
+    size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
+    if (blocks > 1536) blocks = 1536;
+#define RP_MFCC_LAUNCH_HS(KT)                                                                                               \
+    do {                                                                                                                   \
+        static bool attr_done = false;                                                                                     \
+        if (!attr_done) {                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<true, KT, TIN, true>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+            if (e != hipSuccess) return e;                                                                                 \
+            attr_done = true;                                                                                              \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((mfcc_kernel<true, KT, TIN, true>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm,   \
+                           n_samples, pcm_stride, (unsigned)tiles, total, (size_t)0, n_frames, out_frame_pitch, tb.K1,     \
+                           tb.hamming, tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc, (float *)nullptr, hist, hist_pitch, hist_out); \
+    } while (0)
+    if (tb.K1 == 6 && tb.mel_sparse) RP_MFCC_LAUNCH_HS(6);
+    else if (tb.K1 == 17 && tb.mel_sparse) RP_MFCC_LAUNCH_HS(17);
+    else RP_MFCC_LAUNCH_HS(0);
+#undef RP_MFCC_LAUNCH_HS
+    return hipGetLastError();
+}
+
+hipError_t launch_mfcc_stream(hipStream_t st, const MfccTablesDev &tb, const void *pcm, int fmt, size_t S, size_t n_chunks,
+                              size_t pcm_stride, const float *hist, size_t hist_pitch, float *hist_out, size_t out_frame_pitch,
+                              float *mfcc) {
+    switch (fmt) {
+    case 0: return launch_mfcc_stream_t<int8_t>(st, tb, static_cast<const int8_t *>(pcm), S, n_chunks, pcm_stride, hist, hist_pitch, hist_out, out_frame_pitch, mfcc);
+    case 1: return launch_mfcc_stream_t<int16_t>(st, tb, static_cast<const int16_t *>(pcm), S, n_chunks, pcm_stride, hist, hist_pitch, hist_out, out_frame_pitch, mfcc);
+    case 2: return launch_mfcc_stream_t<int32_t>(st, tb, static_cast<const int32_t *>(pcm), S, n_chunks, pcm_stride, hist, hist_pitch, hist_out, out_frame_pitch, mfcc);
+    case 3: return launch_mfcc_stream_t<float>(st, tb, static_cast<const float *>(pcm), S, n_chunks, pcm_stride, hist, hist_pitch, hist_out, out_frame_pitch, mfcc);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_mfcc(hipStream_t st, const MfccTablesDev &tb, const float *pcm, size_t S, size_t n_samples,

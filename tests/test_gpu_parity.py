@@ -569,6 +569,42 @@ def test_stream_batch_many_streams_synthetic(ra, ctx):
     assert np.array_equal(total, n_det)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.int16])
+def test_stream_batch_direct_and_staged_input_interleaved(ra, ctx, dtype):
+    """16 kHz mono chunks are read by the MFCC kernel where they lie (history chunk + new chunks from two buffers);
+    rows whose pitch is not a multiple of 4 samples go through the staging copy.  Calls of both kinds, 1-3 chunks each,
+    interleaved on the same streams: aggregates bitwise the offline ones, same detections."""
+    S, N = 200, 480 * 60
+    tm = ra.Templates(ctx, orc.synth_templates(SEED, 8, 100, 5))
+    cfg = ra.RustpotterConfig.default().detector
+    cfg.avg_threshold, cfg.threshold, cfg.min_scores = 0.0, 0.39, 1  # inside the score range of noise: detections come and go
+    pcm = ctx.synth_pcm(SEED, 3, S, N)
+    if dtype == np.int16:
+        pcm = np.round(pcm * 32767.0).astype(np.int16)
+    det, n_det, _, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    sb = ra.StreamBatch(ctx, tm, cfg, S, max_chunks_per_call=3)
+    rng = np.random.default_rng(2)
+    i, total, call = 0, np.zeros(S, np.int64), 0
+    while i < N:
+        nc = min(int(rng.integers(1, 4)), (N - i) // 480)
+        piece = pcm[:, i:i + 480 * nc]
+        if call % 2:  # odd row pitch: the staged path
+            piece = np.concatenate([piece, np.zeros((S, 1), pcm.dtype)], axis=1)
+        d, nd, a = sb.process(piece, want_agg=True, n_chunks=nc)
+        f0 = 3 * (i // 480) - 3
+        for k in range(a.shape[1]):
+            wi = f0 + k - 99
+            if 0 <= wi < agg.shape[1]:
+                assert np.array_equal(a[:, k], agg[:, wi])
+        for si in np.nonzero(nd)[0]:
+            for j in range(nd[si]):
+                assert _det_tuple(d[si][j]) == _det_tuple(det[si][total[si] + j])
+        total += nd
+        i += 480 * nc
+        call += 1
+    assert np.array_equal(total, n_det) and n_det.sum() > 0
+
+
 def test_batch_detect_multi_equals_detector_with_two_wakewords(ra, ctx):
     """Two wakewords in one detector (run_wakeword_detectors, src/detector.rs:433-447): rp_batch_detect_multi against a
     Rustpotter handle that holds both .rpw files, on a stream in which both are spoken; per-wakeword threshold override."""

@@ -569,6 +569,39 @@ def test_stream_batch_many_streams_synthetic(ra, ctx):
     assert np.array_equal(total, n_det)
 
 
+def test_distinct_handles_in_concurrent_threads(ra):
+    """`WakewordDetector: Send`, one detector per thread (SURVEY 8b threading): four `Rustpotter` handles fed from four
+    threads at once (ctypes drops the GIL during a call) each give the detections of a handle run alone."""
+    import threading
+    e = EXP["simulation"]["max"]
+    s16 = simstream.simulation_stream_i16()
+    n = (len(s16) // 480) * 480
+    cfg = _make_config(ra, e)
+
+    def run(shift, out):
+        rp = ra.Rustpotter.new(cfg)
+        rp.add_wakeword_from_file("w", os.path.join(G, e["rpw"]))
+        x = np.roll(s16[:n], 480 * shift)
+        got = []
+        for i in range(0, n, 480):
+            d = rp.process_samples(x[i:i + 480])
+            if d is not None:
+                got.append((i // 480, d.counter, float(d.score), float(d.avg_score)))
+        out.append(got)
+
+    alone = []
+    for k in range(4):
+        run(7 * k, alone)
+    together = [[] for _ in range(4)]
+    threads = [threading.Thread(target=run, args=(7 * k, together[k])) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(len(a) >= 1 for a in alone)
+    assert [t[0] for t in together] == alone
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.int16])
 def test_stream_batch_direct_and_staged_input_interleaved(ra, ctx, dtype):
     """16 kHz mono chunks are read by the MFCC kernel where they lie (history chunk + new chunks from two buffers);

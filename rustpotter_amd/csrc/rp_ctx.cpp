@@ -14,6 +14,8 @@ const std::string &last_error() { return g_last_error; }
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     set_last_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+    (void)hipGetLastError();  // the runtime keeps the code as its "last error": clear it, or the next kernel launch
+                              // (checked with hipGetLastError) would report this failure again
     return false;
 }
 

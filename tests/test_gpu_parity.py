@@ -569,6 +569,19 @@ def test_stream_batch_many_streams_synthetic(ra, ctx):
     assert np.array_equal(total, n_det)
 
 
+def test_allocation_failure_is_an_error_and_does_not_stick(ra, ctx):
+    """A batch too large for the device is refused with the runtime's message, and the failure is not reported again by
+    the next (valid) call: hipGetLastError() keeps failed calls' codes until they are read."""
+    tm = ra.Templates(ctx, orc.synth_templates(SEED, 4, 40, 5))
+    cfg = ra.RustpotterConfig.default().detector
+    with pytest.raises(ra.RustpotterError, match="out of memory"):
+        ra.StreamBatch(ctx, tm, cfg, 1 << 34)
+    pcm = orc.synth_pcm(SEED, 1, 480 * 20)
+    assert mfcc_close(ctx.mfcc(pcm[None, :], 5)[0], orc.mfcc_stream(pcm, 5))
+    det, n_det = ctx.batch_detect(pcm[None, :], tm, cfg)
+    assert n_det.shape == (1,)
+
+
 def test_distinct_handles_in_concurrent_threads(ra):
     """`WakewordDetector: Send`, one detector per thread (SURVEY 8b threading): four `Rustpotter` handles fed from four
     threads at once (ctypes drops the GIL during a call) each give the detections of a handle run alone."""

@@ -257,7 +257,8 @@ int rp_templates_max_len(const rp_templates *t);
  * src/wakewords/comp/wakeword_comp.rs:22-37,77-139 + src/mfcc/comparator.rs +
  * src/mfcc/dtw.rs:56-105 + src/mfcc/normalizer.rs.  n_win = n_frames - max_len + 1.
  * scores [S][n_win][T]; avg [S][n_win] (NULL or ignored when the template set has no
- * avg template / with_avg == 0); agg [S][n_win] = score_mode aggregate. */
+ * avg template / with_avg == 0); agg [S][n_win] = score_mode aggregate.  band_size 0 is
+ * legal as in the reference (u16): no cell lies in the band and every score is 0. */
 int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames, const rp_templates *t,
                        float score_ref, int band_size, rp_score_mode score_mode, int with_avg,
                        float *scores, float *avg, float *agg);

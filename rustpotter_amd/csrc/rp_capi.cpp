@@ -365,7 +365,7 @@ int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const TemplatesDev &td = t->impl->dev;
         if (n_frames < (size_t)td.max_len) return 0;  // no complete window
-        if (band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
+        if (band_size < 0) { set_last_error("band_size must be >= 0"); return -1; }  // 0: no cell is in the band, every score is 0 (dtw.rs:64-75)
         const size_t n_win = n_frames - td.max_len + 1;
         const bool do_avg = with_avg && td.has_avg;
         if (do_avg && !avg) { set_last_error("avg output required when with_avg is set"); return -1; }
@@ -444,7 +444,6 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
-        if (config->band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
         const TemplatesDev &td = t->impl->dev;
         const MfccTablesDev *tb = c->tables_for(td.K);
         if (!tb) return -1;
@@ -508,7 +507,6 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (n_wakewords < 1 || n_wakewords > (size_t)kScanMaxWakewords) { set_last_error("rp_batch_detect_multi: 1..8 wakewords"); return -1; }
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
-        if (config->band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
         const int K = t[0]->impl->dev.K;
         int max_len = 0;
@@ -634,7 +632,6 @@ int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_co
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (S == 0 || max_chunks_per_call == 0) { set_last_error("rp_stream_batch_new: S and max_chunks_per_call must be >= 1"); return -1; }
-        if (config->band_size < 1) { set_last_error("band_size must be >= 1"); return -1; }
         const TemplatesDev &td = t->impl->dev;
         if (!c->tables_for(td.K)) return -1;
         std::unique_ptr<rp_stream_batch> b(new rp_stream_batch());

@@ -478,6 +478,87 @@ def run_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Reference builder (rp_wakeword_ref_build = WakewordRef::new_from_sample_buffers + save_to_buffer) on random wav files:
+# 8-bit unsigned / 16 / 32-bit PCM and IEEE float, mono / stereo, 16 or 48 kHz, 1-6 samples of different lengths.
+# Templates against the oracle's MfccWavFileExtractor restatement and the averaged template against its averager (same
+# DTW path decisions) at the tolerance of tonal signals (1e-4); thresholds, names, shapes as given.
+def _wav_bytes(x, rate, bits, is_float, channels):
+    import struct
+    if is_float:
+        body = x.astype("<f4")
+        dec = body.astype(np.float32)
+    elif bits == 8:
+        q = np.clip(np.round(x * 127.0), -128, 127).astype(np.int16)
+        body = (q + 128).astype(np.uint8)
+        dec = q.astype(np.float32) / np.float32(127.0)
+    elif bits == 16:
+        q = np.clip(np.round(x * 32767.0), -32768, 32767).astype("<i2")
+        body, dec = q, q.astype(np.float32) / np.float32(32767.0)
+    else:
+        q = np.clip(np.round(x.astype(np.float64) * 2147483647.0), -2147483648, 2147483647).astype("<i4")
+        body, dec = q, q.astype(np.float32) / np.float32(2147483648.0)
+    if channels > 1:
+        body = np.stack([body] + [np.roll(body, 7 * (k + 1)) for k in range(channels - 1)], axis=1).reshape(-1)
+    raw = body.tobytes()
+    fmt = struct.pack("<HHIIHH", 3 if is_float else 1, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits)
+    return b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(raw)) + raw, dec
+
+
+def run_builder_sweep(ra, ctx, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    import rpw_py
+    import tempfile
+    checked = 0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 88, ci])
+        K = int(rng.choice([5, 5, 16, 8]))
+        rate = 48000 if rng.random() < 0.25 else 16000
+        n_s = int(rng.integers(1, 7))
+        samples, feats = {}, {}
+        for i in range(n_s):
+            dur = int(rng.integers(30, 110))  # chunks of 30 ms at 16 kHz
+            x = _utterance(rng, 480 * dur)
+            if rate == 48000:
+                x = np.interp(np.arange(3 * len(x)) / 3.0, np.arange(len(x)), x).astype(np.float32)
+            x = x[:len(x) - int(rng.integers(0, 200))]  # ragged ends
+            kind = int(rng.integers(4))
+            data, dec = _wav_bytes(x, rate, (8, 16, 32, 32)[kind], kind == 3, int(rng.choice([1, 1, 2])))
+            name = "s%d.wav" % i
+            samples[name] = data
+            feats[name] = orc.wav_features(dec, rate, K)
+        thr = None if rng.random() < 0.5 else float(rng.uniform(0.3, 0.6))
+        athr = None if rng.random() < 0.5 else float(rng.uniform(0.0, 0.4))
+        built = ctx.build_wakeword_ref("w%d" % ci, samples, K, threshold=thr, avg_threshold=athr, from_files=bool(rng.random() < 0.5))
+        with tempfile.NamedTemporaryFile(suffix=".rpw") as f:
+            f.write(built)
+            f.flush()
+            got = rpw_py.load_rpw(f.name)
+        where = "builder sweep seed %d case %d (K %d, rate %d, %d samples)" % (seed, ci, K, rate, n_s)
+        assert got["name"] == "w%d" % ci and got["mfcc_size"] == K and set(got["samples_features"]) == set(samples), where
+        assert (got["threshold"] is None) == (thr is None) and (thr is None or np.float32(got["threshold"]) == np.float32(thr)), where
+        assert (got["avg_threshold"] is None) == (athr is None) and (athr is None or np.float32(got["avg_threshold"]) == np.float32(athr)), where
+        for k, ref in feats.items():
+            g = got["samples_features"][k]
+            assert g.shape == ref.shape, "%s %s: %r vs %r" % (where, k, g.shape, ref.shape)
+            scale = np.maximum(np.abs(ref), 1.0) if K <= 5 else np.maximum(np.abs(ref).max(axis=-1, keepdims=True), 1.0)
+            # the synthetic utterances are tonal (MFCC sweep: up to 6.6e-5 there, see run_mfcc_sweep); behind the resampler
+            # the features also move with its 4e-6 of the peak
+            tol = 1e-4 if rate == 16000 else 2e-4
+            assert np.all(np.abs(g - ref) <= tol * scale), "%s %s: %.3g" % (where, k, float(np.max(np.abs(g - ref) / scale)))
+        avg = orc.average_templates(feats)
+        if avg is None:
+            assert got["avg_features"] is None, where
+        else:
+            assert got["avg_features"].shape == avg.shape, where
+            assert np.abs(got["avg_features"] - avg).max() <= (1e-4 if rate == 16000 else 2e-4) * max(1.0, float(np.abs(avg).max())), \
+                "%s avg: %.3g" % (where, float(np.abs(got["avg_features"] - avg).max()))
+        checked += n_s
+        if verbose and ci % 20 == 0:
+            print("builder case %d ok, %d samples compared so far" % (ci, checked), flush=True)
+    return n_cases, checked
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Wakeword models (src/wakewords/nn/wakeword_nn.rs) through the single-stream API: random layer sizes of the four model
 # types, random weights, 2-3 labels.  The forward pass is pinned by the oracle only, so scores compare at
 # 1e-4; which chunks fire, the label and the counter must agree.
@@ -549,6 +630,7 @@ if __name__ == "__main__":
     ap.add_argument("--resample-cases", type=int, default=0, help="resampler cases (rates x channels x sample types)")
     ap.add_argument("--frontend-cases", type=int, default=0, help="decode + gain normaliser + band-pass cases")
     ap.add_argument("--mfcc-cases", type=int, default=0, help="MFCC value cases (signal kinds x levels)")
+    ap.add_argument("--builder-cases", type=int, default=0, help="wakeword references built from random wav files")
     ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
     ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
     ap.add_argument("--extreme-cases", type=int, default=0, help="single-stream API cases with edge-of-range detector parameters")
@@ -571,6 +653,8 @@ if __name__ == "__main__":
                               min_level_exp=a.min_level_exp)
     print("mfcc sweep: %d cases, worst scaled error per signal kind %r (gate 1e-5; tones 2e-4): OK" % (
         n, {k: float("%.3g" % v) for k, v in sorted(worst.items())}))
+    n, checked = run_builder_sweep(ra, ra.BatchContext(0), a.builder_cases, a.seed, verbose=True)
+    print("builder sweep: %d cases, %d wav samples compared: OK" % (n, checked))
     n, total = run_multi_sweep(ra, ra.BatchContext(0), a.multi_cases, a.seed, verbose=True)
     print("multi sweep: %d cases, %d detections compared: OK" % (n, total))
     n, total = run_model_sweep(ra, a.model_cases, a.seed, verbose=True)

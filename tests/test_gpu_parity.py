@@ -1263,6 +1263,14 @@ def test_randomised_resample_sweep(ra, ctx):
     assert n == 40 and 0.0 < worst <= 8e-6
 
 
+def test_randomised_builder_sweep(ra, ctx):
+    """20 wakeword references built from random wav files (8 / 16 / 32-bit PCM, float, stereo, 48 kHz) against the oracle's
+    wav extractor and averager."""
+    import sweep_parity
+    n, checked = sweep_parity.run_builder_sweep(ra, ctx, 20, seed=7)
+    assert n == 20 and checked >= 20
+
+
 def test_randomised_api_sweep(ra):
     """12 random single-stream cases through `Rustpotter` chunk by chunk (several wakewords, filters, VAD, resets,
     stereo, 48 kHz) against the oracle's detector: same chunks fire, same name / counter / partial state, scores 1e-5."""

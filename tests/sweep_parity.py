@@ -586,7 +586,8 @@ def make_model_case(rng):
     return dict(model=model, cfg=cfg, x=x.astype(np.float32))
 
 
-def run_model_sweep(ra, n_cases, seed, verbose=False):
+def run_model_sweep(ra, n_cases, seed, verbose=False, ctx=None):
+    """ctx given: the same stream also goes through rp_batch_detect_model (f32) in one call."""
     from oracle import rp_oracle as orc
     import rpw_py
     total = 0
@@ -606,16 +607,28 @@ def run_model_sweep(ra, n_cases, seed, verbose=False):
                                                                m["rms_level"]))
         where = "model sweep seed %d case %d (%r, %s, K %d, frames %d, labels %r)" % (seed, ci, c, m["m_type"], m["mfcc_size"],
                                                                                      m["train_size"], m["labels"])
+        refs = []
         for k in range(len(x) // 480):
             ref = d.process_f32(x[480 * k:480 * (k + 1)])
             got = rp.process_samples(np.ascontiguousarray(x[480 * k:480 * (k + 1)]))
             assert (got is None) == (ref is None), "%s chunk %d: %r vs %r" % (where, k, got, ref)
             if ref is None:
                 continue
+            refs.append((k, ref))
             total += 1
             assert got.name == ref["name"] and got.counter == ref["counter"], "%s chunk %d: %r vs %r" % (where, k, got, ref)
             assert abs(float(got.score) - float(ref["score"])) <= 1e-4 * max(1.0, abs(float(ref["score"]))), \
                 "%s chunk %d: %r vs %r" % (where, k, got, ref)
+        if ctx is not None:
+            nl = len([k for k in m["weights"] if k.endswith(".weight")])
+            model = ra.Model(ctx, [m["weights"]["ln%d.weight" % (i + 1)] for i in range(nl)], [m["weights"]["ln%d.bias" % (i + 1)] for i in range(nl)])
+            none_index = m["labels"].index("none") if "none" in m["labels"] else -1
+            det, dlab, n_det = ctx.batch_detect_model(x[None, :], model, m["mfcc_size"], none_index, dc, max_det=64)
+            assert n_det[0] == len(refs), "%s batched: %d vs %d detections" % (where, n_det[0], len(refs))
+            for j, (k, ref) in enumerate(refs[:64]):
+                assert det[0][j]["frame"] // 3 + 1 == k and det[0][j]["counter"] == ref["counter"] and m["labels"][dlab[0][j]] == ref["name"], \
+                    "%s batched detection %d" % (where, j)
+                assert abs(float(det[0][j]["score"]) - float(ref["score"])) <= 1e-4 * max(1.0, abs(float(ref["score"]))), "%s batched score %d" % (where, j)
         if verbose and ci % 20 == 0:
             print("model case %d ok, %d detections so far" % (ci, total), flush=True)
     return n_cases, total
@@ -657,5 +670,5 @@ if __name__ == "__main__":
     print("builder sweep: %d cases, %d wav samples compared: OK" % (n, checked))
     n, total = run_multi_sweep(ra, ra.BatchContext(0), a.multi_cases, a.seed, verbose=True)
     print("multi sweep: %d cases, %d detections compared: OK" % (n, total))
-    n, total = run_model_sweep(ra, a.model_cases, a.seed, verbose=True)
+    n, total = run_model_sweep(ra, a.model_cases, a.seed, verbose=True, ctx=ra.BatchContext(0))
     print("model sweep: %d cases, %d detections compared: OK" % (n, total))

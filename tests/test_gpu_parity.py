@@ -1271,14 +1271,14 @@ def test_randomised_builder_sweep(ra, ctx):
     assert n == 20 and checked >= 20
 
 
-def test_randomised_api_sweep(ra):
+def test_randomised_api_sweep(ra, ctx):
     """12 random single-stream cases through `Rustpotter` chunk by chunk (several wakewords, filters, VAD, resets,
     stereo, 48 kHz) against the oracle's detector: same chunks fire, same name / counter / partial state, scores 1e-5."""
     import sweep_parity
     n, total = sweep_parity.run_api_sweep(ra, 12, seed=7)
     assert n == 12 and total >= 3
     # wakeword models of the four types with random layer sizes / weights / labels
-    n, total = sweep_parity.run_model_sweep(ra, 16, seed=7)
+    n, total = sweep_parity.run_model_sweep(ra, 16, seed=7, ctx=ctx)  # ctx: rp_batch_detect_model on the same streams too
     assert n == 16 and total >= 3
 
 

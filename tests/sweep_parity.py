@@ -171,6 +171,62 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Live-stream batches with `Rustpotter::reset` of single streams (rp_stream_batch_reset) at random call boundaries, against
+# the oracle's detector reset at the same chunks.
+def run_live_reset_sweep(ra, ctx, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    total = 0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 22, ci])
+        case = make_case(rng)
+        c, pcm = case["cfg"], case["pcm"]
+        S, cpc = pcm.shape[0], case["chunks_per_call"]
+        n = (pcm.shape[1] // 480) * 480
+        calls = list(range(0, n, 480 * cpc))
+        resets = {}  # call index -> streams reset in front of it (-1: all)
+        for _ in range(int(rng.integers(1, 4))):
+            resets.setdefault(int(rng.integers(len(calls))), []).append(int(rng.integers(-1, S)))
+        dc = ra.DetectorConfig()
+        dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
+        dc.score_ref, dc.band_size = c["score_ref"], c["band_size"]
+        dc.score_mode = getattr(ra.ScoreMode, c["score_mode"].capitalize())
+        dc.vad_mode = {None: None, "easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[c["vad_mode"]]
+        tm = ra.Templates(ctx, case["templates"], avg=case["avg"])
+        sb = ra.StreamBatch(ctx, tm, dc, S, max_chunks_per_call=cpc)
+        ww = {"name": "w", "samples_features": {"t%d" % i: t for i, t in enumerate(case["templates"])},
+              "avg_features": case["avg"], "threshold": None, "avg_threshold": None, "rms_level": 0.0}
+        dets = []
+        for s in range(S):
+            d = orc.Detector(avg_threshold=c["avg_threshold"], threshold=c["threshold"], min_scores=c["min_scores"], eager=c["eager"],
+                             score_ref=c["score_ref"], band_size=c["band_size"], score_mode=c["score_mode"], vad_mode=c["vad_mode"])
+            d.add_ref(ww)
+            dets.append(d)
+        ref = [[] for _ in range(S)]
+        live = [[] for _ in range(S)]
+        for k, i in enumerate(calls):
+            for who in resets.get(k, []):
+                sb.reset(who)
+                for s in (range(S) if who < 0 else [who]):
+                    dets[s].reset()
+            piece = np.ascontiguousarray(pcm[:, i:min(i + 480 * cpc, n)])
+            dd, nd = sb.process(piece, max_det=16)
+            for s in range(S):
+                live[s] += [(int(dd[s][j]["frame"]) // 3 + 1, int(dd[s][j]["counter"]), float(dd[s][j]["score"]), float(dd[s][j]["avg_score"]))
+                            for j in range(nd[s])]
+                for q in range(piece.shape[1] // 480):
+                    x = piece[s, 480 * q:480 * (q + 1)]
+                    r = dets[s].process_i16(x) if x.dtype == np.int16 else dets[s].process_f32(x)
+                    if r is not None:
+                        ref[s].append((i // 480 + q, int(r["counter"]), float(r["score"]), float(r["avg_score"])))
+        ok = all(_same(l, r, 1e-5) for l, r in zip(live, ref))
+        assert ok, "live reset sweep seed %d case %d: cfg %r resets %r cpc %d\noracle %r\nlive   %r" % (seed, ci, c, resets, cpc, ref, live)
+        total += sum(len(r) for r in ref)
+        if verbose and ci % 20 == 0:
+            print("live-reset case %d ok, %d detections so far" % (ci, total), flush=True)
+    return n_cases, total
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # The single-stream drop-in API (`Rustpotter`, src/detector.rs) chunk by chunk against the oracle's detector: several
 # wakewords with their own thresholds, gain normaliser / band-pass, VAD, resets in mid-stream, i16 / f32 input,
 # mono / stereo, 16 kHz or 48 kHz (resampler in front).
@@ -646,12 +702,15 @@ if __name__ == "__main__":
     ap.add_argument("--builder-cases", type=int, default=0, help="wakeword references built from random wav files")
     ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
     ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
+    ap.add_argument("--reset-cases", type=int, default=0, help="live-stream batches with single-stream resets")
     ap.add_argument("--extreme-cases", type=int, default=0, help="single-stream API cases with edge-of-range detector parameters")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
     a = ap.parse_args()
     import rustpotter_amd as ra
     n, total, ties = run_sweep(ra, ra.BatchContext(0), a.cases, a.seed, verbose=True)
     print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
+    n, total = run_live_reset_sweep(ra, ra.BatchContext(0), a.reset_cases, a.seed, verbose=True)
+    print("live reset sweep: %d cases, %d detections compared: OK" % (n, total))
     n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
     print("api sweep: %d cases, %d detections compared: OK" % (n, total))
     n, total, ties = run_sweep(ra, ra.BatchContext(0), a.extreme_cases, a.seed + 2000, verbose=True, extreme=True)

@@ -1236,6 +1236,9 @@ def test_randomised_parity_sweep(ra, ctx):
     import sweep_parity
     n, total, ties = sweep_parity.run_sweep(ra, ctx, 24, seed=7)
     assert n == 24 and total >= 10 and ties <= 2
+    # live-stream batches with single streams reset at random call boundaries
+    n, total = sweep_parity.run_live_reset_sweep(ra, ctx, 16, seed=7)
+    assert n == 16
     # 1-3 wakewords with their own thresholds in rp_batch_detect_multi
     n, total = sweep_parity.run_multi_sweep(ra, ctx, 16, seed=7)
     assert n == 16 and total >= 3

@@ -348,8 +348,9 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
  * the first rp_stream_batch_process -- default 16 kHz mono.  Input that is not 16 kHz is converted per call
  * exactly as one Rustpotter per stream would (the first channel of every frame, rubato-style resampling with the
  * previous input frame of every stream kept on the device; the resampler is not touched by resets).  A chunk is
- * then rp_stream_batch_samples_per_chunk() samples (= get_samples_per_frame(): 1 440 for 48 kHz mono).  Rates
- * whose resampled frame is not 480 samples (the 22.05 kHz family) are refused here. */
+ * then rp_stream_batch_samples_per_chunk() samples (= get_samples_per_frame(): 1 440 for 48 kHz mono).  For the
+ * 11.025 / 22.05 kHz family a chunk is a 40 ms frame (640 encoded samples): a stream then gains four MFCC frames per
+ * chunk (agg has 4 * n_chunks columns) and a detection drops the rest of its 40 ms frame, as in the reference. */
 int rp_stream_batch_set_input(rp_stream_batch *b, size_t sample_rate, int channels);
 size_t rp_stream_batch_samples_per_chunk(const rp_stream_batch *b);
 /* Rustpotter::reset (src/detector.rs:290-302) of one stream, or of all when stream < 0. */

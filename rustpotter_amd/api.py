@@ -475,6 +475,8 @@ class StreamBatch:
         if (sample_rate, channels) != (16000, 1) and self._L.rp_stream_batch_set_input(h, sample_rate, channels) < 0:
             raise _err()
         self.samples_per_chunk = self._L.rp_stream_batch_samples_per_chunk(h)
+        # MFCC frames a stream gains per input frame: 3 (30 ms frames) or 4 (the 40 ms frames of 11.025 / 22.05 kHz input)
+        self.frames_per_chunk = resampler_frame_lengths(sample_rate)[1] // 160
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -501,7 +503,7 @@ class StreamBatch:
         nc = N // spc if n_chunks is None else n_chunks
         det = np.zeros((S, max_det), dtype=DET_DTYPE)
         n_det = np.zeros(S, np.int32)
-        agg = np.empty((S, 3 * nc), np.float32) if want_agg else None
+        agg = np.empty((S, self.frames_per_chunk * nc), np.float32) if want_agg else None
         if self._L.rp_stream_batch_process(self._h, pcm.ctypes.data, fmt, nc, N, det.ctypes.data, n_det.ctypes.data, max_det,
                                            None if agg is None else agg.ctypes.data) < 0:
             raise _err()

@@ -36,6 +36,8 @@ struct rp_stream_batch {
     // resampler plan with every stream's previous input frame
     int channels = 1;
     size_t in_len = 480;
+    size_t out_len = 480;    // encoded (16 kHz) samples per input frame: 480, or 640 for the 11.025 / 22.05 kHz family
+    size_t fpf() const { return out_len / 160; }  // MFCC frames a stream gains per input frame (3 or 4)
     const Resampler *rs = nullptr;
     DevBuf rs_prev[2], rs_xs, rs_out;
     int rs_cur = 0;
@@ -624,6 +626,31 @@ int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int ch
     });
 }
 
+// buffers of a fresh batch, sized for the current input frame length (30 ms frames: 3 MFCC frames each, 40 ms: 4)
+static bool stream_batch_alloc(rp_stream_batch *b) {
+    Ctx *c = b->c;
+    const TemplatesDev &td = b->t->dev;
+    const size_t S = b->S, fpf = b->fpf();
+    b->cap = b->hist_frames + fpf * b->max_chunks * 8;  // compaction every 8 full-size calls
+    const size_t pitch = b->cap, rows = S * fpf * b->max_chunks;
+    const size_t slack = 64 * (size_t)td.K * sizeof(float);  // the DTW band reads up to band_size frames past a row
+    const size_t pcm_bytes = S * (480 + b->max_chunks * b->out_len) * sizeof(float);
+    if (!b->pcm[0].reserve(pcm_bytes) || !b->pcm[1].reserve(pcm_bytes) || !b->mfcc[0].reserve(S * pitch * td.K * sizeof(float) + slack) ||
+        !b->mfcc[1].reserve(S * pitch * td.K * sizeof(float) + slack) || !b->state.reserve(S * stream_state_bytes()) ||
+        !b->scores.reserve(rows * td.T * sizeof(float) + 16) || !b->agg.reserve(rows * sizeof(float) + 16) ||
+        !b->avg.reserve(rows * sizeof(float) + 16) || !b->vad.reserve(rows * sizeof(float) + 16))
+        return false;
+    if (!hip_ok(hipMemsetAsync(b->pcm[0].p, 0, b->pcm[0].cap, c->stream), "hipMemsetAsync") ||
+        !hip_ok(hipMemsetAsync(b->pcm[1].p, 0, b->pcm[1].cap, c->stream), "hipMemsetAsync") ||
+        !hip_ok(hipMemsetAsync(b->mfcc[0].p, 0, b->mfcc[0].cap, c->stream), "hipMemsetAsync") ||
+        !hip_ok(hipMemsetAsync(b->mfcc[1].p, 0, b->mfcc[1].cap, c->stream), "hipMemsetAsync") ||
+        !hip_ok(launch_stream_state_init(c->stream, b->state.p, S), "stream_state_init_kernel"))
+        return false;
+    b->cur = 0; b->fill = b->hist_frames;  // an all-zero history nobody scores against (frames < 0)
+    b->pcur = 0; b->last_off = 0;
+    return true;
+}
+
 int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_config *config, size_t S,
                         size_t max_chunks_per_call, rp_stream_batch **out) {
     return guarded([&]() -> int {
@@ -637,23 +664,7 @@ int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_co
         std::unique_ptr<rp_stream_batch> b(new rp_stream_batch());
         b->c = c; b->t = t->impl.get(); b->cfg = *config; b->S = S; b->max_chunks = max_chunks_per_call;
         b->hist_frames = (size_t)td.max_len - 1;
-        b->cap = b->hist_frames + 3 * max_chunks_per_call * 8;  // compaction every 8 full-size calls
-        const size_t pitch = b->cap, rows = S * 3 * max_chunks_per_call;
-        const size_t slack = 64 * (size_t)td.K * sizeof(float);  // the DTW band reads up to band_size frames past a row
-        const size_t pcm_bytes = S * (1 + max_chunks_per_call) * 480 * sizeof(float);
-        if (!b->pcm[0].reserve(pcm_bytes) || !b->pcm[1].reserve(pcm_bytes) || !b->mfcc[0].reserve(S * pitch * td.K * sizeof(float) + slack) ||
-            !b->mfcc[1].reserve(S * pitch * td.K * sizeof(float) + slack) || !b->state.reserve(S * stream_state_bytes()) ||
-            !b->scores.reserve(rows * td.T * sizeof(float) + 16) || !b->agg.reserve(rows * sizeof(float) + 16) ||
-            !b->avg.reserve(rows * sizeof(float) + 16) || !b->vad.reserve(rows * sizeof(float) + 16))
-            return -1;
-        if (!hip_ok(hipMemsetAsync(b->pcm[0].p, 0, pcm_bytes, c->stream), "hipMemsetAsync") ||
-            !hip_ok(hipMemsetAsync(b->pcm[1].p, 0, pcm_bytes, c->stream), "hipMemsetAsync") ||
-            !hip_ok(hipMemsetAsync(b->mfcc[0].p, 0, b->mfcc[0].cap, c->stream), "hipMemsetAsync") ||
-            !hip_ok(hipMemsetAsync(b->mfcc[1].p, 0, b->mfcc[1].cap, c->stream), "hipMemsetAsync") ||
-            !hip_ok(launch_stream_state_init(c->stream, b->state.p, S), "stream_state_init_kernel"))
-            return -1;
-        b->cur = 0; b->fill = b->hist_frames;  // an all-zero history nobody scores against (frames < 0)
-        b->pcur = 0; b->last_off = 0;
+        if (!stream_batch_alloc(b.get())) return -1;
         *out = b.release();
         return 0;
     });
@@ -670,13 +681,16 @@ int rp_stream_batch_set_input(rp_stream_batch *b, size_t sample_rate, int channe
         if (channels < 1) { set_last_error("Unsupported channel count"); return -1; }
         size_t fi = 480, fo = 480;
         if (!resampler_frame_lengths(sample_rate, &fi, &fo)) { set_last_error("Unsupported sample rate, unable to initialize the resampler"); return -1; }
-        if (fo != 480) { set_last_error("rp_stream_batch: this input rate yields frames of four 10 ms shifts; only 30 ms frames are batched"); return -1; }
         b->channels = channels; b->in_len = fi; b->rs = nullptr;
+        if (fo != b->out_len) {  // 11.025 / 22.05 kHz: 40 ms frames of four 10 ms shifts
+            b->out_len = fo;
+            if (!stream_batch_alloc(b)) return -1;
+        }
         if (sample_rate != 16000) {
             b->rs = c->resampler_for(sample_rate);
             if (!b->rs) return -1;
             if (!b->rs_prev[0].reserve(b->S * fi * sizeof(float)) || !b->rs_prev[1].reserve(b->S * fi * sizeof(float)) ||
-                !b->rs_out.reserve(b->S * b->max_chunks * 480 * sizeof(float))) return -1;
+                !b->rs_out.reserve(b->S * b->max_chunks * fo * sizeof(float))) return -1;
             if (!b->rs->dev.fft48 && !b->rs_xs.reserve(b->S * (1 + b->max_chunks) * fi * sizeof(float) + 64)) return -1;
             if (!hip_ok(hipMemsetAsync(b->rs_prev[0].p, 0, b->S * fi * sizeof(float), c->stream), "hipMemsetAsync")) return -1;
             b->rs_cur = 0;
@@ -693,7 +707,7 @@ int rp_stream_batch_reset(rp_stream_batch *b, long long stream) {
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (stream >= (long long)b->S) { set_last_error("rp_stream_batch_reset: no such stream"); return -1; }
         // the next chunk only refills the extractor: its three frames (3C-3 .. 3C-1) are never emitted
-        return hip_ok(launch_stream_state_reset(c->stream, b->state.p, b->S, stream, 3 * (long long)b->chunks_seen), "stream_state_reset_kernel") ? 0 : -1;
+        return hip_ok(launch_stream_state_reset(c->stream, b->state.p, b->S, stream, (long long)b->fpf() * (long long)b->chunks_seen), "stream_state_reset_kernel") ? 0 : -1;
     });
 }
 
@@ -710,8 +724,10 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         const TemplatesDev &td = b->t->dev;
         const MfccTablesDev *tb = c->tables_for(td.K);
         if (!tb) return -1;
-        const size_t S = b->S, n_new = 3 * n_chunks, hist = b->hist_frames, pitch = b->cap, rows = S * n_new;
-        const size_t n_samples = (1 + n_chunks) * 480, pcm_pitch = (1 + b->max_chunks) * 480;
+        const size_t fo = b->out_len, new_len = n_chunks * fo;  // encoded samples this call adds to every stream
+        const size_t S = b->S, n_new = b->fpf() * n_chunks, hist = b->hist_frames, pitch = b->cap, rows = S * n_new;
+        // a row is [the last 480 encoded samples of the previous call | the new ones]
+        const size_t n_samples = 480 + new_len, pcm_pitch = 480 + b->max_chunks * fo;
         const bool do_avg = td.has_avg && b->cfg.avg_threshold != 0.f;
         Staged sg(c);
         const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
@@ -727,9 +743,9 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
             const size_t fi = b->in_len;
             float *ro = b->rs_out.as<float>();
             float *pv = b->rs_prev[b->rs_cur].as<float>(), *pn = b->rs_prev[b->rs_cur ^ 1].as<float>();
-            if (resample_reads_in_place(b->rs->dev, dp, (int)fmt, pcm_stride, ro, n_chunks * 480)) {
+            if (resample_reads_in_place(b->rs->dev, dp, (int)fmt, pcm_stride, ro, new_len)) {
                 c->time_begin(kKernelResample);
-                bool okr = hip_ok(launch_resample_in_place(c->stream, b->rs->dev, dp, (int)fmt, b->channels, pcm_stride, pv, pn, S, n_chunks, ro, n_chunks * 480), "resample48_fft_kernel");
+                bool okr = hip_ok(launch_resample_in_place(c->stream, b->rs->dev, dp, (int)fmt, b->channels, pcm_stride, pv, pn, S, n_chunks, ro, new_len), "resample48_fft_kernel");
                 c->time_end();
                 if (!okr) return -1;
             } else {
@@ -737,16 +753,16 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
                 float *xs = b->rs_xs.as<float>();
                 if (!hip_ok(launch_resample_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks, (int)fi, pcm_stride, pv, xs), "resample_stage_kernel")) return -1;
                 c->time_begin(kKernelResample);
-                bool okr = hip_ok(launch_resample(c->stream, b->rs->dev, xs, S, n_chunks, ro, n_chunks * 480), "resample kernel");
+                bool okr = hip_ok(launch_resample(c->stream, b->rs->dev, xs, S, n_chunks, ro, new_len), "resample kernel");
                 c->time_end();
                 if (!okr) return -1;
                 if (!hip_ok(launch_carry_rows(c->stream, xs, S, (1 + n_chunks) * fi, n_chunks * fi, fi, pn, fi), "carry_rows_kernel")) return -1;
             }
             b->rs_cur ^= 1;
-            if (!hip_ok(launch_stream_stage(c->stream, ro, 3, 1, S, n_chunks * 480, n_chunks * 480, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+            if (!hip_ok(launch_stream_stage(c->stream, ro, 3, 1, S, new_len, new_len, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
             staged = true;
         } else if (b->channels != 1) {  // previous chunk | new chunks (first channel), decoded to f32
-            if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, n_chunks * 480, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+            if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, b->channels, S, new_len, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
             staged = true;
         }
         // MFCC window rows: [.. valid frames .. | the 3*n_chunks new frames]; a full row keeps its last max_len-1 frames
@@ -764,7 +780,7 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
                                               now + fill * td.K);
             c->time_end();
             if (e == hipErrorNotSupported) {  // rows that do not allow 4-sample loads
-                if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, 1, S, n_chunks * 480, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
+                if (!hip_ok(launch_stream_stage(c->stream, dp, (int)fmt, 1, S, new_len, pcm_stride, hp_old, b->last_off, hp, pcm_pitch), "stream_stage_kernel")) return -1;
                 staged = true;
             } else {
                 if (!hip_ok(e, "mfcc_kernel")) return -1;
@@ -772,7 +788,7 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
             }
         }
         if (staged) {
-            b->pcur ^= 1; b->last_off = n_chunks * 480;  // the last chunk of this call is the extractor history of the next
+            b->pcur ^= 1; b->last_off = new_len;  // the last 480 samples of this call are the extractor history of the next
             c->time_begin(kKernelMfcc);
             ok = hip_ok(launch_mfcc(c->stream, *tb, hp, S, n_samples, pcm_pitch, 0, n_new, pitch, now + fill * td.K), "mfcc_kernel");
             c->time_end();
@@ -794,10 +810,10 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         }
         ScanConfig sc;
         sc.threshold = b->cfg.threshold; sc.avg_threshold = b->cfg.avg_threshold; sc.min_scores = (int)b->cfg.min_scores;
-        sc.eager = b->cfg.eager ? 1 : 0; sc.max_len = td.max_len; sc.avg_enabled = do_avg ? 1 : 0;
+        sc.eager = b->cfg.eager ? 1 : 0; sc.max_len = td.max_len; sc.avg_enabled = do_avg ? 1 : 0; sc.fpf = (int)b->fpf();
         if (dv && !hip_ok(launch_vad_value_rows(c->stream, now + fill * td.K, S, n_new, pitch, td.K, dv), "vad_value_kernel")) return -1;
         c->time_begin(kKernelScan);
-        ok = hip_ok(launch_scan_stream(c->stream, dg, da, dv, vad_mode_value(b->cfg.vad_mode), S, 3 * (long long)b->chunks_seen - 3, (int)n_new,
+        ok = hip_ok(launch_scan_stream(c->stream, dg, da, dv, vad_mode_value(b->cfg.vad_mode), S, (long long)b->fpf() * (long long)b->chunks_seen - 3, (int)n_new,
                                        sc, b->state.p, dd, dn, max_det), "scan_stream_kernel");
         c->time_end();
         if (!ok) return -1;

@@ -84,6 +84,7 @@ constexpr int kR48OffTw240 = 0, kR48OffTw480 = 240, kR48OffTwc = 480, kR48OffW96
 struct ScanConfig {
     float threshold, avg_threshold;
     int min_scores, eager, max_len, avg_enabled;
+    int fpf = 3;  // MFCC frames per input frame of the stream's encoder: 3 (480 encoded samples) or 4 (640: 11.025 / 22.05 kHz input)
 };
 
 // the wakewords of one detector in the batched scan (run_wakeword_detectors, src/detector.rs:433-447): per wakeword

@@ -9,7 +9,9 @@ namespace rp {
 // reset() of :290-302, one lane per stream, over precomputed window scores.  Frame f
 // is emitted while chunk c = f/3 + 1 is processed; after an emit the extractor and the
 // window are cleared, the rest of that chunk's frames are dropped (find_map, :372-375),
-// chunk c+1 only refills the extractor, so the next frame seen is 3*(f/3) + 6.
+// chunk c+1 only refills the extractor, so the next frame seen is 3*(f/3) + 6.  In general, with fpf frames per
+// input frame (4 behind the 11.025 / 22.05 kHz resampler): frame f's last shift f+3 lies in chunk c = (f+3)/fpf, the
+// refill starts with shift fpf*(c+1) and its fourth shift completes frame fpf*(c+1).
 // mean(|mfcc|) of every frame, summed in coefficient order like VadDetector::is_voice (src/mfcc/vad.rs:12)
 __global__ __launch_bounds__(256) void vad_value_kernel(const float *__restrict__ mfcc, size_t n, int K, float *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
                         if (det_ww) det_ww[s * (size_t)max_det + nd] = p_ww;
                     }
                     ++nd;
-                    win_start = resume = 3 * (f / 3) + 6;  // reset()
+                    win_start = resume = cfg.fpf * ((f + 3) / cfg.fpf + 1);  // reset()
                     if (vv) {  // vad.reset()
                         for (int i = 0; i < 50; ++i) vwin[i][lane] = __builtin_nanf("");
                         vad_index = 0; voice_countdown = 0;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(const float *__restrict
                         det[s * (size_t)max_det + nd] = d;
                     }
                     ++nd;
-                    z.win_start = z.resume = 3 * (f / 3) + 6;
+                    z.win_start = z.resume = cfg.fpf * ((f + 3) / cfg.fpf + 1);
                     if (vv) { for (int j = 0; j < 50; ++j) vwin[j][lane] = __builtin_nanf(""); z.vad_index = 0; z.voice_countdown = 0; }
                     continue;
                 }

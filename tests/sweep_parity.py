@@ -237,7 +237,7 @@ def run_live_rate_sweep(ra, ctx, n_cases, seed, verbose=False):
         rng = np.random.default_rng([seed, 23, ci])
         case = make_case(rng)
         c = case["cfg"]
-        rate = int(rng.choice([48000, 48000, 8000, 32000, 44100, 24000, 96000]))  # 30 ms output frames (the batch refuses the 40 ms ones of 22.05 / 11.025 kHz)
+        rate = int(rng.choice([48000, 48000, 8000, 32000, 44100, 24000, 96000, 22050, 11025]))  # the last two: 40 ms frames
         ch = int(rng.choice([1, 2]))
         cpc = int(rng.integers(1, 4))
         fi, fo = ra.resampler_frame_lengths(rate)
@@ -296,7 +296,9 @@ def run_live_rate_sweep(ra, ctx, n_cases, seed, verbose=False):
         det, n_det = ctx.batch_detect(y, tm, dc, max_det=kMaxDet)
         off = [[((int(det[s][j]["frame"]) + 3) // fpf, int(det[s][j]["counter"]), float(det[s][j]["score"]), float(det[s][j]["avg_score"]))
                 for j in range(min(int(n_det[s]), kMaxDet))] + [None] * max(0, int(n_det[s]) - kMaxDet) for s in range(S)]
-        assert all(_same(l, o, 0.0) for l, o in zip(live, off)), "live rate sweep seed %d case %d: rate %d ch %d cpc %d %s: live != offline\n%r\n%r" % (
+        # (40 ms input frames: a detection drops the rest of ITS input frame and the offline pass over 16 kHz audio cuts
+        # frames of 30 ms, so the two legitimately part ways after the first detection of a stream)
+        assert fpf != 3 or all(_same(l, o, 0.0) for l, o in zip(live, off)), "live rate sweep seed %d case %d: rate %d ch %d cpc %d %s: live != offline\n%r\n%r" % (
             seed, ci, rate, ch, cpc, raw.dtype, live, off)
         # (2) against the oracle's resampler + detector.  Behind the resampler the audio differs by up to 4e-6 of the
         # peak, so a VAD or threshold comparison that is nearly a tie can go the other way: such cases are counted

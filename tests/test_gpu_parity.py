@@ -511,8 +511,9 @@ def test_stream_batch_48k_stereo_equals_resample_then_offline(ra, ctx):
                     assert a[si, k] == agg[si, wi]
     for si in range(3):
         assert got[si] == [_det_tuple(det[si][j]) for j in range(n_det[si])]
-    with pytest.raises(ra.RustpotterError, match="four 10 ms shifts"):
-        ra.StreamBatch(ctx, tm, cfg, 3, sample_rate=22050)
+    # 22.05 kHz input: 882-sample frames -> 640 encoded samples = four MFCC frames per input frame
+    sb22 = ra.StreamBatch(ctx, tm, cfg, 3, sample_rate=22050)
+    assert sb22.samples_per_chunk == 882 and sb22.frames_per_chunk == 4
 
 
 def test_stream_batch_wide_templates_generic_tiling(ra, ctx):

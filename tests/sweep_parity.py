@@ -357,9 +357,11 @@ def make_api_case(rng, extreme=False):
         u = utts[int(rng.integers(len(utts)))] * np.float32(rng.uniform(0.7, 1.2))
         at = int(rng.integers(0, max(1, len(x) - len(u))))
         x[at:at + len(u)] += u[:len(x) - at]
-    rate = 48000 if rng.random() < 0.2 else 16000
-    if rate == 48000:  # any 48 kHz signal will do: the encoder in front of the detector is what is compared
-        x = np.interp(np.arange(3 * len(x)) / 3.0, np.arange(len(x)), x).astype(np.float32)
+    rate = int(rng.choice([48000, 48000, 22050, 11025, 8000, 44100, 32000])) if rng.random() < 0.3 else 16000
+    if rate != 16000:  # any signal at that rate will do: the encoder in front of the detector is what is compared
+        m = int(len(x) * rate / 16000)
+        x = np.interp(np.arange(m) * (16000.0 / rate), np.arange(len(x)), x).astype(np.float32)
+        x = np.where(np.abs(x) < 1e-7, np.float32(1e-3) * rng.standard_normal(m).astype(np.float32), x)  # no digital silence behind a resampler
     fmt = str(rng.choice(["f32", "i16"]))
     if fmt == "i16":
         x = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)

@@ -706,6 +706,83 @@ def run_builder_sweep(ra, ctx, n_cases, seed, verbose=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Model trainer (rp_wakeword_model_train = WakewordModel::train_from_buffers): random labelled wav sets, the four model
+# types, mfcc sizes, learning rates and epoch counts.  The start is the product's own seeded initialisation (0 epochs,
+# read back from its file); from there the same full-batch SGD epochs as the oracle's restatement must give the same
+# weights and loss (1e-4 of the larger of weight scale and movement, as in tests/test_gpu_parity.py).
+def run_train_sweep(ra, ctx, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    import rpw_py
+    import tempfile
+
+    def load(data):
+        with tempfile.NamedTemporaryFile(suffix=".rpw") as f:
+            f.write(data)
+            f.flush()
+            return rpw_py.load_rpw(f.name)
+
+    skipped = 0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 99, 7, ci])
+        K = int(rng.choice([16, 16, 8, 5]))
+        m_type = str(rng.choice(["tiny", "small", "medium", "large"]))
+        labels_pool = ["alpha", "beta"][:int(rng.integers(1, 3))]
+        rate = 48000 if rng.random() < 0.2 else 16000
+        train, feats = {}, {}
+        for i in range(int(rng.integers(4, 10))):
+            lab = None if (i % 3 == 2) else labels_pool[i % len(labels_pool)]
+            # broadband samples (shaped noise): their MFCCs agree with the oracle's at 1e-5, so the weights can be held to a
+            # tight tolerance (tonal signals move the features by up to 6e-5, see run_mfcc_sweep)
+            n = 480 * int(rng.integers(40, 90))
+            env = np.interp(np.arange(n), np.linspace(0, n, 12), rng.uniform(0.05, 1.0, 12))
+            x = (env * rng.standard_normal(n) * rng.uniform(0.02, 0.2)).astype(np.float32)
+            if rate == 48000:
+                x = np.interp(np.arange(3 * len(x)) / 3.0, np.arange(len(x)), x).astype(np.float32)
+            data, dec = _wav_bytes(x, rate, 16, False, 1)
+            name = ("[%s]s%d.wav" % (lab, i)) if lab else ("noise%d.wav" % i)
+            train[name] = data
+            feats[name] = orc.wav_features(dec, rate, K).reshape(-1)
+        test = dict(list(train.items())[:2])
+        lr, epochs = float(rng.choice([0.002, 0.01, 0.027])), int(rng.integers(1, 8))
+        where = "train sweep seed %d case %d (%s, K %d, rate %d, %d samples, lr %g, %d epochs)" % (seed, ci, m_type, K, rate, len(train), lr, epochs)
+        try:
+            init, _, _ = ctx.train_wakeword_model(train, test, m_type, lr, 0, 1, K, seed=int(rng.integers(1, 1000)))
+        except ra.RustpotterError as e:  # samples too short for the type: the reference refuses them as well
+            assert "too short" in str(e), where + ": " + str(e)
+            continue
+        m0 = load(init)
+        L = m0["train_size"] * K
+        names = list(train)
+        xs = np.zeros((len(names), L), np.float32)
+        ys = []
+        for r, name in enumerate(names):
+            f = feats[name]
+            xs[r, :min(L, len(f))] = f[:L]
+            ys.append(m0["labels"].index(name[1:name.index("]")] if name.startswith("[") else "none"))
+        nl = len([k for k in m0["weights"] if k.endswith(".weight")])
+        ws = [m0["weights"]["ln%d.weight" % (i + 1)] for i in range(nl)]
+        bs = [m0["weights"]["ln%d.bias" % (i + 1)] for i in range(nl)]
+        data, loss, acc = ctx.train_wakeword_model(train, test, "tiny", lr, epochs, 1, 5, seed=1, prev_model=init)
+        m1 = load(data)
+        assert m1["m_type"] == m0["m_type"] and m1["labels"] == m0["labels"] and m1["train_size"] == m0["train_size"], where
+        rw, rb, rloss = orc.mlp_train(xs, ys, ws, bs, lr, epochs)
+        if not np.isfinite(rloss) or rloss > 20.0:  # a diverging run amplifies the last bit of every feature: nothing to compare
+            skipped += 1
+            continue
+        assert abs(loss - rloss) <= 2e-4 * max(abs(rloss), 1e-3), "%s: loss %g vs %g" % (where, loss, rloss)
+        for i in range(nl):
+            for kind, ref, start in (("weight", rw[i], ws[i]), ("bias", rb[i], bs[i])):
+                got = m1["weights"]["ln%d.%s" % (i + 1, kind)]
+                assert got.shape == ref.shape, where
+                tol = 2e-4 * max(float(np.abs(ref).max()), float(np.abs(ref - start).max()))
+                assert np.abs(got - ref).max() <= tol, "%s ln%d.%s: %.3g > %.3g" % (where, i + 1, kind, float(np.abs(got - ref).max()), tol)
+        if verbose and ci % 10 == 0:
+            print("train case %d ok (%d diverging runs skipped so far)" % (ci, skipped), flush=True)
+    assert skipped <= n_cases // 3, "train sweep: %d of %d runs diverged" % (skipped, n_cases)
+    return n_cases - skipped
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Wakeword models (src/wakewords/nn/wakeword_nn.rs) through the single-stream API: random layer sizes of the four model
 # types, random weights, 2-3 labels.  The forward pass is pinned by the oracle only, so scores compare at
 # 1e-4; which chunks fire, the label and the counter must agree.
@@ -790,6 +867,7 @@ if __name__ == "__main__":
     ap.add_argument("--resample-cases", type=int, default=0, help="resampler cases (rates x channels x sample types)")
     ap.add_argument("--frontend-cases", type=int, default=0, help="decode + gain normaliser + band-pass cases")
     ap.add_argument("--mfcc-cases", type=int, default=0, help="MFCC value cases (signal kinds x levels)")
+    ap.add_argument("--train-cases", type=int, default=0, help="wakeword models trained from random labelled wav sets")
     ap.add_argument("--builder-cases", type=int, default=0, help="wakeword references built from random wav files")
     ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
     ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
@@ -819,6 +897,8 @@ if __name__ == "__main__":
                               min_level_exp=a.min_level_exp)
     print("mfcc sweep: %d cases, worst scaled error per signal kind %r (gate 1e-5; tones 2e-4): OK" % (
         n, {k: float("%.3g" % v) for k, v in sorted(worst.items())}))
+    n = run_train_sweep(ra, ra.BatchContext(0), a.train_cases, a.seed, verbose=True)
+    print("train sweep: %d cases: OK" % n)
     n, checked = run_builder_sweep(ra, ra.BatchContext(0), a.builder_cases, a.seed, verbose=True)
     print("builder sweep: %d cases, %d wav samples compared: OK" % (n, checked))
     n, total = run_multi_sweep(ra, ra.BatchContext(0), a.multi_cases, a.seed, verbose=True)

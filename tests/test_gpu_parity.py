@@ -1278,6 +1278,13 @@ def test_randomised_builder_sweep(ra, ctx):
     assert n == 20 and checked >= 20
 
 
+def test_randomised_train_sweep(ra, ctx):
+    """6 wakeword models trained from random labelled wav sets (four model types, mfcc sizes, learning rates, epochs):
+    same weights and loss as the oracle's training loop from the same start."""
+    import sweep_parity
+    assert sweep_parity.run_train_sweep(ra, ctx, 6, seed=7) >= 4
+
+
 def test_randomised_api_sweep(ra, ctx):
     """12 random single-stream cases through `Rustpotter` chunk by chunk (several wakewords, filters, VAD, resets,
     stereo, 48 kHz) against the oracle's detector: same chunks fire, same name / counter / partial state, scores 1e-5."""

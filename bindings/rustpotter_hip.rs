@@ -138,3 +138,58 @@ pub fn wakeword_ref_from_sample_buffers(name: &str, threshold: Option<f32>, avg_
         res
     }
 }
+
+// ---- offline tooling: WakewordModel::train_from_buffers(..).save_to_buffer() on the device -----------------
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_train_options { pub m_type: c_int, pub learning_rate: f32, pub epochs: usize, pub test_epochs: usize, pub mfcc_size: u16, pub seed: u64 }
+extern "C" {
+    pub fn rp_wakeword_model_train(ctx: *mut rp_ctx, options: *const rp_train_options, n_train: usize, train_names: *const *const c_char,
+                                   train_wavs: *const *const u8, train_lens: *const usize, n_test: usize, test_names: *const *const c_char,
+                                   test_wavs: *const *const u8, test_lens: *const usize, prev_model: *const u8, prev_model_len: usize,
+                                   out_rpw: *mut *mut u8, out_len: *mut usize, final_loss: *mut f32, test_accuracy: *mut f32) -> c_int;
+}
+/// `WakewordModelTrain::train_from_buffers` + `save_to_buffer` (src/wakewords/nn/wakeword_model_train.rs:44-168):
+/// `m_type` 0..3 = ModelType::Tiny..Large; returns (`.rpw` bytes, last loss, test accuracy).
+pub fn wakeword_model_train_from_buffers(m_type: c_int, train: &HashMap<String, Vec<u8>>, test: &HashMap<String, Vec<u8>>,
+                                         learning_rate: f64, epochs: usize, test_epochs: usize, mfcc_size: u16,
+                                         wakeword_model: Option<&[u8]>) -> Result<(Vec<u8>, f32, f32), String> {
+    fn pack(d: &HashMap<String, Vec<u8>>) -> (Vec<CString>, Vec<*const u8>, Vec<usize>) {
+        (d.keys().map(|k| CString::new(k.as_str()).unwrap()).collect(), d.values().map(|v| v.as_ptr()).collect(), d.values().map(|v| v.len()).collect())
+    }
+    let (trn, trb, trl) = pack(train);
+    let (ten, teb, tel) = pack(test);
+    let trp: Vec<*const c_char> = trn.iter().map(|n| n.as_ptr()).collect();
+    let tep: Vec<*const c_char> = ten.iter().map(|n| n.as_ptr()).collect();
+    let opt = rp_train_options { m_type, learning_rate: learning_rate as f32, epochs, test_epochs, mfcc_size, seed: 1 };
+    unsafe {
+        let mut ctx = std::ptr::null_mut();
+        if rp_ctx_new(0, 0, &mut ctx) < 0 { return Err(last_error()); }
+        let (mut out, mut out_len, mut loss, mut acc) = (std::ptr::null_mut(), 0usize, 0f32, 0f32);
+        let (pm, pl) = wakeword_model.map_or((std::ptr::null(), 0), |m| (m.as_ptr(), m.len()));
+        let r = rp_wakeword_model_train(ctx, &opt, trp.len(), trp.as_ptr(), trb.as_ptr(), trl.as_ptr(), tep.len(), tep.as_ptr(), teb.as_ptr(),
+                                        tel.as_ptr(), pm, pl, &mut out, &mut out_len, &mut loss, &mut acc);
+        let res = if r < 0 { Err(last_error()) } else { Ok((std::slice::from_raw_parts(out, out_len).to_vec(), loss, acc)) };
+        if !out.is_null() { rp_buffer_free(out); }
+        rp_ctx_free(ctx);
+        res
+    }
+}
+
+// ---- server side: S live streams per call instead of one `Rustpotter` per stream ----
+pub enum rp_templates {}
+pub enum rp_stream_batch {}
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct rp_batch_detection { pub stream: i32, pub frame: i32, pub window: i32, pub counter: i32, pub avg_score: f32, pub score: f32 }
+extern "C" {
+    pub fn rp_templates_new(ctx: *mut rp_ctx, t: c_int, k: c_int, lens: *const c_int, feats: *const f32, avg_len: c_int, avg: *const f32,
+                            out: *mut *mut rp_templates) -> c_int;
+    pub fn rp_templates_free(t: *mut rp_templates);
+    pub fn rp_stream_batch_new(ctx: *mut rp_ctx, t: *const rp_templates, config: *const rp_detector_config, s: usize,
+                               max_chunks_per_call: usize, out: *mut *mut rp_stream_batch) -> c_int;
+    pub fn rp_stream_batch_free(b: *mut rp_stream_batch);
+    pub fn rp_stream_batch_set_input(b: *mut rp_stream_batch, sample_rate: usize, channels: c_int) -> c_int;
+    pub fn rp_stream_batch_samples_per_chunk(b: *const rp_stream_batch) -> usize;
+    /// pcm: S rows of n_chunks chunks (host pointers with RP_CTX_HOST_POINTERS, else device pointers); fmt = rp_sample_format
+    pub fn rp_stream_batch_process(b: *mut rp_stream_batch, pcm: *const std::ffi::c_void, fmt: c_int, n_chunks: usize, pcm_stride: usize,
+                                   det: *mut rp_batch_detection, n_det: *mut i32, max_det: c_int, agg: *mut f32) -> c_int;
+    pub fn rp_stream_batch_reset(b: *mut rp_stream_batch, stream: i64) -> c_int;
+    pub fn rp_stream_batch_chunks_seen(b: *const rp_stream_batch) -> usize;
+}

@@ -39,7 +39,9 @@ def _utterance(rng, n):
 
 def make_case(rng, extreme=False):
     from oracle import rp_oracle as orc
-    K = int(rng.choice([5, 5, 5, 16, 3, 8, 12, 1]))
+    # (mfcc size 1 is left to the MFCC sweep: with one coefficient every cosine is +-1, window scores repeat exactly and
+    # which of two equal-scoring windows a detection reports -- its avg_score -- hangs on the last bit)
+    K = int(rng.choice([5, 5, 5, 16, 3, 8, 12, 2]))
     T = int(rng.integers(1, 9))
     if rng.random() < 0.3:
         lens = np.full(T, int(rng.integers(20, 100)))

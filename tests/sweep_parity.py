@@ -879,31 +879,40 @@ if __name__ == "__main__":
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
     a = ap.parse_args()
     import rustpotter_amd as ra
-    n, total, ties = run_sweep(ra, ra.BatchContext(0), a.cases, a.seed, verbose=True)
-    print("sweep: %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
-    n, total, nt = run_live_rate_sweep(ra, ra.BatchContext(0), a.rate_cases, a.seed, verbose=True)
-    print("live rate sweep: %d cases live == offline bitwise, %d detections equal to the oracle's, %d near-tie cases: OK" % (n, total, nt))
-    n, total = run_live_reset_sweep(ra, ra.BatchContext(0), a.reset_cases, a.seed, verbose=True)
-    print("live reset sweep: %d cases, %d detections compared: OK" % (n, total))
-    n, total = run_api_sweep(ra, a.cases // 4 if a.api_cases is None else a.api_cases, a.seed, verbose=True)
-    print("api sweep: %d cases, %d detections compared: OK" % (n, total))
-    n, total, ties = run_sweep(ra, ra.BatchContext(0), a.extreme_cases, a.seed + 2000, verbose=True, extreme=True)
-    print("sweep (extreme detector parameters): %d cases, %d detections compared, %d threshold ties skipped: OK" % (n, total, ties))
-    n, total = run_api_sweep(ra, a.extreme_cases, a.seed + 1000, verbose=True, extreme=True)
-    print("api sweep (extreme detector parameters): %d cases, %d detections compared: OK" % (n, total))
-    n, worst = run_resample_sweep(ra, ra.BatchContext(0), a.resample_cases, a.seed, verbose=True)
-    print("resample sweep: %d cases, worst error %.3g of the peak (gate 4e-6, x sqrt(fi / 1440) above 48 kHz): OK" % (n, worst))
-    n, checked = run_frontend_sweep(ra, ra.BatchContext(0), a.frontend_cases, a.seed, verbose=True)
-    print("frontend sweep: %d cases, %d streams compared bit for bit: OK" % (n, checked))
-    n, worst = run_mfcc_sweep(ra, ra.BatchContext(0), a.mfcc_cases, a.seed, verbose=True, strict=not a.report,
-                              min_level_exp=a.min_level_exp)
-    print("mfcc sweep: %d cases, worst scaled error per signal kind %r (gate 1e-5; tones 2e-4): OK" % (
-        n, {k: float("%.3g" % v) for k, v in sorted(worst.items())}))
-    n = run_train_sweep(ra, ra.BatchContext(0), a.train_cases, a.seed, verbose=True)
-    print("train sweep: %d cases: OK" % n)
-    n, checked = run_builder_sweep(ra, ra.BatchContext(0), a.builder_cases, a.seed, verbose=True)
-    print("builder sweep: %d cases, %d wav samples compared: OK" % (n, checked))
-    n, total = run_multi_sweep(ra, ra.BatchContext(0), a.multi_cases, a.seed, verbose=True)
-    print("multi sweep: %d cases, %d detections compared: OK" % (n, total))
-    n, total = run_model_sweep(ra, a.model_cases, a.seed, verbose=True, ctx=ra.BatchContext(0))
-    print("model sweep: %d cases, %d detections compared: OK" % (n, total))
+    ctx = ra.BatchContext(0)
+    mfcc_line = lambda r: "%d cases, worst scaled error per signal kind %r (gate 1e-5; tones 2e-4)" % (
+        r[0], {k: float("%.3g" % v) for k, v in sorted(r[1].items())})
+    families = [  # (name, number of cases, run, result -> text); a failing family is reported and the others still run
+        ("sweep", a.cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True),
+         lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
+        ("live rate sweep", a.rate_cases, lambda n: run_live_rate_sweep(ra, ctx, n, a.seed, verbose=True),
+         lambda r: "%d cases live == offline bitwise, %d detections equal to the oracle's, %d near-tie cases" % r),
+        ("live reset sweep", a.reset_cases, lambda n: run_live_reset_sweep(ra, ctx, n, a.seed, verbose=True),
+         lambda r: "%d cases, %d detections compared" % r),
+        ("api sweep", a.cases // 4 if a.api_cases is None else a.api_cases, lambda n: run_api_sweep(ra, n, a.seed, verbose=True),
+         lambda r: "%d cases, %d detections compared" % r),
+        ("sweep (extreme detector parameters)", a.extreme_cases, lambda n: run_sweep(ra, ctx, n, a.seed + 2000, verbose=True, extreme=True),
+         lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
+        ("api sweep (extreme detector parameters)", a.extreme_cases, lambda n: run_api_sweep(ra, n, a.seed + 1000, verbose=True, extreme=True),
+         lambda r: "%d cases, %d detections compared" % r),
+        ("resample sweep", a.resample_cases, lambda n: run_resample_sweep(ra, ctx, n, a.seed, verbose=True),
+         lambda r: "%d cases, worst error %.3g of the peak (gate 4e-6, x sqrt(fi / 1440) above 48 kHz)" % r),
+        ("frontend sweep", a.frontend_cases, lambda n: run_frontend_sweep(ra, ctx, n, a.seed, verbose=True),
+         lambda r: "%d cases, %d streams compared bit for bit" % r),
+        ("mfcc sweep", a.mfcc_cases, lambda n: run_mfcc_sweep(ra, ctx, n, a.seed, verbose=True, strict=not a.report, min_level_exp=a.min_level_exp), mfcc_line),
+        ("train sweep", a.train_cases, lambda n: (run_train_sweep(ra, ctx, n, a.seed, verbose=True),), lambda r: "%d cases" % r),
+        ("builder sweep", a.builder_cases, lambda n: run_builder_sweep(ra, ctx, n, a.seed, verbose=True),
+         lambda r: "%d cases, %d wav samples compared" % r),
+        ("multi sweep", a.multi_cases, lambda n: run_multi_sweep(ra, ctx, n, a.seed, verbose=True), lambda r: "%d cases, %d detections compared" % r),
+        ("model sweep", a.model_cases, lambda n: run_model_sweep(ra, n, a.seed, verbose=True, ctx=ctx), lambda r: "%d cases, %d detections compared" % r),
+    ]
+    failed = 0
+    for name, n, run, text in families:
+        if n <= 0:
+            continue
+        try:
+            print("%s: %s: OK" % (name, text(run(n))), flush=True)
+        except AssertionError as e:
+            failed += 1
+            print("%s: FAILED: %s" % (name, str(e)[:3000]), flush=True)
+    sys.exit(1 if failed else 0)

@@ -4,7 +4,7 @@ import sweep_parity as sp
 import rustpotter_amd as ra
 ctx = ra.BatchContext(0)
 seed, ci = int(sys.argv[1]), int(sys.argv[2])
-case = sp.make_case(np.random.default_rng([seed, ci]))
+case = sp.make_case(np.random.default_rng([seed, ci]), extreme=len(sys.argv) > 3)
 ref = sp.oracle_detections(case)
 off, live, agg = sp.device_detections(ra, ctx, case)
 print(case["cfg"], case["K"], [len(t) for t in case["templates"]], case["pcm"].shape, case["pcm"].dtype, case["chunks_per_call"])

@@ -583,6 +583,49 @@ def test_allocation_failure_is_an_error_and_does_not_stick(ra, ctx):
     assert n_det.shape == (1,)
 
 
+def test_handles_release_their_device_memory(ra, ctx):
+    """Creating and dropping detectors, template sets, models, live-stream batches and contexts 150 times leaves the
+    device's free memory (hipMemGetInfo) and the process's resident set where they were, within the slack of the
+    runtime's own pools."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    e = EXP["simulation"]["max"]
+    cfg = _make_config(ra, e)
+    s16 = simstream.simulation_stream_i16()
+    tmpl = orc.synth_templates(SEED, 8, 100, 5)
+    m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
+
+    def cycle():
+        rp = ra.Rustpotter.new(cfg)
+        rp.add_wakeword_from_file("w", os.path.join(G, e["rpw"]))
+        for i in range(0, 480 * 40, 480):
+            rp.process_samples(s16[i:i + 480])
+        del rp
+        c2 = ra.BatchContext(0)
+        tm = ra.Templates(c2, tmpl)
+        sb = ra.StreamBatch(c2, tm, cfg.detector, 256, max_chunks_per_call=2)
+        sb.process(np.zeros((256, 960), np.float32))
+        mdl = ra.Model(c2, [m["weights"]["ln1.weight"], m["weights"]["ln2.weight"]], [m["weights"]["ln1.bias"], m["weights"]["ln2.bias"]])
+        c2.batch_detect(np.zeros((4, 480 * 50), np.float32), tm, cfg.detector)
+        del sb, mdl, tm, c2
+
+    import psutil
+    for _ in range(5):
+        cycle()
+    before, rss0 = free_bytes(), psutil.Process().memory_info().rss
+    for _ in range(150):
+        cycle()
+    after, rss1 = free_bytes(), psutil.Process().memory_info().rss
+    assert before - after < 64 << 20, "device memory shrank by %.1f MB over 150 create / free cycles" % ((before - after) / 2**20)
+    assert rss1 - rss0 < 96 << 20, "host memory grew by %.1f MB over 150 create / free cycles" % ((rss1 - rss0) / 2**20)
+
+
 def test_distinct_handles_in_concurrent_threads(ra):
     """`WakewordDetector: Send`, one detector per thread (SURVEY 8b threading): four `Rustpotter` handles fed from four
     threads at once (ctypes drops the GIL during a call) each give the detections of a handle run alone."""

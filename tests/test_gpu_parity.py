@@ -1291,6 +1291,46 @@ def test_randomised_parity_sweep(ra, ctx):
     assert n == 16 and total >= 3
 
 
+def test_long_streams_offline_and_live(ra, ctx):
+    """Two ~2.5 minute streams (5 000 chunks: hundreds of window-buffer compactions in the live batch, thousands of
+    detections' worth of state-machine resets): offline batch and live batch against the oracle's chunked detector."""
+    import sweep_parity
+    case = sweep_parity.make_case(np.random.default_rng([7, 123]))
+    pcm = case["pcm"][:2, :(case["pcm"].shape[1] // 480) * 480]
+    reps = -(-5000 * 480 // pcm.shape[1])
+    case["pcm"] = np.ascontiguousarray(np.tile(pcm, (1, reps)))
+    case["cfg"].update(threshold=0.35, min_scores=2, vad_mode=None)
+    sweep_parity.kMaxDet, keep = 4096, sweep_parity.kMaxDet
+    try:
+        ref = sweep_parity.oracle_detections(case)
+        offline, live, _ = sweep_parity.device_detections(ra, ctx, case)
+    finally:
+        sweep_parity.kMaxDet = keep
+    assert sum(len(r) for r in ref) >= 20
+    for o, l, r in zip(offline, live, ref):
+        assert len(o) == len(l) == len(r)
+        assert [x[:2] for x in o] == [x[:2] for x in r] and o == l
+        assert all(abs(a[2] - b[2]) <= 1e-5 * abs(b[2]) for a, b in zip(o, r))
+    # the same first stream through one `Rustpotter` handle, chunk by chunk (window history compactions of the handle)
+    c = case["cfg"]
+    rc = ra.RustpotterConfig.default()
+    rc.fmt.sample_format = ra.SampleFormat.I16 if case["pcm"].dtype == np.int16 else ra.SampleFormat.F32
+    d = rc.detector
+    d.avg_threshold, d.threshold, d.min_scores, d.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
+    d.score_ref, d.band_size = c["score_ref"], c["band_size"]
+    d.score_mode = getattr(ra.ScoreMode, c["score_mode"].capitalize())
+    rp = ra.Rustpotter.new(rc)
+    rp.add_wakeword_from_buffer("w", rpw_py.dump_rpw_ref("w", {"t%d" % i: t for i, t in enumerate(case["templates"])}, case["avg"]))
+    x = case["pcm"][0]
+    got = []
+    for k in range(len(x) // 480):
+        r = rp.process_samples(x[480 * k:480 * (k + 1)])
+        if r is not None:
+            got.append((k, r.counter, float(r.score)))
+    assert [g[:2] for g in got] == [r[:2] for r in ref[0]]
+    assert all(abs(g[2] - r[2]) <= 1e-5 * abs(r[2]) for g, r in zip(got, ref[0]))
+
+
 def test_randomised_mfcc_sweep(ra, ctx):
     """120 random (signal kind, level, mfcc size, length, sample type) MFCC cases against the oracle."""
     import sweep_parity

@@ -104,7 +104,6 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     TIN cur1[NS], prv[NS];
     f32x4 hcur[HS ? 4 : 1];  // HS: the groups of a stream's first tile that lie in the history chunk (f32x4: a float4
                               // struct array would be copied through scratch)
-    float hprv[HS ? 4 : 1];
     const size_t last = n_samples - 1;
     // position of 4-sample group `it` of this lane in the stream (clamped to the last whole group)
     auto group_pos = [&](unsigned ftile, int it) {
@@ -123,10 +122,8 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
                 if (HS) {  // new data starts at sample 480; only a stream's first tile reaches below it
                     const size_t gn = g >= kFrame ? g - kFrame : 0;
                     cur4[it] = SampleIn<TIN>::ldraw(x + gn);
-                    prv[it] = x[gn ? gn - 1 : 0];
                 } else {
                     cur4[it] = SampleIn<TIN>::ldraw(x + g);
-                    prv[it] = x[g - 1];
                 }
             }
             if (HS && ftile == 0 && first_frame == 0) {
@@ -135,7 +132,6 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
                 for (int it = 0; it < 4; ++it) {
                     const size_t g = group_pos(ftile, it), gh = g < kFrame ? g : kFrame - 4;
                     hcur[it] = *reinterpret_cast<const f32x4 *>(h + gh);
-                    hprv[it] = h[g <= kFrame ? g - 1 : kFrame - 1];  // g >= 160 in the first tile
                 }
             }
         } else {
@@ -153,21 +149,25 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
         const size_t j0 = first_frame + (size_t)tile * kMfccFramesPerWave;
         // pre_emphasis, src/mfcc/extractor.rs:87-97: previous sample is 0 at the start of EVERY shift.
         if (VEC4) {
+            float carry = 0.f;  // last sample of the previous 64 groups
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int q = it * 64 + lane;
                 float4 c = SampleIn<TIN>::cvt4(cur4[it]);
-                float pv = SampleIn<TIN>::cvt(prv[it]);
                 if (HS) {
                     const size_t g = group_pos(tile, it);
                     if (tile == 0 && first_frame == 0) {
                         if (g < kFrame) c = make_float4(hcur[it].x, hcur[it].y, hcur[it].z, hcur[it].w);
-                        pv = g <= kFrame ? hprv[it] : pv;
                     }
                     // this call's last chunk is the next call's history (every sample of it is loaded by the stream's
                     // last tile; groups loaded twice store the same values)
                     if (g >= n_samples - kFrame) *reinterpret_cast<float4 *>(hist_out + s * hist_pitch + (g - (n_samples - kFrame))) = c;
                 }
+                // the sample in front of a group is the left neighbour's last one (groups are consecutive along the lanes):
+                // one DPP wave shift instead of a second global load per group
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c.w), 0x138, 0xf, 0xf, false));  // wave_shr:1
+                const float pv = lane == 0 ? carry : left;
+                carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.w), 63));
                 const float p0 = (q % (kShift / 4) == 0) ? 0.f : pv;
                 float4 y;
                 y.x = c.x - 0.97f * p0;  // separate multiply and subtract, like the reference

@@ -918,6 +918,31 @@ static void det_reset(orc_detector *d) {
 }
 void orc_detector_reset(orc_detector *d) { det_reset(d); }
 
+/* Rustpotter::update_detector_config, src/detector.rs:262-280: the new values, a fresh VadDetector, reset().
+ * (the wakeword detectors take score_ref / band_size / score_mode from the detector on every call here) */
+void orc_detector_update_config(orc_detector *d, float avg_threshold, float threshold, int min_scores, int eager,
+                                float score_ref, int band_size, int score_mode, int vad_mode) {
+    d->avg_threshold = avg_threshold; d->threshold = threshold; d->min_scores = min_scores; d->eager = eager;
+    d->score_ref = score_ref; d->band_size = band_size; d->score_mode = score_mode;
+    d->has_vad = vad_mode != 0;
+    d->vad.mode_value = vad_mode == 1 ? 2.f : vad_mode == 2 ? 2.5f : 3.f;
+    vad_reset(&d->vad);
+    det_reset(d);
+}
+
+/* Rustpotter::update_filters_config, src/detector.rs:284-288: both filters are rebuilt from the config -- the new
+ * GainNormalizerFilter has window_size 1 and, without a fixed gain_ref, NO reference level (NaN: gain stays 1) until
+ * the wakeword set changes again (set_rms_level_ref is only called from on_wakeword_change, :328-346) -- then reset(). */
+void orc_detector_update_filters(orc_detector *d, int gain_enabled, float gain_ref /*NaN=None*/, float min_gain, float max_gain,
+                                 int bp_enabled, float low_cutoff, float high_cutoff) {
+    d->gain_f.enabled = gain_enabled; d->gain_f.min_gain = min_gain; d->gain_f.max_gain = max_gain;
+    d->gain_f.rms_level_ref = gain_ref; d->gain_f.rms_level_sqrt = isnan(gain_ref) ? NAN : sqrtf(gain_ref);
+    d->gain_f.fixed = !isnan(gain_ref); d->gain_f.window_size = 1; d->gain_f.win_len = 0;
+    d->bp.enabled = bp_enabled;
+    if (bp_enabled) bandpass_init(&d->bp, (float)ORC_SAMPLE_RATE, low_cutoff, high_cutoff);
+    det_reset(d);
+}
+
 /* on_wakeword_change, src/detector.rs:328-346 */
 static void on_wakeword_change(orc_detector *d) {
     int mx = 0; float target_rms = NAN;

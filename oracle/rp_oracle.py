@@ -103,6 +103,10 @@ def lib():
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
     L.orc_detector_free.argtypes = [C.c_void_p]
     L.orc_detector_reset.argtypes = [C.c_void_p]
+    L.orc_detector_update_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.orc_detector_update_config.restype = None
+    L.orc_detector_update_filters.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+    L.orc_detector_update_filters.restype = None
     L.orc_detector_add_ref.restype = C.c_int
     L.orc_detector_add_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, fp, C.c_int, fp, C.c_float, C.c_float, C.c_float]
     L.orc_detector_add_model.restype = C.c_int
@@ -450,6 +454,16 @@ class Detector:
         if lib().orc_detector_process_i16(self._h, s.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(det)):
             return self._out(det)
         return None
+
+    def update_detector_config(self, avg_threshold, threshold, min_scores, eager, score_ref, band_size, score_mode, vad_mode):
+        """Rustpotter::update_detector_config (src/detector.rs:262-280)."""
+        lib().orc_detector_update_config(self._h, avg_threshold, threshold, min_scores, int(eager), score_ref, band_size,
+                                         SCORE_MODES[score_mode], {None: 0, "easy": 1, "medium": 2, "hard": 3}[vad_mode])
+
+    def update_filters_config(self, gain_normalizer, gain_ref, min_gain, max_gain, band_pass, low_cutoff, high_cutoff):
+        """Rustpotter::update_filters_config (src/detector.rs:284-288)."""
+        lib().orc_detector_update_filters(self._h, int(gain_normalizer), float("nan") if gain_ref is None else gain_ref, min_gain,
+                                          max_gain, int(band_pass), low_cutoff, high_cutoff)
 
     def reset(self):
         """Rustpotter::reset (src/detector.rs:290-302)."""

@@ -369,7 +369,21 @@ def make_api_case(rng, extreme=False):
     if fmt == "i16":
         x = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
     resets = sorted(set(int(v) for v in rng.integers(0, n_chunks, size=int(rng.integers(0, 3)))))
-    return dict(K=K, wakewords=wakewords, cfg=cfg, x=x, rate=rate, channels=int(rng.choice([1, 1, 2])), resets=resets)
+    # update_detector_config / update_filters_config in mid-stream (src/detector.rs:255-289)
+    updates = {}
+    for _ in range(int(rng.integers(0, 3))):
+        at = int(rng.integers(1, n_chunks))
+        if rng.random() < 0.5:
+            updates[at] = ("detector", dict(threshold=float(rng.uniform(0.25, 0.52)), avg_threshold=float(rng.choice([0.0, rng.uniform(0.1, 0.45)])),
+                                            min_scores=int(rng.integers(1, 7)), eager=bool(rng.random() < 0.3), score_ref=float(rng.uniform(0.15, 0.3)),
+                                            band_size=int(rng.integers(1, 9)), score_mode=str(rng.choice(MODES)),
+                                            vad_mode=[None, None, "easy", "medium", "hard"][int(rng.integers(5))]))
+        else:
+            updates[at] = ("filters", dict(gain_normalizer=bool(rng.random() < 0.5), gain_ref=None if rng.random() < 0.5 else float(rng.uniform(0.01, 0.1)),
+                                           min_gain=float(rng.uniform(0.1, 0.5)), max_gain=float(rng.uniform(1.0, 3.0)),
+                                           band_pass=bool(rng.random() < 0.5), low_cutoff=float(rng.uniform(60, 200)),
+                                           high_cutoff=float(rng.uniform(300, 3000))))
+    return dict(K=K, wakewords=wakewords, cfg=cfg, x=x, rate=rate, channels=int(rng.choice([1, 1, 2])), resets=resets, updates=updates)
 
 
 def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
@@ -409,6 +423,22 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
             if k in case["resets"]:
                 d.reset()
                 rp.reset()
+            if k in case["updates"]:
+                kind, u = case["updates"][k]
+                if kind == "detector":
+                    d.update_detector_config(u["avg_threshold"], u["threshold"], u["min_scores"], u["eager"], u["score_ref"], u["band_size"],
+                                             u["score_mode"], u["vad_mode"])
+                    dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = u["avg_threshold"], u["threshold"], u["min_scores"], u["eager"]
+                    dc.score_ref, dc.band_size = u["score_ref"], u["band_size"]
+                    dc.score_mode = getattr(ra.ScoreMode, u["score_mode"].capitalize())
+                    dc.vad_mode = {None: None, "easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[u["vad_mode"]]
+                    rp.update_detector_config(dc)
+                else:
+                    d.update_filters_config(u["gain_normalizer"], u["gain_ref"], u["min_gain"], u["max_gain"], u["band_pass"],
+                                            u["low_cutoff"], u["high_cutoff"])
+                    g.enabled, g.gain_ref, g.min_gain, g.max_gain = u["gain_normalizer"], u["gain_ref"], u["min_gain"], u["max_gain"]
+                    b.enabled, b.low_cutoff, b.high_cutoff = u["band_pass"], u["low_cutoff"], u["high_cutoff"]
+                    rp.update_filters_config(rc.filters)
             mono = x[k * per:(k + 1) * per]
             if rs:
                 ref = d.process_resampled(rs, mono.astype(np.float32) / np.float32(32767.0) if x.dtype == np.int16 else mono)

@@ -437,6 +437,8 @@ typedef struct {
     int train_size, n_labels, none_index, n_layers;
     int dims[4];     /* layer sizes in->...->labels */
     float *W[3], *B[3];
+    int uid;         /* n-th wakeword ever added to its detector: what a detection reports (the reference keeps the
+                        wakeword's NAME in the partial detection, so it survives a remove_wakeword) */
 } orc_wakeword;
 
 typedef struct {
@@ -887,6 +889,7 @@ typedef struct orc_detector {
     int detection_countdown;
     float rms_level, gain;
     float *frames_tmp;
+    int next_uid;
 } orc_detector;
 
 /* Rustpotter::new, src/detector.rs:95-141.  vad_mode: 0 none, 1 easy, 2 medium, 3 hard. */
@@ -972,6 +975,7 @@ static int add_common(orc_detector *d, int K) { /* add_wakeword, src/detector.rs
     } else if (d->K != K) return -1; /* "Usage of wakewords with different mfcc size is not supported..." */
     d->ww = (orc_wakeword *)realloc(d->ww, sizeof(orc_wakeword) * (size_t)(d->n_ww + 1));
     memset(&d->ww[d->n_ww], 0, sizeof(orc_wakeword));
+    d->ww[d->n_ww].uid = d->next_uid++;
     return d->n_ww++;
 }
 
@@ -1018,13 +1022,25 @@ int orc_detector_add_model(orc_detector *d, int train_size, int K, int n_labels,
     return wi;
 }
 
+static void wakeword_release(orc_wakeword *w) {
+    if (w->kind == ORC_KIND_REF) { for (int t = 0; t < w->T; ++t) free(w->feats[t]); free(w->feats); free(w->lens); free(w->avg); }
+    else for (int l = 0; l < w->n_layers; ++l) { free(w->W[l]); free(w->B[l]); }
+}
+
+/* Rustpotter::remove_wakeword, src/detector.rs:180-189: drop it and on_wakeword_change() -- no reset: the frames already
+ * in the window stay, even if the window is now longer than the largest remaining wakeword needs */
+int orc_detector_remove(orc_detector *d, int index) {
+    if (index < 0 || index >= d->n_ww) return 0;
+    wakeword_release(&d->ww[index]);
+    memmove(&d->ww[index], &d->ww[index + 1], sizeof(orc_wakeword) * (size_t)(d->n_ww - index - 1));
+    d->n_ww -= 1;
+    on_wakeword_change(d);
+    return 1;
+}
+
 void orc_detector_free(orc_detector *d) {
     if (!d) return;
-    for (int i = 0; i < d->n_ww; ++i) {
-        orc_wakeword *w = &d->ww[i];
-        if (w->kind == ORC_KIND_REF) { for (int t = 0; t < w->T; ++t) free(w->feats[t]); free(w->feats); free(w->lens); free(w->avg); }
-        else for (int l = 0; l < w->n_layers; ++l) { free(w->W[l]); free(w->B[l]); }
-    }
+    for (int i = 0; i < d->n_ww; ++i) wakeword_release(&d->ww[i]);
     free(d->ww); free(d->window); free(d->frames_tmp); free(d->gain_f.win);
     orc_mfcc_free(d->mfcc);
     free(d);
@@ -1037,8 +1053,8 @@ static int run_wakeword_detectors(orc_detector *d, orc_detection *out) {
     for (int i = 0; i < d->n_ww; ++i) {
         orc_wakeword *w = &d->ww[i];
         int ok = w->kind == ORC_KIND_REF
-            ? comp_run_detection(w, i, d->window, d->win_len, d->avg_threshold, d->threshold, d->band_size, d->score_ref, d->score_mode, &tmp)
-            : nn_run_detection(w, i, d->window, d->win_len, d->avg_threshold, d->threshold, d->score_ref, &tmp);
+            ? comp_run_detection(w, w->uid, d->window, d->win_len, d->avg_threshold, d->threshold, d->band_size, d->score_ref, d->score_mode, &tmp)
+            : nn_run_detection(w, w->uid, d->window, d->win_len, d->avg_threshold, d->threshold, d->score_ref, &tmp);
         if (ok && (!found || tmp.score > out->score)) { *out = tmp; found = 1; }
     }
     return found;

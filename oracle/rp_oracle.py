@@ -103,6 +103,8 @@ def lib():
                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
     L.orc_detector_free.argtypes = [C.c_void_p]
     L.orc_detector_reset.argtypes = [C.c_void_p]
+    L.orc_detector_remove.argtypes = [C.c_void_p, C.c_int]
+    L.orc_detector_remove.restype = C.c_int
     L.orc_detector_update_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
     L.orc_detector_update_config.restype = None
     L.orc_detector_update_filters.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
@@ -454,6 +456,10 @@ class Detector:
         if lib().orc_detector_process_i16(self._h, s.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(det)):
             return self._out(det)
         return None
+
+    def remove(self, index):
+        """Rustpotter::remove_wakeword (src/detector.rs:180-189) of the index-th wakeword (insertion order)."""
+        return bool(lib().orc_detector_remove(self._h, index))  # self.names is indexed by the wakeword's uid: nothing to delete
 
     def update_detector_config(self, avg_threshold, threshold, min_scores, eager, score_ref, band_size, score_mode, vad_mode):
         """Rustpotter::update_detector_config (src/detector.rs:262-280)."""

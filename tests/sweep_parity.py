@@ -383,7 +383,22 @@ def make_api_case(rng, extreme=False):
                                            min_gain=float(rng.uniform(0.1, 0.5)), max_gain=float(rng.uniform(1.0, 3.0)),
                                            band_pass=bool(rng.random() < 0.5), low_cutoff=float(rng.uniform(60, 200)),
                                            high_cutoff=float(rng.uniform(300, 3000))))
-    return dict(K=K, wakewords=wakewords, cfg=cfg, x=x, rate=rate, channels=int(rng.choice([1, 1, 2])), resets=resets, updates=updates)
+    # remove_wakeword / add_wakeword in mid-stream (src/detector.rs:144-202, on_wakeword_change :328-346): the window is
+    # NOT reset, so it can be longer than the largest remaining wakeword needs, or has to grow for a longer new one
+    n_initial = len(wakewords)
+    ww_events = {}
+    if rng.random() < 0.4:
+        for wi in range(n_initial, n_initial + int(rng.integers(0, 3))):  # extra wakewords that join later
+            T = int(rng.integers(1, 4))
+            lens = rng.integers(20, 120, size=T)
+            us = [_utterance(rng, 480 * ((int(L) + 5) // 3)) for L in lens]
+            feats = {"s%d.wav" % i: orc.normalize(orc.mfcc_stream(u, K))[:int(L)] for i, (u, L) in enumerate(zip(us, lens))}
+            wakewords.append({"name": "ww%d" % wi, "samples_features": feats, "avg_features": None, "threshold": None,
+                              "avg_threshold": None, "rms_level": float(rng.uniform(0.01, 0.2))})
+        for _ in range(int(rng.integers(1, 4))):
+            ww_events[int(rng.integers(1, n_chunks))] = (str(rng.choice(["remove", "add"])), int(rng.integers(len(wakewords))))
+    return dict(K=K, wakewords=wakewords, n_initial=n_initial, ww_events=ww_events, cfg=cfg, x=x, rate=rate,
+                channels=int(rng.choice([1, 1, 2])), resets=resets, updates=updates)
 
 
 def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
@@ -410,10 +425,16 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
         g.enabled, g.gain_ref, g.min_gain, g.max_gain = c["gain_normalizer"], c["gain_ref"], c["min_gain"], c["max_gain"]
         b.enabled, b.low_cutoff, b.high_cutoff = c["band_pass"], c["low_cutoff"], c["high_cutoff"]
         rp = ra.Rustpotter.new(rc)
-        for w in case["wakewords"]:
+        active = []  # names in insertion order = the oracle's indices
+
+        def add(w):
             d.add_ref(w)
             rp.add_wakeword_from_buffer(w["name"], rpw_py.dump_rpw_ref(w["name"], w["samples_features"], w["avg_features"],
                                                                         w["threshold"], w["avg_threshold"], w["rms_level"]))
+            active.append(w["name"])
+
+        for w in case["wakewords"][:case["n_initial"]]:
+            add(w)
         rs = orc.Resampler(case["rate"]) if case["rate"] != 16000 else None
         spf = rp.get_samples_per_frame()
         per = spf // case["channels"]
@@ -423,6 +444,14 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
             if k in case["resets"]:
                 d.reset()
                 rp.reset()
+            if k in case["ww_events"]:
+                what, wi = case["ww_events"][k]
+                w = case["wakewords"][wi]
+                if what == "remove" and w["name"] in active:
+                    assert rp.remove_wakeword(w["name"]) and d.remove(active.index(w["name"]))
+                    active.remove(w["name"])
+                elif what == "add" and w["name"] not in active:
+                    add(w)
             if k in case["updates"]:
                 kind, u = case["updates"][k]
                 if kind == "detector":

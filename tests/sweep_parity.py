@@ -416,6 +416,10 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
         x = case["x"]
         rc.fmt.sample_rate, rc.fmt.channels = case["rate"], case["channels"]
         rc.fmt.sample_format = ra.SampleFormat.I16 if x.dtype == np.int16 else ra.SampleFormat.F32
+        # a third of the cases hand the chunks over as bytes (process_bytes, src/detector.rs:234-243) in either byte order
+        byte_order = [None, None, "<", ">"][int(np.random.default_rng([seed, 78, ci]).integers(4))]
+        if byte_order:
+            rc.fmt.endianness = ra.Endianness.Little if byte_order == "<" else ra.Endianness.Big
         dc = rc.detector
         dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
         dc.score_ref, dc.band_size = c["score_ref"], c["band_size"]
@@ -474,7 +478,10 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
             else:
                 ref = d.process_i16(mono) if x.dtype == np.int16 else d.process_f32(mono)
             inter = mono if case["channels"] == 1 else np.stack([mono, mono[::-1]], axis=1).reshape(-1)
-            got = rp.process_samples(np.ascontiguousarray(inter))
+            if byte_order:
+                got = rp.process_bytes(np.ascontiguousarray(inter).astype(byte_order + ("i2" if x.dtype == np.int16 else "f4")).tobytes())
+            else:
+                got = rp.process_samples(np.ascontiguousarray(inter))
             assert (got is None) == (ref is None), "%s chunk %d: %r vs %r" % (where, k, got, ref)
             part = rp.get_partial_detection()
             assert (-1 if part is None else part.counter) == d.state()["partial_counter"], "%s chunk %d partial" % (where, k)

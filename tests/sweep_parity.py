@@ -322,7 +322,7 @@ def run_live_rate_sweep(ra, ctx, n_cases, seed, verbose=False):
 # The single-stream drop-in API (`Rustpotter`, src/detector.rs) chunk by chunk against the oracle's detector: several
 # wakewords with their own thresholds, gain normaliser / band-pass, VAD, resets in mid-stream, i16 / f32 input,
 # mono / stereo, 16 kHz or 48 kHz (resampler in front).
-def make_api_case(rng, extreme=False):
+def make_api_case(rng, extreme=False, models=False):
     """extreme: detector parameters from the edges of (and outside) their sensible ranges -- band 0 / wider than the
     templates, thresholds <= 0 or > 1, min_scores 0, tiny / huge score_ref -- where the reference's arithmetic is still
     defined (all paths empty -> +inf cost -> score 0, everything above a threshold <= 0, ...)."""
@@ -383,6 +383,19 @@ def make_api_case(rng, extreme=False):
                                            min_gain=float(rng.uniform(0.1, 0.5)), max_gain=float(rng.uniform(1.0, 3.0)),
                                            band_pass=bool(rng.random() < 0.5), low_cutoff=float(rng.uniform(60, 200)),
                                            high_cutoff=float(rng.uniform(300, 3000))))
+    # a wakeword model next to the references now and then (run_wakeword_detectors picks the best score across both kinds)
+    if models and rng.random() < 0.25:
+        fr = int(rng.integers(30, 110))
+        mt = int(rng.integers(4))
+        hidden = {0: [fr // 15], 1: [fr // 6, (fr // 6) // 2], 2: [fr // 3, fr // 6], 3: [(fr // 3) * 2, fr // 6]}[mt]
+        labels = ["none", "gamma", "delta"][:int(rng.integers(2, 4))]
+        dims = [fr * K] + hidden + [len(labels)]
+        weights = {}
+        for i in range(len(dims) - 1):
+            weights["ln%d.weight" % (i + 1)] = (rng.standard_normal((dims[i + 1], dims[i])) * (1.5 / np.sqrt(dims[i]))).astype(np.float32)
+            weights["ln%d.bias" % (i + 1)] = (rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32)
+        wakewords.append({"kind": "model", "name": "model", "labels": labels, "train_size": fr, "mfcc_size": K,
+                          "m_type": ["Tiny", "Small", "Medium", "Large"][mt], "weights": weights, "rms_level": float(rng.uniform(0.01, 0.2))})
     # remove_wakeword / add_wakeword in mid-stream (src/detector.rs:144-202, on_wakeword_change :328-346): the window is
     # NOT reset, so it can be longer than the largest remaining wakeword needs, or has to grow for a longer new one
     n_initial = len(wakewords)
@@ -406,7 +419,7 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
     import rpw_py
     total = 0
     for ci in range(n_cases):
-        case = make_api_case(np.random.default_rng([seed, 77, ci]), extreme=extreme)
+        case = make_api_case(np.random.default_rng([seed, 77, ci]), extreme=extreme, models=True)
         c = case["cfg"]
         d = orc.Detector(avg_threshold=c["avg_threshold"], threshold=c["threshold"], min_scores=c["min_scores"], eager=c["eager"],
                          score_ref=c["score_ref"], band_size=c["band_size"], score_mode=c["score_mode"], vad_mode=c["vad_mode"],
@@ -432,9 +445,14 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
         active = []  # names in insertion order = the oracle's indices
 
         def add(w):
-            d.add_ref(w)
-            rp.add_wakeword_from_buffer(w["name"], rpw_py.dump_rpw_ref(w["name"], w["samples_features"], w["avg_features"],
-                                                                        w["threshold"], w["avg_threshold"], w["rms_level"]))
+            if w.get("kind") == "model":
+                d.add_model(w)
+                rp.add_wakeword_from_buffer(w["name"], rpw_py.dump_rpw_model(w["labels"], w["train_size"], w["mfcc_size"], w["m_type"],
+                                                                              w["weights"], w["rms_level"]))
+            else:
+                d.add_ref(w)
+                rp.add_wakeword_from_buffer(w["name"], rpw_py.dump_rpw_ref(w["name"], w["samples_features"], w["avg_features"],
+                                                                            w["threshold"], w["avg_threshold"], w["rms_level"]))
             active.append(w["name"])
 
         for w in case["wakewords"][:case["n_initial"]]:
@@ -491,7 +509,8 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
             assert got.name == ref["name"] and got.counter == ref["counter"], "%s chunk %d: %r vs %r" % (where, k, got, ref)
             for u, v in [(got.score, ref["score"]), (got.avg_score, ref["avg_score"]), (got.gain, ref["gain"])] + \
                         [(got.scores[n], ref["scores"][n]) for n in ref["scores"]]:
-                assert abs(float(u) - float(v)) <= (1e-3 if extreme else 1e-5) * abs(float(v)), "%s chunk %d: %r vs %r" % (where, k, got, ref)
+                tol = 1e-3 if extreme else 1e-4 if any(w.get("kind") == "model" for w in case["wakewords"]) else 1e-5
+                assert abs(float(u) - float(v)) <= tol * max(abs(float(v)), 1e-3 if tol == 1e-4 else 0.0), "%s chunk %d: %r vs %r" % (where, k, got, ref)
             assert sorted(got.scores) == sorted(ref["scores"])
         if verbose and ci % 20 == 0:
             print("api case %d ok, %d detections so far" % (ci, total), flush=True)

@@ -135,6 +135,12 @@ def device_detections(ra, ctx, case):
 kMaxDet = 32
 
 
+def _to_f32(v):
+    """`v as f32 / T::MAX as f32` (src/audio/audio_types.rs:98-137)"""
+    scale = {np.dtype(np.int8): 127.0, np.dtype(np.int16): 32767.0, np.dtype(np.int32): 2147483648.0}.get(v.dtype)
+    return v if scale is None else v.astype(np.float32) / np.float32(scale)
+
+
 def _same(a, b, rtol):
     if len(a) != len(b):
         return False
@@ -365,9 +371,10 @@ def make_api_case(rng, extreme=False, models=False):
         m = int(len(x) * rate / 16000)
         x = np.interp(np.arange(m) * (16000.0 / rate), np.arange(len(x)), x).astype(np.float32)
         x = np.where(np.abs(x) < 1e-7, np.float32(1e-3) * rng.standard_normal(m).astype(np.float32), x)  # no digital silence behind a resampler
-    fmt = str(rng.choice(["f32", "i16"]))
-    if fmt == "i16":
-        x = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+    fmt = str(rng.choice(["f32", "f32", "i16", "i16", "i8", "i32"]))  # the reference's four `Sample` types
+    if fmt != "f32":
+        info = np.iinfo({"i16": np.int16, "i8": np.int8, "i32": np.int32}[fmt])
+        x = np.clip(np.round(x.astype(np.float64) * (8.0 if fmt == "i8" else 1.0) * info.max), info.min, info.max).astype(info.dtype)  # (i8: louder, 7 bits)
     resets = sorted(set(int(v) for v in rng.integers(0, n_chunks, size=int(rng.integers(0, 3)))))
     # update_detector_config / update_filters_config in mid-stream (src/detector.rs:255-289)
     updates = {}
@@ -428,7 +435,11 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
         rc = ra.RustpotterConfig.default()
         x = case["x"]
         rc.fmt.sample_rate, rc.fmt.channels = case["rate"], case["channels"]
-        rc.fmt.sample_format = ra.SampleFormat.I16 if x.dtype == np.int16 else ra.SampleFormat.F32
+        rc.fmt.sample_format = {np.dtype(np.int8): ra.SampleFormat.I8, np.dtype(np.int16): ra.SampleFormat.I16,
+                                np.dtype(np.int32): ra.SampleFormat.I32, np.dtype(np.float32): ra.SampleFormat.F32}[x.dtype]
+        # `v as f32 / T::MAX as f32` (src/audio/audio_types.rs:98-137) for the oracle's f32 entry points
+        to_f32 = {np.dtype(np.int8): lambda v: v.astype(np.float32) / np.float32(127.0), np.dtype(np.int16): lambda v: v.astype(np.float32) / np.float32(32767.0),
+                  np.dtype(np.int32): lambda v: v.astype(np.float32) / np.float32(2147483648.0), np.dtype(np.float32): lambda v: v}[x.dtype]
         # a third of the cases hand the chunks over as bytes (process_bytes, src/detector.rs:234-243) in either byte order
         byte_order = [None, None, "<", ">"][int(np.random.default_rng([seed, 78, ci]).integers(4))]
         if byte_order:
@@ -492,12 +503,12 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
                     rp.update_filters_config(rc.filters)
             mono = x[k * per:(k + 1) * per]
             if rs:
-                ref = d.process_resampled(rs, mono.astype(np.float32) / np.float32(32767.0) if x.dtype == np.int16 else mono)
+                ref = d.process_resampled(rs, to_f32(mono))
             else:
-                ref = d.process_i16(mono) if x.dtype == np.int16 else d.process_f32(mono)
+                ref = d.process_i16(mono) if x.dtype == np.int16 else d.process_f32(to_f32(mono))
             inter = mono if case["channels"] == 1 else np.stack([mono, mono[::-1]], axis=1).reshape(-1)
             if byte_order:
-                got = rp.process_bytes(np.ascontiguousarray(inter).astype(byte_order + ("i2" if x.dtype == np.int16 else "f4")).tobytes())
+                got = rp.process_bytes(np.ascontiguousarray(inter).astype(byte_order + {1: "i1", 2: "i2"}.get(x.dtype.itemsize, "i4" if x.dtype == np.int32 else "f4")).tobytes())
             else:
                 got = rp.process_samples(np.ascontiguousarray(inter))
             assert (got is None) == (ref is None), "%s chunk %d: %r vs %r" % (where, k, got, ref)
@@ -509,8 +520,11 @@ def run_api_sweep(ra, n_cases, seed, verbose=False, extreme=False):
             assert got.name == ref["name"] and got.counter == ref["counter"], "%s chunk %d: %r vs %r" % (where, k, got, ref)
             for u, v in [(got.score, ref["score"]), (got.avg_score, ref["avg_score"]), (got.gain, ref["gain"])] + \
                         [(got.scores[n], ref["scores"][n]) for n in ref["scores"]]:
-                tol = 1e-3 if extreme else 1e-4 if any(w.get("kind") == "model" for w in case["wakewords"]) else 1e-5
-                assert abs(float(u) - float(v)) <= tol * max(abs(float(v)), 1e-3 if tol == 1e-4 else 0.0), "%s chunk %d: %r vs %r" % (where, k, got, ref)
+                # a model's `scores` are its logits: sums of large cancelling terms, compared relative to the largest of them
+                is_model = any(w.get("kind") == "model" for w in case["wakewords"])
+                tol = 1e-3 if extreme else 1e-4 if is_model else 1e-5
+                floor = max([abs(float(t)) for t in ref["scores"].values()] + [1.0]) if is_model else 0.0
+                assert abs(float(u) - float(v)) <= tol * max(abs(float(v)), floor), "%s chunk %d: %r %r vs %r" % (where, k, got, got.scores, ref)
             assert sorted(got.scores) == sorted(ref["scores"])
         if verbose and ci % 20 == 0:
             print("api case %d ok, %d detections so far" % (ci, total), flush=True)
@@ -689,7 +703,7 @@ def run_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
             d.add_ref(w)
         ref = []
         for k in range(len(x) // 480):
-            r = d.process_i16(x[480 * k:480 * (k + 1)]) if x.dtype == np.int16 else d.process_f32(x[480 * k:480 * (k + 1)])
+            r = d.process_i16(x[480 * k:480 * (k + 1)]) if x.dtype == np.int16 else d.process_f32(_to_f32(x[480 * k:480 * (k + 1)]))
             if r is not None:
                 ref.append((k, r["counter"], r["name"], float(r["score"]), float(r["avg_score"])))
         dc = ra.DetectorConfig()

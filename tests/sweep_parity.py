@@ -80,9 +80,10 @@ def make_case(rng, extreme=False):
             seg += u[:len(seg)]
     if rng.random() < 0.15:
         pcm[0, : N // 2] = 0.0  # digital silence: constant features, zero vectors in the cosine
-    fmt = str(rng.choice(["f32", "f32", "i16"]))
-    if fmt == "i16":
-        pcm = np.clip(np.round(pcm * 32767.0), -32768, 32767).astype(np.int16)
+    fmt = str(rng.choice(["f32", "f32", "i16", "i16", "i8", "i32"]))
+    if fmt != "f32":
+        info = np.iinfo({"i16": np.int16, "i8": np.int8, "i32": np.int32}[fmt])
+        pcm = np.clip(np.round(pcm.astype(np.float64) * (8.0 if fmt == "i8" else 1.0) * info.max), info.min, info.max).astype(info.dtype)
     return dict(K=K, templates=templates, avg=avg, cfg=cfg, pcm=pcm, chunks_per_call=int(rng.integers(1, 6)))
 
 
@@ -99,7 +100,7 @@ def oracle_detections(case):
         x = case["pcm"][s]
         got = []
         for i in range(0, len(x) - 479, 480):
-            r = d.process_i16(x[i:i + 480]) if x.dtype == np.int16 else d.process_f32(x[i:i + 480])
+            r = d.process_i16(x[i:i + 480]) if x.dtype == np.int16 else d.process_f32(_to_f32(x[i:i + 480]))
             if r is not None:
                 got.append((i // 480, int(r["counter"]), float(r["score"]), float(r["avg_score"])))
         out.append(got)
@@ -224,7 +225,7 @@ def run_live_reset_sweep(ra, ctx, n_cases, seed, verbose=False):
                             for j in range(nd[s])]
                 for q in range(piece.shape[1] // 480):
                     x = piece[s, 480 * q:480 * (q + 1)]
-                    r = dets[s].process_i16(x) if x.dtype == np.int16 else dets[s].process_f32(x)
+                    r = dets[s].process_i16(x) if x.dtype == np.int16 else dets[s].process_f32(_to_f32(x))
                     if r is not None:
                         ref[s].append((i // 480 + q, int(r["counter"]), float(r["score"]), float(r["avg_score"])))
         ok = all(_same(l, r, 1e-5) for l, r in zip(live, ref))
@@ -250,7 +251,7 @@ def run_live_rate_sweep(ra, ctx, n_cases, seed, verbose=False):
         ch = int(rng.choice([1, 2]))
         cpc = int(rng.integers(1, 4))
         fi, fo = ra.resampler_frame_lengths(rate)
-        base = case["pcm"].astype(np.float32) / (np.float32(32767.0) if case["pcm"].dtype == np.int16 else np.float32(1.0))
+        base = _to_f32(case["pcm"])
         # no digital silence here: behind a resampler silence turns into 1e-9 ringing whose log-mel features are chaotic in
         # any implementation (the reason the reference's 48 kHz model goldens cannot be pinned either)
         quiet = np.abs(base) < 1e-7

@@ -22,7 +22,7 @@ constexpr int kMfccWaveScratch = kMfccFramesPerWave * 240;      // float2 per wa
 
 __host__ __device__ inline size_t mfcc_lds_bytes(int K1) {
     size_t f = 480 + (size_t)K1 * kBins + (size_t)K1 * K1 + (size_t)kMfccWaves * kMfccFramesPerWave * K1;
-    size_t c = (size_t)kMfccWaves * kMfccWaveScratch + 240 + 240;
+    size_t c = (size_t)kMfccWaves * kMfccWaveScratch + 240;  // wave scratch + W480 (W240 is only read once per lane, from global)
     return c * sizeof(float2) + f * sizeof(float);
 }
 
@@ -37,7 +37,7 @@ template <int K1T> __device__ constexpr bool mel_uses(int f, int k2, bool mirror
 // kernel leaves this call's last chunk (decoded) at hist_out for the next call, so that no staging copy runs in front
 // of it.  n_samples counts the history chunk.  Needs VEC4.
 template <bool VEC4, int K1T, class TIN, bool HS = false>
-__global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
+__global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
     const TIN *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
     size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1rt, const float *__restrict__ g_ham,
     const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
@@ -47,8 +47,7 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
     const int K1 = K1T > 0 ? K1T : K1rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     v2f *scr_all = reinterpret_cast<v2f *>(smem);               // [waves][4][240]
-    v2f *tw240 = scr_all + kMfccWaves * kMfccWaveScratch;       // [240]
-    v2f *tw480 = tw240 + 240;                                   // [240]
+    v2f *tw480 = scr_all + kMfccWaves * kMfccWaveScratch;       // [240]
     float *ham = reinterpret_cast<float *>(tw480 + 240);        // [480]
     float *fb = ham + 480;                                      // [K1][240]
     float *dct = fb + K1 * kBins;                               // [K1][K1]
@@ -56,10 +55,7 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
 
     const int tid = threadIdx.x;
     for (int i = tid; i < 480; i += kMfccThreads) ham[i] = g_ham[i];
-    for (int i = tid; i < 240; i += kMfccThreads) {
-        tw240[i] = (v2f){g_tw240[i].x, g_tw240[i].y};
-        tw480[i] = (v2f){g_tw480[i].x, g_tw480[i].y};
-    }
+    for (int i = tid; i < 240; i += kMfccThreads) tw480[i] = (v2f){g_tw480[i].x, g_tw480[i].y};
     for (int i = tid; i < K1 * kBins; i += kMfccThreads) fb[i] = g_fb[i];
     for (int i = tid; i < K1 * K1; i += kMfccThreads) dct[i] = g_dct[i];
     __syncthreads();
@@ -87,7 +83,7 @@ __global__ __launch_bounds__(kMfccThreads, 3) void mfcc_kernel(
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int d = 0; d < 4; ++d) twl[4 * c + d] = tw240[l15 * (c + 4 * d)];
+        for (int d = 0; d < 4; ++d) { const float2 w = g_tw240[l15 * (c + 4 * d)]; twl[4 * c + d] = (v2f){w.x, w.y}; }
 
     // (stream, tile) of this wave's tile, advanced by the grid stride without a division per tile
     const size_t wave_stride = (size_t)gridDim.x * kMfccWaves;
@@ -291,9 +287,9 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     // 4-sample vector loads need rows aligned to 4 samples (and at least one full vector before the last sample)
     const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
-    // persistent grid: 3 workgroups of 4 waves per CU x 2 rounds, fewer for small problems
+    // persistent grid: 4 workgroups of 4 waves per CU x 2 rounds, fewer for small problems
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
-    if (blocks > 1536) blocks = 1536;
+    if (blocks > 2048) blocks = 2048;
 #define RP_MFCC_LAUNCH(V, KT)                                                                                              \
     do {                                                                                                                   \
         static bool attr_done = false;                                                                                     \

@@ -116,9 +116,14 @@ typedef struct {
 /* ------------------------------------------- single-stream `Rustpotter` mirror */
 typedef struct rp_detector rp_detector;
 
-/* Rustpotter::new, src/detector.rs:95-141.  Errors: "Unsupported sample rate, unable
- * to initialize the resampler" (src/audio/encoder.rs:78) for every rate != 16000 --
- * the rubato resampler is outside this library's scope. */
+/* Rustpotter::new, src/detector.rs:95-141.  config->fmt.sample_rate may be any rate AudioEncoder::new
+ * (src/audio/encoder.rs:63-83) accepts whose 16 kHz output frame is 480 or 640 samples -- every standard
+ * audio rate: 8 / 16 / 32 / 48 / 96 kHz and the 44.1 kHz family give 30 ms input frames (3 MFCC frames per
+ * call), 11.025 / 22.05 kHz give 40 ms frames (640 encoded samples, 4 MFCC frames per call).  Input that is
+ * not 16 kHz goes through the device resampler (rubato FftFixedInOut restated);
+ * rp_get_samples_per_frame() is then the resampler's input frame x channels (1 440 for 48 kHz mono).
+ * Errors: "Unsupported sample rate, unable to initialize the resampler" (src/audio/encoder.rs:78) for rate 0
+ * and for rates whose output frame has no device kernel (rp_resampler_frame_lengths tells). */
 int rp_new(const rp_config *config, rp_detector **out);
 void rp_free(rp_detector *d);
 
@@ -333,6 +338,9 @@ int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int ch
  * (src/detector.rs:62-79) and the VadDetector window.  Frames are numbered as in rp_batch_detect
  * (frame f is the f-th MFCC frame since the batch was created), so feeding a stream in pieces gives
  * the detections of rp_batch_detect over the concatenation. */
+/* Lifetime: a stream batch borrows `ctx` and `t` -- both must outlive it (free the batch first).  A call that fails
+ * (-1) leaves the batch unusable: part of its device state may already have advanced, so every later
+ * rp_stream_batch_process on it fails with "stream batch is in a failed state"; free it and create a new one. */
 typedef struct rp_stream_batch rp_stream_batch;
 int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_config *config, size_t S,
                         size_t max_chunks_per_call, rp_stream_batch **out);

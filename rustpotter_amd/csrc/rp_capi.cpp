@@ -24,6 +24,7 @@ struct rp_stream_batch {
     const Templates *t = nullptr;
     rp_detector_config cfg{};
     size_t S = 0, max_chunks = 0, chunks_seen = 0, hist_frames = 0;
+    bool poisoned = false;   // a launch failed after part of the persistent state had advanced
     // MFCC window: rows of `cap` frames; a call appends its frames behind the `fill` valid ones and only when a row
     // is full are the last max_len-1 frames moved to the front of the other buffer
     int cur = 0;
@@ -301,6 +302,7 @@ int rp_frontend_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples || out_stride < n_samples) { set_last_error("stride smaller than n_samples"); return -1; }
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        if (!filters) { set_last_error("null argument"); return -1; }
         const rp_gain_normalization_config &g = filters->gain_normalizer;
         const rp_band_pass_config &b = filters->band_pass;
         if (g.enabled && g.has_gain_ref) rms_level_ref = g.gain_ref;  // fixed_rms_level, gain_normalizer_filter.rs:56-66
@@ -402,6 +404,7 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
                    rp_batch_detection *det, int32_t *n_det, int max_det) {
     return guarded([&]() -> int {
         if (!ctx) { set_last_error("null handle"); return -1; }
+        if (!config || (S && (!agg || !det || !n_det))) { set_last_error("null argument"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const bool vad = config->vad_mode != RP_VAD_NONE;
@@ -443,6 +446,7 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
                         int max_det, float *scores, float *agg) {
     return guarded([&]() -> int {
         if (!ctx || !t) { set_last_error("null handle"); return -1; }
+        if (!config || (S && (!pcm || !det || !n_det))) { set_last_error("null argument"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
@@ -505,6 +509,8 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                           int32_t *det_wakeword, int32_t *n_det, int max_det) {
     return guarded([&]() -> int {
         if (!ctx) { set_last_error("null handle"); return -1; }
+        if (!config || !t || (S && (!pcm || !det || !n_det))) { set_last_error("null argument"); return -1; }
+        for (size_t j = 0; j < n_wakewords && j < (size_t)kScanMaxWakewords; ++j) if (!t[j]) { set_last_error("null handle"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (n_wakewords < 1 || n_wakewords > (size_t)kScanMaxWakewords) { set_last_error("rp_batch_detect_multi: 1..8 wakewords"); return -1; }
@@ -655,6 +661,7 @@ int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_co
                         size_t max_chunks_per_call, rp_stream_batch **out) {
     return guarded([&]() -> int {
         if (!ctx || !t) { set_last_error("null handle"); return -1; }
+        if (!config || !out) { set_last_error("null argument"); return -1; }
         *out = nullptr;
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
@@ -705,16 +712,32 @@ int rp_stream_batch_reset(rp_stream_batch *b, long long stream) {
         if (!b) { set_last_error("null handle"); return -1; }
         Ctx *c = b->c;
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (b->poisoned) { set_last_error("stream batch is in a failed state (an earlier call failed half way); free it and create a new one"); return -1; }
         if (stream >= (long long)b->S) { set_last_error("rp_stream_batch_reset: no such stream"); return -1; }
         // the next chunk only refills the extractor: its three frames (3C-3 .. 3C-1) are never emitted
         return hip_ok(launch_stream_state_reset(c->stream, b->state.p, b->S, stream, (long long)b->fpf() * (long long)b->chunks_seen), "stream_state_reset_kernel") ? 0 : -1;
     });
 }
 
+static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
+                                     rp_batch_detection *det, int32_t *n_det, int max_det, float *agg, bool *state_touched);
+
 int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
                             rp_batch_detection *det, int32_t *n_det, int max_det, float *agg) {
+    if (!b) { set_last_error("null handle"); return -1; }
+    if (b->poisoned) { set_last_error("stream batch is in a failed state (an earlier call failed half way); free it and create a new one"); return -1; }
+    // The call advances device-resident state launch by launch (resampler tail, history chunk, MFCC rows, scan state);
+    // a failure after the first such step cannot be rolled back, so the batch refuses further work instead of pairing
+    // the wrong history with later chunks.
+    bool touched = false;
+    const int r = stream_batch_process_impl(b, pcm, fmt, n_chunks, pcm_stride, det, n_det, max_det, agg, &touched);
+    if (r != 0 && touched) b->poisoned = true;
+    return r;
+}
+
+static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
+                                     rp_batch_detection *det, int32_t *n_det, int max_det, float *agg, bool *state_touched) {
     return guarded([&]() -> int {
-        if (!b) { set_last_error("null handle"); return -1; }
         Ctx *c = b->c;
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (n_chunks == 0 || n_chunks > b->max_chunks) { set_last_error("rp_stream_batch_process: n_chunks out of range"); return -1; }
@@ -736,6 +759,7 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
         if (!dp || !dd || !dn) { if (!pcm || !det || !n_det) set_last_error("null argument"); return -1; }
         const float *hp_old = b->pcm[b->pcur].as<float>();
         float *hp = b->pcm[b->pcur ^ 1].as<float>();
+        *state_touched = true;  // from here on every launch moves persistent state
         // 16 kHz mono input is read where it lies: the MFCC kernel takes [history chunk | new chunks] from two buffers and
         // leaves the last chunk as the next call's history.  Other inputs are staged into one row per stream first.
         bool staged = false;
@@ -880,6 +904,7 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                           rp_batch_detection *det, int32_t *det_label, int32_t *n_det, int max_det) {
     return guarded([&]() -> int {
         if (!ctx || !model) { set_last_error("null handle"); return -1; }
+        if (!config || (S && (!pcm || !det || !n_det))) { set_last_error("null argument"); return -1; }
         Ctx *c = ctx->impl.get();
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }

@@ -3,9 +3,26 @@
 #include <cmath>
 #include <cstring>
 
+#include <mutex>
+
 #include "rp_host.h"
 
 namespace rp {
+
+hipError_t allow_dynamic_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> done;  // (device, kernel) -> bytes granted
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = done.find({dev, kernel});
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[{dev, kernel}] = bytes;
+    return e;
+}
+
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &msg) { g_last_error = msg; }

@@ -222,6 +222,10 @@ bool Rustpotter::add_wakeword_model(const std::string &key, WakewordModelData &&
         else if ((int)wi->second.first[1] != w->dims.back()) { set_last_error("Incorrect model layers"); return false; }
         w->dims.push_back((int)wi->second.first[0]);
         if (bi->second.second.size() != wi->second.first[0]) { set_last_error("Incorrect model layers"); return false; }
+        // the tensor must hold exactly out x in values (the dims are attacker-controlled: Model::create copies out*in floats)
+        if (wi->second.first[0] == 0 || wi->second.first[1] == 0 || wi->second.first[0] > 0x7fffffffULL || wi->second.first[1] > 0x7fffffffULL ||
+            wi->second.second.size() / wi->second.first[0] != wi->second.first[1] ||
+            wi->second.second.size() % wi->second.first[0] != 0) { set_last_error("Incorrect model layers"); return false; }
         wp.push_back(wi->second.second.data());
         bp.push_back(bi->second.second.data());
     }

@@ -606,13 +606,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     const int Wmax = band > t.max_diff ? band : t.max_diff;
     const size_t lds = ((size_t)(64 + t.max_len - 1) * KP + (size_t)t.K * 64 + (size_t)(2 * Wmax + 1) * 64) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_generic_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_generic_kernel), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
                        (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, Ttot,
                        t.max_len, band, score_ref, scores, avg);

@@ -68,6 +68,10 @@ struct TemplatesDev {
     int class_count[3] = {0, 0, 0};  // chunks per class (class 2 includes the avg chunk if has_avg)
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs
+// (one rp_ctx per device) has to set it on each of them.  Sets it once per (current device, kernel), thread-safe.
+hipError_t allow_dynamic_lds(const void *kernel, int bytes);
+
 enum KernelId { kKernelMfcc = 0, kKernelDtw = 1, kKernelAggregate = 2, kKernelScan = 3, kKernelMlp = 4, kKernelResample = 5, kKernelCount = 6 };
 
 // Sample-rate converter plan (rp_resampler.cpp): out[j] = sum_n x2[n] * g2t[j][n], x2 = previous | current input frame

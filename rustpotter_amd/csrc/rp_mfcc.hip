@@ -292,13 +292,8 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
     if (blocks > 2048) blocks = 2048;
 #define RP_MFCC_LAUNCH(V, KT)                                                                                              \
     do {                                                                                                                   \
-        static bool attr_done = false;                                                                                     \
-        if (!attr_done) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<V, KT, TIN>),                     \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
-            if (e != hipSuccess) return e;                                                                                 \
-            attr_done = true;                                                                                              \
-        }                                                                                                                  \
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mfcc_kernel<V, KT, TIN>), 160 * 1024);             \
+        if (e != hipSuccess) return e;                                                                                     \
         hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, \
                            pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
                            tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc, mfcc2);                                                       \
@@ -330,13 +325,8 @@ static hipError_t launch_mfcc_stream_t(hipStream_t st, const MfccTablesDev &tb, 
     if (blocks > 1536) blocks = 1536;
 #define RP_MFCC_LAUNCH_HS(KT)                                                                                               \
     do {                                                                                                                   \
-        static bool attr_done = false;                                                                                     \
-        if (!attr_done) {                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mfcc_kernel<true, KT, TIN, true>),            \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
-            if (e != hipSuccess) return e;                                                                                 \
-            attr_done = true;                                                                                              \
-        }                                                                                                                  \
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mfcc_kernel<true, KT, TIN, true>), 160 * 1024);    \
+        if (e != hipSuccess) return e;                                                                                     \
         hipLaunchKernelGGL((mfcc_kernel<true, KT, TIN, true>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm,   \
                            n_samples, pcm_stride, (unsigned)tiles, total, (size_t)0, n_frames, out_frame_pitch, tb.K1,     \
                            tb.hamming, tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc, (float *)nullptr, hist, hist_pitch, hist_out); \

@@ -466,16 +466,8 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     wbuf = (wbuf + 3) & ~(size_t)3;
     const size_t lds = ((size_t)((m.tail_floats + 3) & ~3) + wbuf + (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpBf16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF32>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpBf16>), 160 * 1024); e != hipSuccess) return e;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF32>), 160 * 1024); e != hipSuccess) return e;
     if (precision == kMlpBf16)
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,

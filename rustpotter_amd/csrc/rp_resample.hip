@@ -124,13 +124,7 @@ static hipError_t launch_resample_t(hipStream_t st, const ResamplerDev &rs, cons
     const size_t blocks = (units + 16 * kRsWaves - 1) / (16 * kRsWaves);
     if (blocks > 0x7fffffffULL || n_chunks > 0xffffffffULL) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * 16 * NT * kRsPitch * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(resample_mfma_kernel<NT>), (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(resample_mfma_kernel<NT>, dim3((unsigned)blocks), dim3(64 * kRsWaves), lds, st, xs, (1 + n_chunks) * (size_t)rs.fi,
                        units, (unsigned)n_chunks, rs.fi, rs.kpad, rs.g2t, out, out_stride);
     return hipGetLastError();
@@ -379,13 +373,7 @@ static hipError_t launch_resample48_t(hipStream_t st, const float *tables, const
     const size_t n_waves = S * n_seg, blocks = (n_waves + kR48Waves - 1) / kR48Waves;
     if (blocks > 0x7fffffffULL || n_chunks > 0x7fffffffULL) return hipErrorInvalidValue;
     const size_t lds = (size_t)kR48Waves * kR48WaveLds;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample48_fft_kernel<TIN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(resample48_fft_kernel<TIN>), (int)lds); e != hipSuccess) return e;
     const v2f *t = reinterpret_cast<const v2f *>(tables);
     hipLaunchKernelGGL(resample48_fft_kernel<TIN>, dim3((unsigned)blocks), dim3(64 * kR48Waves), lds, st, xs, xs_pitch, channels, has_hist,
                        prev, prev_out, n_waves, (unsigned)n_chunks, (unsigned)seg_len, (unsigned)n_seg, t + kR48OffTw240,

@@ -2,7 +2,9 @@
 // ciborium 0.2.1 through serde: src/wakewords/wakeword_file.rs:10-42).  Definite
 // lengths only; floats may be f16/f32/f64 (minimal-width encoding); TensorData.bytes
 // is an ARRAY of small uints, not a byte string.
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 
 #include "rp_host.h"
@@ -107,11 +109,13 @@ bool read_matrix(Cur &c, std::vector<float> *out, int *rows, int *cols, bool *is
     if (mj == 7 && (info == 22 || info == 23) && is_null) { *is_null = true; *rows = *cols = 0; return true; }
     if (is_null) *is_null = false;
     if (mj != 4) return c.fail("expected an array of mfcc frames");
+    if (v > 0x7fffffffULL) return c.fail("mfcc matrix too large");
     *rows = (int)v; *cols = -1; out->clear();
     for (uint64_t r = 0; r < v; ++r) {
         int mj2, info2; uint64_t n;
         if (!c.head(&mj2, &info2, &n)) return false;
         if (mj2 != 4) return c.fail("expected an array of mfcc coefficients");
+        if (n > 0x7fffffffULL) return c.fail("mfcc matrix too large");
         if (*cols < 0) *cols = (int)n; else if (*cols != (int)n) return c.fail("ragged mfcc matrix");
         for (uint64_t i = 0; i < n; ++i) { float f; if (!read_number(c, &f, nullptr)) return false; out->push_back(f); }
     }
@@ -181,19 +185,25 @@ bool parse_rpw(const uint8_t *buf, size_t len, RpwKind *kind, WakewordRefData *r
                         int mj4, info4; uint64_t nb;
                         ok = c.head(&mj4, &info4, &nb);
                         if (ok && mj4 == 2) { ok = c.need((size_t)nb); if (ok) { bytes.assign(c.p, c.p + nb); c.p += nb; } }
-                        else if (ok && mj4 == 4) { bytes.reserve((size_t)nb); for (uint64_t b = 0; ok && b < nb; ++b) { uint64_t v; ok = read_uint(c, &v); bytes.push_back((uint8_t)v); } }
+                        else if (ok && mj4 == 4) { bytes.reserve((size_t)std::min<uint64_t>(nb, (uint64_t)(c.end - c.p))); for (uint64_t b = 0; ok && b < nb; ++b) { uint64_t v; ok = read_uint(c, &v); bytes.push_back((uint8_t)v); } }
                         else if (ok) ok = c.fail("TensorData.bytes: expected an array");
                     } else if (fk == "dims") {
                         int mj4, info4; uint64_t nd;
                         ok = c.head(&mj4, &info4, &nd) && (mj4 == 4 || c.fail("TensorData.dims: expected an array"));
-                        for (uint64_t d = 0; ok && d < nd; ++d) { uint64_t v; ok = read_uint(c, &v); dims.push_back((size_t)v); }
+                        for (uint64_t d = 0; ok && d < nd; ++d) {
+                            uint64_t v; ok = read_uint(c, &v);
+                            if (ok && v > 0x7fffffffULL) ok = c.fail("TensorData.dims: dimension too large");  // the detector keeps dims as int
+                            dims.push_back((size_t)v);
+                        }
                     } else if (fk == "d_type") ok = read_text(c, &dtype);
                     else ok = skip_item(c);
                 }
                 if (ok) {
                     if (dtype != "f32") { ok = c.fail("unsupported tensor d_type (only f32)"); break; }
-                    size_t cnt = 1; for (size_t d : dims) cnt *= d;
-                    if (bytes.size() != cnt * 4) { ok = c.fail("tensor byte length does not match dims"); break; }
+                    // element count with an overflow check (a wrapped product once passed the length test below)
+                    size_t cnt = 1; bool ovf = false;
+                    for (size_t d : dims) { if (d && cnt > (SIZE_MAX / 4) / d) ovf = true; else cnt *= d; }
+                    if (ovf || bytes.size() != cnt * 4) { ok = c.fail("tensor byte length does not match dims"); break; }
                     std::vector<float> data(cnt);
                     std::memcpy(data.data(), bytes.data(), cnt * 4);  // little-endian f32
                     model->weights[wn] = std::make_pair(dims, std::move(data));

@@ -1,6 +1,7 @@
 // Test infrastructure: mutation fuzzer for the product's .rpw reader (rustpotter_amd/csrc/rpw_reader.cpp), built with
 // g++ -fsanitize=address,undefined by tests/test_rpw_fuzz.py.  Seeds are the reference's own .rpw files (tests/golden);
 // every mutant must be either parsed or rejected with an error text -- never crash, over-read or allocate without bound.
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,7 +17,23 @@ static uint64_t rnd() {
 }
 
 int main(int argc, char **argv) {
-    if (argc < 3) { std::fprintf(stderr, "usage: fuzz_rpw <iterations> <seed.rpw>...\n"); return 2; }
+    if (argc == 3 && std::strcmp(argv[1], "check") == 0) {  // fuzz_rpw check <file>: "parsed" or "rejected: <text>"
+        FILE *f = std::fopen(argv[2], "rb");
+        if (!f) { std::perror(argv[2]); return 2; }
+        std::vector<uint8_t> data;
+        uint8_t tmp[65536];
+        size_t n;
+        while ((n = std::fread(tmp, 1, sizeof tmp, f)) > 0) data.insert(data.end(), tmp, tmp + n);
+        std::fclose(f);
+        uint8_t *buf = (uint8_t *)std::malloc(data.size() ? data.size() : 1);  // exact-size copy: ASan sees over-reads
+        std::memcpy(buf, data.data(), data.size());
+        rp::RpwKind kind; rp::WakewordRefData ref; rp::WakewordModelData model; std::string err;
+        if (rp::parse_rpw(buf, data.size(), &kind, &ref, &model, &err)) std::printf("parsed\n");
+        else std::printf("rejected: %s\n", err.c_str());
+        std::free(buf);
+        return 0;
+    }
+    if (argc < 3) { std::fprintf(stderr, "usage: fuzz_rpw <iterations> <seed.rpw>... | fuzz_rpw check <file>\n"); return 2; }
     const long iters = std::atol(argv[1]);
     long parsed = 0, rejected = 0;
     for (int a = 2; a < argc; ++a) {
@@ -87,7 +104,10 @@ int main(int argc, char **argv) {
                     ok = model.mfcc_size > 0;
                     for (const auto &kv : model.weights) {
                         size_t n = 1;
-                        for (size_t d : kv.second.first) n *= d;
+                        for (size_t d : kv.second.first) {
+                            if (d > 0x7fffffffULL || (d && n > (SIZE_MAX / 4) / d)) { ok = false; break; }  // no wrapped products
+                            n *= d;
+                        }
                         if (n != kv.second.second.size()) ok = false;
                     }
                 }

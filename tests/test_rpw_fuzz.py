@@ -27,6 +27,63 @@ def test_rpw_reader_survives_mutants_under_asan(tmp_path):
     assert parsed > 100 and rejected > 100  # both outcomes are exercised
 
 
+def _model_with_dims(dims, n_values):
+    """A Tiny wakeword model whose ln1.weight claims `dims` but carries n_values f32 values."""
+    sys.path.insert(0, HERE)
+    import rpw_py
+    out = rpw_py._head(5, 6)
+    out += rpw_py._text("labels") + rpw_py._head(4, 2) + rpw_py._text("none") + rpw_py._text("w")
+    out += rpw_py._text("train_size") + rpw_py._head(0, 4) + rpw_py._text("mfcc_size") + rpw_py._head(0, 2)
+    out += rpw_py._text("m_type") + rpw_py._text("Tiny") + rpw_py._text("weights") + rpw_py._head(5, 4)
+
+    def tensor(name, dims_, values):
+        raw = np.asarray(values, "<f4").tobytes()
+        return (rpw_py._text(name) + rpw_py._head(5, 3) + rpw_py._text("bytes") + rpw_py._head(4, len(raw)) +
+                b"".join(rpw_py._head(0, v) for v in raw) + rpw_py._text("dims") + rpw_py._head(4, len(dims_)) +
+                b"".join(rpw_py._head(0, d) for d in dims_) + rpw_py._text("d_type") + rpw_py._text("f32"))
+    out += tensor("ln1.weight", dims, np.ones(n_values)) + tensor("ln1.bias", [dims[0]], np.zeros(dims[0] if dims[0] < 64 else 1))
+    out += tensor("ln2.weight", [2, dims[0] if dims[0] < 64 else 3], np.ones(2 * (dims[0] if dims[0] < 64 else 3)))
+    out += tensor("ln2.bias", [2], np.zeros(2))
+    out += rpw_py._text("rms_level") + rpw_py._f32(0.0)
+    return out
+
+
+# dims whose product wraps modulo 2^64 to the number of values actually present (ADVICE r1: 3 * 0x5555555555555556 * 4
+# bytes == 8 bytes mod 2^64), a dimension beyond int, and a plain mismatch
+CRAFTED = [([3, 0x5555555555555556], 2), ([1 << 40, 1], 1), ([0x80000000, 2], 0), ([3, 8], 23)]
+
+
+def test_rpw_reader_refuses_wrapped_tensor_dims(tmp_path):
+    exe = str(tmp_path / "fuzz_rpw")
+    csrc = os.path.join(ROOT, "rustpotter_amd", "csrc")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + csrc,
+           os.path.join(HERE, "fuzz", "fuzz_rpw.cpp"), os.path.join(csrc, "rpw_reader.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, timeout=300)
+    good = tmp_path / "good.rpw"
+    good.write_bytes(_model_with_dims([3, 8], 24))
+    r = subprocess.run([exe, "check", str(good)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "parsed", r.stdout + r.stderr
+    for i, (dims, n) in enumerate(CRAFTED):
+        f = tmp_path / ("crafted%d.rpw" % i)
+        f.write_bytes(_model_with_dims(dims, n))
+        r = subprocess.run([exe, "check", str(f)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stdout.startswith("rejected: "), (dims, r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_crafted_model_dims_through_the_detector():
+    """The same files through Rustpotter::add_wakeword_from_buffer: an error text, no 17 GB copy from an 8-byte vector."""
+    sys.path.insert(0, ROOT)
+    import rustpotter_amd as ra
+    cfg = ra.RustpotterConfig.default()
+    rp = ra.Rustpotter.new(cfg)
+    rp.add_wakeword_from_buffer("ok", _model_with_dims([3, 8], 24))
+    for dims, n in CRAFTED:
+        with pytest.raises(ra.RustpotterError):
+            ra.Rustpotter.new(cfg).add_wakeword_from_buffer("w", _model_with_dims(dims, n))
+
+
 def _mutants(seed, n, rng):
     for _ in range(n):
         m = bytearray(seed)

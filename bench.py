@@ -8,9 +8,12 @@ step in steady state = one scored window.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched by torch.distributed.run, one rank per GPU; streams are sharded by rank
-(weak scaling: every GPU gets --streams streams), the only exchange is an RCCL all_gather
-of the per-stream detection summary at the end of each step.
+N > 1: one rank per GPU over torch.distributed (backend nccl == RCCL on ROCm); streams are sharded by
+rank (weak scaling: every GPU gets --streams streams), the only exchange is an RCCL all_gather of the
+per-stream detection summary at the end of each step.  The ranks are either started by the caller
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: WORLD_SIZE is set) or, when
+WORLD_SIZE is not set, by bench.py itself: the parent starts that same command as a child process BEFORE
+anything touches the GPU, relays the child's output (rank 0 prints the one JSON line) and exits with its code.
 """
 import argparse
 import json
@@ -25,6 +28,33 @@ if ROOT not in sys.path:
 SEED = 0x5EED000000000001
 HBM_PEAK = 8.0e12      # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 VALU_PEAK = 157.3e12   # FLOP/s fp32 vector, same table
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child process group.  Nothing in this
+    process has initialised the GPU (torch.cuda.device_count() does not); the child is a separate program, not an exec."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if have < n:
+        if os.environ.get("RP_BENCH_OVERSUBSCRIBE") != "1":
+            sys.stderr.write("bench.py: --gpus %d but this node has %d GPU(s); set RP_BENCH_OVERSUBSCRIBE=1 for a dry run in which "
+                             "ranks share devices over gloo (reported as oversubscribed, not a scaling number)\n" % (n, have))
+            return 2
+        env["RP_BENCH_BACKEND"] = "gloo"
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(r.stdout)
+    sys.stdout.flush()
+    return r.returncode
 
 
 def main():
@@ -47,7 +77,15 @@ def main():
     ap.add_argument("--pcm-format", choices=["f32", "i16"], default="f32", help="--mode resample: sample format of the 48 kHz input")
     ap.add_argument("--channels", type=int, default=1, help="--mode resample: interleaved channels of the 48 kHz input")
     ap.add_argument("--mlp-precision", choices=["f32", "bf16"], default="bf16")
+    ap.add_argument("--template-lens", default="", help="comma-separated template lengths in frames (overrides --templates / "
+                    "--template-len), e.g. 108,96,90,93,102 = the shape of the reference's oye_casa_g.rpw")
+    ap.add_argument("--score-mode", choices=["average", "max", "median", "p25", "p50", "p75", "p80", "p90", "p95"], default="max")
+    ap.add_argument("--avg-gate", action="store_true", help="reference defaults: an averaged template and avg_threshold 0.2 -- windows "
+                    "whose avg_score is below it are not compared with the sample templates (wakeword_comp.rs:85-93)")
+    ap.add_argument("--full-scores", action="store_true", help="with --avg-gate: compare every window with every template anyway (RP_CTX_FULL_SCORES)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -85,41 +123,43 @@ def main():
     if args.mode == "resample":
         return bench_resample(args, ra, torch, dist, dev, world, rank, local_rank)
 
-    S, N, T, L, K = args.streams, args.samples, args.templates, args.template_len, args.mfcc_size
+    S, N, K = args.streams, args.samples, args.mfcc_size
+    lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
+    T, L = len(lens), max(lens)
     nf = ra.mfcc_num_frames(N)
     n_win = nf - L + 1
-    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
+    ctx = ra.BatchContext(device=local_rank, host_pointers=False, full_scores=args.full_scores)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    # templates (BASELINE.md §2): T synthetic utterances, MFCC by the HIP path, whole-matrix mean
-    # normalisation, truncated to L frames.  Identical arrays are handed to the CPU baseline.
-    n_t = 480 * -(-(L + 3) // 3)
-    tp = torch.empty((T, n_t), dtype=torch.float32, device=dev)
-    for t in range(T):
-        ctx.synth_dev(SEED + 1 + t, 0, 1, n_t, n_t, tp[t].data_ptr())
-    tm_frames = ra.mfcc_num_frames(n_t)
-    tmf = torch.empty((T, tm_frames, K), dtype=torch.float32, device=dev)
-    ctx.mfcc_dev(tp.data_ptr(), T, n_t, n_t, K, tmf.data_ptr())
-    torch.cuda.synchronize()
-    tmf = tmf.cpu().numpy()
-    templates = [np.ascontiguousarray((m - m.mean(axis=0, dtype=np.float32))[:L], dtype=np.float32) for m in tmf]
-    tmpl = ra.Templates(ctx, templates)
+    # templates (BASELINE.md S2): T synthetic utterances, MFCC by the HIP path, whole-matrix mean
+    # normalisation, truncated to their length.  Identical arrays are handed to the CPU baseline.
+    templates = make_templates(ra, ctx, torch, dev, lens, K)
+    avg_t = None
+    if args.avg_gate:
+        # synthetic averaged template: the frame-wise mean of the templates cut to the shortest one (the reference's
+        # MfccAverager aligns them by DTW first; only the amount of work matters here)
+        lm = min(lens)
+        avg_t = np.ascontiguousarray(np.mean([t[:lm] for t in templates], axis=0, dtype=np.float32), dtype=np.float32)
+    tmpl = ra.Templates(ctx, templates, avg=avg_t)
 
     # resident inputs / outputs
     pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
     ctx.synth_dev(SEED, sharding.weak_first_stream(S, rank), S, N, N, pcm.data_ptr())
-    scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev)
-    agg = torch.empty((S, n_win), dtype=torch.float32, device=dev)
+    want_arrays = not args.avg_gate  # the per-window arrays are defined for every window: asking for them keeps every DTW
+    scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev) if want_arrays else None
+    agg = torch.empty((S, n_win), dtype=torch.float32, device=dev) if want_arrays else None
     max_det = 4
     det = torch.zeros((S, max_det, 6), dtype=torch.int32, device=dev)
     n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
     cfg = ra.DetectorConfig()
-    cfg.avg_threshold = 0.0  # avg gate off: exactly T DTWs per scoring
+    cfg.score_mode = {"average": 0, "max": 1, "median": 2, "p25": 3, "p50": 4, "p75": 5, "p80": 6, "p90": 7, "p95": 8}[args.score_mode]
+    if not args.avg_gate:
+        cfg.avg_threshold = 0.0  # avg gate off: exactly T DTWs per scoring
 
     def step():
-        # one C call: mfcc_kernel -> dtw_band_kernel -> aggregate_kernel -> scan_kernel on the launch stream
+        # one C call: mfcc_kernel -> dtw kernel(s) -> aggregate kernel -> scan_kernel on the launch stream
         ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), max_det,
-                             scores.data_ptr(), agg.data_ptr())
+                             scores.data_ptr() if want_arrays else None, agg.data_ptr() if want_arrays else None)
         return sharding.gather_per_stream(n_det, world)  # final per-stream result gather (RCCL over xGMI)
 
     def fence():
@@ -143,7 +183,7 @@ def main():
     scorings_per_step = S * n_win * world
     value = scorings_per_step * args.steps / dt
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+    # ---- rooflines, measured live with HIP events on the launch stream (rp_ctx_timing_*: one event pair per launch)
     ctx.timing_enable(True)
     ctx.timing_reset()
     for _ in range(max(2, min(args.steps, 5))):
@@ -152,64 +192,102 @@ def main():
     k_ms = {name: ctx.timing_read(i) for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
     ctx.timing_enable(False)
     per_gpu_scorings = S * n_win
-    # algorithmic bytes per unit: whole path 160*4 + 4*(T+2) per scoring;
-    # stage split: mfcc kernel 640 + 4K per frame, dtw kernel (reading MFCC from HBM) 4K + 4(T+2) per scoring
-    cells = sum((min(L, r + 5 - 1) - max(1, r - 5) + 1) for r in range(1, L))  # band cells of rows 1..m-1
-    f_dtw = cells * (2 * K + 7) + 2 * L * 2 * K + 2 * L * K
+    W = 5
+    # reference-shaped flops of one template DTW (SURVEY.md S8d F_dtw: 3 dot products + sqrt + divide per cell = 2K+7, norms,
+    # normalisation) and the flops the kernel executes (unit-length rows: K FMAs + 2 min3 + 1 add per cell; per row and
+    # window one ring column: K subtracts, K FMAs, rsqrt, K multiplies, shared by the templates of a chunk)
+    def cells(Lt):
+        return sum((min(Lt, r + W - 1) - max(1, r - W) + 1) for r in range(1, Lt))
+    f_dtw_ref = sum(cells(Lt) * (2 * K + 7) + 2 * Lt * 2 * K + 2 * Lt * K for Lt in lens)
+    by_len = {}
+    for Lt in lens:
+        by_len[Lt] = by_len.get(Lt, 0) + 1
+    n_chunks = sum(-(-c // 8) for c in by_len.values())
+    f_dtw_exec = sum((Lt - 1) * 2 * W * (2 * K + 3) for Lt in lens) + sum(-(-c // 8) * ((Lt - 1) * (4 * K + 1) + Lt * K) for Lt, c in by_len.items())
     f_mfcc = 13.2e3
     dom = max(("mfcc", "dtw"), key=lambda n: k_ms[n][0])
-    if dom == "dtw":
-        alg_bytes = per_gpu_scorings * (4 * K + 4 * (T + 2))
-        alg_flops = per_gpu_scorings * T * f_dtw
-    else:
-        alg_bytes = S * nf * (640 + 4 * K)
-        alg_flops = S * nf * f_mfcc
-    dom_s = k_ms[dom][0] * 1e-3
-    achieved = alg_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
-    # command (rocprofv3 cannot run inside the timed process); null for any other workload.
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-        w = tj["workload"]
-        if (w["streams"], w["samples"], w["templates"], w["template_len"], w["mfcc_size"]) == (S, N, T, L, K):
-            for name, d in tj["kernels"].items():
-                if dom in name and "hbm_bytes_per_launch_corrected" in d:
-                    traffic = d["hbm_bytes_per_launch_corrected"]
-    except Exception:
-        traffic = None
-    # at ~250 flop/B the path sits on the fp32 compute roofline, not on HBM.  The kernels issue packed-f32
-    # VALU FMAs; their peak (157.3 TFLOP/s) is also the dense f32 MFMA peak of MI355X_MICROARCH.md, so the contract's
-    # "mfma" bound is the compute roofline here.  achieved = ALGORITHMIC flops per launch (F_dtw per template
-    # DTW, F_mfcc per frame, as the reference formulates them) / the launch duration measured above.  The HBM view of
-    # the same launch is kept next to it.
-    tflops = alg_flops / dom_s / 1e12 if dom_s > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": dom + "_kernel", "achieved": tflops, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s",
-                "frac": tflops * 1e12 / VALU_PEAK, "traffic": traffic, "algorithmic_flops_per_launch": alg_flops,
-                "avg_launch_ms": k_ms[dom][0],
-                "note": "compute roofline (SURVEY.md 8d: ~250 flop/B, fp32-VALU bound): packed-f32 VALU FMAs, peak 157.3 TFLOP/s = "
-                        "the dense f32 MFMA peak; flops are the algorithmic count of the reference's formulation (the kernel "
-                        "executes fewer: unit-length rows, one fma chain per cell); `hbm` is the same launch against 8 TB/s",
-                "hbm": {"achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
-                        "algorithmic_bytes_per_launch": alg_bytes},
-                "kernels_ms": {k: round(v[0], 4) for k, v in k_ms.items()},
-                "path_hbm_frac": (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK,
-                "path_valu_frac_fp32": (value / world) * (f_mfcc * nf / n_win + T * f_dtw) / VALU_PEAK}
+    # PMC byte / instruction counts per launch come from the committed rocprofv3 passes of this same command (a profiler
+    # cannot run inside the timed process); null for any other workload.
+    pmc, pmc_src = {}, None
+    if not args.avg_gate and args.score_mode == "max":
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            w = tj["workload"]
+            if (w["streams"], w["samples"], w["templates"], w["template_len"], w["mfcc_size"]) == (S, N, T, L, K) and len(set(lens)) == 1:
+                for name, d in tj["kernels"].items():
+                    for kn in ("mfcc", "dtw"):
+                        if kn + "_" in name and "hbm_bytes_per_launch_corrected" in d:
+                            pmc[kn] = d
+                pmc_src = "profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc passes of this command, not this run)"
+        except Exception:
+            pmc = {}
+    dtw_s, mfcc_s = k_ms["dtw"][0] * 1e-3, k_ms["mfcc"][0] * 1e-3
+    simd_cycles = lambda sec: 1024 * sec * 2.4e9  # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
+    dtw_ref_flops, dtw_exec_flops = per_gpu_scorings * f_dtw_ref, per_gpu_scorings * f_dtw_exec
+    dtw_bytes = per_gpu_scorings * (4 * K + 4 * (T + 2))
+    r_dtw = {"bound": "valu", "kernel": "dtw_band_kernel", "achieved": dtw_ref_flops / dtw_s / 1e12 if dtw_s else 0.0, "peak": VALU_PEAK / 1e12,
+             "unit": "TFLOP/s", "frac": dtw_ref_flops / dtw_s / VALU_PEAK if dtw_s else 0.0,
+             "traffic": pmc.get("dtw", {}).get("hbm_bytes_per_launch_corrected"), "traffic_source": pmc_src if "dtw" in pmc else None,
+             "avg_launch_ms": k_ms["dtw"][0], "launches_timed": k_ms["dtw"][1],
+             "algorithmic_flops_per_launch": dtw_ref_flops, "executed_flops_per_launch": dtw_exec_flops,
+             "executed_flop_frac": dtw_exec_flops / dtw_s / VALU_PEAK if dtw_s else 0.0,
+             "hbm": {"achieved": dtw_bytes / dtw_s / 1e9 if dtw_s else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": dtw_bytes / dtw_s / HBM_PEAK if dtw_s else 0.0, "algorithmic_bytes_per_launch": dtw_bytes},
+             "note": "fp32 vector roofline (no MFMA instruction in this kernel): `achieved`/`frac` price the REFERENCE-shaped flop count "
+                     "(SURVEY.md 8d: 2K+7 flops per band cell) against 157.3 TFLOP/s; the kernel executes fewer (executed_flops: K FMAs + 2 "
+                     "min3 + 1 add per cell), so executed_flop_frac is the honest flop fraction and valu_issue_frac the pipe saturation: "
+                     "VALU instructions x 4 cycles (packed-f32 issue slot) / (1024 SIMDs x launch time x 2.4 GHz)"}
+    if "dtw" in pmc and "instructions_per_launch" in pmc["dtw"]:
+        r_dtw["valu_insts_per_launch"] = pmc["dtw"]["instructions_per_launch"]["SQ_INSTS_VALU"]
+        r_dtw["valu_issue_frac"] = 4.0 * r_dtw["valu_insts_per_launch"] / simd_cycles(dtw_s) if dtw_s else 0.0
+    mfcc_bytes, mfcc_flops = S * nf * (640 + 4 * K), S * nf * f_mfcc
+    r_mfcc = {"bound": "hbm", "kernel": "mfcc_kernel", "achieved": mfcc_bytes / mfcc_s / 1e9 if mfcc_s else 0.0, "peak": HBM_PEAK / 1e9,
+              "unit": "GB/s", "frac": mfcc_bytes / mfcc_s / HBM_PEAK if mfcc_s else 0.0,
+              "traffic": pmc.get("mfcc", {}).get("hbm_bytes_per_launch_corrected"), "traffic_source": pmc_src if "mfcc" in pmc else None,
+              "avg_launch_ms": k_ms["mfcc"][0], "launches_timed": k_ms["mfcc"][1], "algorithmic_bytes_per_launch": mfcc_bytes,
+              "fp32_frac": mfcc_flops / mfcc_s / VALU_PEAK if mfcc_s else 0.0,
+              "note": "660 B per frame (640 B of new PCM + 4K B out) against 8 TB/s; fp32_frac = 13.2 kflop per frame against 157.3 TFLOP/s"}
+    if "mfcc" in pmc and "instructions_per_launch" in pmc["mfcc"]:
+        r_mfcc["valu_insts_per_launch"] = pmc["mfcc"]["instructions_per_launch"]["SQ_INSTS_VALU"]
+        r_mfcc["valu_issue_frac"] = 4.0 * r_mfcc["valu_insts_per_launch"] / simd_cycles(mfcc_s) if mfcc_s else 0.0
+    roofline = dict(r_dtw if dom == "dtw" else r_mfcc)
+    roofline["kernels_ms"] = {k: round(v[0], 4) for k, v in k_ms.items()}
+    roofline["path_hbm_frac"] = (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK
+    roofline["path_valu_frac_fp32"] = (value / world) * (f_mfcc * nf / n_win + f_dtw_ref) / VALU_PEAK
 
+    tag = {(65536, 8): "C3", (8192, 64): "C4 (per-GPU share)", (1024, 8): "C2"}.get((S, T), "custom") if len(set(lens)) == 1 and lens[0] == 100 else "custom"
     out = {
         "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d synthetic 16 kHz f32 streams x %d templates per GPU (%g s streams, L=%d, K=%d, band 5, "
-                               "ScoreMode::Max, avg gate off)" % ({(65536, 8): "C3", (8192, 64): "C4 (per-GPU share)", (1024, 8): "C2"}.get((S, T), "custom"),
-                                                                  S, T, N / 16000.0, L, K),
+        "config": {"workload": "%s: %d synthetic 16 kHz f32 streams x %d templates per GPU (%g s streams, L=%s, K=%d, band 5, "
+                               "ScoreMode::%s, %s)" % (tag, S, T, N / 16000.0, lens[0] if len(set(lens)) == 1 else "/".join(map(str, lens)), K,
+                                                       args.score_mode.capitalize(),
+                                                       ("averaged template + avg_threshold 0.2 (reference default), " +
+                                                        ("every window scored anyway" if args.full_scores else "gated windows skipped"))
+                                                       if args.avg_gate else "avg gate off"),
                    "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
-                   "windows_per_stream": n_win, "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world},
-        "roofline": roofline,
+                   "windows_per_stream": n_win, "template_chunks": n_chunks,
+                   "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world},
+        "roofline": roofline, "roofline_other": r_mfcc if dom == "dtw" else r_dtw,
     }
+    if backend != "nccl" and world > 1:
+        out["oversubscribed"] = {"devices": torch.cuda.device_count(), "backend": backend,
+                                 "note": "ranks share GPUs: a launch-path dry run, not a scaling measurement"}
+    if args.avg_gate:
+        # how many windows pass the gate on this input (one extra pass over the averaged template, not timed)
+        mf = torch.empty((S, nf, K), dtype=torch.float32, device=dev)
+        ctx.mfcc_dev(pcm.data_ptr(), S, N, N, K, mf.data_ptr())
+        sc_ = torch.empty((S, n_win, T), dtype=torch.float32, device=dev)
+        av_ = torch.empty((S, n_win), dtype=torch.float32, device=dev)
+        ag_ = torch.empty((S, n_win), dtype=torch.float32, device=dev)
+        ctx.dtw_dev(mf.data_ptr(), S, nf, tmpl, cfg.score_ref, cfg.band_size, cfg.score_mode, 1, sc_.data_ptr(), av_.data_ptr(), ag_.data_ptr())
+        torch.cuda.synchronize()
+        out["config"]["gate_pass_fraction"] = float((~(av_ < cfg.avg_threshold)).float().mean().item())
+        del mf, sc_, av_, ag_
 
     # ---- CPU baseline: the oracle's restatement of the reference algorithm on this host's cores
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.avg_gate and len(set(lens)) == 1:
         from oracle import rp_oracle as orc
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         try:  # honour a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
@@ -232,9 +310,10 @@ def main():
         dist.destroy_process_group()
 
 
-def make_templates(args, ra, ctx, torch, dev):
+def make_templates(ra, ctx, torch, dev, lens, K):
+    """Template t = MFCC (HIP path) of a synthetic utterance seeded SEED+1+t, whole-matrix mean normalisation, cut to lens[t]."""
     import numpy as np
-    T, L, K = args.templates, args.template_len, args.mfcc_size
+    T, L = len(lens), max(lens)
     n_t = 480 * -(-(L + 3) // 3)
     tp = torch.empty((T, n_t), dtype=torch.float32, device=dev)
     for t in range(T):
@@ -242,7 +321,7 @@ def make_templates(args, ra, ctx, torch, dev):
     tmf = torch.empty((T, ra.mfcc_num_frames(n_t), K), dtype=torch.float32, device=dev)
     ctx.mfcc_dev(tp.data_ptr(), T, n_t, n_t, K, tmf.data_ptr())
     torch.cuda.synchronize()
-    return [np.ascontiguousarray((m - m.mean(axis=0, dtype=np.float32))[:L], dtype=np.float32) for m in tmf.cpu().numpy()]
+    return [np.ascontiguousarray((m - m.mean(axis=0, dtype=np.float32))[:lens[t]], dtype=np.float32) for t, m in enumerate(tmf.cpu().numpy())]
 
 
 def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
@@ -252,7 +331,7 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
     S, T, n = args.streams, args.templates, args.chunks_per_call
     ctx = ra.BatchContext(device=local_rank, host_pointers=False)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    tmpl = ra.Templates(ctx, make_templates(args, ra, ctx, torch, dev))
+    tmpl = ra.Templates(ctx, make_templates(ra, ctx, torch, dev, [args.template_len] * args.templates, args.mfcc_size))
     cfg = ra.DetectorConfig()
     cfg.avg_threshold = 0.0
     sb = ra.StreamBatch(ctx, tmpl, cfg, S, max_chunks_per_call=n)
@@ -305,6 +384,8 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
 
 def bench_resample(args, ra, torch, dist, dev, world, rank, local_rank):
     """The sample-rate converter in front of the path: S streams of 4 s at 48 kHz f32 -> 16 kHz."""
+    if world > 1:
+        raise SystemExit("--mode resample is a single-GPU measurement (launch it with --gpus 1)")
     fs = 48000
     S = min(args.streams, 16384)  # 16384 x 4 s x 48 kHz f32 = 12.6 GB in, 4.2 GB out, + the staged copy
     fi, fo = ra.resampler_frame_lengths(fs)

@@ -171,7 +171,10 @@ const char *rp_last_error(void);
 typedef struct rp_ctx rp_ctx;
 typedef struct rp_templates rp_templates;
 
-enum { RP_CTX_DEVICE_POINTERS = 0, RP_CTX_HOST_POINTERS = 1 };
+/* RP_CTX_FULL_SCORES: rp_batch_detect* compare every window with every sample template even when the averaged-template
+ * gate (avg_threshold != 0, wakeword_comp.rs:85-93) would skip them -- the behaviour of the per-window score outputs,
+ * forced for calls that do not ask for them (same detections either way; used to time the two paths). */
+enum { RP_CTX_DEVICE_POINTERS = 0, RP_CTX_HOST_POINTERS = 1, RP_CTX_FULL_SCORES = 2 };
 
 /* device: HIP device ordinal.  Fails (<0) if no HIP device is usable. */
 int rp_ctx_new(int device, int flags, rp_ctx **out);
@@ -294,7 +297,10 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
  * det [S][max_det], n_det [S] as in rp_detect_scan.  Optional outputs (NULL to skip): scores
  * [S][n_win][T] and agg [S][n_win] with n_win = rp_mfcc_num_frames(n_samples) - max_len + 1.
  * The wakeword's own threshold / avg_threshold overrides (Option<f32> in the .rpw) are passed in
- * `config` by the caller; avg gate as in WakewordComparator::run_detection :83-93. */
+ * `config` by the caller; avg gate as in WakewordComparator::run_detection :83-93: with an averaged template and
+ * avg_threshold != 0, windows whose avg_score is below the threshold are NOT compared with the sample templates
+ * (one DTW instead of T+1) unless `scores` / `agg` are requested -- those arrays hold every window -- or the
+ * context has RP_CTX_FULL_SCORES; the detections are the same on either path. */
 int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, const rp_templates *t,
                     const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det,
                     float *scores, float *agg);
@@ -303,6 +309,19 @@ int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, s
 int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                         const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                         int max_det, float *scores, float *agg);
+
+/* Multi-GPU form of rp_batch_detect_fmt: independent streams shard across the GPUs of a node, nothing is
+ * exchanged but the final per-stream results.  The caller owns one context per device (rp_ctx_new(device g)) with the
+ * wakeword replicated on each (rp_templates_new on every context; <= 128 KB).  Shard g = S[g] streams whose PCM
+ * pcm[g] lives on ctxs[g]'s device (or in host memory if the contexts have RP_CTX_HOST_POINTERS); global stream ids are
+ * assigned in shard order (shard g holds streams sum(S[0..g)) .. ).  One host thread per shard drives its device and
+ * stream -- the reference's `Rustpotter: Send`, one detector per thread -- and every shard's detections are gathered
+ * into ONE block: det [sum S][max_det] / n_det [sum S], `stream` fields holding global ids, in host memory
+ * (RP_CTX_HOST_POINTERS) or on ctxs[0]'s device (peer copies over xGMI).  Returns when the gathered block is complete.
+ * Same detections as one rp_batch_detect_fmt call over the concatenated streams. */
+int rp_batch_detect_sharded(rp_ctx *const *ctxs, const rp_templates *const *t, int n_shards, const void *const *pcm,
+                            rp_sample_format fmt, const size_t *S, size_t n_samples, size_t pcm_stride,
+                            const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det);
 
 /* rp_batch_detect for a detector that holds SEVERAL wakewords (run_wakeword_detectors, src/detector.rs:433-447: every
  * wakeword whose own thresholds pass proposes a detection for the frame, the best score wins; max_mfcc_frames is the

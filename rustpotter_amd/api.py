@@ -107,7 +107,7 @@ SYMBOLS = [
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
     "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
     "rp_wakeword_model_train", "rp_stream_batch_set_input", "rp_stream_batch_samples_per_chunk",
-    "rp_batch_detect_multi", "rp_batch_detect_model",
+    "rp_batch_detect_multi", "rp_batch_detect_model", "rp_batch_detect_sharded",
 ]
 
 
@@ -179,6 +179,8 @@ def load_library():
                                           C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), fp, fp]
     L.rp_batch_detect_multi.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp),
                                         C.POINTER(_DetectorConfig), fp, fp, vp, vp, vp, C.c_int]
+    L.rp_batch_detect_sharded.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_int, C.POINTER(C.c_size_t), C.c_size_t,
+                                          C.c_size_t, C.POINTER(_DetectorConfig), vp, vp, C.c_int]
     L.rp_batch_detect_model.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_int, C.c_int,
                                         C.POINTER(_DetectorConfig), C.c_int, vp, vp, vp, C.c_int]
     L.rp_resampler_frame_lengths.argtypes = [C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
@@ -518,15 +520,55 @@ class StreamBatch:
             raise _err()
 
 
+def batch_detect_sharded(ctxs, templates, pcms, detector_config, max_det=8):
+    """rp_batch_detect_sharded with host-pointer contexts: pcms = one [S_g][N] numpy array per shard (same N and dtype)
+    -> (det [sum S][max_det], n_det [sum S]) gathered, global stream ids."""
+    import numpy as np
+    L = load_library()
+    n = len(ctxs)
+    assert n == len(templates) == len(pcms) and all(c.host for c in ctxs)
+    arrs = [np.ascontiguousarray(p) for p in pcms]
+    fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(arrs[0].dtype)
+    if fmt is None:
+        arrs, fmt = [np.ascontiguousarray(a, np.float32) for a in arrs], 3
+    N = arrs[0].shape[1]
+    S = (C.c_size_t * n)(*[a.shape[0] for a in arrs])
+    total = sum(a.shape[0] for a in arrs)
+    det = np.zeros((total, max_det), dtype=DET_DTYPE)
+    n_det = np.zeros(total, np.int32)
+    c = detector_config._c()
+    hc = (C.c_void_p * n)(*[x._h for x in ctxs])
+    ht = (C.c_void_p * n)(*[x._h for x in templates])
+    hp = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    if L.rp_batch_detect_sharded(hc, ht, n, hp, fmt, S, N, N, C.byref(c), det.ctypes.data, n_det.ctypes.data, max_det) < 0:
+        raise _err()
+    return det, n_det
+
+
+def batch_detect_sharded_dev(ctxs, templates, pcm_ptrs, S_list, N, stride, detector_config, det_ptr, n_det_ptr, max_det):
+    """Device-pointer form: pcm_ptrs[g] on ctxs[g]'s device, det / n_det gathered on ctxs[0]'s device."""
+    L = load_library()
+    n = len(ctxs)
+    c = detector_config._c()
+    hc = (C.c_void_p * n)(*[x._h for x in ctxs])
+    ht = (C.c_void_p * n)(*[x._h for x in templates])
+    hp = (C.c_void_p * n)(*pcm_ptrs)
+    S = (C.c_size_t * n)(*S_list)
+    if L.rp_batch_detect_sharded(hc, ht, n, hp, 3, S, N, stride, C.byref(c), det_ptr, n_det_ptr, max_det) < 0:
+        raise _err()
+
+
 class BatchContext:
     """rp_ctx.  host_pointers=True: numpy in / numpy out (tests); False: raw device
     pointers (bench.py passes torch tensors' data_ptr())."""
 
-    def __init__(self, device=0, host_pointers=True):
+    def __init__(self, device=0, host_pointers=True, full_scores=False):
+        """full_scores (RP_CTX_FULL_SCORES): batch_detect compares every window with every sample template even where the
+        averaged-template gate would skip them."""
         self._L = load_library()
         self._h = C.c_void_p()
         self.host = host_pointers
-        if self._L.rp_ctx_new(device, 1 if host_pointers else 0, C.byref(self._h)) < 0:
+        if self._L.rp_ctx_new(device, (1 if host_pointers else 0) | (2 if full_scores else 0), C.byref(self._h)) < 0:
             self._h = None
             raise _err()
 

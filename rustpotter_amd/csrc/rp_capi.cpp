@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "rp_host.h"
 
@@ -441,9 +442,24 @@ int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, s
     return rp_batch_detect_fmt(ctx, pcm, RP_SAMPLE_F32, S, n_samples, pcm_stride, t, config, det, n_det, max_det, scores, agg);
 }
 
+// The body of rp_batch_detect_fmt.  gather (rp_batch_detect_sharded): the detections of this shard are reported with
+// stream ids starting at stream_base and, instead of going to `det` / `n_det` directly, are copied from this context's
+// buffers into the gathered block `det` / `n_det` (rows stream_base..) that lives in host memory (gather_host) or on
+// device gather_device (peer copy over xGMI).
+struct GatherTo { bool on = false, host = true; int device = 0; int stream_base = 0; };
+static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                             const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
+                             int max_det, float *scores, float *agg, const GatherTo &gather);
+
 int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                         const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                         int max_det, float *scores, float *agg) {
+    return batch_detect_impl(ctx, pcm, fmt, S, n_samples, pcm_stride, t, config, det, n_det, max_det, scores, agg, GatherTo{});
+}
+
+static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                             const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
+                             int max_det, float *scores, float *agg, const GatherTo &gather) {
     return guarded([&]() -> int {
         if (!ctx || !t) { set_last_error("null handle"); return -1; }
         if (!config || (S && (!pcm || !det || !n_det))) { set_last_error("null argument"); return -1; }
@@ -462,9 +478,18 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
         const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
         BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
         int32_t *dn = static_cast<int32_t *>(sg.out(n_det, S * sizeof(int32_t), c->stage_out2));
+        if (gather.on) {  // results are produced in this context's own buffers and copied into the gathered block below
+            if (!c->stage_out.reserve(S * (size_t)max_det * sizeof(BatchDetection) + 16) || !c->stage_out2.reserve(S * sizeof(int32_t) + 16)) return -1;
+            dd = c->stage_out.as<BatchDetection>(); dn = c->stage_out2.as<int32_t>();
+        }
         // caller-provided score arrays are used directly when they are device pointers
         float *ds = (scores && !sg.host) ? scores : nullptr, *dg = (agg && !sg.host) ? agg : nullptr;
-        if (!c->ws_mfcc.reserve(S * nf * td.K * sizeof(float) + 16)) return -1;
+        if (!c->ws_mfcc.reserve(S * nf * td.K * sizeof(float) + 64 * td.K * sizeof(float))) return -1;  // slack: the list kernel's band reads past a row
+        // The averaged-template gate as the reference runs it (wakeword_comp.rs:85-93): a window whose avg_score is below
+        // avg_threshold is never compared with the sample templates.  Taken when the caller did not ask for the
+        // per-window score arrays (those are defined for every window) and RP_CTX_FULL_SCORES is not set.
+        const bool gated = do_avg && !scores && !agg && !(c->flags & RP_CTX_FULL_SCORES) && dtw_gate_supported(td, config->band_size, rows);
+        if (gated && !c->ws_list.reserve((rows + 1) * sizeof(uint32_t) + 16)) return -1;
         if (!ds) { if (!c->ws_scores.reserve(rows * td.T * sizeof(float) + 16)) return -1; ds = c->ws_scores.as<float>(); }
         if (!dg) { if (!c->ws_agg.reserve(rows * sizeof(float) + 16)) return -1; dg = c->ws_agg.as<float>(); }
         float *da = nullptr;
@@ -476,7 +501,13 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
         c->time_end();
         if (!ok) return -1;
         c->time_begin(kKernelDtw);
-        ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+        if (gated) {
+            uint32_t *lst = c->ws_list.as<uint32_t>();
+            ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, n_win, config->band_size, config->score_ref, config->avg_threshold,
+                                         ds, da, lst + 1, lst), "dtw kernels (gated)");
+        } else {
+            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+        }
         c->time_end();
         if (!ok) return -1;
         c->time_begin(kKernelAggregate);
@@ -486,6 +517,7 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
         ScanConfig sc;
         sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
         sc.eager = config->eager ? 1 : 0; sc.max_len = td.max_len; sc.avg_enabled = do_avg ? 1 : 0;
+        sc.stream_base = gather.stream_base;
         float *dv = nullptr;
         if (config->vad_mode != RP_VAD_NONE) {
             if (!c->ws_vad.reserve(S * nf * sizeof(float) + 16)) return -1;
@@ -496,10 +528,66 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
         ok = hip_ok(launch_scan(c->stream, dg, da, dv, vad_mode_value(config->vad_mode), S, nf, sc, dd, dn, max_det), "scan_kernel");
         c->time_end();
         if (!ok) return -1;
+        if (gather.on) {
+            // final result gather: this shard's block into the gathered arrays -- device to host, or a peer
+            // copy to the gathering device (xGMI between the GPUs of a node)
+            rp_batch_detection *gd = det + (size_t)gather.stream_base * (size_t)max_det;
+            int32_t *gn = n_det + gather.stream_base;
+            const size_t bd = S * (size_t)max_det * sizeof(BatchDetection), bn = S * sizeof(int32_t);
+            if (gather.host) {
+                if (!hip_ok(hipMemcpyAsync(gd, dd, bd, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync(gather)") ||
+                    !hip_ok(hipMemcpyAsync(gn, dn, bn, hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync(gather)")) return -1;
+            } else {
+                if (!hip_ok(hipMemcpyPeerAsync(gd, gather.device, dd, c->device, bd, c->stream), "hipMemcpyPeerAsync(gather)") ||
+                    !hip_ok(hipMemcpyPeerAsync(gn, gather.device, dn, c->device, bn, c->stream), "hipMemcpyPeerAsync(gather)")) return -1;
+            }
+            return hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize") ? 0 : -1;
+        }
         if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
         if (sg.host && scores && !sg.back(scores, ds, rows * td.T * sizeof(float))) return -1;
         if (sg.host && agg && !sg.back(agg, dg, rows * sizeof(float))) return -1;
         return sg.finish() ? 0 : -1;
+    });
+}
+
+int rp_batch_detect_sharded(rp_ctx *const *ctxs, const rp_templates *const *t, int n_shards, const void *const *pcm,
+                            rp_sample_format fmt, const size_t *S, size_t n_samples, size_t pcm_stride,
+                            const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det) {
+    return guarded([&]() -> int {
+        if (!ctxs || !t || !pcm || !S || !config || !det || !n_det) { set_last_error("null argument"); return -1; }
+        if (n_shards < 1 || n_shards > 64) { set_last_error("rp_batch_detect_sharded: 1..64 shards"); return -1; }
+        size_t total = 0;
+        std::vector<size_t> first((size_t)n_shards);
+        for (int g = 0; g < n_shards; ++g) {
+            if (!ctxs[g] || !t[g]) { set_last_error("null handle"); return -1; }
+            if (t[g]->impl->ctx != ctxs[g]->impl.get()) { set_last_error("rp_batch_detect_sharded: templates[g] must have been created on ctxs[g]"); return -1; }
+            if ((ctxs[g]->impl->flags & RP_CTX_HOST_POINTERS) != (ctxs[0]->impl->flags & RP_CTX_HOST_POINTERS)) {
+                set_last_error("rp_batch_detect_sharded: all contexts must agree on RP_CTX_HOST_POINTERS"); return -1;
+            }
+            for (int h = 0; h < g; ++h) if (ctxs[h] == ctxs[g]) { set_last_error("rp_batch_detect_sharded: a context may serve one shard only"); return -1; }
+            if (S[g] && !pcm[g]) { set_last_error("null argument"); return -1; }
+            first[g] = total; total += S[g];
+        }
+        if (total > 0x7fffffffULL) { set_last_error("rp_batch_detect_sharded: too many streams"); return -1; }
+        GatherTo to;
+        to.on = true; to.host = (ctxs[0]->impl->flags & RP_CTX_HOST_POINTERS) != 0; to.device = ctxs[0]->impl->device;
+        // one host thread per shard drives that shard's device and stream; the shards share nothing but read-only inputs
+        std::vector<int> status((size_t)n_shards, 0);
+        std::vector<std::string> errs((size_t)n_shards);
+        auto run = [&](int g) {
+            GatherTo mine = to;
+            mine.stream_base = (int)first[g];
+            status[g] = S[g] ? batch_detect_impl(ctxs[g], pcm[g], fmt, S[g], n_samples, pcm_stride, t[g], config, det, n_det, max_det, nullptr,
+                                                 nullptr, mine) : 0;
+            if (status[g] != 0) errs[g] = last_error();  // the error text is thread-local: hand it to the caller's thread
+        };
+        std::vector<std::thread> th;
+        for (int g = 1; g < n_shards; ++g) th.emplace_back(run, g);
+        run(0);
+        for (auto &x : th) x.join();
+        for (int g = 0; g < n_shards; ++g)
+            if (status[g] != 0) { set_last_error("shard " + std::to_string(g) + ": " + errs[g]); return -1; }
+        return 0;
     });
 }
 

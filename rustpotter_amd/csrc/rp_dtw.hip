@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
     const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
-    int flat, size_t n_streams) {
+    int flat, size_t n_streams, const uint32_t *__restrict__ list = nullptr, const uint32_t *__restrict__ list_count = nullptr) {
     constexpr int B = 2 * W;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -54,8 +54,17 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     const float *xl;
     if (GX) {
         static_assert(!GX || KP == K, "global-memory frames have pitch K");
-        const size_t f = (size_t)tile * kDtwWin + lane;
-        valid = f < n_streams * n_win;
+        size_t f = (size_t)tile * kDtwWin + lane;
+        if (list) {
+            // the windows that passed the averaged-template gate (gate_compact_kernel): row ids s * n_win + w.  The grid is
+            // sized for every window; tiles past the list's end have nothing to do.
+            const uint32_t n_listed = *list_count;
+            if ((size_t)tile * kDtwWin >= n_listed) return;
+            valid = f < n_listed;
+            f = list[valid ? f : n_listed - 1];
+        } else {
+            valid = f < n_streams * n_win;
+        }
         s = valid ? f / n_win : 0;
         w = valid ? (int)(f - s * n_win) : 0;
         xl = mfcc + (s * frame_pitch + first_win + (size_t)w) * K;
@@ -405,23 +414,25 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
 }
 
 template <int K, int W, int TC>
-static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
+static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                                    size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
-                                   float score_ref, float *scores, float *avg, bool few_windows) {
+                                   float score_ref, float *scores, float *avg, bool few_windows, const uint32_t *list = nullptr,
+                                   const uint32_t *list_count = nullptr) {
     if (n_chunks <= 0) return hipSuccess;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
-    if (few_windows && KP == K && W == 5) {
-        // streams contribute fewer than 64 windows each: lanes of a wave span many streams and read their frames
-        // from global memory (the caller guarantees W*K floats of slack after the last stream's frames)
+    if ((few_windows || list) && KP == K) {
+        // streams contribute fewer than 64 windows each (or the windows come from a list): lanes of a wave span many
+        // streams and read their frames from global memory (the caller guarantees W*K floats of slack after the last
+        // stream's frames)
         const size_t ft = (S * n_win + kDtwWin - 1) / kDtwWin;
         const size_t blocks = ft * (size_t)n_chunks;
         if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-        if (W == 5)
-            hipLaunchKernelGGL((dtw_band_kernel<K, 5, TC, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
-                               frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
-                               t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S);
+        hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
+                           frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
+                           t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S, list, list_count);
         return hipGetLastError();
     }
+    if (list) return hipErrorNotSupported;
     // flattened (stream, window) tiling when every stream has at least one full tile of windows
     const int flat = (n_win >= (size_t)kDtwWin && S > 1) ? 1 : 0;
     const size_t ft = flat ? (S * n_win + kDtwWin - 1) / kDtwWin : tiles;
@@ -429,7 +440,7 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int cl
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + W)) * KP * sizeof(float);
     hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
-                       frame_pitch, (unsigned)ft, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+                       frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
     return hipGetLastError();
 }
@@ -558,11 +569,79 @@ int dtw_register_tile(int K, int band) {
 template <int W>
 static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n2, const float *mfcc, size_t S, size_t frame_pitch,
                                 size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
-                                float *scores, float *avg, bool few) {
+                                float *scores, float *avg, bool few, const uint32_t *list = nullptr, const uint32_t *list_count = nullptr) {
     hipError_t e;
-    if ((e = launch_dtw_class<5, W, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)) != hipSuccess) return e;
-    if ((e = launch_dtw_class<5, W, 4>(st, t, 1, t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)) != hipSuccess) return e;
-    return launch_dtw_class<5, W, 8>(st, t, 2, t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+    if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
+    if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
+    return launch_dtw_class<5, W, 8>(st, t, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count);
+}
+
+// ---- the averaged-template gate as a skip (wakeword_comp.rs:85-93) -------------------------------------------------
+// The reference scores the window against the averaged template first and returns None when that score is below
+// avg_threshold: the T sample templates are never compared.  Batched: pass 1 scores EVERY window against the averaged
+// template only, gate_compact_kernel lists the rows that pass, pass 3 runs the sample templates on the listed rows
+// (one lane per listed window, frames read from global memory).  Rows that are not listed keep whatever `scores` held.
+// One wave lists 16 x 64 consecutive rows with a single atomic (one atomic per wave-row of 64 would serialise on the
+// counter: ~300 k atomics at C3); the order inside a wave's block is preserved, so neighbouring windows stay neighbours.
+__global__ __launch_bounds__(256) void gate_compact_kernel(const float *__restrict__ avg, size_t rows, float avg_threshold,
+                                                           uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t r0 = wave * 1024;
+    if (r0 >= rows) return;
+    unsigned long long m[16];
+    unsigned total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const size_t r = r0 + (size_t)i * 64 + lane;
+        const bool pass = r < rows && !(avg[r] < avg_threshold);  // `avg_score < avg_threshold -> None`
+        m[i] = __ballot(pass);
+        total += (unsigned)__popcll(m[i]);
+    }
+    if (total == 0) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(count, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if ((m[i] >> lane) & 1ull) list[base + (unsigned)__popcll(m[i] & ((1ull << lane) - 1ull))] = (uint32_t)(r0 + (size_t)i * 64 + lane);
+        base += (unsigned)__popcll(m[i]);
+    }
+}
+
+bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows) {
+    return t.has_avg && t.K == 5 && band >= 3 && band <= 6 && t.max_diff == 0 && t.chunks && rows > 0 && rows < 0xffffffffULL;
+}
+
+hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t n_win,
+                            int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                            uint32_t *count) {
+    const size_t rows = S * n_win;
+    if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
+    const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
+    const int avg_chunk = t.class_first[0] + t.class_count[0] - 1;  // the averaged template: last chunk of class 2
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    // pass 1: the averaged template over every window (LDS-staged tiles like the ungated kernel)
+    switch (band) {
+    case 3: e = launch_dtw_class<5, 3, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    case 4: e = launch_dtw_class<5, 4, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    case 5: e = launch_dtw_class<5, 5, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    default: e = launch_dtw_class<5, 6, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    }
+    if (e != hipSuccess) return e;
+    // pass 2: list the rows whose avg_score is not below the threshold
+    const size_t waves = (rows + 1023) / 1024, blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // pass 3: the sample templates on the listed rows
+    const int n2 = t.class_count[0] - 1;
+    switch (band) {
+    case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
+    case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
+    case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
+    default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
+    }
 }
 
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,

@@ -109,7 +109,7 @@ struct Ctx {
     // staging for RP_CTX_HOST_POINTERS
     DevBuf stage_in, stage_out, stage_out2, stage_out3;
     // intermediates of rp_batch_detect
-    DevBuf ws_mfcc, ws_scores, ws_agg, ws_avg, ws_vad, ws_ring, ws_rms, ws_gain;
+    DevBuf ws_mfcc, ws_scores, ws_agg, ws_avg, ws_vad, ws_ring, ws_rms, ws_gain, ws_list;
 
     static Ctx *create(int device, int flags);
     ~Ctx();

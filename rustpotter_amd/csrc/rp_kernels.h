@@ -89,6 +89,7 @@ struct ScanConfig {
     float threshold, avg_threshold;
     int min_scores, eager, max_len, avg_enabled;
     int fpf = 3;  // MFCC frames per input frame of the stream's encoder: 3 (480 encoded samples) or 4 (640: 11.025 / 22.05 kHz input)
+    int stream_base = 0;  // added to the stream index a detection reports (a shard's first global stream, rp_batch_detect_sharded)
 };
 
 // the wakewords of one detector in the batched scan (run_wakeword_detectors, src/detector.rs:433-447): per wakeword
@@ -122,6 +123,15 @@ hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                       float *scores, float *avg, bool padded_rows = false);
+
+// The averaged-template gate as a skip (wakeword_comp.rs:85-93): every window against the averaged template (-> avg),
+// the rows with avg >= avg_threshold listed (list [S*n_win] / count: device workspaces), the sample templates on the
+// listed rows only (-> scores; other rows are not written).  mfcc needs 64*K floats of slack behind the last stream.
+// hipErrorNotSupported when the template set has no register kernel for this (see dtw_gate_supported).
+bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows);
+hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t n_win,
+                            int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                            uint32_t *count);
 
 // Largest template tile the register DTW kernel is built for (0: only the generic kernel applies).
 int dtw_register_tile(int K, int band);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
                 if (p_counter >= cfg.min_scores) {
                     if (nd < max_det) {
                         BatchDetection d;
-                        d.stream = (int32_t)s; d.frame = (int32_t)f; d.window = p_window; d.counter = p_counter;
+                        d.stream = (int32_t)s + cfg.stream_base; d.frame = (int32_t)f; d.window = p_window; d.counter = p_counter;
                         d.avg_score = p_avg; d.score = p_score;
                         det[s * (size_t)max_det + nd] = d;
                         if (det_ww) det_ww[s * (size_t)max_det + nd] = p_ww;

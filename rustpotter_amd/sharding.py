@@ -42,6 +42,8 @@ def gather_ragged(local, world_size, group=None):
     import torch.distributed as dist
     if world_size == 1:
         return local
+    if local.is_cuda and dist.get_backend(group) == "gloo":  # CPU-backend dry runs: stage through host memory
+        return gather_ragged(local.cpu(), world_size, group).to(local.device)
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world_size)]
     dist.all_gather(sizes, n, group=group)

@@ -1,0 +1,368 @@
+"""GPU tests added in round 2 (all through the C ABI): the averaged-template gate as a skip, the multi-GPU paths
+(two ranks sharing one GPU over gloo, rp_batch_detect_sharded, bench.py starting its own ranks), BASELINE configs C2 and
+C5 at their full sizes, and NULL-argument handling with live handles."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import rpw_py
+import simstream
+from oracle import rp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = simstream.GOLDEN
+EXP = json.load(open(os.path.join(G, "expectations.json")))
+SEED = 0x5EED000000000001
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rustpotter_amd
+    return rustpotter_amd
+
+
+def _fixture_streams(n_variants=6):
+    """Variants of the reference's simulation stream (tests/detector.rs:372-426): shifted by whole chunks, with noise."""
+    base = simstream.i16_to_f32(simstream.simulation_stream_i16())
+    rng = np.random.default_rng(7)
+    n = (len(base) // 480) * 480
+    out = [base[:n]]
+    for i in range(1, n_variants):
+        v = np.roll(base, 480 * (3 + 5 * i))
+        if i % 2:
+            v = v + rng.standard_normal(len(base)).astype(np.float32) * np.float32(0.001 * i)
+        out.append(v[:n].astype(np.float32))
+    return np.stack(out)
+
+
+def _wakeword(ra, ctx, name="oye_casa_g.rpw"):
+    w = rpw_py.load_rpw(os.path.join(G, name))
+    return ra.Templates(ctx, list(w["samples_features"].values()), avg=w["avg_features"])
+
+
+# ------------------------------------------------------------------ the averaged-template gate as a skip
+@pytest.mark.parametrize("avg_threshold,threshold", [(0.2, 0.5), (0.4, 0.45), (0.55, 0.45), (0.62, 0.3), (0.9, 0.3)])
+def test_avg_gate_skip_gives_the_detections_of_full_scoring(ra, avg_threshold, threshold):
+    """wakeword_comp.rs:85-93: a window whose avg_score is below avg_threshold is not compared with the sample templates.
+    The skipping path (one DTW for gated windows) and RP_CTX_FULL_SCORES (T+1 DTWs for every window) must report the
+    same detections, field by field and bit by bit, whatever part of the windows the gate removes."""
+    pcm = _fixture_streams()
+    gated, full = ra.BatchContext(0), ra.BatchContext(0, full_scores=True)
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold, cfg.threshold = avg_threshold, threshold
+    det_g, n_g = gated.batch_detect(pcm, _wakeword(ra, gated), cfg)
+    det_f, n_f = full.batch_detect(pcm, _wakeword(ra, full), cfg)
+    assert np.array_equal(n_g, n_f)
+    assert det_g.tobytes() == det_f.tobytes()
+    # the per-window arrays stay complete when they are asked for (then nothing is skipped)
+    det_s, n_s, scores, agg = gated.batch_detect(pcm, _wakeword(ra, gated), cfg, want_scores=True)
+    assert np.array_equal(n_s, n_f) and det_s.tobytes() == det_f.tobytes()
+    assert np.isfinite(scores).all() and np.isfinite(agg).all()
+    if avg_threshold <= 0.55:
+        assert n_f.sum() >= 1   # the planted utterances are found
+    if avg_threshold >= 0.9:
+        assert n_f.sum() == 0   # nothing passes the gate: the list is empty and every tile of pass 3 exits
+
+
+def test_avg_gate_skip_on_synthetic_noise_many_streams(ra):
+    """Many streams whose windows straddle the gate (threshold at the median avg_score): detections with a low score
+    threshold must agree between the two paths; band sizes 3..6 take the same route."""
+    S, N, K, L, T = 700, 480 * 60, 5, 40, 5
+    templates = orc.synth_templates(SEED, T, L, K)
+    avg = np.mean(templates, axis=0, dtype=np.float32)
+    gated, full = ra.BatchContext(0), ra.BatchContext(0, full_scores=True)
+    pcm = gated.synth_pcm(SEED, 0, S, N)
+    tg, tf = ra.Templates(gated, templates, avg=avg), ra.Templates(full, templates, avg=avg)
+    mf = gated.mfcc(pcm, K)
+    for band in (5, 3, 6):
+        _, av, ag = gated.dtw_scores(mf, tg, band_size=band, with_avg=True)
+        cfg = ra.DetectorConfig()
+        cfg.band_size = band
+        cfg.avg_threshold = float(np.median(av))
+        cfg.threshold = float(np.quantile(ag, 0.7))
+        cfg.min_scores = 2
+        det_g, n_g = gated.batch_detect(pcm, tg, cfg, max_det=6)
+        det_f, n_f = full.batch_detect(pcm, tf, cfg, max_det=6)
+        assert n_f.sum() > S // 4, "the case must produce detections"
+        assert np.array_equal(n_g, n_f) and det_g.tobytes() == det_f.tobytes()
+
+
+# ------------------------------------------------------------------ multi-GPU: ranks, shards, gather
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_worker(rank, world, port, out_path):
+    """One rank of the data-parallel path as bench.py runs it: its shard of the streams through rp_batch_detect on its
+    device (here both ranks share GPU 0), then ONE all_gather of the per-stream results."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import rustpotter_amd as ra
+    from rustpotter_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pcm_all = _fixture_streams(8)
+        lo, hi = sharding.shard_bounds(pcm_all.shape[0], world, rank)
+        torch.cuda.set_device(0)
+        ctx = ra.BatchContext(device=0, host_pointers=False)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        tm = _wakeword(ra, ctx)
+        cfg = ra.DetectorConfig()
+        cfg.threshold = 0.45
+        S, N = hi - lo, pcm_all.shape[1]
+        nf = ra.mfcc_num_frames(N)
+        n_win = nf - tm.max_len + 1
+        pcm = torch.from_numpy(pcm_all[lo:hi].copy()).cuda()
+        det = torch.zeros((S, 4, 6), dtype=torch.int32, device="cuda")
+        n_det = torch.zeros((S,), dtype=torch.int32, device="cuda")
+        scores = torch.empty((S, n_win, tm.T), dtype=torch.float32, device="cuda")
+        agg = torch.empty((S, n_win), dtype=torch.float32, device="cuda")
+        ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tm, cfg, det.data_ptr(), n_det.data_ptr(), 4, scores.data_ptr(), agg.data_ptr())
+        torch.cuda.synchronize()
+        det[:, :, 0] += lo  # global stream ids
+        chk = scores.view(torch.int32).to(torch.int64).sum(dim=(1, 2))  # per-stream checksum of the score bits
+        all_n = sharding.gather_ragged(n_det, world)
+        all_det = sharding.gather_ragged(det, world)
+        all_chk = sharding.gather_ragged(chk, world)
+        if rank == 0:
+            np.savez(out_path, n_det=all_n.cpu().numpy(), det=all_det.cpu().numpy(), chk=all_chk.cpu().numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_one_gpu_equal_a_single_rank(ra, tmp_path):
+    """SURVEY.md 8e on the product: 2 ranks (gloo, both on GPU 0) run rp_batch_detect on their stream shards and gather;
+    the gathered block equals one rank's run over all the streams (n_det, every detection record, score checksums)."""
+    import torch
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "gathered.npz")
+    mp.spawn(_rank_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    z = np.load(out)
+    pcm_all = _fixture_streams(8)
+    ctx = ra.BatchContext(device=0, host_pointers=True)
+    tm = _wakeword(ra, ctx)
+    cfg = ra.DetectorConfig()
+    cfg.threshold = 0.45
+    det, n_det, scores, _ = ctx.batch_detect(pcm_all, tm, cfg, max_det=4, want_scores=True)
+    assert np.array_equal(z["n_det"], n_det) and n_det.sum() >= 8
+    assert z["det"].astype(np.int32).tobytes() == det.view(np.int32).reshape(det.shape[0], 4, 6).tobytes()
+    assert np.array_equal(z["chk"], scores.view(np.int32).astype(np.int64).sum(axis=(1, 2)))
+
+
+def test_batch_detect_sharded_abi_equals_one_call(ra):
+    """rp_batch_detect_sharded: one context + one host thread per shard (here three contexts on GPU 0, ragged shards, one
+    of them empty), results gathered into one host block with global stream ids."""
+    pcm_all = _fixture_streams(7)
+    ctxs = [ra.BatchContext(0) for _ in range(3)]
+    tms = [_wakeword(ra, c) for c in ctxs]
+    cfg = ra.DetectorConfig()
+    cfg.threshold = 0.45
+    one = ra.BatchContext(0)
+    det1, n1 = one.batch_detect(pcm_all, _wakeword(ra, one), cfg, max_det=4)
+    for cuts in ((0, 3, 5, 7), (0, 7, 7, 7), (0, 0, 2, 7)):
+        parts = [pcm_all[cuts[g]:cuts[g + 1]] for g in range(3)]
+        det, n_det = ra.batch_detect_sharded(ctxs, tms, parts, cfg, max_det=4)
+        assert np.array_equal(n_det, n1) and det.tobytes() == det1.tobytes()
+        assert [int(d["stream"]) for s in range(7) for d in det[s][:n_det[s]]] == [s for s in range(7) for _ in range(n_det[s])]
+    # errors: a context used for two shards, templates that live on another context
+    with pytest.raises(ra.RustpotterError):
+        ra.batch_detect_sharded([ctxs[0], ctxs[0]], [tms[0], tms[0]], [pcm_all[:3], pcm_all[3:]], cfg)
+    with pytest.raises(ra.RustpotterError):
+        ra.batch_detect_sharded([ctxs[0], ctxs[1]], [tms[1], tms[0]], [pcm_all[:3], pcm_all[3:]], cfg)
+
+
+def test_batch_detect_sharded_device_pointers(ra):
+    """Device-pointer form: every shard's PCM on its own device, the gathered block on the first context's device."""
+    import torch
+    pcm_all = _fixture_streams(6)
+    ctxs = [ra.BatchContext(0, host_pointers=False) for _ in range(2)]
+    tms = [_wakeword(ra, c) for c in ctxs]
+    cfg = ra.DetectorConfig()
+    cfg.threshold = 0.45
+    N = pcm_all.shape[1]
+    parts = [torch.from_numpy(pcm_all[:2].copy()).cuda(), torch.from_numpy(pcm_all[2:].copy()).cuda()]
+    det = torch.zeros((6, 4, 6), dtype=torch.int32, device="cuda")
+    n_det = torch.zeros((6,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ra.batch_detect_sharded_dev(ctxs, tms, [p.data_ptr() for p in parts], [2, 4], N, N, cfg, det.data_ptr(), n_det.data_ptr(), 4)
+    one = ra.BatchContext(0)
+    det1, n1 = one.batch_detect(pcm_all, _wakeword(ra, one), cfg, max_det=4)
+    assert np.array_equal(n_det.cpu().numpy(), n1)
+    assert det.cpu().numpy().tobytes() == det1.view(np.int32).reshape(6, 4, 6).tobytes()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (the shape of the driver's command): the parent starts the two ranks
+    before touching the GPU and relays rank 0's JSON line.  On a one-GPU box the ranks share the device (dry run)."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env["RP_BENCH_OVERSUBSCRIBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "2048", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["steps"] == 2 and j["scaling"] == "weak"
+    assert j["roofline"]["bound"] in ("valu", "hbm") and j["roofline_other"]["kernel"] != j["roofline"]["kernel"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert j["oversubscribed"]["devices"] == torch.cuda.device_count()
+        # without the override a node with too few GPUs is refused, not silently oversubscribed
+        env.pop("RP_BENCH_OVERSUBSCRIBE")
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "512"], capture_output=True,
+                            text=True, timeout=300, env=env, cwd=ROOT)
+        assert r2.returncode != 0 and "RP_BENCH_OVERSUBSCRIBE" in r2.stderr
+
+
+def test_contexts_on_one_device_use_large_lds_kernels(ra):
+    """The >64 KB dynamic-LDS attribute is set per (device, kernel), not once per process: a second context still
+    launches the generic DTW kernel with a long template (LDS above 64 KB)."""
+    K, L = 24, 600   # (64 + L - 1) * 25 * 4 B = 66 KB of frames alone
+    rng = np.random.default_rng(1)
+    templates = [rng.standard_normal((L, K)).astype(np.float32)]
+    mf = rng.standard_normal((2, L + 70, K)).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        ctx = ra.BatchContext(0)
+        scores, _, _ = ctx.dtw_scores(mf, ra.Templates(ctx, templates))
+        outs.append(scores)
+    assert np.array_equal(outs[0], outs[1]) and np.isfinite(outs[0]).all()
+    ref, _ = orc.score_stream(mf[0][:L + 3], templates)
+    assert np.allclose(outs[0][0][:ref.shape[0]], ref, rtol=1e-5, atol=0)
+
+
+# ------------------------------------------------------------------ NULL arguments with live handles
+def test_null_arguments_with_live_handles(ra):
+    """config / pcm / det == NULL next to a valid context and template set is an error return, not a crash."""
+    import ctypes as C
+    L = ra.load_library()
+    ctx = ra.BatchContext(0)
+    tm = _wakeword(ra, ctx)
+    cfg = ra.DetectorConfig()._c()
+    pcm = np.zeros((1, 4800), np.float32)
+    det = np.zeros((1, 4), dtype=[("a", "<i4", 6)])
+    n_det = np.zeros(1, np.int32)
+    ok = L.rp_batch_detect_fmt(ctx._h, pcm.ctypes.data, 3, 1, 4800, 4800, tm._h, C.byref(cfg), det.ctypes.data, n_det.ctypes.data, 4, None, None)
+    assert ok == 0
+    assert L.rp_batch_detect_fmt(ctx._h, pcm.ctypes.data, 3, 1, 4800, 4800, tm._h, None, det.ctypes.data, n_det.ctypes.data, 4, None, None) == -1
+    assert b"null" in L.rp_last_error()
+    assert L.rp_batch_detect_fmt(ctx._h, None, 3, 1, 4800, 4800, tm._h, C.byref(cfg), det.ctypes.data, n_det.ctypes.data, 4, None, None) == -1
+    assert L.rp_batch_detect_fmt(ctx._h, pcm.ctypes.data, 3, 1, 4800, 4800, tm._h, C.byref(cfg), None, n_det.ctypes.data, 4, None, None) == -1
+    h = C.c_void_p()
+    assert L.rp_stream_batch_new(ctx._h, tm._h, None, 4, 1, C.byref(h)) == -1
+    assert L.rp_detect_scan(ctx._h, pcm.ctypes.data, None, 1, 10, 5, None, 0, None, 0, det.ctypes.data, n_det.ctypes.data, 4) == -1
+
+
+# ------------------------------------------------------------------ BASELINE configs at their sizes
+def test_c2_full_size_vs_oracle(ra):
+    """BASELINE config C2 (1 024 streams x 8 templates, 4 s streams) at size: probabilities, aggregate = row maximum,
+    no detection on noise, bit-reproducible, and 16 sampled streams x ALL 297 windows against the oracle at 1e-5."""
+    import torch
+    S, T, N, L, K = 1024, 8, 64000, 100, 5
+    ctx = ra.BatchContext(device=0, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    templates = orc.synth_templates(SEED, T, L, K)
+    tmpl = ra.Templates(ctx, templates)
+    nf = ra.mfcc_num_frames(N)
+    n_win = nf - L + 1
+    pcm = torch.empty((S, N), dtype=torch.float32, device="cuda")
+    ctx.synth_dev(SEED, 0, S, N, N, pcm.data_ptr())
+    scores = torch.empty((S, n_win, T), dtype=torch.float32, device="cuda")
+    agg = torch.empty((S, n_win), dtype=torch.float32, device="cuda")
+    det = torch.zeros((S, 4, 6), dtype=torch.int32, device="cuda")
+    n_det = torch.zeros((S,), dtype=torch.int32, device="cuda")
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), 4, scores.data_ptr(), agg.data_ptr())
+    torch.cuda.synchronize()
+    assert n_win == 297 and bool(torch.isfinite(scores).all()) and float(scores.min()) > 0.0 and float(scores.max()) < 1.0
+    assert torch.equal(agg, scores.max(dim=2).values) and int(n_det.sum()) == 0
+    s2 = torch.empty_like(scores)
+    ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), 4, s2.data_ptr(), agg.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(scores, s2)
+    for s in list(range(0, S, 73)) + [S - 1]:
+        ref_pcm = orc.synth_pcm(SEED, s, N)
+        ref_s, _ = orc.score_stream(orc.mfcc_stream(ref_pcm, K), templates)
+        got = scores[s].cpu().numpy()
+        assert ref_s.shape == got.shape and np.all(np.abs(got - ref_s) <= 1e-5 * np.abs(ref_s)), s
+
+
+def test_c3_sampled_streams_all_windows_vs_oracle(ra):
+    """BASELINE config C3 at size (65 536 x 8): 16 sampled streams x all 297 windows against the oracle at 1e-5 (the
+    size-independent properties are test_full_size_properties)."""
+    import torch
+    S, T, N, L, K = 65536, 8, 64000, 100, 5
+    ctx = ra.BatchContext(device=0, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    templates = orc.synth_templates(SEED, T, L, K)
+    tmpl = ra.Templates(ctx, templates)
+    nf = ra.mfcc_num_frames(N)
+    n_win = nf - L + 1
+    pcm = torch.empty((S, N), dtype=torch.float32, device="cuda")
+    ctx.synth_dev(SEED, 0, S, N, N, pcm.data_ptr())
+    scores = torch.empty((S, n_win, T), dtype=torch.float32, device="cuda")
+    agg = torch.empty((S, n_win), dtype=torch.float32, device="cuda")
+    det = torch.zeros((S, 4, 6), dtype=torch.int32, device="cuda")
+    n_det = torch.zeros((S,), dtype=torch.int32, device="cuda")
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), 4, scores.data_ptr(), agg.data_ptr())
+    torch.cuda.synchronize()
+    picks = [0, 1, 63, 64, 4095, 4096, 21845, 21846, 32767, 32768, 43690, 43691, 54321, 65000, 65534, 65535]
+    for s in picks:
+        ref_s, ref_a = orc.score_stream(orc.mfcc_stream(orc.synth_pcm(SEED, s, N), K), templates)
+        got = scores[s].cpu().numpy()
+        assert ref_s.shape == got.shape and np.all(np.abs(got - ref_s) <= 1e-5 * np.abs(ref_s)), s
+        assert np.all(np.abs(agg[s].cpu().numpy() - ref_a) <= 1e-5 * np.abs(ref_a)), s
+
+
+def test_c5_full_size_model_forward(ra):
+    """BASELINE config C5 at size: B = 65 536 rows x 3 120 features through the Small stack 3120 -> 32 -> 16 -> 2.
+    Finite logits, bit-reproducible, a row's logits do not depend on the batch it is in, 256 sampled rows against the f32
+    oracle at 2e-5 (f32 MFMA) and against the bf16-rounding oracle at 1e-3 (bf16 MFMA)."""
+    import torch
+    B, dims = 65536, [3120, 32, 16, 2]
+    rng = np.random.default_rng(5)
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+    ctx = ra.BatchContext(device=0, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    model = ra.Model(ctx, ws, bs)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((B, dims[0]), dtype=torch.float32, device="cuda", generator=gen)
+    rows = np.unique(np.concatenate([[0, 1, 15, 16, 127, 128, B - 1], np.random.default_rng(2).integers(0, B, 256)]))
+    xs = x[torch.from_numpy(rows).cuda()].contiguous()
+    for prec, tol, bf in (("f32", 2e-5, False), ("bf16", 1e-3, True)):
+        out = torch.empty((B, 2), dtype=torch.float32, device="cuda")
+        out2 = torch.empty_like(out)
+        ctx.mlp_dev(model, x.data_ptr(), B, prec, out.data_ptr())
+        ctx.mlp_dev(model, x.data_ptr(), B, prec, out2.data_ptr())
+        small = torch.empty((len(rows), 2), dtype=torch.float32, device="cuda")
+        ctx.mlp_dev(model, xs.data_ptr(), len(rows), prec, small.data_ptr())
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out).all()) and torch.equal(out, out2)
+        got = out[torch.from_numpy(rows).cuda()].cpu().numpy()
+        assert np.array_equal(got, small.cpu().numpy())  # batch invariance
+        ref = orc.mlp_forward(xs.cpu().numpy(), ws, bs, bf16_layer1=bf)
+        assert np.allclose(got, ref, rtol=tol, atol=tol), (prec, np.abs(got - ref).max())

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--score-mode", choices=["average", "max", "median", "p25", "p50", "p75", "p80", "p90", "p95"], default="max")
     ap.add_argument("--avg-gate", action="store_true", help="reference defaults: an averaged template and avg_threshold 0.2 -- windows "
                     "whose avg_score is below it are not compared with the sample templates (wakeword_comp.rs:85-93)")
+    ap.add_argument("--avg-threshold", type=float, default=0.2, help="with --avg-gate: DetectorConfig.avg_threshold (reference default 0.2)")
     ap.add_argument("--full-scores", action="store_true", help="with --avg-gate: compare every window with every template anyway (RP_CTX_FULL_SCORES)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -153,8 +154,7 @@ def main():
     n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
     cfg = ra.DetectorConfig()
     cfg.score_mode = {"average": 0, "max": 1, "median": 2, "p25": 3, "p50": 4, "p75": 5, "p80": 6, "p90": 7, "p95": 8}[args.score_mode]
-    if not args.avg_gate:
-        cfg.avg_threshold = 0.0  # avg gate off: exactly T DTWs per scoring
+    cfg.avg_threshold = args.avg_threshold if args.avg_gate else 0.0  # gate off: exactly T DTWs per scoring
 
     def step():
         # one C call: mfcc_kernel -> dtw kernel(s) -> aggregate kernel -> scan_kernel on the launch stream
@@ -263,7 +263,7 @@ def main():
         "config": {"workload": "%s: %d synthetic 16 kHz f32 streams x %d templates per GPU (%g s streams, L=%s, K=%d, band 5, "
                                "ScoreMode::%s, %s)" % (tag, S, T, N / 16000.0, lens[0] if len(set(lens)) == 1 else "/".join(map(str, lens)), K,
                                                        args.score_mode.capitalize(),
-                                                       ("averaged template + avg_threshold 0.2 (reference default), " +
+                                                       ("averaged template + avg_threshold %g%s, " % (args.avg_threshold, " (reference default)" if args.avg_threshold == 0.2 else "") +
                                                         ("every window scored anyway" if args.full_scores else "gated windows skipped"))
                                                        if args.avg_gate else "avg gate off"),
                    "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
@@ -283,7 +283,10 @@ def main():
         ag_ = torch.empty((S, n_win), dtype=torch.float32, device=dev)
         ctx.dtw_dev(mf.data_ptr(), S, nf, tmpl, cfg.score_ref, cfg.band_size, cfg.score_mode, 1, sc_.data_ptr(), av_.data_ptr(), ag_.data_ptr())
         torch.cuda.synchronize()
+        out["config"]["avg_threshold"] = cfg.avg_threshold
         out["config"]["gate_pass_fraction"] = float((~(av_ < cfg.avg_threshold)).float().mean().item())
+        qs = torch.quantile(av_.flatten()[:: max(1, av_.numel() // 4000000)], torch.tensor([0.001, 0.01, 0.1, 0.5, 0.9, 0.99, 0.999], device=dev))
+        out["config"]["avg_score_quantiles"] = {"q": [0.001, 0.01, 0.1, 0.5, 0.9, 0.99, 0.999], "avg_score": [round(float(x), 4) for x in qs]}
         del mf, sc_, av_, ag_
 
     # ---- CPU baseline: the oracle's restatement of the reference algorithm on this host's cores

@@ -285,7 +285,8 @@ typedef struct {
  * src/detector.rs:290-302,377-454, run over precomputed window scores.  With config->vad_mode set,
  * the VadDetector gate (src/mfcc/vad.rs:11-36, :379-383) is evaluated per stream from `mfcc`
  * ([S][n_frames][K], required then; may be NULL otherwise).
- * det [S][max_det] (device or host per ctx flag), n_det [S]. */
+ * det [S][max_det] (device or host per ctx flag), n_det [S] (may exceed max_det: only the first max_det detections of a
+ * stream are stored; slots behind a stream's detections are zero). */
 int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, size_t n_frames, int max_len,
                    const rp_detector_config *config, int avg_enabled, const float *mfcc, int K,
                    rp_batch_detection *det, int32_t *n_det, int max_det);

@@ -108,10 +108,31 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         const size_t g = base + 4 * (size_t)(q < 240 ? q : 239);
         return g + 3 <= last ? g : (last - 3) & ~(size_t)3;
     };
+    // byte offsets of this lane's four 4-sample groups inside a tile (the last 16 lanes of the fourth round repeat group 239)
+    constexpr unsigned kGroupBytes = 4 * sizeof(TIN);
+    const unsigned goff_lo = (unsigned)lane * kGroupBytes;
+    const unsigned goff_3 = (unsigned)(192 + lane < 240 ? 192 + lane : 239) * kGroupBytes;
     auto fetch = [&](size_t fs, unsigned ftile) {
         const TIN *x = pcm + fs * pcm_stride;
         const size_t base = (first_frame + (size_t)ftile * kMfccFramesPerWave + 1) * kShift;
-        if (VEC4) {
+        if (VEC4 && !HS) {
+            // One wave-uniform 64-bit base per group round and a 32-bit lane offset (per-lane 64-bit positions cost ~80
+            // VALU instructions per tile).  Positions are clamped to the last whole group of the stream -- only a ragged
+            // last tile reaches it: lim = byte offset of that group from the tile's first sample, applied as a scalar
+            // cap on the round's base and one v_min on the lane offset.
+            const char *sp = reinterpret_cast<const char *>(x + base);
+            const size_t room = n_samples - base;                       // >= 4: a tile starts at least one frame before the end
+            const unsigned lim = (unsigned)((room < (size_t)kMfccStage ? room : (size_t)kMfccStage) / 4 - 1) * kGroupBytes;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const unsigned c = (unsigned)it * 64u * kGroupBytes;
+                const unsigned cb = c < lim ? c : lim, rest = lim - cb;   // scalar
+                const unsigned t = goff_lo < rest ? goff_lo : rest;
+                cur4[it] = SampleIn<TIN>::ldraw(reinterpret_cast<const TIN *>(sp + cb + (size_t)t));
+            }
+            const unsigned t3 = goff_3 < lim ? goff_3 : lim;
+            cur4[3] = SampleIn<TIN>::ldraw(reinterpret_cast<const TIN *>(sp + (size_t)t3));
+        } else if (VEC4) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const size_t g = group_pos(ftile, it);
@@ -206,8 +227,10 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
             dft15(u, z);
         }
         wave_lds_sync();
+        // only the mirrors are read back: bin 240-k of lane l, k2 = 0..7, is Z[(16-l) + 16(14-k2)] (lane 0: Z[16(15-k2)]),
+        // i.e. registers 7..14 of the partner lane
 #pragma unroll
-        for (int k2 = 0; k2 < 15; ++k2) zdst[16 * k2] = z[k2];
+        for (int k2 = 7; k2 < 15; ++k2) zdst[16 * k2] = z[k2];
         wave_lds_sync();
         // ---- untangle the two interleaved real sequences, bins k = l + 16*k2 <= 120 together with their
         // mirrors 240-k (X[240-k] = conj(E - W480^k O) shares E, O and the twiddle product with X[k]).

@@ -81,7 +81,15 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
     }
     size_t s = (size_t)blockIdx.x * 64 + lane;
     if (s >= S) return;
-    if (!((candidates >> lane) & 1ull)) { n_det[s] = 0; return; }
+    // slots behind the detections a stream reports are zeroed: the output block is a function of the input alone
+    auto clear_from = [&](int from) {
+        BatchDetection zero{};
+        for (int i = from; i < max_det; ++i) {
+            det[s * (size_t)max_det + i] = zero;
+            if (det_ww) det_ww[s * (size_t)max_det + i] = 0;
+        }
+    };
+    if (!((candidates >> lane) & 1ull)) { n_det[s] = 0; clear_from(0); return; }
     const size_t row0 = s * (size_t)(n_win > 0 ? n_win : 0);
     const float *vv = vad_value ? vad_value + s * n_frames : nullptr;
     // VadDetector state (src/mfcc/vad.rs:3-50)
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
         }
     }
     n_det[s] = nd;
+    clear_from(nd < max_det ? nd : max_det);
 }
 
 hipError_t launch_scan_multi(hipStream_t st, const ScanWakewords &ww, const float *vad_value, float vad_mode_value, size_t S,
@@ -339,6 +348,7 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(const float *__restrict
         for (int i = 0; i < 50; ++i) z.vad_window[i] = vwin[i][lane];
     state[s] = z;
     n_det[s] = nd;
+    for (int i = nd; i < max_det; ++i) det[s * (size_t)max_det + i] = BatchDetection{};
 }
 
 hipError_t launch_scan_stream(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,

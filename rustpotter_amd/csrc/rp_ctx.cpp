@@ -187,32 +187,32 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     if (!hip_ok(hipMemcpy(d.lens, hl.data(), sizeof(int) * Ttot, hipMemcpyHostToDevice), "hipMemcpy(lens)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.unit, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice), "hipMemcpy(templates)")) return nullptr;
 
-    // chunks for the register kernel: sample templates grouped by length, up to 8 per chunk, tile
-    // class 2/4/8 by chunk size; the averaged template is its own chunk, last of class 2.
+    // chunks for the register kernels: sample templates grouped by length, up to 8 per chunk, classed by chunk size
+    // (TemplatesDev::class_first); the averaged template is its own chunk, last of the single-template class.
     std::vector<int> order(T);
     for (int t = 0; t < T; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hl[a] < hl[b]; });
     const int reg_tile = dtw_register_tile(K, 5);  // chunk size is fixed at upload time, before the band is known
     const int chunk_cap = reg_tile > 0 ? reg_tile : kChunkMax;
-    std::vector<DtwChunk> byclass[3];
+    std::vector<DtwChunk> byclass[4];
     for (int i = 0; i < T;) {
         int j = i;
         while (j < T && hl[order[j]] == hl[order[i]] && j - i < chunk_cap) ++j;
         DtwChunk c{};
         c.len = hl[order[i]]; c.count = j - i; c.tc = c.count <= 2 ? 2 : c.count <= 4 ? 4 : 8;
         for (int q = 0; q < kChunkMax; ++q) c.tid[q] = order[i + (q < c.count ? q : 0)];
-        byclass[c.tc == 2 ? 0 : c.tc == 4 ? 1 : 2].push_back(c);
+        byclass[c.count == 1 ? 3 : c.tc == 2 ? 0 : c.tc == 4 ? 1 : 2].push_back(c);
         i = j;
     }
     if (has_avg) {
         DtwChunk c{};
         c.len = avg_len; c.count = 1; c.tc = 2;
         for (int q = 0; q < kChunkMax; ++q) c.tid[q] = T;
-        byclass[0].push_back(c);
+        byclass[3].push_back(c);
     }
     std::vector<DtwChunk> chunks;
     std::vector<float> dup;
-    for (int cls = 0; cls < 3; ++cls) {
+    for (int cls = 0; cls < 4; ++cls) {
         d.class_first[cls] = (int)chunks.size();
         d.class_count[cls] = (int)byclass[cls].size();
         for (DtwChunk c : byclass[cls]) {

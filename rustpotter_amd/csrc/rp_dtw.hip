@@ -211,6 +211,184 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     }
 }
 
+// One template, TWO windows per lane.  A chunk that holds a single template (every template of a ragged reference such as
+// the reference's own oye_casa_g.rpw, 108/96/90/93/102 frames; the averaged template) would leave one half of every packed
+// instruction of dtw_band_kernel<.., 2> idle.  Here the two halves are two windows: a wave owns 128 consecutive entries
+// of the flattened (stream, window) space, lane l entries l and l + 64; means, ring and band are all register pairs,
+// the template coefficient is a scalar broadcast to both halves.  Same operations per cell as dtw_band_kernel, same
+// bits.  GX / list as there (entries read their frames from global memory).
+template <int K, int W, bool GX>
+__global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
+    int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
+    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
+    int flat, size_t n_streams, const uint32_t *__restrict__ list = nullptr, const uint32_t *__restrict__ list_count = nullptr) {
+    constexpr int B = 2 * W, NW = 2 * kDtwWin;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *xs = reinterpret_cast<float *>(smem);  // [128 + 2 (L + W)][KP]: up to two stream segments
+
+    const unsigned tile = blockIdx.x % tiles;
+    const unsigned ci = (blockIdx.x / tiles) % n_chunks;
+    const int lane = threadIdx.x;
+    const DtwChunk *ch = chunks + chunk_base + ci;
+    const int L = ch->len;  // m == n == L
+    size_t s[2];
+    int w[2];
+    bool valid[2];
+    const float *xl[2];
+    if (GX) {
+        static_assert(!GX || KP == K, "global-memory frames have pitch K");
+        unsigned n_listed = 0;
+        if (list) {
+            n_listed = *list_count;
+            if ((size_t)tile * NW >= n_listed) return;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            size_t f = (size_t)tile * NW + (size_t)e * kDtwWin + lane;
+            if (list) {
+                valid[e] = f < n_listed;
+                f = list[valid[e] ? f : n_listed - 1];
+            } else {
+                valid[e] = f < n_streams * n_win;
+            }
+            s[e] = valid[e] ? f / n_win : 0;
+            w[e] = valid[e] ? (int)(f - s[e] * n_win) : 0;
+            xl[e] = mfcc + (s[e] * frame_pitch + first_win + (size_t)w[e]) * K;
+        }
+    } else {
+        size_t sA, sB = 0;
+        int wA, nA, nB = 0;
+        if (flat) {
+            const size_t f0 = (size_t)tile * NW;
+            sA = f0 / n_win;
+            wA = (int)(f0 - sA * n_win);
+            nA = (int)n_win - wA < NW ? (int)n_win - wA : NW;
+            if (nA < NW && sA + 1 < n_streams) { sB = sA + 1; nB = NW - nA; }
+        } else {
+            sA = blockIdx.x / ((size_t)tiles * n_chunks);
+            wA = (int)tile * NW;
+            nA = (int)n_win - wA < NW ? (int)n_win - wA : NW;
+        }
+        const int segA = nA + L + W;
+        {
+            const float *src = mfcc + sA * frame_pitch * K;
+            const size_t g0 = first_win + wA;
+            for (int i = lane; i < segA * K; i += kDtwWin) {
+                int f = i / K, k = i - f * K;
+                size_t g = g0 + f;
+                xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+            }
+        }
+        if (nB > 0) {
+            const float *src = mfcc + sB * frame_pitch * K;
+            const int segB = nB + L + W;
+            for (int i = lane; i < segB * K; i += kDtwWin) {
+                int f = i / K, k = i - f * K;
+                size_t g = first_win + f;
+                xs[(segA + f) * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ent = e * kDtwWin + lane;
+            const bool inA = ent < nA;
+            valid[e] = inA || (ent - nA < nB);
+            s[e] = inA ? sA : sB;
+            w[e] = inA ? wA + ent : ent - nA;
+            xl[e] = xs + (inA ? ent : (valid[e] ? segA + ent - nA : 0)) * KP;
+        }
+    }
+    const float *x0 = xl[0], *x1 = xl[1];
+    // MfccNormalizer::normalize: sequential column sums, both windows at once
+    v2f mu[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = (v2f){0.f, 0.f};
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) mu[k] += (v2f){x0[i * KP + k], x1[i * KP + k]};
+    }
+    const float fl = (float)L;
+#pragma unroll
+    for (int k = 0; k < K; ++k) mu[k] = (v2f){mu[k].x / fl, mu[k].y / fl};
+
+    v2f ring[B][K];  // ring[slot][k] = unit-length frame of the slot, (window 0, window 1)
+#pragma unroll
+    for (int j = 0; j < B; ++j)
+#pragma unroll
+        for (int k = 0; k < K; ++k) ring[j][k] = (v2f){0.f, 0.f};
+
+#define RP_LOAD_COL2(c, slot)                                                                       \
+    do {                                                                                            \
+        v2f y_[K], bb_ = (v2f){0.f, 0.f};                                                           \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) {                                             \
+            y_[k] = (v2f){x0[((c)-1) * KP + k], x1[((c)-1) * KP + k]} - mu[k];                      \
+            bb_ = __builtin_elementwise_fma(y_[k], y_[k], bb_);                                     \
+        }                                                                                           \
+        const v2f inv_ = (v2f){bb_.x > 0.f ? rsqrtf(bb_.x) : 0.f, bb_.y > 0.f ? rsqrtf(bb_.y) : 0.f}; \
+        _Pragma("unroll") for (int k = 0; k < K; ++k) ring[slot][k] = y_[k] * inv_;                 \
+    } while (0)
+
+#pragma unroll
+    for (int c = 1; c < W; ++c) RP_LOAD_COL2(c, c % B);
+
+    v2f P[B + 1];
+#pragma unroll
+    for (int q = 0; q <= B; ++q) P[q] = (v2f){RP_INF, RP_INF};
+    P[W] = (v2f){0.f, 0.f};
+
+    const float *rows = dup + ch->rows_off;  // [len][1][K][2]: the template's coefficients (stored twice)
+#define RP_ROWS2(GUARD)                                                                                \
+    _Pragma("unroll") for (int u = 0; u < B; ++u) {                                                    \
+        const int r = r0 + u;                                                                          \
+        if (r < L) {                                                                                   \
+            RP_LOAD_COL2(r + W - 1, (u + W) % B);                                                      \
+            const float *arow = rows + (size_t)(r - 1) * K * 2;                                        \
+            v2f d[B];                                                                                  \
+            _Pragma("unroll") for (int q = 0; q < B; ++q) d[q] = (v2f){1.f, 1.f};                      \
+            _Pragma("unroll") for (int k = 0; k < K; ++k) {                                            \
+                const float a = arow[2 * k];                                                           \
+                const v2f na = (v2f){-a, -a};                                                          \
+                _Pragma("unroll") for (int q = 0; q < B; ++q)                                          \
+                    d[q] = __builtin_elementwise_fma(na, ring[(1 + u + q + B - W) % B][k], d[q]);      \
+            }                                                                                          \
+            v2f left = (v2f){RP_INF, RP_INF};                                                          \
+            _Pragma("unroll") for (int q = 0; q < B; ++q) {                                            \
+                v2f m;                                                                                 \
+                m.x = fminf(fminf(P[q + 1].x, left.x), P[q].x);                                        \
+                m.y = fminf(fminf(P[q + 1].y, left.y), P[q].y);                                        \
+                v2f v = d[q] + m;                                                                      \
+                if (GUARD) v = (r - W + q >= 1) ? v : (v2f){RP_INF, RP_INF};                           \
+                P[q] = v;                                                                              \
+                left = v;                                                                              \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    {
+        const int r0 = 1;
+        RP_ROWS2(true)
+    }
+    for (int r0 = 1 + B; r0 < L; r0 += B) { RP_ROWS2(false) }
+#undef RP_ROWS2
+#undef RP_LOAD_COL2
+
+    const float denom = (float)(L + L);
+    const int tid = ch->tid[0];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (valid[e]) {
+            const size_t row = s[e] * out_win_pitch + (size_t)w[e];
+            const float cost = e ? P[W + 1].y : P[W + 1].x;  // D[m-1][n] for m == n
+            const float nc = cost / denom;
+            const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+            if (tid < T) scores[row * T + tid] = sc;
+            else avg[row] = sc;
+        }
+    }
+}
+
 // Variant for wide frames (K = 16): the ring alone is 160 registers, so the band costs are formed one
 // template at a time with two band cells per v_pk_fma_f32 (coefficient duplicated into a scalar pair)
 // instead of holding the costs of a template pair for all 2W cells.
@@ -445,6 +623,37 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int ch
     return hipGetLastError();
 }
 
+// chunks of ONE template: two windows per lane (dtw_band2_kernel)
+template <int K, int W>
+static hipError_t launch_dtw_single_chunks(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S,
+                                           size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
+                                           float *scores, float *avg, bool few_windows, const uint32_t *list = nullptr,
+                                           const uint32_t *list_count = nullptr) {
+    if (n_chunks <= 0) return hipSuccess;
+    constexpr int KP = (K % 2 == 0) ? K + 1 : K;
+    constexpr int NW = 2 * kDtwWin;
+    if ((few_windows || list) && KP == K) {
+        const size_t ft = (S * n_win + NW - 1) / NW;
+        const size_t blocks = ft * (size_t)n_chunks;
+        if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((dtw_band2_kernel<K, W, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
+                           frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
+                           t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S, list, list_count);
+        return hipGetLastError();
+    }
+    if (list) return hipErrorNotSupported;
+    const size_t tiles = (n_win + NW - 1) / NW;
+    const int flat = (n_win >= (size_t)NW && S > 1) ? 1 : 0;
+    const size_t ft = flat ? (S * n_win + NW - 1) / NW : tiles;
+    const size_t blocks = flat ? ft * (size_t)n_chunks : tiles * (size_t)n_chunks * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(NW + 2 * (t.max_len + W)) * KP * sizeof(float);
+    hipLaunchKernelGGL((dtw_band2_kernel<K, W, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+                       frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
+                       t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
+    return hipGetLastError();
+}
+
 template <int K, int W, int TC>
 static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
                                   size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
@@ -461,7 +670,7 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
 }
 
 // Largest template tile the register kernels are built for at this (mfcc_size, band) (0 = only the generic
-// kernel applies).  Built: mfcc_size 5 with band 3..6, mfcc_size 16 with band 5.
+// kernel applies).  Built: mfcc_size 5 with band 3..6 (tile 8), mfcc_size 13 and 16 with band 3..6 (tile 2).
 // ---- one DTW per wave, for a handful of windows (the single-stream API: three new windows per 30 ms chunk) -----
 // The register kernels above give every lane a whole DTW: with 3 windows x 5 templates that is 15 busy lanes walking
 // ~100 dependent rows each (35 us).  Here a workgroup of one wave owns ONE (window, template) pair: all 64 lanes
@@ -562,16 +771,18 @@ __global__ __launch_bounds__(64) void dtw_single_kernel(
 
 int dtw_register_tile(int K, int band) {
     if (K == 5 && band >= 3 && band <= 6) return 8;
-    if (K == 16 && band == 5) return 2;
+    if ((K == 13 || K == 16) && band >= 3 && band <= 6) return 2;
     return 0;
 }
 
 template <int W>
-static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n2, const float *mfcc, size_t S, size_t frame_pitch,
+static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, const float *mfcc, size_t S, size_t frame_pitch,
                                 size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
                                 float *scores, float *avg, bool few, const uint32_t *list = nullptr, const uint32_t *list_count = nullptr) {
     hipError_t e;
-    if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
+    // n1: single-template chunks to score (class 3; the averaged template is its last chunk)
+    if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
+    if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
     if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
     return launch_dtw_class<5, W, 8>(st, t, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count);
 }
@@ -619,15 +830,15 @@ hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *
     const size_t rows = S * n_win;
     if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
-    const int avg_chunk = t.class_first[0] + t.class_count[0] - 1;  // the averaged template: last chunk of class 2
+    const int avg_chunk = t.class_first[3] + t.class_count[3] - 1;  // the averaged template: last of the single-template chunks
     hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     // pass 1: the averaged template over every window (LDS-staged tiles like the ungated kernel)
     switch (band) {
-    case 3: e = launch_dtw_class<5, 3, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
-    case 4: e = launch_dtw_class<5, 4, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
-    case 5: e = launch_dtw_class<5, 5, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
-    default: e = launch_dtw_class<5, 6, 2>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    case 3: e = launch_dtw_single_chunks<5, 3>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    case 4: e = launch_dtw_single_chunks<5, 4>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    case 5: e = launch_dtw_single_chunks<5, 5>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
+    default: e = launch_dtw_single_chunks<5, 6>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
     }
     if (e != hipSuccess) return e;
     // pass 2: list the rows whose avg_score is not below the threshold
@@ -635,7 +846,7 @@ hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // pass 3: the sample templates on the listed rows
-    const int n2 = t.class_count[0] - 1;
+    const int n2 = t.class_count[3] - 1;
     switch (band) {
     case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
     case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
@@ -667,7 +878,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
     // the register kernels assume m == n (no template longer than the window)
     if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks) {
-        const int n2 = t.class_count[0] - ((t.has_avg && !do_avg) ? 1 : 0);
+        const int n2 = t.class_count[3] - ((t.has_avg && !do_avg) ? 1 : 0);  // single-template chunks to score
         if (t.K == 5) {
             switch (band) {
             case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
@@ -676,7 +887,18 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
             default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
             }
         }
-        return launch_dtw_wide<16, 5, 2>(st, t, 0, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg);
+        // wide frames (mfcc_size 13 / 16): single-template chunks (class 3) and pairs (class 0) through the same kernel
+#define RP_WIDE(KK, WW)                                                                                                                   \
+        do {                                                                                                                              \
+            if (hipError_t e = launch_dtw_wide<KK, WW, 2>(st, t, 3, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg); e != hipSuccess) return e; \
+            return launch_dtw_wide<KK, WW, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg); \
+        } while (0)
+        if (t.K == 16) {
+            switch (band) { case 3: RP_WIDE(16, 3); case 4: RP_WIDE(16, 4); case 5: RP_WIDE(16, 5); default: RP_WIDE(16, 6); }
+        } else {
+            switch (band) { case 3: RP_WIDE(13, 3); case 4: RP_WIDE(13, 4); case 5: RP_WIDE(13, 5); default: RP_WIDE(13, 6); }
+        }
+#undef RP_WIDE
     }
     const size_t blocks = tiles * (size_t)Ttot * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
@@ -735,7 +957,74 @@ __global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__
     }
 }
 
-// Median / percentiles: sort ascending, then the reference's f32 interpolation
+// Median / percentiles: sort ascending, then the reference's f32 interpolation (wakeword_comp.rs:38-49).
+// T <= 64: a workgroup copies its 64 rows [64][T] (one contiguous block) to LDS with coalesced loads, lane r takes row r
+// into NT registers (padded with +inf) and sorts them with a compile-time bitonic network -- no scratch memory, no
+// data-dependent loop; the percentile position depends only on T and the mode, so it is wave-uniform.
+template <int NT> __device__ __forceinline__ void bitonic_sort(float (&v)[NT]) {
+#pragma unroll
+    for (int k = 2; k <= NT; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const float a = v[i], b = v[l];
+                    const float lo = fminf(a, b), hi = fmaxf(a, b);
+                    v[i] = up ? lo : hi;
+                    v[l] = up ? hi : lo;
+                }
+            }
+}
+
+__device__ __forceinline__ float percentile_of_mode(int mode) {
+    switch (mode) {
+    case 3: return 25.f;
+    case 5: return 75.f;
+    case 6: return 80.f;
+    case 7: return 90.f;
+    case 8: return 95.f;
+    default: return 50.f;  // Median, P50
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void aggregate_sorted_reg_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
+                                                                  float *__restrict__ agg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tile = reinterpret_cast<float *>(smem);  // [64][T + 1]
+    const size_t row0 = (size_t)blockIdx.x * 64;
+    const size_t nr = n_rows - row0 < 64 ? n_rows - row0 : 64;
+    const float *src = scores + row0 * T;
+    const int total = (int)nr * T, P = T + 1;
+    for (int i = threadIdx.x; i < total; i += 64) {
+        const int r = i / T, t = i - r * T;
+        tile[r * P + t] = src[i];
+    }
+    __syncthreads();
+    const int r = threadIdx.x;
+    if ((size_t)r >= nr) return;
+    float v[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) v[i] = i < T ? tile[r * P + i] : RP_INF;
+    bitonic_sort<NT>(v);
+    // get_percentile: index = p/100 * (T-1) in f32; an exact integer takes the element, else linear interpolation
+    const float index = percentile_of_mode(mode) / 100.0f * (float)(T - 1);
+    const float fl = floorf(index);
+    const int i0 = (int)fl;  // wave-uniform
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        lo = i == i0 ? v[i] : lo;
+        hi = i == i0 + 1 ? v[i] : hi;
+    }
+    const float d = index - fl;
+    agg[row0 + r] = fl == index ? lo : lo * (1.0f - d) + hi * d;
+}
+
+// T > 64: per-lane insertion sort in scratch memory
 __global__ __launch_bounds__(64) void aggregate_sorted_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
                                                               float *__restrict__ agg) {
     size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -748,16 +1037,7 @@ __global__ __launch_bounds__(64) void aggregate_sorted_kernel(const float *__res
         while (j >= 0 && tmp[j] > x) { tmp[j + 1] = tmp[j]; --j; }
         tmp[j + 1] = x;
     }
-    float p = 50.f;
-    switch (mode) {
-    case 3: p = 25.f; break;
-    case 5: p = 75.f; break;
-    case 6: p = 80.f; break;
-    case 7: p = 90.f; break;
-    case 8: p = 95.f; break;
-    default: p = 50.f; break;  // Median, P50
-    }
-    agg[row] = percentile_sorted(tmp, T, p);
+    agg[row] = percentile_sorted(tmp, T, percentile_of_mode(mode));
 }
 
 hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg) {
@@ -767,7 +1047,17 @@ hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, 
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     if (mode == 0 || mode == 1)
         hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), (size_t)64 * (T + 1) * sizeof(float), st, scores, n_rows, T, mode, agg);
-    else hipLaunchKernelGGL(aggregate_sorted_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
+    else if (T <= 64) {
+        const size_t lds = (size_t)64 * (T + 1) * sizeof(float);
+#define RP_AGG_SORTED(NT) hipLaunchKernelGGL(aggregate_sorted_reg_kernel<NT>, dim3((unsigned)blocks), dim3(64), lds, st, scores, n_rows, T, mode, agg)
+        if (T <= 2) RP_AGG_SORTED(2);
+        else if (T <= 4) RP_AGG_SORTED(4);
+        else if (T <= 8) RP_AGG_SORTED(8);
+        else if (T <= 16) RP_AGG_SORTED(16);
+        else if (T <= 32) RP_AGG_SORTED(32);
+        else RP_AGG_SORTED(64);
+#undef RP_AGG_SORTED
+    } else hipLaunchKernelGGL(aggregate_sorted_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
     return hipGetLastError();
 }
 

@@ -59,13 +59,14 @@ struct TemplatesDev {
     int max_diff = 0; // max(0, longest template incl. avg - max_len): >0 forces the generic kernel
     int *lens = nullptr;   // [T+has_avg]
     float *unit = nullptr; // [T+has_avg][Lpad][K] rows scaled to unit L2 norm (zero rows stay zero)
-    // register-kernel layout: chunks sorted by tile class (2, 4, 8); the avg template is the
-    // LAST chunk of class 2.  dup holds per chunk [len][tc/2][K][2]: the coefficients of two templates
+    // register-kernel layout: chunks sorted by class (see class_first); dup holds per chunk [len][tc/2][K][2]: the coefficients of two templates
     // interleaved, so that one scalar 8-byte load feeds both halves of a packed f32 FMA.
     DtwChunk *chunks = nullptr;
     float *dup = nullptr;
-    int class_first[3] = {0, 0, 0};  // first chunk index of tile class 2 / 4 / 8
-    int class_count[3] = {0, 0, 0};  // chunks per class (class 2 includes the avg chunk if has_avg)
+    // chunk classes: 0 = two templates (tc 2), 1 = three or four (tc 4), 2 = five to eight (tc 8), 3 = ONE template (scored two
+    // windows per lane by dtw_band2_kernel; the averaged template is the LAST chunk of class 3)
+    int class_first[4] = {0, 0, 0, 0};
+    int class_count[4] = {0, 0, 0, 0};
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs

@@ -135,7 +135,8 @@ def _rank_worker(rank, world, port, out_path):
         agg = torch.empty((S, n_win), dtype=torch.float32, device="cuda")
         ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tm, cfg, det.data_ptr(), n_det.data_ptr(), 4, scores.data_ptr(), agg.data_ptr())
         torch.cuda.synchronize()
-        det[:, :, 0] += lo  # global stream ids
+        used = torch.arange(4, device="cuda")[None, :] < n_det[:, None]
+        det[:, :, 0] += lo * used.to(torch.int32)  # global stream ids in the slots that hold a detection (the others stay zero)
         chk = scores.view(torch.int32).to(torch.int64).sum(dim=(1, 2))  # per-stream checksum of the score bits
         all_n = sharding.gather_ragged(n_det, world)
         all_det = sharding.gather_ragged(det, world)

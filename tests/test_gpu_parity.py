@@ -157,9 +157,11 @@ def test_score_modes(ra, ctx, mode):
     assert rel_close(agg[0], ref_a)
 
 
-@pytest.mark.parametrize("K,band,L", [(5, 5, 100), (5, 3, 64), (5, 4, 80), (5, 6, 90), (16, 5, 50), (5, 9, 30), (16, 3, 40), (3, 1, 12)])
+@pytest.mark.parametrize("K,band,L", [(5, 5, 100), (5, 3, 64), (5, 4, 80), (5, 6, 90), (16, 5, 50), (5, 9, 30), (16, 3, 40), (3, 1, 12),
+                                      (13, 5, 60), (13, 3, 40), (13, 6, 70), (13, 4, 33), (16, 4, 45), (16, 6, 48), (13, 7, 30), (12, 5, 30)])
 def test_dtw_synthetic(ra, ctx, K, band, L):
-    """Register kernel (K=5, band=5) and the generic kernel on BASELINE-style synthetic input."""
+    """Register kernels (mfcc_size 5 at band 3..6, one- and multi-template chunks; mfcc_size 13 / 16 at band 3..6) and the
+    generic kernel (everything else) on BASELINE-style synthetic input."""
     T, S, N = 3, 4, 480 * 60
     templates = orc.synth_templates(SEED, T, L, K)
     templates[1] = templates[1][: L - 7].copy()  # ragged template lengths

@@ -193,3 +193,66 @@ extern "C" {
     pub fn rp_stream_batch_reset(b: *mut rp_stream_batch, stream: i64) -> c_int;
     pub fn rp_stream_batch_chunks_seen(b: *const rp_stream_batch) -> usize;
 }
+
+// ---- multi-GPU: independent streams sharded over the GPUs of a node ----
+pub const RP_CTX_DEVICE_POINTERS: c_int = 0;
+pub const RP_CTX_HOST_POINTERS: c_int = 1;
+/// compare every window with every sample template even where the averaged-template gate would skip them
+pub const RP_CTX_FULL_SCORES: c_int = 2;
+extern "C" {
+    pub fn rp_batch_detect_fmt(ctx: *mut rp_ctx, pcm: *const std::ffi::c_void, fmt: c_int, s: usize, n_samples: usize, pcm_stride: usize,
+                               t: *const rp_templates, config: *const rp_detector_config, det: *mut rp_batch_detection, n_det: *mut i32,
+                               max_det: c_int, scores: *mut f32, agg: *mut f32) -> c_int;
+    /// ctxs[g] / t[g]: one context and one replica of the wakeword per device; pcm[g]: the S[g] streams of shard g
+    /// ([S[g]][pcm_stride], on ctxs[g]'s device or in host memory per the contexts' flag); det / n_det: ONE gathered
+    /// block for all sum(S) streams, `stream` = global id in shard order.  One host thread per shard inside the call.
+    pub fn rp_batch_detect_sharded(ctxs: *const *mut rp_ctx, t: *const *const rp_templates, n_shards: c_int,
+                                   pcm: *const *const std::ffi::c_void, fmt: c_int, s: *const usize, n_samples: usize, pcm_stride: usize,
+                                   config: *const rp_detector_config, det: *mut rp_batch_detection, n_det: *mut i32, max_det: c_int) -> c_int;
+}
+
+/// All streams of `shards` (one Vec of equally long f32 streams per GPU, host memory) through the whole path on
+/// `devices[g]`; returns the detections of every stream in shard order.  The wakeword is given as its templates
+/// ([T] x [len][K], as `WakewordRef::samples_features` holds them) plus the optional averaged template.
+pub fn batch_detect_sharded(devices: &[c_int], templates: &[Vec<Vec<f32>>], avg: Option<&Vec<Vec<f32>>>, config: &rp_detector_config,
+                            shards: &[Vec<Vec<f32>>], max_det: usize) -> Result<Vec<Vec<rp_batch_detection>>, String> {
+    assert_eq!(devices.len(), shards.len());
+    let k = templates[0][0].len();
+    let lens: Vec<c_int> = templates.iter().map(|t| t.len() as c_int).collect();
+    let feats: Vec<f32> = templates.iter().flat_map(|t| t.iter().flatten().copied()).collect();
+    let avg_flat: Option<Vec<f32>> = avg.map(|a| a.iter().flatten().copied().collect());
+    let n_samples = shards.iter().flat_map(|s| s.iter()).map(|x| x.len()).next().unwrap_or(0);
+    unsafe {
+        let mut ctxs: Vec<*mut rp_ctx> = Vec::new();
+        let mut tms: Vec<*const rp_templates> = Vec::new();
+        let free = |ctxs: &Vec<*mut rp_ctx>, tms: &Vec<*const rp_templates>| {
+            for t in tms { rp_templates_free(*t as *mut rp_templates); }
+            for c in ctxs { rp_ctx_free(*c); }
+        };
+        for &d in devices {
+            let mut c = std::ptr::null_mut();
+            if rp_ctx_new(d, RP_CTX_HOST_POINTERS, &mut c) < 0 { let e = last_error(); free(&ctxs, &tms); return Err(e); }
+            ctxs.push(c);
+            let mut t = std::ptr::null_mut();
+            let (ap, al) = avg_flat.as_ref().map_or((std::ptr::null(), 0), |a| (a.as_ptr(), avg.unwrap().len() as c_int));
+            if rp_templates_new(c, lens.len() as c_int, k as c_int, lens.as_ptr(), feats.as_ptr(), al, ap, &mut t) < 0 {
+                let e = last_error(); free(&ctxs, &tms); return Err(e);
+            }
+            tms.push(t as *const rp_templates);
+        }
+        let flat: Vec<Vec<f32>> = shards.iter().map(|s| s.iter().flatten().copied().collect()).collect();
+        let ptrs: Vec<*const std::ffi::c_void> = flat.iter().map(|f| f.as_ptr() as *const std::ffi::c_void).collect();
+        let counts: Vec<usize> = shards.iter().map(|s| s.len()).collect();
+        let total: usize = counts.iter().sum();
+        let mut det = vec![rp_batch_detection::default(); total * max_det];
+        let mut n_det = vec![0i32; total];
+        let r = rp_batch_detect_sharded(ctxs.as_ptr(), tms.as_ptr(), devices.len() as c_int, ptrs.as_ptr(), 3, counts.as_ptr(), n_samples,
+                                        n_samples, config, det.as_mut_ptr(), n_det.as_mut_ptr(), max_det as c_int);
+        let res = if r < 0 { Err(last_error()) } else {
+            Ok((0..total).map(|s| det[s * max_det..s * max_det + (n_det[s] as usize).min(max_det)].to_vec()).collect())
+        };
+        free(&ctxs, &tms);
+        res
+    }
+}
+

@@ -642,8 +642,17 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
             const bool do_avg = td.has_avg && athr != 0.f;  // wakeword_comp.rs:85
             float *dg = c->ws_agg.as<float>() + j * rows, *da = do_avg ? c->ws_avg.as<float>() + j * rows : nullptr;
             if (n_win) {
+                // windows below the wakeword's avg_threshold are not compared with its sample templates (wakeword_comp.rs:85-93)
+                const bool gated = do_avg && !(c->flags & RP_CTX_FULL_SCORES) && dtw_gate_supported(td, config->band_size, rows);
+                if (gated && !c->ws_list.reserve((rows + 1) * sizeof(uint32_t) + 16)) return -1;
                 c->time_begin(kKernelDtw);
-                ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+                if (gated) {
+                    uint32_t *lst = c->ws_list.as<uint32_t>();
+                    ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst),
+                                "dtw kernels (gated)");
+                } else {
+                    ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+                }
                 c->time_end();
                 if (!ok) return -1;
                 c->time_begin(kKernelAggregate);

@@ -94,6 +94,21 @@ def test_avg_gate_skip_on_synthetic_noise_many_streams(ra):
         assert np.array_equal(n_g, n_f) and det_g.tobytes() == det_f.tobytes()
 
 
+def test_avg_gate_skip_with_several_wakewords(ra):
+    """rp_batch_detect_multi: each wakeword's own avg_threshold gates its own sample templates; same detections and same
+    firing wakeword as the path that scores everything."""
+    pcm = _fixture_streams(4)
+    cfg = ra.DetectorConfig()
+    cfg.threshold, cfg.min_scores = 0.45, 3
+    outs = []
+    for full in (False, True):
+        ctx = ra.BatchContext(0, full_scores=full)
+        tms = [_wakeword(ra, ctx, "oye_casa_g.rpw"), _wakeword(ra, ctx, "alexa.rpw")]
+        outs.append(ctx.batch_detect_multi(pcm, tms, cfg, avg_thresholds=[0.5, 0.3]))
+    (d0, w0, n0), (d1, w1, n1) = outs
+    assert np.array_equal(n0, n1) and n0.sum() >= 4 and d0.tobytes() == d1.tobytes() and np.array_equal(w0, w1)
+
+
 # ------------------------------------------------------------------ multi-GPU: ranks, shards, gather
 def _free_port():
     s = socket.socket()

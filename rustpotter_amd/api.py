@@ -17,7 +17,8 @@ class RustpotterError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "librustpotter_hip.so")
+    # RP_LIB_PATH: load another build of the same library (kernel experiments under tools/scratch); the product is the in-tree one
+    return os.environ.get("RP_LIB_PATH") or os.path.join(_HERE, "librustpotter_hip.so")
 
 
 class SampleFormat(enum.IntEnum):  # src/audio/audio_types.rs:4-9

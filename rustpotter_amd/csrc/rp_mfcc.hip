@@ -40,6 +40,9 @@ template <int K1T> __device__ constexpr bool mel_uses(int f, int k2, bool mirror
     else return true;
 }
 
+// RP_ABL_*: ablation builds only (never defined in the product; DESIGN.md 4.1 has the numbers they gave): NOSTAGE drops the
+// staging write of the pre-emphasised samples, NOT1 the transposition between FFT16 and DFT15, NOMIR the mirror exchange
+// before the untangle step, NOMEL the mel / log stage -- each leaves the arithmetic in place and produces wrong values.
 // K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.  TIN: input sample type.
 // HS (live-stream batches): the stream is [history chunk | new chunks] in two buffers -- samples 0..479 are the
 // previous call's last chunk, decoded f32 at hist[s * hist_pitch + i]; sample 480 + i is pcm[s * pcm_stride + i] -- and the
@@ -200,7 +203,11 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
                 y.y = c.y - 0.97f * c.x;
                 y.z = c.z - 0.97f * c.y;
                 y.w = c.w - 0.97f * c.z;
+#ifndef RP_ABL_NOSTAGE
                 if (q < 240) *reinterpret_cast<float4 *>(ypre + 4 * q) = y;
+#else
+                asm volatile("" :: "v"(y.x), "v"(y.y), "v"(y.z), "v"(y.w));
+#endif
             }
         } else {
 #pragma unroll
@@ -220,26 +227,37 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = lds_read_b64(ysrc + 15 * n1) * lds_read_b64(hsrc + 15 * n1);
         wave_lds_sync();  // every lane has its samples in registers: the scratch may now overwrite them
         fft16(v);
+#ifndef RP_ABL_NOT1
         if (l < 15) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) t1dst[(c + 4 * d) * 15] = cmul(v[4 * c + d], twl[4 * c + d]);  // W240^{n2*k1}
         }
+#else
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = cmul(v[c], twl[c]);
+#endif
         wave_lds_sync();
         // ---- step 3: lane k1=l: DFT15 over n2 -> Z[k1 + 16*k2]
         v2f z[15];
         {
             v2f u[15];
 #pragma unroll
+#ifndef RP_ABL_NOT1
             for (int n2 = 0; n2 < 15; ++n2) u[n2] = lds_read_b64(t1src + n2);
+#else
+            for (int n2 = 0; n2 < 15; ++n2) u[n2] = v[n2];
+#endif
             dft15(u, z);
         }
         wave_lds_sync();
         // only the mirrors are read back: bin 240-k of lane l, k2 = 0..7, is Z[(16-l) + 16(14-k2)] (lane 0: Z[16(15-k2)]),
         // i.e. registers 7..14 of the partner lane
+#ifndef RP_ABL_NOMIR
 #pragma unroll
         for (int k2 = 7; k2 < 15; ++k2) zdst[16 * k2] = z[k2];
+#endif
         wave_lds_sync();
         // ---- untangle the two interleaved real sequences, bins k = l + 16*k2 <= 120 together with their
         // mirrors 240-k (X[240-k] = conj(E - W480^k O) shares E, O and the twiddle product with X[k]).
@@ -249,7 +267,11 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         for (int k2 = 0; k2 < 8; ++k2) {
             const int k = l + 16 * k2;
             const v2f a = z[k2];
+#ifndef RP_ABL_NOMIR
             const v2f b = (k2 == 0 && l == 0) ? a : lds_read_b64(zmir - 16 * k2);
+#else
+            const v2f b = z[14 - k2];
+#endif
             const v2f e = add_conj(a, b);                        // 2E = a + conj(b)
             const v2f o = mi_sub_conj(a, b);                     // 2O = -i (a - conj(b))
             const v2f t = cmul(lds_read_b64(w480 + 16 * k2), o);
@@ -263,6 +285,15 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         // the triangles are known at compile time (mel_touches): a filter is only accumulated over the 16-bin groups
         // it can be non-zero in -- 31 multiply-adds and weight loads instead of 96 (41 instead of 272), bit-identical
         // (the skipped terms are exact + 0.0; the table is checked against the mask on upload).
+#ifdef RP_ABL_NOMEL
+        {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) sacc += Pk[k2] + Pm[k2];
+            if (l < 8 && l < K1) lgb[l] = sacc;
+        }
+        if (false)
+#endif
 #pragma unroll
         for (int i0 = 0; i0 < (K1T > 0 ? K1T : K1); i0 += 8) {
             float acc[8];

@@ -4,6 +4,7 @@ import csv, glob, json, collections, statistics, shutil, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"   # round tag of the files written
 short = lambda n: n.split("(")[0]
 
 def agg(tag):
@@ -27,7 +28,7 @@ for k in fe:
     if "mfcc_kernel" in k:
         d["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
         d["note"] = "reads are 16 B/lane: FETCH_SIZE doubled per the guide"
-    elif any(x in k for x in ("dtw_band_kernel", "aggregate_kernel", "scan_kernel")):
+    elif any(x in k for x in ("dtw_band_kernel", "dtw_band2_kernel", "aggregate_kernel", "scan_kernel")):
         d["hbm_bytes_per_launch_corrected"] = (f + w) * 1024
         d["note"] = "4-byte reads: FETCH_SIZE taken at face value"
     if k in sq and sq[k].get("SQ_WAVE_CYCLES"):
@@ -36,13 +37,17 @@ for k in fe:
         d["instructions_per_launch"] = ins[k]
     out["kernels"][k] = d
 json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
-json.dump(out, open("profiles/r01_final_pmc.json", "w"), indent=1)
-shutil.copy(glob.glob("gpurun_out/prof_final/**/*kernel_stats.csv", recursive=True)[0], "profiles/r01_final_kernel_stats.csv")
+json.dump(out, open("profiles/%s_final_pmc.json" % R, "w"), indent=1)
+shutil.copy(glob.glob("gpurun_out/prof_final/**/*kernel_stats.csv", recursive=True)[0], "profiles/%s_final_kernel_stats.csv" % R)
 line = [l for l in open("gpurun_out/prof_final_bench.log") if l.startswith("{")][-1]
-open("profiles/r01_final_bench_under_rocprof.json", "w").write(line)
-names = {"bench_default": "r01_final_bench", "stream1": "bench_r01_stream_1chunk", "stream8": "bench_r01_stream_8chunks",
-         "rs_fft": "bench_r01_resample_fft", "rs_gemm": "bench_r01_resample_gemm", "rs_fft_i16_stereo": "bench_r01_resample_fft_i16_stereo",
-         "c5_bf16": "bench_r01_c5_bf16", "c5_f32": "bench_r01_c5_f32", "k16": "bench_r01_k16_8192streams", "c4": "bench_r01_c4_per_gpu"}
+open("profiles/%s_final_bench_under_rocprof.json" % R, "w").write(line)
+names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk" % R, "stream8": "bench_%s_stream_8chunks" % R,
+         "rs_fft": "bench_%s_resample_fft" % R, "rs_gemm": "bench_%s_resample_gemm" % R, "rs_fft_i16_stereo": "bench_%s_resample_fft_i16_stereo" % R,
+         "c5_bf16": "bench_%s_c5_bf16" % R, "c5_f32": "bench_%s_c5_f32" % R, "k16": "bench_%s_k16_8192streams" % R, "k13": "bench_%s_k13_8192streams" % R,
+         "c4": "bench_%s_c4_per_gpu" % R, "c2": "bench_%s_c2" % R, "ragged5": "bench_%s_ragged5_templates" % R, "t3": "bench_%s_t3_len126" % R,
+         "median": "bench_%s_median" % R, "gate_default": "bench_%s_avg_gate_default" % R, "gate_default_full": "bench_%s_avg_gate_default_full_scores" % R,
+         "gate_04": "bench_%s_avg_gate_04" % R, "gate_04_full": "bench_%s_avg_gate_04_full_scores" % R,
+         "two_ranks_one_gpu": "bench_%s_two_ranks_one_gpu_dry_run" % R}
 for a, b in names.items():
     src = "gpurun_out/final/%s.json" % a
     if os.path.exists(src) and os.path.getsize(src) > 10:
@@ -50,11 +55,11 @@ for a, b in names.items():
         x = json.loads(open(src).read().strip().splitlines()[-1])
         print(b, "%.4g %s" % (x["value"], x["unit"]), "%.3f ms" % x["ms_per_step"], x.get("roofline", {}).get("kernels_ms", ""))
 txt = []
-for f in ("model_detect.txt", "latency.txt"):
+for f in ("model_detect.txt", "latency.txt", "frontend.txt"):
     p = "gpurun_out/final/" + f
     if os.path.exists(p):
         txt.append(open(p).read().strip())
-open("profiles/r01_final_misc.txt", "w").write("\n".join(txt) + "\n")
+open("profiles/%s_final_misc.txt" % R, "w").write("\n".join(txt) + "\n")
 tr = glob.glob("gpurun_out/prof_final/**/*kernel_trace.csv", recursive=True)[0]
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(tr)):

@@ -5,9 +5,19 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/final
 O=gpurun_out/final
-B="python3 bench.py --steps 5 --warmup 2"
+B="python3 bench.py --steps 10 --warmup 3"
 line() { grep '^{' | tail -1; }
 $B 2>/dev/null | line > $O/bench_default.json
+$B --no-cpu-baseline --streams 1024 2>/dev/null | line > $O/c2.json
+$B --no-cpu-baseline --streams 8192 --templates 64 2>/dev/null | line > $O/c4.json
+$B --no-cpu-baseline --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5.json
+$B --no-cpu-baseline --templates 3 --template-len 126 2>/dev/null | line > $O/t3.json
+$B --no-cpu-baseline --score-mode median 2>/dev/null | line > $O/median.json
+$B --no-cpu-baseline --avg-gate 2>/dev/null | line > $O/gate_default.json
+$B --no-cpu-baseline --avg-gate --full-scores 2>/dev/null | line > $O/gate_default_full.json
+$B --no-cpu-baseline --avg-gate --avg-threshold 0.4 2>/dev/null | line > $O/gate_04.json
+$B --no-cpu-baseline --avg-gate --avg-threshold 0.4 --full-scores 2>/dev/null | line > $O/gate_04_full.json
+RP_BENCH_OVERSUBSCRIBE=1 $B --no-cpu-baseline --gpus 2 --streams 32768 2>/dev/null | line > $O/two_ranks_one_gpu.json
 $B --no-cpu-baseline --mode stream --chunks-per-call 1 2>/dev/null | line > $O/stream1.json
 $B --no-cpu-baseline --mode stream --chunks-per-call 8 2>/dev/null | line > $O/stream8.json
 $B --no-cpu-baseline --mode resample --streams 8192 2>/dev/null | line > $O/rs_fft.json
@@ -16,7 +26,7 @@ $B --no-cpu-baseline --mode resample --streams 8192 --pcm-format i16 --channels 
 $B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_bf16.json
 $B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
-$B --no-cpu-baseline --streams 8192 --templates 64 2>/dev/null | line > $O/c4.json
+$B --no-cpu-baseline --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13.json
 python3 tools/bench_model_detect.py > $O/model_detect.txt 2>/dev/null
 python3 tools/latency_probe.py > $O/latency.txt 2>/dev/null
 python3 tools/bench_frontend.py > $O/frontend.txt 2>/dev/null

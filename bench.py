@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--template-len", type=int, default=100)
     ap.add_argument("--mfcc-size", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--mode", choices=["dtw", "mlp", "stream", "resample"], default="dtw",
                     help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward; "
                          "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process); "

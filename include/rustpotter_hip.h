@@ -369,7 +369,8 @@ void rp_stream_batch_free(rp_stream_batch *b);
  * default; 1 <= n_chunks <= max_chunks_per_call).
  * det [S][max_det], n_det [S]: detections emitted during these chunks (n_det may exceed max_det; only
  * the first max_det are stored).  agg (NULL to skip) [S][3*n_chunks]: aggregate score of the window
- * ending at each new frame (garbage for windows that reach before frame 0). */
+ * ending at each new frame (garbage for windows that reach before frame 0).  Without `agg` (and without
+ * RP_CTX_FULL_SCORES) windows below avg_threshold are not compared with the sample templates, as in rp_batch_detect. */
 int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
                             rp_batch_detection *det, int32_t *n_det, int max_det, float *agg);
 /* The AudioFmt of the streams (RustpotterConfig.fmt: sample_rate, channels; src/config.rs:10-29), to be set before

@@ -33,7 +33,7 @@ struct rp_stream_batch {
     // previous chunk | new chunks (f32), ping-pong so that one kernel both carries the old chunk and decodes the new
     int pcur = 0;
     size_t last_off = 0;     // where the last chunk of the previous call sits in pcm[pcur]'s rows
-    DevBuf pcm[2], mfcc[2], state, scores, agg, avg, vad;
+    DevBuf pcm[2], mfcc[2], state, scores, agg, avg, vad, list;
     // AudioEncoder of the streams (src/audio/encoder.rs): channel count and, for input that is not 16 kHz, the
     // resampler plan with every stream's previous input frame
     int channels = 1;
@@ -503,7 +503,7 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         c->time_begin(kKernelDtw);
         if (gated) {
             uint32_t *lst = c->ws_list.as<uint32_t>();
-            ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, n_win, config->band_size, config->score_ref, config->avg_threshold,
+            ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, config->avg_threshold,
                                          ds, da, lst + 1, lst), "dtw kernels (gated)");
         } else {
             ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
@@ -648,7 +648,7 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                 c->time_begin(kKernelDtw);
                 if (gated) {
                     uint32_t *lst = c->ws_list.as<uint32_t>();
-                    ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst),
+                    ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst),
                                 "dtw kernels (gated)");
                 } else {
                     ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
@@ -741,7 +741,8 @@ static bool stream_batch_alloc(rp_stream_batch *b) {
     if (!b->pcm[0].reserve(pcm_bytes) || !b->pcm[1].reserve(pcm_bytes) || !b->mfcc[0].reserve(S * pitch * td.K * sizeof(float) + slack) ||
         !b->mfcc[1].reserve(S * pitch * td.K * sizeof(float) + slack) || !b->state.reserve(S * stream_state_bytes()) ||
         !b->scores.reserve(rows * td.T * sizeof(float) + 16) || !b->agg.reserve(rows * sizeof(float) + 16) ||
-        !b->avg.reserve(rows * sizeof(float) + 16) || !b->vad.reserve(rows * sizeof(float) + 16))
+        !b->avg.reserve(rows * sizeof(float) + 16) || !b->vad.reserve(rows * sizeof(float) + 16) ||
+        !b->list.reserve((rows + 1) * sizeof(uint32_t) + 16))
         return false;
     if (!hip_ok(hipMemsetAsync(b->pcm[0].p, 0, b->pcm[0].cap, c->stream), "hipMemsetAsync") ||
         !hip_ok(hipMemsetAsync(b->pcm[1].p, 0, b->pcm[1].cap, c->stream), "hipMemsetAsync") ||
@@ -917,8 +918,16 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
         }
         b->fill += n_new;
         float *ds = b->scores.as<float>(), *dg = b->agg.as<float>(), *da = do_avg ? b->avg.as<float>() : nullptr;
+        // the averaged-template gate as a skip (wakeword_comp.rs:85-93), unless the caller wants every window's aggregate
+        const bool gated = do_avg && !agg && !(c->flags & RP_CTX_FULL_SCORES) && dtw_gate_supported(td, b->cfg.band_size, rows);
         c->time_begin(kKernelDtw);
-        ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true), "dtw kernel");
+        if (gated) {
+            uint32_t *lst = b->list.as<uint32_t>();
+            ok = hip_ok(launch_dtw_gated(c->stream, td, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, b->cfg.avg_threshold,
+                                         ds, da, lst + 1, lst, true), "dtw kernels (gated)");
+        } else {
+            ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true), "dtw kernel");
+        }
         c->time_end();
         if (!ok) return -1;
         c->time_begin(kKernelAggregate);

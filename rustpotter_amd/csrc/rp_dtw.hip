@@ -392,34 +392,57 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
 // Variant for wide frames (K = 16): the ring alone is 160 registers, so the band costs are formed one
 // template at a time with two band cells per v_pk_fma_f32 (coefficient duplicated into a scalar pair)
 // instead of holding the costs of a template pair for all 2W cells.
-template <int K, int W, int TC>
+template <int K, int W, int TC, bool GX = false>
 __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
-    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
+    size_t n_streams = 0, const uint32_t *__restrict__ list = nullptr, const uint32_t *__restrict__ list_count = nullptr) {
     constexpr int B = 2 * W;
-    constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
+    constexpr int TP = TC >= 2 ? TC / 2 : 1;      // template pairs per row of `dup` (a one-template chunk is stored as a pair)
+    // LDS rows get an odd pitch (conflict-free lane-strided reads); GX lanes read rows of pitch K from global memory
+    constexpr int KP = GX ? K : ((K % 2 == 0) ? K + 1 : K);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *xs = reinterpret_cast<float *>(smem);  // [64 + L + W][KP]
 
     const unsigned tile = blockIdx.x % tiles;
     const unsigned ci = (blockIdx.x / tiles) % n_chunks;
-    const size_t s = blockIdx.x / ((size_t)tiles * n_chunks);
     const int lane = threadIdx.x;
     const DtwChunk *ch = chunks + chunk_base + ci;
     const int L = ch->len;  // m == n == L
-    const size_t w0 = first_win + (size_t)tile * kDtwWin;
-
-    const int n_stage = kDtwWin + L + W;
-    const float *src = mfcc + s * frame_pitch * K;
-    for (int i = lane; i < n_stage * K; i += kDtwWin) {
-        int f = i / K, k = i - f * K;
-        size_t g = w0 + f;
-        xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+    size_t s;
+    size_t wl;      // window index of this lane inside its stream
+    bool valid;
+    const float *xl;
+    if (GX) {
+        // lanes are consecutive entries of the flattened (stream, window) space, or of the gate's list (see dtw_band_kernel)
+        size_t f = (size_t)tile * kDtwWin + lane;
+        if (list) {
+            const uint32_t n_listed = *list_count;
+            if ((size_t)tile * kDtwWin >= n_listed) return;
+            valid = f < n_listed;
+            f = list[valid ? f : n_listed - 1];
+        } else {
+            valid = f < n_streams * n_win;
+        }
+        s = valid ? f / n_win : 0;
+        wl = valid ? f - s * n_win : 0;
+        xl = mfcc + (s * frame_pitch + first_win + wl) * K;
+    } else {
+        s = blockIdx.x / ((size_t)tiles * n_chunks);
+        const size_t w0 = first_win + (size_t)tile * kDtwWin;
+        const int n_stage = kDtwWin + L + W;
+        const float *src = mfcc + s * frame_pitch * K;
+        for (int i = lane; i < n_stage * K; i += kDtwWin) {
+            int f = i / K, k = i - f * K;
+            size_t g = w0 + f;
+            xs[f * KP + k] = g < n_frames_total ? src[g * K + k] : 0.f;
+        }
+        __syncthreads();
+        wl = (size_t)tile * kDtwWin + lane;
+        valid = wl < n_win;
+        xl = xs + lane * KP;
     }
-    __syncthreads();
-
-    const float *xl = xs + lane * KP;
     // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums
     float mu[K];
 #pragma unroll
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
         if (r < L) { /* rows 1..m-1 only: row m is never read (dtw.rs:101) */                          \
             RP_LOAD_COL(r + W - 1, (u + W) % B);                                                       \
             _Pragma("unroll") for (int t = 0; t < TC; ++t) {                                           \
-                const float *arow = rows + ((size_t)(r - 1) * (TC / 2) + t / 2) * K * 2 + (t & 1);     \
+                const float *arow = rows + ((size_t)(r - 1) * TP + t / 2) * K * 2 + (t & 1);           \
                 v2f dd[B / 2];                                                                         \
                 _Pragma("unroll") for (int j = 0; j < B / 2; ++j) dd[j] = (v2f){1.f, 1.f};             \
                 _Pragma("unroll") for (int k = 0; k < K; ++k) {                                        \
@@ -499,8 +522,8 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
 #undef RP_ROWS
 #undef RP_LOAD_COL
 
-    if (tile * (size_t)kDtwWin + lane < n_win) {
-        const size_t row = s * out_win_pitch + (size_t)tile * kDtwWin + lane;
+    if (valid) {
+        const size_t row = s * out_win_pitch + wl;
         const float denom = (float)(L + L);
 #pragma unroll
         for (int t = 0; t < TC; ++t) {
@@ -657,17 +680,48 @@ static hipError_t launch_dtw_single_chunks(hipStream_t st, const TemplatesDev &t
 template <int K, int W, int TC>
 static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
                                   size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
-                                  float score_ref, float *scores, float *avg) {
+                                  float score_ref, float *scores, float *avg, bool few_windows = false, const uint32_t *list = nullptr,
+                                  const uint32_t *list_count = nullptr, int chunk_base = -1) {
     if (n_chunks <= 0) return hipSuccess;
+    if (chunk_base < 0) chunk_base = t.class_first[cls];
+    if (few_windows || list) {
+        // lanes span streams (few windows per stream) or come from the gate's list: frames read from global memory
+        const size_t ft = (S * n_win + kDtwWin - 1) / kDtwWin;
+        const size_t blocks = ft * (size_t)n_chunks;
+        if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC, true>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
+                           frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
+                           t.chunks, t.dup, t.T, score_ref, scores, avg, S, list, list_count);
+        return hipGetLastError();
+    }
     const size_t blocks = tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     const size_t lds = (size_t)(kDtwWin + t.max_len + W) * KP * sizeof(float);
-    hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
-                       frame_pitch, (unsigned)tiles, (unsigned)n_chunks, t.class_first[cls], first_win, n_win, out_win_pitch,
+    hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
+                       frame_pitch, (unsigned)tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg);
     return hipGetLastError();
 }
+
+// wide frames (mfcc_size 13 / 16): single-template chunks (class 3, n1 of them) one template per lane, pairs (class 0) two
+template <int K, int W>
+static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int n1, const float *mfcc, size_t S, size_t frame_pitch,
+                                      size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores,
+                                      float *avg, bool few, const uint32_t *list = nullptr, const uint32_t *list_count = nullptr) {
+    if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, n1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count); e != hipSuccess) return e;
+    return launch_dtw_wide<K, W, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count);
+}
+
+// dispatch on the (mfcc_size, band) pairs the wide kernels are built for
+#define RP_WIDE_DISPATCH(CALL)                                                                 \
+    do {                                                                                       \
+        if (t.K == 16) {                                                                       \
+            switch (band) { case 3: return CALL(16, 3); case 4: return CALL(16, 4); case 5: return CALL(16, 5); default: return CALL(16, 6); } \
+        } else {                                                                               \
+            switch (band) { case 3: return CALL(13, 3); case 4: return CALL(13, 4); case 5: return CALL(13, 5); default: return CALL(13, 6); } \
+        }                                                                                      \
+    } while (0)
 
 // Largest template tile the register kernels are built for at this (mfcc_size, band) (0 = only the generic
 // kernel applies).  Built: mfcc_size 5 with band 3..6 (tile 8), mfcc_size 13 and 16 with band 3..6 (tile 2).
@@ -821,38 +875,60 @@ __global__ __launch_bounds__(256) void gate_compact_kernel(const float *__restri
 }
 
 bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows) {
-    return t.has_avg && t.K == 5 && band >= 3 && band <= 6 && t.max_diff == 0 && t.chunks && rows > 0 && rows < 0xffffffffULL;
+    return t.has_avg && dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && rows > 0 && rows < 0xffffffffULL;
 }
 
-hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t n_win,
-                            int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
-                            uint32_t *count) {
-    const size_t rows = S * n_win;
-    if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
-    const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
-    const int avg_chunk = t.class_first[3] + t.class_count[3] - 1;  // the averaged template: last of the single-template chunks
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    // pass 1: the averaged template over every window (LDS-staged tiles like the ungated kernel)
-    switch (band) {
-    case 3: e = launch_dtw_single_chunks<5, 3>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
-    case 4: e = launch_dtw_single_chunks<5, 4>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
-    case 5: e = launch_dtw_single_chunks<5, 5>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
-    default: e = launch_dtw_single_chunks<5, 6>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, 0, n_win, n_win, score_ref, scores, avg, false); break;
-    }
+template <int W>
+static hipError_t gated_k5(hipStream_t st, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
+                           size_t first_win, size_t n_win, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                           uint32_t *count, bool few) {
+    const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
+    // pass 1: the averaged template over every window
+    hipError_t e = launch_dtw_single_chunks<5, W>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, first_win, n_win, n_win, score_ref, scores, avg, few);
     if (e != hipSuccess) return e;
     // pass 2: list the rows whose avg_score is not below the threshold
     const size_t waves = (rows + 1023) / 1024, blocks = (waves + 3) / 4;
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // pass 3: the sample templates on the listed rows
-    const int n2 = t.class_count[3] - 1;
-    switch (band) {
-    case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
-    case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
-    case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
-    default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, 0, n_win, n_win, score_ref, scores, avg, false, list, count);
+    return launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, list, count);
+}
+
+template <int K, int W>
+static hipError_t gated_wide(hipStream_t st, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
+                             size_t first_win, size_t n_win, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                             uint32_t *count, bool few) {
+    const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
+    hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, few, nullptr, nullptr, avg_chunk);
+    if (e != hipSuccess) return e;
+    const size_t waves = (rows + 1023) / 1024, blocks = (waves + 3) / 4;
+    hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, list, count);
+}
+
+// first_win / few_windows as in launch_dtw (live-stream batches score the few newest windows of every stream: then pass 1
+// also reads its frames from global memory); scores / avg rows have pitch n_win.
+hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                            size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                            uint32_t *count, bool few_windows) {
+    const size_t rows = S * n_win;
+    if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
+    const bool few = few_windows && S > 1 && n_win < (size_t)kDtwWin;
+    const int avg_chunk = t.class_first[3] + t.class_count[3] - 1;  // the averaged template: last of the single-template chunks
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (t.K == 5) {
+        switch (band) {
+        case 3: return gated_k5<3>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
+        case 4: return gated_k5<4>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
+        case 5: return gated_k5<5>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
+        default: return gated_k5<6>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
+        }
     }
+#define RP_WIDE_CALL(KK, WW) gated_wide<KK, WW>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few)
+    RP_WIDE_DISPATCH(RP_WIDE_CALL);
+#undef RP_WIDE_CALL
 }
 
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
@@ -887,18 +963,9 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
             default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
             }
         }
-        // wide frames (mfcc_size 13 / 16): single-template chunks (class 3) and pairs (class 0) through the same kernel
-#define RP_WIDE(KK, WW)                                                                                                                   \
-        do {                                                                                                                              \
-            if (hipError_t e = launch_dtw_wide<KK, WW, 2>(st, t, 3, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg); e != hipSuccess) return e; \
-            return launch_dtw_wide<KK, WW, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg); \
-        } while (0)
-        if (t.K == 16) {
-            switch (band) { case 3: RP_WIDE(16, 3); case 4: RP_WIDE(16, 4); case 5: RP_WIDE(16, 5); default: RP_WIDE(16, 6); }
-        } else {
-            switch (band) { case 3: RP_WIDE(13, 3); case 4: RP_WIDE(13, 4); case 5: RP_WIDE(13, 5); default: RP_WIDE(13, 6); }
-        }
-#undef RP_WIDE
+#define RP_WIDE_CALL(KK, WW) launch_dtw_wide_all<KK, WW>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)
+        RP_WIDE_DISPATCH(RP_WIDE_CALL);
+#undef RP_WIDE_CALL
     }
     const size_t blocks = tiles * (size_t)Ttot * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;

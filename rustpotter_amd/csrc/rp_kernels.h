@@ -127,12 +127,12 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
 
 // The averaged-template gate as a skip (wakeword_comp.rs:85-93): every window against the averaged template (-> avg),
 // the rows with avg >= avg_threshold listed (list [S*n_win] / count: device workspaces), the sample templates on the
-// listed rows only (-> scores; other rows are not written).  mfcc needs 64*K floats of slack behind the last stream.
+// listed rows only (-> scores [S][n_win][T]; other rows are not written).  mfcc needs 64*K floats of slack behind the last stream.
 // hipErrorNotSupported when the template set has no register kernel for this (see dtw_gate_supported).
 bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows);
-hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t n_win,
-                            int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
-                            uint32_t *count);
+hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                            size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                            uint32_t *count, bool few_windows = false);
 
 // Largest template tile the register DTW kernel is built for (0: only the generic kernel applies).
 int dtw_register_tile(int K, int band);

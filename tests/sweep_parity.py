@@ -117,6 +117,11 @@ def device_detections(ra, ctx, case):
     tm = ra.Templates(ctx, case["templates"], avg=case["avg"])
     pcm = case["pcm"]
     det, n_det, scores, agg = ctx.batch_detect(pcm, tm, dc, max_det=kMaxDet, want_scores=True)
+    # the same call without the per-window arrays: with an averaged template and avg_threshold != 0 this takes the gate-skip
+    # path where a register kernel exists (windows below avg_threshold are not compared with the sample templates) -- the
+    # detections must be the same bits
+    det2, n_det2 = ctx.batch_detect(pcm, tm, dc, max_det=kMaxDet)
+    assert np.array_equal(n_det, n_det2) and det.tobytes() == det2.tobytes(), "gate-skip path differs from the full path"
     # n_det counts every detection; the first max_det are stored
     offline = [[(int(det[s][j]["frame"]) // 3 + 1, int(det[s][j]["counter"]), float(det[s][j]["score"]), float(det[s][j]["avg_score"]))
                 for j in range(min(int(n_det[s]), kMaxDet))] + [None] * max(0, int(n_det[s]) - kMaxDet) for s in range(pcm.shape[0])]

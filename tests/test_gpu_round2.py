@@ -94,6 +94,54 @@ def test_avg_gate_skip_on_synthetic_noise_many_streams(ra):
         assert np.array_equal(n_g, n_f) and det_g.tobytes() == det_f.tobytes()
 
 
+@pytest.mark.parametrize("K", [13, 16])
+def test_avg_gate_skip_wide_frames(ra, K):
+    """The same for mfcc_size 13 / 16 (dtw_band_wide_kernel in list mode), ragged templates so that one- and two-template
+    chunks both occur."""
+    S, N, L, T = 300, 480 * 50, 40, 5
+    templates = orc.synth_templates(SEED, T, L, K)
+    templates[1] = templates[1][:L - 5].copy()
+    templates[3] = templates[3][:L - 9].copy()
+    avg = np.mean([t[:L - 9] for t in templates], axis=0, dtype=np.float32)
+    gated, full = ra.BatchContext(0), ra.BatchContext(0, full_scores=True)
+    pcm = gated.synth_pcm(SEED, 0, S, N)
+    tg, tf = ra.Templates(gated, templates, avg=avg), ra.Templates(full, templates, avg=avg)
+    mf = gated.mfcc(pcm, K)
+    for band in (5, 4):
+        _, av, ag = gated.dtw_scores(mf, tg, band_size=band, with_avg=True)
+        cfg = ra.DetectorConfig()
+        cfg.band_size, cfg.min_scores = band, 2
+        cfg.avg_threshold, cfg.threshold = float(np.median(av)), float(np.quantile(ag, 0.7))
+        det_g, n_g = gated.batch_detect(pcm, tg, cfg, max_det=6)
+        det_f, n_f = full.batch_detect(pcm, tf, cfg, max_det=6)
+        assert n_f.sum() > S // 4 and np.array_equal(n_g, n_f) and det_g.tobytes() == det_f.tobytes()
+
+
+@pytest.mark.parametrize("avg_threshold,chunks_per_call", [(0.2, 1), (0.5, 1), (0.5, 4), (0.62, 7)])
+def test_avg_gate_skip_in_live_stream_batches(ra, avg_threshold, chunks_per_call):
+    """rp_stream_batch_process skips the sample templates of gated windows too: fed chunk by chunk it reports the detections
+    of the offline call that scores everything."""
+    pcm = _fixture_streams(5)
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold, cfg.threshold = avg_threshold, 0.45
+    full = ra.BatchContext(0, full_scores=True)
+    det_f, n_f = full.batch_detect(pcm, _wakeword(ra, full), cfg, max_det=6)
+    ctx = ra.BatchContext(0)
+    sb = ra.StreamBatch(ctx, _wakeword(ra, ctx), cfg, pcm.shape[0], max_chunks_per_call=chunks_per_call)
+    live = [[] for _ in range(pcm.shape[0])]
+    step = 480 * chunks_per_call
+    for i in range(0, pcm.shape[1], step):
+        d, nd = sb.process(np.ascontiguousarray(pcm[:, i:i + step]), max_det=8)
+        for s in range(pcm.shape[0]):
+            live[s] += [d[s][j] for j in range(nd[s])]
+    for s in range(pcm.shape[0]):
+        assert len(live[s]) == n_f[s]
+        for a, b in zip(live[s], det_f[s][:n_f[s]]):
+            assert (a["frame"], a["window"], a["counter"]) == (b["frame"], b["window"], b["counter"])
+            assert a["score"] == b["score"] and a["avg_score"] == b["avg_score"]
+    assert n_f.sum() >= (5 if avg_threshold <= 0.5 else 0)
+
+
 def test_avg_gate_skip_with_several_wakewords(ra):
     """rp_batch_detect_multi: each wakeword's own avg_threshold gates its own sample templates; same detections and same
     firing wakeword as the path that scores everything."""

@@ -17,6 +17,17 @@ namespace rp {
 // reproduces the reference's "magnitude == 0 -> similarity 0".
 constexpr int kDtwWin = 64;   // windows per wave
 
+// The averaged-template gate's hand-over to the template kernels (launch_dtw_gated).  count == nullptr: no gate, every
+// window is scored.  list != nullptr: LIST mode -- the lanes take the listed rows (windows that passed) and read their frames
+// from global memory; the launch does nothing when the list is dense (*count >= dense_min).  list == nullptr with a count:
+// DENSE mode -- the ordinary LDS-staged launch over every window, which does nothing unless the list is dense.  (Nearly
+// everything passing is the common case at the reference's default threshold; scoring all rows through the staged kernel is
+// then ~6 % cheaper than gathering them one by one.  Both launches are always issued; one of them exits on a scalar compare.)
+struct GateList {
+    const uint32_t *list = nullptr, *count = nullptr;
+    uint32_t dense_min = 0;
+};
+
 // One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
 // Per lane: the window's column means, a ring of the 2W unit-length window frames inside the
 // band (shared by all TC templates), and TC bands of 2W+1 running costs held as register pairs of
@@ -34,7 +45,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
     const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
-    int flat, size_t n_streams, const uint32_t *__restrict__ list = nullptr, const uint32_t *__restrict__ list_count = nullptr) {
+    int flat, size_t n_streams, GateList gl = GateList{}) {
     constexpr int B = 2 * W;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;  // odd pitch: conflict-free lane-strided LDS reads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -55,20 +66,22 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     if (GX) {
         static_assert(!GX || KP == K, "global-memory frames have pitch K");
         size_t f = (size_t)tile * kDtwWin + lane;
-        if (list) {
+        if (gl.list) {
             // the windows that passed the averaged-template gate (gate_compact_kernel): row ids s * n_win + w.  The grid is
             // sized for every window; tiles past the list's end have nothing to do.
-            const uint32_t n_listed = *list_count;
-            if ((size_t)tile * kDtwWin >= n_listed) return;
+            const uint32_t n_listed = *gl.count;
+            if ((size_t)tile * kDtwWin >= n_listed || (gl.dense_min && n_listed >= gl.dense_min)) return;
             valid = f < n_listed;
-            f = list[valid ? f : n_listed - 1];
+            f = gl.list[valid ? f : n_listed - 1];
         } else {
+            if (gl.count && *gl.count < gl.dense_min) return;
             valid = f < n_streams * n_win;
         }
         s = valid ? f / n_win : 0;
         w = valid ? (int)(f - s * n_win) : 0;
         xl = mfcc + (s * frame_pitch + first_win + (size_t)w) * K;
     } else {
+        if (gl.count && *gl.count < gl.dense_min) return;  // DENSE mode of the gate: only when (nearly) every window passed
         size_t sA, sB = 0;
         int wA, nA, nB = 0;
         if (flat) {
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
     const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
-    int flat, size_t n_streams, const uint32_t *__restrict__ list = nullptr, const uint32_t *__restrict__ list_count = nullptr) {
+    int flat, size_t n_streams, GateList gl = GateList{}) {
     constexpr int B = 2 * W, NW = 2 * kDtwWin;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -240,16 +253,16 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
     if (GX) {
         static_assert(!GX || KP == K, "global-memory frames have pitch K");
         unsigned n_listed = 0;
-        if (list) {
-            n_listed = *list_count;
-            if ((size_t)tile * NW >= n_listed) return;
-        }
+        if (gl.list) {
+            n_listed = *gl.count;
+            if ((size_t)tile * NW >= n_listed || (gl.dense_min && n_listed >= gl.dense_min)) return;
+        } else if (gl.count && *gl.count < gl.dense_min) return;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             size_t f = (size_t)tile * NW + (size_t)e * kDtwWin + lane;
-            if (list) {
+            if (gl.list) {
                 valid[e] = f < n_listed;
-                f = list[valid[e] ? f : n_listed - 1];
+                f = gl.list[valid[e] ? f : n_listed - 1];
             } else {
                 valid[e] = f < n_streams * n_win;
             }
@@ -258,6 +271,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
             xl[e] = mfcc + (s[e] * frame_pitch + first_win + (size_t)w[e]) * K;
         }
     } else {
+        if (gl.count && *gl.count < gl.dense_min) return;
         size_t sA, sB = 0;
         int wA, nA, nB = 0;
         if (flat) {
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, unsigned n_chunks,
     int chunk_base, size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks,
     const float *__restrict__ dup, int T, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
-    size_t n_streams = 0, const uint32_t *__restrict__ list = nullptr, const uint32_t *__restrict__ list_count = nullptr) {
+    size_t n_streams = 0, GateList gl = GateList{}) {
     constexpr int B = 2 * W;
     constexpr int TP = TC >= 2 ? TC / 2 : 1;      // template pairs per row of `dup` (a one-template chunk is stored as a pair)
     // LDS rows get an odd pitch (conflict-free lane-strided reads); GX lanes read rows of pitch K from global memory
@@ -417,18 +431,20 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
     if (GX) {
         // lanes are consecutive entries of the flattened (stream, window) space, or of the gate's list (see dtw_band_kernel)
         size_t f = (size_t)tile * kDtwWin + lane;
-        if (list) {
-            const uint32_t n_listed = *list_count;
-            if ((size_t)tile * kDtwWin >= n_listed) return;
+        if (gl.list) {
+            const uint32_t n_listed = *gl.count;
+            if ((size_t)tile * kDtwWin >= n_listed || (gl.dense_min && n_listed >= gl.dense_min)) return;
             valid = f < n_listed;
-            f = list[valid ? f : n_listed - 1];
+            f = gl.list[valid ? f : n_listed - 1];
         } else {
+            if (gl.count && *gl.count < gl.dense_min) return;
             valid = f < n_streams * n_win;
         }
         s = valid ? f / n_win : 0;
         wl = valid ? f - s * n_win : 0;
         xl = mfcc + (s * frame_pitch + first_win + wl) * K;
     } else {
+        if (gl.count && *gl.count < gl.dense_min) return;
         s = blockIdx.x / ((size_t)tiles * n_chunks);
         const size_t w0 = first_win + (size_t)tile * kDtwWin;
         const int n_stage = kDtwWin + L + W;
@@ -617,11 +633,10 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
 template <int K, int W, int TC>
 static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                                    size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
-                                   float score_ref, float *scores, float *avg, bool few_windows, const uint32_t *list = nullptr,
-                                   const uint32_t *list_count = nullptr) {
+                                   float score_ref, float *scores, float *avg, bool few_windows, GateList gl = GateList{}) {
     if (n_chunks <= 0) return hipSuccess;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
-    if ((few_windows || list) && KP == K) {
+    if ((few_windows || gl.list) && KP == K) {
         // streams contribute fewer than 64 windows each (or the windows come from a list): lanes of a wave span many
         // streams and read their frames from global memory (the caller guarantees W*K floats of slack after the last
         // stream's frames)
@@ -630,10 +645,10 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int ch
         if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
         hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
                            frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
-                           t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S, list, list_count);
+                           t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S, gl);
         return hipGetLastError();
     }
-    if (list) return hipErrorNotSupported;
+    if (gl.list) return hipErrorNotSupported;
     // flattened (stream, window) tiling when every stream has at least one full tile of windows
     const int flat = (n_win >= (size_t)kDtwWin && S > 1) ? 1 : 0;
     const size_t ft = flat ? (S * n_win + kDtwWin - 1) / kDtwWin : tiles;
@@ -642,7 +657,7 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int ch
     const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + W)) * KP * sizeof(float);
     hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
-                       t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
+                       t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S, gl);
     return hipGetLastError();
 }
 
@@ -650,21 +665,20 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int ch
 template <int K, int W>
 static hipError_t launch_dtw_single_chunks(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
-                                           float *scores, float *avg, bool few_windows, const uint32_t *list = nullptr,
-                                           const uint32_t *list_count = nullptr) {
+                                           float *scores, float *avg, bool few_windows, GateList gl = GateList{}) {
     if (n_chunks <= 0) return hipSuccess;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     constexpr int NW = 2 * kDtwWin;
-    if ((few_windows || list) && KP == K) {
+    if ((few_windows || gl.list) && KP == K) {
         const size_t ft = (S * n_win + NW - 1) / NW;
         const size_t blocks = ft * (size_t)n_chunks;
         if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
         hipLaunchKernelGGL((dtw_band2_kernel<K, W, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
                            frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
-                           t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S, list, list_count);
+                           t.chunks, t.dup, t.T, score_ref, scores, avg, 1, S, gl);
         return hipGetLastError();
     }
-    if (list) return hipErrorNotSupported;
+    if (gl.list) return hipErrorNotSupported;
     const size_t tiles = (n_win + NW - 1) / NW;
     const int flat = (n_win >= (size_t)NW && S > 1) ? 1 : 0;
     const size_t ft = flat ? (S * n_win + NW - 1) / NW : tiles;
@@ -673,25 +687,24 @@ static hipError_t launch_dtw_single_chunks(hipStream_t st, const TemplatesDev &t
     const size_t lds = (size_t)(NW + 2 * (t.max_len + W)) * KP * sizeof(float);
     hipLaunchKernelGGL((dtw_band2_kernel<K, W, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
-                       t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S);
+                       t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S, gl);
     return hipGetLastError();
 }
 
 template <int K, int W, int TC>
 static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls, int n_chunks, const float *mfcc, size_t S,
                                   size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
-                                  float score_ref, float *scores, float *avg, bool few_windows = false, const uint32_t *list = nullptr,
-                                  const uint32_t *list_count = nullptr, int chunk_base = -1) {
+                                  float score_ref, float *scores, float *avg, bool few_windows = false, GateList gl = GateList{}, int chunk_base = -1) {
     if (n_chunks <= 0) return hipSuccess;
     if (chunk_base < 0) chunk_base = t.class_first[cls];
-    if (few_windows || list) {
+    if (few_windows || gl.list) {
         // lanes span streams (few windows per stream) or come from the gate's list: frames read from global memory
         const size_t ft = (S * n_win + kDtwWin - 1) / kDtwWin;
         const size_t blocks = ft * (size_t)n_chunks;
         if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
         hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC, true>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
                            frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
-                           t.chunks, t.dup, t.T, score_ref, scores, avg, S, list, list_count);
+                           t.chunks, t.dup, t.T, score_ref, scores, avg, S, gl);
         return hipGetLastError();
     }
     const size_t blocks = tiles * (size_t)n_chunks * S;
@@ -700,7 +713,7 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
     const size_t lds = (size_t)(kDtwWin + t.max_len + W) * KP * sizeof(float);
     hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
-                       t.chunks, t.dup, t.T, score_ref, scores, avg);
+                       t.chunks, t.dup, t.T, score_ref, scores, avg, (size_t)0, gl);
     return hipGetLastError();
 }
 
@@ -708,9 +721,9 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
 template <int K, int W>
 static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int n1, const float *mfcc, size_t S, size_t frame_pitch,
                                       size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores,
-                                      float *avg, bool few, const uint32_t *list = nullptr, const uint32_t *list_count = nullptr) {
-    if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, n1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count); e != hipSuccess) return e;
-    return launch_dtw_wide<K, W, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count);
+                                      float *avg, bool few, GateList gl = GateList{}) {
+    if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, n1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl); e != hipSuccess) return e;
+    return launch_dtw_wide<K, W, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
 }
 
 // dispatch on the (mfcc_size, band) pairs the wide kernels are built for
@@ -832,13 +845,13 @@ int dtw_register_tile(int K, int band) {
 template <int W>
 static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, const float *mfcc, size_t S, size_t frame_pitch,
                                 size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
-                                float *scores, float *avg, bool few, const uint32_t *list = nullptr, const uint32_t *list_count = nullptr) {
+                                float *scores, float *avg, bool few, GateList gl = GateList{}) {
     hipError_t e;
     // n1: single-template chunks to score (class 3; the averaged template is its last chunk)
-    if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
-    if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
-    if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count)) != hipSuccess) return e;
-    return launch_dtw_class<5, W, 8>(st, t, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, list, list_count);
+    if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+    if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+    if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+    return launch_dtw_class<5, W, 8>(st, t, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
 }
 
 // ---- the averaged-template gate as a skip (wakeword_comp.rs:85-93) -------------------------------------------------
@@ -890,8 +903,15 @@ static hipError_t gated_k5(hipStream_t st, const TemplatesDev &t, int avg_chunk,
     const size_t waves = (rows + 1023) / 1024, blocks = (waves + 3) / 4;
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    // pass 3: the sample templates on the listed rows
-    return launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, list, count);
+    // pass 3: the sample templates on the listed rows -- or, when (nearly) every row is listed, on all rows through the
+    // ordinary staged launch (GateList; with few windows per stream both forms read global memory: list mode only)
+    GateList gl;
+    gl.list = list; gl.count = count;
+    gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
+    e = launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
+    if (e != hipSuccess || few) return e;
+    gl.list = nullptr;
+    return launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
 }
 
 template <int K, int W>
@@ -899,12 +919,18 @@ static hipError_t gated_wide(hipStream_t st, const TemplatesDev &t, int avg_chun
                              size_t first_win, size_t n_win, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
                              uint32_t *count, bool few) {
     const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
-    hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, few, nullptr, nullptr, avg_chunk);
+    hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, few, GateList{}, avg_chunk);
     if (e != hipSuccess) return e;
     const size_t waves = (rows + 1023) / 1024, blocks = (waves + 3) / 4;
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    return launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, list, count);
+    GateList gl;
+    gl.list = list; gl.count = count;
+    gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
+    e = launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
+    if (e != hipSuccess || few) return e;
+    gl.list = nullptr;
+    return launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
 }
 
 // first_win / few_windows as in launch_dtw (live-stream batches score the few newest windows of every stream: then pass 1

@@ -101,3 +101,46 @@ print("ALL-OK")
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _build_example(name, tmp_path, extra=()):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / name)
+    lib_dir = os.path.join(root, "rustpotter_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", name + ".c"),
+           "-L" + lib_dir, "-lrustpotter_hip", "-Wl,-rpath," + lib_dir, "-o", exe] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_the_c_examples_link(tmp_path):
+    """include/rustpotter_hip.h is the boundary document for a host written in any language: it must compile as C99 on its
+    own, and the plain-C programs under examples/ (no Python, no torch) must build and link against the shared library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        os.path.join(root, "include", "rustpotter_hip.h")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    _build_example("detect_wav", tmp_path)
+    _build_example("sharded_batch", tmp_path, ["-lm"])
+
+
+@pytest.mark.gpu
+def test_c_examples_run(tmp_path):
+    """The same programs on the GPU: the reference's golden wav through the single-stream API from C, and the sharded batch
+    entry point with three shards (each finds the utterance planted into its first stream)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = os.path.join(root, "tests", "golden")
+    exe = _build_example("detect_wav", tmp_path)
+    r = subprocess.run([exe, os.path.join(g, "oye_casa_g.rpw"), os.path.join(g, "oye_casa_g_1.wav")], capture_output=True, text=True, timeout=300)
+    # the values tests/detector.rs:24-37 asserts for this recording (Max mode): avg_score 0.6495044, score 0.7310586
+    assert r.returncode == 0 and 'detection "oye casa" score 0.7310586 avg_score 0.6495044' in r.stdout and "1 detection(s)" in r.stdout, r.stdout + r.stderr
+    exe = _build_example("sharded_batch", tmp_path, ["-lm"])
+    r = subprocess.run([exe, "3", "100"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "303 streams in 3 shards" in r.stdout, r.stdout + r.stderr
+    for shard, glob in ((0, 0), (1, 100), (2, 201)):
+        assert "shard %d stream 0 (global %d):" % (shard, glob) in r.stdout, r.stdout
+

@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--avg-gate", action="store_true", help="reference defaults: an averaged template and avg_threshold 0.2 -- windows "
                     "whose avg_score is below it are not compared with the sample templates (wakeword_comp.rs:85-93)")
     ap.add_argument("--avg-threshold", type=float, default=0.2, help="with --avg-gate: DetectorConfig.avg_threshold (reference default 0.2)")
+    ap.add_argument("--detect-only", action="store_true", help="do not ask for the per-window score arrays: the call returns detections only and "
+                    "(ScoreMode::Max) may abandon DTWs that can no longer reach the threshold (same detections; NOT the headline workload, which "
+                    "scores every window against every template)")
     ap.add_argument("--full-scores", action="store_true", help="with --avg-gate: compare every window with every template anyway (RP_CTX_FULL_SCORES)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -146,7 +149,7 @@ def main():
     # resident inputs / outputs
     pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
     ctx.synth_dev(SEED, sharding.weak_first_stream(S, rank), S, N, N, pcm.data_ptr())
-    want_arrays = not args.avg_gate  # the per-window arrays are defined for every window: asking for them keeps every DTW
+    want_arrays = not (args.avg_gate or args.detect_only)  # the per-window arrays are defined for every window: asking for them keeps every DTW
     scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev) if want_arrays else None
     agg = torch.empty((S, n_win), dtype=torch.float32, device=dev) if want_arrays else None
     max_det = 4
@@ -265,7 +268,8 @@ def main():
                                                        args.score_mode.capitalize(),
                                                        ("averaged template + avg_threshold %g%s, " % (args.avg_threshold, " (reference default)" if args.avg_threshold == 0.2 else "") +
                                                         ("every window scored anyway" if args.full_scores else "gated windows skipped"))
-                                                       if args.avg_gate else "avg gate off"),
+                                                       if args.avg_gate else ("avg gate off" + (", detect-only call: DTWs that cannot reach threshold 0.5 "
+                                                                                               "any more are abandoned" if args.detect_only else ""))),
                    "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
                    "windows_per_stream": n_win, "template_chunks": n_chunks,
                    "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world},

@@ -171,9 +171,10 @@ const char *rp_last_error(void);
 typedef struct rp_ctx rp_ctx;
 typedef struct rp_templates rp_templates;
 
-/* RP_CTX_FULL_SCORES: rp_batch_detect* compare every window with every sample template even when the averaged-template
- * gate (avg_threshold != 0, wakeword_comp.rs:85-93) would skip them -- the behaviour of the per-window score outputs,
- * forced for calls that do not ask for them (same detections either way; used to time the two paths). */
+/* RP_CTX_FULL_SCORES: rp_batch_detect* compare every window with every sample template to the end even when the
+ * averaged-template gate (avg_threshold != 0, wakeword_comp.rs:85-93) would skip them or the running cost already rules a
+ * detection out -- the behaviour of the per-window score outputs, forced for calls that do not ask for them (same
+ * detections either way; used to time the paths against each other). */
 enum { RP_CTX_DEVICE_POINTERS = 0, RP_CTX_HOST_POINTERS = 1, RP_CTX_FULL_SCORES = 2 };
 
 /* device: HIP device ordinal.  Fails (<0) if no HIP device is usable. */
@@ -301,7 +302,10 @@ int rp_detect_scan(rp_ctx *ctx, const float *agg, const float *avg, size_t S, si
  * `config` by the caller; avg gate as in WakewordComparator::run_detection :83-93: with an averaged template and
  * avg_threshold != 0, windows whose avg_score is below the threshold are NOT compared with the sample templates
  * (one DTW instead of T+1) unless `scores` / `agg` are requested -- those arrays hold every window -- or the
- * context has RP_CTX_FULL_SCORES; the detections are the same on either path. */
+ * context has RP_CTX_FULL_SCORES; the detections are the same on either path.  A call that asks for neither array is
+ * "detect-only": in ScoreMode::Max it may also stop DTWs whose running cost already rules out a score above
+ * `threshold` (cell costs are >= 0, so the cost can only grow) -- only where a whole wave of 64 windows is past that bound,
+ * so every window that can fire keeps exact scores and the detections do not change. */
 int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, size_t pcm_stride, const rp_templates *t,
                     const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det,
                     float *scores, float *agg);

@@ -488,7 +488,10 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         // The averaged-template gate as the reference runs it (wakeword_comp.rs:85-93): a window whose avg_score is below
         // avg_threshold is never compared with the sample templates.  Taken when the caller did not ask for the
         // per-window score arrays (those are defined for every window) and RP_CTX_FULL_SCORES is not set.
-        const bool gated = do_avg && !scores && !agg && !(c->flags & RP_CTX_FULL_SCORES) && dtw_gate_supported(td, config->band_size, rows);
+        const bool detect_only = !scores && !agg && !(c->flags & RP_CTX_FULL_SCORES);
+        const bool gated = do_avg && detect_only && dtw_gate_supported(td, config->band_size, rows);
+        // detect-only calls in ScoreMode::Max may also stop DTWs that can no longer reach `threshold` (rp_kernels.h, launch_dtw)
+        const float abandon = (detect_only && config->score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(config->threshold, config->score_ref) : __builtin_inff();
         if (gated && !c->ws_list.reserve((rows + 1) * sizeof(uint32_t) + 16)) return -1;
         if (!ds) { if (!c->ws_scores.reserve(rows * td.T * sizeof(float) + 16)) return -1; ds = c->ws_scores.as<float>(); }
         if (!dg) { if (!c->ws_agg.reserve(rows * sizeof(float) + 16)) return -1; dg = c->ws_agg.as<float>(); }
@@ -504,9 +507,9 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         if (gated) {
             uint32_t *lst = c->ws_list.as<uint32_t>();
             ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, config->avg_threshold,
-                                         ds, da, lst + 1, lst), "dtw kernels (gated)");
+                                         ds, da, lst + 1, lst, false, abandon), "dtw kernels (gated)");
         } else {
-            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, false, abandon), "dtw kernel");
         }
         c->time_end();
         if (!ok) return -1;
@@ -643,15 +646,17 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
             float *dg = c->ws_agg.as<float>() + j * rows, *da = do_avg ? c->ws_avg.as<float>() + j * rows : nullptr;
             if (n_win) {
                 // windows below the wakeword's avg_threshold are not compared with its sample templates (wakeword_comp.rs:85-93)
-                const bool gated = do_avg && !(c->flags & RP_CTX_FULL_SCORES) && dtw_gate_supported(td, config->band_size, rows);
+                const bool detect_only = !(c->flags & RP_CTX_FULL_SCORES);  // this entry point has no per-window outputs
+                const bool gated = do_avg && detect_only && dtw_gate_supported(td, config->band_size, rows);
+                const float abandon = (detect_only && config->score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(thr, config->score_ref) : __builtin_inff();
                 if (gated && !c->ws_list.reserve((rows + 1) * sizeof(uint32_t) + 16)) return -1;
                 c->time_begin(kKernelDtw);
                 if (gated) {
                     uint32_t *lst = c->ws_list.as<uint32_t>();
-                    ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst),
-                                "dtw kernels (gated)");
+                    ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst,
+                                                 false, abandon), "dtw kernels (gated)");
                 } else {
-                    ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+                    ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, false, abandon), "dtw kernel");
                 }
                 c->time_end();
                 if (!ok) return -1;
@@ -919,14 +924,16 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
         b->fill += n_new;
         float *ds = b->scores.as<float>(), *dg = b->agg.as<float>(), *da = do_avg ? b->avg.as<float>() : nullptr;
         // the averaged-template gate as a skip (wakeword_comp.rs:85-93), unless the caller wants every window's aggregate
-        const bool gated = do_avg && !agg && !(c->flags & RP_CTX_FULL_SCORES) && dtw_gate_supported(td, b->cfg.band_size, rows);
+        const bool detect_only = !agg && !(c->flags & RP_CTX_FULL_SCORES);
+        const bool gated = do_avg && detect_only && dtw_gate_supported(td, b->cfg.band_size, rows);
+        const float abandon = (detect_only && b->cfg.score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(b->cfg.threshold, b->cfg.score_ref) : __builtin_inff();
         c->time_begin(kKernelDtw);
         if (gated) {
             uint32_t *lst = b->list.as<uint32_t>();
             ok = hip_ok(launch_dtw_gated(c->stream, td, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, b->cfg.avg_threshold,
-                                         ds, da, lst + 1, lst, true), "dtw kernels (gated)");
+                                         ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
         } else {
-            ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true), "dtw kernel");
+            ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
         }
         c->time_end();
         if (!ok) return -1;

@@ -26,6 +26,12 @@ constexpr int kDtwWin = 64;   // windows per wave
 struct GateList {
     const uint32_t *list = nullptr, *count = nullptr;
     uint32_t dense_min = 0;
+    // Early abandon (detect-only calls in ScoreMode::Max): a DTW whose cheapest band cell already costs more than
+    // abandon_nc * (m + n) cannot end with a score above the detection threshold (cell costs are >= 0 and every warping
+    // path crosses every row), so a wave whose 64 windows x templates are ALL past that bound stops and reports score 0 for
+    // them.  Windows that can still fire are never touched: their wave runs to the end, with every template exact.
+    // +inf: off (the per-window score arrays are part of the call's result).  See dtw_abandon_nc().
+    float abandon_nc = __builtin_inff();
 };
 
 // One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
@@ -203,7 +209,27 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
         const int r0 = 1;
         RP_ROWS(true)
     }
-    for (int r0 = 1 + B; r0 < L; r0 += B) { RP_ROWS(false) }
+    const float abandon_cost = gl.abandon_nc * (float)(L + L);
+    for (int r0 = 1 + B; r0 < L; r0 += B) {
+        if (gl.abandon_nc < RP_INF) {  // wave-uniform; once per 2W rows
+            bool alive = false;
+#pragma unroll
+            for (int t = 0; t < TC / 2; ++t) {
+                v2f m = P[t][0];
+#pragma unroll
+                for (int q = 1; q < B; ++q) m = (v2f){fminf(m.x, P[t][q].x), fminf(m.y, P[t][q].y)};
+                alive = alive || (2 * t < ch->count && m.x <= abandon_cost) || (2 * t + 1 < ch->count && m.y <= abandon_cost);
+            }
+            if (!__any(alive && valid)) {
+                if (valid) {
+                    const size_t row = s * out_win_pitch + (size_t)w;
+                    for (int t = 0; t < ch->count; ++t) scores[row * T + ch->tid[t]] = 0.f;
+                }
+                return;
+            }
+        }
+        RP_ROWS(false)
+    }
 #undef RP_ROWS
 #undef RP_LOAD_COL
 
@@ -384,12 +410,27 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
         const int r0 = 1;
         RP_ROWS2(true)
     }
-    for (int r0 = 1 + B; r0 < L; r0 += B) { RP_ROWS2(false) }
+    const int tid = ch->tid[0];
+    const float abandon_cost = gl.abandon_nc * (float)(L + L);
+    for (int r0 = 1 + B; r0 < L; r0 += B) {
+        if (gl.abandon_nc < RP_INF && tid < T) {  // never for the averaged template: its score is reported and gates
+            v2f m = P[0];
+#pragma unroll
+            for (int q = 1; q < B; ++q) m = (v2f){fminf(m.x, P[q].x), fminf(m.y, P[q].y)};
+            const bool alive = (valid[0] && m.x <= abandon_cost) || (valid[1] && m.y <= abandon_cost);
+            if (!__any(alive)) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    if (valid[e]) scores[(s[e] * out_win_pitch + (size_t)w[e]) * T + tid] = 0.f;
+                return;
+            }
+        }
+        RP_ROWS2(false)
+    }
 #undef RP_ROWS2
 #undef RP_LOAD_COL2
 
     const float denom = (float)(L + L);
-    const int tid = ch->tid[0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         if (valid[e]) {
@@ -534,7 +575,25 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
         const int r0 = 1;
         RP_ROWS(true)
     }
-    for (int r0 = 1 + B; r0 < L; r0 += B) { RP_ROWS(false) }
+    const float abandon_cost = gl.abandon_nc * (float)(L + L);
+    for (int r0 = 1 + B; r0 < L; r0 += B) {
+        if (gl.abandon_nc < RP_INF && ch->tid[0] < T) {
+            bool alive = false;
+#pragma unroll
+            for (int t = 0; t < TC; ++t) {
+                float m = P[t][0];
+#pragma unroll
+                for (int q = 1; q < B; ++q) m = fminf(m, P[t][q]);
+                alive = alive || (t < ch->count && m <= abandon_cost);
+            }
+            if (!__any(alive && valid)) {
+                if (valid)
+                    for (int t = 0; t < ch->count; ++t) scores[(s * out_win_pitch + wl) * T + ch->tid[t]] = 0.f;
+                return;
+            }
+        }
+        RP_ROWS(false)
+    }
 #undef RP_ROWS
 #undef RP_LOAD_COL
 
@@ -894,7 +953,7 @@ bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows) {
 template <int W>
 static hipError_t gated_k5(hipStream_t st, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
                            size_t first_win, size_t n_win, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
-                           uint32_t *count, bool few) {
+                           uint32_t *count, bool few, float abandon_nc) {
     const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
     // pass 1: the averaged template over every window
     hipError_t e = launch_dtw_single_chunks<5, W>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, first_win, n_win, n_win, score_ref, scores, avg, few);
@@ -906,7 +965,7 @@ static hipError_t gated_k5(hipStream_t st, const TemplatesDev &t, int avg_chunk,
     // pass 3: the sample templates on the listed rows -- or, when (nearly) every row is listed, on all rows through the
     // ordinary staged launch (GateList; with few windows per stream both forms read global memory: list mode only)
     GateList gl;
-    gl.list = list; gl.count = count;
+    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc;
     gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
     e = launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
     if (e != hipSuccess || few) return e;
@@ -917,7 +976,7 @@ static hipError_t gated_k5(hipStream_t st, const TemplatesDev &t, int avg_chunk,
 template <int K, int W>
 static hipError_t gated_wide(hipStream_t st, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
                              size_t first_win, size_t n_win, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
-                             uint32_t *count, bool few) {
+                             uint32_t *count, bool few, float abandon_nc) {
     const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
     hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, few, GateList{}, avg_chunk);
     if (e != hipSuccess) return e;
@@ -925,7 +984,7 @@ static hipError_t gated_wide(hipStream_t st, const TemplatesDev &t, int avg_chun
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     GateList gl;
-    gl.list = list; gl.count = count;
+    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc;
     gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
     e = launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
     if (e != hipSuccess || few) return e;
@@ -937,7 +996,7 @@ static hipError_t gated_wide(hipStream_t st, const TemplatesDev &t, int avg_chun
 // also reads its frames from global memory); scores / avg rows have pitch n_win.
 hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                             size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
-                            uint32_t *count, bool few_windows) {
+                            uint32_t *count, bool few_windows, float abandon_nc) {
     const size_t rows = S * n_win;
     if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
     const bool few = few_windows && S > 1 && n_win < (size_t)kDtwWin;
@@ -946,21 +1005,32 @@ hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *
     if (e != hipSuccess) return e;
     if (t.K == 5) {
         switch (band) {
-        case 3: return gated_k5<3>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
-        case 4: return gated_k5<4>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
-        case 5: return gated_k5<5>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
-        default: return gated_k5<6>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few);
+        case 3: return gated_k5<3>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
+        case 4: return gated_k5<4>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
+        case 5: return gated_k5<5>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
+        default: return gated_k5<6>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
         }
     }
-#define RP_WIDE_CALL(KK, WW) gated_wide<KK, WW>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few)
+#define RP_WIDE_CALL(KK, WW) gated_wide<KK, WW>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc)
     RP_WIDE_DISPATCH(RP_WIDE_CALL);
 #undef RP_WIDE_CALL
 }
 
+// Normalised-cost bound above which a DTW cannot reach `threshold` any more: score = 1 / (1 + exp((nc - ref) / ref)) > thr
+// <=> nc < ref * (1 + ln(1/thr - 1)) (comparator.rs:18-26), with a margin for the rounding of the running costs.
+float dtw_abandon_nc(float threshold, float score_ref) {
+    if (!(score_ref > 0.f) || !(threshold > 0.f)) return __builtin_inff();  // everything can fire (or the formula is degenerate): never abandon
+    if (threshold >= 1.f) return 0.f;                                         // a score is < 1: nothing can fire
+    const float nc = score_ref * (1.f + logf(1.f / threshold - 1.f));
+    return nc > 0.f ? nc * 1.001f + 1e-4f : nc + 1e-4f;
+}
+
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
-                      float *scores, float *avg, bool padded_rows) {
+                      float *scores, float *avg, bool padded_rows, float abandon_nc) {
     if (S == 0 || n_win == 0) return hipSuccess;
+    GateList gl;
+    gl.abandon_nc = abandon_nc;
     // many streams with few windows each (streaming batches): cross-stream waves reading frames from global memory;
     // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
     const bool few = padded_rows && S > 1 && n_win < (size_t)kDtwWin;
@@ -983,13 +1053,13 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
         const int n2 = t.class_count[3] - ((t.has_avg && !do_avg) ? 1 : 0);  // single-template chunks to score
         if (t.K == 5) {
             switch (band) {
-            case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
-            case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
-            case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
-            default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few);
+            case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
+            case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
+            case 5: return launch_dtw_k5<5>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
+            default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
             }
         }
-#define RP_WIDE_CALL(KK, WW) launch_dtw_wide_all<KK, WW>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few)
+#define RP_WIDE_CALL(KK, WW) launch_dtw_wide_all<KK, WW>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)
         RP_WIDE_DISPATCH(RP_WIDE_CALL);
 #undef RP_WIDE_CALL
     }

@@ -121,9 +121,13 @@ hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *
                            size_t pcm_stride, size_t first_frame, size_t n_frames, size_t out_frame_pitch, float *mfcc);
 
 // scores [S][n_win][T]; avg [S][n_win] or nullptr.  mfcc rows have `frame_pitch` frames per stream.
+// abandon_nc (dtw_abandon_nc(threshold, score_ref), or +inf = off): DETECT-ONLY calls in ScoreMode::Max may stop a wave
+// whose windows x templates all cost more than any score above `threshold` allows; those rows get score 0 (GateList in
+// rp_dtw.hip).  Every window that can fire keeps exact scores, so the detections do not change.
+float dtw_abandon_nc(float threshold, float score_ref);
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
-                      float *scores, float *avg, bool padded_rows = false);
+                      float *scores, float *avg, bool padded_rows = false, float abandon_nc = __builtin_inff());
 
 // The averaged-template gate as a skip (wakeword_comp.rs:85-93): every window against the averaged template (-> avg),
 // the rows with avg >= avg_threshold listed (list [S*n_win] / count: device workspaces), the sample templates on the
@@ -132,7 +136,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
 bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows);
 hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                             size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
-                            uint32_t *count, bool few_windows = false);
+                            uint32_t *count, bool few_windows = false, float abandon_nc = __builtin_inff());
 
 // Largest template tile the register DTW kernel is built for (0: only the generic kernel applies).
 int dtw_register_tile(int K, int band);

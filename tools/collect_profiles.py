@@ -47,7 +47,8 @@ names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk
          "c4": "bench_%s_c4_per_gpu" % R, "c2": "bench_%s_c2" % R, "ragged5": "bench_%s_ragged5_templates" % R, "t3": "bench_%s_t3_len126" % R,
          "median": "bench_%s_median" % R, "gate_default": "bench_%s_avg_gate_default" % R, "gate_default_full": "bench_%s_avg_gate_default_full_scores" % R,
          "gate_04": "bench_%s_avg_gate_04" % R, "gate_04_full": "bench_%s_avg_gate_04_full_scores" % R,
-         "two_ranks_one_gpu": "bench_%s_two_ranks_one_gpu_dry_run" % R}
+         "two_ranks_one_gpu": "bench_%s_two_ranks_one_gpu_dry_run" % R, "detect_only": "bench_%s_detect_only" % R,
+         "detect_only_ragged5": "bench_%s_detect_only_ragged5" % R}
 for a, b in names.items():
     src = "gpurun_out/final/%s.json" % a
     if os.path.exists(src) and os.path.getsize(src) > 10:

@@ -13,6 +13,8 @@ $B --no-cpu-baseline --streams 8192 --templates 64 2>/dev/null | line > $O/c4.js
 $B --no-cpu-baseline --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5.json
 $B --no-cpu-baseline --templates 3 --template-len 126 2>/dev/null | line > $O/t3.json
 $B --no-cpu-baseline --score-mode median 2>/dev/null | line > $O/median.json
+$B --no-cpu-baseline --detect-only 2>/dev/null | line > $O/detect_only.json
+$B --no-cpu-baseline --detect-only --template-lens 108,96,90,93,102 2>/dev/null | line > $O/detect_only_ragged5.json
 $B --no-cpu-baseline --avg-gate 2>/dev/null | line > $O/gate_default.json
 $B --no-cpu-baseline --avg-gate --full-scores 2>/dev/null | line > $O/gate_default_full.json
 $B --no-cpu-baseline --avg-gate --avg-threshold 0.4 2>/dev/null | line > $O/gate_04.json

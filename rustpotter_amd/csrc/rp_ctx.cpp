@@ -158,6 +158,14 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     longest = max_len;
     const int has_avg = (avg && avg_len > 0) ? 1 : 0;
     if (has_avg && avg_len > longest) longest = avg_len;
+    {   // the DTW kernels keep a tile of windows plus one template length of frames in the CU's 160 KB of LDS
+        const size_t need = ((size_t)(64 + longest - 1) * (size_t)(K | 1) + (size_t)K * 64 + 11 * 64) * sizeof(float);
+        if (need > 160 * 1024) {
+            set_last_error("wakeword template of " + std::to_string(longest) + " frames is too long for the device kernels (limit " +
+                           std::to_string((160 * 1024 / sizeof(float) - (size_t)K * 64 - 11 * 64) / (size_t)(K | 1) - 63) + " frames at mfcc_size " + std::to_string(K) + ")");
+            return nullptr;
+        }
+    }
     const int Ttot = T + has_avg, Lpad = longest;
     std::vector<float> unit((size_t)Ttot * Lpad * K, 0.f);
     std::vector<int> hl(Ttot);

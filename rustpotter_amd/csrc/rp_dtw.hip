@@ -714,6 +714,8 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int ch
     const size_t blocks = flat ? ft * (size_t)n_chunks : tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const size_t lds = (size_t)(kDtwWin + 2 * (t.max_len + W)) * KP * sizeof(float);
+    if (lds > 64 * 1024)
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_band_kernel<K, W, TC, false>), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S, gl);
@@ -744,6 +746,8 @@ static hipError_t launch_dtw_single_chunks(hipStream_t st, const TemplatesDev &t
     const size_t blocks = flat ? ft * (size_t)n_chunks : tiles * (size_t)n_chunks * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const size_t lds = (size_t)(NW + 2 * (t.max_len + W)) * KP * sizeof(float);
+    if (lds > 64 * 1024)
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_band2_kernel<K, W, false>), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL((dtw_band2_kernel<K, W, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)ft, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg, flat, S, gl);
@@ -770,6 +774,8 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     const size_t lds = (size_t)(kDtwWin + t.max_len + W) * KP * sizeof(float);
+    if (lds > 64 * 1024)
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_band_wide_kernel<K, W, TC, false>), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL((dtw_band_wide_kernel<K, W, TC, false>), dim3((unsigned)blocks), dim3(kDtwWin), lds, st, mfcc, frame_pitch,
                        frame_pitch, (unsigned)tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch,
                        t.chunks, t.dup, t.T, score_ref, scores, avg, (size_t)0, gl);
@@ -947,7 +953,8 @@ __global__ __launch_bounds__(256) void gate_compact_kernel(const float *__restri
 }
 
 bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows) {
-    return t.has_avg && dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && rows > 0 && rows < 0xffffffffULL;
+    return t.has_avg && dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && rows > 0 && rows < 0xffffffffULL &&
+           (size_t)(2 * kDtwWin + 2 * (t.max_len + 8)) * (size_t)(t.K | 1) * sizeof(float) <= 160 * 1024;
 }
 
 template <int W>
@@ -1049,7 +1056,10 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     }
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
     // the register kernels assume m == n (no template longer than the window)
-    if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks) {
+    // (a register kernel stages 64..128 windows + two template lengths of frames in LDS: templates beyond ~4 000 frames at
+    // mfcc_size 5 -- 40 s -- do not fit the CU's 160 KB; the generic kernel stages one length and takes them up to ~8 000)
+    const size_t reg_lds = (size_t)(2 * kDtwWin + 2 * (t.max_len + 8)) * (size_t)(t.K | 1) * sizeof(float);
+    if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && (few || reg_lds <= 160 * 1024)) {
         const int n2 = t.class_count[3] - ((t.has_avg && !do_avg) ? 1 : 0);  // single-template chunks to score
         if (t.K == 5) {
             switch (band) {
@@ -1069,7 +1079,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     // the band is widened to |m-n| inside the kernel; size for the worst case over templates
     const int Wmax = band > t.max_diff ? band : t.max_diff;
     const size_t lds = ((size_t)(64 + t.max_len - 1) * KP + (size_t)t.K * 64 + (size_t)(2 * Wmax + 1) * 64) * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 160 * 1024) return hipErrorMemoryAllocation;  // reported as "template too long" by the callers' hip_ok text
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_generic_kernel), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
                        (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, Ttot,

@@ -371,6 +371,22 @@ def test_contexts_on_one_device_use_large_lds_kernels(ra):
     assert np.allclose(outs[0][0][:ref.shape[0]], ref, rtol=1e-5, atol=0)
 
 
+def test_very_long_templates(ra):
+    """Templates far beyond the usual 1-2 s: 25 s (the register kernels with > 64 KB of LDS), 50 s (too long for them: the
+    generic kernel), and 90 s (refused with a text that names the limit, not a launch failure)."""
+    ctx = ra.BatchContext(0)
+    K = 5
+    for L in (2500, 5000):
+        rng = np.random.default_rng(L)
+        templates = [rng.standard_normal((L, K)).astype(np.float32), rng.standard_normal((L - 7, K)).astype(np.float32)]
+        mf = rng.standard_normal((2, L + 20, K)).astype(np.float32)
+        sc, _, _ = ctx.dtw_scores(mf, ra.Templates(ctx, templates))
+        ref, _ = orc.score_stream(mf[1][:L + 2], templates)
+        assert np.allclose(sc[1][:ref.shape[0]], ref, rtol=1e-5, atol=0)
+    with pytest.raises(ra.RustpotterError, match="too long for the device kernels"):
+        ra.Templates(ctx, [np.ones((9000, K), np.float32)])
+
+
 # ------------------------------------------------------------------ NULL arguments with live handles
 def test_null_arguments_with_live_handles(ra):
     """config / pcm / det == NULL next to a valid context and template set is an error return, not a crash."""

@@ -243,6 +243,9 @@ def main():
     if "dtw" in pmc and "instructions_per_launch" in pmc["dtw"]:
         r_dtw["valu_insts_per_launch"] = pmc["dtw"]["instructions_per_launch"]["SQ_INSTS_VALU"]
         r_dtw["valu_issue_frac"] = 4.0 * r_dtw["valu_insts_per_launch"] / simd_cycles(dtw_s) if dtw_s else 0.0
+        if "effective_clock_ghz" in pmc["dtw"]:  # the chip clocks below 2.4 GHz under this load (GRBM_GUI_ACTIVE / duration, same PMC file)
+            r_dtw["effective_clock_ghz"] = pmc["dtw"]["effective_clock_ghz"]
+            r_dtw["valu_issue_frac_at_effective_clock"] = r_dtw["valu_issue_frac"] * 2.4 / pmc["dtw"]["effective_clock_ghz"]
     mfcc_bytes, mfcc_flops = S * nf * (640 + 4 * K), S * nf * f_mfcc
     r_mfcc = {"bound": "hbm", "kernel": "mfcc_kernel", "achieved": mfcc_bytes / mfcc_s / 1e9 if mfcc_s else 0.0, "peak": HBM_PEAK / 1e9,
               "unit": "GB/s", "frac": mfcc_bytes / mfcc_s / HBM_PEAK if mfcc_s else 0.0,
@@ -253,6 +256,9 @@ def main():
     if "mfcc" in pmc and "instructions_per_launch" in pmc["mfcc"]:
         r_mfcc["valu_insts_per_launch"] = pmc["mfcc"]["instructions_per_launch"]["SQ_INSTS_VALU"]
         r_mfcc["valu_issue_frac"] = 4.0 * r_mfcc["valu_insts_per_launch"] / simd_cycles(mfcc_s) if mfcc_s else 0.0
+        if "effective_clock_ghz" in pmc["mfcc"]:
+            r_mfcc["effective_clock_ghz"] = pmc["mfcc"]["effective_clock_ghz"]
+            r_mfcc["valu_issue_frac_at_effective_clock"] = r_mfcc["valu_issue_frac"] * 2.4 / pmc["mfcc"]["effective_clock_ghz"]
     roofline = dict(r_dtw if dom == "dtw" else r_mfcc)
     roofline["kernels_ms"] = {k: round(v[0], 4) for k, v in k_ms.items()}
     roofline["path_hbm_frac"] = (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK

@@ -15,9 +15,18 @@ def agg(tag):
     return {k: {c: statistics.median(v) for c, v in d.items()} for k, d in a.items()}
 
 fe, wr, sq, ins = agg("final_fetch"), agg("final_write"), agg("final_sq"), agg("final_inst")
+try:  # effective shader clock: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the launch's duration in the same pass
+    clk = agg("final_clk")
+    trc = glob.glob("gpurun_out/pmc_final_clk/**/*kernel_trace.csv", recursive=True)[0]
+    durs = collections.defaultdict(list)
+    for r in csv.DictReader(open(trc)):
+        durs[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    clk = {k: (v["GRBM_GUI_ACTIVE"], statistics.median(durs[k])) for k, v in clk.items() if k in durs}
+except Exception:
+    clk = {}
 out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                   "(separate passes: FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; "
-                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES -- tools/profile_pmc.sh)",
+                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r2_final.sh)",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch as reported by rocprofv3 (TCC_EA0 request counters); FETCH_SIZE of "
                 "16-byte-per-lane streaming reads under-reports by 2x on gfx950 (MI355X_MICROARCH.md HBM section); values are the "
                 "MEDIAN over the launches of a kernel in the run (the run also holds one tiny mfcc launch for the templates)",
@@ -35,6 +44,9 @@ for k in fe:
         d["sq_fractions_of_wave_cycles"] = {n: sq[k][n] / sq[k]["SQ_WAVE_CYCLES"] for n in sq[k] if n != "SQ_WAVE_CYCLES"}
     if k in ins:
         d["instructions_per_launch"] = ins[k]
+    if k in clk and clk[k][1] > 0:
+        d["grbm_gui_active_per_launch"] = clk[k][0]
+        d["effective_clock_ghz"] = clk[k][0] / 8.0 / clk[k][1]   # cycles per ns
     out["kernels"][k] = d
 json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
 json.dump(out, open("profiles/%s_final_pmc.json" % R, "w"), indent=1)

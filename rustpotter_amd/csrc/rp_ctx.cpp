@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include <mutex>
+#include <type_traits>
 
 #include "rp_host.h"
 
@@ -70,7 +71,7 @@ Ctx::~Ctx() {
     for (auto &t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &kv : tables) {
         MfccTablesDev &t = kv.second;
-        (void)hipFree(t.hamming); (void)hipFree(t.tw240); (void)hipFree(t.tw480); (void)hipFree(t.fb); (void)hipFree(t.dct);
+        (void)hipFree(t.hamming); (void)hipFree(t.tw240); (void)hipFree(t.tw480); (void)hipFree(t.fb); (void)hipFree(t.dct); if (t.melw) (void)hipFree(t.melw);
     }
     if (own_stream) (void)hipStreamDestroy(own_stream);
 }
@@ -120,6 +121,23 @@ const MfccTablesDev *Ctx::tables_for(int K) {
     if (!upload(&d.hamming, h.hamming) || !upload(&d.tw240, h.tw240) || !upload(&d.tw480, h.tw480) ||
         !upload(&d.fb, h.fb) || !upload(&d.dct, h.dct))
         return nullptr;
+    if (d.mel_sparse) {  // compact per-lane rows for the 16-byte LDS reads of the sparse kernels
+        auto build = [&](auto k1c) {
+            constexpr int K1C = decltype(k1c)::value;
+            std::vector<float> w((size_t)16 * kMelRowPitch<K1C>, 0.f);
+            for (int l = 0; l < 16; ++l)
+                for (int f = 0; f < K1C; ++f)
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        const int k = l + 16 * k2;
+                        if (mel_touches<K1C>(f, k2, false)) w[(size_t)l * kMelRowPitch<K1C> + mel_index<K1C>(f, k2, false)] = h.fb[(size_t)f * kBins + k];
+                        // bin 240 - k; for k == 0 it does not exist (the kernel forces that power to 0)
+                        if (mel_touches<K1C>(f, k2, true)) w[(size_t)l * kMelRowPitch<K1C> + mel_index<K1C>(f, k2, true)] = k > 0 ? h.fb[(size_t)f * kBins + (240 - k)] : 0.f;
+                    }
+            return w;
+        };
+        const std::vector<float> w = h.K1 == 6 ? build(std::integral_constant<int, 6>{}) : build(std::integral_constant<int, 17>{});
+        if (!upload(&d.melw, w)) return nullptr;
+    }
     return &(tables[K] = d);
 }
 

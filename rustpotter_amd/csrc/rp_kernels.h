@@ -29,6 +29,25 @@ template <int K1T> __host__ __device__ constexpr bool mel_touches(int f, int k2,
     return g_hi >= lo && g_lo <= hi;
 }
 
+// The sparse mel tables of the mfcc_size 5 / 16 kernels: per lane l (= bin residue mod 16) the weights of exactly the
+// (filter, 16-bin group, direct / mirror) triples mel_touches<K1T> admits, in the order the kernel accumulates them
+// (filter ascending, group ascending, direct before mirror) -- one contiguous row of kMelRowPitch<K1T> floats per lane,
+// read with 16-byte LDS loads (a pitch of 36 / 44 floats keeps the 16 lanes of a frame on distinct banks).
+template <int K1T> __host__ __device__ constexpr int mel_index(int f, int k2, bool mirror) {
+    int n = 0;
+    for (int ff = 0; ff < K1T; ++ff)
+        for (int kk = 0; kk < 8; ++kk) {
+            if (ff == f && kk == k2 && !mirror) return n;
+            if (mel_touches<K1T>(ff, kk, false)) ++n;
+            if (ff == f && kk == k2 && mirror) return n;
+            if (mel_touches<K1T>(ff, kk, true)) ++n;
+        }
+    return n;  // f == K1T: the number of entries
+}
+template <int K1T> constexpr int kMelEntries = mel_index<K1T>(K1T, 0, false);
+template <int K1T> constexpr int kMelRowPitch = ((kMelEntries<K1T> + 3) / 4) * 4 + (((kMelEntries<K1T> + 3) / 4) % 2 == 0 ? 4 : 0);  // 16-byte units: odd count
+static_assert(kMelEntries<6> == 31 && kMelRowPitch<6> == 36 && kMelEntries<17> == 41 && kMelRowPitch<17> == 44, "mel table shape");
+
 struct MfccTablesDev {
     int K1 = 0;               // K+1 filters / cepstral coefficients
     bool mel_sparse = false;  // K1 is 6 or 17 and the mel bank is non-zero only where mel_touches<K1> says (checked on upload)
@@ -36,6 +55,7 @@ struct MfccTablesDev {
     float2 *tw240 = nullptr;  // [240] exp(-2*pi*i*k/240)
     float2 *tw480 = nullptr;  // [240] exp(-2*pi*i*k/480)
     float *fb = nullptr;      // [K1][240]
+    float *melw = nullptr;    // mel_sparse: [16][kMelRowPitch<K1>] compact per-lane weights (mel_index order)
     float *dct = nullptr;     // [K1][K1] cos table, row k col n
 };
 

@@ -4,6 +4,7 @@
 #include "rp_device.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace rp {
 
@@ -22,8 +23,12 @@ constexpr int kMfccThreads = 64 * kMfccWaves;
 constexpr int kMfccStage = (kMfccFramesPerWave + 2) * kShift;  // 960 samples per wave tile
 constexpr int kMfccWaveScratch = kMfccFramesPerWave * 240;      // float2 per wave (aliases the samples)
 
-__host__ __device__ inline size_t mfcc_lds_bytes(int K1) {
-    size_t f = 480 + (size_t)K1 * kBins + (size_t)K1 * K1 + (size_t)kMfccWaves * kMfccFramesPerWave * K1;
+// floats the mel table takes in LDS: the compact per-lane rows of the sparse kernels (rp_kernels.h, mel_index) or [K1][240]
+__host__ __device__ inline size_t mel_lds_floats(int K1, bool sparse) {
+    return sparse && K1 == 6 ? (size_t)16 * kMelRowPitch<6> : sparse && K1 == 17 ? (size_t)16 * kMelRowPitch<17> : (size_t)K1 * kBins;
+}
+__host__ __device__ inline size_t mfcc_lds_bytes(int K1, bool sparse) {
+    size_t f = 480 + mel_lds_floats(K1, sparse) + (size_t)K1 * K1 + (size_t)kMfccWaves * kMfccFramesPerWave * K1;
     size_t c = (size_t)kMfccWaves * kMfccWaveScratch + 240;  // wave scratch + W480 (W240 is only read once per lane, from global)
     return c * sizeof(float2) + f * sizeof(float);
 }
@@ -61,14 +66,15 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
     v2f *scr_all = reinterpret_cast<v2f *>(smem);               // [waves][4][240]
     v2f *tw480 = scr_all + kMfccWaves * kMfccWaveScratch;       // [240]
     float *ham = reinterpret_cast<float *>(tw480 + 240);        // [480]
-    float *fb = ham + 480;                                      // [K1][240]
-    float *dct = fb + K1 * kBins;                               // [K1][K1]
+    float *fb = ham + 480;                                      // [K1][240], or the compact rows [16][kMelRowPitch] (K1T > 0)
+    const int fb_floats = (int)mel_lds_floats(K1, K1T > 0);
+    float *dct = fb + fb_floats;                                // [K1][K1]
     float *lgb_all = dct + K1 * K1;                             // [waves][4][K1]
 
     const int tid = threadIdx.x;
     for (int i = tid; i < 480; i += kMfccThreads) ham[i] = g_ham[i];
     for (int i = tid; i < 240; i += kMfccThreads) tw480[i] = (v2f){g_tw480[i].x, g_tw480[i].y};
-    for (int i = tid; i < K1 * kBins; i += kMfccThreads) fb[i] = g_fb[i];
+    for (int i = tid; i < fb_floats; i += kMfccThreads) fb[i] = g_fb[i];
     for (int i = tid; i < K1 * K1; i += kMfccThreads) dct[i] = g_dct[i];
     __syncthreads();
 
@@ -292,32 +298,71 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
             for (int k2 = 0; k2 < 8; ++k2) sacc += Pk[k2] + Pm[k2];
             if (l < 8 && l < K1) lgb[l] = sacc;
         }
-        if (false)
 #endif
+        {
+            // one pass = 8 filters; i0v is the pass's first filter: a compile-time constant for the sparse kernels (K1T > 0),
+            // a run-time value for the general one
+            auto mel_pass = [&](auto i0v) {
+                const int i0 = (int)i0v;
+                float acc[8];
+                if constexpr (K1T > 0) {
+                    constexpr int I0 = decltype(i0v)::value;
+                    // this lane's weights of the pass, 16 bytes per LDS read (its row holds them in accumulation order)
+                    constexpr int e0 = mel_index<K1T>(I0 < K1T ? I0 : K1T, 0, false), e1 = mel_index<K1T>(I0 + 8 < K1T ? I0 + 8 : K1T, 0, false);
+                    constexpr int v0 = e0 / 4, nv = (e1 + 3) / 4 - v0;
+                    f32x4 wv[nv > 0 ? nv : 1];
+                    const f32x4 *row = reinterpret_cast<const f32x4 *>(fb + l * kMelRowPitch<K1T>) + v0;
 #pragma unroll
-        for (int i0 = 0; i0 < (K1T > 0 ? K1T : K1); i0 += 8) {
-            float acc[8];
+                    for (int v = 0; v < nv; ++v) wv[v] = row[v];
+                    int e = e0 - 4 * v0;  // running position in wv: a compile-time constant at every use once the loops are unrolled
 #pragma unroll
-            for (int ii = 0; ii < 8; ++ii) {
-                acc[ii] = 0.f;
-                if (i0 + ii < K1) {
-                    const float *rk = fbk + (i0 + ii) * kBins, *rm = fbm + (i0 + ii) * kBins;
+                    for (int ii = 0; ii < 8; ++ii) {
+                        acc[ii] = 0.f;
+                        if (I0 + ii < K1T) {
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; ++k2) {
-                        if (mel_uses<K1T>(i0 + ii, k2, false)) acc[ii] = fmaf(Pk[k2], rk[16 * k2], acc[ii]);
-                        if (mel_uses<K1T>(i0 + ii, k2, true)) acc[ii] = fmaf(Pm[k2], rm[-16 * k2], acc[ii]);
+                            for (int k2 = 0; k2 < 8; ++k2) {
+                                if (mel_touches<K1T>(I0 + ii, k2, false)) { acc[ii] = fmaf(Pk[k2], wv[e / 4][e % 4], acc[ii]); ++e; }
+                                if (mel_touches<K1T>(I0 + ii, k2, true)) { acc[ii] = fmaf(Pm[k2], wv[e / 4][e % 4], acc[ii]); ++e; }
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int ii = 0; ii < 8; ++ii) {
+                        acc[ii] = 0.f;
+                        if (i0 + ii < K1) {
+                            const float *rk = fbk + (i0 + ii) * kBins, *rm = fbm + (i0 + ii) * kBins;
+#pragma unroll
+                            for (int k2 = 0; k2 < 8; ++k2) {
+                                acc[ii] = fmaf(Pk[k2], rk[16 * k2], acc[ii]);
+                                acc[ii] = fmaf(Pm[k2], rm[-16 * k2], acc[ii]);
+                            }
+                        }
                     }
                 }
-            }
-            // every lane ends up with all totals; lane ii keeps filter i0+ii's and one logf serves the whole pass
-            float mine = 0.f;
+                // every lane ends up with all totals; lane ii keeps filter i0+ii's and one logf serves the whole pass
+                float mine = 0.f;
 #pragma unroll
-            for (int ii = 0; ii < 8; ++ii) {
-                if (K1T > 0 && i0 + ii >= K1T) continue;
-                const float tot = row16_sum(acc[ii]);
-                mine = l == ii ? tot : mine;
+                for (int ii = 0; ii < 8; ++ii) {
+                    if (K1T > 0 && i0 + ii >= K1T) continue;
+                    const float tot = row16_sum(acc[ii]);
+                    mine = l == ii ? tot : mine;
+                }
+                if (l < 8 && i0 + l < K1) lgb[i0 + l] = logf(0.25f * mine + FLT_MIN);
+            };
+#ifdef RP_ABL_NOMEL
+            if (false)
+#endif
+            {
+                if constexpr (K1T > 0) {
+                    mel_pass(std::integral_constant<int, 0>{});
+                    if constexpr (K1T > 8) mel_pass(std::integral_constant<int, 8>{});
+                    if constexpr (K1T > 16) mel_pass(std::integral_constant<int, 16>{});
+                    static_assert(K1T <= 24, "three passes of eight filters");
+                } else {
+                    for (int i0 = 0; i0 < K1; i0 += 8) mel_pass(i0);
+                }
             }
-            if (l < 8 && i0 + l < K1) lgb[i0 + l] = logf(0.25f * mine + FLT_MIN);
         }
         wave_lds_sync();
         // ---- DCT-II x2, coefficient 0 dropped, src/mfcc/extractor.rs:84,146-163.  Sequential
@@ -346,8 +391,7 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
     const size_t tiles = (n_frames + kMfccFramesPerWave - 1) / kMfccFramesPerWave;
     const size_t total = tiles * S;
     if (tiles > 0xffffffffULL) return hipErrorInvalidValue;
-    const size_t lds = mfcc_lds_bytes(tb.K1);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (mfcc_lds_bytes(tb.K1, false) > 160 * 1024) return hipErrorInvalidValue;
     // 4-sample vector loads need rows aligned to 4 samples (and at least one full vector before the last sample)
     const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) && n_samples >= 8;
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
@@ -361,9 +405,9 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
     do {                                                                                                                   \
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mfcc_kernel<V, KT, TIN>), 160 * 1024);             \
         if (e != hipSuccess) return e;                                                                                     \
-        hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm, n_samples, \
-                           pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
-                           tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc, mfcc2);                                                       \
+        hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), mfcc_lds_bytes(tb.K1, KT > 0), st, pcm, \
+                           n_samples, pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
+                           tb.tw240, tb.tw480, KT > 0 ? tb.melw : tb.fb, tb.dct, mfcc, mfcc2);                              \
     } while (0)
     if (vec4 && tb.K1 == 6 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 6);
     else if (vec4 && tb.K1 == 17 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 17);
@@ -383,7 +427,7 @@ static hipError_t launch_mfcc_stream_t(hipStream_t st, const MfccTablesDev &tb, 
     if (S == 0 || n_chunks == 0) return hipSuccess;
     const size_t n_frames = 3 * n_chunks, n_samples = (1 + n_chunks) * kFrame;
     const size_t tiles = (n_frames + kMfccFramesPerWave - 1) / kMfccFramesPerWave, total = tiles * S;
-    const size_t lds = mfcc_lds_bytes(tb.K1);
+    const size_t lds = mfcc_lds_bytes(tb.K1, false);  // upper bound, for the feasibility check
     const bool vec4 = (reinterpret_cast<uintptr_t>(pcm) % (4 * sizeof(TIN)) == 0) && (pcm_stride % 4 == 0) &&
                       (reinterpret_cast<uintptr_t>(hist) % 16 == 0) && (reinterpret_cast<uintptr_t>(hist_out) % 16 == 0) &&
                       (hist_pitch % 4 == 0);
@@ -394,9 +438,9 @@ static hipError_t launch_mfcc_stream_t(hipStream_t st, const MfccTablesDev &tb, 
     do {                                                                                                                   \
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mfcc_kernel<true, KT, TIN, true>), 160 * 1024);    \
         if (e != hipSuccess) return e;                                                                                     \
-        hipLaunchKernelGGL((mfcc_kernel<true, KT, TIN, true>), dim3((unsigned)blocks), dim3(kMfccThreads), lds, st, pcm,   \
+        hipLaunchKernelGGL((mfcc_kernel<true, KT, TIN, true>), dim3((unsigned)blocks), dim3(kMfccThreads), mfcc_lds_bytes(tb.K1, KT > 0), st, pcm, \
                            n_samples, pcm_stride, (unsigned)tiles, total, (size_t)0, n_frames, out_frame_pitch, tb.K1,     \
-                           tb.hamming, tb.tw240, tb.tw480, tb.fb, tb.dct, mfcc, (float *)nullptr, hist, hist_pitch, hist_out); \
+                           tb.hamming, tb.tw240, tb.tw480, KT > 0 ? tb.melw : tb.fb, tb.dct, mfcc, (float *)nullptr, hist, hist_pitch, hist_out); \
     } while (0)
     if (tb.K1 == 6 && tb.mel_sparse) RP_MFCC_LAUNCH_HS(6);
     else if (tb.K1 == 17 && tb.mel_sparse) RP_MFCC_LAUNCH_HS(17);

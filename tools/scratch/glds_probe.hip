@@ -1,0 +1,113 @@
+// scratch: how fast can x [B][3120] f32 (818 MB) be streamed into MFMA-A-fragment shape?
+//   lin    : plain 16 B/lane lane-linear grid-stride read of the whole array (the read ceiling)
+//   frag   : fragment-shaped register loads, 16 rows x 64 B per instruction (what mlp_mfma_kernel did in rounds 1-2)
+//   glds   : LDS-DMA in full 128-B lines (8 rows x 128 B per wave-instruction, XOR-swizzled by the SOURCE address),
+//            per-wave ring of NS units of 4 KB (2 lines x 16 rows), fragments by ds_read_b128; persistent waves
+// build: hipcc --offload-arch=gfx950 -O3 -o glds_probe glds_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDSP(p) ((__attribute__((address_space(3))) void *)(p))
+
+__global__ __launch_bounds__(256) void lin_kernel(const f32x4 *__restrict__ x, size_t n16, float *out) {
+    f32x4 s = {0, 0, 0, 0};
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i + 3 * st < n16; i += 4 * st) {
+        f32x4 a = x[i], b = x[i + st], c = x[i + 2 * st], d = x[i + 3 * st];
+        s += a + b + c + d;
+    }
+    for (; i < n16; i += st) s += x[i];
+    if (s.x + s.y + s.z + s.w == 1.2345f) out[0] = s.x;
+}
+
+template <int KU> __global__ __launch_bounds__(512) void frag_kernel(const float *__restrict__ x, size_t B, int in, float *out) {
+    int l = threadIdx.x & 63, wave = threadIdx.x >> 6, li = l & 15, lk = l >> 4;
+    size_t row = ((size_t)blockIdx.x * 8 + wave) * 16 + li;
+    float s = 0.f;
+    for (int kb = 0; kb < in / 16; kb += KU) {
+        f32x4 a[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) { int k0 = 16 * (kb + u) + 4 * lk; a[u] = (k0 + 3 < in) ? *reinterpret_cast<const f32x4 *>(x + row * in + k0) : (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) s += a[u].x + a[u].y + a[u].z + a[u].w;
+    }
+    if (s == 1.2345f) out[row] = s;
+}
+
+// rows of one parity per block (row stride 12 480 B = 97.5 lines: even rows start on a line, odd rows in the middle of one);
+// the line grid is absolute: line j of a row covers bytes [128 j, 128 j + 128) from the line start at or below the row start
+template <int WAVES, int NS, int NT, int PAR>
+__global__ __launch_bounds__(64 * WAVES) void glds_kernel(const float *__restrict__ x, size_t B, int in, int ntiles, float *out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int l = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *ring = smem + (size_t)wave * NS * 4096;
+    const int li = l & 15, lk = l >> 4, r8 = l >> 3, c8 = l & 7;
+    const int sw = 2 * (r8 >> 1);                 // source swizzle of the DMA slot (row r8 of the piece)
+    const int ch = c8 ^ sw;                       // global 16-B chunk this lane fetches
+    const int rr = li & 7, rsw = 2 * (rr >> 1);
+    const unsigned rd0 = (li >> 3) * 1024 + rr * 128 + ((lk ^ rsw) & 7) * 16;
+    const unsigned rd1 = (li >> 3) * 1024 + rr * 128 + (((lk + 4) ^ rsw) & 7) * 16;
+    const int nlines = 98, upt = nlines / 2;       // units (line pairs) per tile
+    // tiles: 16 rows of one parity: tile t -> span (t / 2) * 32 rows, parity t & 1 (PAR) or 16 consecutive rows (!PAR)
+    const int wstride = gridDim.x * WAVES;
+    const int first = blockIdx.x * WAVES + wave;
+    int my_tiles = first < ntiles ? (ntiles - first + wstride - 1) / wstride : 0;
+    const int total = my_tiles * upt;
+    auto issue = [&](int u) __attribute__((always_inline)) {
+        const int tl = u / upt, lp = u - tl * upt;
+        const int t = first + tl * wstride;
+        unsigned char *dst = ring + (u % NS) * 4096;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // q = line (q>>1), piece (q&1)
+            const int rowi = 8 * (q & 1) + r8;
+            const size_t row = PAR ? (size_t)(t >> 1) * 32 + 2 * rowi + (t & 1) : (size_t)t * 16 + rowi;
+            const size_t byte0 = (row * (size_t)in * 4) & ~(size_t)127;   // line start at or below the row start
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(x) + byte0 + (size_t)(2 * lp + (q >> 1)) * 128 + ch * 16;
+            const unsigned char *end = reinterpret_cast<const unsigned char *>(x) + B * (size_t)in * 4 - 16;
+            if (src > end) src = end;
+            __builtin_amdgcn_global_load_lds(src, LDSP(dst + q * 1024), 16, 0, NT ? 2 : 0);
+        }
+    };
+    f32x4 s = {0, 0, 0, 0};
+    for (int u = 0; u < NS - 1 && u < total; ++u) issue(u);
+    for (int u = 0; u < total; ++u) {
+        if (u + NS - 1 < total) { issue(u + NS - 1); asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * (NS - 1)) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned char *src = ring + (u % NS) * 4096;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 a = *reinterpret_cast<const f32x4 *>(src + j * 2048 + rd0);
+            f32x4 b = *reinterpret_cast<const f32x4 *>(src + j * 2048 + rd1);
+            s += a + b;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (s.x + s.y + s.z + s.w == 1.2345f) out[first] = s.x;
+}
+
+int main() {
+    size_t B = 65536; int in = 3120;
+    float *x, *out; CK(hipMalloc(&x, B * in * 4)); CK(hipMalloc(&out, B * 4)); CK(hipMemset(x, 0x3c, B * in * 4));
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    auto run = [&](const char *name, auto launch) {
+        float best = 1e9f, sum = 0.f; const int reps = 20;
+        for (int it = 0; it < 3; ++it) launch();
+        for (int it = 0; it < reps; ++it) { hipEventRecord(a, 0); launch(); hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); sum += ms; if (ms < best) best = ms; }
+        CK(hipGetLastError());
+        printf("%-34s avg %.4f ms %.2f TB/s   best %.4f ms %.2f TB/s\n", name, sum / reps, B * in * 4.0 / (sum / reps) / 1e9, best, B * in * 4.0 / best / 1e9);
+    };
+    for (int g : {1024, 2048, 4096, 16384}) { char nm[64]; sprintf(nm, "lin grid %d", g); run(nm, [&] { hipLaunchKernelGGL(lin_kernel, dim3(g), dim3(256), 0, 0, (const f32x4 *)x, B * in / 4, out); }); }
+    run("frag KU=8", [&] { hipLaunchKernelGGL(frag_kernel<8>, dim3(B / 128), dim3(512), 0, 0, x, B, in, out); });
+    run("frag KU=16", [&] { hipLaunchKernelGGL(frag_kernel<16>, dim3(B / 128), dim3(512), 0, 0, x, B, in, out); });
+    const int ntiles = (int)(B / 16);
+#define G(W, NS, NT, PAR, GRID) do { char nm[80]; sprintf(nm, "glds W%d NS%d nt%d par%d grid%d", W, NS, NT, PAR, GRID); \
+        CK(hipFuncSetAttribute((const void *)glds_kernel<W, NS, NT, PAR>, hipFuncAttributeMaxDynamicSharedMemorySize, W * NS * 4096)); \
+        run(nm, [&] { hipLaunchKernelGGL((glds_kernel<W, NS, NT, PAR>), dim3(GRID), dim3(64 * W), W * NS * 4096, 0, x, B, in, ntiles, out); }); } while (0)
+    G(8, 4, 0, 1, 256); G(8, 4, 1, 1, 256); G(8, 4, 0, 0, 256); G(8, 4, 1, 0, 256);
+    G(8, 3, 1, 1, 256); G(8, 2, 1, 1, 256); G(4, 8, 1, 1, 256); G(4, 4, 1, 1, 256); G(4, 4, 1, 1, 512); G(4, 6, 1, 1, 512);
+    G(8, 4, 1, 1, 512); G(8, 2, 1, 1, 512); G(8, 2, 1, 1, 1024); G(4, 4, 1, 1, 1024); G(4, 2, 1, 1, 2048); G(2, 8, 1, 1, 1024);
+    G(16, 2, 1, 1, 256); G(16, 2, 0, 1, 256);
+    return 0;
+}

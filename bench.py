@@ -68,7 +68,10 @@ def main():
     ap.add_argument("--template-len", type=int, default=100)
     ap.add_argument("--mfcc-size", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None,
+                    help="BASELINE.json presets: C2 = 1 024 streams x 8 templates; C3 = 65 536 x 8 (the default workload); C4 = 65 536 streams x 64 "
+                         "templates SPLIT over the --gpus ranks (strong scaling, RCCL gather of the per-stream results); C5 = --mode mlp")
     ap.add_argument("--mode", choices=["dtw", "mlp", "stream", "resample"], default="dtw",
                     help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward; "
                          "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process); "
@@ -88,6 +91,15 @@ def main():
                     "scores every window against every template)")
     ap.add_argument("--full-scores", action="store_true", help="with --avg-gate: compare every window with every template anyway (RP_CTX_FULL_SCORES)")
     args = ap.parse_args()
+    args.total_streams = None
+    if args.config == "C2":
+        args.streams, args.templates = 1024, 8
+    elif args.config == "C3":
+        args.streams, args.templates = 65536, 8
+    elif args.config == "C4":   # strong scaling: the 65 536 streams are split over the ranks (shard by stream)
+        args.total_streams, args.templates = 65536, 64
+    elif args.config == "C5":
+        args.mode = "mlp"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
@@ -127,6 +139,10 @@ def main():
     if args.mode == "resample":
         return bench_resample(args, ra, torch, dist, dev, world, rank, local_rank)
 
+    first_stream = None
+    if args.total_streams is not None:   # strong scaling: this rank's contiguous block of the fixed stream set
+        lo, hi = sharding.shard_bounds(args.total_streams, world, rank)
+        args.streams, first_stream = hi - lo, lo
     S, N, K = args.streams, args.samples, args.mfcc_size
     lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
     T, L = len(lens), max(lens)
@@ -148,7 +164,7 @@ def main():
 
     # resident inputs / outputs
     pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
-    ctx.synth_dev(SEED, sharding.weak_first_stream(S, rank), S, N, N, pcm.data_ptr())
+    ctx.synth_dev(SEED, sharding.weak_first_stream(S, rank) if first_stream is None else first_stream, S, N, N, pcm.data_ptr())
     want_arrays = not (args.avg_gate or args.detect_only)  # the per-window arrays are defined for every window: asking for them keeps every DTW
     scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev) if want_arrays else None
     agg = torch.empty((S, n_win), dtype=torch.float32, device=dev) if want_arrays else None
@@ -163,7 +179,8 @@ def main():
         # one C call: mfcc_kernel -> dtw kernel(s) -> aggregate kernel -> scan_kernel on the launch stream
         ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), max_det,
                              scores.data_ptr() if want_arrays else None, agg.data_ptr() if want_arrays else None)
-        return sharding.gather_per_stream(n_det, world)  # final per-stream result gather (RCCL over xGMI)
+        # final per-stream result gather (RCCL over xGMI); shards of a fixed stream set may differ by one stream
+        return sharding.gather_per_stream(n_det, world) if first_stream is None else sharding.gather_ragged(n_det, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -183,7 +200,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    scorings_per_step = S * n_win * world
+    scorings_per_step = (S * world if args.total_streams is None else args.total_streams) * n_win
     value = scorings_per_step * args.steps / dt
 
     # ---- rooflines, measured live with HIP events on the launch stream (rp_ctx_timing_*: one event pair per launch)
@@ -261,16 +278,21 @@ def main():
             r_mfcc["valu_issue_frac_at_effective_clock"] = r_mfcc["valu_issue_frac"] * 2.4 / pmc["mfcc"]["effective_clock_ghz"]
     roofline = dict(r_dtw if dom == "dtw" else r_mfcc)
     roofline["kernels_ms"] = {k: round(v[0], 4) for k, v in k_ms.items()}
+    work_skipped = args.detect_only or (args.avg_gate and not args.full_scores)
     roofline["path_hbm_frac"] = (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK
     roofline["path_valu_frac_fp32"] = (value / world) * (f_mfcc * nf / n_win + f_dtw_ref) / VALU_PEAK
 
     tag = {(65536, 8): "C3", (8192, 64): "C4 (per-GPU share)", (1024, 8): "C2"}.get((S, T), "custom") if len(set(lens)) == 1 and lens[0] == 100 else "custom"
+    if args.total_streams is not None:
+        tag = "C4"
     out = {
         "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d synthetic 16 kHz f32 streams x %d templates per GPU (%g s streams, L=%s, K=%d, band 5, "
-                               "ScoreMode::%s, %s)" % (tag, S, T, N / 16000.0, lens[0] if len(set(lens)) == 1 else "/".join(map(str, lens)), K,
+        "scaling": "weak" if args.total_streams is None else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s synthetic 16 kHz f32 streams x %d templates%s (%g s streams, L=%s, K=%d, band 5, "
+                               "ScoreMode::%s, %s)" % (tag, ("%d" % S) if args.total_streams is None else ("%d" % args.total_streams), T,
+                                                       " per GPU" if args.total_streams is None else " split over %d rank(s) by stream" % world,
+                                                       N / 16000.0, lens[0] if len(set(lens)) == 1 else "/".join(map(str, lens)), K,
                                                        args.score_mode.capitalize(),
                                                        ("averaged template + avg_threshold %g%s, " % (args.avg_threshold, " (reference default)" if args.avg_threshold == 0.2 else "") +
                                                         ("every window scored anyway" if args.full_scores else "gated windows skipped"))
@@ -278,9 +300,16 @@ def main():
                                                                                                "any more are abandoned" if args.detect_only else ""))),
                    "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
                    "windows_per_stream": n_win, "template_chunks": n_chunks,
-                   "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world},
-        "roofline": roofline, "roofline_other": r_mfcc if dom == "dtw" else r_dtw,
+                   "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world,
+                   "world_size": world, "backend": (backend if world > 1 else "none (one rank)")},
+        # work is skipped by design in detect-only / gated runs: pricing the full flop count against the shorter time would
+        # print a fraction above 1, so those lines carry the kernel times only
+        "roofline": roofline if not work_skipped else None,
+        "roofline_other": (r_mfcc if dom == "dtw" else r_dtw) if not work_skipped else None,
     }
+    if work_skipped:
+        out["kernels_ms"] = roofline["kernels_ms"]
+        out["note"] = "work is skipped by design in this mode (gated windows / abandoned DTWs): no roofline fraction is quoted"
     if backend != "nccl" and world > 1:
         out["oversubscribed"] = {"devices": torch.cuda.device_count(), "backend": backend,
                                  "note": "ranks share GPUs: a launch-path dry run, not a scaling measurement"}
@@ -493,13 +522,64 @@ def bench_mlp(args, ra, torch, dist, dev, world, rank, local_rank):
     torch.cuda.synchronize()
     ms, _n = ctx.timing_read(4)
     alg = B * (dims[0] * 4 + dims[-1] * 4)
+    stream = os.environ.get("RP_MLP_STREAM", "1") != "0"
+    kname = "mlp_stream_kernel" if stream else "mlp_mfma_kernel"
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (a profiler cannot run inside the
+    # timed process); null for any other workload
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_c5_latest.json")))
+        w = tj["workload"]
+        if (w["rows"], w["features"], w["precision"]) == (B, dims[0], args.mlp_precision):
+            for name, d in tj["kernels"].items():
+                if name.startswith(kname) and "hbm_bytes_per_launch_corrected" in d:
+                    traffic = d["hbm_bytes_per_launch_corrected"]
+                    traffic_src = "profiles/pmc_c5_latest.json (committed rocprofv3 --pmc passes of this command, not this run)"
+    except Exception:
+        pass
     res = {"metric": "wakeword-model rows/sec (BASELINE config C5)", "value": B * world * args.steps / dt, "unit": "rows/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16 inputs, f32 accumulate" if args.mlp_precision == "bf16" else "f32", "data": "synthetic",
            "config": {"workload": "C5: %d rows x %d features, MLP %s" % (B, dims[0], "->".join(map(str, dims)))},
-           "roofline": {"bound": "hbm", "kernel": "mlp_mfma_kernel", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK, "traffic": None, "avg_launch_ms": ms}}
+           "roofline": {"bound": "hbm", "kernel": kname, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                        "avg_launch_ms": ms, "launches_timed": _n, "algorithmic_bytes_per_launch": alg,
+                        "note": "12 480 B of features in + 8 B of logits out per row (SURVEY.md 8d) against 8 TB/s"}}
+    # ---- CPU baseline: the oracle's restatement of the reference forward (candle's Linear -> ReLU chain, f32) on this host's cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import threading
+        from oracle import rp_oracle as orc
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                cores = max(1, min(cores, int(int(quota) / int(period))))
+        except Exception:
+            pass
+        xh = x[:4096].cpu().numpy()
+        t0 = time.perf_counter()
+        orc.mlp_forward(xh[:256], ws, bs)
+        per_row = (time.perf_counter() - t0) / 256
+        n_cpu = int(max(cores, args.cpu_seconds * cores / per_row))   # rows of the same input, cycled per thread
+        per_thread = max(1, n_cpu // cores)
+
+        def work():
+            left = per_thread
+            while left > 0:
+                n = min(left, xh.shape[0])
+                orc.mlp_forward(xh[:n], ws, bs)   # ctypes releases the GIL: the threads run on separate cores
+                left -= n
+        th = [threading.Thread(target=work) for _ in range(cores)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        secs = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": per_thread * cores / secs, "unit": "rows/s", "cores": cores, "kind": "port",
+                               "sample": "%d of the same rows through the same model in %.1f s on %d threads; C restatement of the reference "
+                                         "forward (f32 Linear -> ReLU chain), not the Rust crate / candle" % (per_thread * cores, secs, cores)}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -64,6 +64,7 @@ pub const RP_MLP_BF16: c_int = 1;
 #[repr(C)] #[derive(Clone, Copy)] pub struct rp_config { pub fmt: rp_audio_fmt, pub detector: rp_detector_config, pub filters: rp_filters_config }
 #[repr(C)] pub struct rp_detection { pub name: *const c_char, pub avg_score: f32, pub score: f32, pub n_scores: usize, pub score_names: *const *const c_char, pub scores: *const f32, pub counter: usize, pub gain: f32 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct rp_train_options { pub m_type: c_int, pub learning_rate: f32, pub epochs: usize, pub test_epochs: usize, pub mfcc_size: u16, pub seed: u64 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct rp_wakeword_spec { pub templates: *const rp_templates, pub model: *const rp_model, pub none_index: c_int, pub precision: c_int, pub threshold: f32, pub avg_threshold: f32 }
 #[repr(C)] #[derive(Clone, Copy, Default, Debug, PartialEq)] pub struct rp_batch_detection { pub stream: i32, pub frame: i32, pub window: i32, pub counter: i32, pub avg_score: f32, pub score: f32 }
 pub enum rp_detector {}
 pub enum rp_ctx {}
@@ -154,6 +155,10 @@ extern "C" {
     pub fn rp_stream_batch_samples_per_chunk(b: *const rp_stream_batch) -> usize;
     pub fn rp_stream_batch_reset(b: *mut rp_stream_batch, stream: i64) -> c_int;
     pub fn rp_stream_batch_chunks_seen(b: *const rp_stream_batch) -> usize;
+    pub fn rp_stream_batch_new_multi(ctx: *mut rp_ctx, n_wakewords: usize, wakewords: *const rp_wakeword_spec, mfcc_size: c_int,
+                                     config: *const rp_detector_config, S: usize, max_chunks_per_call: usize, out: *mut *mut rp_stream_batch) -> c_int;
+    pub fn rp_stream_batch_process_multi(b: *mut rp_stream_batch, pcm: *const c_void, fmt: c_int, n_chunks: usize, pcm_stride: usize,
+                                         det: *mut rp_batch_detection, det_wakeword: *mut i32, det_label: *mut i32, n_det: *mut i32, max_det: c_int) -> c_int;
     pub fn rp_model_new(ctx: *mut rp_ctx, n_layers: c_int, dims: *const c_int, weights: *const *const f32, biases: *const *const f32,
                         out: *mut *mut rp_model) -> c_int;
     pub fn rp_model_free(m: *mut rp_model);
@@ -530,14 +535,53 @@ impl HipContext {
 
 /// S live streams that each receive a few 30 ms chunks per call: the batched form of S `Rustpotter` handles
 /// (INTEGRATION.md §4).  Borrows the context and the templates, like the C handle does.
-pub struct StreamBatch<'a> { h: *mut rp_stream_batch, n_streams: usize, _ctx: &'a HipContext, _t: &'a Templates }
+pub struct StreamBatch<'a> { h: *mut rp_stream_batch, n_streams: usize, _ctx: &'a HipContext, _t: std::marker::PhantomData<&'a Templates> }
+/// One wakeword of a detector that holds several (`Rustpotter::add_wakeword_ref` / `add_wakeword_model`, src/detector.rs:144-150)
+pub enum BatchWakeword<'a> {
+    /// a reference with its own `threshold` / `avg_threshold` options (`WakewordRef::threshold`, `::avg_threshold`)
+    Ref { templates: &'a Templates, threshold: Option<f32>, avg_threshold: Option<f32> },
+    /// a model: index of the "none" label (if any) and whether layer 1 runs with bf16 inputs
+    Model { model: &'a Model, none_index: Option<usize>, bf16: bool },
+}
 impl<'a> Drop for StreamBatch<'a> { fn drop(&mut self) { unsafe { rp_stream_batch_free(self.h) } } }
 impl<'a> StreamBatch<'a> {
     pub fn new(ctx: &'a HipContext, t: &'a Templates, config: &DetectorConfig, n_streams: usize, max_chunks_per_call: usize) -> Result<StreamBatch<'a>, String> {
         let c: rp_detector_config = config.into();
         let mut h = std::ptr::null_mut();
         status(unsafe { rp_stream_batch_new(ctx.h, t.h, &c, n_streams, max_chunks_per_call, &mut h) })?;
-        Ok(StreamBatch { h, n_streams, _ctx: ctx, _t: t })
+        Ok(StreamBatch { h, n_streams, _ctx: ctx, _t: std::marker::PhantomData })
+    }
+    /// S detectors that each hold `wakewords` (references and / or models sharing `mfcc_size`): the best score of the wakewords
+    /// whose own thresholds pass wins a frame (`run_wakeword_detectors`, src/detector.rs:433-447)
+    pub fn new_multi(ctx: &'a HipContext, wakewords: &[BatchWakeword<'a>], mfcc_size: u16, config: &DetectorConfig, n_streams: usize,
+                     max_chunks_per_call: usize) -> Result<StreamBatch<'a>, String> {
+        let c: rp_detector_config = config.into();
+        let specs: Vec<rp_wakeword_spec> = wakewords.iter().map(|w| match w {
+            BatchWakeword::Ref { templates, threshold, avg_threshold } => rp_wakeword_spec {
+                templates: templates.h as *const rp_templates, model: std::ptr::null(), none_index: -1, precision: RP_MLP_F32,
+                threshold: threshold.unwrap_or(f32::NAN), avg_threshold: avg_threshold.unwrap_or(f32::NAN) },
+            BatchWakeword::Model { model, none_index, bf16 } => rp_wakeword_spec {
+                templates: std::ptr::null(), model: model.h as *const rp_model, none_index: none_index.map_or(-1, |i| i as c_int),
+                precision: if *bf16 { RP_MLP_BF16 } else { RP_MLP_F32 }, threshold: f32::NAN, avg_threshold: f32::NAN },
+        }).collect();
+        let mut h = std::ptr::null_mut();
+        status(unsafe { rp_stream_batch_new_multi(ctx.h, specs.len(), specs.as_ptr(), mfcc_size as c_int, &c, n_streams, max_chunks_per_call, &mut h) })?;
+        Ok(StreamBatch { h, n_streams, _ctx: ctx, _t: std::marker::PhantomData })
+    }
+    /// `process` that also tells which wakeword fired and, for a model, which label: (detections, wakeword indices, label indices or -1)
+    pub fn process_multi(&mut self, pcm: &[f32], n_chunks: usize, max_det: usize) -> Result<(Detections, Vec<Vec<i32>>, Vec<Vec<i32>>), String> {
+        let stride = n_chunks * self.samples_per_chunk();
+        assert!(pcm.len() >= self.n_streams * stride);
+        let mut det = vec![rp_batch_detection::default(); self.n_streams * max_det];
+        let (mut which, mut label) = (vec![0i32; self.n_streams * max_det], vec![0i32; self.n_streams * max_det]);
+        let mut n_det = vec![0i32; self.n_streams];
+        status(unsafe {
+            rp_stream_batch_process_multi(self.h, pcm.as_ptr() as *const c_void, RP_SAMPLE_F32, n_chunks, stride, det.as_mut_ptr(), which.as_mut_ptr(),
+                                          label.as_mut_ptr(), n_det.as_mut_ptr(), max_det as c_int)
+        })?;
+        let cut = |v: &Vec<i32>| -> Vec<Vec<i32>> { (0..self.n_streams).map(|s| v[s * max_det..s * max_det + (n_det[s].max(0) as usize).min(max_det)].to_vec()).collect() };
+        let (w, l) = (cut(&which), cut(&label));
+        Ok((split_detections(det, n_det, max_det), w, l))
     }
     /// `RustpotterConfig.fmt` of the streams (sample rate, channels); before the first `process`
     pub fn set_input(&mut self, sample_rate: usize, channels: u16) -> Result<(), String> { status(unsafe { rp_stream_batch_set_input(self.h, sample_rate, channels as c_int) }) }

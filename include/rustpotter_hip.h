@@ -391,9 +391,33 @@ int rp_stream_batch_reset(rp_stream_batch *b, long long stream);
 /* chunks consumed so far (per stream) */
 size_t rp_stream_batch_chunks_seen(const rp_stream_batch *b);
 
+/* Live-stream batches whose detectors hold SEVERAL wakewords and / or wakeword MODELS (add_wakeword*, run_wakeword_detectors:
+ * src/detector.rs:304-346,433-447): every wakeword whose own thresholds pass proposes a detection for the frame and the best
+ * score wins; the window is as long as the longest wakeword and each wakeword scores its oldest frames
+ * (wakeword_comp.rs:22-27, wakeword_nn.rs:137: truncate).  One entry per wakeword: exactly one of `templates` / `model`;
+ * threshold / avg_threshold: a reference's own Option<f32> overrides, NaN = the value in `config`; none_index / precision as in
+ * rp_batch_detect_model.  All wakewords share mfcc_size (else "Usage of wakewords with different mfcc size is not supported,
+ * ignoring wakeword").  The batch borrows the context and every templates / model handle. */
+typedef struct rp_model rp_model;
+typedef struct {
+    const rp_templates *templates;
+    const rp_model *model;
+    int none_index;
+    int precision;
+    float threshold;
+    float avg_threshold;
+} rp_wakeword_spec;
+int rp_stream_batch_new_multi(rp_ctx *ctx, size_t n_wakewords, const rp_wakeword_spec *wakewords, int mfcc_size,
+                              const rp_detector_config *config, size_t S, size_t max_chunks_per_call, rp_stream_batch **out);
+/* rp_stream_batch_process that also tells which wakeword fired: det_wakeword [S][max_det] = index into `wakewords`,
+ * det_label [S][max_det] = the label index when that wakeword is a model, else -1 (either may be NULL).  Works on every
+ * stream batch (a batch of rp_stream_batch_new reports wakeword 0, label -1).  Fed the same audio piece by piece it gives
+ * the detections of rp_batch_detect_multi / rp_batch_detect_model over the concatenation. */
+int rp_stream_batch_process_multi(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
+                                  rp_batch_detection *det, int32_t *det_wakeword, int32_t *det_label, int32_t *n_det, int max_det);
+
 /* A wakeword model (src/wakewords/wakeword_model.rs:11-18) resident on the device.  weights are
  * HOST arrays W_l [dims[l+1]][dims[l]] (candle Linear: x.W^T + b), biases b_l [dims[l+1]]; 1..3 layers. */
-typedef struct rp_model rp_model;
 int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
                  rp_model **out);
 void rp_model_free(rp_model *m);

@@ -109,7 +109,13 @@ SYMBOLS = [
     "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
     "rp_wakeword_model_train", "rp_stream_batch_set_input", "rp_stream_batch_samples_per_chunk",
     "rp_batch_detect_multi", "rp_batch_detect_model", "rp_batch_detect_sharded",
+    "rp_stream_batch_new_multi", "rp_stream_batch_process_multi",
 ]
+
+
+class _WakewordSpec(C.Structure):  # rp_wakeword_spec
+    _fields_ = [("templates", C.c_void_p), ("model", C.c_void_p), ("none_index", C.c_int), ("precision", C.c_int),
+                ("threshold", C.c_float), ("avg_threshold", C.c_float)]
 
 
 def load_library():
@@ -187,6 +193,9 @@ def load_library():
     L.rp_resampler_frame_lengths.argtypes = [C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.rp_resample_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.rp_stream_batch_new.argtypes = [vp, vp, C.POINTER(_DetectorConfig), C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.rp_stream_batch_new_multi.argtypes = [vp, C.c_size_t, C.POINTER(_WakewordSpec), C.c_int, C.POINTER(_DetectorConfig), C.c_size_t,
+                                            C.c_size_t, C.POINTER(vp)]
+    L.rp_stream_batch_process_multi.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, vp, vp, vp, vp, C.c_int]
     L.rp_stream_batch_free.argtypes = [vp]
     L.rp_stream_batch_free.restype = None
     L.rp_stream_batch_process.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, vp, vp, C.c_int, vp]
@@ -467,13 +476,30 @@ class StreamBatch:
     """S live streams fed chunk by chunk (rp_stream_batch_*): the batched form of calling
     Rustpotter::process_samples on S instances sharing one wakeword and config."""
 
-    def __init__(self, ctx, templates, detector_config, S, max_chunks_per_call=1, sample_rate=16000, channels=1):
+    def __init__(self, ctx, templates, detector_config, S, max_chunks_per_call=1, sample_rate=16000, channels=1, wakewords=None,
+                 mfcc_size=None):
+        """templates: one wakeword reference (rp_stream_batch_new).  wakewords (rp_stream_batch_new_multi): a list of
+        dicts, each {"templates": Templates} or {"model": Model, "none_index": int, "precision": "f32" | "bf16"}, optionally
+        with "threshold" / "avg_threshold" (the wakeword's own overrides); mfcc_size is then required."""
         self._L = load_library()
         self.ctx, self.templates, self.S, self.max_chunks = ctx, templates, S, max_chunks_per_call
         h = C.c_void_p()
         c = detector_config._c()
-        if self._L.rp_stream_batch_new(ctx._h, templates._h, C.byref(c), S, max_chunks_per_call, C.byref(h)) < 0:
-            raise _err()
+        if wakewords is None:
+            if self._L.rp_stream_batch_new(ctx._h, templates._h, C.byref(c), S, max_chunks_per_call, C.byref(h)) < 0:
+                raise _err()
+        else:
+            specs = (_WakewordSpec * len(wakewords))()
+            self._keep = list(wakewords)   # the batch borrows the handles
+            for sp, w in zip(specs, wakewords):
+                sp.templates = w["templates"]._h if w.get("templates") is not None else None
+                sp.model = w["model"]._h if w.get("model") is not None else None
+                sp.none_index = w.get("none_index", -1)
+                sp.precision = {"f32": 0, "bf16": 1}[w.get("precision", "f32")]
+                sp.threshold = float("nan") if w.get("threshold") is None else w["threshold"]
+                sp.avg_threshold = float("nan") if w.get("avg_threshold") is None else w["avg_threshold"]
+            if self._L.rp_stream_batch_new_multi(ctx._h, len(wakewords), specs, mfcc_size, C.byref(c), S, max_chunks_per_call, C.byref(h)) < 0:
+                raise _err()
         self._h = h
         if (sample_rate, channels) != (16000, 1) and self._L.rp_stream_batch_set_input(h, sample_rate, channels) < 0:
             raise _err()
@@ -512,6 +538,28 @@ class StreamBatch:
             raise _err()
         return (det, n_det, agg) if want_agg else (det, n_det)
 
+    def process_multi(self, pcm, max_det=4, n_chunks=None):
+        """rp_stream_batch_process_multi -> (det, det_wakeword, det_label, n_det)"""
+        import numpy as np
+        assert self.ctx.host
+        pcm = np.ascontiguousarray(pcm)
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(pcm.dtype)
+        if fmt is None:
+            pcm, fmt = np.ascontiguousarray(pcm, np.float32), 3
+        S, N = pcm.shape
+        spc = self.samples_per_chunk
+        if S != self.S or (n_chunks is None and N % spc) or (n_chunks is not None and n_chunks * spc > N):
+            raise ValueError("pcm must be [S][n_chunks*samples_per_chunk]")
+        nc = N // spc if n_chunks is None else n_chunks
+        det = np.zeros((S, max_det), dtype=DET_DTYPE)
+        dww = np.zeros((S, max_det), np.int32)
+        dlab = np.zeros((S, max_det), np.int32)
+        n_det = np.zeros(S, np.int32)
+        if self._L.rp_stream_batch_process_multi(self._h, pcm.ctypes.data, fmt, nc, N, det.ctypes.data, dww.ctypes.data, dlab.ctypes.data,
+                                                 n_det.ctypes.data, max_det) < 0:
+            raise _err()
+        return det, dww, dlab, n_det
+
     def process_dev(self, pcm_ptr, fmt, n_chunks, stride, det_ptr, n_det_ptr, max_det, agg_ptr=None):
         if self._L.rp_stream_batch_process(self._h, pcm_ptr, fmt, n_chunks, stride, det_ptr, n_det_ptr, max_det, agg_ptr) < 0:
             raise _err()
@@ -529,10 +577,15 @@ def batch_detect_sharded(ctxs, templates, pcms, detector_config, max_det=8):
     n = len(ctxs)
     assert n == len(templates) == len(pcms) and all(c.host for c in ctxs)
     arrs = [np.ascontiguousarray(p) for p in pcms]
+    # the C call reads every shard as S_g * N samples of ONE format: refuse shards of another length or sample type
+    if any(a.ndim != 2 for a in arrs):
+        raise ValueError("batch_detect_sharded: every shard must be a 2-D array [streams][samples]")
+    N = arrs[0].shape[1]
+    if any(a.shape[1] != N or a.dtype != arrs[0].dtype for a in arrs):
+        raise ValueError("batch_detect_sharded: all shards must hold streams of the same length and sample type")
     fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(arrs[0].dtype)
     if fmt is None:
         arrs, fmt = [np.ascontiguousarray(a, np.float32) for a in arrs], 3
-    N = arrs[0].shape[1]
     S = (C.c_size_t * n)(*[a.shape[0] for a in arrs])
     total = sum(a.shape[0] for a in arrs)
     det = np.zeros((total, max_det), dtype=DET_DTYPE)
@@ -550,6 +603,10 @@ def batch_detect_sharded_dev(ctxs, templates, pcm_ptrs, S_list, N, stride, detec
     """Device-pointer form: pcm_ptrs[g] on ctxs[g]'s device, det / n_det gathered on ctxs[0]'s device."""
     L = load_library()
     n = len(ctxs)
+    if not (n == len(templates) == len(pcm_ptrs) == len(S_list)):
+        raise ValueError("batch_detect_sharded_dev: one context, template set, PCM pointer and stream count per shard")
+    if any(x.host for x in ctxs):
+        raise ValueError("batch_detect_sharded_dev: the contexts must take device pointers (host_pointers=False)")
     c = detector_config._c()
     hc = (C.c_void_p * n)(*[x._h for x in ctxs])
     ht = (C.c_void_p * n)(*[x._h for x in templates])

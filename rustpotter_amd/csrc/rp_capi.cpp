@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <thread>
 
 #include "rp_host.h"
@@ -20,9 +21,21 @@ struct rp_detector {
 struct rp_ctx { std::unique_ptr<Ctx> impl; };
 struct rp_templates { std::unique_ptr<Templates> impl; };
 struct rp_model { std::unique_ptr<Model> impl; };
+// one wakeword of a live-stream batch that holds several (rp_stream_batch_new_multi): a reference or a model
+struct StreamWakeword {
+    const Templates *t = nullptr;
+    const Model *m = nullptr;
+    int none_index = -1, precision = 0;
+    float threshold = 0.f, avg_threshold = 0.f;   // the wakeword's own values (the config's where it has none)
+    DevBuf agg, avg, label;                       // [S][frames per call] of this wakeword
+};
+
 struct rp_stream_batch {
     Ctx *c = nullptr;
-    const Templates *t = nullptr;
+    const Templates *t = nullptr;                 // the one wakeword reference of rp_stream_batch_new; nullptr with `ww`
+    std::vector<std::unique_ptr<StreamWakeword>> ww;  // rp_stream_batch_new_multi: 1..8 wakewords
+    int K = 0, max_len = 0, Tmax = 1;             // mfcc_size, max_mfcc_frames (longest wakeword), most templates of a reference
+    DevBuf det_ww, det_label, logits, mean, xrows, xs2;
     rp_detector_config cfg{};
     size_t S = 0, max_chunks = 0, chunks_seen = 0, hist_frames = 0;
     bool poisoned = false;   // a launch failed after part of the persistent state had advanced
@@ -490,6 +503,8 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         // per-window score arrays (those are defined for every window) and RP_CTX_FULL_SCORES is not set.
         const bool detect_only = !scores && !agg && !(c->flags & RP_CTX_FULL_SCORES);
         const bool gated = do_avg && detect_only && dtw_gate_supported(td, config->band_size, rows);
+        // template sets only the generic kernel serves: the same gate at wave granularity (launch_dtw_generic_gated)
+        const bool gated_generic = do_avg && detect_only && !gated && rows > 0 && dtw_uses_generic(td, config->band_size, S, n_win);
         // detect-only calls in ScoreMode::Max may also stop DTWs that can no longer reach `threshold` (rp_kernels.h, launch_dtw)
         const float abandon = (detect_only && config->score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(config->threshold, config->score_ref) : __builtin_inff();
         if (gated && !c->ws_list.reserve((rows + 1) * sizeof(uint32_t) + 16)) return -1;
@@ -508,13 +523,25 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
             uint32_t *lst = c->ws_list.as<uint32_t>();
             ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, config->avg_threshold,
                                          ds, da, lst + 1, lst, false, abandon), "dtw kernels (gated)");
+        } else if (gated_generic) {
+            ok = hip_ok(launch_dtw_generic_gated(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref,
+                                                 config->avg_threshold, ds, da), "dtw_generic_kernel (gated)");
         } else {
             ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, false, abandon), "dtw kernel");
         }
         c->time_end();
         if (!ok) return -1;
+        // the aggregate pass also tells the scan which streams can fire at all (a flag per stream) and writes 0 for the
+        // windows the averaged-template gate rejected (their `scores` rows were never written)
+        AggExtra ax;
+        if (n_win) {
+            if (!c->ws_hot.reserve(S * sizeof(uint32_t) + 16)) return -1;
+            if (!hip_ok(hipMemsetAsync(c->ws_hot.p, 0, S * sizeof(uint32_t), c->stream), "hipMemsetAsync(hot)")) return -1;
+            ax.hot = c->ws_hot.as<uint32_t>(); ax.threshold = config->threshold; ax.n_win = n_win;
+            if (gated || gated_generic) { ax.gate_avg = da; ax.gate_threshold = config->avg_threshold; }  // only rows the gate really skipped
+        }
         c->time_begin(kKernelAggregate);
-        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg), "aggregate_kernel");
+        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg, ax), "aggregate_kernel");
         c->time_end();
         if (!ok) return -1;
         ScanConfig sc;
@@ -528,7 +555,7 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
             if (!hip_ok(launch_vad_value(c->stream, dm, S * nf, td.K, dv), "vad_value_kernel")) return -1;
         }
         c->time_begin(kKernelScan);
-        ok = hip_ok(launch_scan(c->stream, dg, da, dv, vad_mode_value(config->vad_mode), S, nf, sc, dd, dn, max_det), "scan_kernel");
+        ok = hip_ok(launch_scan(c->stream, dg, da, dv, vad_mode_value(config->vad_mode), S, nf, sc, dd, dn, max_det, ax.hot), "scan_kernel");
         c->time_end();
         if (!ok) return -1;
         if (gather.on) {
@@ -577,19 +604,41 @@ int rp_batch_detect_sharded(rp_ctx *const *ctxs, const rp_templates *const *t, i
         // one host thread per shard drives that shard's device and stream; the shards share nothing but read-only inputs
         std::vector<int> status((size_t)n_shards, 0);
         std::vector<std::string> errs((size_t)n_shards);
-        auto run = [&](int g) {
-            GatherTo mine = to;
-            mine.stream_base = (int)first[g];
-            status[g] = S[g] ? batch_detect_impl(ctxs[g], pcm[g], fmt, S[g], n_samples, pcm_stride, t[g], config, det, n_det, max_det, nullptr,
-                                                 nullptr, mine) : 0;
-            if (status[g] != 0) errs[g] = last_error();  // the error text is thread-local: hand it to the caller's thread
+        // device-resident gather: let every other device write into ctxs[0]'s device directly (xGMI) where the node allows it;
+        // without peer access hipMemcpyPeerAsync still works (staged by the runtime), so a refusal here is not an error
+        if (!to.host)
+            for (int g = 1; g < n_shards; ++g) {
+                const int dev = ctxs[g]->impl->device;
+                int can = 0;
+                if (dev != to.device && hipDeviceCanAccessPeer(&can, dev, to.device) == hipSuccess && can && hipSetDevice(dev) == hipSuccess) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(to.device, 0);
+                    if (pe != hipSuccess) (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled or a refusal: both fine
+                }
+            }
+        auto run = [&](int g) noexcept {
+            try {
+                GatherTo mine = to;
+                mine.stream_base = (int)first[g];
+                status[g] = S[g] ? batch_detect_impl(ctxs[g], pcm[g], fmt, S[g], n_samples, pcm_stride, t[g], config, det, n_det, max_det, nullptr,
+                                                     nullptr, mine) : 0;
+                if (status[g] != 0) errs[g] = last_error();  // the error text is thread-local: hand it to the caller's thread
+            } catch (...) {  // e.g. bad_alloc while copying the error text: never let an exception leave a thread
+                status[g] = -1;
+            }
         };
+        // shard 0 runs on the caller's thread; if the process cannot start another thread the remaining shards run here too
         std::vector<std::thread> th;
-        for (int g = 1; g < n_shards; ++g) th.emplace_back(run, g);
+        th.reserve((size_t)n_shards);
+        int on_threads = 1;  // shards [1, on_threads) have a thread of their own
+        for (int g = 1; g < n_shards; ++g) {
+            try { th.emplace_back(run, g); } catch (const std::system_error &) { break; }
+            on_threads = g + 1;
+        }
         run(0);
+        for (int g = on_threads; g < n_shards; ++g) run(g);
         for (auto &x : th) x.join();
         for (int g = 0; g < n_shards; ++g)
-            if (status[g] != 0) { set_last_error("shard " + std::to_string(g) + ": " + errs[g]); return -1; }
+            if (status[g] != 0) { set_last_error("shard " + std::to_string(g) + ": " + (errs[g].empty() ? std::string("failed") : errs[g])); return -1; }
         return 0;
     });
 }
@@ -660,8 +709,10 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                 }
                 c->time_end();
                 if (!ok) return -1;
+                AggExtra ax;   // windows the gate rejected were never scored: their aggregate is 0, not what `scores` held
+                if (gated) { ax.gate_avg = da; ax.gate_threshold = athr; }
                 c->time_begin(kKernelAggregate);
-                ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg), "aggregate_kernel");
+                ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg, ax), "aggregate_kernel");
                 c->time_end();
                 if (!ok) return -1;
             }
@@ -737,12 +788,15 @@ int rp_resample_batch(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, int ch
 // buffers of a fresh batch, sized for the current input frame length (30 ms frames: 3 MFCC frames each, 40 ms: 4)
 static bool stream_batch_alloc(rp_stream_batch *b) {
     Ctx *c = b->c;
-    const TemplatesDev &td = b->t->dev;
+    struct { int K, T; } td{b->K, b->Tmax};
     const size_t S = b->S, fpf = b->fpf();
     b->cap = b->hist_frames + fpf * b->max_chunks * 8;  // compaction every 8 full-size calls
     const size_t pitch = b->cap, rows = S * fpf * b->max_chunks;
     const size_t slack = 64 * (size_t)td.K * sizeof(float);  // the DTW band reads up to band_size frames past a row
     const size_t pcm_bytes = S * (480 + b->max_chunks * b->out_len) * sizeof(float);
+    for (auto &w : b->ww)
+        if (!w->agg.reserve(rows * sizeof(float) + 16) || !w->avg.reserve(rows * sizeof(float) + 16) || !w->label.reserve(rows * sizeof(int32_t) + 16))
+            return false;
     if (!b->pcm[0].reserve(pcm_bytes) || !b->pcm[1].reserve(pcm_bytes) || !b->mfcc[0].reserve(S * pitch * td.K * sizeof(float) + slack) ||
         !b->mfcc[1].reserve(S * pitch * td.K * sizeof(float) + slack) || !b->state.reserve(S * stream_state_bytes()) ||
         !b->scores.reserve(rows * td.T * sizeof(float) + 16) || !b->agg.reserve(rows * sizeof(float) + 16) ||
@@ -773,6 +827,7 @@ int rp_stream_batch_new(rp_ctx *ctx, const rp_templates *t, const rp_detector_co
         if (!c->tables_for(td.K)) return -1;
         std::unique_ptr<rp_stream_batch> b(new rp_stream_batch());
         b->c = c; b->t = t->impl.get(); b->cfg = *config; b->S = S; b->max_chunks = max_chunks_per_call;
+        b->K = td.K; b->max_len = td.max_len; b->Tmax = td.T;
         b->hist_frames = (size_t)td.max_len - 1;
         if (!stream_batch_alloc(b.get())) return -1;
         *out = b.release();
@@ -823,7 +878,10 @@ int rp_stream_batch_reset(rp_stream_batch *b, long long stream) {
 }
 
 static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
-                                     rp_batch_detection *det, int32_t *n_det, int max_det, float *agg, bool *state_touched);
+                                     rp_batch_detection *det, int32_t *n_det, int max_det, float *agg, int32_t *det_wakeword,
+                                     int32_t *det_label, bool *state_touched);
+static int stream_batch_score_multi(rp_stream_batch *b, Staged &sg, const float *now, size_t fill, size_t n_new, BatchDetection *dd,
+                                    int32_t *dn, int max_det, int32_t *det_wakeword, int32_t *det_label);
 
 int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
                             rp_batch_detection *det, int32_t *n_det, int max_det, float *agg) {
@@ -833,13 +891,24 @@ int rp_stream_batch_process(rp_stream_batch *b, const void *pcm, rp_sample_forma
     // a failure after the first such step cannot be rolled back, so the batch refuses further work instead of pairing
     // the wrong history with later chunks.
     bool touched = false;
-    const int r = stream_batch_process_impl(b, pcm, fmt, n_chunks, pcm_stride, det, n_det, max_det, agg, &touched);
+    const int r = stream_batch_process_impl(b, pcm, fmt, n_chunks, pcm_stride, det, n_det, max_det, agg, nullptr, nullptr, &touched);
+    if (r != 0 && touched) b->poisoned = true;
+    return r;
+}
+
+int rp_stream_batch_process_multi(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
+                                  rp_batch_detection *det, int32_t *det_wakeword, int32_t *det_label, int32_t *n_det, int max_det) {
+    if (!b) { set_last_error("null handle"); return -1; }
+    if (b->poisoned) { set_last_error("stream batch is in a failed state (an earlier call failed half way); free it and create a new one"); return -1; }
+    bool touched = false;
+    const int r = stream_batch_process_impl(b, pcm, fmt, n_chunks, pcm_stride, det, n_det, max_det, nullptr, det_wakeword, det_label, &touched);
     if (r != 0 && touched) b->poisoned = true;
     return r;
 }
 
 static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sample_format fmt, size_t n_chunks, size_t pcm_stride,
-                                     rp_batch_detection *det, int32_t *n_det, int max_det, float *agg, bool *state_touched) {
+                                     rp_batch_detection *det, int32_t *n_det, int max_det, float *agg, int32_t *det_wakeword,
+                                     int32_t *det_label, bool *state_touched) {
     return guarded([&]() -> int {
         Ctx *c = b->c;
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
@@ -847,7 +916,11 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
         const size_t in_chunk = b->in_len * (size_t)b->channels;
         if (pcm_stride < n_chunks * in_chunk) { set_last_error("pcm_stride smaller than n_chunks * samples per chunk"); return -1; }
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
-        const TemplatesDev &td = b->t->dev;
+        const bool multi = !b->ww.empty();
+        if (multi && agg) { set_last_error("rp_stream_batch_process: a batch of several wakewords has no single aggregate per window"); return -1; }
+        static const TemplatesDev no_templates{};
+        const TemplatesDev &td_one = multi ? no_templates : b->t->dev;
+        struct { int K, T, max_len, has_avg; } td{b->K, td_one.T, b->max_len, td_one.has_avg};
         const MfccTablesDev *tb = c->tables_for(td.K);
         if (!tb) return -1;
         const size_t fo = b->out_len, new_len = n_chunks * fo;  // encoded samples this call adds to every stream
@@ -922,23 +995,32 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
             if (!ok) return -1;
         }
         b->fill += n_new;
+        if (multi) {
+            if (stream_batch_score_multi(b, sg, now, fill, n_new, dd, dn, max_det, det_wakeword, det_label) != 0) return -1;
+            b->chunks_seen += n_chunks;
+            if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
+            return sg.finish() ? 0 : -1;
+        }
         float *ds = b->scores.as<float>(), *dg = b->agg.as<float>(), *da = do_avg ? b->avg.as<float>() : nullptr;
         // the averaged-template gate as a skip (wakeword_comp.rs:85-93), unless the caller wants every window's aggregate
         const bool detect_only = !agg && !(c->flags & RP_CTX_FULL_SCORES);
-        const bool gated = do_avg && detect_only && dtw_gate_supported(td, b->cfg.band_size, rows);
+        // (a single live stream keeps launch_dtw's one-wave-per-DTW kernel: the gated path's lane-serial passes cost it latency)
+        const bool gated = do_avg && detect_only && dtw_gate_supported(td_one, b->cfg.band_size, rows) && !(S == 1 && n_new <= 8);
         const float abandon = (detect_only && b->cfg.score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(b->cfg.threshold, b->cfg.score_ref) : __builtin_inff();
         c->time_begin(kKernelDtw);
         if (gated) {
             uint32_t *lst = b->list.as<uint32_t>();
-            ok = hip_ok(launch_dtw_gated(c->stream, td, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, b->cfg.avg_threshold,
+            ok = hip_ok(launch_dtw_gated(c->stream, td_one, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, b->cfg.avg_threshold,
                                          ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
         } else {
-            ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
+            ok = hip_ok(launch_dtw(c->stream, td_one, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
         }
         c->time_end();
         if (!ok) return -1;
+        AggExtra ax;   // windows the gate rejected were never scored: their aggregate is 0, not what `scores` held
+        if (gated) { ax.gate_avg = da; ax.gate_threshold = b->cfg.avg_threshold; }
         c->time_begin(kKernelAggregate);
-        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)b->cfg.score_mode, dg), "aggregate_kernel");
+        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)b->cfg.score_mode, dg, ax), "aggregate_kernel");
         c->time_end();
         if (!ok) return -1;
         float *dv = nullptr;
@@ -956,12 +1038,163 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
         if (!ok) return -1;
         b->chunks_seen += n_chunks;
         if (!sg.back(det, dd, S * (size_t)max_det * sizeof(BatchDetection)) || !sg.back(n_det, dn, S * sizeof(int32_t))) return -1;
+        if (det_wakeword || det_label) {   // one wakeword reference: wakeword 0, no label
+            const size_t nb = S * (size_t)max_det * sizeof(int32_t);
+            if (sg.host) { if (det_wakeword) std::memset(det_wakeword, 0, nb); if (det_label) std::memset(det_label, 0xff, nb); }
+            else if ((det_wakeword && !hip_ok(hipMemsetAsync(det_wakeword, 0, nb, c->stream), "hipMemsetAsync")) ||
+                     (det_label && !hip_ok(hipMemsetAsync(det_label, 0xff, nb, c->stream), "hipMemsetAsync"))) return -1;
+        }
         if (agg) {
             if (sg.host) { if (!sg.back(agg, dg, rows * sizeof(float))) return -1; }
             else if (!hip_ok(hipMemcpyAsync(agg, dg, rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync(D2D)")) return -1;
         }
         return sg.finish() ? 0 : -1;
     });
+}
+
+static hipError_t mlp_rows_mfma(Ctx *c, const Model &m, const float *dx, size_t B, int precision, float *out);
+
+// ---- live-stream batches that hold several wakewords and / or a wakeword model (src/detector.rs:304-346,433-447)
+int rp_stream_batch_new_multi(rp_ctx *ctx, size_t n_wakewords, const rp_wakeword_spec *wakewords, int mfcc_size,
+                              const rp_detector_config *config, size_t S, size_t max_chunks_per_call, rp_stream_batch **out) {
+    return guarded([&]() -> int {
+        if (!ctx) { set_last_error("null handle"); return -1; }
+        if (!config || !out || !wakewords) { set_last_error("null argument"); return -1; }
+        *out = nullptr;
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        if (S == 0 || max_chunks_per_call == 0) { set_last_error("rp_stream_batch_new: S and max_chunks_per_call must be >= 1"); return -1; }
+        if (n_wakewords < 1 || n_wakewords > (size_t)kScanMaxWakewords) { set_last_error("rp_stream_batch_new_multi: 1..8 wakewords"); return -1; }
+        if (mfcc_size < 1) { set_last_error("rp_stream_batch_new_multi: mfcc_size must be >= 1"); return -1; }
+        std::unique_ptr<rp_stream_batch> b(new rp_stream_batch());
+        b->c = c; b->t = nullptr; b->cfg = *config; b->S = S; b->max_chunks = max_chunks_per_call;
+        b->K = mfcc_size; b->max_len = 0; b->Tmax = 1;
+        for (size_t j = 0; j < n_wakewords; ++j) {
+            const rp_wakeword_spec &w = wakewords[j];
+            if ((w.templates != nullptr) == (w.model != nullptr)) { set_last_error("rp_stream_batch_new_multi: every wakeword is a reference OR a model"); return -1; }
+            std::unique_ptr<StreamWakeword> e(new StreamWakeword());
+            e->threshold = std::isnan(w.threshold) ? config->threshold : w.threshold;
+            e->avg_threshold = std::isnan(w.avg_threshold) ? config->avg_threshold : w.avg_threshold;
+            if (w.templates) {
+                e->t = w.templates->impl.get();
+                if (e->t->ctx != c) { set_last_error("rp_stream_batch_new_multi: the wakewords must have been created on this context"); return -1; }
+                // add_wakeword, src/detector.rs:316-319
+                if (e->t->dev.K != mfcc_size) { set_last_error("Usage of wakewords with different mfcc size is not supported, ignoring wakeword"); return -1; }
+                b->max_len = std::max(b->max_len, e->t->dev.max_len);
+                b->Tmax = std::max(b->Tmax, e->t->dev.T);
+            } else {
+                e->m = w.model->impl.get();
+                if (e->m->ctx != c) { set_last_error("rp_stream_batch_new_multi: the wakewords must have been created on this context"); return -1; }
+                const int nl = (int)e->m->dims.size() - 1;
+                if (e->m->dims[0] % mfcc_size != 0) { set_last_error("Usage of wakewords with different mfcc size is not supported, ignoring wakeword"); return -1; }
+                if (w.none_index >= e->m->dims[nl]) { set_last_error("none_index out of range"); return -1; }
+                if (w.precision != RP_MLP_F32 && w.precision != RP_MLP_BF16) { set_last_error("unknown MLP precision"); return -1; }
+                if (!e->m->mfma_ok && w.precision == RP_MLP_BF16) { set_last_error("this layer-1 shape has no bf16 MFMA kernel"); return -1; }
+                e->none_index = w.none_index; e->precision = w.precision;
+                b->max_len = std::max(b->max_len, e->m->dims[0] / mfcc_size);
+            }
+            b->ww.push_back(std::move(e));
+        }
+        if (!c->tables_for(b->K)) return -1;
+        b->hist_frames = (size_t)b->max_len - 1;   // on_wakeword_change, src/detector.rs:328-334: the longest wakeword sets the window
+        if (!stream_batch_alloc(b.get())) return -1;
+        *out = b.release();
+        return 0;
+    });
+}
+
+// scores of this call's n_new windows per stream for every wakeword, then the state machine over all of them
+static int stream_batch_score_multi(rp_stream_batch *b, Staged &sg, const float *now, size_t fill, size_t n_new, BatchDetection *dd,
+                                    int32_t *dn, int max_det, int32_t *det_wakeword, int32_t *det_label) {
+    Ctx *c = b->c;
+    const size_t S = b->S, hist = b->hist_frames, pitch = b->cap, rows = S * n_new;
+    const int K = b->K;
+    const bool detect_only = !(c->flags & RP_CTX_FULL_SCORES);
+    ScanWakewords sw{};
+    sw.n = (int)b->ww.size();
+    bool ok = true;
+    for (size_t j = 0; j < b->ww.size(); ++j) {
+        StreamWakeword &w = *b->ww[j];
+        float *dg = w.agg.as<float>();
+        if (w.t) {
+            const TemplatesDev &td = w.t->dev;
+            const bool do_avg = td.has_avg && w.avg_threshold != 0.f;  // wakeword_comp.rs:85
+            float *da = do_avg ? w.avg.as<float>() : nullptr, *ds = b->scores.as<float>();
+            // the window starts where the longest wakeword's does and this one scores its oldest frames (wakeword_comp.rs:22-27)
+            const bool gated = do_avg && detect_only && dtw_gate_supported(td, b->cfg.band_size, rows);
+            const float abandon = (detect_only && b->cfg.score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(w.threshold, b->cfg.score_ref) : __builtin_inff();
+            c->time_begin(kKernelDtw);
+            if (gated) {
+                uint32_t *lst = b->list.as<uint32_t>();
+                ok = hip_ok(launch_dtw_gated(c->stream, td, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, w.avg_threshold,
+                                             ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
+            } else {
+                ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
+            }
+            c->time_end();
+            if (!ok) return -1;
+            AggExtra ax;
+            if (gated) { ax.gate_avg = da; ax.gate_threshold = w.avg_threshold; }
+            c->time_begin(kKernelAggregate);
+            ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)b->cfg.score_mode, dg, ax), "aggregate_kernel");
+            c->time_end();
+            if (!ok) return -1;
+            sw.agg[j] = dg; sw.avg[j] = da; sw.threshold[j] = w.threshold; sw.avg_threshold[j] = w.avg_threshold; sw.label[j] = nullptr;
+        } else {
+            const Model &m = *w.m;
+            const int nl_layers = (int)m.dims.size() - 1, L = m.dims[0] / K, n_labels = m.dims[nl_layers];
+            if (!b->logits.reserve(rows * (size_t)n_labels * sizeof(float) + 16)) return -1;
+            float *dlog = b->logits.as<float>();
+            const float *first = now + (fill - hist) * K;   // window i of stream s starts at frame s * pitch + i from here
+            const float *wsum = (m.mfma_ok && K % 4 == 0) ? const_cast<Model &>(m).wsum_for(K) : nullptr;  // as rp_batch_detect_model
+            if (wsum) {
+                if (!b->mean.reserve(rows * (size_t)K * sizeof(float) + 16)) return -1;
+                float *dmean = b->mean.as<float>();
+                if (!hip_ok(launch_window_means(c->stream, first, S, pitch, n_new, L, K, dmean), "window_means_kernel")) return -1;
+                c->time_begin(kKernelMlp);
+                ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, first, S, pitch, n_new, K, dmean, wsum, dlog, pitch), "mlp_mfma_kernel");
+                c->time_end();
+                if (!ok) return -1;
+            } else {
+                int maxd = 0;
+                for (int d : m.dims) maxd = std::max(maxd, d);
+                if (!b->xrows.reserve(rows * (size_t)m.dims[0] * sizeof(float) + 64)) return -1;
+                if (!m.mfma_ok && !b->xs2.reserve(2 * rows * (size_t)maxd * sizeof(float) + 16)) return -1;
+                float *dx = b->xrows.as<float>();
+                if (!hip_ok(launch_normalize_windows_batch(c->stream, first, pitch, n_new, 0, rows, L, K, dx), "normalize_windows_kernel")) return -1;
+                c->time_begin(kKernelMlp);
+                if (m.mfma_ok) ok = hip_ok(mlp_rows_mfma(c, m, dx, rows, w.precision, dlog), "mlp_mfma_kernel");
+                else ok = hip_ok(launch_mlp(c->stream, dx, rows, nl_layers, m.dims.data(), m.W.data(), m.B.data(), b->xs2.as<float>(),
+                                            b->xs2.as<float>() + rows * (size_t)maxd, dlog), "mlp_layer_kernel");
+                c->time_end();
+                if (!ok) return -1;
+            }
+            float *da = w.avg.as<float>();
+            int32_t *dlab = w.label.as<int32_t>();
+            if (!hip_ok(launch_nn_score(c->stream, dlog, rows, n_labels, w.none_index, b->cfg.score_ref * 10.f, w.avg_threshold != 0.f ? 1 : 0,
+                                        w.threshold, w.avg_threshold, dg, da, dlab), "nn_score_kernel")) return -1;
+            sw.agg[j] = dg; sw.avg[j] = da; sw.label[j] = dlab;
+            sw.threshold[j] = -1.f; sw.avg_threshold[j] = -1.f;  // the gates were applied by nn_score_kernel (>=, not >)
+        }
+    }
+    float *dv = nullptr;
+    if (b->cfg.vad_mode != RP_VAD_NONE) {
+        dv = b->vad.as<float>();
+        if (!hip_ok(launch_vad_value_rows(c->stream, now + fill * K, S, n_new, pitch, K, dv), "vad_value_kernel")) return -1;
+    }
+    ScanConfig sc;
+    sc.threshold = b->cfg.threshold; sc.avg_threshold = b->cfg.avg_threshold; sc.min_scores = (int)b->cfg.min_scores;
+    sc.eager = b->cfg.eager ? 1 : 0; sc.max_len = b->max_len; sc.avg_enabled = 0; sc.fpf = (int)b->fpf();
+    int32_t *dw = det_wakeword ? static_cast<int32_t *>(sg.out(det_wakeword, S * (size_t)max_det * sizeof(int32_t), b->det_ww)) : nullptr;
+    int32_t *dl = det_label ? static_cast<int32_t *>(sg.out(det_label, S * (size_t)max_det * sizeof(int32_t), b->det_label)) : nullptr;
+    if ((det_wakeword && !dw) || (det_label && !dl)) return -1;
+    c->time_begin(kKernelScan);
+    ok = hip_ok(launch_scan_stream_multi(c->stream, sw, dv, vad_mode_value(b->cfg.vad_mode), S, (long long)b->fpf() * (long long)b->chunks_seen - 3,
+                                         (int)n_new, sc, b->state.p, dd, dw, dl, dn, max_det), "scan_stream_kernel");
+    c->time_end();
+    if (!ok) return -1;
+    if ((dw && !sg.back(det_wakeword, dw, S * (size_t)max_det * sizeof(int32_t))) || (dl && !sg.back(det_label, dl, S * (size_t)max_det * sizeof(int32_t)))) return -1;
+    return 0;
 }
 
 int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases,
@@ -979,6 +1212,19 @@ int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const 
 }
 void rp_model_free(rp_model *m) { delete m; }
 
+// Dense rows through layer 1 on the matrix cores: the line-streaming kernel (rp_mlp_stream.hip) for bf16 inputs, where the
+// pass is bound by the HBM stream (0.132 against 0.155 ms at BASELINE config C5); the register-fragment kernel for exact f32,
+// where the f32 matrix rate binds and its 24 waves per CU overlap better (0.198 against 0.207 ms).  RP_MLP_STREAM=0 / 2 force
+// the latter / the former for both precisions (benchmarks, tests).
+static hipError_t mlp_rows_mfma(Ctx *c, const Model &m, const float *dx, size_t B, int precision, float *out) {
+    const char *e = std::getenv("RP_MLP_STREAM");
+    const int mode = e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1;
+    MlpStreamPlan plan;
+    if ((mode == 2 || (mode == 1 && precision == RP_MLP_BF16)) && const_cast<Model &>(m).stream_plan(dx, B, precision, &plan))
+        return launch_mlp_stream(c->stream, m.dev, plan, dx, B, precision, out, c->n_cu);
+    return launch_mlp_mfma(c->stream, m.dev, dx, B, precision, out);
+}
+
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits) {
     return guarded([&]() -> int {
         if (!ctx || !model) { set_last_error("null handle"); return -1; }
@@ -994,7 +1240,7 @@ int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, siz
         bool ok;
         if (m.mfma_ok) {
             c->time_begin(kKernelMlp);
-            ok = hip_ok(launch_mlp_mfma(c->stream, m.dev, dx, B, precision, dl), "mlp_mfma_kernel");
+            ok = hip_ok(mlp_rows_mfma(c, m, dx, B, precision, dl), "mlp_mfma_kernel");
             c->time_end();
         } else {
             if (precision == RP_MLP_BF16) { set_last_error("this layer-1 shape has no bf16 MFMA kernel"); return -1; }
@@ -1073,7 +1319,7 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                 const size_t nr = std::min(slab, rows - r0);
                 if (!hip_ok(launch_normalize_windows_batch(c->stream, dm, nf, n_win, r0, nr, L, K, dx), "normalize_windows_kernel")) return -1;
                 c->time_begin(kKernelMlp);
-                if (m.mfma_ok) ok = hip_ok(launch_mlp_mfma(c->stream, m.dev, dx, nr, precision, dlog + r0 * n_labels), "mlp_mfma_kernel");
+                if (m.mfma_ok) ok = hip_ok(mlp_rows_mfma(c, m, dx, nr, precision, dlog + r0 * n_labels), "mlp_mfma_kernel");
                 else ok = hip_ok(launch_mlp(c->stream, dx, nr, nl_layers, m.dims.data(), m.W.data(), m.B.data(), c->ws_gain.as<float>(),
                                             c->ws_gain.as<float>() + slab * (size_t)maxd, dlog + r0 * n_labels), "mlp_layer_kernel");
                 c->time_end();

@@ -31,7 +31,11 @@ const std::string &last_error() { return g_last_error; }
 
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
-    set_last_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+    if (e == hipErrorMemoryAllocation && std::strncmp(what, "dtw", 3) == 0)   // launch_dtw: the band and one template length of frames
+        set_last_error(std::string("HIP error in ") + what + ": band_size and template length need more than the 160 KB of LDS a compute "
+                       "unit has (lower band_size or shorten the wakeword's templates)");
+    else
+        set_last_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
     (void)hipGetLastError();  // the runtime keeps the code as its "last error": clear it, or the next kernel launch
                               // (checked with hipGetLastError) would report this failure again
     return false;
@@ -47,6 +51,20 @@ bool DevBuf::reserve(size_t bytes) {
     return true;
 }
 
+int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+    return n;
+}
+
 Ctx *Ctx::create(int device, int flags) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -60,6 +78,8 @@ Ctx *Ctx::create(int device, int flags) {
     std::unique_ptr<Ctx> c(new Ctx());
     c->device = device;
     c->flags = flags;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cu = cus;
     if (!hip_ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
     c->stream = c->own_stream;
     return c.release();
@@ -176,11 +196,19 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     longest = max_len;
     const int has_avg = (avg && avg_len > 0) ? 1 : 0;
     if (has_avg && avg_len > longest) longest = avg_len;
-    {   // the DTW kernels keep a tile of windows plus one template length of frames in the CU's 160 KB of LDS
-        const size_t need = ((size_t)(64 + longest - 1) * (size_t)(K | 1) + (size_t)K * 64 + 11 * 64) * sizeof(float);
+    {   // the DTW kernels keep a tile of windows plus one template length of frames in the CU's 160 KB of LDS; the band is at
+        // least |m - n| wide (dtw.rs:64-67: an averaged template longer than the window) and 5 by default -- a larger
+        // band_size is only known at scoring time, where launch_dtw refuses what does not fit
+        int window_len = 0;
+        for (int t = 0; t < T; ++t) window_len = std::max(window_len, lens[t]);
+        const int diff = longest - window_len, wmin = std::max(5, diff);
+        const size_t band_floats = (size_t)(2 * wmin + 1) * 64;
+        const size_t need = ((size_t)(64 + longest - 1) * (size_t)(K | 1) + (size_t)K * 64 + band_floats) * sizeof(float);
         if (need > 160 * 1024) {
+            const size_t fixed = (size_t)K * 64 + band_floats;
+            const size_t lim = 160 * 1024 / sizeof(float) > fixed ? (160 * 1024 / sizeof(float) - fixed) / (size_t)(K | 1) : 0;
             set_last_error("wakeword template of " + std::to_string(longest) + " frames is too long for the device kernels (limit " +
-                           std::to_string((160 * 1024 / sizeof(float) - (size_t)K * 64 - 11 * 64) / (size_t)(K | 1) - 63) + " frames at mfcc_size " + std::to_string(K) + ")");
+                           std::to_string(lim > 63 ? lim - 63 : 0) + " frames at mfcc_size " + std::to_string(K) + ")");
             return nullptr;
         }
     }
@@ -238,10 +266,22 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     }
     std::vector<DtwChunk> chunks;
     std::vector<float> dup;
-    for (int cls = 0; cls < 4; ++cls) {
-        d.class_first[cls] = (int)chunks.size();
-        d.class_count[cls] = (int)byclass[cls].size();
-        for (DtwChunk c : byclass[cls]) {
+    // class 4 (not a launch class of its own): the tc-4 halves of the class-2 chunks, see TemplatesDev::split_first
+    std::vector<DtwChunk> halves;
+    bool can_split = !byclass[2].empty();
+    for (const DtwChunk &c : byclass[2]) can_split = can_split && c.count >= 7;
+    if (can_split)
+        for (const DtwChunk &c : byclass[2])
+            for (int h = 0; h < 2; ++h) {
+                DtwChunk x{};
+                x.len = c.len; x.count = h == 0 ? 4 : c.count - 4; x.tc = 4;
+                for (int q = 0; q < kChunkMax; ++q) x.tid[q] = c.tid[4 * h + (q < x.count ? q : 0)];
+                halves.push_back(x);
+            }
+    for (int cls = 0; cls < 5; ++cls) {
+        if (cls < 4) { d.class_first[cls] = (int)chunks.size(); d.class_count[cls] = (int)byclass[cls].size(); }
+        else { d.split_first = (int)chunks.size(); d.split_count = (int)halves.size(); }
+        for (DtwChunk c : (cls < 4 ? byclass[cls] : halves)) {
             c.rows_off = (int)dup.size();
             for (int r = 0; r < c.len; ++r)
                 for (int pr = 0; pr < c.tc / 2; ++pr)
@@ -322,6 +362,7 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
         }
         if (tail.empty()) tail.push_back(0.f);
         d.tail_floats = (int)tail.size();
+        if (!mlp_mfma_fits(d)) { m->mfma_ok = false; d.nt = 0; return m.release(); }   // e.g. a 255-wide hidden layer: per-layer kernel
         if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) ||
             !up(b1.data(), b1.size() * 4, reinterpret_cast<void **>(&d.b1)) || !up(tail.data(), tail.size() * 4, reinterpret_cast<void **>(&d.tail)))
             return nullptr;
@@ -347,6 +388,56 @@ const float *Model::wsum_for(int K) {
     const float *p = b->as<float>();
     wsums[K] = std::move(b);
     return p;
+}
+
+// Plan of mlp_stream_kernel for rows starting at x.  The layer-1 weights are laid out in the order its MFMA lanes read
+// them: k-step m covers k in [32m, 32m + 32); lane (li = l & 15, lk = l >> 4) holds, for output 16 n + li, the eight k
+// its A fragment carries -- k = 32m + 4lk + e and 32m + 16 + 4lk + e, e < 4 -- as one 16-byte piece per (k-step, n) in
+// bf16, or two (one per half) in f32.  Zero past dims[0] and past dims[1].  The image does not depend on where the rows
+// start (the kernel shifts its reads instead), so it is built once per precision.
+bool Model::stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *plan) {
+    if (!mfma_ok || !mlp_stream_supported(dev, x) || (precision != kMlpF32 && precision != kMlpBf16)) return false;
+    const int in = dims[0], n1 = dims[1], nt = dev.nt;
+    const int q0 = (int)((reinterpret_cast<uintptr_t>(x) >> 4) & 7);
+    const int par = ((in / 4) % 8) != 0;  // in % 16 == 0: the row pitch is 0 or 4 chunks mod 8
+    const int q1 = par ? (q0 + 4) & 7 : q0;
+    const int lines = (in - 1 + 4 * std::max(q0, q1)) / 32 + 1;   // lines that hold bytes of a row
+    plan->units = (lines + 1) / 2;
+    plan->par = par;
+    plan->q[0] = q0; plan->q[1] = q1;
+    plan->nbt = par ? 2 * (int)((B + 255) / 256) : (int)((B + 127) / 128);
+    const int lines_max = (in - 1 + 4 * 7) / 32 + 1;             // at the largest phase
+    const int ksteps = 2 * ((lines_max + 1) / 2);                // two per unit, for every phase
+    std::unique_ptr<DevBuf> &buf = stream_img[precision == kMlpF32 ? 0 : 1];
+    if (!buf) {
+        const bool f32 = precision == kMlpF32;
+        const size_t wk = (size_t)(f32 ? 2048 : 1024) * nt;
+        std::vector<uint8_t> img(wk * ksteps, 0);
+        auto wat = [&](int o, long k) -> float { return (o < n1 && k < in) ? w1_host[(size_t)o * in + k] : 0.f; };
+        for (int m = 0; m < ksteps; ++m)
+            for (int n = 0; n < nt; ++n)
+                for (int l = 0; l < 64; ++l) {
+                    const int li = l & 15, lk = l >> 4, o = 16 * n + li;
+                    const long k0 = 32L * m + 4L * lk;
+                    if (f32) {
+                        for (int h = 0; h < 2; ++h) {
+                            float *dst = reinterpret_cast<float *>(img.data() + wk * m + ((size_t)h * nt + n) * 1024 + l * 16);
+                            for (int e = 0; e < 4; ++e) dst[e] = wat(o, k0 + 16 * h + e);
+                        }
+                    } else {
+                        uint16_t *dst = reinterpret_cast<uint16_t *>(img.data() + wk * m + (size_t)n * 1024 + l * 16);
+                        for (int e = 0; e < 8; ++e) dst[e] = f32_to_bf16(wat(o, k0 + (e < 4 ? e : 12 + e)));
+                    }
+                }
+        std::unique_ptr<DevBuf> b(new DevBuf());
+        if (!b->reserve(img.size())) return false;
+        if (!hip_ok(hipMemcpy(b->p, img.data(), img.size(), hipMemcpyHostToDevice), "hipMemcpy(stream weights)")) return false;
+        buf = std::move(b);
+        stream_ksteps = ksteps;
+    }
+    if (2 * plan->units > stream_ksteps) return false;
+    plan->wimg = buf->p;
+    return true;
 }
 
 Model::~Model() {

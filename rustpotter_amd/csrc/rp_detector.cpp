@@ -427,17 +427,30 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
     float *res = result_.dev_as<float>();  // page-locked host memory: the kernels write the results where the host reads them
     // the new frames go behind the window history and, packed, to the front of the result buffer
     if (!hip_ok(launch_mfcc(st, *tb, up_.dev_as<float>(), 1, up_len, up_len, i0, nfr, nfr, hist + n_hist_ * K, res), "mfcc_kernel")) return -1;
+    // The averaged-template gate (WakewordComparator::run_detection :83-93): `avg_score < avg_threshold -> None`, the sample
+    // templates are never compared.  Here: the averaged template first (one wave per window), a look at its scores in the
+    // page-locked result buffer, and the sample templates + the aggregate only for a wakeword that has a window left --
+    // on silence and noise that is one short launch instead of T+1 DTWs and an aggregate per chunk.
+    std::vector<Wakeword *> gated;
+    const size_t frames_valid = n_hist_ + nfr;
     if (cnt) {
-        const size_t frames_valid = n_hist_ + nfr;
         for (auto &kv : wakewords_) {
             Wakeword &w = *kv.second;
             if (!w.is_model) {
                 // WakewordComparator::run_detection :83-85: the avg DTW only runs when avg_threshold != 0
                 const float avg_thr = w.ref.has_avg_threshold ? w.ref.avg_threshold : det_.avg_threshold;
                 w.with_avg = w.ref.has_avg && avg_thr != 0.f;
+                const int T = (int)w.ref.lens.size();
+                if (w.with_avg) {
+                    const hipError_t e = launch_dtw_single_part(st, w.tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size,
+                                                                det_.score_ref, T, 1, res + w.off_scores, res + w.off_avg);
+                    if (e == hipSuccess) { gated.push_back(&w); continue; }
+                    if (e != hipErrorNotSupported) { hip_ok(e, "dtw kernel"); return -1; }
+                    (void)hipGetLastError();
+                }
                 if (!hip_ok(launch_dtw(st, w.tmpl->dev, hist, 1, frames_valid, first_win, cnt, cnt, det_.band_size, det_.score_ref,
                                        w.with_avg ? 1 : 0, res + w.off_scores, res + w.off_avg), "dtw kernel")) return -1;
-                if (!hip_ok(launch_aggregate(st, res + w.off_scores, cnt, (int)w.ref.lens.size(), (int)det_.score_mode, res + w.off_agg), "aggregate_kernel")) return -1;
+                if (!hip_ok(launch_aggregate(st, res + w.off_scores, cnt, T, (int)det_.score_mode, res + w.off_agg), "aggregate_kernel")) return -1;
             } else {
                 const int L = (int)w.model.train_size;
                 w.shape_ok = (size_t)L * K == (size_t)w.dims[0] && first_win + cnt - 1 + L <= frames_valid;
@@ -453,8 +466,26 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
             }
         }
     }
+    if (!gated.empty()) {
+        if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
+        const float *hres = result_.as<float>();
+        bool again = false;
+        for (Wakeword *w : gated) {
+            const float avg_thr = w->ref.has_avg_threshold ? w->ref.avg_threshold : det_.avg_threshold;
+            bool any = false;
+            for (size_t i = 0; i < cnt; ++i) any = any || !(hres[w->off_avg + i] < avg_thr);
+            if (!any) continue;   // every window of this chunk is `None` for this wakeword
+            const int T = (int)w->ref.lens.size();
+            if (!hip_ok(launch_dtw_single_part(st, w->tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size, det_.score_ref, 0, T,
+                                               res + w->off_scores, res + w->off_avg), "dtw kernel")) return -1;
+            if (!hip_ok(launch_aggregate(st, res + w->off_scores, cnt, T, (int)det_.score_mode, res + w->off_agg), "aggregate_kernel")) return -1;
+            again = true;
+        }
+        if (!again) { keep_last_two(); goto scored; }
+    }
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
     keep_last_two();  // after the synchronise: the upload above read up_
+scored:
 
     // .into_iter().find_map(process_new_mfccs), src/detector.rs:372-397
     for (int i = 0; i < NF; ++i) {

@@ -3,6 +3,9 @@
 // in registers) and aggregate_kernel (src/wakewords/comp/wakeword_comp.rs:38-49,108-139).  DESIGN.md §4.2.
 #include "rp_device.h"
 
+#include <cmath>
+#include <cstdlib>
+
 namespace rp {
 
 // -------------------------------------------------------------------------- DTW
@@ -218,12 +221,16 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
                 v2f m = P[t][0];
 #pragma unroll
                 for (int q = 1; q < B; ++q) m = (v2f){fminf(m.x, P[t][q].x), fminf(m.y, P[t][q].y)};
-                alive = alive || (2 * t < ch->count && m.x <= abandon_cost) || (2 * t + 1 < ch->count && m.y <= abandon_cost);
+                // the averaged template (tid == T) is never abandoned: its score is reported and gates (as in the band2 / wide
+                // kernels); Templates::create keeps it out of this kernel's chunks today, this guard keeps that an optimisation
+                alive = alive || (2 * t < ch->count && (m.x <= abandon_cost || ch->tid[2 * t] >= T)) ||
+                        (2 * t + 1 < ch->count && (m.y <= abandon_cost || ch->tid[2 * t + 1] >= T));
             }
             if (!__any(alive && valid)) {
                 if (valid) {
                     const size_t row = s * out_win_pitch + (size_t)w;
-                    for (int t = 0; t < ch->count; ++t) scores[row * T + ch->tid[t]] = 0.f;
+                    for (int t = 0; t < ch->count; ++t)
+                        if (ch->tid[t] < T) scores[row * T + ch->tid[t]] = 0.f;
                 }
                 return;
             }
@@ -619,13 +626,22 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
 __global__ __launch_bounds__(64) void dtw_generic_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, size_t first_win,
     size_t n_win, size_t out_win_pitch, const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K,
-    int T, int Ttot, int max_len, int band, float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    int T, int t_first, int t_count, int max_len, int band, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
+    const float *__restrict__ gate_avg, float gate_threshold) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int KP = K | 1;
     const unsigned tile = blockIdx.x % tiles;
-    const int t = (blockIdx.x / tiles) % Ttot;
-    const size_t s = blockIdx.x / ((size_t)tiles * Ttot);
+    const int t = t_first + (int)((blockIdx.x / tiles) % t_count);   // templates t_first .. t_first + t_count - 1 (T = the averaged one)
+    const size_t s = blockIdx.x / ((size_t)tiles * t_count);
     const int lane = threadIdx.x;
+    // the averaged-template gate (wakeword_comp.rs:85-93) at wave granularity: when none of the wave's 64 windows passed it,
+    // the sample templates are not compared at all; a wave with a passing window scores all of its windows and the
+    // aggregate pass writes 0 for the rejected ones, so both cases leave the same aggregates
+    if (gate_avg) {
+        const size_t wl = (size_t)tile * 64 + lane;
+        const bool pass = wl < n_win && !(gate_avg[s * out_win_pitch + wl] < gate_threshold);
+        if (!__any(pass)) return;
+    }
     const size_t w0 = first_win + (size_t)tile * 64;
     const int m = lens[t];
     const int n = m < max_len ? m : max_len;  // window cut to the template length
@@ -812,12 +828,12 @@ static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int
 // per cell as dtw_band_kernel, same results.
 __global__ __launch_bounds__(64) void dtw_single_kernel(
     const float *__restrict__ mfcc, size_t n_frames_total, size_t first_win, unsigned n_win, size_t out_win_pitch,
-    const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K, int T, int Ttot, int max_len, int W,
+    const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K, int T, int t_first, int t_count, int max_len, int W,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    const unsigned wi = blockIdx.x / Ttot;
-    const int t = blockIdx.x - wi * Ttot;
+    const unsigned wi = blockIdx.x / t_count;
+    const int t = t_first + (int)(blockIdx.x - wi * t_count);
     const int m = lens[t];
     const int L = m < max_len ? m : max_len;  // m == n == L (checked by the launcher): the window is cut to L frames
     const int B = 2 * W, KP = K | 1;
@@ -916,6 +932,16 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
     if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
     if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
     if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+    // Small batches: tc-8 waves run two per SIMD; a launch that fills those slots 2.x times leaves the chip mostly idle in
+    // its last round.  The same templates as tc-4 half chunks are twice as many waves of 0.83 of the length (measured at C2), three per SIMD
+    // (146 VGPRs).  Taken when the modelled makespan is shorter; large batches (>= 3 rounds of tc-8 waves) never are.
+    if (t.class_count[2] > 0 && t.split_count == 2 * t.class_count[2] && std::getenv("RP_DTW_NO_SPLIT") == nullptr) {
+        const double waves8 = (double)((S * n_win + kDtwWin - 1) / kDtwWin) * t.class_count[2];
+        const double slots = 4.0 * device_cu_count();
+        const double cost8 = std::ceil(waves8 / (2.0 * slots)), cost4 = 0.85 * std::ceil(2.0 * waves8 / (3.0 * slots));
+        if (waves8 < 3.0 * 2.0 * slots && cost4 < cost8)
+            return launch_dtw_class<5, W, 4>(st, t, t.split_first, t.split_count, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
+    }
     return launch_dtw_class<5, W, 8>(st, t, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
 }
 
@@ -1049,7 +1075,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
         const size_t lds = (2 * (size_t)t.max_len * KP + ((t.K + 3) & ~3) + (size_t)(2 * t.max_len + 2 * band + 16) * 2 * band) * sizeof(float);
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(dtw_single_kernel, dim3((unsigned)(n_win * Ttot)), dim3(64), lds, st, mfcc, frame_pitch, first_win,
-                               (unsigned)n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, Ttot, t.max_len, band, score_ref,
+                               (unsigned)n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, Ttot, t.max_len, band, score_ref,
                                scores, avg);
             return hipGetLastError();
         }
@@ -1082,8 +1108,59 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     if (lds > 160 * 1024) return hipErrorMemoryAllocation;  // reported as "template too long" by the callers' hip_ok text
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_generic_kernel), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
-                       (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, Ttot,
-                       t.max_len, band, score_ref, scores, avg);
+                       (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, Ttot,
+                       t.max_len, band, score_ref, scores, avg, static_cast<const float *>(nullptr), 0.f);
+    return hipGetLastError();
+}
+
+// true when launch_dtw serves this template set with dtw_generic_kernel (any mfcc_size / band / an averaged template longer
+// than the window)
+bool dtw_uses_generic(const TemplatesDev &t, int band, size_t S, size_t n_win) {
+    if (S == 1 && n_win <= 8 && t.max_diff == 0 && band >= 1 && 2 * band <= 16) {   // dtw_single_kernel, if its LDS fits
+        const size_t lds1 = (2 * (size_t)t.max_len * (t.K | 1) + ((t.K + 3) & ~3) + (size_t)(2 * t.max_len + 2 * band + 16) * 2 * band) * sizeof(float);
+        if (lds1 <= 64 * 1024) return false;
+    }
+    const size_t reg_lds = (size_t)(2 * kDtwWin + 2 * (t.max_len + 8)) * (size_t)(t.K | 1) * sizeof(float);
+    return !(dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && reg_lds <= 160 * 1024);
+}
+
+// The averaged-template gate behind the generic kernel: pass 1 scores every window against the averaged template (-> avg),
+// pass 2 the sample templates, each wave leaving at once when none of its 64 windows passed (scores of such rows are not
+// written; the aggregate pass gives them 0).
+hipError_t launch_dtw_generic_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                                    size_t n_win, size_t out_win_pitch, int band, float score_ref, float avg_threshold, float *scores,
+                                    float *avg) {
+    if (S == 0 || n_win == 0) return hipSuccess;
+    if (!t.has_avg || !avg) return hipErrorInvalidValue;
+    const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
+    if (tiles * (size_t)t.T * S > 0x7fffffffULL) return hipErrorInvalidValue;
+    const int KP = t.K | 1;
+    const int Wmax = band > t.max_diff ? band : t.max_diff;
+    const size_t lds = ((size_t)(64 + t.max_len - 1) * KP + (size_t)t.K * 64 + (size_t)(2 * Wmax + 1) * 64) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorMemoryAllocation;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_generic_kernel), 160 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)(tiles * S)), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch, (unsigned)tiles,
+                       first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, t.T, 1, t.max_len, band, score_ref, scores, avg,
+                       static_cast<const float *>(nullptr), 0.f);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)(tiles * (size_t)t.T * S)), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
+                       (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, t.T, t.max_len, band, score_ref,
+                       scores, avg, static_cast<const float *>(avg), avg_threshold);
+    return hipGetLastError();
+}
+
+// A handful of windows of ONE stream (the single-stream API), templates t_first .. t_first + t_count - 1 only (index T = the
+// averaged template): the caller scores the averaged template first and the sample templates only when a window passed
+// the gate.  hipErrorNotSupported when dtw_single_kernel does not take this set (the caller then scores everything).
+hipError_t launch_dtw_single_part(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t frame_pitch, size_t first_win, size_t n_win,
+                                  size_t out_win_pitch, int band, float score_ref, int t_first, int t_count, float *scores, float *avg) {
+    if (n_win == 0 || t_count <= 0) return hipSuccess;
+    if (!(n_win <= 8 && t.max_diff == 0 && band >= 1 && 2 * band <= 16) || t_first + t_count > t.T + (t.has_avg ? 1 : 0)) return hipErrorNotSupported;
+    const int KP = t.K | 1;
+    const size_t lds = (2 * (size_t)t.max_len * KP + ((t.K + 3) & ~3) + (size_t)(2 * t.max_len + 2 * band + 16) * 2 * band) * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorNotSupported;
+    hipLaunchKernelGGL(dtw_single_kernel, dim3((unsigned)(n_win * t_count)), dim3(64), lds, st, mfcc, frame_pitch, first_win, (unsigned)n_win,
+                       out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, t_first, t_count, t.max_len, band, score_ref, scores, avg);
     return hipGetLastError();
 }
 
@@ -1103,8 +1180,20 @@ constexpr int kAggMaxT = 256;
 // Max / Average: no sort buffer, so no scratch memory to set up (the single-stream path launches this for 3 rows).
 // A workgroup owns 64 consecutive rows: the [64][T] block of scores is one contiguous range, copied to LDS with
 // coalesced loads (row pitch T+1: conflict-free), then lane r walks row r in template order.
+// What a row's aggregate means downstream: a window the averaged-template gate rejected was never compared with the
+// sample templates (its `scores` row holds nothing), so its aggregate is written as 0 here instead of leaving that to the
+// scan's own avg test; and the first window of a stream that can fire (agg > threshold, gate passed) raises the stream's
+// `hot` flag, so that scan_kernel does not have to sweep the rows of quiet streams to learn that nothing can happen
+// (src/detector.rs:398-430: without such a window no partial detection ever exists).
+__device__ __forceinline__ void agg_store(float *__restrict__ agg, size_t row, float a, const AggExtra &x) {
+    const bool gated = x.gate_avg && x.gate_avg[row] < x.gate_threshold;
+    if (gated) a = 0.f;
+    agg[row] = a;
+    if (x.hot && !gated && a > x.threshold) x.hot[row / x.n_win] = 1u;   // every writer stores the same value
+}
+
 __global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
-                                                       float *__restrict__ agg) {
+                                                       float *__restrict__ agg, AggExtra x) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tile = reinterpret_cast<float *>(smem);  // [64][T + 1]
     const size_t row0 = (size_t)blockIdx.x * 64;
@@ -1122,11 +1211,11 @@ __global__ __launch_bounds__(64) void aggregate_kernel(const float *__restrict__
     if (mode == 1) {  // Max
         float m = v[0];
         for (int i = 1; i < T; ++i) m = fmaxf(m, v[i]);
-        agg[row0 + r] = m;
+        agg_store(agg, row0 + r, m, x);
     } else {  // Average: sequential sum in template order
         float sum = 0.f;
         for (int i = 0; i < T; ++i) sum += v[i];
-        agg[row0 + r] = sum / (float)T;
+        agg_store(agg, row0 + r, sum / (float)T, x);
     }
 }
 
@@ -1165,7 +1254,7 @@ __device__ __forceinline__ float percentile_of_mode(int mode) {
 
 template <int NT>
 __global__ __launch_bounds__(64) void aggregate_sorted_reg_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
-                                                                  float *__restrict__ agg) {
+                                                                  float *__restrict__ agg, AggExtra x) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tile = reinterpret_cast<float *>(smem);  // [64][T + 1]
     const size_t row0 = (size_t)blockIdx.x * 64;
@@ -1194,12 +1283,12 @@ __global__ __launch_bounds__(64) void aggregate_sorted_reg_kernel(const float *_
         hi = i == i0 + 1 ? v[i] : hi;
     }
     const float d = index - fl;
-    agg[row0 + r] = fl == index ? lo : lo * (1.0f - d) + hi * d;
+    agg_store(agg, row0 + r, fl == index ? lo : lo * (1.0f - d) + hi * d, x);
 }
 
 // T > 64: per-lane insertion sort in scratch memory
 __global__ __launch_bounds__(64) void aggregate_sorted_kernel(const float *__restrict__ scores, size_t n_rows, int T, int mode,
-                                                              float *__restrict__ agg) {
+                                                              float *__restrict__ agg, AggExtra x) {
     size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (row >= n_rows) return;
     const float *v = scores + row * T;
@@ -1210,19 +1299,19 @@ __global__ __launch_bounds__(64) void aggregate_sorted_kernel(const float *__res
         while (j >= 0 && tmp[j] > x) { tmp[j + 1] = tmp[j]; --j; }
         tmp[j + 1] = x;
     }
-    agg[row] = percentile_sorted(tmp, T, percentile_of_mode(mode));
+    agg_store(agg, row, percentile_sorted(tmp, T, percentile_of_mode(mode)), x);
 }
 
-hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg) {
+hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg, AggExtra x) {
     if (n_rows == 0) return hipSuccess;
     if (T < 1 || T > kAggMaxT) return hipErrorInvalidValue;
     size_t blocks = (n_rows + 63) / 64;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     if (mode == 0 || mode == 1)
-        hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), (size_t)64 * (T + 1) * sizeof(float), st, scores, n_rows, T, mode, agg);
+        hipLaunchKernelGGL(aggregate_kernel, dim3((unsigned)blocks), dim3(64), (size_t)64 * (T + 1) * sizeof(float), st, scores, n_rows, T, mode, agg, x);
     else if (T <= 64) {
         const size_t lds = (size_t)64 * (T + 1) * sizeof(float);
-#define RP_AGG_SORTED(NT) hipLaunchKernelGGL(aggregate_sorted_reg_kernel<NT>, dim3((unsigned)blocks), dim3(64), lds, st, scores, n_rows, T, mode, agg)
+#define RP_AGG_SORTED(NT) hipLaunchKernelGGL(aggregate_sorted_reg_kernel<NT>, dim3((unsigned)blocks), dim3(64), lds, st, scores, n_rows, T, mode, agg, x)
         if (T <= 2) RP_AGG_SORTED(2);
         else if (T <= 4) RP_AGG_SORTED(4);
         else if (T <= 8) RP_AGG_SORTED(8);
@@ -1230,7 +1319,7 @@ hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, 
         else if (T <= 32) RP_AGG_SORTED(32);
         else RP_AGG_SORTED(64);
 #undef RP_AGG_SORTED
-    } else hipLaunchKernelGGL(aggregate_sorted_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg);
+    } else hipLaunchKernelGGL(aggregate_sorted_kernel, dim3((unsigned)blocks), dim3(64), 0, st, scores, n_rows, T, mode, agg, x);
     return hipGetLastError();
 }
 

@@ -2,6 +2,7 @@
 // context, and the C++ mirror of the reference's `Rustpotter` (src/detector.rs).
 #pragma once
 #include <map>
+#include <tuple>
 #include <memory>
 #include <string>
 #include <vector>
@@ -95,6 +96,7 @@ struct PinBuf {
 struct Ctx {
     int device = 0;
     int flags = 0;
+    int n_cu = 256;  // compute units of the device (persistent kernels launch one workgroup per CU)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::map<int, MfccTablesDev> tables;  // by K
@@ -109,7 +111,7 @@ struct Ctx {
     // staging for RP_CTX_HOST_POINTERS
     DevBuf stage_in, stage_out, stage_out2, stage_out3;
     // intermediates of rp_batch_detect
-    DevBuf ws_mfcc, ws_scores, ws_agg, ws_avg, ws_vad, ws_ring, ws_rms, ws_gain, ws_list;
+    DevBuf ws_mfcc, ws_scores, ws_agg, ws_avg, ws_vad, ws_ring, ws_rms, ws_gain, ws_list, ws_hot;
 
     static Ctx *create(int device, int flags);
     ~Ctx();
@@ -146,6 +148,10 @@ struct Model {
     std::vector<float> w1_host;                     // layer-1 weights [dims[1]][dims[0]]
     std::map<int, std::unique_ptr<DevBuf>> wsums;   // per mfcc_size K: [16*nt][K], sum over frames of the layer-1 weights
     const float *wsum_for(int K);                   // (takes the window mean out after layer 1, launch_mlp_mfma_windows)
+    std::unique_ptr<DevBuf> stream_img[2];          // per precision: layer-1 weights in the stream kernel's fragment order
+    int stream_ksteps = 0;                          // k-steps of 32 the images hold (zero padded past dims[0])
+    // plan of launch_mlp_stream for rows starting at x (x decides the phases); false: use launch_mlp_mfma
+    bool stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *plan);
     // weights/biases: HOST arrays, W_l [dims[l+1]][dims[l]], b_l [dims[l+1]]
     static Model *create(Ctx *ctx, int n_layers, const int *dims, const float *const *weights, const float *const *biases);
     ~Model();

@@ -87,11 +87,16 @@ struct TemplatesDev {
     // windows per lane by dtw_band2_kernel; the averaged template is the LAST chunk of class 3)
     int class_first[4] = {0, 0, 0, 0};
     int class_count[4] = {0, 0, 0, 0};
+    // every class-2 chunk once more as two tc-4 halves (only when each of them holds 7 or 8 templates): a small batch whose
+    // tc-8 waves would fill the chip 2.x times is scored by twice as many tc-4 waves, three resident per SIMD instead of two
+    int split_first = 0, split_count = 0;
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs
 // (one rp_ctx per device) has to set it on each of them.  Sets it once per (current device, kernel), thread-safe.
 hipError_t allow_dynamic_lds(const void *kernel, int bytes);
+// compute units of the current device (cached per device)
+int device_cu_count();
 
 enum KernelId { kKernelMfcc = 0, kKernelDtw = 1, kKernelAggregate = 2, kKernelScan = 3, kKernelMlp = 4, kKernelResample = 5, kKernelCount = 6 };
 
@@ -121,6 +126,7 @@ struct ScanWakewords {
     const float *agg[kScanMaxWakewords], *avg[kScanMaxWakewords];
     float threshold[kScanMaxWakewords], avg_threshold[kScanMaxWakewords];
     const int32_t *label[kScanMaxWakewords];  // model wakewords: the winning label of every window (reported instead of j)
+    const uint32_t *hot = nullptr;            // [S] from the aggregate pass (AggExtra): 0 = no window of the stream can fire
 };
 
 struct BatchDetection {  // == rp_batch_detection
@@ -149,6 +155,15 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                       float *scores, float *avg, bool padded_rows = false, float abandon_nc = __builtin_inff());
 
+// the same gate for template sets only dtw_generic_kernel serves (dtw_uses_generic), at wave granularity, and for the
+// single-stream API (one launch for the averaged template, one for the sample templates when a window passed)
+bool dtw_uses_generic(const TemplatesDev &t, int band, size_t S, size_t n_win);
+hipError_t launch_dtw_generic_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                                    size_t n_win, size_t out_win_pitch, int band, float score_ref, float avg_threshold, float *scores,
+                                    float *avg);
+hipError_t launch_dtw_single_part(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t frame_pitch, size_t first_win, size_t n_win,
+                                  size_t out_win_pitch, int band, float score_ref, int t_first, int t_count, float *scores, float *avg);
+
 // The averaged-template gate as a skip (wakeword_comp.rs:85-93): every window against the averaged template (-> avg),
 // the rows with avg >= avg_threshold listed (list [S*n_win] / count: device workspaces), the sample templates on the
 // listed rows only (-> scores [S][n_win][T]; other rows are not written).  mfcc needs 64*K floats of slack behind the last stream.
@@ -161,7 +176,17 @@ hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *
 // Largest template tile the register DTW kernel is built for (0: only the generic kernel applies).
 int dtw_register_tile(int K, int band);
 
-hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg);
+// optional extras of the aggregate pass (all null = plain aggregate): gate_avg / gate_threshold -- rows whose averaged-template
+// score is below the threshold get aggregate 0 (they were never scored); hot / threshold / n_win -- hot[row / n_win] = 1 for
+// streams with a window that can fire (the caller zeroes `hot` first)
+struct AggExtra {
+    const float *gate_avg = nullptr;
+    float gate_threshold = 0.f;
+    uint32_t *hot = nullptr;
+    float threshold = 0.f;
+    size_t n_win = 1;
+};
+hipError_t launch_aggregate(hipStream_t st, const float *scores, size_t n_rows, int T, int mode, float *agg, AggExtra x = AggExtra{});
 
 // vad_value [S][n_frames] = mean |mfcc| per frame (launch_vad_value) or nullptr (no VAD);
 // vad_mode_value = VADMode::get_value (2 / 2.5 / 3, src/config.rs:140-146)
@@ -169,8 +194,10 @@ hipError_t launch_vad_value(hipStream_t st, const float *mfcc, size_t n_frames_t
 hipError_t launch_vad_value_rows(hipStream_t st, const float *mfcc, size_t S, size_t n, size_t pitch, int K, float *out);
 hipError_t launch_scan_multi(hipStream_t st, const ScanWakewords &ww, const float *vad_value, float vad_mode_value, size_t S,
                              size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *det_ww, int32_t *n_det, int max_det);
+// hot (optional): the per-stream flags of the aggregate pass (AggExtra) -- streams whose flag is 0 report no detection unseen
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
-                       size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det);
+                       size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det,
+                       const uint32_t *hot = nullptr);
 
 // Decode + GainNormalizerFilter + BandPassFilter over whole streams.  ring [S][window_size], rms / gains
 // [S][n_samples/480] are device workspaces; biquad coefficients as BandPassFilter::new computes them.
@@ -203,6 +230,11 @@ hipError_t launch_stream_state_reset(hipStream_t st, void *state, size_t S, long
 hipError_t launch_scan_stream(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                               size_t S, long long f0, int n_new, const ScanConfig &cfg, void *state, BatchDetection *det,
                               int32_t *n_det, int max_det);
+// the same for a detector that holds several wakewords (references and / or models); det_ww / det_label (optional): the
+// wakeword a detection belongs to and, when that wakeword is a model, its label index (else -1)
+hipError_t launch_scan_stream_multi(hipStream_t st, const ScanWakewords &ww, const float *vad_value, float vad_mode_value, size_t S,
+                                    long long f0, int n_new, const ScanConfig &cfg, void *state, BatchDetection *det, int32_t *det_ww,
+                                    int32_t *det_label, int32_t *n_det, int max_det);
 
 hipError_t launch_synth(hipStream_t st, uint64_t seed, uint64_t first_stream, size_t S, size_t n_samples,
                         size_t pcm_stride, float *pcm);
@@ -230,13 +262,29 @@ enum { kMlpF32 = 0, kMlpBf16 = 1 };
 // Fused forward of all layers; layer 1 on the matrix cores (f32-input MFMA: bit-for-bit an fmaf
 // chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.
 hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out);
+bool mlp_mfma_fits(const MlpDev &m);   // the fused kernel's LDS fits a CU (else: the per-layer kernel)
+// The same forward for dense rows with the rows streamed through LDS by LDS-DMA in whole 128-byte lines (rp_mlp_stream.hip):
+// layer-1 widths <= 32, row pitch a multiple of 64 bytes, x 16-byte aligned (mlp_stream_supported).  The plan holds the
+// layer-1 weights in MFMA-fragment order and the line phases of the rows (Model::stream_plan).
+struct MlpStreamPlan {
+    const void *wimg = nullptr;                // [k-step m][...] k-step m = k in [32m, 32m+32), zero padded; see Model::stream_plan
+    int q[2] = {0, 0};                         // even / odd rows: 16-byte chunks between a row's start and the line start below it
+    int units = 0;                             // 64-k steps per row (2 lines of 128 bytes)
+    int par = 0;                               // 1: even and odd rows differ in phase -- a workgroup takes rows of one parity
+    int nbt = 0;                               // workgroup tiles: 128 rows (256-row span of one parity when par)
+};
+bool mlp_stream_supported(const MlpDev &m, const float *x);
+hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out,
+                             int n_cu);
 // The rows are windows of L = dims[0]/K frames read IN PLACE from mfcc [S][n_frames][K] (a window's flattened features
 // are a contiguous slice of the frame array), row = s * n_win + w; the window mean (MfccNormalizer::normalize) is taken
 // out after layer 1: W.(f - mu) = W.f - sum_k mu[k] * wsum[o][k], wsum[o][k] = sum_i W[o][i*K + k].  f32 MFMA.
 // mean [S*n_win][K] from launch_window_means, wsum [16*nt][K].
 hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int L, int K, float *mean);
+// frame_pitch (0 = n_win + L - 1, whole streams): frames between the rows of two streams -- live-stream batches keep their
+// windows in longer rows (window w of stream s starts at frame s * frame_pitch + w, counted from `mfcc`)
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
-                                   const float *mean, const float *wsum, float *out);
+                                   const float *mean, const float *wsum, float *out, size_t frame_pitch = 0);
 
 // WakewordModelTrain (src/wakewords/nn/wakeword_model_train.rs:204-209): act[l] / dz[l] are [B][dims[l+1]] device buffers
 hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,

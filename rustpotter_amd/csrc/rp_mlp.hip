@@ -479,6 +479,20 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     return hipGetLastError();
 }
 
+// LDS of mlp_mfma_kernel for this model (tail weights + staged layer-1 group(s) / h1 + the hidden tail layer): wide hidden
+// layers do not fit the CU's 160 KB and take the per-layer kernel instead (Model::create)
+bool mlp_mfma_fits(const MlpDev &m) {
+    int h2w = 1;
+    for (int l2 = 2; l2 < m.n_layers; ++l2) h2w = m.dims[l2] + 1 > h2w ? m.dims[l2] + 1 : h2w;
+    h2w |= 1;
+    size_t wbuf = (size_t)16 * m.nt * mlp_wpitch_f32() * (m.nt <= 2 ? 2 : 1);
+    const size_t h1 = (size_t)kMlpWaves * kMlpRowsPerWave * (16 * m.nt + 1);
+    if (h1 > wbuf) wbuf = h1;
+    wbuf = (wbuf + 3) & ~(size_t)3;
+    const size_t lds = ((size_t)((m.tail_floats + 3) & ~3) + wbuf + (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
+    return lds <= 160 * 1024;
+}
+
 hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out) {
     if (B == 0) return hipSuccess;
     switch (m.nt) {
@@ -522,16 +536,21 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 }
 
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
-                                   const float *mean, const float *wsum, float *out) {
+                                   const float *mean, const float *wsum, float *out, size_t frame_pitch) {
     const size_t B = S * n_win;
     if (B == 0) return hipSuccess;
     if (K < 1 || K % 4 != 0 || m.dims[0] % K != 0) return hipErrorInvalidValue;  // 16-byte aligned window rows
     const size_t L = (size_t)m.dims[0] / K;
+    // window w of stream s starts at frame s * pitch + w: rows advance by K floats, a new stream skips the rest of its row
+    const size_t pitch = frame_pitch ? frame_pitch : n_win + L - 1;
+    if (pitch < n_win) return hipErrorInvalidValue;
+    (void)n_frames;
+    const size_t skip = (pitch - n_win) * K;
     switch (m.nt) {
-    case 1: return launch_mlp_nt<1>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
-    case 2: return launch_mlp_nt<2>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
-    case 5: return launch_mlp_nt<5>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
-    case 9: return launch_mlp_nt<9>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, (L - 1) * K, mean, wsum, K);
+    case 1: return launch_mlp_nt<1>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
+    case 2: return launch_mlp_nt<2>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
+    case 5: return launch_mlp_nt<5>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
+    case 9: return launch_mlp_nt<9>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
     }
     return hipErrorInvalidValue;
 }

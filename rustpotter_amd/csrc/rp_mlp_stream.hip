@@ -1,0 +1,365 @@
+// rp_mlp_stream.hip -- wakeword-model forward for dense rows x [B][in] (BASELINE config C5), layer 1 on the matrix cores
+// with the rows STREAMED through LDS by LDS-DMA in whole 128-byte lines (src/wakewords/nn/wakeword_nn.rs:101-106,305-389).
+// DESIGN.md §4.4.
+//
+// Why a second kernel: mlp_mfma_kernel loads its A fragments straight into registers, 16 rows x 64 B per instruction --
+// every 128-byte line is requested by two instructions, and a plain load is cached like data that will be read again.
+// Measured on the same array (tools/scratch/glds_probe.hip): 5.2-5.6 TB/s for that shape, 6.0 TB/s for line-shaped
+// LDS-DMA, 6.3 TB/s for LDS-DMA with the non-temporal policy on a grid that starts at the row (odd rows straddle lines),
+// 6.8 TB/s for non-temporal LDS-DMA of whole lines.  So here:
+//   * one wave-instruction moves 8 rows x 128 B (global_load_lds_dwordx4, nt); the 16-byte chunks of a line are XOR-swizzled
+//     by the SOURCE address (the LDS image of an LDS-DMA is lane-linear) so that the fragment reads are conflict-free;
+//   * the line grid is absolute: a row that starts q 16-byte chunks into a line (row pitch 12 480 B = 97.5 lines: q = 0 for
+//     even rows, 4 for odd ones) is read from the line start below it.  The k index an MFMA lane works on does NOT move
+//     with q -- k-step m always covers k in [32m, 32m + 32), lane (row, lk) the two chunks k = 32m + 4lk.. and
+//     32m + 16 + 4lk.. -- the lane just finds them q chunks further along: chunk (lk + q) & 7 of line m + ((lk + q) >> 3).
+//     So one fragment-ordered copy of the layer-1 weights serves every phase, and a row's logits are bit-identical
+//     wherever the row sits (batch invariance, test_c5_full_size_model_forward).  All 16 rows of a wave and all 8 waves
+//     of a workgroup share q (rows of one parity), which keeps the line selects uniform per lane;
+//   * a unit of the stream = 2 lines (64 k) of 16 rows per wave = 4 KB.  k-step 2u+1 may need line 2u+2, so the steps
+//     run half a unit behind the data: iteration u does k-steps 2u-1 and 2u, carrying line 2u+1's chunks in registers,
+//     and the tile ends with a flush step;
+//   * the weights of a unit are shared by the workgroup through a small LDS ring, also filled by LDS-DMA;
+//   * waves are persistent: the DMA stream runs D units ahead across tile boundaries and never drains.
+// vmcnt discipline: every wait names the number of DMA instructions issued after the unit it waits for; the kernel's
+// only other vector-memory traffic is the stores of finished rows, and a store that is still pending only makes a wait
+// stricter.  s_barrier is the raw instruction (a __syncthreads() would drain the DMA queue).
+#include "rp_device.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace rp {
+
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+#define RP_LDSP(p) ((__attribute__((address_space(3))) void *)(p))
+
+constexpr int kStreamWavesMax = 8;
+// timing ablations (results wrong): 1 no workgroup barrier, 2 also no weight DMA, 3 also no MFMA, 4 no epilogue,
+// 5 no weight reads, 6 epilogue without the tail layers, 7 epilogue = a store that never happens
+#ifndef RP_STREAM_ABL
+#define RP_STREAM_ABL 0
+#endif
+
+// tail layers in LDS: rows padded to whole 16-byte pieces plus one piece (pitch 4 mod 8 pieces... odd in pieces: the four
+// rows a wave reads at once fall on distinct bank quads), zeros in the padding
+__host__ __device__ constexpr int stream_pad4(int n) { return ((n + 3) & ~3) + 4; }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <int NT, int PREC, int D, int kStreamWaves>
+__global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_stream_kernel(
+    const float *__restrict__ x, size_t B, int in, const unsigned char *__restrict__ wimg, int q_even, int q_odd, int units, int par,
+    int nbt, const float *__restrict__ b1, const float *__restrict__ tail, int tail_lds, int n_layers, int d1, int d2, int d3,
+    int h2p, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N1P = 16 * NT;
+    constexpr int WK = (PREC == kMlpF32 ? 2048 : 1024) * NT;   // bytes of fragment-ordered weights per k-step (32 k)
+    constexpr int WU = 2 * WK;                                 // per unit
+    constexpr int WP = WU / 1024;                              // 1 KB DMA pieces per unit, one per wave
+    constexpr int NS = D + 1, NW = D + 2;                      // ring depths (rows: private to a wave; weights: shared); D + 1
+                                                               // units are in flight while a unit is being worked on
+    constexpr int WF = PREC == kMlpF32 ? 2 * NT : NT;          // 16-byte weight pieces a lane holds per k-step
+    constexpr int WPW = (WP + kStreamWaves - 1) / kStreamWaves;   // weight pieces a wave moves per unit (the last ones may move one fewer)
+    constexpr int H1P = N1P + 4;                               // h1 row pitch: 16-byte aligned rows on distinct bank quads
+    float *tl = reinterpret_cast<float *>(smem);
+    float *b1s = tl + tail_lds;
+    unsigned char *wring = reinterpret_cast<unsigned char *>(b1s + N1P);
+    unsigned char *xring_all = wring + NW * WU;
+    float *h1_all = reinterpret_cast<float *>(xring_all + kStreamWaves * NS * 4096);
+    float *h2_all = h1_all + kStreamWaves * 16 * H1P;
+    {   // tail layers -> LDS, rows padded (W_l [out][in] then b_l [out], layer after layer, as in `tail`)
+        const int dd[4] = {in, d1, d2, d3};
+        int src = 0, dst = 0;
+        for (int layer = 1; layer < n_layers; ++layer) {
+            const int in_l = dd[layer], on = dd[layer + 1], P = stream_pad4(in_l), on4 = (on + 3) & ~3;
+            for (int i = threadIdx.x; i < on * P; i += blockDim.x) {
+                const int o = i / P, k = i - o * P;
+                tl[dst + i] = k < in_l ? tail[src + o * in_l + k] : 0.f;
+            }
+            for (int i = threadIdx.x; i < on4; i += blockDim.x) tl[dst + on * P + i] = i < on ? tail[src + on * in_l + i] : 0.f;
+            src += on * in_l + on;
+            dst += on * P + on4;
+        }
+    }
+    for (int i = threadIdx.x; i < N1P; i += blockDim.x) b1s[i] = b1[i];
+    __syncthreads();   // the only ordinary loads of the kernel are behind us: nothing below makes the compiler drain vmcnt
+
+    const int l = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = l & 15, lk = l >> 4, r8 = l >> 3, c8 = l & 7;
+    const int ch_src = c8 ^ (2 * (r8 >> 1));                  // DMA slot (row r8, chunk c8) fetches this chunk of the line
+    const int rr = li & 7, rsw = 2 * (rr >> 1);
+    const unsigned rd_row = (li >> 3) * 1024 + rr * 128;      // row li inside a line's 2 KB (two 8-row pieces)
+    unsigned char *xring = xring_all + wave * NS * 4096;
+    const int my_w = (WP - wave + kStreamWaves - 1) / kStreamWaves;   // pieces wave, wave + waves, .. < WP
+    const bool has_w = my_w == WPW;                                  // else WPW - 1
+    const unsigned long long xa = reinterpret_cast<unsigned long long>(x);
+    const unsigned long long x_last = xa + (unsigned long long)B * in * 4 - 16;
+
+    const int my_bts = (int)blockIdx.x < nbt ? (nbt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int total = my_bts * units;
+
+    // first row of wave-tile `bt` and the step between its rows
+    auto tile_row0 = [&](int bt) -> size_t {
+        return par ? (size_t)(bt >> 1) * (32 * kStreamWaves) + 32 * wave + (bt & 1) : (size_t)bt * (16 * kStreamWaves) + 16 * wave;
+    };
+    const int rstep = par ? 2 : 1;
+
+    // ---- issue side: unit g of the stream = (tile g / units, unit g % units)
+    int iu = 0, ibt = blockIdx.x, islot_x = 0, islot_w = 0;
+    unsigned long long xb0 = 0, xb1 = 0;
+    const unsigned char *wsrc = wimg + wave * 1024 + l * 16;
+    bool clamp_tile = false;   // wave-uniform: this tile's lines may reach past the array's last byte
+    auto issue_tile_setup = [&]() __attribute__((always_inline)) {
+        const size_t r0 = tile_row0(ibt);
+        size_t ra = r0 + (size_t)rstep * r8, rb = r0 + (size_t)rstep * (8 + r8);
+        if (ra >= B) ra = B - 1;
+        if (rb >= B) rb = B - 1;
+        xb0 = ((xa + ra * (unsigned long long)in * 4) & ~127ull) + ch_src * 16;
+        xb1 = ((xa + rb * (unsigned long long)in * 4) & ~127ull) + ch_src * 16;
+        // the lines of a row end at most 127 + 128 bytes behind it (a second line of an odd unit count): only the array's
+        // last rows can reach past x_last
+        clamp_tile = r0 + (size_t)rstep * 16 + 1 >= B;
+    };
+    auto issue = [&]() __attribute__((always_inline)) {
+        unsigned char *dst = xring + islot_x * 4096;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned long long a0 = xb0 + (unsigned long long)j * 128, a1 = xb1 + (unsigned long long)j * 128;
+            if (clamp_tile) {   // never read outside the array (such chunks are never used)
+                if (a0 > x_last) a0 = x_last;
+                if (a1 > x_last) a1 = x_last;
+            }
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a0), RP_LDSP(dst + (2 * j) * 1024), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const void *>(a1), RP_LDSP(dst + (2 * j + 1) * 1024), 16, 0, 2);
+        }
+        xb0 += 256; xb1 += 256;
+        if (!(RP_STREAM_ABL == 2 || RP_STREAM_ABL == 3)) {
+#pragma unroll
+            for (int i = 0; i < WPW; ++i)
+                if (i < my_w)
+                    __builtin_amdgcn_global_load_lds(wsrc + (size_t)iu * WU + (size_t)i * kStreamWaves * 1024,
+                                                     RP_LDSP(wring + islot_w * WU + (wave + i * kStreamWaves) * 1024), 16, 0, 0);
+        }
+        islot_x = islot_x + 1 == NS ? 0 : islot_x + 1;
+        islot_w = islot_w + 1 == NW ? 0 : islot_w + 1;
+        if (++iu == units) { iu = 0; ibt += gridDim.x; if (ibt < nbt) issue_tile_setup(); }
+    };
+
+    f32x4 acc[NT];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // one k-step: A halves a0 (k = 32m + 4lk..) and a1 (k = 32m + 16 + 4lk..) against the lane's weight pieces of that step
+    struct WFrag { f32x4 w[WF]; };
+    auto wload = [&](const unsigned char *ws) __attribute__((always_inline)) {
+        WFrag f;
+#pragma unroll
+        for (int i = 0; i < WF; ++i) f.w[i] = *reinterpret_cast<const f32x4 *>(ws + i * 1024);
+        return f;
+    };
+    auto kstep = [&](int m, f32x4 a0, f32x4 a1, const WFrag &wf) __attribute__((always_inline)) {
+        if (32 * m + 32 > in) {   // the row ends inside this step: what lies behind it (the next row, clamped reads) is not data
+            if (32 * m + 4 * lk >= in) a0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (32 * m + 16 + 4 * lk >= in) a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (RP_STREAM_ABL == 3) { acc[0] += a0 + a1 + wf.w[0]; return; }
+        if (PREC == kMlpF32) {   // pieces: [half][n]
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], wf.w[n][e], acc[n], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wf.w[NT + n][e], acc[n], 0, 0, 0);
+        } else {                 // pieces: [n], eight bf16 each
+            bf16x8s av;
+            av[0] = (__bf16)a0.x; av[1] = (__bf16)a0.y; av[2] = (__bf16)a0.z; av[3] = (__bf16)a0.w;
+            av[4] = (__bf16)a1.x; av[5] = (__bf16)a1.y; av[6] = (__bf16)a1.z; av[7] = (__bf16)a1.w;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
+        }
+    };
+
+    // ---- finished tile: layer-1 bias (+ReLU) -> LDS (C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg), then the tail
+    // layers per row: lane = (row l & 15, output phase l >> 4), outputs strided by 4 over the phases, 16-byte LDS reads.
+    // Even inputs accumulate in s0, odd ones in s1 (the padding adds exact zeros).
+    auto epilogue = [&](int bt) __attribute__((always_inline)) {
+        float *h1 = h1_all + wave * 16 * H1P;
+        const bool relu1 = n_layers > 1;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[n][e] + b1s[16 * n + li];
+                if (relu1 && v < 0.f) v = 0.f;
+                h1[(4 * lk + e) * H1P + 16 * n + li] = v;
+            }
+        wave_lds_sync();
+        const int ri = l & 15, ph = l >> 4;
+        const size_t row = tile_row0(bt) + (size_t)rstep * ri;
+        const bool row_ok = row < B;
+        const float *hin = h1 + ri * H1P;
+        float *h2 = h2_all + (wave * 16 + ri) * h2p;
+        const int dd[4] = {in, d1, d2, d3};
+        const float *wp = tl;
+        int cur_in = d1;
+        float *dst = out + row * (size_t)dd[n_layers];
+        if (n_layers == 1 && row_ok)
+            for (int o = ph; o < d1; o += 4) dst[o] = hin[o];
+        for (int layer = 1; layer < n_layers; ++layer) {
+            const int on = dd[layer + 1], P = stream_pad4(cur_in), in4 = (cur_in + 3) & ~3;
+            const bool last = layer + 1 == n_layers;
+            for (int o = ph; o < on; o += 4) {
+                const float *wr = wp + o * P;
+                float s0 = 0.f, s1 = 0.f;
+                for (int i0 = 0; i0 < in4; i0 += 32) {   // 32 inputs per round: all sixteen reads go out before the first is used
+                    f32x4 hv[8], wv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool in_row = i0 + 4 * j < in4;
+                        hv[j] = in_row ? *reinterpret_cast<const f32x4 *>(hin + i0 + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        wv[j] = in_row ? *reinterpret_cast<const f32x4 *>(wr + i0 + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (i0 + 4 * j < in4) {
+                            s0 = fmaf(hv[j].x, wv[j].x, s0); s1 = fmaf(hv[j].y, wv[j].y, s1);
+                            s0 = fmaf(hv[j].z, wv[j].z, s0); s1 = fmaf(hv[j].w, wv[j].w, s1);
+                        }
+                }
+                float sacc = (s0 + s1) + wp[on * P + o];
+                if (!last && sacc < 0.f) sacc = 0.f;
+                if (last) { if (row_ok) dst[o] = sacc; } else h2[o] = sacc;
+            }
+            if (!last && ph == 0)
+                for (int o = on; o < ((on + 3) & ~3); ++o) h2[o] = 0.f;   // the next layer reads whole 16-byte pieces
+            wave_lds_sync();
+            wp += on * P + ((on + 3) & ~3);
+            cur_in = on;
+            hin = h2;
+        }
+        wave_lds_sync();   // h1 / h2 are free again before the next tile's epilogue writes them
+    };
+
+    if (total == 0) return;
+    issue_tile_setup();
+#pragma unroll
+    for (int d = 0; d <= D; ++d) if (d < total) issue();   // D + 1 units in flight
+    zero_acc();
+    int cu = 0, cbt = blockIdx.x, cslot_x = 0, cslot_w = 0;
+    // where this lane finds its two chunks of a k-step: chunk (lk + 4h + q) & 7 of line m + ((lk + 4h + q) >> 3)
+    unsigned rd0 = 0, rd1 = 0;
+    bool nx0 = false, nx1 = false;
+    auto phase_setup = [&]() __attribute__((always_inline)) {
+        const int q = (par && (cbt & 1)) ? q_odd : q_even;
+        const int i0 = lk + q, i1 = lk + 4 + q;
+        rd0 = rd_row + (((i0 & 7) ^ rsw) & 7) * 16; nx0 = i0 >= 8;
+        rd1 = rd_row + (((i1 & 7) ^ rsw) & 7) * 16; nx1 = i1 >= 8;
+    };
+    phase_setup();
+    f32x4 carry0 = {0.f, 0.f, 0.f, 0.f}, carry1 = {0.f, 0.f, 0.f, 0.f};
+    WFrag wcarry = {};   // the weights of k-step 2u+1 wait in registers with the chunks they meet in the next iteration
+    constexpr bool kWDma = !(RP_STREAM_ABL == 2 || RP_STREAM_ABL == 3);
+    for (int g = 0; g < total; ++g) {
+        // unit g has landed when at most the DMA instructions of the units behind it are outstanding: g+1 .. g+D
+        if (g + D < total) {
+            if (!kWDma) wait_vm<4 * D>();
+            else if (has_w) wait_vm<(4 + WPW) * D>();
+            else wait_vm<(4 + WPW - 1) * D>();
+        }
+        else wait_vm<0>();
+        if (RP_STREAM_ABL == 0 || RP_STREAM_ABL == 4) __builtin_amdgcn_s_barrier();   // every wave's share of this unit's weights has landed; unit g-1 is read by everyone
+        const unsigned char *xs = xring + cslot_x * 4096;
+        const unsigned char *wcur = wring + cslot_w * WU + l * 16;
+        const f32x4 r00 = *reinterpret_cast<const f32x4 *>(xs + rd0), r01 = *reinterpret_cast<const f32x4 *>(xs + rd1);
+        const f32x4 r10 = *reinterpret_cast<const f32x4 *>(xs + 2048 + rd0), r11 = *reinterpret_cast<const f32x4 *>(xs + 2048 + rd1);
+        const WFrag weven = RP_STREAM_ABL == 5 ? wcarry : wload(wcur), wodd = RP_STREAM_ABL == 5 ? wcarry : wload(wcur + WK);
+        // the unit is in registers: its slot takes the next DMA at once (unit g+D+1), before the arithmetic
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (g + D + 1 < total) issue();
+        if (cu > 0) kstep(2 * cu - 1, nx0 ? r00 : carry0, nx1 ? r01 : carry1, wcarry);
+        kstep(2 * cu, nx0 ? r10 : r00, nx1 ? r11 : r01, weven);
+        carry0 = r10; carry1 = r11; wcarry = wodd;
+        cslot_x = cslot_x + 1 == NS ? 0 : cslot_x + 1;
+        if (++cu == units) {
+            // flush: the last k-step of the unit; a chunk it would take from the next line lies behind the row's end
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (32 * (2 * units - 1) < in) kstep(2 * units - 1, nx0 ? z : carry0, nx1 ? z : carry1, wcarry);
+            if (RP_STREAM_ABL == 7) { if (acc[0].x == 1.2345f) out[0] = acc[NT - 1].y; }
+            else if (RP_STREAM_ABL == 6) { if (tile_row0(cbt) + li < B) out[(tile_row0(cbt) + li) * 2 + (lk & 1)] = acc[0].x + acc[NT - 1].y; }
+            else if (RP_STREAM_ABL != 4) epilogue(cbt);
+            zero_acc();
+            cu = 0;
+            cbt += gridDim.x;
+            phase_setup();
+        }
+        cslot_w = cslot_w + 1 == NW ? 0 : cslot_w + 1;
+    }
+}
+
+// floats of the padded tail-layer copy, and the pitch of the hidden-layer rows
+static int stream_tail_lds(const MlpDev &m, int *h2p) {
+    int n = 0, hp = 4;
+    for (int l = 1; l < m.n_layers; ++l) {
+        n += m.dims[l + 1] * stream_pad4(m.dims[l]) + ((m.dims[l + 1] + 3) & ~3);
+        if (l + 1 < m.n_layers) hp = std::max(hp, stream_pad4(m.dims[l + 1]));
+    }
+    *h2p = hp;
+    return n;
+}
+
+static size_t stream_lds_bytes(int nt, int precision, int depth, int tail_lds, int h2p, int waves = kStreamWavesMax) {
+    const size_t wu = (size_t)(precision == kMlpF32 ? 4096 : 2048) * nt;
+    return ((size_t)tail_lds + 16 * nt) * 4 + (depth + 2) * wu + (size_t)waves * (depth + 1) * 4096 +
+           (size_t)waves * 16 * (16 * nt + 4) * 4 + (size_t)waves * 16 * h2p * 4;
+}
+
+template <int NT, int PREC, int D, int WAVES>
+static hipError_t launch_stream_t(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p0, const float *x, size_t B, float *out, int tail_lds,
+                                  int h2p, int n_cu) {
+    const size_t lds = stream_lds_bytes(NT, PREC, D, tail_lds, h2p, WAVES);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    MlpStreamPlan p = p0;   // workgroup tiles of 16 * WAVES rows
+    p.nbt = p.par ? 2 * (int)((B + 32 * WAVES - 1) / (32 * WAVES)) : (int)((B + 16 * WAVES - 1) / (16 * WAVES));
+    const int slots = n_cu * (8 / WAVES);
+    const int grid = p.nbt < slots ? p.nbt : slots;   // persistent workgroups, 8 waves per CU
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_stream_kernel<NT, PREC, D, WAVES>), 160 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mlp_stream_kernel<NT, PREC, D, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, st, x, B, m.dims[0],
+                       static_cast<const unsigned char *>(p.wimg), p.q[0], p.q[1], p.units, p.par, p.nbt, m.b1, m.tail, tail_lds, m.n_layers,
+                       m.dims[1], m.dims[2], m.dims[3], h2p, out);
+    return hipGetLastError();
+}
+
+bool mlp_stream_supported(const MlpDev &m, const float *x) {
+    if (!((m.nt == 1 || m.nt == 2) && m.dims[0] % 16 == 0 && m.dims[0] >= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)) return false;
+    int h2p = 4;
+    const int tail_lds = stream_tail_lds(m, &h2p);
+    return stream_lds_bytes(m.nt, kMlpF32, 1, tail_lds, h2p) <= 160 * 1024;   // wide hidden layers: mlp_mfma_kernel
+}
+
+hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out, int n_cu) {
+    if (B == 0) return hipSuccess;
+    int h2p = 4;
+    const int tail_lds = stream_tail_lds(m, &h2p);
+    int depth = stream_lds_bytes(m.nt, precision, 2, tail_lds, h2p) <= 160 * 1024 ? 2 : 1;
+    if (const char *e = getenv("RP_MLP_STREAM_DEPTH")) if (e[0] == '1') depth = 1;   // benchmarks: the shallower ring
+    int waves = 8;
+    if (const char *e = getenv("RP_MLP_STREAM_WAVES")) if (e[0] == '4' && 2 * stream_lds_bytes(m.nt, precision, 1, tail_lds, h2p, 4) <= 160 * 1024) { waves = 4; depth = 1; }
+#define RP_STREAM_CASE(NT_, PREC_)                                                                        \
+    if (m.nt == NT_ && precision == PREC_) {                                                              \
+        if (waves == 4) return launch_stream_t<NT_, PREC_, 1, 4>(st, m, p, x, B, out, tail_lds, h2p, n_cu); \
+        return depth == 2 ? launch_stream_t<NT_, PREC_, 2, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu)   \
+                          : launch_stream_t<NT_, PREC_, 1, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu);  \
+    }
+    RP_STREAM_CASE(1, kMlpF32)
+    RP_STREAM_CASE(1, kMlpBf16)
+    RP_STREAM_CASE(2, kMlpF32)
+    RP_STREAM_CASE(2, kMlpBf16)
+#undef RP_STREAM_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace rp

@@ -60,7 +60,12 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
     // A detection needs at least one window whose aggregate passes the thresholds (run_detection :411-429;
     // the VAD only gates).  The wave first sweeps the block's 64 score rows with coalesced loads; streams
     // without such a window (all of them on non-matching audio) are done, the others run the state machine.
-    {
+    // When the aggregate pass has already raised a flag per stream (ww.hot), that flag is the answer and nothing is swept.
+    bool candidate = true;
+    if (ww.hot) {
+        const size_t sh = (size_t)blockIdx.x * 64 + lane;
+        candidate = sh < S && ww.hot[sh] != 0u;
+    } else {
         if (lane == 0) candidates = 0;
         __syncthreads();
         const size_t s0 = (size_t)blockIdx.x * 64;
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
         }
         if (mask) atomicOr(&candidates, mask);
         __syncthreads();
+        candidate = (candidates >> lane) & 1ull;
     }
     size_t s = (size_t)blockIdx.x * 64 + lane;
     if (s >= S) return;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
             if (det_ww) det_ww[s * (size_t)max_det + i] = 0;
         }
     };
-    if (!((candidates >> lane) & 1ull)) { n_det[s] = 0; clear_from(0); return; }
+    if (!candidate) { n_det[s] = 0; clear_from(0); return; }
     const size_t row0 = s * (size_t)(n_win > 0 ? n_win : 0);
     const float *vv = vad_value ? vad_value + s * n_frames : nullptr;
     // VadDetector state (src/mfcc/vad.rs:3-50)
@@ -179,9 +185,11 @@ hipError_t launch_scan_multi(hipStream_t st, const ScanWakewords &ww, const floa
 }
 
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
-                       size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det) {
+                       size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det,
+                       const uint32_t *hot) {
     ScanWakewords ww{};
     ww.n = 1;
+    ww.hot = hot;
     ww.agg[0] = agg; ww.avg[0] = cfg.avg_enabled ? avg : nullptr;
     ww.threshold[0] = cfg.threshold; ww.avg_threshold[0] = cfg.avg_threshold;
     return launch_scan_multi(st, ww, vad_value, vad_mode_value, S, n_frames, cfg, det, nullptr, n_det, max_det);
@@ -192,7 +200,10 @@ hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const
 // detection / window bookkeeping (src/detector.rs:62-79) in absolute frame numbers, and the VadDetector.
 struct StreamState {
     long long win_start, resume;
-    int has_partial, p_counter, countdown, vad_index, voice_countdown, pad;
+    int has_partial, p_counter, countdown, vad_index, voice_countdown;
+    int p_ww;        // wakeword the partial detection belongs to (detectors that hold several)
+    int p_label;     // its label index when that wakeword is a model, else -1
+    int pad;
     long long p_window;
     float p_score, p_avg;
     float vad_window[50];
@@ -249,6 +260,7 @@ __global__ __launch_bounds__(64) void stream_state_init_kernel(StreamState *__re
     if (s >= S) return;
     StreamState z;
     z.win_start = 0; z.resume = 0; z.has_partial = 0; z.p_counter = 0; z.countdown = 0; z.vad_index = 0; z.voice_countdown = 0; z.pad = 0;
+    z.p_ww = 0; z.p_label = -1;
     z.p_window = 0; z.p_score = 0.f; z.p_avg = 0.f;
     for (int i = 0; i < 50; ++i) z.vad_window[i] = __builtin_nanf("");
     st[s] = z;
@@ -279,19 +291,19 @@ hipError_t launch_stream_state_reset(hipStream_t st, void *state, size_t S, long
 }
 
 // scan_kernel over the n_new frames of this call with carried state.  Frame i of the call is absolute frame
-// f0 + i; the window ending at it is row i of agg / avg (the history prefix is max_len-1 frames long).
-__global__ __launch_bounds__(64) void scan_stream_kernel(const float *__restrict__ agg, const float *__restrict__ avg,
-                                                         const float *__restrict__ vad_value, float vad_mode_value, size_t S,
+// f0 + i; the window ending at it is row i of every wakeword's agg / avg (the history prefix is max_len-1 frames long).
+// Several wakewords as in scan_kernel (run_wakeword_detectors, src/detector.rs:433-447).
+__global__ __launch_bounds__(64) void scan_stream_kernel(ScanWakewords ww, const float *__restrict__ vad_value, float vad_mode_value, size_t S,
                                                          long long f0, int n_new, ScanConfig cfg, StreamState *__restrict__ state,
-                                                         BatchDetection *__restrict__ det, int32_t *__restrict__ n_det, int max_det) {
+                                                         BatchDetection *__restrict__ det, int32_t *__restrict__ det_ww,
+                                                         int32_t *__restrict__ det_label, int32_t *__restrict__ n_det, int max_det) {
     __shared__ float vwin[50][64];
     const int lane = threadIdx.x;
     const size_t s = (size_t)blockIdx.x * 64 + lane;
     if (s >= S) return;
     StreamState z = state[s];
     const long long max_len = cfg.max_len;
-    const float *a = agg + s * (size_t)n_new;
-    const float *v = avg ? avg + s * (size_t)n_new : nullptr;
+    const size_t row0 = s * (size_t)n_new;
     const float *vv = vad_value ? vad_value + s * (size_t)n_new : nullptr;
     if (vv)
         for (int i = 0; i < 50; ++i) vwin[i][lane] = z.vad_window[i];
@@ -325,6 +337,8 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(const float *__restrict
                         d.stream = (int32_t)s; d.frame = (int32_t)f; d.window = (int32_t)z.p_window; d.counter = z.p_counter;
                         d.avg_score = z.p_avg; d.score = z.p_score;
                         det[s * (size_t)max_det + nd] = d;
+                        if (det_ww) det_ww[s * (size_t)max_det + nd] = z.p_ww;
+                        if (det_label) det_label[s * (size_t)max_det + nd] = z.p_label;
                     }
                     ++nd;
                     z.win_start = z.resume = cfg.fpf * ((f + 3) / cfg.fpf + 1);
@@ -333,13 +347,22 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(const float *__restrict
                 }
             }
         }
-        const float sc = a[i];
-        float av = 0.f;
-        bool pass = true;
-        if (cfg.avg_enabled) { av = v[i]; pass = !(av < cfg.avg_threshold); }
-        if (pass && sc > cfg.threshold) {
+        // every wakeword whose own thresholds pass proposes a detection, the best score wins (the first of equals)
+        float sc = 0.f, av = 0.f;
+        int best = -1;
+        for (int j = 0; j < ww.n; ++j) {
+            const float sj = ww.agg[j][row0 + i];
+            float aj = 0.f;
+            bool pass = true;
+            if (ww.avg[j]) { aj = ww.avg[j][row0 + i]; pass = !(aj < ww.avg_threshold[j]); }
+            if (pass && sj > ww.threshold[j] && (best < 0 || sj > sc)) { best = j; sc = sj; av = aj; }
+        }
+        if (best >= 0) {
             const int counter = z.has_partial ? z.p_counter + 1 : 1;
-            if (!z.has_partial || z.p_score < sc) { z.p_score = sc; z.p_avg = av; z.p_window = f - max_len + 1; z.has_partial = 1; }
+            if (!z.has_partial || z.p_score < sc) {
+                z.p_score = sc; z.p_avg = av; z.p_window = f - max_len + 1; z.has_partial = 1;
+                z.p_ww = best; z.p_label = ww.label[best] ? ww.label[best][row0 + i] : -1;
+            }
             z.p_counter = counter;
             z.countdown = (int)(max_len / 2);
         }
@@ -348,16 +371,31 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(const float *__restrict
         for (int i = 0; i < 50; ++i) z.vad_window[i] = vwin[i][lane];
     state[s] = z;
     n_det[s] = nd;
-    for (int i = nd; i < max_det; ++i) det[s * (size_t)max_det + i] = BatchDetection{};
+    for (int i = nd; i < max_det; ++i) {
+        det[s * (size_t)max_det + i] = BatchDetection{};
+        if (det_ww) det_ww[s * (size_t)max_det + i] = 0;
+        if (det_label) det_label[s * (size_t)max_det + i] = 0;
+    }
+}
+
+hipError_t launch_scan_stream_multi(hipStream_t st, const ScanWakewords &ww, const float *vad_value, float vad_mode_value, size_t S,
+                                    long long f0, int n_new, const ScanConfig &cfg, void *state, BatchDetection *det, int32_t *det_ww,
+                                    int32_t *det_label, int32_t *n_det, int max_det) {
+    if (S == 0) return hipSuccess;
+    if (ww.n < 1 || ww.n > kScanMaxWakewords) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scan_stream_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, ww, vad_value, vad_mode_value, S, f0, n_new, cfg,
+                       static_cast<StreamState *>(state), det, det_ww, det_label, n_det, max_det);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan_stream(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                               size_t S, long long f0, int n_new, const ScanConfig &cfg, void *state, BatchDetection *det,
                               int32_t *n_det, int max_det) {
-    if (S == 0) return hipSuccess;
-    hipLaunchKernelGGL(scan_stream_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, agg, avg, vad_value, vad_mode_value, S, f0,
-                       n_new, cfg, static_cast<StreamState *>(state), det, n_det, max_det);
-    return hipGetLastError();
+    ScanWakewords ww{};
+    ww.n = 1;
+    ww.agg[0] = agg; ww.avg[0] = cfg.avg_enabled ? avg : nullptr;
+    ww.threshold[0] = cfg.threshold; ww.avg_threshold[0] = cfg.avg_threshold;
+    return launch_scan_stream_multi(st, ww, vad_value, vad_mode_value, S, f0, n_new, cfg, state, det, nullptr, nullptr, n_det, max_det);
 }
 
 }  // namespace rp

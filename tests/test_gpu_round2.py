@@ -42,6 +42,19 @@ def _fixture_streams(n_variants=6):
     return np.stack(out)
 
 
+def _devices(n):
+    """Device ordinals for n shards / ranks: DISTINCT devices the moment the node has that many (then the peer-copy
+    gather crosses xGMI and the ranks talk RCCL); on a smaller node the shards share what there is."""
+    import torch
+    have = max(1, torch.cuda.device_count())
+    return [g % have for g in range(n)]
+
+
+def _distinct(n):
+    import torch
+    return torch.cuda.device_count() >= n
+
+
 def _wakeword(ra, ctx, name="oye_casa_g.rpw"):
     w = rpw_py.load_rpw(os.path.join(G, name))
     return ra.Templates(ctx, list(w["samples_features"].values()), avg=w["avg_features"])
@@ -222,9 +235,10 @@ def _free_port():
     return p
 
 
-def _rank_worker(rank, world, port, out_path):
+def _rank_worker(rank, world, port, out_path, backend, devices):
     """One rank of the data-parallel path as bench.py runs it: its shard of the streams through rp_batch_detect on its
-    device (here both ranks share GPU 0), then ONE all_gather of the per-stream results."""
+    device, then ONE all_gather of the per-stream results -- RCCL (backend nccl) with one device per rank when the node
+    has them, gloo with the ranks sharing GPU 0 otherwise."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -234,12 +248,16 @@ def _rank_worker(rank, world, port, out_path):
     import torch.distributed as dist
     import rustpotter_amd as ra
     from rustpotter_amd import sharding
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev_id = devices[rank]
+    torch.cuda.set_device(dev_id)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_id))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         pcm_all = _fixture_streams(8)
         lo, hi = sharding.shard_bounds(pcm_all.shape[0], world, rank)
-        torch.cuda.set_device(0)
-        ctx = ra.BatchContext(device=0, host_pointers=False)
+        ctx = ra.BatchContext(device=dev_id, host_pointers=False)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         tm = _wakeword(ra, ctx)
         cfg = ra.DetectorConfig()
@@ -267,13 +285,15 @@ def _rank_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_one_gpu_equal_a_single_rank(ra, tmp_path):
-    """SURVEY.md 8e on the product: 2 ranks (gloo, both on GPU 0) run rp_batch_detect on their stream shards and gather;
-    the gathered block equals one rank's run over all the streams (n_det, every detection record, score checksums)."""
+def test_two_ranks_equal_a_single_rank(ra, tmp_path):
+    """SURVEY.md 8e on the product: 2 ranks run rp_batch_detect on their stream shards and gather; the gathered block
+    equals one rank's run over all the streams (n_det, every detection record, score checksums).  With two GPUs visible
+    the ranks own one each and gather over RCCL; on a one-GPU box they share GPU 0 and gather over gloo."""
     import torch
     import torch.multiprocessing as mp
     out = str(tmp_path / "gathered.npz")
-    mp.spawn(_rank_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    backend = "nccl" if _distinct(2) else "gloo"
+    mp.spawn(_rank_worker, args=(2, _free_port(), out, backend, _devices(2)), nprocs=2, join=True)
     z = np.load(out)
     pcm_all = _fixture_streams(8)
     ctx = ra.BatchContext(device=0, host_pointers=True)
@@ -287,10 +307,10 @@ def test_two_ranks_sharing_one_gpu_equal_a_single_rank(ra, tmp_path):
 
 
 def test_batch_detect_sharded_abi_equals_one_call(ra):
-    """rp_batch_detect_sharded: one context + one host thread per shard (here three contexts on GPU 0, ragged shards, one
-    of them empty), results gathered into one host block with global stream ids."""
+    """rp_batch_detect_sharded: one context + one host thread per shard (three contexts -- on three devices when the node
+    has them, else sharing -- ragged shards, one of them empty), results gathered into one host block with global stream ids."""
     pcm_all = _fixture_streams(7)
-    ctxs = [ra.BatchContext(0) for _ in range(3)]
+    ctxs = [ra.BatchContext(d) for d in _devices(3)]
     tms = [_wakeword(ra, c) for c in ctxs]
     cfg = ra.DetectorConfig()
     cfg.threshold = 0.45
@@ -306,22 +326,32 @@ def test_batch_detect_sharded_abi_equals_one_call(ra):
         ra.batch_detect_sharded([ctxs[0], ctxs[0]], [tms[0], tms[0]], [pcm_all[:3], pcm_all[3:]], cfg)
     with pytest.raises(ra.RustpotterError):
         ra.batch_detect_sharded([ctxs[0], ctxs[1]], [tms[1], tms[0]], [pcm_all[:3], pcm_all[3:]], cfg)
+    # shards that disagree in stream length or sample type are refused before the C call would mis-read them
+    with pytest.raises(ValueError):
+        ra.batch_detect_sharded(ctxs[:2], tms[:2], [pcm_all[:3], pcm_all[3:, :-480]], cfg)
+    with pytest.raises(ValueError):
+        ra.batch_detect_sharded(ctxs[:2], tms[:2], [pcm_all[:3], (pcm_all[3:] * 32767).astype(np.int16)], cfg)
 
 
 def test_batch_detect_sharded_device_pointers(ra):
-    """Device-pointer form: every shard's PCM on its own device, the gathered block on the first context's device."""
+    """Device-pointer form: every shard's PCM on its own device, the gathered block on the first context's device -- the
+    second shard's results cross to it with hipMemcpyPeerAsync (over xGMI when the two contexts sit on different GPUs)."""
     import torch
     pcm_all = _fixture_streams(6)
-    ctxs = [ra.BatchContext(0, host_pointers=False) for _ in range(2)]
+    devs = _devices(2)
+    ctxs = [ra.BatchContext(d, host_pointers=False) for d in devs]
     tms = [_wakeword(ra, c) for c in ctxs]
     cfg = ra.DetectorConfig()
     cfg.threshold = 0.45
     N = pcm_all.shape[1]
-    parts = [torch.from_numpy(pcm_all[:2].copy()).cuda(), torch.from_numpy(pcm_all[2:].copy()).cuda()]
-    det = torch.zeros((6, 4, 6), dtype=torch.int32, device="cuda")
-    n_det = torch.zeros((6,), dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+    parts = [torch.from_numpy(pcm_all[:2].copy()).to("cuda:%d" % devs[0]), torch.from_numpy(pcm_all[2:].copy()).to("cuda:%d" % devs[1])]
+    det = torch.zeros((6, 4, 6), dtype=torch.int32, device="cuda:%d" % devs[0])
+    n_det = torch.zeros((6,), dtype=torch.int32, device="cuda:%d" % devs[0])
+    for d in set(devs):
+        torch.cuda.synchronize(d)
     ra.batch_detect_sharded_dev(ctxs, tms, [p.data_ptr() for p in parts], [2, 4], N, N, cfg, det.data_ptr(), n_det.data_ptr(), 4)
+    with pytest.raises(ValueError):
+        ra.batch_detect_sharded_dev(ctxs, tms, [parts[0].data_ptr()], [2, 4], N, N, cfg, det.data_ptr(), n_det.data_ptr(), 4)
     one = ra.BatchContext(0)
     det1, n1 = one.batch_detect(pcm_all, _wakeword(ra, one), cfg, max_det=4)
     assert np.array_equal(n_det.cpu().numpy(), n1)
@@ -335,7 +365,11 @@ def test_bench_starts_its_own_ranks():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     env.pop("LOCAL_RANK", None)
-    env["RP_BENCH_OVERSUBSCRIBE"] = "1"
+    import torch
+    if torch.cuda.device_count() < 2:
+        env["RP_BENCH_OVERSUBSCRIBE"] = "1"   # one GPU: the two ranks share it over gloo (a launch-path dry run)
+    else:
+        env.pop("RP_BENCH_OVERSUBSCRIBE", None)  # two or more: one rank per GPU over RCCL, exactly the driver's run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "2048", "--steps", "2", "--warmup", "1",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -344,7 +378,6 @@ def test_bench_starts_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["steps"] == 2 and j["scaling"] == "weak"
     assert j["roofline"]["bound"] in ("valu", "hbm") and j["roofline_other"]["kernel"] != j["roofline"]["kernel"]
-    import torch
     if torch.cuda.device_count() < 2:
         assert j["oversubscribed"]["devices"] == torch.cuda.device_count()
         # without the override a node with too few GPUs is refused, not silently oversubscribed
@@ -352,6 +385,40 @@ def test_bench_starts_its_own_ranks():
         r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--streams", "512"], capture_output=True,
                             text=True, timeout=300, env=env, cwd=ROOT)
         assert r2.returncode != 0 and "RP_BENCH_OVERSUBSCRIBE" in r2.stderr
+
+
+def test_bench_c4_preset_is_strong_scaling():
+    """`bench.py --gpus 2 --config C4`: BASELINE config C4 as stated -- 65 536 streams x 64 templates SPLIT over the ranks by
+    shard_bounds, RCCL gather of the per-stream results; the line says strong scaling and the world size it ran with."""
+    import torch
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["RP_BENCH_OVERSUBSCRIBE"] = "1"
+    else:
+        env.pop("RP_BENCH_OVERSUBSCRIBE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C4", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["world_size"] == 2
+    assert j["config"]["workload"].startswith("C4: 65536 synthetic") and "split over 2 rank(s)" in j["config"]["workload"]
+    assert j["config"]["streams_per_gpu"] == 32768 and j["config"]["templates"] == 64
+    # 65 536 streams x 297 windows per step, whatever the number of ranks
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 - 65536 * 297) < 1.0
+    assert j["config"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+
+
+def test_rccl_smoke_world_size_1():
+    """The exchange bench.py does after a pass, on the real backend: init_process_group("nccl") (= RCCL), all_gather of a
+    per-stream int32 tensor, barrier, MAX all_reduce -- one rank, so that it runs on a one-GPU box too."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_smoke.py")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
 def test_contexts_on_one_device_use_large_lds_kernels(ra):

@@ -22,6 +22,29 @@ __global__ __launch_bounds__(256) void lin_kernel(const f32x4 *__restrict__ x, s
     if (s.x + s.y + s.z + s.w == 1.2345f) out[0] = s.x;
 }
 
+template <int KU> __global__ __launch_bounds__(512) void fragnt_kernel(const float *__restrict__ x, size_t B, int in, float *out) {
+    int l = threadIdx.x & 63, wave = threadIdx.x >> 6, li = l & 15, lk = l >> 4;
+    size_t row = ((size_t)blockIdx.x * 8 + wave) * 16 + li;
+    float s = 0.f;
+    for (int kb = 0; kb < in / 16; kb += KU) {
+        f32x4 a[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) { int k0 = 16 * (kb + u) + 4 * lk; a[u] = (k0 + 3 < in) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(x + row * in + k0)) : (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) s += a[u].x + a[u].y + a[u].z + a[u].w;
+    }
+    if (s == 1.2345f) out[row] = s;
+}
+__global__ __launch_bounds__(256) void linnt_kernel(const f32x4 *__restrict__ x, size_t n16, float *out) {
+    f32x4 s = {0, 0, 0, 0};
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, st = (size_t)gridDim.x * 256;
+    for (; i + 3 * st < n16; i += 4 * st) {
+        f32x4 a = __builtin_nontemporal_load(x + i), b = __builtin_nontemporal_load(x + i + st), c = __builtin_nontemporal_load(x + i + 2 * st), d = __builtin_nontemporal_load(x + i + 3 * st);
+        s += a + b + c + d;
+    }
+    for (; i < n16; i += st) s += x[i];
+    if (s.x + s.y + s.z + s.w == 1.2345f) out[0] = s.x;
+}
 template <int KU> __global__ __launch_bounds__(512) void frag_kernel(const float *__restrict__ x, size_t B, int in, float *out) {
     int l = threadIdx.x & 63, wave = threadIdx.x >> 6, li = l & 15, lk = l >> 4;
     size_t row = ((size_t)blockIdx.x * 8 + wave) * 16 + li;
@@ -62,8 +85,8 @@ __global__ __launch_bounds__(64 * WAVES) void glds_kernel(const float *__restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // q = line (q>>1), piece (q&1)
             const int rowi = 8 * (q & 1) + r8;
-            const size_t row = PAR ? (size_t)(t >> 1) * 32 + 2 * rowi + (t & 1) : (size_t)t * 16 + rowi;
-            const size_t byte0 = (row * (size_t)in * 4) & ~(size_t)127;   // line start at or below the row start
+            const size_t row = PAR == 1 ? (size_t)(t >> 1) * 32 + 2 * rowi + (t & 1) : (size_t)t * 16 + rowi;
+            const size_t byte0 = PAR == 2 ? row * (size_t)in * 4 : (row * (size_t)in * 4) & ~(size_t)127;   // line start at or below the row start (PAR 2: the row start itself)
             const unsigned char *src = reinterpret_cast<const unsigned char *>(x) + byte0 + (size_t)(2 * lp + (q >> 1)) * 128 + ch * 16;
             const unsigned char *end = reinterpret_cast<const unsigned char *>(x) + B * (size_t)in * 4 - 16;
             if (src > end) src = end;
@@ -99,15 +122,17 @@ int main() {
         printf("%-34s avg %.4f ms %.2f TB/s   best %.4f ms %.2f TB/s\n", name, sum / reps, B * in * 4.0 / (sum / reps) / 1e9, best, B * in * 4.0 / best / 1e9);
     };
     for (int g : {1024, 2048, 4096, 16384}) { char nm[64]; sprintf(nm, "lin grid %d", g); run(nm, [&] { hipLaunchKernelGGL(lin_kernel, dim3(g), dim3(256), 0, 0, (const f32x4 *)x, B * in / 4, out); }); }
+    for (int g : {2048, 16384}) { char nm[64]; sprintf(nm, "lin nt grid %d", g); run(nm, [&] { hipLaunchKernelGGL(linnt_kernel, dim3(g), dim3(256), 0, 0, (const f32x4 *)x, B * in / 4, out); }); }
+    run("frag nt KU=8", [&] { hipLaunchKernelGGL(fragnt_kernel<8>, dim3(B / 128), dim3(512), 0, 0, x, B, in, out); });
+    run("frag nt KU=16", [&] { hipLaunchKernelGGL(fragnt_kernel<16>, dim3(B / 128), dim3(512), 0, 0, x, B, in, out); });
     run("frag KU=8", [&] { hipLaunchKernelGGL(frag_kernel<8>, dim3(B / 128), dim3(512), 0, 0, x, B, in, out); });
     run("frag KU=16", [&] { hipLaunchKernelGGL(frag_kernel<16>, dim3(B / 128), dim3(512), 0, 0, x, B, in, out); });
     const int ntiles = (int)(B / 16);
 #define G(W, NS, NT, PAR, GRID) do { char nm[80]; sprintf(nm, "glds W%d NS%d nt%d par%d grid%d", W, NS, NT, PAR, GRID); \
         CK(hipFuncSetAttribute((const void *)glds_kernel<W, NS, NT, PAR>, hipFuncAttributeMaxDynamicSharedMemorySize, W * NS * 4096)); \
         run(nm, [&] { hipLaunchKernelGGL((glds_kernel<W, NS, NT, PAR>), dim3(GRID), dim3(64 * W), W * NS * 4096, 0, x, B, in, ntiles, out); }); } while (0)
-    G(8, 4, 0, 1, 256); G(8, 4, 1, 1, 256); G(8, 4, 0, 0, 256); G(8, 4, 1, 0, 256);
-    G(8, 3, 1, 1, 256); G(8, 2, 1, 1, 256); G(4, 8, 1, 1, 256); G(4, 4, 1, 1, 256); G(4, 4, 1, 1, 512); G(4, 6, 1, 1, 512);
-    G(8, 4, 1, 1, 512); G(8, 2, 1, 1, 512); G(8, 2, 1, 1, 1024); G(4, 4, 1, 1, 1024); G(4, 2, 1, 1, 2048); G(2, 8, 1, 1, 1024);
-    G(16, 2, 1, 1, 256); G(16, 2, 0, 1, 256);
+    G(8, 4, 0, 1, 256); G(8, 4, 1, 1, 256); G(8, 4, 1, 0, 256); G(8, 4, 1, 2, 256); G(8, 4, 0, 2, 256);
+    G(8, 3, 1, 1, 256); G(8, 2, 1, 1, 256); G(4, 4, 1, 1, 256); G(4, 4, 1, 1, 512);
+    G(8, 2, 1, 1, 512); G(4, 2, 1, 1, 2048);
     return 0;
 }

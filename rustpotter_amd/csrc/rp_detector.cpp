@@ -428,9 +428,12 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
     // the new frames go behind the window history and, packed, to the front of the result buffer
     if (!hip_ok(launch_mfcc(st, *tb, up_.dev_as<float>(), 1, up_len, up_len, i0, nfr, nfr, hist + n_hist_ * K, res), "mfcc_kernel")) return -1;
     // The averaged-template gate (WakewordComparator::run_detection :83-93): `avg_score < avg_threshold -> None`, the sample
-    // templates are never compared.  Here: the averaged template first (one wave per window), a look at its scores in the
-    // page-locked result buffer, and the sample templates + the aggregate only for a wakeword that has a window left --
-    // on silence and noise that is one short launch instead of T+1 DTWs and an aggregate per chunk.
+    // templates are never compared.  One wave scores one (window, template) pair, so all T+1 DTWs of a chunk run side by side
+    // in one 19 us launch and skipping T of them saves no time by itself; scoring the averaged template FIRST and the others
+    // only when a window is left costs a second launch + synchronise when the gate lets the window through (75 against 44 us
+    // per call on noise, whose avg_score 0.28-0.40 passes the default 0.2) and saves the aggregate launch and T DTWs of
+    // device work when it does not (40 us).  So the order is chosen from the previous chunk: gate-first while the gate has
+    // been rejecting every window (silence, quiet rooms), everything at once otherwise; a wrong guess costs one slow call.
     std::vector<Wakeword *> gated;
     const size_t frames_valid = n_hist_ + nfr;
     if (cnt) {
@@ -441,7 +444,7 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
                 const float avg_thr = w.ref.has_avg_threshold ? w.ref.avg_threshold : det_.avg_threshold;
                 w.with_avg = w.ref.has_avg && avg_thr != 0.f;
                 const int T = (int)w.ref.lens.size();
-                if (w.with_avg) {
+                if (w.with_avg && gate_first_) {
                     const hipError_t e = launch_dtw_single_part(st, w.tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size,
                                                                 det_.score_ref, T, 1, res + w.off_scores, res + w.off_avg);
                     if (e == hipSuccess) { gated.push_back(&w); continue; }
@@ -466,6 +469,7 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
             }
         }
     }
+    bool any_passed = false, any_gate = false;   // for the next chunk's order
     if (!gated.empty()) {
         if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
         const float *hres = result_.as<float>();
@@ -474,17 +478,30 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
             const float avg_thr = w->ref.has_avg_threshold ? w->ref.avg_threshold : det_.avg_threshold;
             bool any = false;
             for (size_t i = 0; i < cnt; ++i) any = any || !(hres[w->off_avg + i] < avg_thr);
+            any_gate = true;
             if (!any) continue;   // every window of this chunk is `None` for this wakeword
+            any_passed = true;
             const int T = (int)w->ref.lens.size();
             if (!hip_ok(launch_dtw_single_part(st, w->tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size, det_.score_ref, 0, T,
                                                res + w->off_scores, res + w->off_avg), "dtw kernel")) return -1;
             if (!hip_ok(launch_aggregate(st, res + w->off_scores, cnt, T, (int)det_.score_mode, res + w->off_agg), "aggregate_kernel")) return -1;
             again = true;
         }
-        if (!again) { keep_last_two(); goto scored; }
+        if (!again) { gate_first_ = true; keep_last_two(); goto scored; }
     }
     if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return -1;
     keep_last_two();  // after the synchronise: the upload above read up_
+    if (cnt) {   // did the gate reject every window of every gated wakeword?  (all-at-once chunks: read the avg scores now)
+        const float *hres = result_.as<float>();
+        for (auto &kv : wakewords_) {
+            Wakeword &w = *kv.second;
+            if (w.is_model || !w.with_avg) continue;
+            any_gate = true;
+            const float avg_thr = w.ref.has_avg_threshold ? w.ref.avg_threshold : det_.avg_threshold;
+            for (size_t i = 0; i < cnt; ++i) any_passed = any_passed || !(hres[w.off_avg + i] < avg_thr);
+        }
+        gate_first_ = any_gate && !any_passed;
+    }
 scored:
 
     // .into_iter().find_map(process_new_mfccs), src/detector.rs:372-397

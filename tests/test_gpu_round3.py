@@ -418,3 +418,12 @@ def test_avg_gate_skip_behind_the_generic_kernel(ra, K, band):
             for j, (chunk, r) in enumerate(want):
                 assert det_f[s][j]["frame"] // 3 + 1 == chunk and det_f[s][j]["counter"] == r["counter"]
     assert some
+
+
+def test_live_multi_sweep_few_cases(ra, ctx):
+    """A few cases of the randomised live-stream sweep with several wakewords / a model per detector (tests/sweep_parity.py
+    --live-multi-cases; 150 cases in profiles/sweep_r03.txt): the oracle's chunked detector and, for references only, the
+    offline batch bit for bit."""
+    import sweep_parity
+    n, total, with_model, ties = sweep_parity.run_live_multi_sweep(ra, ctx, 20, seed=7)
+    assert n == 20 and total >= 5 and ties <= 1

@@ -280,11 +280,13 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         wave_lds_sync();
         // only the mirrors are read back: bin 240-k of lane l, k2 = 0..7, is Z[(16-l) + 16(14-k2)] (lane 0: Z[16(15-k2)]),
         // i.e. registers 7..14 of the partner lane
-#ifndef RP_ABL_NOMIR
+#if !defined(RP_ABL_NOMIR) && !defined(RP_MFCC_DPP_MIRROR)
 #pragma unroll
         for (int k2 = 7; k2 < 15; ++k2) lds_write_b64(zdst + 16 * k2, z[k2]);
 #endif
+#ifndef RP_MFCC_DPP_MIRROR
         wave_lds_sync();
+#endif
         // ---- untangle the two interleaved real sequences, bins k = l + 16*k2 <= 120 together with their
         // mirrors 240-k (X[240-k] = conj(E - W480^k O) shares E, O and the twiddle product with X[k]).
         // Everything is kept at twice its value; the factor 4 on the powers is removed before the log.
@@ -293,7 +295,17 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         for (int k2 = 0; k2 < 8; ++k2) {
             const int k = l + 16 * k2;
             const v2f a = z[k2];
-#ifndef RP_ABL_NOMIR
+#if defined(RP_MFCC_DPP_MIRROR)
+            // A/B: the partner's register by two DPP moves (row_mirror: lane l <- 15 - l, then row_ror:1: lane l <- l - 1, together
+            // lane l <- 16 - l) instead of the LDS exchange; lane 0 pairs with its own registers
+            auto mir = [](float x) {
+                const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true);
+                return __int_as_float(__builtin_amdgcn_update_dpp(0, t, 0x121, 0xf, 0xf, true));
+            };
+            const v2f own = k2 == 0 ? a : z[15 - k2];
+            const v2f far = (v2f){mir(z[14 - k2].x), mir(z[14 - k2].y)};
+            const v2f b = l == 0 ? own : far;
+#elif !defined(RP_ABL_NOMIR)
             const v2f b = (k2 == 0 && l == 0) ? a : lds_read_b64(zmir - 16 * k2);
 #else
             const v2f b = z[14 - k2];

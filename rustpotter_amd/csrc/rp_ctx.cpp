@@ -183,6 +183,52 @@ void Ctx::time_collect() {
     pending.clear();
 }
 
+// f32 -> f16 bits, rounded toward zero (what v_cvt_pkrtz_f16_f32 does to the window side); |v| <= 1 here
+static uint16_t f16_rtz_bits(float v) {
+    uint32_t b;
+    std::memcpy(&b, &v, 4);
+    const uint32_t sign = (b >> 16) & 0x8000u, mant = b & 0x7fffffu;
+    const int be = (int)((b >> 23) & 0xff), e = be - 127;
+    if (be == 0 || e < -24) return (uint16_t)sign;
+    if (e > 15) return (uint16_t)(sign | 0x7bffu);
+    if (e < -14) return (uint16_t)(sign | ((0x800000u | mant) >> (-e - 1)));
+    return (uint16_t)(sign | ((uint32_t)(e + 15) << 10) | (mant >> 13));
+}
+static float f16_bits_to_f32(uint16_t hb) {
+    const int e = (hb >> 10) & 0x1f;
+    const uint32_t m = hb & 0x3ffu;
+    const float v = e == 0 ? std::ldexp((float)m, -24) : std::ldexp((float)(0x400u | m), e - 25);
+    return (hb & 0x8000u) ? -v : v;
+}
+
+// dtw_mfma_kernel's A operand of one chunk (rp_dtw_mfma.hip): per template row r [k half 2][template slot 8] x 8 f16.  With
+// a = -(unit row) = a0 + a1 (a0 = rtz_f16(a), a1 = rtz_f16(a - a0)) and the half's components (ca, cb) = (0, 1) / (3, 4), the eight
+// slots pair with the window side's (xa0, xb0 | xa1, xb1 | xa0, xb0 | x2_0, x2_1 or 1.0):
+//   [ca.0, cb.0 | ca.0, cb.0 | ca.1, cb.1 | half 0: c2.0, c2.0 / half 1: c2.1, 1.0]
+// i.e. x0 a0 + x1 a0 + x0 a1 for every component, and 1.0 x 1.0: the instruction accumulates 1 - a.x.  Slots past the chunk's
+// count and the 12 rows after the last one are zero.
+static void append_mfma_image(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad) {
+    const int K = 5;
+    const size_t base = img.size();
+    img.resize(base + (size_t)(c.len + 12) * kDtwMfmaRowBytes / 2, 0);
+    for (int r = 0; r < c.len; ++r)
+        for (int t = 0; t < c.count; ++t) {
+            uint16_t p[5][2];
+            for (int k = 0; k < K; ++k) {
+                const float a = -unit[((size_t)c.tid[t] * Lpad + r) * K + k];
+                p[k][0] = f16_rtz_bits(a);
+                p[k][1] = f16_rtz_bits(a - f16_bits_to_f32(p[k][0]));
+            }
+            for (int kh = 0; kh < 2; ++kh) {
+                const int ca = kh ? 3 : 0, cb = ca + 1;
+                uint16_t sl[8] = {p[ca][0], p[cb][0], p[ca][0], p[cb][0], p[ca][1], p[cb][1], 0, 0};
+                if (kh == 0) { sl[6] = p[2][0]; sl[7] = p[2][0]; }
+                else { sl[6] = p[2][1]; sl[7] = 0x3c00; }
+                std::memcpy(&img[base + ((size_t)r * kDtwMfmaRowBytes + kh * 128 + t * 16) / 2], sl, 16);
+            }
+        }
+}
+
 // Template rows are scaled to unit L2 norm in f64 and rounded once to f32; an all-zero
 // row stays zero so that its cosine similarity is 0 (src/mfcc/comparator.rs:43-47).
 Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len,
@@ -266,6 +312,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     }
     std::vector<DtwChunk> chunks;
     std::vector<float> dup;
+    std::vector<uint16_t> aimg;  // dtw_mfma_kernel's A images (mfcc_size 5, chunks of 3..8 templates)
     // class 4 (not a launch class of its own): the tc-4 halves of the class-2 chunks, see TemplatesDev::split_first
     std::vector<DtwChunk> halves;
     bool can_split = !byclass[2].empty();
@@ -283,6 +330,12 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         else { d.split_first = (int)chunks.size(); d.split_count = (int)halves.size(); }
         for (DtwChunk c : (cls < 4 ? byclass[cls] : halves)) {
             c.rows_off = (int)dup.size();
+            c.aimg_off = 0;
+            if (K == 5 && (cls == 1 || cls == 2)) {
+                c.aimg_off = (int)(aimg.size() * sizeof(uint16_t) / 16);
+                append_mfma_image(aimg, c, unit.data(), Lpad);
+                d.mfma_min_len = d.mfma_min_len == 0 ? c.len : std::min(d.mfma_min_len, c.len);
+            }
             for (int r = 0; r < c.len; ++r)
                 for (int pr = 0; pr < c.tc / 2; ++pr)
                     for (int k = 0; k < K; ++k)
@@ -297,6 +350,10 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.dup), sizeof(float) * dup.size()), "hipMalloc(dup)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.chunks, chunks.data(), sizeof(DtwChunk) * chunks.size(), hipMemcpyHostToDevice), "hipMemcpy(chunks)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.dup, dup.data(), sizeof(float) * dup.size(), hipMemcpyHostToDevice), "hipMemcpy(dup)")) return nullptr;
+    if (!aimg.empty()) {
+        if (!hip_ok(hipMalloc(&d.aimg, sizeof(uint16_t) * aimg.size()), "hipMalloc(aimg)")) return nullptr;
+        if (!hip_ok(hipMemcpy(d.aimg, aimg.data(), sizeof(uint16_t) * aimg.size(), hipMemcpyHostToDevice), "hipMemcpy(aimg)")) return nullptr;
+    }
     return tp.release();
 }
 
@@ -305,6 +362,7 @@ Templates::~Templates() {
     if (dev.unit) (void)hipFree(dev.unit);
     if (dev.chunks) (void)hipFree(dev.chunks);
     if (dev.dup) (void)hipFree(dev.dup);
+    if (dev.aimg) (void)hipFree(dev.aimg);
 }
 
 // f32 -> bf16, round to nearest even (matches the kernel's in-register conversion)

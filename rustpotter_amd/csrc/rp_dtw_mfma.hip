@@ -1,0 +1,307 @@
+// rp_dtw_mfma.hip -- dtw_mfma_kernel: the banded DTW of mfcc_size 5 with the cosine costs on the matrix cores (DESIGN.md §4.2,
+// round 3).  Same scoring as dtw_band_kernel (src/mfcc/dtw.rs:56-105 + comparator.rs:15-48 + normalizer.rs:17-29 +
+// wakeword_comp.rs:22-37), other arithmetic for the cell cost:
+//
+//   * dtw_band_kernel spends 5 of the 8 issue slots of a band cell of a template pair on v_pk_fma_f32 for `1 - a.x` -- at the f32
+//     FMA peak of the vector pipe (tools/scratch/valu_rate_probe.hip: 4.7 cycles per packed op, 4.2 per v_min3_f32).  Here the costs of
+//     a whole band COLUMN come out of v_mfma_f32_32x32x16_f16 and the vector pipe only runs the recurrence.
+//   * A wave owns 32 windows x one chunk of up to 8 same-length templates.  Lane l = (window l & 31, half h = l >> 5) runs the
+//     recurrence of templates 4h..4h+3 (two packed pairs) of its window: the MFMA's C/D layout (col = lane & 31,
+//     row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) puts exactly those costs into that lane, pairs in consecutive registers.
+//   * Column-major sweep: step c takes window frame c against the 2W template rows of its band (rows c-W+1 .. c+W).  M = 8
+//     templates x 12 circular row slots (row r lives in slot r mod 12) = 3 tiles of 32 rows, N = 32 windows, K = 16 f16 slots
+//     = one instruction per tile.  A (the negated unit rows, split on the host, 256 B per template row in LDS) changes by one
+//     row per template and column: one tile's operand is re-read per column.
+//   * Precision: x = x0 + x1, a = a0 + a1 with x0 = rtz_f16(x), x1 = rtz_f16(x - x0) (22 significant bits); the slots hold
+//     x0 a0, x1 a0, x0 a1 for the five components (15) and 1.0 x 1.0, accumulated in f32 on C = 0: the instruction leaves
+//     1 - a.x with an error below 2^-20 (measured against the f32 CPU restatement: scores within 1e-6; the parity gate is 1e-5).
+//     Lane (n, h) centres, scales and splits only components (0, 1) or (3, 4) and component 2; the two partial squared norms
+//     meet through v_permlane32_swap.
+//   * Software pipeline per column c: the A tile of column c+1 is re-read, the cells of column c run (two independent chains of
+//     v_min3_f32 x2 + add x2 per cell), each tile's MFMA for column c+1 is issued right after the last cell that reads the tile, and
+//     the frame of column c+2 is prepared in ten pieces between the cells.  Columns are unrolled 12 at a time so that every
+//     slot, tile and band index is a compile-time register.
+// Measured (tools/scratch/dtw_mfma_probe2.hip, 8 192 streams x 288 windows x 8 templates of 100 frames): 1.62 ms against 2.36 ms at
+// dtw_band_kernel's C3 rate; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles), matrix pipe 21 % busy.
+#include "rp_device.h"
+
+#include <cstdlib>
+
+namespace rp {
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMK = 5;         // MFCC coefficients per frame
+constexpr int kMSlots = 12;    // circular template-row slots = 3 MFMA tiles x 4
+constexpr int kMWin = 32;      // windows per wave
+
+__device__ __forceinline__ unsigned pkrtz(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+__device__ __forceinline__ float lo_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[0]; }
+__device__ __forceinline__ float hi_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[1]; }
+
+// last band position q of column phase u whose MFMA row slot (u + q + 12 - W + 2) mod 12 lies in tile g; -1: the tile is not read
+template <int W>
+__host__ __device__ constexpr int mfma_last_use(int u, int g) {
+    int last = -1;
+    for (int q = 0; q < 2 * W; ++q)
+        if (((u + q + kMSlots - W + 2) % kMSlots) / 4 == g) last = q;
+    return last;
+}
+
+}  // namespace
+
+// One workgroup = NW waves on one chunk (its A image is staged once); waves walk the 32-entry tiles of the flattened
+// (stream, window) space grid-stride.  A tile may straddle two streams (n_win >= 32).  dense_count / dense_min: the DENSE
+// mode of the averaged-template gate (rp_dtw.hip GateList): the launch does nothing unless *dense_count >= dense_min.
+template <int W, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
+    size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
+    float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *dense_count,
+    uint32_t dense_min) {
+    constexpr int K = kMK, B = 2 * W, NS = kMSlots;
+    constexpr int kRowBytes = kDtwMfmaRowBytes;
+    static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 12 row slots");
+    if (dense_count && *dense_count < dense_min) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned ci = blockIdx.x % n_chunks;
+    const size_t group = blockIdx.x / n_chunks, n_groups = gridDim.x / n_chunks;
+    const DtwChunk *ch = chunks + chunk_base + ci;
+    const int L = ch->len;  // m == n == L
+    const int a_bytes = (max_len + NS) * kRowBytes;
+    const int xs_floats = dtw_mfma_stage_floats(max_len);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const u32x4 *asrc = reinterpret_cast<const u32x4 *>(aimg) + ch->aimg_off;
+        u32x4 *adst = reinterpret_cast<u32x4 *>(smem);
+        for (int i = tid; i < (L + NS) * kRowBytes / 16; i += 64 * NW) adst[i] = asrc[i];
+    }
+    __syncthreads();
+    float *xs = reinterpret_cast<float *>(smem + a_bytes) + wave * xs_floats;
+    const int n = lane & 31, h = lane >> 5;
+    // A operand: this lane supplies row m = lane & 31 of a tile = (slot 4g + jj, template 4h' + r'), k half = lane >> 5
+    const int jj = (lane & 31) >> 3, tA = ((lane >> 2) & 1) * 4 + (lane & 3);
+    const unsigned a_lane = (unsigned)(h * 128 + tA * 16);
+    unsigned dl[4];  // byte offset back to the row this lane's slot holds when the newest row sits in slot e of its tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dl[e] = (unsigned)(((e - jj + NS) % NS) * kRowBytes);
+    const unsigned sel_one = h ? 0x07060100u : 0x03020100u;  // slot 7: x1 of component 2 (half 0) / the constant 1.0 (half 1)
+    const size_t total_entries = n_streams * n_win;
+
+    for (size_t tile = group * NW + wave; tile < total_tiles; tile += n_groups * NW) {
+        // ---- lanes -> (stream, window); stage the frames of up to two stream segments ----
+        const size_t f0 = tile * kMWin;
+        const size_t sA = f0 / n_win;
+        const int wA = (int)(f0 - sA * n_win);
+        const int nA = (int)n_win - wA < kMWin ? (int)n_win - wA : kMWin;
+        const int nB = (nA < kMWin && sA + 1 < n_streams) ? kMWin - nA : 0;
+        const int segA = nA + L + 2;  // frames staged for the first segment (columns L + 1, L + 2 are read ahead, never used)
+        {
+            const float *src = mfcc + sA * frame_pitch * K;
+            const size_t g0 = first_win + wA;
+            for (int i = lane; i < segA * K; i += 64) {
+                const int f = i / K;
+                xs[i] = g0 + f < n_frames_total ? src[g0 * K + i] : 0.f;
+            }
+        }
+        if (nB > 0) {
+            const float *src = mfcc + (sA + 1) * frame_pitch * K;
+            const int segB = nB + L + 2;
+            for (int i = lane; i < segB * K; i += 64) {
+                const int f = i / K;
+                xs[segA * K + i] = first_win + f < n_frames_total ? src[first_win * K + i] : 0.f;
+            }
+        }
+        wave_lds_sync();
+        const bool inA = n < nA;
+        const bool valid = inA || (n - nA < nB);
+        const size_t s = inA ? sA : sA + 1;
+        const int w = inA ? wA + n : n - nA;
+        const float *xw = xs + (inA ? n : (valid ? segA + n - nA : 0)) * K;
+        const float *xa = xw + (h ? 3 : 0);  // this half's two components; component 2 at xw + 2
+        const float *x2 = xw + 2;
+        // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums (of this lane's three components)
+        float mua = 0.f, mub = 0.f, mu2 = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
+        mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;
+
+        // Q[p][q] = D[(c - 1) - W + 1 + q][c - 1] of the template pair p (band position, as P[] of dtw_band_kernel with rows and
+        // columns swapped); column 0: D[0][0] = 0 sits at q = W - 1.  Q[p][B] stays +inf (the cell below the band).
+        v2f Q[2][B + 1];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int q = 0; q <= B; ++q) Q[p][q] = (v2f){RP_INF, RP_INF};
+            Q[p][W - 1] = (v2f){0.f, 0.f};
+        }
+        u32x4 Areg[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int slot = 4 * g + jj;
+            int r = W - ((W - slot + NS) % NS);  // 1-based template row in this slot for the state "newest row = W"
+            r = r < 1 ? 1 : r;
+            Areg[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)(r - 1) * kRowBytes);
+        }
+        v16f acc[3];   // costs of the current column; a tile is refilled for the next column as soon as its last cell is done
+        u32x4 bop[2];  // B operand of column cc in bop[cc & 1]: built two columns ahead, in pieces between the cells
+
+// The frame work of column cc, cut into ten pieces P0..P9 that are placed between the cells of the recurrence.
+#define RP_P0(cc) fa_ = xa[((cc) - 1) * K]; fb_ = xa[((cc) - 1) * K + 1]; f2_ = x2[((cc) - 1) * K];
+#define RP_P1(cc) da_ = fa_ - mua; db_ = fb_ - mub; d2_ = f2_ - mu2;
+#define RP_P2(cc) own_ = fmaf(da_, da_, db_ * db_);
+#define RP_P3(cc) { const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(own_), __float_as_uint(own_), false, false); \
+                    bb_ = fmaf(d2_, d2_, __uint_as_float(sw_[0]) + __uint_as_float(sw_[1])); }
+#define RP_P4(cc) inv_ = bb_ > 0.f ? __builtin_amdgcn_rsqf(bb_) : 0.f;  /* zero frame -> zero vector -> cost 1 (comparator.rs:43-47) */
+#define RP_P5(cc) ua_ = da_ * inv_; ub_ = db_ * inv_; u2_ = d2_ * inv_;
+#define RP_P6(cc, par) bop[par].x = pkrtz(ua_, ub_); bop[par].z = bop[par].x;
+#define RP_P7(cc, par) bop[par].y = pkrtz(ua_ - lo_f32(bop[par].x), ub_ - hi_f32(bop[par].x));
+#define RP_P8(cc) t_ = pkrtz(u2_, 0.f);
+#define RP_P9(cc, par) bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pkrtz(u2_, u2_ - lo_f32(t_)), sel_one);
+#define RP_PREP_ALL(cc, par) RP_P0(cc) RP_P1(cc) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)
+// the A tile that receives template row cc + W (cc = 1 + uu mod 12)
+#define RP_AREF(cc, uu, GUARD)                                                                                                \
+    {                                                                                                                         \
+        const int sn = ((uu) + 1 + W) % NS, g = sn / 4, e = sn % 4;                                                           \
+        int off = ((cc) + W - 1) * kRowBytes - (int)dl[e];                                                                    \
+        if (GUARD) off = off < 0 ? 0 : off;                                                                                   \
+        Areg[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)off);                                            \
+    }
+#define RP_MFMA(g, par)                                                                                                       \
+    do {                                                                                                                      \
+        const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  \
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g]), __builtin_bit_cast(f16x8, bop[par]), zero16, 0, 0, 0); \
+    } while (0)
+
+// column c (c = 1 + u mod 12): rows r_q = c - W + 1 + q, q = 0..2W-1, sit in MFMA row slot (u + q + 14 - W) mod 12
+#define RP_STEP(GUARD)                                                                                                        \
+    do {                                                                                                                      \
+        RP_AREF(c + 1, (u + 1) % NS, GUARD)                                                                                   \
+        v2f up[2] = {(v2f){RP_INF, RP_INF}, (v2f){RP_INF, RP_INF}};                                                           \
+        _Pragma("unroll") for (int q = 0; q < B; ++q) {                                                                       \
+            const int sl = (u + q + NS - W + 2) % NS;                                                                         \
+            _Pragma("unroll") for (int p = 0; p < 2; ++p) { /* two independent chains, interleaved */                         \
+                const v2f cost = (v2f){acc[sl / 4][4 * (sl % 4) + 2 * p], acc[sl / 4][4 * (sl % 4) + 2 * p + 1]};             \
+                v2f m, v;                                                                                                     \
+                m.x = fminf(fminf(up[p].x, Q[p][q + 1].x), Q[p][q].x);                                                        \
+                m.y = fminf(fminf(up[p].y, Q[p][q + 1].y), Q[p][q].y);                                                        \
+                v.x = cost.x + m.x; v.y = cost.y + m.y; /* two plain adds (2.4 cycles each) beat v_pk_add_f32 (4.7 + a wait state) */ \
+                if (GUARD) v = (c - W + 1 + q >= 1) ? v : (v2f){RP_INF, RP_INF};                                              \
+                Q[p][q] = v;                                                                                                  \
+                up[p] = v;                                                                                                    \
+            }                                                                                                                 \
+            /* piece k of the frame of column c + 2 after cell (k B) / 10: the pieces fill the wait states between a cell's adds  \
+               and the next cell's v_min3 */                                                                                  \
+            if (q == (0 * B) / 10) { RP_P0(c + 2) } if (q == (1 * B) / 10) { RP_P1(c + 2) } if (q == (2 * B) / 10) { RP_P2(c + 2) } \
+            if (q == (3 * B) / 10) { RP_P3(c + 2) } if (q == (4 * B) / 10) { RP_P4(c + 2) } if (q == (5 * B) / 10) { RP_P5(c + 2) } \
+            if (q == (6 * B) / 10) { RP_P6(c + 2, (u + 1) & 1) } if (q == (7 * B) / 10) { RP_P7(c + 2, (u + 1) & 1) }         \
+            if (q == (8 * B) / 10) { RP_P8(c + 2) } if (q == (9 * B) / 10) { RP_P9(c + 2, (u + 1) & 1) }                      \
+            _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                                     \
+                if (mfma_last_use<W>(u, g) == q) RP_MFMA(g, u & 1);                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                                         \
+            if (mfma_last_use<W>(u, g) < 0) RP_MFMA(g, u & 1);                                                                \
+    } while (0)
+
+        float fa_, fb_, f2_, da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_;
+        unsigned t_;
+        RP_AREF(1, 0, true)
+        RP_PREP_ALL(1, 1)
+        RP_MFMA(0, 1); RP_MFMA(1, 1); RP_MFMA(2, 1);
+        RP_PREP_ALL(2, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        int c0 = 1;
+        {   // first block: cells of rows < 1 stay +inf (L >= 12)
+#pragma unroll
+            for (int u = 0; u < NS; ++u) { const int c = c0 + u; RP_STEP(true); }
+        }
+        for (c0 = 1 + NS; c0 + NS - 1 <= L; c0 += NS) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) { const int c = c0 + u; RP_STEP(false); }
+        }
+#pragma unroll
+        for (int u = 0; u < NS - 1; ++u) {  // the last L mod 12 columns
+            const int c = c0 + u;
+            if (c <= L) RP_STEP(false);
+        }
+#undef RP_STEP
+#undef RP_MFMA
+#undef RP_AREF
+#undef RP_PREP_ALL
+#undef RP_P0
+#undef RP_P1
+#undef RP_P2
+#undef RP_P3
+#undef RP_P4
+#undef RP_P5
+#undef RP_P6
+#undef RP_P7
+#undef RP_P8
+#undef RP_P9
+
+        // D[m - 1][n] with m == n == L (dtw.rs:101): band position q = (L - 1) - (L - W + 1) = W - 2
+        if (valid && f0 + n < total_entries) {
+            const size_t row = s * out_win_pitch + (size_t)w;
+            const float denom = (float)(L + L);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int slot = 4 * h + 2 * p + e;
+                    if (slot < ch->count) {
+                        const float cost = e ? Q[p][W - 2].y : Q[p][W - 2].x;
+                        const float nc = cost / denom;
+                        const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+                        const int t = ch->tid[slot];
+                        if (t < T) scores[row * T + t] = sc;
+                        else avg[row] = sc;
+                    }
+                }
+            }
+        }
+        wave_lds_sync();  // the next tile restages xs
+    }
+}
+
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, int chunk_base, int n_chunks) {
+    static const bool off = [] { const char *e = std::getenv("RP_DTW_MFMA"); return e && e[0] == '0'; }();
+    if (off || t.K != kMK || band != 5 || !t.aimg || n_chunks <= 0 || t.max_diff != 0 || n_win < (size_t)kMWin) return false;
+    if (t.mfma_min_len < kMSlots) return false;  // the first 12 columns are one unguarded block
+    (void)chunk_base;
+    return dtw_mfma_lds_bytes(t.max_len, 8) <= 160 * 1024;
+}
+
+hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
+                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
+                           const uint32_t *dense_count, uint32_t dense_min) {
+    if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
+    const size_t total_tiles = (S * n_win + kMWin - 1) / kMWin;
+    const int nw = dtw_mfma_lds_bytes(t.max_len, 12) <= 160 * 1024 ? 12 : 8;
+    const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw);
+    // one workgroup per CU and chunk group; a workgroup's waves walk the tiles grid-stride
+    size_t groups = (size_t)device_cu_count() / (size_t)n_chunks;
+    if (groups < 1) groups = 1;
+    const size_t need = (total_tiles + nw - 1) / nw;
+    if (groups > need) groups = need;
+    const size_t blocks = groups * (size_t)n_chunks;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+#define RP_LAUNCH_MFMA(NW)                                                                                                          \
+    do {                                                                                                                            \
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<5, NW>), 160 * 1024); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((dtw_mfma_kernel<5, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch,  \
+                           total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
+                           reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, dense_count, dense_min); \
+    } while (0)
+    if (nw == 12) RP_LAUNCH_MFMA(12);
+    else RP_LAUNCH_MFMA(8);
+#undef RP_LAUNCH_MFMA
+    return hipGetLastError();
+}
+
+}  // namespace rp

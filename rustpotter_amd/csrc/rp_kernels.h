@@ -67,7 +67,16 @@ struct DtwChunk {
     int tc;               // register tile the kernel is instantiated for: 2, 4 or 8
     int rows_off;         // float offset of the chunk's rows in TemplatesDev::dup
     int tid[kChunkMax];   // output column of each template; T means the averaged template
+    int aimg_off;         // chunks of 3..8 templates at mfcc_size 5: offset (16-byte units) of the chunk's A image in TemplatesDev::aimg
 };
+
+// dtw_mfma_kernel (rp_dtw_mfma.hip): A image = per template row [k half 2][template 8] x 8 f16 (the negated unit row, split in two f16
+// parts, in the slot order of the MFMA's B operand) for len + 12 rows (the tail rows are zero); per wave two stream segments of frames.
+constexpr int kDtwMfmaRowBytes = 256;
+__host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 + 2 * (max_len + 2)) * 5 + 3) & ~3; }
+inline size_t dtw_mfma_lds_bytes(int max_len, int waves) {
+    return (size_t)(max_len + 12) * kDtwMfmaRowBytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);
+}
 
 // Device-resident template set of one wakeword reference.
 struct TemplatesDev {
@@ -90,7 +99,17 @@ struct TemplatesDev {
     // every class-2 chunk once more as two tc-4 halves (only when each of them holds 7 or 8 templates): a small batch whose
     // tc-8 waves would fill the chip 2.x times is scored by twice as many tc-4 waves, three resident per SIMD instead of two
     int split_first = 0, split_count = 0;
+    // dtw_mfma_kernel: A images of the class-1 and class-2 chunks (mfcc_size 5 only), and the shortest template among them
+    void *aimg = nullptr;
+    int mfma_min_len = 0;
 };
+
+// The matrix-core DTW kernel for chunks [chunk_base, chunk_base + n_chunks) of classes 1 / 2 (3..8 templates): mfcc_size 5, band 5,
+// LDS-staged launches over every window (n_win >= 32), no early abandon.  dense_count / dense_min: DENSE mode of the averaged-template gate.
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, int chunk_base, int n_chunks);
+hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
+                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
+                           const uint32_t *dense_count, uint32_t dense_min);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs
 // (one rp_ctx per device) has to set it on each of them.  Sets it once per (current device, kernel), thread-safe.

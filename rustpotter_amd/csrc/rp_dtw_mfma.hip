@@ -56,18 +56,29 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 }  // namespace
 
 // One workgroup = NW waves on one chunk (its A image is staged once); waves walk the 32-entry tiles of the flattened
-// (stream, window) space grid-stride.  A tile may straddle two streams (n_win >= 32).  dense_count / dense_min: the DENSE
-// mode of the averaged-template gate (rp_dtw.hip GateList): the launch does nothing unless *dense_count >= dense_min.
-template <int W, int NW>
+// (stream, window) space grid-stride.  GX = false: a tile's frames are staged in LDS, a tile may straddle two streams
+// (n_win >= 32).  GX = true: lanes read their window's frames from global memory (live-stream batches: a few windows per
+// stream; LIST mode of the averaged-template gate: list[] holds the rows that passed, *count of them).  list == nullptr with a
+// count: DENSE mode of the gate -- the launch does nothing unless *count >= dense_min; LIST mode does nothing when the list is
+// dense (rp_dtw.hip GateList).  abandon_nc < inf: early abandon of detect-only calls -- every 12 columns a wave stops when the
+// cheapest band cell of every (window, template) it holds is past abandon_nc * (m + n), writing score 0 (cell costs are >= 0 and
+// every warping path crosses every column, so that cell bounds the final cost from below; the averaged template never stops).
+template <int W, int NW, bool GX>
 __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
-    float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *dense_count,
-    uint32_t dense_min) {
+    float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,
+    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc) {
     constexpr int K = kMK, B = 2 * W, NS = kMSlots;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
     static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 12 row slots");
-    if (dense_count && *dense_count < dense_min) return;
+    size_t total_entries = n_streams * n_win;
+    if (list) {
+        const uint32_t n_listed = *count;
+        if (dense_min && n_listed >= dense_min) return;
+        total_entries = n_listed;
+        total_tiles = ((size_t)n_listed + kMWin - 1) / kMWin;
+    } else if (count && *count < dense_min) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned ci = blockIdx.x % n_chunks;
     const size_t group = blockIdx.x / n_chunks, n_groups = gridDim.x / n_chunks;
@@ -76,6 +87,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const int a_bytes = (max_len + NS) * kRowBytes;
     const int xs_floats = dtw_mfma_stage_floats(max_len);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (group * NW >= total_tiles) return;  // workgroup-uniform: nothing for this workgroup (short lists)
     {
         const u32x4 *asrc = reinterpret_cast<const u32x4 *>(aimg) + ch->aimg_off;
         u32x4 *adst = reinterpret_cast<u32x4 *>(smem);
@@ -83,6 +95,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     }
     __syncthreads();
     float *xs = reinterpret_cast<float *>(smem + a_bytes) + wave * xs_floats;
+    (void)xs;
     const int n = lane & 31, h = lane >> 5;
     // A operand: this lane supplies row m = lane & 31 of a tile = (slot 4g + jj, template 4h' + r'), k half = lane >> 5
     const int jj = (lane & 31) >> 3, tA = ((lane >> 2) & 1) * 4 + (lane & 3);
@@ -91,43 +104,61 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) dl[e] = (unsigned)(((e - jj + NS) % NS) * kRowBytes);
     const unsigned sel_one = h ? 0x07060100u : 0x03020100u;  // slot 7: x1 of component 2 (half 0) / the constant 1.0 (half 1)
-    const size_t total_entries = n_streams * n_win;
+    const float abandon_cost = abandon_nc * (float)(L + L);
+    // which of this lane's four templates can keep a wave alive: real ones; the averaged template (tid >= T) always does
+    bool slot_real[4], slot_avg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { slot_real[e] = 4 * h + e < ch->count; slot_avg[e] = slot_real[e] && ch->tid[4 * h + e] >= T; }
 
     for (size_t tile = group * NW + wave; tile < total_tiles; tile += n_groups * NW) {
-        // ---- lanes -> (stream, window); stage the frames of up to two stream segments ----
+        // ---- lanes -> (stream, window) ----
         const size_t f0 = tile * kMWin;
-        const size_t sA = f0 / n_win;
-        const int wA = (int)(f0 - sA * n_win);
-        const int nA = (int)n_win - wA < kMWin ? (int)n_win - wA : kMWin;
-        const int nB = (nA < kMWin && sA + 1 < n_streams) ? kMWin - nA : 0;
-        const int segA = nA + L + 2;  // frames staged for the first segment (columns L + 1, L + 2 are read ahead, never used)
-        {
-            const float *src = mfcc + sA * frame_pitch * K;
-            const size_t g0 = first_win + wA;
-            for (int i = lane; i < segA * K; i += 64) {
-                const int f = i / K;
-                xs[i] = g0 + f < n_frames_total ? src[g0 * K + i] : 0.f;
+        bool valid;
+        size_t s;
+        int w;
+        const float *xw;
+        if (GX) {
+            size_t f = f0 + n;
+            valid = f < total_entries;
+            if (list) f = list[valid ? f : total_entries - 1];  // row ids s * n_win + w of the windows that passed the gate
+            s = valid ? f / n_win : 0;
+            w = valid ? (int)(f - s * n_win) : 0;
+            xw = mfcc + (s * frame_pitch + first_win + (size_t)w) * K;  // the caller leaves W * K floats of slack after the last frame
+        } else {
+            // stage the frames of up to two stream segments (columns L + 1 .. L + 3 are read ahead, never used)
+            const size_t sA = f0 / n_win;
+            const int wA = (int)(f0 - sA * n_win);
+            const int nA = (int)n_win - wA < kMWin ? (int)n_win - wA : kMWin;
+            const int nB = (nA < kMWin && sA + 1 < n_streams) ? kMWin - nA : 0;
+            const int segA = nA + L + 3;
+            {
+                const float *src = mfcc + sA * frame_pitch * K;
+                const size_t g0 = first_win + wA;
+                for (int i = lane; i < segA * K; i += 64) {
+                    const int f = i / K;
+                    xs[i] = g0 + f < n_frames_total ? src[g0 * K + i] : 0.f;
+                }
             }
-        }
-        if (nB > 0) {
-            const float *src = mfcc + (sA + 1) * frame_pitch * K;
-            const int segB = nB + L + 2;
-            for (int i = lane; i < segB * K; i += 64) {
-                const int f = i / K;
-                xs[segA * K + i] = first_win + f < n_frames_total ? src[first_win * K + i] : 0.f;
+            if (nB > 0) {
+                const float *src = mfcc + (sA + 1) * frame_pitch * K;
+                const int segB = nB + L + 3;
+                for (int i = lane; i < segB * K; i += 64) {
+                    const int f = i / K;
+                    xs[segA * K + i] = first_win + f < n_frames_total ? src[first_win * K + i] : 0.f;
+                }
             }
+            wave_lds_sync();
+            const bool inA = n < nA;
+            valid = inA || (n - nA < nB);
+            s = inA ? sA : sA + 1;
+            w = inA ? wA + n : n - nA;
+            xw = xs + (inA ? n : (valid ? segA + n - nA : 0)) * K;
         }
-        wave_lds_sync();
-        const bool inA = n < nA;
-        const bool valid = inA || (n - nA < nB);
-        const size_t s = inA ? sA : sA + 1;
-        const int w = inA ? wA + n : n - nA;
-        const float *xw = xs + (inA ? n : (valid ? segA + n - nA : 0)) * K;
         const float *xa = xw + (h ? 3 : 0);  // this half's two components; component 2 at xw + 2
         const float *x2 = xw + 2;
         // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums (of this lane's three components)
         float mua = 0.f, mub = 0.f, mu2 = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
         mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;
 
@@ -195,9 +226,9 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
                 Q[p][q] = v;                                                                                                  \
                 up[p] = v;                                                                                                    \
             }                                                                                                                 \
-            /* piece k of the frame of column c + 2 after cell (k B) / 10: the pieces fill the wait states between a cell's adds  \
-               and the next cell's v_min3 */                                                                                  \
-            if (q == (0 * B) / 10) { RP_P0(c + 2) } if (q == (1 * B) / 10) { RP_P1(c + 2) } if (q == (2 * B) / 10) { RP_P2(c + 2) } \
+            /* piece k of the frame of column c + 2 after cell (k B) / 10 (its values were requested one column earlier, P0): the  \
+               pieces fill the wait states between a cell's adds and the next cell's v_min3 */                                                                                  \
+            if (q == (0 * B) / 10) { RP_P1(c + 2) RP_P0(c + 3) } if (q == (2 * B) / 10) { RP_P2(c + 2) }                       \
             if (q == (3 * B) / 10) { RP_P3(c + 2) } if (q == (4 * B) / 10) { RP_P4(c + 2) } if (q == (5 * B) / 10) { RP_P5(c + 2) } \
             if (q == (6 * B) / 10) { RP_P6(c + 2, (u + 1) & 1) } if (q == (7 * B) / 10) { RP_P7(c + 2, (u + 1) & 1) }         \
             if (q == (8 * B) / 10) { RP_P8(c + 2) } if (q == (9 * B) / 10) { RP_P9(c + 2, (u + 1) & 1) }                      \
@@ -215,21 +246,43 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         RP_PREP_ALL(1, 1)
         RP_MFMA(0, 1); RP_MFMA(1, 1); RP_MFMA(2, 1);
         RP_PREP_ALL(2, 0)
+        RP_P0(3)
         __builtin_amdgcn_sched_barrier(0);
         int c0 = 1;
+        bool dead = false;
         {   // first block: cells of rows < 1 stay +inf (L >= 12)
 #pragma unroll
             for (int u = 0; u < NS; ++u) { const int c = c0 + u; RP_STEP(true); }
         }
+// early abandon: wave-uniform, once per 12 columns
+#define RP_ABANDON_CHECK()                                                                                                    \
+    if (abandon_nc < RP_INF) {                                                                                                \
+        bool alive = false;                                                                                                   \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                       \
+            v2f m = Q[p][0];                                                                                                  \
+            _Pragma("unroll") for (int q = 1; q < B; ++q) m = (v2f){fminf(m.x, Q[p][q].x), fminf(m.y, Q[p][q].y)};             \
+            alive = alive || (slot_real[2 * p] && (m.x <= abandon_cost || slot_avg[2 * p])) ||                                \
+                    (slot_real[2 * p + 1] && (m.y <= abandon_cost || slot_avg[2 * p + 1]));                                   \
+        }                                                                                                                     \
+        if (!__any(alive && valid)) dead = true;                                                                              \
+    }
         for (c0 = 1 + NS; c0 + NS - 1 <= L; c0 += NS) {
+            RP_ABANDON_CHECK()
+            if (dead) break;
 #pragma unroll
             for (int u = 0; u < NS; ++u) { const int c = c0 + u; RP_STEP(false); }
         }
+        if (!dead && c0 <= L) {
+            RP_ABANDON_CHECK()
+            if (!dead) {
 #pragma unroll
-        for (int u = 0; u < NS - 1; ++u) {  // the last L mod 12 columns
-            const int c = c0 + u;
-            if (c <= L) RP_STEP(false);
+                for (int u = 0; u < NS - 1; ++u) {  // the last L mod 12 columns
+                    const int c = c0 + u;
+                    if (c <= L) RP_STEP(false);
+                }
+            }
         }
+#undef RP_ABANDON_CHECK
 #undef RP_STEP
 #undef RP_MFMA
 #undef RP_AREF
@@ -246,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #undef RP_P9
 
         // D[m - 1][n] with m == n == L (dtw.rs:101): band position q = (L - 1) - (L - W + 1) = W - 2
-        if (valid && f0 + n < total_entries) {
+        if (valid) {
             const size_t row = s * out_win_pitch + (size_t)w;
             const float denom = (float)(L + L);
 #pragma unroll
@@ -257,30 +310,31 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
                     if (slot < ch->count) {
                         const float cost = e ? Q[p][W - 2].y : Q[p][W - 2].x;
                         const float nc = cost / denom;
-                        const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+                        const float sc = dead ? 0.f : 1.f / (1.f + expf((nc - score_ref) / score_ref));
                         const int t = ch->tid[slot];
                         if (t < T) scores[row * T + t] = sc;
-                        else avg[row] = sc;
+                        else if (!dead) avg[row] = sc;
                     }
                 }
             }
         }
-        wave_lds_sync();  // the next tile restages xs
+        if (!GX) wave_lds_sync();  // the next tile restages xs
     }
 }
 
-bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, int chunk_base, int n_chunks) {
-    static const bool off = [] { const char *e = std::getenv("RP_DTW_MFMA"); return e && e[0] == '0'; }();
-    if (off || t.K != kMK || band != 5 || !t.aimg || n_chunks <= 0 || t.max_diff != 0 || n_win < (size_t)kMWin) return false;
-    if (t.mfma_min_len < kMSlots) return false;  // the first 12 columns are one unguarded block
-    (void)chunk_base;
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global) {
+    const char *env = std::getenv("RP_DTW_MFMA");  // "0": the register kernels only (A/B runs and the cross-check tests); read per call
+    if ((env && env[0] == '0') || t.K != kMK || band != 5 || !t.aimg || t.max_diff != 0) return false;
+    if (!from_global && n_win < (size_t)kMWin) return false;  // a staged tile holds at most two stream segments
+    if (t.mfma_min_len < kMSlots) return false;               // the first 12 columns are one unguarded block
     return dtw_mfma_lds_bytes(t.max_len, 8) <= 160 * 1024;
 }
 
 hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
-                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
-                           const uint32_t *dense_count, uint32_t dense_min) {
+                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, bool from_global,
+                           const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc) {
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
+    if (list && !from_global) return hipErrorNotSupported;
     const size_t total_tiles = (S * n_win + kMWin - 1) / kMWin;
     const int nw = dtw_mfma_lds_bytes(t.max_len, 12) <= 160 * 1024 ? 12 : 8;
     const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw);
@@ -291,15 +345,16 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base
     if (groups > need) groups = need;
     const size_t blocks = groups * (size_t)n_chunks;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-#define RP_LAUNCH_MFMA(NW)                                                                                                          \
+#define RP_LAUNCH_MFMA(NW, GXV)                                                                                                     \
     do {                                                                                                                            \
-        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<5, NW>), 160 * 1024); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((dtw_mfma_kernel<5, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch,  \
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<5, NW, GXV>), 160 * 1024); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((dtw_mfma_kernel<5, NW, GXV>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
-                           reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, dense_count, dense_min); \
+                           reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
+                           abandon_nc);                                                                                             \
     } while (0)
-    if (nw == 12) RP_LAUNCH_MFMA(12);
-    else RP_LAUNCH_MFMA(8);
+    if (from_global) { if (nw == 12) RP_LAUNCH_MFMA(12, true); else RP_LAUNCH_MFMA(8, true); }
+    else { if (nw == 12) RP_LAUNCH_MFMA(12, false); else RP_LAUNCH_MFMA(8, false); }
 #undef RP_LAUNCH_MFMA
     return hipGetLastError();
 }

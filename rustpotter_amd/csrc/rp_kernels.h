@@ -73,7 +73,7 @@ struct DtwChunk {
 // dtw_mfma_kernel (rp_dtw_mfma.hip): A image = per template row [k half 2][template 8] x 8 f16 (the negated unit row, split in two f16
 // parts, in the slot order of the MFMA's B operand) for len + 12 rows (the tail rows are zero); per wave two stream segments of frames.
 constexpr int kDtwMfmaRowBytes = 256;
-__host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 + 2 * (max_len + 2)) * 5 + 3) & ~3; }
+__host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 + 2 * (max_len + 3)) * 5 + 3) & ~3; }
 inline size_t dtw_mfma_lds_bytes(int max_len, int waves) {
     return (size_t)(max_len + 12) * kDtwMfmaRowBytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);
 }
@@ -104,12 +104,13 @@ struct TemplatesDev {
     int mfma_min_len = 0;
 };
 
-// The matrix-core DTW kernel for chunks [chunk_base, chunk_base + n_chunks) of classes 1 / 2 (3..8 templates): mfcc_size 5, band 5,
-// LDS-staged launches over every window (n_win >= 32), no early abandon.  dense_count / dense_min: DENSE mode of the averaged-template gate.
-bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, int chunk_base, int n_chunks);
+// The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of classes 1 / 2 (3..8 templates): mfcc_size 5, band 5.  from_global: lanes
+// read their frames from global memory (live-stream batches, LIST mode of the averaged-template gate) instead of an LDS stage
+// (needs n_win >= 32).  list / count / dense_min / abandon_nc: as GateList in rp_dtw.hip.
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global);
 hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
-                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
-                           const uint32_t *dense_count, uint32_t dense_min);
+                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, bool from_global,
+                           const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs
 // (one rp_ctx per device) has to set it on each of them.  Sets it once per (current device, kernel), thread-safe.

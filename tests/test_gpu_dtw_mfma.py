@@ -1,0 +1,166 @@
+"""dtw_mfma_kernel (rustpotter_amd/csrc/rp_dtw_mfma.hip): the banded DTW whose cosine costs come out of the matrix cores, taken for
+mfcc_size 5 / band 5 chunks of 3..8 same-length templates.  Against the oracle (1e-5, the gate of every DTW test), against the
+register kernels it replaces (RP_DTW_MFMA=0: same scores to 2e-6, and not the same bits -- i.e. the kernel really runs), and in
+its other modes: tiles that straddle streams, frames read from global memory (live-stream batches, the gate's list), early abandon."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import rp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED000000000001
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rustpotter_amd
+    return rustpotter_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(ra):
+    return ra.BatchContext(device=0, host_pointers=True)
+
+
+def rel_close(a, b, tol=1e-5):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return bool(np.all(np.abs(a - b) <= tol * np.maximum(np.abs(b), 1e-30)))
+
+
+def _streams(S, n_frames, K=5, first=0):
+    n = 480 * (n_frames // 3 + 2)
+    mf = [orc.mfcc_stream(orc.synth_pcm(SEED, first + s, n), K)[:n_frames] for s in range(S)]
+    assert all(m.shape[0] == n_frames for m in mf)
+    return np.stack(mf)
+
+
+class _registers_only:
+    """RP_DTW_MFMA=0 for the calls inside: the library reads the variable per call."""
+    def __enter__(self):
+        self.old = os.environ.get("RP_DTW_MFMA")
+        os.environ["RP_DTW_MFMA"] = "0"
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["RP_DTW_MFMA"]
+        else:
+            os.environ["RP_DTW_MFMA"] = self.old
+
+
+@pytest.mark.parametrize("L,T", [(12, 3), (13, 8), (23, 5), (24, 4), (25, 8), (36, 7), (59, 6), (100, 8), (126, 3)])
+def test_scores_match_the_oracle(ra, ctx, L, T):
+    """Template lengths around the 12-column blocks (12, 13, 23..25, 36), chunk sizes 3..8, window counts that are not a multiple
+    of the 32-window tile: the flattened tiles straddle the three streams."""
+    K, S = 5, 3
+    n_win = 45 if L < 60 else 39
+    templates = orc.synth_templates(SEED + L, T, L, K)
+    mf = _streams(S, n_win + L - 1, K, first=L)
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(mf, tm)
+    assert scores.shape == (S, n_win, T)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates)
+        assert rel_close(scores[s], ref_s), np.abs(scores[s] / ref_s - 1).max()
+        assert rel_close(agg[s], ref_a)
+    with _registers_only():
+        reg, _, _ = ctx.dtw_scores(mf, tm)
+    assert rel_close(scores, reg, 2e-6), np.abs(scores / reg - 1).max()
+    assert not np.array_equal(scores, reg), "the matrix-core kernel did not run"
+
+
+def test_mixed_chunk_classes_and_an_averaged_template(ra, ctx):
+    """19 templates: 8 + 8 of one length (two chunks), 3 of another, plus two ragged ones and the averaged template -- the matrix
+    kernel takes the three multi-template chunks, the register kernels the rest, every column against the oracle."""
+    K = 5
+    templates = orc.synth_templates(SEED + 5, 21, 64, K)
+    for i in (16, 17, 18):
+        templates[i] = templates[i][:50].copy()
+    templates[19] = templates[19][:41].copy()
+    templates[20] = templates[20][:33].copy()
+    avg = orc.synth_templates(SEED + 6, 1, 64, K)[0]
+    mf = _streams(2, 64 + 70, K, first=40)
+    tm = ra.Templates(ctx, templates, avg=avg)
+    scores, avg_s, agg = ctx.dtw_scores(mf, tm, with_avg=True, score_mode=ra.ScoreMode.Median)
+    for s in range(2):
+        ref_s, ref_a = orc.score_stream(mf[s], templates, mode="median")
+        assert rel_close(scores[s], ref_s), np.abs(scores[s] / ref_s - 1).max()
+        assert rel_close(agg[s], ref_a)
+        ref_avg = np.array([orc.score_window(mf[s][w:w + 64], avg) for w in range(0, scores.shape[1], 7)])
+        assert rel_close(avg_s[s][::7], ref_avg)
+
+
+def test_zero_rows_constant_windows_and_silence(ra, ctx):
+    """`magnitude == 0 -> similarity 0` (comparator.rs:43-47) on both sides: all-zero template rows, windows whose frames all
+    equal their mean (the centred frame is the zero vector) and windows that mix constant and live frames."""
+    K, L, T = 5, 40, 8
+    templates = orc.synth_templates(SEED + 9, T, L, K)
+    templates[2][5:9] = 0.0
+    templates[7][:] = 0.0
+    templates[0][L - 1] = 0.0
+    mf = _streams(2, 130, K, first=60)
+    mf[0, 30:90] = mf[0, 30]          # 60 identical frames: windows 30..50 are constant, their neighbours partly so
+    mf[1, :] = 0.0                     # digital silence after the extractor
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(mf, tm)
+    for s in range(2):
+        ref_s, ref_a = orc.score_stream(mf[s], templates)
+        assert rel_close(scores[s], ref_s), np.abs(scores[s] / ref_s - 1).max()
+        assert rel_close(agg[s], ref_a)
+    # a constant window costs exactly 1 per cell against anything
+    ref_const = orc.score_window(mf[0][35:35 + L], templates[1])
+    assert rel_close(scores[0, 35, 1], ref_const, 1e-6)
+    assert np.all(scores[1] == scores[1, 0])
+
+
+def test_identical_window_and_template(ra, ctx):
+    """A window that IS the template (after centring): costs of the matching cells are 1 - 1 = a few ulps around zero, possibly
+    negative -- the score must still match the oracle's."""
+    K, L, T = 5, 48, 4
+    mf = _streams(1, 48 + 40, K, first=80)
+    templates = orc.synth_templates(SEED + 11, T, L, K)
+    w = mf[0, 17:17 + L]
+    templates[1] = (w - w.mean(axis=0, keepdims=True)).astype(np.float32)
+    tm = ra.Templates(ctx, templates)
+    scores, _, _ = ctx.dtw_scores(mf, tm)
+    ref_s, _ = orc.score_stream(mf[0], templates)
+    assert rel_close(scores[0], ref_s), np.abs(scores[0] / ref_s - 1).max()
+    assert scores[0, 17, 1] > 0.7
+
+
+def test_long_templates_take_the_eight_wave_shape(ra, ctx):
+    """250-frame templates: the A image and twelve waves' frame stages do not fit the CU's LDS together, the launch falls back to
+    eight waves per workgroup."""
+    K, L, T = 5, 250, 5
+    templates = orc.synth_templates(SEED + 13, T, L, K)
+    mf = _streams(2, L + 33, K, first=90)
+    tm = ra.Templates(ctx, templates)
+    scores, _, _ = ctx.dtw_scores(mf, tm)
+    assert scores.shape == (2, 34, T)
+    for s in range(2):
+        for w in (0, 1, 16, 31, 32, 33):
+            for t in (0, 2, 4):
+                assert rel_close(scores[s, w, t], orc.score_window(mf[s][w:w + L], templates[t]))
+    with _registers_only():
+        reg, _, _ = ctx.dtw_scores(mf, tm)
+    assert rel_close(scores, reg, 2e-6) and not np.array_equal(scores, reg)
+
+
+def test_many_streams_equal_their_single_stream_scores(ra, ctx):
+    """Size-independent property at a size the oracle does not reach: 1 500 streams x 77 windows x 8 templates in one launch (every
+    wave walks several tiles, most tiles straddle two streams) give, stream by stream, the bits of that stream scored alone."""
+    K, L, T, S = 5, 30, 8, 1500
+    templates = orc.synth_templates(SEED + 17, T, L, K)
+    base = _streams(12, 106, K, first=120)
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, 12, S)
+    gain = (0.5 + rng.random(S)).astype(np.float32)
+    mf = base[pick] * gain[:, None, None]
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(mf, tm)
+    for s in (0, 1, 2, 700, 1498, 1499):
+        one, _, one_agg = ctx.dtw_scores(mf[s], tm)
+        assert np.array_equal(scores[s], one[0]) and np.array_equal(agg[s], one_agg[0])
+    ref_s, _ = orc.score_stream(mf[1499], templates)
+    assert rel_close(scores[1499], ref_s)

@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 SEED = 0x5EED000000000001
 HBM_PEAK = 8.0e12      # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 VALU_PEAK = 157.3e12   # FLOP/s fp32 vector, same table
+MFMA_F16_PEAK = 2.5e15  # FLOP/s dense f16 / bf16 MFMA, same table
 
 
 def self_launch(n):
@@ -236,7 +237,7 @@ def main():
             if (w["streams"], w["samples"], w["templates"], w["template_len"], w["mfcc_size"]) == (S, N, T, L, K) and len(set(lens)) == 1:
                 for name, d in tj["kernels"].items():
                     for kn in ("mfcc", "dtw"):
-                        if kn + "_" in name and "hbm_bytes_per_launch_corrected" in d:
+                        if kn + "_" in name and "hbm_bytes_per_launch_corrected" in d and (kn != "dtw" or "dtw_mfma" in name or "dtw" not in pmc):
                             pmc[kn] = d
                 pmc_src = "profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc passes of this command, not this run)"
         except Exception:
@@ -245,7 +246,15 @@ def main():
     simd_cycles = lambda sec: 1024 * sec * 2.4e9  # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
     dtw_ref_flops, dtw_exec_flops = per_gpu_scorings * f_dtw_ref, per_gpu_scorings * f_dtw_exec
     dtw_bytes = per_gpu_scorings * (4 * K + 4 * (T + 2))
-    r_dtw = {"bound": "valu", "kernel": "dtw_band_kernel", "achieved": dtw_ref_flops / dtw_s / 1e12 if dtw_s else 0.0, "peak": VALU_PEAK / 1e12,
+    # which DTW kernel ran (rp_dtw.hip launch_dtw_k5): chunks of 5..8 same-length templates at mfcc_size 5 / band 5 go to the
+    # matrix-core kernel unless RP_DTW_MFMA=0
+    mfma_used = (K == 5 and os.environ.get("RP_DTW_MFMA", "1")[:1] != "0" and min(lens) >= 12 and any(c >= 5 for c in by_len.values())
+                 )
+    # executed arithmetic of dtw_mfma_kernel: per window and column (L columns) three 32x32x16 MFMAs per 32 windows and chunk
+    # (3 x 32768 / 32 flops), vector side per cell one v_min3 (2) + one add, per column and lane ~20 flops of frame work (2 lanes)
+    f_mfma_matrix = sum(-(-c // 8) * (Lt + 1) * 3 * 32768 / 32.0 for Lt, c in by_len.items() if c >= 5)
+    f_mfma_vector = sum(c * Lt * 2 * W * 3 for Lt, c in by_len.items() if c >= 5) + sum(-(-c // 8) * Lt * 40 for Lt, c in by_len.items() if c >= 5)
+    r_dtw = {"bound": "valu", "kernel": "dtw_mfma_kernel" if mfma_used else "dtw_band_kernel", "achieved": dtw_ref_flops / dtw_s / 1e12 if dtw_s else 0.0, "peak": VALU_PEAK / 1e12,
              "unit": "TFLOP/s", "frac": dtw_ref_flops / dtw_s / VALU_PEAK if dtw_s else 0.0,
              "traffic": pmc.get("dtw", {}).get("hbm_bytes_per_launch_corrected"), "traffic_source": pmc_src if "dtw" in pmc else None,
              "avg_launch_ms": k_ms["dtw"][0], "launches_timed": k_ms["dtw"][1],
@@ -253,16 +262,34 @@ def main():
              "executed_flop_frac": dtw_exec_flops / dtw_s / VALU_PEAK if dtw_s else 0.0,
              "hbm": {"achieved": dtw_bytes / dtw_s / 1e9 if dtw_s else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": dtw_bytes / dtw_s / HBM_PEAK if dtw_s else 0.0, "algorithmic_bytes_per_launch": dtw_bytes},
-             "note": "fp32 vector roofline (no MFMA instruction in this kernel): `achieved`/`frac` price the REFERENCE-shaped flop count "
-                     "(SURVEY.md 8d: 2K+7 flops per band cell) against 157.3 TFLOP/s; the kernel executes fewer (executed_flops: K FMAs + 2 "
-                     "min3 + 1 add per cell), so executed_flop_frac is the honest flop fraction and valu_issue_frac the pipe saturation: "
-                     "VALU instructions x 4 cycles (packed-f32 issue slot) / (1024 SIMDs x launch time x 2.4 GHz)"}
+             "note": "fp32 vector roofline: `achieved`/`frac` price the REFERENCE-shaped flop count (SURVEY.md 8d: 2K+7 flops per band "
+                     "cell) against 157.3 TFLOP/s; the register kernel executes fewer (executed_flops: K FMAs + 2 min3 + 1 add per cell), "
+                     "so executed_flop_frac is its honest flop fraction and valu_issue_frac the pipe saturation: VALU instructions x 4 "
+                     "cycles (packed-f32 issue slot) / (1024 SIMDs x launch time x 2.4 GHz)"}
+    if mfma_used:
+        # the cosine costs are formed by v_mfma_f32_32x32x16_f16 (f16 two-way splits, f32 accumulate): the reference-shaped flop rate
+        # can exceed the VECTOR peak (frac > 1) because those flops no longer run on the vector pipe.  What bounds the kernel is VALU
+        # issue (the recurrence: v_min3 x2 + add x2 per cell pair); valu_busy_frac / mfma_busy_frac below are PMC-measured.
+        r_dtw["executed_flops_per_launch"] = per_gpu_scorings * f_mfma_vector
+        r_dtw["executed_matrix_flops_per_launch"] = per_gpu_scorings * f_mfma_matrix
+        r_dtw["executed_flop_frac"] = per_gpu_scorings * f_mfma_vector / dtw_s / VALU_PEAK if dtw_s else 0.0
+        r_dtw["mfma_f16_frac"] = per_gpu_scorings * f_mfma_matrix / dtw_s / MFMA_F16_PEAK if dtw_s else 0.0
+        r_dtw["note"] = ("dtw_mfma_kernel: the cosine costs of a band column come out of v_mfma_f32_32x32x16_f16 (f16 two-way splits of both "
+                         "operands, f32 accumulate), the vector pipe runs the recurrence.  `achieved`/`frac` still price the REFERENCE-shaped "
+                         "flop count (SURVEY.md 8d) against the 157.3 TFLOP/s VECTOR peak, as in earlier rounds -- above 1 means the kernel "
+                         "beats what any f32 vector formulation of the reference's arithmetic could reach, not that a roof is exceeded.  "
+                         "Bound: VALU issue -- valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x shader cycles) and mfma_busy_frac = "
+                         "SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x shader cycles), both from the committed PMC passes; mfma_f16_frac = executed "
+                         "matrix flops against the 2.5 PFLOP/s dense f16 peak")
     if "dtw" in pmc and "instructions_per_launch" in pmc["dtw"]:
         r_dtw["valu_insts_per_launch"] = pmc["dtw"]["instructions_per_launch"]["SQ_INSTS_VALU"]
         r_dtw["valu_issue_frac"] = 4.0 * r_dtw["valu_insts_per_launch"] / simd_cycles(dtw_s) if dtw_s else 0.0
         if "effective_clock_ghz" in pmc["dtw"]:  # the chip clocks below 2.4 GHz under this load (GRBM_GUI_ACTIVE / duration, same PMC file)
             r_dtw["effective_clock_ghz"] = pmc["dtw"]["effective_clock_ghz"]
             r_dtw["valu_issue_frac_at_effective_clock"] = r_dtw["valu_issue_frac"] * 2.4 / pmc["dtw"]["effective_clock_ghz"]
+    for kf in ("valu_busy_frac", "mfma_busy_frac"):
+        if "dtw" in pmc and kf in pmc["dtw"]:
+            r_dtw[kf] = pmc["dtw"][kf]
     mfcc_bytes, mfcc_flops = S * nf * (640 + 4 * K), S * nf * f_mfcc
     r_mfcc = {"bound": "hbm", "kernel": "mfcc_kernel", "achieved": mfcc_bytes / mfcc_s / 1e9 if mfcc_s else 0.0, "peak": HBM_PEAK / 1e9,
               "unit": "GB/s", "frac": mfcc_bytes / mfcc_s / HBM_PEAK if mfcc_s else 0.0,

@@ -312,7 +312,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     }
     std::vector<DtwChunk> chunks;
     std::vector<float> dup;
-    std::vector<uint16_t> aimg;  // dtw_mfma_kernel's A images (mfcc_size 5, chunks of 3..8 templates)
+    std::vector<uint16_t> aimg;  // dtw_mfma_kernel's A images (mfcc_size 5, chunks of 5..8 templates)
     // class 4 (not a launch class of its own): the tc-4 halves of the class-2 chunks, see TemplatesDev::split_first
     std::vector<DtwChunk> halves;
     bool can_split = !byclass[2].empty();
@@ -331,7 +331,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         for (DtwChunk c : (cls < 4 ? byclass[cls] : halves)) {
             c.rows_off = (int)dup.size();
             c.aimg_off = 0;
-            if (K == 5 && (cls == 1 || cls == 2)) {
+            if (K == 5 && cls == 2) {
                 c.aimg_off = (int)(aimg.size() * sizeof(uint16_t) / 16);
                 append_mfma_image(aimg, c, unit.data(), Lpad);
                 d.mfma_min_len = d.mfma_min_len == 0 ? c.len : std::min(d.mfma_min_len, c.len);

@@ -931,16 +931,16 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
     // n1: single-template chunks to score (class 3; the averaged template is its last chunk)
     if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
     if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
-    // chunks of 3..8 templates: the matrix-core kernel (rp_dtw_mfma.hip) at band 5, in every mode (LDS-staged, frames from
-    // global memory for live-stream batches and the gate's list, early abandon)
+    if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+    // chunks of 5..8 templates: the matrix-core kernel (rp_dtw_mfma.hip) at band 5, in every mode (LDS-staged, frames from global
+    // memory for live-stream batches and the gate's list, early abandon).  Chunks of 3 or 4 stay with the tc-4 register kernel:
+    // the matrix kernel always pays for eight template slots (C3 shape with 3 templates of 126 frames: 14.6 against 13.6 ms).
     {
         const bool from_global = few || gl.list != nullptr;
-        if (W == 5 && t.class_count[1] + t.class_count[2] > 0 && t.class_first[2] == t.class_first[1] + t.class_count[1] &&
-            dtw_mfma_supported(t, W, n_win, from_global))
-            return launch_dtw_mfma(st, t, t.class_first[1], t.class_count[1] + t.class_count[2], mfcc, S, frame_pitch, first_win, n_win,
-                                   out_win_pitch, score_ref, scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc);
+        if (W == 5 && t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global))
+            return launch_dtw_mfma(st, t, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+                                   scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc);
     }
-    if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
     // Small batches: tc-8 waves run two per SIMD; a launch that fills those slots 2.x times leaves the chip mostly idle in
     // its last round.  The same templates as tc-4 half chunks are twice as many waves of 0.83 of the length (measured at C2), three per SIMD
     // (146 VGPRs).  Taken when the modelled makespan is shorter; large batches (>= 3 rounds of tc-8 waves) never are.

@@ -67,7 +67,7 @@ struct DtwChunk {
     int tc;               // register tile the kernel is instantiated for: 2, 4 or 8
     int rows_off;         // float offset of the chunk's rows in TemplatesDev::dup
     int tid[kChunkMax];   // output column of each template; T means the averaged template
-    int aimg_off;         // chunks of 3..8 templates at mfcc_size 5: offset (16-byte units) of the chunk's A image in TemplatesDev::aimg
+    int aimg_off;         // chunks of 5..8 templates at mfcc_size 5: offset (16-byte units) of the chunk's A image in TemplatesDev::aimg
 };
 
 // dtw_mfma_kernel (rp_dtw_mfma.hip): A image = per template row [k half 2][template 8] x 8 f16 (the negated unit row, split in two f16
@@ -99,12 +99,12 @@ struct TemplatesDev {
     // every class-2 chunk once more as two tc-4 halves (only when each of them holds 7 or 8 templates): a small batch whose
     // tc-8 waves would fill the chip 2.x times is scored by twice as many tc-4 waves, three resident per SIMD instead of two
     int split_first = 0, split_count = 0;
-    // dtw_mfma_kernel: A images of the class-1 and class-2 chunks (mfcc_size 5 only), and the shortest template among them
+    // dtw_mfma_kernel: A images of the class-2 chunks (mfcc_size 5 only), and the shortest template among them
     void *aimg = nullptr;
     int mfma_min_len = 0;
 };
 
-// The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of classes 1 / 2 (3..8 templates): mfcc_size 5, band 5.  from_global: lanes
+// The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of class 2 (5..8 templates): mfcc_size 5, band 5.  from_global: lanes
 // read their frames from global memory (live-stream batches, LIST mode of the averaged-template gate) instead of an LDS stage
 // (needs n_win >= 32).  list / count / dense_min / abandon_nc: as GateList in rp_dtw.hip.
 bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global);

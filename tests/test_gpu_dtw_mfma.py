@@ -1,7 +1,7 @@
 """dtw_mfma_kernel (rustpotter_amd/csrc/rp_dtw_mfma.hip): the banded DTW whose cosine costs come out of the matrix cores, taken for
-mfcc_size 5 / band 5 chunks of 3..8 same-length templates.  Against the oracle (1e-5, the gate of every DTW test), against the
+mfcc_size 5 / band 5 chunks of 5..8 same-length templates.  Against the oracle (1e-5, the gate of every DTW test), against the
 register kernels it replaces (RP_DTW_MFMA=0: same scores to 2e-6, and not the same bits -- i.e. the kernel really runs), and in
-its other modes: tiles that straddle streams, frames read from global memory (live-stream batches, the gate's list), early abandon."""
+its other modes (chunks of 5..8 same-length templates): tiles that straddle streams, frames read from global memory (live-stream batches, the gate's list), early abandon."""
 import os
 
 import numpy as np
@@ -49,10 +49,11 @@ class _registers_only:
             os.environ["RP_DTW_MFMA"] = self.old
 
 
-@pytest.mark.parametrize("L,T", [(12, 3), (13, 8), (23, 5), (24, 4), (25, 8), (36, 7), (59, 6), (100, 8), (126, 3)])
+@pytest.mark.parametrize("L,T", [(12, 5), (13, 8), (23, 5), (24, 6), (25, 8), (36, 7), (59, 6), (100, 8), (126, 5), (40, 4), (100, 3)])
 def test_scores_match_the_oracle(ra, ctx, L, T):
-    """Template lengths around the 12-column blocks (12, 13, 23..25, 36), chunk sizes 3..8, window counts that are not a multiple
-    of the 32-window tile: the flattened tiles straddle the three streams."""
+    """Template lengths around the 12-column blocks (12, 13, 23..25, 36), chunk sizes 5..8, window counts that are not a multiple
+    of the 32-window tile: the flattened tiles straddle the three streams.  Chunks of 3 or 4 templates stay with the tc-4
+    register kernel (the last two cases: the switch changes nothing there)."""
     K, S = 5, 3
     n_win = 45 if L < 60 else 39
     templates = orc.synth_templates(SEED + L, T, L, K)
@@ -67,12 +68,12 @@ def test_scores_match_the_oracle(ra, ctx, L, T):
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm)
     assert rel_close(scores, reg, 2e-6), np.abs(scores / reg - 1).max()
-    assert not np.array_equal(scores, reg), "the matrix-core kernel did not run"
+    assert np.array_equal(scores, reg) == (T < 5), "chunks of 5..8 templates take the matrix-core kernel, smaller ones do not"
 
 
 def test_mixed_chunk_classes_and_an_averaged_template(ra, ctx):
-    """19 templates: 8 + 8 of one length (two chunks), 3 of another, plus two ragged ones and the averaged template -- the matrix
-    kernel takes the three multi-template chunks, the register kernels the rest, every column against the oracle."""
+    """21 templates: 8 + 8 of one length (two chunks for the matrix kernel), 3 of another (tc-4 register kernel), two ragged ones
+    and the averaged template (two windows per lane) -- every column against the oracle."""
     K = 5
     templates = orc.synth_templates(SEED + 5, 21, 64, K)
     for i in (16, 17, 18):
@@ -117,7 +118,7 @@ def test_zero_rows_constant_windows_and_silence(ra, ctx):
 def test_identical_window_and_template(ra, ctx):
     """A window that IS the template (after centring): costs of the matching cells are 1 - 1 = a few ulps around zero, possibly
     negative -- the score must still match the oracle's."""
-    K, L, T = 5, 48, 4
+    K, L, T = 5, 48, 6
     mf = _streams(1, 48 + 40, K, first=80)
     templates = orc.synth_templates(SEED + 11, T, L, K)
     w = mf[0, 17:17 + L]

@@ -15,6 +15,10 @@ def agg(tag):
     return {k: {c: statistics.median(v) for c, v in d.items()} for k, d in a.items()}
 
 fe, wr, sq, ins = agg("final_fetch"), agg("final_write"), agg("final_sq"), agg("final_inst")
+try:  # VALU / matrix pipe occupancy (its own pass)
+    vp = agg("final_valu")
+except Exception:
+    vp = {}
 try:  # effective shader clock: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the launch's duration in the same pass
     clk = agg("final_clk")
     trc = glob.glob("gpurun_out/pmc_final_clk/**/*kernel_trace.csv", recursive=True)[0]
@@ -26,7 +30,7 @@ except Exception:
     clk = {}
 out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                   "(separate passes: FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; "
-                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r3_final.sh)",
+                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r3_final.sh)",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch as reported by rocprofv3 (TCC_EA0 request counters); FETCH_SIZE of "
                 "16-byte-per-lane streaming reads under-reports by 2x on gfx950 (MI355X_MICROARCH.md HBM section); values are the "
                 "MEDIAN over the launches of a kernel in the run (the run also holds one tiny mfcc launch for the templates)",
@@ -37,7 +41,7 @@ for k in fe:
     if "mfcc_kernel" in k:
         d["hbm_bytes_per_launch_corrected"] = (2 * f + w) * 1024
         d["note"] = "reads are 16 B/lane: FETCH_SIZE doubled per the guide"
-    elif any(x in k for x in ("dtw_band_kernel", "dtw_band2_kernel", "aggregate_kernel", "scan_kernel")):
+    elif any(x in k for x in ("dtw_mfma_kernel", "dtw_band_kernel", "dtw_band2_kernel", "aggregate_kernel", "scan_kernel")):
         d["hbm_bytes_per_launch_corrected"] = (f + w) * 1024
         d["note"] = "4-byte reads: FETCH_SIZE taken at face value"
     if k in sq and sq[k].get("SQ_WAVE_CYCLES"):
@@ -47,6 +51,13 @@ for k in fe:
     if k in clk and clk[k][1] > 0:
         d["grbm_gui_active_per_launch"] = clk[k][0]
         d["effective_clock_ghz"] = clk[k][0] / 8.0 / clk[k][1]   # cycles per ns
+        if k in vp and vp[k].get("SQ_ACTIVE_INST_VALU"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the waves; SQ_VALU_MFMA_BUSY_CYCLES cycles summed over the SIMDs
+            simd_cycles = 1024.0 * clk[k][0] / 8.0
+            d["valu_pipe_counters_per_launch"] = vp[k]
+            d["valu_busy_frac"] = 4.0 * vp[k]["SQ_ACTIVE_INST_VALU"] / simd_cycles
+            if vp[k].get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                d["mfma_busy_frac"] = vp[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
     out["kernels"][k] = d
 json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
 json.dump(out, open("profiles/%s_final_pmc.json" % R, "w"), indent=1)

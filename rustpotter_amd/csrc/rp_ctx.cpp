@@ -353,6 +353,8 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     if (!aimg.empty()) {
         if (!hip_ok(hipMalloc(&d.aimg, sizeof(uint16_t) * aimg.size()), "hipMalloc(aimg)")) return nullptr;
         if (!hip_ok(hipMemcpy(d.aimg, aimg.data(), sizeof(uint16_t) * aimg.size(), hipMemcpyHostToDevice), "hipMemcpy(aimg)")) return nullptr;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.mfma_sched), sizeof(uint32_t) * 2 * chunks.size()), "hipMalloc(sched)")) return nullptr;
+        if (!hip_ok(hipMemset(d.mfma_sched, 0, sizeof(uint32_t) * 2 * chunks.size()), "hipMemset(sched)")) return nullptr;
     }
     return tp.release();
 }
@@ -363,6 +365,7 @@ Templates::~Templates() {
     if (dev.chunks) (void)hipFree(dev.chunks);
     if (dev.dup) (void)hipFree(dev.dup);
     if (dev.aimg) (void)hipFree(dev.aimg);
+    if (dev.mfma_sched) (void)hipFree(dev.mfma_sched);
 }
 
 // f32 -> bf16, round to nearest even (matches the kernel's in-register conversion)

@@ -55,8 +55,8 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 
 }  // namespace
 
-// One workgroup = NW waves on one chunk (its A image is staged once); waves walk the 32-entry tiles of the flattened
-// (stream, window) space grid-stride.  GX = false: a tile's frames are staged in LDS, a tile may straddle two streams
+// One workgroup = NW waves on one chunk (its A image is staged once); waves take the 32-entry tiles of the flattened
+// (stream, window) space from an atomic counter.  GX = false: a tile's frames are staged in LDS, a tile may straddle two streams
 // (n_win >= 32).  GX = true: lanes read their window's frames from global memory (live-stream batches: a few windows per
 // stream; LIST mode of the averaged-template gate: list[] holds the rows that passed, *count of them).  list == nullptr with a
 // count: DENSE mode of the gate -- the launch does nothing unless *count >= dense_min; LIST mode does nothing when the list is
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,
-    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc) {
+    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched) {
     constexpr int K = kMK, B = 2 * W, NS = kMSlots;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
     static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 12 row slots");
@@ -81,13 +81,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     } else if (count && *count < dense_min) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned ci = blockIdx.x % n_chunks;
-    const size_t group = blockIdx.x / n_chunks, n_groups = gridDim.x / n_chunks;
+    const unsigned n_groups = gridDim.x / n_chunks;
     const DtwChunk *ch = chunks + chunk_base + ci;
     const int L = ch->len;  // m == n == L
     const int a_bytes = (max_len + NS) * kRowBytes;
     const int xs_floats = dtw_mfma_stage_floats(max_len);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (group * NW >= total_tiles) return;  // workgroup-uniform: nothing for this workgroup (short lists)
     {
         const u32x4 *asrc = reinterpret_cast<const u32x4 *>(aimg) + ch->aimg_off;
         u32x4 *adst = reinterpret_cast<u32x4 *>(smem);
@@ -110,7 +109,15 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) { slot_real[e] = 4 * h + e < ch->count; slot_avg[e] = slot_real[e] && ch->tid[4 * h + e] >= T; }
 
-    for (size_t tile = group * NW + wave; tile < total_tiles; tile += n_groups * NW) {
+    // Tiles are handed out by an atomic counter per chunk (sched[2 ci]): a small batch is a few tiles per wave, and a static
+    // split leaves most of the chip waiting for the waves that got one tile more (BASELINE config C2: 3.09 tiles per wave).
+    // The last workgroup of a chunk to finish (sched[2 ci + 1] counts them) puts both words back to zero for the next launch.
+    uint32_t *next_tile = sched + 2 * (chunk_base + ci);
+    for (;;) {
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(next_tile, 1u);
+        const size_t tile = (size_t)__builtin_amdgcn_readfirstlane(ticket);
+        if (tile >= total_tiles) break;
         // ---- lanes -> (stream, window) ----
         const size_t f0 = tile * kMWin;
         bool valid;
@@ -320,6 +327,14 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         }
         if (!GX) wave_lds_sync();  // the next tile restages xs
     }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(next_tile + 1, 1u) == n_groups - 1) {  // every workgroup of this chunk has taken its last ticket
+            next_tile[0] = 0;
+            next_tile[1] = 0;
+        }
+    }
 }
 
 bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global) {
@@ -338,7 +353,8 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base
     const size_t total_tiles = (S * n_win + kMWin - 1) / kMWin;
     const int nw = dtw_mfma_lds_bytes(t.max_len, 12) <= 160 * 1024 ? 12 : 8;
     const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw);
-    // one workgroup per CU and chunk group; a workgroup's waves walk the tiles grid-stride
+    // one workgroup per CU and chunk group; the waves take tiles from the chunk's counter
+    if (!t.mfma_sched) return hipErrorInvalidValue;
     size_t groups = (size_t)device_cu_count() / (size_t)n_chunks;
     if (groups < 1) groups = 1;
     const size_t need = (total_tiles + nw - 1) / nw;
@@ -351,7 +367,7 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base
         hipLaunchKernelGGL((dtw_mfma_kernel<5, NW, GXV>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
                            reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
-                           abandon_nc);                                                                                             \
+                           abandon_nc, t.mfma_sched);                                                                               \
     } while (0)
     if (from_global) { if (nw == 12) RP_LAUNCH_MFMA(12, true); else RP_LAUNCH_MFMA(8, true); }
     else { if (nw == 12) RP_LAUNCH_MFMA(12, false); else RP_LAUNCH_MFMA(8, false); }

@@ -102,6 +102,7 @@ struct TemplatesDev {
     // dtw_mfma_kernel: A images of the class-2 chunks (mfcc_size 5 only), and the shortest template among them
     void *aimg = nullptr;
     int mfma_min_len = 0;
+    uint32_t *mfma_sched = nullptr;  // per chunk {next tile, workgroups done}: dtw_mfma_kernel's tile counter, zero between launches
 };
 
 // The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of class 2 (5..8 templates): mfcc_size 5, band 5.  from_global: lanes

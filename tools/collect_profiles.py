@@ -55,9 +55,12 @@ for k in fe:
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the waves; SQ_VALU_MFMA_BUSY_CYCLES cycles summed over the SIMDs
             simd_cycles = 1024.0 * clk[k][0] / 8.0
             d["valu_pipe_counters_per_launch"] = vp[k]
-            d["valu_busy_frac"] = 4.0 * vp[k]["SQ_ACTIVE_INST_VALU"] / simd_cycles
-            if vp[k].get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
-                d["mfma_busy_frac"] = vp[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+            mfma_busy = vp[k].get("SQ_VALU_MFMA_BUSY_CYCLES") or 0.0
+            # SQ_ACTIVE_INST_VALU charges an MFMA its whole execution time (32 cycles) although vector instructions of other waves
+            # issue beside part of it: with MFMAs the raw ratio can exceed 1; the vector share is what is left without them
+            d["valu_active_frac_raw"] = 4.0 * vp[k]["SQ_ACTIVE_INST_VALU"] / simd_cycles
+            d["valu_busy_frac"] = (4.0 * vp[k]["SQ_ACTIVE_INST_VALU"] - mfma_busy) / simd_cycles
+            d["mfma_busy_frac"] = mfma_busy / simd_cycles
     out["kernels"][k] = d
 json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
 json.dump(out, open("profiles/%s_final_pmc.json" % R, "w"), indent=1)

@@ -522,12 +522,13 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         if (gated) {
             uint32_t *lst = c->ws_list.as<uint32_t>();
             ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, config->avg_threshold,
-                                         ds, da, lst + 1, lst, false, abandon), "dtw kernels (gated)");
+                                         ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
         } else if (gated_generic) {
             ok = hip_ok(launch_dtw_generic_gated(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref,
                                                  config->avg_threshold, ds, da), "dtw_generic_kernel (gated)");
         } else {
-            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, false, abandon), "dtw kernel");
+            // ws_mfcc ends with slack: short streams (fewer than 64 windows each) are scored by cross-stream waves like live-stream batches
+            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
         }
         c->time_end();
         if (!ok) return -1;
@@ -703,9 +704,9 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                 if (gated) {
                     uint32_t *lst = c->ws_list.as<uint32_t>();
                     ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst,
-                                                 false, abandon), "dtw kernels (gated)");
+                                                 true, abandon), "dtw kernels (gated)");
                 } else {
-                    ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, false, abandon), "dtw kernel");
+                    ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
                 }
                 c->time_end();
                 if (!ok) return -1;

@@ -339,13 +339,13 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 
 bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global) {
     const char *env = std::getenv("RP_DTW_MFMA");  // "0": the register kernels only (A/B runs and the cross-check tests); read per call
-    if ((env && env[0] == '0') || t.K != kMK || band != 5 || !t.aimg || t.max_diff != 0) return false;
+    if ((env && env[0] == '0') || t.K != kMK || band < 3 || band > 5 || !t.aimg || t.max_diff != 0) return false;  // 12 row slots hold 2 band + 2 rows
     if (!from_global && n_win < (size_t)kMWin) return false;  // a staged tile holds at most two stream segments
     if (t.mfma_min_len < kMSlots) return false;               // the first 12 columns are one unguarded block
     return dtw_mfma_lds_bytes(t.max_len, 8) <= 160 * 1024;
 }
 
-hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
+hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
                            size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, bool from_global,
                            const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc) {
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
@@ -361,16 +361,26 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base
     if (groups > need) groups = need;
     const size_t blocks = groups * (size_t)n_chunks;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-#define RP_LAUNCH_MFMA(NW, GXV)                                                                                                     \
+#define RP_LAUNCH_MFMA(WW, NW, GXV)                                                                                                 \
     do {                                                                                                                            \
-        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<5, NW, GXV>), 160 * 1024); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((dtw_mfma_kernel<5, NW, GXV>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<WW, NW, GXV>), 160 * 1024); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
                            reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
                            abandon_nc, t.mfma_sched);                                                                               \
     } while (0)
-    if (from_global) { if (nw == 12) RP_LAUNCH_MFMA(12, true); else RP_LAUNCH_MFMA(8, true); }
-    else { if (nw == 12) RP_LAUNCH_MFMA(12, false); else RP_LAUNCH_MFMA(8, false); }
+#define RP_LAUNCH_MFMA_W(WW)                                                                                                        \
+    do {                                                                                                                            \
+        if (from_global) { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, true); else RP_LAUNCH_MFMA(WW, 8, true); }                          \
+        else { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, false); else RP_LAUNCH_MFMA(WW, 8, false); }                                    \
+    } while (0)
+    switch (band) {
+    case 3: RP_LAUNCH_MFMA_W(3); break;
+    case 4: RP_LAUNCH_MFMA_W(4); break;
+    case 5: RP_LAUNCH_MFMA_W(5); break;
+    default: return hipErrorNotSupported;
+    }
+#undef RP_LAUNCH_MFMA_W
 #undef RP_LAUNCH_MFMA
     return hipGetLastError();
 }

@@ -105,11 +105,11 @@ struct TemplatesDev {
     uint32_t *mfma_sched = nullptr;  // per chunk {next tile, workgroups done}: dtw_mfma_kernel's tile counter, zero between launches
 };
 
-// The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of class 2 (5..8 templates): mfcc_size 5, band 5.  from_global: lanes
+// The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of class 2 (5..8 templates): mfcc_size 5, band 3..5.  from_global: lanes
 // read their frames from global memory (live-stream batches, LIST mode of the averaged-template gate) instead of an LDS stage
 // (needs n_win >= 32).  list / count / dense_min / abandon_nc: as GateList in rp_dtw.hip.
 bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global);
-hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
+hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
                            size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, bool from_global,
                            const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc);
 

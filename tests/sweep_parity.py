@@ -37,7 +37,7 @@ def _utterance(rng, n):
     return x.astype(np.float32)
 
 
-def make_case(rng, extreme=False):
+def make_case(rng, extreme=False, mfma=False):
     from oracle import rp_oracle as orc
     # (mfcc size 1 is left to the MFCC sweep: with one coefficient every cosine is +-1, window scores repeat exactly and
     # which of two equal-scoring windows a detection reports -- its avg_score -- hangs on the last bit)
@@ -51,6 +51,12 @@ def make_case(rng, extreme=False):
         K = int(rng.choice([5, 16, 40, 2]))
         T = int(rng.choice([1, 2, 9, 20]))
         lens = np.full(T, int(rng.integers(20, 60))) if rng.random() < 0.4 else rng.choice([1, 2, 3, 5, 8, 30, 64, 65, 128], size=T)
+    if mfma:  # the shapes dtw_mfma_kernel takes: mfcc_size 5, chunks of 5..8 same-length templates (plus, sometimes, a few others)
+        K = 5
+        T = int(rng.integers(5, 17))
+        lens = np.full(T, int(rng.integers(12, 110)))
+        if rng.random() < 0.4:
+            lens[: int(rng.integers(1, 4))] = rng.integers(12, 110)
     utts = [_utterance(rng, 480 * ((int(L) + 3 + 2) // 3)) for L in lens]
     templates = [orc.normalize(orc.mfcc_stream(u, K))[:int(L)] for u, L in zip(utts, lens)]
     avg = None
@@ -62,6 +68,10 @@ def make_case(rng, extreme=False):
                min_scores=int(rng.integers(1, 7)), eager=bool(rng.random() < 0.3), score_ref=float(rng.uniform(0.15, 0.3)),
                band_size=int(rng.integers(1, 9)), score_mode=str(rng.choice(MODES)),
                vad_mode=[None, None, None, "easy", "medium", "hard"][int(rng.integers(6))])
+    if mfma:
+        cfg.update(band_size=int(rng.choice([3, 4, 5, 5, 5])))
+        if rng.random() < 0.5:  # detect-only calls in ScoreMode::Max abandon hopeless DTWs: half of the cases take that path too
+            cfg.update(score_mode="max")
     if extreme:  # see make_api_case
         cfg.update(band_size=int(rng.choice([0, 1, 2, 15, 40, 120])), min_scores=int(rng.choice([0, 1, 2, 50])),
                    threshold=float(rng.choice([0.0, 1e-6, 0.3, 0.99, 1.5, -0.5])),
@@ -159,12 +169,12 @@ def _same(a, b, rtol):
     return True
 
 
-def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False):
+def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False):
     """-> (cases, detections compared, ties skipped); raises AssertionError with the case number on a mismatch."""
     total = ties = 0
     for ci in range(n_cases):
-        rng = np.random.default_rng([seed, ci])
-        case = make_case(rng, extreme=extreme)
+        rng = np.random.default_rng([seed, 77, ci] if mfma else [seed, ci])
+        case = make_case(rng, extreme=extreme, mfma=mfma)
         ref = oracle_detections(case)
         offline, live, agg = device_detections(ra, ctx, case)
         # extreme parameters: a small score_ref puts the scores at 1e-20, where the logistic turns 1e-7 of cost into 1e-5 of
@@ -1114,6 +1124,7 @@ if __name__ == "__main__":
     ap.add_argument("--reset-cases", type=int, default=0, help="live-stream batches with single-stream resets")
     ap.add_argument("--extreme-cases", type=int, default=0, help="single-stream API cases with edge-of-range detector parameters")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
+    ap.add_argument("--mfma-cases", type=int, default=0, help="batch cases in the shapes the matrix-core DTW kernel takes (mfcc_size 5, 5..16 same-length templates, band 3..5)")
     a = ap.parse_args()
     import rustpotter_amd as ra
     ctx = ra.BatchContext(0)
@@ -1122,6 +1133,8 @@ if __name__ == "__main__":
     families = [  # (name, number of cases, run, result -> text); a failing family is reported and the others still run
         ("sweep", a.cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
+        ("matrix-core DTW sweep", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True),
+         lambda r: "%d cases (mfcc_size 5, 5..16 same-length templates, band 3..5), %d detections compared, %d threshold ties skipped" % r),
         ("live rate sweep", a.rate_cases, lambda n: run_live_rate_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases live == offline bitwise, %d detections equal to the oracle's, %d near-tie cases" % r),
         ("live reset sweep", a.reset_cases, lambda n: run_live_reset_sweep(ra, ctx, n, a.seed, verbose=True),

@@ -71,6 +71,28 @@ def test_scores_match_the_oracle(ra, ctx, L, T):
     assert np.array_equal(scores, reg) == (T < 5), "chunks of 5..8 templates take the matrix-core kernel, smaller ones do not"
 
 
+@pytest.mark.parametrize("band,L,T", [(3, 37, 8), (4, 50, 6), (3, 12, 5), (4, 24, 7)])
+def test_bands_three_and_four(ra, ctx, band, L, T):
+    """band_size 3 and 4 use the same twelve row slots (2 band + 2 <= 12); band 6 would need a fourth tile and stays with the
+    register kernel, as does every band beyond."""
+    K, S, n_win = 5, 2, 41
+    templates = orc.synth_templates(SEED + 31 * band + L, T, L, K)
+    mf = _streams(S, n_win + L - 1, K, first=200 + L)
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(mf, tm, band_size=band)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates, band=band)
+        assert rel_close(scores[s], ref_s), np.abs(scores[s] / ref_s - 1).max()
+        assert rel_close(agg[s], ref_a)
+    with _registers_only():
+        reg, _, _ = ctx.dtw_scores(mf, tm, band_size=band)
+    assert rel_close(scores, reg, 2e-6) and not np.array_equal(scores, reg)
+    six, _, _ = ctx.dtw_scores(mf, tm, band_size=6)
+    with _registers_only():
+        six_reg, _, _ = ctx.dtw_scores(mf, tm, band_size=6)
+    assert np.array_equal(six, six_reg)
+
+
 def test_mixed_chunk_classes_and_an_averaged_template(ra, ctx):
     """21 templates: 8 + 8 of one length (two chunks for the matrix kernel), 3 of another (tc-4 register kernel), two ragged ones
     and the averaged template (two windows per lane) -- every column against the oracle."""
@@ -119,14 +141,15 @@ def test_identical_window_and_template(ra, ctx):
     """A window that IS the template (after centring): costs of the matching cells are 1 - 1 = a few ulps around zero, possibly
     negative -- the score must still match the oracle's."""
     K, L, T = 5, 48, 6
-    mf = _streams(1, 48 + 40, K, first=80)
+    mf = _streams(2, 48 + 40, K, first=80)
     templates = orc.synth_templates(SEED + 11, T, L, K)
     w = mf[0, 17:17 + L]
     templates[1] = (w - w.mean(axis=0, keepdims=True)).astype(np.float32)
     tm = ra.Templates(ctx, templates)
     scores, _, _ = ctx.dtw_scores(mf, tm)
-    ref_s, _ = orc.score_stream(mf[0], templates)
-    assert rel_close(scores[0], ref_s), np.abs(scores[0] / ref_s - 1).max()
+    for s in range(2):
+        ref_s, _ = orc.score_stream(mf[s], templates)
+        assert rel_close(scores[s], ref_s), np.abs(scores[s] / ref_s - 1).max()
     assert scores[0, 17, 1] > 0.7
 
 
@@ -150,7 +173,7 @@ def test_long_templates_take_the_eight_wave_shape(ra, ctx):
 
 def test_many_streams_equal_their_single_stream_scores(ra, ctx):
     """Size-independent property at a size the oracle does not reach: 1 500 streams x 77 windows x 8 templates in one launch (every
-    wave walks several tiles, most tiles straddle two streams) give, stream by stream, the bits of that stream scored alone."""
+    wave takes several tiles, most tiles straddle two streams) give, stream by stream, the bits of that stream scored alone."""
     K, L, T, S = 5, 30, 8, 1500
     templates = orc.synth_templates(SEED + 17, T, L, K)
     base = _streams(12, 106, K, first=120)
@@ -165,3 +188,41 @@ def test_many_streams_equal_their_single_stream_scores(ra, ctx):
         assert np.array_equal(scores[s], one[0]) and np.array_equal(agg[s], one_agg[0])
     ref_s, _ = orc.score_stream(mf[1499], templates)
     assert rel_close(scores[1499], ref_s)
+
+
+@pytest.mark.parametrize("cpc", [1, 2, 5])
+def test_one_stream_live_equals_offline(ra, ctx, cpc):
+    """One stream alone is a batch too: fed one, two or five chunks per call (3 .. 15 new windows: the shapes the single-stream mirror
+    hands to dtw_single_kernel) a live-stream batch of ONE stream takes the matrix-core kernel with frames from global memory and gives
+    the aggregates of the offline call bit for bit -- a stream's bits do not depend on the batch it is scored in."""
+    K, L, T = 5, 40, 8
+    templates = orc.synth_templates(SEED + 19, T, L, K)
+    tm = ra.Templates(ctx, templates)
+    pcm = np.stack([orc.synth_pcm(SEED, 150, 480 * 70)])
+    cfg = ra.DetectorConfig()
+    cfg.threshold, cfg.min_scores = 0.3, 1
+    _, _, scores, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    with _registers_only():
+        _, _, reg, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    assert rel_close(scores, reg, 2e-6) and not np.array_equal(scores, reg)
+    sb = ra.StreamBatch(ctx, tm, cfg, 1, max_chunks_per_call=cpc)
+    compared = 0
+    for i in range(0, pcm.shape[1], 480 * cpc):
+        _, _, a = sb.process(pcm[:, i:i + 480 * cpc], want_agg=True)
+        f0 = 3 * (i // 480) - 3  # frame index of the call's first aggregate column; window = frame - (L - 1)
+        for k in range(a.shape[1]):
+            wi = f0 + k - (L - 1)
+            if 0 <= wi < agg.shape[1]:
+                assert a[0, k] == agg[0, wi]
+                compared += 1
+    assert compared > 100
+
+
+def test_matrix_core_sweep_few_cases(ra):
+    """A few cases of the randomised sweep in the kernel's shapes (tests/sweep_parity.py --mfma-cases; 600 of them in
+    profiles/sweep_r03.txt): oracle detections (chunk and counter exact, scores 1e-5), the gate-skip call against the full one and
+    the live-stream batch against the offline batch bit for bit."""
+    import sweep_parity
+    ctx = ra.BatchContext(0)
+    n, total, ties = sweep_parity.run_sweep(ra, ctx, 10, 3, mfma=True)
+    assert n == 10 and ties <= 1

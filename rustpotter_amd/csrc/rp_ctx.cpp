@@ -206,11 +206,11 @@ static float f16_bits_to_f32(uint16_t hb) {
 // slots pair with the window side's (xa0, xb0 | xa1, xb1 | xa0, xb0 | x2_0, x2_1 or 1.0):
 //   [ca.0, cb.0 | ca.0, cb.0 | ca.1, cb.1 | half 0: c2.0, c2.0 / half 1: c2.1, 1.0]
 // i.e. x0 a0 + x1 a0 + x0 a1 for every component, and 1.0 x 1.0: the instruction accumulates 1 - a.x.  Slots past the chunk's
-// count and the 12 rows after the last one are zero.
+// count and the 16 rows after the last one are zero.
 static void append_mfma_image(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad) {
     const int K = 5;
     const size_t base = img.size();
-    img.resize(base + (size_t)(c.len + 12) * kDtwMfmaRowBytes / 2, 0);
+    img.resize(base + (size_t)(c.len + 16) * kDtwMfmaRowBytes / 2, 0);
     for (int r = 0; r < c.len; ++r)
         for (int t = 0; t < c.count; ++t) {
             uint16_t p[5][2];
@@ -312,7 +312,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     }
     std::vector<DtwChunk> chunks;
     std::vector<float> dup;
-    std::vector<uint16_t> aimg;  // dtw_mfma_kernel's A images (mfcc_size 5, chunks of 5..8 templates)
+    std::vector<uint16_t> aimg;  // dtw_mfma_kernel's A images (mfcc_size 5, chunks of 3..8 templates)
     // class 4 (not a launch class of its own): the tc-4 halves of the class-2 chunks, see TemplatesDev::split_first
     std::vector<DtwChunk> halves;
     bool can_split = !byclass[2].empty();
@@ -331,10 +331,11 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         for (DtwChunk c : (cls < 4 ? byclass[cls] : halves)) {
             c.rows_off = (int)dup.size();
             c.aimg_off = 0;
-            if (K == 5 && cls == 2) {
+            if (K == 5 && (cls == 1 || cls == 2)) {
                 c.aimg_off = (int)(aimg.size() * sizeof(uint16_t) / 16);
                 append_mfma_image(aimg, c, unit.data(), Lpad);
-                d.mfma_min_len = d.mfma_min_len == 0 ? c.len : std::min(d.mfma_min_len, c.len);
+                int &ml = cls == 2 ? d.mfma_min_len : d.mfma_min_len4;
+                ml = ml == 0 ? c.len : std::min(ml, c.len);
             }
             for (int r = 0; r < c.len; ++r)
                 for (int pr = 0; pr < c.tc / 2; ++pr)

@@ -931,14 +931,17 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
     // n1: single-template chunks to score (class 3; the averaged template is its last chunk)
     if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
     if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
-    if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
-    // chunks of 5..8 templates: the matrix-core kernel (rp_dtw_mfma.hip) at band 3..5, in every mode (LDS-staged, frames from global
-    // memory for live-stream batches and the gate's list, early abandon).  Chunks of 3 or 4 stay with the tc-4 register kernel:
-    // the matrix kernel always pays for eight template slots (C3 shape with 3 templates of 126 frames: 14.6 against 13.6 ms).
+    // chunks of 3..8 templates: the matrix-core kernel (rp_dtw_mfma.hip) in every mode (LDS-staged, frames from global memory for
+    // live-stream batches and the gate's list, early abandon): 5..8 templates at band 3..5 with eight template slots per wave, 3..4 at
+    // band 5 with four.
     {
         const bool from_global = few || gl.list != nullptr;
-        if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global))
-            return launch_dtw_mfma(st, t, W, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+        if (t.class_count[1] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 4)) {
+            if ((e = launch_dtw_mfma(st, t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+                                     scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc)) != hipSuccess) return e;
+        } else if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+        if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8))
+            return launch_dtw_mfma(st, t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                    scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc);
     }
     // Small batches: tc-8 waves run two per SIMD; a launch that fills those slots 2.x times leaves the chip mostly idle in
@@ -1042,7 +1045,8 @@ hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *
     const size_t rows = S * n_win;
     if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
     // (as in launch_dtw: one stream alone is scored like a batch when the matrix-core kernel serves its templates)
-    const bool mfma_batch = few_windows && t.K == 5 && t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true);
+    const bool mfma_batch = few_windows && t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
+                                                        (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)));
     const bool few = few_windows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const int avg_chunk = t.class_first[3] + t.class_count[3] - 1;  // the averaged template: last of the single-template chunks
     hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
@@ -1079,7 +1083,8 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
     // (one stream alone is a batch too when the matrix-core kernel serves its templates: a stream's bits must not depend on the
     // batch it is scored in, live or offline -- only the single-stream mirror, which never passes padded_rows, keeps dtw_single_kernel)
-    const bool mfma_batch = padded_rows && t.K == 5 && t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true);
+    const bool mfma_batch = padded_rows && t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
+                                                         (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)));
     const bool few = padded_rows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const bool do_avg = with_avg && t.has_avg;
     const int Ttot = t.T + (do_avg ? 1 : 0);

@@ -37,19 +37,29 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMK = 5;         // MFCC coefficients per frame
-constexpr int kMSlots = 12;    // circular template-row slots = 3 MFMA tiles x 4
 constexpr int kMWin = 32;      // windows per wave
+// NT template slots per chunk: 8 (chunks of 5..8 templates; a tile of 32 rows = 4 row slots x 8 templates, 12 circular row slots = 3
+// tiles, a lane runs two template pairs) or 4 (chunks of 3..4; a tile = 8 row slots x 4 templates, 16 row slots = 2 tiles, one pair)
+constexpr int mfma_slots(int nt) { return nt == 8 ? 12 : 16; }
+constexpr int mfma_tiles(int nt) { return nt == 8 ? 3 : 2; }
+constexpr int kMSlotsMax = 16;  // rows of zero padding behind a chunk's A image
+// accumulator register of (row slot, template pair p, pair element e) in its tile: the C/D layout puts row (reg & 3) + 8 (reg >> 2) +
+// 4 (lane >> 5) into `reg` of lane half lane >> 5.  NT = 8: row = 8 (slot % 4) + 4 h + (2 p + e); NT = 4: row = 8 (s >> 1) + 4 h +
+// 2 (s & 1) + e with s = slot % 8.
+constexpr int mfma_acc_reg(int nt, int slot, int p, int e) {
+    return nt == 8 ? 4 * (slot % 4) + 2 * p + e : 4 * ((slot % 8) >> 1) + 2 * (slot & 1) + e;
+}
 
 __device__ __forceinline__ unsigned pkrtz(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
 __device__ __forceinline__ float lo_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[0]; }
 __device__ __forceinline__ float hi_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[1]; }
 
-// last band position q of column phase u whose MFMA row slot (u + q + 12 - W + 2) mod 12 lies in tile g; -1: the tile is not read
-template <int W>
+// last band position q of column phase u whose MFMA row slot (u + q + NS - W + 2) mod NS lies in tile g; -1: the tile is not read
+template <int W, int NT>
 __host__ __device__ constexpr int mfma_last_use(int u, int g) {
     int last = -1;
     for (int q = 0; q < 2 * W; ++q)
-        if (((u + q + kMSlots - W + 2) % kMSlots) / 4 == g) last = q;
+        if (((u + q + mfma_slots(NT) - W + 2) % mfma_slots(NT)) / (32 / NT) == g) last = q;
     return last;
 }
 
@@ -60,18 +70,19 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 // (n_win >= 32).  GX = true: lanes read their window's frames from global memory (live-stream batches: a few windows per
 // stream; LIST mode of the averaged-template gate: list[] holds the rows that passed, *count of them).  list == nullptr with a
 // count: DENSE mode of the gate -- the launch does nothing unless *count >= dense_min; LIST mode does nothing when the list is
-// dense (rp_dtw.hip GateList).  abandon_nc < inf: early abandon of detect-only calls -- every 12 columns a wave stops when the
+// dense (rp_dtw.hip GateList).  abandon_nc < inf: early abandon of detect-only calls -- every 12 (16) columns a wave stops when the
 // cheapest band cell of every (window, template) it holds is past abandon_nc * (m + n), writing score 0 (cell costs are >= 0 and
 // every warping path crosses every column, so that cell bounds the final cost from below; the averaged template never stops).
-template <int W, int NW, bool GX>
+template <int W, int NW, bool GX, int NT>
 __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,
     const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched) {
-    constexpr int K = kMK, B = 2 * W, NS = kMSlots;
+    constexpr int K = kMK, B = 2 * W, NS = mfma_slots(NT), NTILE = mfma_tiles(NT), SPT = 32 / NT, NP = NT / 4;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
-    static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 12 row slots");
+    static_assert(NT == 8 || NT == 4, "template slots per chunk");
+    static_assert(B + 2 <= NS, "the band and its two neighbours must fit the circular row slots");
     size_t total_entries = n_streams * n_win;
     if (list) {
         const uint32_t n_listed = *count;
@@ -84,30 +95,36 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const unsigned n_groups = gridDim.x / n_chunks;
     const DtwChunk *ch = chunks + chunk_base + ci;
     const int L = ch->len;  // m == n == L
-    const int a_bytes = (max_len + NS) * kRowBytes;
+    const int a_bytes = (max_len + kMSlotsMax) * kRowBytes;
     const int xs_floats = dtw_mfma_stage_floats(max_len);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         const u32x4 *asrc = reinterpret_cast<const u32x4 *>(aimg) + ch->aimg_off;
         u32x4 *adst = reinterpret_cast<u32x4 *>(smem);
-        for (int i = tid; i < (L + NS) * kRowBytes / 16; i += 64 * NW) adst[i] = asrc[i];
+        for (int i = tid; i < (L + kMSlotsMax) * kRowBytes / 16; i += 64 * NW) adst[i] = asrc[i];
     }
     __syncthreads();
     float *xs = reinterpret_cast<float *>(smem + a_bytes) + wave * xs_floats;
     (void)xs;
     const int n = lane & 31, h = lane >> 5;
-    // A operand: this lane supplies row m = lane & 31 of a tile = (slot 4g + jj, template 4h' + r'), k half = lane >> 5
-    const int jj = (lane & 31) >> 3, tA = ((lane >> 2) & 1) * 4 + (lane & 3);
+    // A operand: this lane supplies row m = lane & 31 of a tile, k half = lane >> 5.  NT = 8: m = 8 jj + 4 h' + r' = (row slot jj of the
+    // tile, template 4 h' + r'); NT = 4: m = 8 G + 4 h' + 2 sp + e = (row slot 2 G + sp, template 2 h' + e).
+    const int mrow = lane & 31;
+    const int jj = NT == 8 ? mrow >> 3 : 2 * (mrow >> 3) + ((mrow >> 1) & 1);
+    const int tA = NT == 8 ? ((mrow >> 2) & 1) * 4 + (mrow & 3) : ((mrow >> 2) & 1) * 2 + (mrow & 1);
     const unsigned a_lane = (unsigned)(h * 128 + tA * 16);
-    unsigned dl[4];  // byte offset back to the row this lane's slot holds when the newest row sits in slot e of its tile
+    unsigned dl[SPT];  // byte offset back to the row this lane's slot holds when the newest row sits in slot e of its tile
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dl[e] = (unsigned)(((e - jj + NS) % NS) * kRowBytes);
+    for (int e = 0; e < SPT; ++e) dl[e] = (unsigned)(((e - jj + NS) % NS) * kRowBytes);
     const unsigned sel_one = h ? 0x07060100u : 0x03020100u;  // slot 7: x1 of component 2 (half 0) / the constant 1.0 (half 1)
     const float abandon_cost = abandon_nc * (float)(L + L);
-    // which of this lane's four templates can keep a wave alive: real ones; the averaged template (tid >= T) always does
-    bool slot_real[4], slot_avg[4];
+    // which of this lane's templates (NT / 2 of them) can keep a wave alive: real ones; the averaged template (tid >= T) always does
+    bool slot_real[2 * NP], slot_avg[2 * NP];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { slot_real[e] = 4 * h + e < ch->count; slot_avg[e] = slot_real[e] && ch->tid[4 * h + e] >= T; }
+    for (int e = 0; e < 2 * NP; ++e) {
+        slot_real[e] = 2 * NP * h + e < ch->count;
+        slot_avg[e] = slot_real[e] && ch->tid[2 * NP * h + e] >= T;
+    }
 
     // Tiles are handed out by an atomic counter per chunk (sched[2 ci]): a small batch is a few tiles per wave, and a static
     // split leaves most of the chip waiting for the waves that got one tile more (BASELINE config C2: 3.09 tiles per wave).
@@ -171,22 +188,22 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 
         // Q[p][q] = D[(c - 1) - W + 1 + q][c - 1] of the template pair p (band position, as P[] of dtw_band_kernel with rows and
         // columns swapped); column 0: D[0][0] = 0 sits at q = W - 1.  Q[p][B] stays +inf (the cell below the band).
-        v2f Q[2][B + 1];
+        v2f Q[NP][B + 1];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
             for (int q = 0; q <= B; ++q) Q[p][q] = (v2f){RP_INF, RP_INF};
             Q[p][W - 1] = (v2f){0.f, 0.f};
         }
-        u32x4 Areg[3];
+        u32x4 Areg[NTILE];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const int slot = 4 * g + jj;
+        for (int g = 0; g < NTILE; ++g) {
+            const int slot = SPT * g + jj;
             int r = W - ((W - slot + NS) % NS);  // 1-based template row in this slot for the state "newest row = W"
             r = r < 1 ? 1 : r;
             Areg[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)(r - 1) * kRowBytes);
         }
-        v16f acc[3];   // costs of the current column; a tile is refilled for the next column as soon as its last cell is done
+        v16f acc[NTILE];   // costs of the current column; a tile is refilled for the next column as soon as its last cell is done
         u32x4 bop[2];  // B operand of column cc in bop[cc & 1]: built two columns ahead, in pieces between the cells
 
 // The frame work of column cc, cut into ten pieces P0..P9 that are placed between the cells of the recurrence.
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 // the A tile that receives template row cc + W (cc = 1 + uu mod 12)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
     {                                                                                                                         \
-        const int sn = ((uu) + 1 + W) % NS, g = sn / 4, e = sn % 4;                                                           \
+        const int sn = ((uu) + 1 + W) % NS, g = sn / SPT, e = sn % SPT;                                                       \
         int off = ((cc) + W - 1) * kRowBytes - (int)dl[e];                                                                    \
         if (GUARD) off = off < 0 ? 0 : off;                                                                                   \
         Areg[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)off);                                            \
@@ -223,8 +240,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         v2f up[2] = {(v2f){RP_INF, RP_INF}, (v2f){RP_INF, RP_INF}};                                                           \
         _Pragma("unroll") for (int q = 0; q < B; ++q) {                                                                       \
             const int sl = (u + q + NS - W + 2) % NS;                                                                         \
-            _Pragma("unroll") for (int p = 0; p < 2; ++p) { /* two independent chains, interleaved */                         \
-                const v2f cost = (v2f){acc[sl / 4][4 * (sl % 4) + 2 * p], acc[sl / 4][4 * (sl % 4) + 2 * p + 1]};             \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) { /* NT = 8: two independent chains, interleaved */                \
+                const v2f cost = (v2f){acc[sl / SPT][mfma_acc_reg(NT, sl, p, 0)], acc[sl / SPT][mfma_acc_reg(NT, sl, p, 1)]}; \
                 v2f m, v;                                                                                                     \
                 m.x = fminf(fminf(up[p].x, Q[p][q + 1].x), Q[p][q].x);                                                        \
                 m.y = fminf(fminf(up[p].y, Q[p][q + 1].y), Q[p][q].y);                                                        \
@@ -239,25 +256,26 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             if (q == (3 * B) / 10) { RP_P3(c + 2) } if (q == (4 * B) / 10) { RP_P4(c + 2) } if (q == (5 * B) / 10) { RP_P5(c + 2) } \
             if (q == (6 * B) / 10) { RP_P6(c + 2, (u + 1) & 1) } if (q == (7 * B) / 10) { RP_P7(c + 2, (u + 1) & 1) }         \
             if (q == (8 * B) / 10) { RP_P8(c + 2) } if (q == (9 * B) / 10) { RP_P9(c + 2, (u + 1) & 1) }                      \
-            _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                                     \
-                if (mfma_last_use<W>(u, g) == q) RP_MFMA(g, u & 1);                                                           \
+            _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                 \
+                if (mfma_last_use<W, NT>(u, g) == q) RP_MFMA(g, u & 1);                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
-        _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                                         \
-            if (mfma_last_use<W>(u, g) < 0) RP_MFMA(g, u & 1);                                                                \
+        _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                     \
+            if (mfma_last_use<W, NT>(u, g) < 0) RP_MFMA(g, u & 1);                                                            \
     } while (0)
 
         float fa_, fb_, f2_, da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_;
         unsigned t_;
         RP_AREF(1, 0, true)
         RP_PREP_ALL(1, 1)
-        RP_MFMA(0, 1); RP_MFMA(1, 1); RP_MFMA(2, 1);
+        RP_MFMA(0, 1); RP_MFMA(1, 1);
+        if (NTILE > 2) RP_MFMA(NTILE - 1, 1);
         RP_PREP_ALL(2, 0)
         RP_P0(3)
         __builtin_amdgcn_sched_barrier(0);
         int c0 = 1;
         bool dead = false;
-        {   // first block: cells of rows < 1 stay +inf (L >= 12)
+        {   // first block: cells of rows < 1 stay +inf (L >= NS)
 #pragma unroll
             for (int u = 0; u < NS; ++u) { const int c = c0 + u; RP_STEP(true); }
         }
@@ -265,7 +283,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #define RP_ABANDON_CHECK()                                                                                                    \
     if (abandon_nc < RP_INF) {                                                                                                \
         bool alive = false;                                                                                                   \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                                       \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                      \
             v2f m = Q[p][0];                                                                                                  \
             _Pragma("unroll") for (int q = 1; q < B; ++q) m = (v2f){fminf(m.x, Q[p][q].x), fminf(m.y, Q[p][q].y)};             \
             alive = alive || (slot_real[2 * p] && (m.x <= abandon_cost || slot_avg[2 * p])) ||                                \
@@ -310,10 +328,10 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             const size_t row = s * out_win_pitch + (size_t)w;
             const float denom = (float)(L + L);
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int slot = 4 * h + 2 * p + e;
+                    const int slot = 2 * NP * h + 2 * p + e;
                     if (slot < ch->count) {
                         const float cost = e ? Q[p][W - 2].y : Q[p][W - 2].x;
                         const float nc = cost / denom;
@@ -337,17 +355,19 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     }
 }
 
-bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global) {
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots) {
     const char *env = std::getenv("RP_DTW_MFMA");  // "0": the register kernels only (A/B runs and the cross-check tests); read per call
-    if ((env && env[0] == '0') || t.K != kMK || band < 3 || band > 5 || !t.aimg || t.max_diff != 0) return false;  // 12 row slots hold 2 band + 2 rows
-    if (!from_global && n_win < (size_t)kMWin) return false;  // a staged tile holds at most two stream segments
-    if (t.mfma_min_len < kMSlots) return false;               // the first 12 columns are one unguarded block
+    if ((env && env[0] == '0') || t.K != kMK || !t.aimg || t.max_diff != 0) return false;
+    if (slots == 8 ? (band < 3 || band > 5) : band != 5) return false;  // 12 (16) row slots hold 2 band + 2 rows; 4 slots: band 5 only
+    if (!from_global && n_win < (size_t)kMWin) return false;            // a staged tile holds at most two stream segments
+    // the first 12 (16) columns are one guarded block
+    if (slots == 8 ? t.mfma_min_len < mfma_slots(8) : t.mfma_min_len4 < mfma_slots(4)) return false;
     return dtw_mfma_lds_bytes(t.max_len, 8) <= 160 * 1024;
 }
 
-hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
-                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, bool from_global,
-                           const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc) {
+hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
+                           size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
+                           bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc) {
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
     if (list && !from_global) return hipErrorNotSupported;
     const size_t total_tiles = (S * n_win + kMWin - 1) / kMWin;
@@ -361,24 +381,29 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int 
     if (groups > need) groups = need;
     const size_t blocks = groups * (size_t)n_chunks;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-#define RP_LAUNCH_MFMA(WW, NW, GXV)                                                                                                 \
+#define RP_LAUNCH_MFMA(WW, NW, GXV, NT)                                                                                             \
     do {                                                                                                                            \
-        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<WW, NW, GXV>), 160 * 1024); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<WW, NW, GXV, NT>), 160 * 1024); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV, NT>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
                            reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
                            abandon_nc, t.mfma_sched);                                                                               \
     } while (0)
-#define RP_LAUNCH_MFMA_W(WW)                                                                                                        \
+#define RP_LAUNCH_MFMA_W(WW, NT)                                                                                                    \
     do {                                                                                                                            \
-        if (from_global) { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, true); else RP_LAUNCH_MFMA(WW, 8, true); }                          \
-        else { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, false); else RP_LAUNCH_MFMA(WW, 8, false); }                                    \
+        if (from_global) { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, true, NT); else RP_LAUNCH_MFMA(WW, 8, true, NT); }                  \
+        else { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, false, NT); else RP_LAUNCH_MFMA(WW, 8, false, NT); }                            \
     } while (0)
-    switch (band) {
-    case 3: RP_LAUNCH_MFMA_W(3); break;
-    case 4: RP_LAUNCH_MFMA_W(4); break;
-    case 5: RP_LAUNCH_MFMA_W(5); break;
-    default: return hipErrorNotSupported;
+    if (slots == 4) {
+        if (band != 5) return hipErrorNotSupported;
+        RP_LAUNCH_MFMA_W(5, 4);
+    } else {
+        switch (band) {
+        case 3: RP_LAUNCH_MFMA_W(3, 8); break;
+        case 4: RP_LAUNCH_MFMA_W(4, 8); break;
+        case 5: RP_LAUNCH_MFMA_W(5, 8); break;
+        default: return hipErrorNotSupported;
+        }
     }
 #undef RP_LAUNCH_MFMA_W
 #undef RP_LAUNCH_MFMA

@@ -67,15 +67,15 @@ struct DtwChunk {
     int tc;               // register tile the kernel is instantiated for: 2, 4 or 8
     int rows_off;         // float offset of the chunk's rows in TemplatesDev::dup
     int tid[kChunkMax];   // output column of each template; T means the averaged template
-    int aimg_off;         // chunks of 5..8 templates at mfcc_size 5: offset (16-byte units) of the chunk's A image in TemplatesDev::aimg
+    int aimg_off;         // chunks of 3..8 templates at mfcc_size 5: offset (16-byte units) of the chunk's A image in TemplatesDev::aimg
 };
 
 // dtw_mfma_kernel (rp_dtw_mfma.hip): A image = per template row [k half 2][template 8] x 8 f16 (the negated unit row, split in two f16
-// parts, in the slot order of the MFMA's B operand) for len + 12 rows (the tail rows are zero); per wave two stream segments of frames.
+// parts, in the slot order of the MFMA's B operand) for len + 16 rows (the tail rows are zero); per wave two stream segments of frames.
 constexpr int kDtwMfmaRowBytes = 256;
 __host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 + 2 * (max_len + 3)) * 5 + 3) & ~3; }
 inline size_t dtw_mfma_lds_bytes(int max_len, int waves) {
-    return (size_t)(max_len + 12) * kDtwMfmaRowBytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);
+    return (size_t)(max_len + 16) * kDtwMfmaRowBytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);
 }
 
 // Device-resident template set of one wakeword reference.
@@ -99,19 +99,21 @@ struct TemplatesDev {
     // every class-2 chunk once more as two tc-4 halves (only when each of them holds 7 or 8 templates): a small batch whose
     // tc-8 waves would fill the chip 2.x times is scored by twice as many tc-4 waves, three resident per SIMD instead of two
     int split_first = 0, split_count = 0;
-    // dtw_mfma_kernel: A images of the class-2 chunks (mfcc_size 5 only), and the shortest template among them
+    // dtw_mfma_kernel: A images of the class-1 and class-2 chunks (mfcc_size 5 only), and the shortest template among them
     void *aimg = nullptr;
-    int mfma_min_len = 0;
+    int mfma_min_len = 0;   // shortest template among the class-2 chunks (8 template slots; needs >= 12 frames)
+    int mfma_min_len4 = 0;  // ... among the class-1 chunks (4 template slots; needs >= 16 frames)
     uint32_t *mfma_sched = nullptr;  // per chunk {next tile, workgroups done}: dtw_mfma_kernel's tile counter, zero between launches
 };
 
-// The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of class 2 (5..8 templates): mfcc_size 5, band 3..5.  from_global: lanes
-// read their frames from global memory (live-stream batches, LIST mode of the averaged-template gate) instead of an LDS stage
-// (needs n_win >= 32).  list / count / dense_min / abandon_nc: as GateList in rp_dtw.hip.
-bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global);
-hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int chunk_base, int n_chunks, const float *mfcc, size_t S, size_t frame_pitch,
-                           size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, bool from_global,
-                           const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc);
+// The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of class 2 (5..8 templates; slots = 8, band 3..5) and class 1 (3..4
+// templates; slots = 4, band 5) at mfcc_size 5.  from_global: lanes read their frames from global memory (live-stream batches, LIST mode
+// of the averaged-template gate) instead of an LDS stage (needs n_win >= 32).  list / count / dense_min / abandon_nc: as GateList in
+// rp_dtw.hip.
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots = 8);
+hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
+                           size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
+                           bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs
 // (one rp_ctx per device) has to set it on each of them.  Sets it once per (current device, kernel), thread-safe.

@@ -1,7 +1,7 @@
 """dtw_mfma_kernel (rustpotter_amd/csrc/rp_dtw_mfma.hip): the banded DTW whose cosine costs come out of the matrix cores, taken for
-mfcc_size 5 / band 5 chunks of 5..8 same-length templates.  Against the oracle (1e-5, the gate of every DTW test), against the
+mfcc_size 5 chunks of 3..8 same-length templates (5..8: band 3..5, eight template slots per wave; 3..4: band 5, four slots).  Against the oracle (1e-5, the gate of every DTW test), against the
 register kernels it replaces (RP_DTW_MFMA=0: same scores to 2e-6, and not the same bits -- i.e. the kernel really runs), and in
-its other modes (chunks of 5..8 same-length templates): tiles that straddle streams, frames read from global memory (live-stream batches, the gate's list), early abandon."""
+its other modes: tiles that straddle streams, frames read from global memory (live-stream batches, the gate's list), early abandon."""
 import os
 
 import numpy as np
@@ -49,11 +49,13 @@ class _registers_only:
             os.environ["RP_DTW_MFMA"] = self.old
 
 
-@pytest.mark.parametrize("L,T", [(12, 5), (13, 8), (23, 5), (24, 6), (25, 8), (36, 7), (59, 6), (100, 8), (126, 5), (40, 4), (100, 3)])
+@pytest.mark.parametrize("L,T", [(12, 5), (13, 8), (23, 5), (24, 6), (25, 8), (36, 7), (59, 6), (100, 8), (126, 5),
+                                 (16, 3), (17, 4), (31, 4), (32, 3), (33, 4), (47, 4), (48, 3), (100, 4), (126, 3), (12, 4), (15, 3), (40, 2)])
 def test_scores_match_the_oracle(ra, ctx, L, T):
-    """Template lengths around the 12-column blocks (12, 13, 23..25, 36), chunk sizes 5..8, window counts that are not a multiple
-    of the 32-window tile: the flattened tiles straddle the three streams.  Chunks of 3 or 4 templates stay with the tc-4
-    register kernel (the last two cases: the switch changes nothing there)."""
+    """Template lengths around the column blocks (12 columns with eight template slots: 12, 13, 23..25, 36; 16 with four: 16, 17,
+    31..33, 47, 48), chunk sizes 3..8, window counts that are not a multiple of the 32-window tile: the flattened tiles straddle the
+    three streams.  Chunks of two templates and chunks of 3..4 templates shorter than 16 frames stay with the register kernels (the
+    last three cases: the switch changes nothing there)."""
     K, S = 5, 3
     n_win = 45 if L < 60 else 39
     templates = orc.synth_templates(SEED + L, T, L, K)
@@ -68,7 +70,8 @@ def test_scores_match_the_oracle(ra, ctx, L, T):
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm)
     assert rel_close(scores, reg, 2e-6), np.abs(scores / reg - 1).max()
-    assert np.array_equal(scores, reg) == (T < 5), "chunks of 5..8 templates take the matrix-core kernel, smaller ones do not"
+    matrix = (T >= 5 and L >= 12) or (3 <= T <= 4 and L >= 16)
+    assert np.array_equal(scores, reg) == (not matrix), "which chunks take the matrix-core kernel"
 
 
 @pytest.mark.parametrize("band,L,T", [(3, 37, 8), (4, 50, 6), (3, 12, 5), (4, 24, 7)])
@@ -91,6 +94,12 @@ def test_bands_three_and_four(ra, ctx, band, L, T):
     with _registers_only():
         six_reg, _, _ = ctx.dtw_scores(mf, tm, band_size=6)
     assert np.array_equal(six, six_reg)
+    # four template slots per wave exist for band 5 only
+    tm4 = ra.Templates(ctx, templates[:4])
+    four, _, _ = ctx.dtw_scores(mf, tm4, band_size=band)
+    with _registers_only():
+        four_reg, _, _ = ctx.dtw_scores(mf, tm4, band_size=band)
+    assert np.array_equal(four, four_reg)
 
 
 def test_mixed_chunk_classes_and_an_averaged_template(ra, ctx):

@@ -229,6 +229,42 @@ static void append_mfma_image(std::vector<uint16_t> &img, const DtwChunk &c, con
         }
 }
 
+// dtw_mfma_wide_kernel's A operand of one chunk (rp_dtw_mfma_wide.hip): per template row [k-step][k half 2][template slot 8] x 8 f16.
+// Lane half kh owns components kh * CHM .. kh * CHM + CHM - 1 (zero beyond K).  With a = -(unit row) = a0 + a1 the registers of a half
+// are, per component pair (p, q): (a0p, a0q), (a0p, a0q), (a1p, a1q) against the window side's (x0p, x0q), (x1p, x1q), (x0p, x0q); an odd
+// last component s: (a0s, a0s), (a1s, c) against (x0s, x1s), (x0s, c); an even count: (c, 0) against (c, 0); c = 1.0 in half 1 only.
+static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad, int K) {
+    const int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, KS = dtw_mfma_wide_ksteps(K), row_bytes = KS * 256;
+    const size_t base = img.size();
+    img.resize(base + (size_t)(c.len + 16) * row_bytes / 2, 0);
+    for (int r = 0; r < c.len; ++r)
+        for (int t = 0; t < c.count; ++t)
+            for (int kh = 0; kh < 2; ++kh) {
+                std::vector<uint16_t> v(8 * KS, 0);  // 4 KS registers of two f16
+                auto part = [&](int j, int which) -> uint16_t {
+                    const int comp = kh * CHM + j;
+                    if (comp >= K) return 0;
+                    const float a = -unit[((size_t)c.tid[t] * Lpad + r) * K + comp];
+                    const uint16_t a0 = f16_rtz_bits(a);
+                    return which == 0 ? a0 : f16_rtz_bits(a - f16_bits_to_f32(a0));
+                };
+                for (int j = 0; j < NPAIR; ++j) {
+                    v[2 * (3 * j) + 0] = part(2 * j, 0); v[2 * (3 * j) + 1] = part(2 * j + 1, 0);
+                    v[2 * (3 * j + 1) + 0] = part(2 * j, 0); v[2 * (3 * j + 1) + 1] = part(2 * j + 1, 0);
+                    v[2 * (3 * j + 2) + 0] = part(2 * j, 1); v[2 * (3 * j + 2) + 1] = part(2 * j + 1, 1);
+                }
+                const uint16_t cst = kh ? 0x3c00 : 0;
+                if (CHM % 2) {
+                    v[2 * (3 * NPAIR) + 0] = part(CHM - 1, 0); v[2 * (3 * NPAIR) + 1] = part(CHM - 1, 0);
+                    v[2 * (3 * NPAIR + 1) + 0] = part(CHM - 1, 1); v[2 * (3 * NPAIR + 1) + 1] = cst;
+                } else {
+                    v[2 * (3 * NPAIR) + 0] = cst;
+                }
+                for (int ks = 0; ks < KS; ++ks)
+                    std::memcpy(&img[base + ((size_t)r * row_bytes + ks * 256 + kh * 128 + t * 16) / 2], &v[8 * ks], 16);
+            }
+}
+
 // Template rows are scaled to unit L2 norm in f64 and rounded once to f32; an all-zero
 // row stays zero so that its cosine similarity is 0 (src/mfcc/comparator.rs:43-47).
 Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len,
@@ -345,6 +381,32 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
                             dup.push_back(unit[((size_t)c.tid[tt < c.count ? tt : 0] * Lpad + r) * K + k]);
                         }
             chunks.push_back(c);
+        }
+    }
+    if (K == 13 || K == 16) {  // dtw_mfma_wide_kernel: every length at least three times, else the wide register kernels keep the set
+        std::vector<DtwChunk> wide8;
+        bool all3 = T >= 3;
+        for (int i = 0; i < T && all3;) {
+            int j = i;
+            while (j < T && hl[order[j]] == hl[order[i]]) ++j;
+            if (j - i < 3) { all3 = false; break; }
+            for (int b = i; b < j; b += kChunkMax) {
+                DtwChunk c{};
+                c.len = hl[order[i]]; c.count = std::min(kChunkMax, j - b); c.tc = 8;
+                for (int q = 0; q < kChunkMax; ++q) c.tid[q] = order[b + (q < c.count ? q : 0)];
+                wide8.push_back(c);
+            }
+            i = j;
+        }
+        if (all3) {
+            d.wide8_first = (int)chunks.size(); d.wide8_count = (int)wide8.size();
+            for (DtwChunk c : wide8) {
+                c.rows_off = 0;
+                c.aimg_off = (int)(aimg.size() * sizeof(uint16_t) / 16);
+                append_mfma_wide_image(aimg, c, unit.data(), Lpad, K);
+                d.mfma_min_len = d.mfma_min_len == 0 ? c.len : std::min(d.mfma_min_len, c.len);
+                chunks.push_back(c);
+            }
         }
     }
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.chunks), sizeof(DtwChunk) * chunks.size()), "hipMalloc(chunks)")) return nullptr;

@@ -802,7 +802,16 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
 template <int K, int W>
 static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int n1, const float *mfcc, size_t S, size_t frame_pitch,
                                       size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores,
-                                      float *avg, bool few, GateList gl = GateList{}) {
+                                      float *avg, bool few, GateList gl = GateList{}, bool padded = false) {
+    // every length at least three times, band 5, rows with slack behind them: the sample templates on the matrix cores
+    // (rp_dtw_mfma_wide.hip), the averaged template -- if it is to be scored here -- through the one-template register kernel
+    if (W == 5 && (padded || few || gl.list) && dtw_mfma_wide_supported(t, W)) {
+        if (t.has_avg && n1 == t.class_count[3])
+            if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
+                                                        few, gl, t.class_first[3] + t.class_count[3] - 1); e != hipSuccess) return e;
+        return launch_dtw_mfma_wide(st, t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, gl.list, gl.count,
+                                    gl.dense_min, gl.abandon_nc);
+    }
     if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, n1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl); e != hipSuccess) return e;
     return launch_dtw_wide<K, W, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
 }
@@ -1031,10 +1040,10 @@ static hipError_t gated_wide(hipStream_t st, const TemplatesDev &t, int avg_chun
     GateList gl;
     gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc;
     gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
-    e = launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
+    e = launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl, true);
     if (e != hipSuccess || few) return e;
     gl.list = nullptr;
-    return launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
+    return launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl, true);
 }
 
 // first_win / few_windows as in launch_dtw (live-stream batches score the few newest windows of every stream: then pass 1
@@ -1045,8 +1054,9 @@ hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *
     const size_t rows = S * n_win;
     if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
     // (as in launch_dtw: one stream alone is scored like a batch when the matrix-core kernel serves its templates)
-    const bool mfma_batch = few_windows && t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
-                                                        (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)));
+    const bool mfma_batch = few_windows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
+                                                          (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)))) ||
+                                            dtw_mfma_wide_supported(t, band));
     const bool few = few_windows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const int avg_chunk = t.class_first[3] + t.class_count[3] - 1;  // the averaged template: last of the single-template chunks
     hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
@@ -1083,8 +1093,9 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
     // (one stream alone is a batch too when the matrix-core kernel serves its templates: a stream's bits must not depend on the
     // batch it is scored in, live or offline -- only the single-stream mirror, which never passes padded_rows, keeps dtw_single_kernel)
-    const bool mfma_batch = padded_rows && t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
-                                                         (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)));
+    const bool mfma_batch = padded_rows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
+                                                           (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)))) ||
+                                            dtw_mfma_wide_supported(t, band));
     const bool few = padded_rows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const bool do_avg = with_avg && t.has_avg;
     const int Ttot = t.T + (do_avg ? 1 : 0);
@@ -1114,7 +1125,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
             default: return launch_dtw_k5<6>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
             }
         }
-#define RP_WIDE_CALL(KK, WW) launch_dtw_wide_all<KK, WW>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)
+#define RP_WIDE_CALL(KK, WW) launch_dtw_wide_all<KK, WW>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl, padded_rows)
         RP_WIDE_DISPATCH(RP_WIDE_CALL);
 #undef RP_WIDE_CALL
     }

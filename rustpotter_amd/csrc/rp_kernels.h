@@ -74,6 +74,11 @@ struct DtwChunk {
 // parts, in the slot order of the MFMA's B operand) for len + 16 rows (the tail rows are zero); per wave two stream segments of frames.
 constexpr int kDtwMfmaRowBytes = 256;
 __host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 + 2 * (max_len + 3)) * 5 + 3) & ~3; }
+// dtw_mfma_wide_kernel (mfcc_size 13 / 16): components per lane half and k-steps of 16 f16 slots (rp_dtw_mfma_wide.hip)
+__host__ __device__ constexpr int dtw_mfma_wide_chm(int K) { return (K + 1) / 2; }
+__host__ __device__ constexpr int dtw_mfma_wide_ksteps(int K) {
+    return (3 * (dtw_mfma_wide_chm(K) / 2) + (dtw_mfma_wide_chm(K) % 2 ? 2 : 1) + 3) / 4;
+}
 inline size_t dtw_mfma_lds_bytes(int max_len, int waves) {
     return (size_t)(max_len + 16) * kDtwMfmaRowBytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);
 }
@@ -103,6 +108,9 @@ struct TemplatesDev {
     void *aimg = nullptr;
     int mfma_min_len = 0;   // shortest template among the class-2 chunks (8 template slots; needs >= 12 frames)
     int mfma_min_len4 = 0;  // ... among the class-1 chunks (4 template slots; needs >= 16 frames)
+    // mfcc_size 13 / 16: the sample templates once more as chunks of up to 8 same-length templates for dtw_mfma_wide_kernel (only when
+    // every length occurs at least three times: the matrix kernel always pays for eight template slots)
+    int wide8_first = 0, wide8_count = 0;
     uint32_t *mfma_sched = nullptr;  // per chunk {next tile, workgroups done}: dtw_mfma_kernel's tile counter, zero between launches
 };
 
@@ -111,6 +119,11 @@ struct TemplatesDev {
 // of the averaged-template gate) instead of an LDS stage (needs n_win >= 32).  list / count / dense_min / abandon_nc: as GateList in
 // rp_dtw.hip.
 bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots = 8);
+// mfcc_size 13 / 16 at band 5: frames always from global memory (the caller's rows end with slack: launch_dtw's padded_rows)
+bool dtw_mfma_wide_supported(const TemplatesDev &t, int band);
+hipError_t launch_dtw_mfma_wide(hipStream_t st, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                                size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, const uint32_t *list,
+                                const uint32_t *count, uint32_t dense_min, float abandon_nc);
 hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
                            bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc);

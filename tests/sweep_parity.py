@@ -52,11 +52,13 @@ def make_case(rng, extreme=False, mfma=False):
         T = int(rng.choice([1, 2, 9, 20]))
         lens = np.full(T, int(rng.integers(20, 60))) if rng.random() < 0.4 else rng.choice([1, 2, 3, 5, 8, 30, 64, 65, 128], size=T)
     if mfma:  # the shapes dtw_mfma_kernel takes: mfcc_size 5, chunks of 3..8 same-length templates (plus, sometimes, a few others)
-        K = 5
+        K = int(rng.choice([5, 5, 5, 16, 13]))  # 13 / 16: dtw_mfma_wide_kernel, when every length occurs at least three times
         T = int(rng.integers(3, 17))
         lens = np.full(T, int(rng.integers(12, 110)))
-        if rng.random() < 0.4:
+        if rng.random() < (0.4 if K == 5 else 0.15):
             lens[: int(rng.integers(1, 4))] = rng.integers(12, 110)
+        elif K != 5 and T >= 6 and rng.random() < 0.4:
+            lens[: T // 2] = int(rng.integers(12, 110))  # two lengths, three or more templates each
     utts = [_utterance(rng, 480 * ((int(L) + 3 + 2) // 3)) for L in lens]
     templates = [orc.normalize(orc.mfcc_stream(u, K))[:int(L)] for u, L in zip(utts, lens)]
     avg = None
@@ -69,7 +71,7 @@ def make_case(rng, extreme=False, mfma=False):
                band_size=int(rng.integers(1, 9)), score_mode=str(rng.choice(MODES)),
                vad_mode=[None, None, None, "easy", "medium", "hard"][int(rng.integers(6))])
     if mfma:
-        cfg.update(band_size=int(rng.choice([3, 4, 5, 5, 5])))
+        cfg.update(band_size=int(rng.choice([3, 4, 5, 5, 5])) if K == 5 else 5)
         if rng.random() < 0.5:  # detect-only calls in ScoreMode::Max abandon hopeless DTWs: half of the cases take that path too
             cfg.update(score_mode="max")
     if extreme:  # see make_api_case
@@ -1124,7 +1126,7 @@ if __name__ == "__main__":
     ap.add_argument("--reset-cases", type=int, default=0, help="live-stream batches with single-stream resets")
     ap.add_argument("--extreme-cases", type=int, default=0, help="single-stream API cases with edge-of-range detector parameters")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
-    ap.add_argument("--mfma-cases", type=int, default=0, help="batch cases in the shapes the matrix-core DTW kernel takes (mfcc_size 5, 3..16 same-length templates, band 3..5)")
+    ap.add_argument("--mfma-cases", type=int, default=0, help="batch cases in the shapes the matrix-core DTW kernel takes (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates)")
     a = ap.parse_args()
     import rustpotter_amd as ra
     ctx = ra.BatchContext(0)
@@ -1134,7 +1136,7 @@ if __name__ == "__main__":
         ("sweep", a.cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
         ("matrix-core DTW sweep", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True),
-         lambda r: "%d cases (mfcc_size 5, 3..16 same-length templates, band 3..5), %d detections compared, %d threshold ties skipped" % r),
+         lambda r: "%d cases (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates), %d detections compared, %d threshold ties skipped" % r),
         ("live rate sweep", a.rate_cases, lambda n: run_live_rate_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases live == offline bitwise, %d detections equal to the oracle's, %d near-tie cases" % r),
         ("live reset sweep", a.reset_cases, lambda n: run_live_reset_sweep(ra, ctx, n, a.seed, verbose=True),

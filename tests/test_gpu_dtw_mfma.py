@@ -235,3 +235,52 @@ def test_matrix_core_sweep_few_cases(ra):
     ctx = ra.BatchContext(0)
     n, total, ties = sweep_parity.run_sweep(ra, ctx, 10, 3, mfma=True)
     assert n == 10 and ties <= 1
+
+
+@pytest.mark.parametrize("K,L,T", [(16, 40, 8), (16, 12, 3), (16, 61, 11), (13, 37, 5), (13, 24, 8), (13, 100, 3)])
+def test_wide_frames_match_the_oracle(ra, ctx, K, L, T):
+    """mfcc_size 13 / 16 (dtw_mfma_wide_kernel, rp_dtw_mfma_wide.hip): every length at least three times, band 5, through the batched
+    detector (its frame rows end with slack: the kernel reads its frames from global memory).  Scores against the oracle, against the
+    wide register kernels (2e-6, not the same bits), and the live-stream batch against the offline call bit for bit."""
+    S, N = 3, 480 * 45
+    templates = orc.synth_templates(SEED + K + L, T, L, K)
+    tm = ra.Templates(ctx, templates)
+    pcm = np.stack([orc.synth_pcm(SEED, 300 + s, N) for s in range(S)])
+    cfg = ra.DetectorConfig()
+    cfg.threshold, cfg.min_scores = 0.3, 1
+    _, _, scores, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(orc.mfcc_stream(pcm[s], K), templates)
+        assert rel_close(scores[s], ref_s), np.abs(scores[s] / ref_s - 1).max()
+        assert rel_close(agg[s], ref_a)
+    with _registers_only():
+        _, _, reg, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    assert rel_close(scores, reg, 2e-6) and not np.array_equal(scores, reg)
+    sb = ra.StreamBatch(ctx, tm, cfg, S, max_chunks_per_call=2)
+    compared = 0
+    for i in range(0, N, 960):
+        _, _, a = sb.process(pcm[:, i:i + 960], want_agg=True)
+        f0 = 3 * (i // 480) - 3
+        for k in range(a.shape[1]):
+            wi = f0 + k - (L - 1)
+            if 0 <= wi < agg.shape[1]:
+                assert np.array_equal(a[:, k], agg[:, wi])
+                compared += 1
+    assert compared >= 30
+
+
+def test_wide_frames_with_a_rare_length_keep_the_register_kernels(ra, ctx):
+    """A length that occurs fewer than three times: the matrix kernel would pay for eight template slots -- the whole set stays with
+    the wide register kernels (the switch changes nothing)."""
+    K = 16
+    templates = orc.synth_templates(SEED + 71, 5, 40, K)
+    templates[4] = templates[4][:33].copy()
+    tm = ra.Templates(ctx, templates)
+    pcm = np.stack([orc.synth_pcm(SEED, 320 + s, 480 * 40) for s in range(2)])
+    cfg = ra.DetectorConfig()
+    _, _, scores, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    with _registers_only():
+        _, _, reg, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    assert np.array_equal(scores, reg)
+    ref_s, _ = orc.score_stream(orc.mfcc_stream(pcm[0], K), templates)
+    assert rel_close(scores[0], ref_s)

@@ -248,8 +248,9 @@ def main():
     dtw_bytes = per_gpu_scorings * (4 * K + 4 * (T + 2))
     # which DTW kernel ran (rp_dtw.hip launch_dtw_k5): chunks of 3..8 same-length templates at mfcc_size 5 / band 5 go to the
     # matrix-core kernel unless RP_DTW_MFMA=0
-    mfma_used = (K == 5 and os.environ.get("RP_DTW_MFMA", "1")[:1] != "0" and min(lens) >= 12 and any(c >= 3 for c in by_len.values())
-                 )
+    mfma_on = os.environ.get("RP_DTW_MFMA", "1")[:1] != "0" and min(lens) >= 12
+    mfma_wide = mfma_on and K in (13, 16) and all(c >= 3 for c in by_len.values())  # dtw_mfma_wide_kernel (rp_dtw_mfma_wide.hip)
+    mfma_used = mfma_wide or (mfma_on and K == 5 and any(c >= 3 for c in by_len.values()))
     # executed arithmetic of dtw_mfma_kernel: per window and column (L columns) three 32x32x16 MFMAs per 32 windows and chunk
     # (3 x 32768 / 32 flops), vector side per cell one v_min3 (2) + one add, per column and lane ~20 flops of frame work (2 lanes)
     def mfma_chunks(c):  # (chunks with eight template slots, chunks with four, templates left to the register kernels)
@@ -257,7 +258,11 @@ def main():
         return full + (1 if rem >= 5 else 0), 1 if 3 <= rem <= 4 else 0, rem if rem <= 2 else 0
     f_mfma_matrix = sum((mfma_chunks(c)[0] * 3 + mfma_chunks(c)[1] * 2) * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
     f_mfma_vector = sum((c - mfma_chunks(c)[2]) * Lt * 2 * W * 3 + (mfma_chunks(c)[0] + mfma_chunks(c)[1]) * Lt * 40 for Lt, c in by_len.items())
-    r_dtw = {"bound": "valu", "kernel": "dtw_mfma_kernel" if mfma_used else "dtw_band_kernel", "achieved": dtw_ref_flops / dtw_s / 1e12 if dtw_s else 0.0, "peak": VALU_PEAK / 1e12,
+    if mfma_wide:  # every template in chunks of eight slots; 3 tiles x (4 k-steps at mfcc_size 16, 3 at 13) MFMAs per column
+        ksteps = 4 if K == 16 else 3
+        f_mfma_matrix = sum(-(-c // 8) * 3 * ksteps * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
+        f_mfma_vector = sum(c * Lt * 2 * W * 3 + -(-c // 8) * Lt * 8 * K for Lt, c in by_len.items())
+    r_dtw = {"bound": "valu", "kernel": "dtw_mfma_wide_kernel" if mfma_wide else "dtw_mfma_kernel" if mfma_used else "dtw_band_kernel" if K == 5 else "dtw_band_wide_kernel", "achieved": dtw_ref_flops / dtw_s / 1e12 if dtw_s else 0.0, "peak": VALU_PEAK / 1e12,
              "unit": "TFLOP/s", "frac": dtw_ref_flops / dtw_s / VALU_PEAK if dtw_s else 0.0,
              "traffic": pmc.get("dtw", {}).get("hbm_bytes_per_launch_corrected"), "traffic_source": pmc_src if "dtw" in pmc else None,
              "avg_launch_ms": k_ms["dtw"][0], "launches_timed": k_ms["dtw"][1],

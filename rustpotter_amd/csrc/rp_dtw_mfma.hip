@@ -1,4 +1,4 @@
-// rp_dtw_mfma.hip -- dtw_mfma_kernel: the banded DTW of mfcc_size 5 with the cosine costs on the matrix cores (DESIGN.md §4.2,
+// rp_dtw_mfma.hip -- dtw_mfma_kernel: the banded DTW of mfcc_size 5 with the cosine costs on the matrix cores (DESIGN.md §4.2b,
 // round 3).  Same scoring as dtw_band_kernel (src/mfcc/dtw.rs:56-105 + comparator.rs:15-48 + normalizer.rs:17-29 +
 // wakeword_comp.rs:22-37), other arithmetic for the cell cost:
 //
@@ -21,8 +21,12 @@
 //     v_min3_f32 x2 + add x2 per cell), each tile's MFMA for column c+1 is issued right after the last cell that reads the tile, and
 //     the frame of column c+2 is prepared in ten pieces between the cells.  Columns are unrolled 12 at a time so that every
 //     slot, tile and band index is a compile-time register.
+//   * Two shapes (NT): eight template slots as described (chunks of 5..8 templates, band 3..5), or four (chunks of 3..4, band 5): a
+//     tile is then 8 row slots x 4 templates, 16 circular row slots = 2 tiles, one template pair per lane, columns unrolled 16 at a time.
+//     mfcc_size 13 / 16 have their own K axis: rp_dtw_mfma_wide.hip.
 // Measured (tools/scratch/dtw_mfma_probe2.hip, 8 192 streams x 288 windows x 8 templates of 100 frames): 1.62 ms against 2.36 ms at
-// dtw_band_kernel's C3 rate; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles), matrix pipe 21 % busy.
+// dtw_band_kernel's C3 rate; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles), matrix pipe 21 % busy.  In the product
+// at C3: 19.5 -> 12.0 ms (profiles/r03_final_*).
 #include "rp_device.h"
 
 #include <cstdlib>

@@ -219,9 +219,16 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #define RP_P4(cc) inv_ = bb_ > 0.f ? __builtin_amdgcn_rsqf(bb_) : 0.f;  /* zero frame -> zero vector -> cost 1 (comparator.rs:43-47) */
 #define RP_P5(cc) ua_ = da_ * inv_; ub_ = db_ * inv_; u2_ = d2_ * inv_;
 #define RP_P6(cc, par) bop[par].x = pkrtz(ua_, ub_); bop[par].z = bop[par].x;
-#define RP_P7(cc, par) bop[par].y = pkrtz(ua_ - lo_f32(bop[par].x), ub_ - hi_f32(bop[par].x));
-#define RP_P8(cc) t_ = pkrtz(u2_, 0.f);
-#define RP_P9(cc, par) bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pkrtz(u2_, u2_ - lo_f32(t_)), sel_one);
+// x1 = rtz_f16(x - x0): x0 as f32 is x with the low 13 mantissa bits cleared (one full-rate v_and instead of a half-rate v_cvt_f32_f16;
+// below the f16 normal range, |x| < 6.1e-5, the two differ by less than the f16 subnormal spacing 6e-8 -- far below the kernel's error)
+#ifndef RP_MFMA_CVT_BACK
+#define RP_X0F(x, packed, hi) __uint_as_float(__float_as_uint(x) & 0xffffe000u)
+#else
+#define RP_X0F(x, packed, hi) ((hi) ? hi_f32(packed) : lo_f32(packed))
+#endif
+#define RP_P7(cc, par) bop[par].y = pkrtz(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1));
+#define RP_P8(cc)
+#define RP_P9(cc, par) bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pkrtz(u2_, u2_ - RP_X0F(u2_, pkrtz(u2_, 0.f), 0)), sel_one);
 #define RP_PREP_ALL(cc, par) RP_P0(cc) RP_P1(cc) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 12)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
@@ -269,7 +276,6 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     } while (0)
 
         float fa_, fb_, f2_, da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_;
-        unsigned t_;
         RP_AREF(1, 0, true)
         RP_PREP_ALL(1, 1)
         RP_MFMA(0, 1); RP_MFMA(1, 1);
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #undef RP_P7
 #undef RP_P8
 #undef RP_P9
+#undef RP_X0F
 
         // D[m - 1][n] with m == n == L (dtw.rs:101): band position q = (L - 1) - (L - W + 1) = W - 2
         if (valid) {

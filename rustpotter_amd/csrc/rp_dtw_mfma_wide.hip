@@ -27,8 +27,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWWin = 32, kWSlots = 12, kWTiles = 3;
 
 __device__ __forceinline__ unsigned pkrtz(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
-__device__ __forceinline__ float lo_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[0]; }
-__device__ __forceinline__ float hi_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[1]; }
+// x0 = rtz_f16(x) as f32: x with the low 13 mantissa bits cleared (a full-rate v_and; below the f16 normal range the two differ by less
+// than the f16 subnormal spacing, 6e-8)
+__device__ __forceinline__ float x0f(float x) { return __uint_as_float(__float_as_uint(x) & 0xffffe000u); }
 
 template <int W>
 __host__ __device__ constexpr int wide_last_use(int u, int g) {
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
             const float ua_ = d_[2 * j] * inv_, ub_ = d_[2 * j + 1] * inv_;                                                   \
             const unsigned p_ = pkrtz(ua_, ub_);                                                                              \
             v_[3 * j] = p_; v_[3 * j + 2] = p_;                                                                               \
-            v_[3 * j + 1] = pkrtz(ua_ - lo_f32(p_), ub_ - hi_f32(p_));                                                        \
+            v_[3 * j + 1] = pkrtz(ua_ - x0f(ua_), ub_ - x0f(ub_));                                                            \
         }                                                                                                                     \
         if (ODD) {                                                                                                            \
             const float us_ = d_[CHM - 1] * inv_;                                                                             \
             const unsigned t_ = pkrtz(us_, 0.f);                                                                              \
-            v_[3 * NPAIR] = pkrtz(us_, us_ - lo_f32(t_));                                                                     \
+            v_[3 * NPAIR] = pkrtz(us_, us_ - x0f(us_));                                                                       \
             v_[3 * NPAIR + 1] = __builtin_amdgcn_perm(0x3c000000u, t_, sel_c);                                                \
         } else {                                                                                                              \
             v_[3 * NPAIR] = c_lo;                                                                                             \

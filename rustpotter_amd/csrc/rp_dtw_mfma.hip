@@ -55,8 +55,10 @@ constexpr int mfma_acc_reg(int nt, int slot, int p, int e) {
 }
 
 __device__ __forceinline__ unsigned pkrtz(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+#ifdef RP_MFMA_CVT_BACK  // A/B build only: x0 as f32 by converting the f16 back (see RP_X0F)
 __device__ __forceinline__ float lo_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[0]; }
 __device__ __forceinline__ float hi_f32(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p)[1]; }
+#endif
 
 // last band position q of column phase u whose MFMA row slot (u + q + NS - W + 2) mod NS lies in tile g; -1: the tile is not read
 template <int W, int NT>

@@ -53,6 +53,14 @@ __global__ __launch_bounds__(64) void k(float *out, int iters, float seed) {
                 if (OP == 32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
                 if (OP == 33) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c0));
                 if (OP == 34) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+                if (OP == 35 && i < NCH / 2) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(p[i]) : "v"(b[i]), "v"(c0) : "vcc");
+                if (OP == 36 && i < NCH / 2) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(p[i]) : "v"(p[(i + 1) % (NCH / 2)]));
+                if (OP == 37) asm volatile("v_add_f32_dpp %0, %1, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 38) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 39 && i < NCH / 2) asm volatile("v_mov_b64 %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) % (NCH / 2)]));
+                if (OP == 40) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
+                if (OP == 41) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+                if (OP == 42) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c0));
             }
         }
     }
@@ -89,5 +97,7 @@ int main() {
     run<23>("v_add3_u32", 64, out); run<24>("v_and_or_b32", 64, out); run<25>("v_bfi_b32", 64, out); run<26>("v_cvt_f16_f32", 64, out);
     run<27>("v_lshlrev_b32", 64, out); run<28>("v_cmp+v_cndmask (2)", 64, out); run<29>("v_max_u32", 64, out); run<30>("v_min_u16", 64, out);
     run<31>("v_pk_min_u16", 64, out); run<32>("v_add_u32", 64, out); run<33>("v_fmac_f32", 64, out); run<34>("v_sub_u32", 64, out);
+    run<35>("v_mad_u64_u32", 32, out); run<36>("v_lshl_add_u64", 32, out); run<37>("v_add_f32_dpp", 64, out); run<38>("v_mov_b32_dpp", 64, out);
+    run<39>("v_mov_b64", 32, out); run<40>("v_log_f32", 64, out); run<41>("v_mul_lo_u32", 64, out); run<42>("v_mad_u32_u24", 64, out);
     return 0;
 }

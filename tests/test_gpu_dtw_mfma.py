@@ -284,3 +284,28 @@ def test_wide_frames_with_a_rare_length_keep_the_register_kernels(ra, ctx):
     assert np.array_equal(scores, reg)
     ref_s, _ = orc.score_stream(orc.mfcc_stream(pcm[0], K), templates)
     assert rel_close(scores[0], ref_s)
+
+
+def test_full_size_against_the_register_kernels(ra):
+    """BASELINE config C3 at FULL size (65 536 streams x 297 windows x 8 templates = 155.7 M scores): the matrix-core kernel against the
+    register kernels on every score -- the largest relative difference stays below 5e-6 (parity gate against the reference: 1e-5), no
+    score is further than that from the vector-only arithmetic, and the run is bit-reproducible."""
+    import torch
+    from test_gpu_parity import _full_size_run
+    ctx, tmpl, cfg, templates, pcm, scores, agg, det, n_det = _full_size_run(ra, 65536, 8)
+    S, N = 65536, 64000
+    reg = torch.empty_like(scores)
+    with _registers_only():
+        ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), 4, reg.data_ptr(), agg.data_ptr())
+        torch.cuda.synchronize()
+    again = torch.empty_like(scores)
+    ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), 4, again.data_ptr(), agg.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(again, scores)
+    assert not torch.equal(reg, scores), "the matrix-core kernel did not run"
+    worst = 0.0
+    for i in range(0, S, 8192):  # in slices: the difference of two 623 MB arrays
+        a, b = scores[i:i + 8192], reg[i:i + 8192]
+        worst = max(worst, float(((a - b).abs() / b).max()))
+    assert worst < 5e-6, worst
+    print("largest relative difference over %d scores: %.3g" % (scores.numel(), worst))

@@ -403,9 +403,16 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         // multiply-then-add in the reference's order (NOT fused): see the file header.
         const size_t j = j0 + grp;
         if (j < first_frame + n_frames) {
-            float *dst = out + (s_now * out_frame_pitch + (j - first_frame)) * (size_t)K;
+#ifndef RP_MFCC_VECTOR_ADDR
+            // wave-uniform 64-bit row base + a 32-bit lane offset (frame of the group): the stores take `saddr + voffset`; forming the
+            // whole address per lane cost six v_mad_u64_u32 and their moves per tile
+            float *dst = out + (s_now * out_frame_pitch + (j0 - first_frame)) * (size_t)K + grp * K;
             // optional second copy, frames packed [n_frames][K] (the single-stream path hands the new frames to the host)
+            float *dst2 = out2 ? out2 + (s_now * n_frames + (j0 - first_frame)) * (size_t)K + grp * K : nullptr;
+#else
+            float *dst = out + (s_now * out_frame_pitch + (j - first_frame)) * (size_t)K;
             float *dst2 = out2 ? out2 + (s_now * n_frames + (j - first_frame)) * (size_t)K : nullptr;
+#endif
             for (int c = 1 + l; c <= K; c += 16) {
                 float sum = 0.f;
                 for (int n = 0; n < K1; ++n) sum += lgb[n] * dct[c * K1 + n];

@@ -62,8 +62,13 @@ template <int K1T> __device__ constexpr bool mel_uses(int f, int k2, bool mirror
 // previous call's last chunk, decoded f32 at hist[s * hist_pitch + i]; sample 480 + i is pcm[s * pcm_stride + i] -- and the
 // kernel leaves this call's last chunk (decoded) at hist_out for the next call, so that no staging copy runs in front
 // of it.  n_samples counts the history chunk.  Needs VEC4.
+#ifdef RP_MFCC_HAM_REGS
+#define RP_MFCC_MIN_WGS(HS) 3
+#else
+#define RP_MFCC_MIN_WGS(HS) ((HS) ? 3 : 4)
+#endif
 template <bool VEC4, int K1T, class TIN, bool HS = false>
-__global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
+__global__ __launch_bounds__(kMfccThreads, RP_MFCC_MIN_WGS(HS)) void mfcc_kernel(
     const TIN *__restrict__ pcm, size_t n_samples, size_t pcm_stride, unsigned tiles_per_stream, size_t total_tiles,
     size_t first_frame, size_t n_frames, size_t out_frame_pitch, int K1rt, const float *__restrict__ g_ham,
     const float2 *__restrict__ g_tw240, const float2 *__restrict__ g_tw480, const float *__restrict__ g_fb,
@@ -119,6 +124,12 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
 #pragma unroll
         for (int d = 0; d < 4; ++d) { const float2 w = g_tw240[l15 * (c + 4 * d)]; twl[4 * c + d] = (v2f){w.x, w.y}; }
 
+#ifdef RP_MFCC_HAM_REGS
+    // A/B: the lane's Hamming row in registers for the whole launch (32 VGPRs: three waves per SIMD instead of four)
+    f32x4 hreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hreg[i] = hrow[i];
+#endif
     // (stream, tile) of this wave's tile, advanced by the grid stride without a division per tile
     const size_t wave_stride = (size_t)gridDim.x * kMfccWaves;
     const size_t stride_s = wave_stride / tiles_per_stream;
@@ -247,7 +258,11 @@ __global__ __launch_bounds__(kMfccThreads, HS ? 3 : 4) void mfcc_kernel(
         v2f v[16];
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1 += 2) {
+#ifdef RP_MFCC_HAM_REGS
+            const f32x4 h = hreg[n1 / 2];
+#else
             const f32x4 h = hrow[n1 / 2];
+#endif
             v[n1] = lds_read_b64(ysrc + 15 * n1) * (v2f){h.x, h.y};
             v[n1 + 1] = lds_read_b64(ysrc + 15 * (n1 + 1)) * (v2f){h.z, h.w};
         }

@@ -375,7 +375,9 @@ bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from
     if (!from_global && n_win < (size_t)kMWin) return false;            // a staged tile holds at most two stream segments
     // the first 12 (16) columns are one guarded block
     if (slots == 8 ? t.mfma_min_len < mfma_slots(8) : t.mfma_min_len4 < mfma_slots(4)) return false;
-    return dtw_mfma_lds_bytes(t.max_len, 8) <= 160 * 1024;
+    // long templates: the A image leaves room for eight waves' frame stages only.  The four-slot form is built for twelve waves (its
+    // eight-wave build spills: the register allocator loses its way in the 16-column unroll) -- such chunks keep the tc-4 register kernel
+    return dtw_mfma_lds_bytes(t.max_len, slots == 8 ? 8 : 12) <= 160 * 1024;
 }
 
 hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
@@ -408,8 +410,8 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int 
         else { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, false, NT); else RP_LAUNCH_MFMA(WW, 8, false, NT); }                            \
     } while (0)
     if (slots == 4) {
-        if (band != 5) return hipErrorNotSupported;
-        RP_LAUNCH_MFMA_W(5, 4);
+        if (band != 5 || nw != 12) return hipErrorNotSupported;
+        if (from_global) RP_LAUNCH_MFMA(5, 12, true, 4); else RP_LAUNCH_MFMA(5, 12, false, 4);
     } else {
         switch (band) {
         case 3: RP_LAUNCH_MFMA_W(3, 8); break;

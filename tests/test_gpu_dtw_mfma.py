@@ -180,6 +180,21 @@ def test_long_templates_take_the_eight_wave_shape(ra, ctx):
     assert rel_close(scores, reg, 2e-6) and not np.array_equal(scores, reg)
 
 
+def test_long_templates_in_a_chunk_of_four_keep_the_register_kernel(ra, ctx):
+    """250-frame templates, four of them: twelve waves' frame stages do not fit beside the A image and the four-slot form exists for
+    twelve waves only -- the chunk stays with the tc-4 register kernel (the switch changes nothing), scores against the oracle."""
+    K, L, T = 5, 250, 4
+    templates = orc.synth_templates(SEED + 23, T, L, K)
+    mf = _streams(2, L + 33, K, first=95)
+    tm = ra.Templates(ctx, templates)
+    scores, _, _ = ctx.dtw_scores(mf, tm)
+    with _registers_only():
+        reg, _, _ = ctx.dtw_scores(mf, tm)
+    assert np.array_equal(scores, reg)
+    for w in (0, 17, 33):
+        assert rel_close(scores[1, w, 3], orc.score_window(mf[1][w:w + L], templates[3]))
+
+
 def test_many_streams_equal_their_single_stream_scores(ra, ctx):
     """Size-independent property at a size the oracle does not reach: 1 500 streams x 77 windows x 8 templates in one launch (every
     wave takes several tiles, most tiles straddle two streams) give, stream by stream, the bits of that stream scored alone."""

@@ -489,7 +489,10 @@ static hipError_t launch_mfcc_stream_t(hipStream_t st, const MfccTablesDev &tb, 
                       (hist_pitch % 4 == 0);
     if (!vec4 || lds > 160 * 1024 || tiles > 0xffffffffULL) return hipErrorNotSupported;
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
-    if (blocks > 1536) blocks = 1536;
+    {   // three workgroups per CU are resident (HS form); RP_MFCC_HS_BLOCKS overrides the cap for tuning
+        static const size_t cap = [] { const char *e = getenv("RP_MFCC_HS_BLOCKS"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)1536; }();
+        if (blocks > cap) blocks = cap;
+    }
 #define RP_MFCC_LAUNCH_HS(KT)                                                                                               \
     do {                                                                                                                   \
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mfcc_kernel<true, KT, TIN, true>), 160 * 1024);    \

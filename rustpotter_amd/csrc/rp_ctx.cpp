@@ -137,6 +137,7 @@ const MfccTablesDev *Ctx::tables_for(int K) {
         return true;
     };
     if (h.K1 == 6) d.mel_sparse = covered([](int f, int k2, bool m) { return mel_touches<6>(f, k2, m); });
+    if (h.K1 == 14) d.mel_sparse = covered([](int f, int k2, bool m) { return mel_touches<14>(f, k2, m); });
     if (h.K1 == 17) d.mel_sparse = covered([](int f, int k2, bool m) { return mel_touches<17>(f, k2, m); });
     if (!upload(&d.hamming, h.hamming) || !upload(&d.tw240, h.tw240) || !upload(&d.tw480, h.tw480) ||
         !upload(&d.fb, h.fb) || !upload(&d.dct, h.dct))
@@ -155,7 +156,8 @@ const MfccTablesDev *Ctx::tables_for(int K) {
                     }
             return w;
         };
-        const std::vector<float> w = h.K1 == 6 ? build(std::integral_constant<int, 6>{}) : build(std::integral_constant<int, 17>{});
+        const std::vector<float> w = h.K1 == 6 ? build(std::integral_constant<int, 6>{}) : h.K1 == 14 ? build(std::integral_constant<int, 14>{})
+                                                 : build(std::integral_constant<int, 17>{});
         if (!upload(&d.melw, w)) return nullptr;
     }
     return &(tables[K] = d);

@@ -18,6 +18,7 @@ constexpr int kBins = 240;    // src/mfcc/extractor.rs:28
 // the table on upload, Ctx::tables_for).
 template <int K1T> struct MelCentres;
 template <> struct MelCentres<6> { static constexpr int c[8] = {0, 9, 22, 41, 68, 106, 161, 240}; };
+template <> struct MelCentres<14> { static constexpr int c[16] = {0, 4, 8, 14, 20, 28, 37, 47, 60, 74, 92, 112, 137, 166, 200, 240}; };
 template <> struct MelCentres<17> {
     static constexpr int c[19] = {0, 3, 7, 11, 16, 21, 28, 35, 43, 53, 64, 77, 92, 109, 128, 150, 176, 206, 240};
 };

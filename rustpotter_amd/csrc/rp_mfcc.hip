@@ -25,7 +25,8 @@ constexpr int kMfccWaveScratch = kMfccFramesPerWave * 240;      // float2 per wa
 
 // floats the mel table takes in LDS: the compact per-lane rows of the sparse kernels (rp_kernels.h, mel_index) or [K1][240]
 __host__ __device__ inline size_t mel_lds_floats(int K1, bool sparse) {
-    return sparse && K1 == 6 ? (size_t)16 * kMelRowPitch<6> : sparse && K1 == 17 ? (size_t)16 * kMelRowPitch<17> : (size_t)K1 * kBins;
+    return sparse && K1 == 6 ? (size_t)16 * kMelRowPitch<6> : sparse && K1 == 14 ? (size_t)16 * kMelRowPitch<14>
+           : sparse && K1 == 17 ? (size_t)16 * kMelRowPitch<17> : (size_t)K1 * kBins;
 }
 // The window and the untangling twiddles are kept as one row per lane (lane l only ever needs window values 2(15 n1 + l),
 // +1 and twiddles W480^(l + 16 k2)): consecutive entries of a row are read two at a time with 16-byte LDS reads, the row
@@ -50,7 +51,7 @@ typedef __attribute__((address_space(3))) volatile v2f lds_v2f;
 __device__ __forceinline__ void lds_write_b64(v2f *p, v2f v) { *(lds_v2f *)p = v; }
 
 template <int K1T> __device__ constexpr bool mel_uses(int f, int k2, bool mirror) {
-    if constexpr (K1T == 6 || K1T == 17) return mel_touches<K1T>(f, k2, mirror);
+    if constexpr (K1T == 6 || K1T == 14 || K1T == 17) return mel_touches<K1T>(f, k2, mirror);
     else return true;
 }
 
@@ -466,6 +467,7 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
                            tb.tw240, tb.tw480, KT > 0 ? tb.melw : tb.fb, tb.dct, mfcc, mfcc2);                              \
     } while (0)
     if (vec4 && tb.K1 == 6 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 6);
+    else if (vec4 && tb.K1 == 14 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 14);
     else if (vec4 && tb.K1 == 17 && tb.mel_sparse) RP_MFCC_LAUNCH(true, 17);
     else if (vec4) RP_MFCC_LAUNCH(true, 0);
     else RP_MFCC_LAUNCH(false, 0);
@@ -502,6 +504,7 @@ static hipError_t launch_mfcc_stream_t(hipStream_t st, const MfccTablesDev &tb, 
                            tb.hamming, tb.tw240, tb.tw480, KT > 0 ? tb.melw : tb.fb, tb.dct, mfcc, (float *)nullptr, hist, hist_pitch, hist_out); \
     } while (0)
     if (tb.K1 == 6 && tb.mel_sparse) RP_MFCC_LAUNCH_HS(6);
+    else if (tb.K1 == 14 && tb.mel_sparse) RP_MFCC_LAUNCH_HS(14);
     else if (tb.K1 == 17 && tb.mel_sparse) RP_MFCC_LAUNCH_HS(17);
     else RP_MFCC_LAUNCH_HS(0);
 #undef RP_MFCC_LAUNCH_HS

@@ -58,7 +58,7 @@ def test_synth_generator_bit_exact(ctx):
         assert np.array_equal(pcm[s], orc.synth_pcm(SEED, 7 + s, 1000))
 
 
-@pytest.mark.parametrize("K", [5, 16, 1, 23])
+@pytest.mark.parametrize("K", [5, 16, 13, 1, 23])
 def test_mfcc_synthetic_streams(ctx, K):
     S, N = 5, 480 * 37 + 123  # ragged tail: the last 123 samples are ignored like chunks_exact does
     pcm = np.stack([orc.synth_pcm(SEED, s, N) for s in range(S)])

@@ -87,6 +87,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched) {
     constexpr int K = kMK, B = 2 * W, NS = mfma_slots(NT), NTILE = mfma_tiles(NT), SPT = 32 / NT, NP = NT / 4;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
+    #ifndef RP_MFMA_GX_PD  // A/B builds: 1 = the one-column look-ahead of the staged form
+    constexpr int PD = GX ? (NS % 3 == 0 ? 3 : 4) : 1;  // columns a frame is requested ahead of its use (RP_P0)
+#else
+    constexpr int PD = GX ? RP_MFMA_GX_PD : 1;
+#endif
+    static_assert(NS % PD == 0, "the frame ring's slot must be a compile-time index");
     static_assert(NT == 8 || NT == 4, "template slots per chunk");
     static_assert(B + 2 <= NS, "the band and its two neighbours must fit the circular row slots");
     size_t total_entries = n_streams * n_win;
@@ -188,7 +194,10 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         const float *x2 = xw + 2;
         // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums (of this lane's three components)
         float mua = 0.f, mub = 0.f, mu2 = 0.f;
-#pragma unroll 8
+#ifndef RP_MFMA_GX_MEAN_UNROLL
+#define RP_MFMA_GX_MEAN_UNROLL 20
+#endif
+#pragma unroll(GX ? RP_MFMA_GX_MEAN_UNROLL : 8)  // from global memory: 20 frames in flight per wait (an L2 round trip each), sums in the same order
         for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
         mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;
 
@@ -213,8 +222,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         u32x4 bop[2];  // B operand of column cc in bop[cc & 1]: built two columns ahead, in pieces between the cells
 
 // The frame work of column cc, cut into ten pieces P0..P9 that are placed between the cells of the recurrence.
-#define RP_P0(cc) fa_ = xa[((cc) - 1) * K]; fb_ = xa[((cc) - 1) * K + 1]; f2_ = x2[((cc) - 1) * K];
-#define RP_P1(cc) da_ = fa_ - mua; db_ = fb_ - mub; d2_ = f2_ - mu2;
+// P0 requests the frame of column cc into ring slot rs, P1 takes it out PD columns later (rs = cc mod PD, spelled out by the caller:
+// c0 - 1 is a multiple of NS and PD divides NS, so the slot is a compile-time register).  LDS-staged tiles look one column ahead;
+// frames from global memory (GX) three or four: at one column (~0.6 us of a SIMD shared by three waves) the loads of the
+// L2 / Infinity Cache (> 1 us under load) were what a live-stream launch waited for.
+#define RP_P0(cc, rs) fa_[rs] = xa[((cc) - 1) * K]; fb_[rs] = xa[((cc) - 1) * K + 1]; f2_[rs] = x2[((cc) - 1) * K];
+#define RP_P1(cc, rs) da_ = fa_[rs] - mua; db_ = fb_[rs] - mub; d2_ = f2_[rs] - mu2;
 #define RP_P2(cc) own_ = fmaf(da_, da_, db_ * db_);
 #define RP_P3(cc) { const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(own_), __float_as_uint(own_), false, false); \
                     bb_ = fmaf(d2_, d2_, __uint_as_float(sw_[0]) + __uint_as_float(sw_[1])); }
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #define RP_P7(cc, par) bop[par].y = pkrtz(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1));
 #define RP_P8(cc)
 #define RP_P9(cc, par) bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pkrtz(u2_, u2_ - RP_X0F(u2_, pkrtz(u2_, 0.f), 0)), sel_one);
-#define RP_PREP_ALL(cc, par) RP_P0(cc) RP_P1(cc) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)
+#define RP_PREP_ALL(cc, par) RP_P0(cc, (cc) % PD) RP_P1(cc, (cc) % PD) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 12)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
     {                                                                                                                         \
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             }                                                                                                                 \
             /* piece k of the frame of column c + 2 after cell (k B) / 10 (its values were requested one column earlier, P0): the  \
                pieces fill the wait states between a cell's adds and the next cell's v_min3 */                                                                                  \
-            if (q == (0 * B) / 10) { RP_P1(c + 2) RP_P0(c + 3) } if (q == (2 * B) / 10) { RP_P2(c + 2) }                       \
+            if (q == (0 * B) / 10) { RP_P1(c + 2, (u + 3) % PD) RP_P0(c + 2 + PD, (u + 3) % PD) } if (q == (2 * B) / 10) { RP_P2(c + 2) }                       \
             if (q == (3 * B) / 10) { RP_P3(c + 2) } if (q == (4 * B) / 10) { RP_P4(c + 2) } if (q == (5 * B) / 10) { RP_P5(c + 2) } \
             if (q == (6 * B) / 10) { RP_P6(c + 2, (u + 1) & 1) } if (q == (7 * B) / 10) { RP_P7(c + 2, (u + 1) & 1) }         \
             if (q == (8 * B) / 10) { RP_P8(c + 2) } if (q == (9 * B) / 10) { RP_P9(c + 2, (u + 1) & 1) }                      \
@@ -277,13 +290,14 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             if (mfma_last_use<W, NT>(u, g) < 0) RP_MFMA(g, u & 1);                                                            \
     } while (0)
 
-        float fa_, fb_, f2_, da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_;
+        float fa_[PD], fb_[PD], f2_[PD], da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_;
         RP_AREF(1, 0, true)
         RP_PREP_ALL(1, 1)
         RP_MFMA(0, 1); RP_MFMA(1, 1);
         if (NTILE > 2) RP_MFMA(NTILE - 1, 1);
         RP_PREP_ALL(2, 0)
-        RP_P0(3)
+#pragma unroll
+        for (int a = 0; a < PD; ++a) { RP_P0(3 + a, (3 + a) % PD) }
         __builtin_amdgcn_sched_barrier(0);
         int c0 = 1;
         bool dead = false;

@@ -114,6 +114,11 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
         float mu[CHM], fl[CHM];
 #pragma unroll
         for (int j = 0; j < CHM; ++j) mu[j] = 0.f;
+        // ten frames requested per wait: left rolled, every frame paid a whole memory round trip before its eight adds (same sums, same order)
+#ifndef RP_WIDE_MEAN_UNROLL
+#define RP_WIDE_MEAN_UNROLL 10
+#endif
+#pragma unroll RP_WIDE_MEAN_UNROLL
         for (int i = 1; i <= L; ++i) {
             RP_LOADF(i);
 #pragma unroll

@@ -408,7 +408,9 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
     S, T, n = args.streams, args.templates, args.chunks_per_call
     ctx = ra.BatchContext(device=local_rank, host_pointers=False)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    tmpl = ra.Templates(ctx, make_templates(ra, ctx, torch, dev, [args.template_len] * args.templates, args.mfcc_size))
+    lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
+    T = len(lens)
+    tmpl = ra.Templates(ctx, make_templates(ra, ctx, torch, dev, lens, args.mfcc_size))
     cfg = ra.DetectorConfig()
     cfg.avg_threshold = 0.0
     sb = ra.StreamBatch(ctx, tmpl, cfg, S, max_chunks_per_call=n)
@@ -425,7 +427,7 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
         sb.process_dev(pcm.data_ptr() + 4 * off, 3, n, pcm.shape[1], det.data_ptr(), n_det.data_ptr(), 4)
 
     # fill the window first so that every timed call scores complete windows
-    for _ in range(-(-args.template_len // (3 * n)) + 1 + args.warmup):
+    for _ in range(-(-max(lens) // (3 * n)) + 1 + args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -451,7 +453,7 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
     res = {"metric": "10ms-frame MFCC+DTW scorings/sec (streaming calls)", "value": S * 3 * n * world * args.steps / dt,
            "unit": "scorings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%d live streams x %d templates per GPU, %d chunk(s) of 30 ms per call" % (S, T, n),
+           "config": {"workload": "%d live streams x %d templates (%s frames) per GPU, %d chunk(s) of 30 ms per call" % (S, T, "/".join(str(x) for x in sorted(set(lens))), n),
                       "real_time_factor": 30.0 * n / ms, "kernels_ms": k_ms}}
     if rank == 0:
         print(json.dumps(res))

@@ -134,6 +134,10 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
     float mu[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) mu[k] = 0.f;
+#ifndef RP_DTW_MEAN_UNROLL  // frames in flight per wait: left rolled, every frame of a window paid a whole LDS / memory round trip
+#define RP_DTW_MEAN_UNROLL 10
+#endif
+#pragma unroll RP_DTW_MEAN_UNROLL
     for (int i = 0; i < L; ++i) {
 #pragma unroll
         for (int k = 0; k < K; ++k) mu[k] += xl[i * KP + k];
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
     v2f mu[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) mu[k] = (v2f){0.f, 0.f};
+#pragma unroll RP_DTW_MEAN_UNROLL
     for (int i = 0; i < L; ++i) {
 #pragma unroll
         for (int k = 0; k < K; ++k) mu[k] += (v2f){x0[i * KP + k], x1[i * KP + k]};
@@ -511,6 +516,10 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
     float mu[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) mu[k] = 0.f;
+#ifndef RP_DTW_MEAN_UNROLL_WIDE  // 13 / 16 components per frame: four frames in flight keep the register count where it was
+#define RP_DTW_MEAN_UNROLL_WIDE 4
+#endif
+#pragma unroll RP_DTW_MEAN_UNROLL_WIDE
     for (int i = 0; i < L; ++i) {
 #pragma unroll
         for (int k = 0; k < K; ++k) mu[k] += xl[i * KP + k];

@@ -6,7 +6,7 @@ O=gpurun_out/r3gxab; mkdir -p $O
 BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-result -Wno-pass-failed"
 n=0
 for flags in "$@"; do
-  touch rustpotter_amd/csrc/rp_dtw_mfma.hip rustpotter_amd/csrc/rp_dtw_mfma_wide.hip
+  touch rustpotter_amd/csrc/rp_dtw.hip rustpotter_amd/csrc/rp_dtw_mfma.hip rustpotter_amd/csrc/rp_dtw_mfma_wide.hip
   make -C rustpotter_amd/csrc -j8 CXXFLAGS="$BASE $flags" > $O/make_$n.log 2>&1 || { tail -5 $O/make_$n.log; exit 1; }
   cp rustpotter_amd/librustpotter_hip.so $O/lib_$n.so
   n=$((n+1))
@@ -16,8 +16,8 @@ for rep in 1 2; do
   i=0
   for flags in "$@"; do
     cp $O/lib_$i.so rustpotter_amd/librustpotter_hip.so
-    for w in "stream1:--mode stream --chunks-per-call 1" "stream8:--mode stream --chunks-per-call 8" "k16:--streams 8192 --mfcc-size 16" "k13:--streams 8192 --mfcc-size 13" "gate04:--avg-gate --avg-threshold 0.4"; do
-      name=${w%%:*}; args=${w#*:}
+    for w in ${RP_AB_WORKLOADS:-"stream1:--mode_stream_--chunks-per-call_1" "k16:--streams_8192_--mfcc-size_16"}; do
+      name=${w%%:*}; args=${w#*:}; args=${args//_/ }
       timeout 600 $B $args 2> $O/${name}_${i}_$rep.err | grep '^{' | tail -1 > $O/${name}_${i}_$rep.json
       python3 - <<PY
 import json

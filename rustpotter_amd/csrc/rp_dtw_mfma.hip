@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,
-    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched) {
+    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds) {
     constexpr int K = kMK, B = 2 * W, NS = mfma_slots(NT), NTILE = mfma_tiles(NT), SPT = 32 / NT, NP = NT / 4;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
     #ifndef RP_MFMA_GX_PD  // A/B builds: 1 = the one-column look-ahead of the staged form
@@ -142,10 +142,22 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     // split leaves most of the chip waiting for the waves that got one tile more (BASELINE config C2: 3.09 tiles per wave).
     // The last workgroup of a chunk to finish (sched[2 ci + 1] counts them) puts both words back to zero for the next launch.
     uint32_t *next_tile = sched + 2 * (chunk_base + ci);
+    unsigned round = 0;
+    const size_t chunk_waves = (size_t)n_groups * NW;  // waves working on this chunk
     for (;;) {
-        unsigned ticket = 0;
-        if (lane == 0) ticket = atomicAdd(next_tile, 1u);
-        const size_t tile = (size_t)__builtin_amdgcn_readfirstlane(ticket);
+        // the first static_rounds tiles of a wave are its own index among the chunk's waves (+ a round's worth each time), the following
+        // ones come from the counter: 3 072 waves asking one address for a ticket at the same moment queue up behind each other (a
+        // launch of two tiles per wave -- a live-stream call -- lost a quarter of its time there); the host keeps the counter for the
+        // rounds in which balancing matters (mfma_static_rounds)
+        size_t tile;
+        if (round < static_rounds) {
+            tile = (size_t)round * chunk_waves + (size_t)(blockIdx.x / n_chunks) * NW + (size_t)wave;
+            ++round;
+        } else {
+            unsigned ticket = 0;
+            if (lane == 0) ticket = atomicAdd(next_tile, 1u);
+            tile = (size_t)__builtin_amdgcn_readfirstlane(ticket) + (size_t)static_rounds * chunk_waves;
+        }
         if (tile >= total_tiles) break;
         // ---- lanes -> (stream, window) ----
         const size_t f0 = tile * kMWin;
@@ -197,7 +209,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #ifndef RP_MFMA_GX_MEAN_UNROLL
 #define RP_MFMA_GX_MEAN_UNROLL 20
 #endif
-#pragma unroll(GX ? RP_MFMA_GX_MEAN_UNROLL : 8)  // from global memory: 20 frames in flight per wait (an L2 round trip each), sums in the same order
+        constexpr int kMeanUnroll = GX ? RP_MFMA_GX_MEAN_UNROLL : 8;  // from global memory: 20 frames in flight per wait (an L2 round trip each), sums in the same order
+#pragma unroll kMeanUnroll
         for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
         mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;
 
@@ -410,13 +423,14 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int 
     if (groups > need) groups = need;
     const size_t blocks = groups * (size_t)n_chunks;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const unsigned static_rounds = mfma_static_rounds(total_tiles, groups * (size_t)nw, list != nullptr);
 #define RP_LAUNCH_MFMA(WW, NW, GXV, NT)                                                                                             \
     do {                                                                                                                            \
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<WW, NW, GXV, NT>), 160 * 1024); e != hipSuccess) return e; \
         hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV, NT>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
                            reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
-                           abandon_nc, t.mfma_sched);                                                                               \
+                           abandon_nc, t.mfma_sched, static_rounds);                                                                \
     } while (0)
 #define RP_LAUNCH_MFMA_W(WW, NT)                                                                                                    \
     do {                                                                                                                            \

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t total_tiles, unsigned n_chunks, int chunk_base, size_t first_win,
     size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T, float score_ref,
     float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, const uint32_t *__restrict__ list,
-    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched) {
+    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds) {
     constexpr int B = 2 * W, NS = kWSlots, NTILE = kWTiles;
     constexpr int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, ODD = CHM % 2, KS = dtw_mfma_wide_ksteps(K);
     constexpr int kRowBytes = KS * 256;
@@ -85,10 +85,22 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     for (int e = 0; e < 4; ++e) { slot_real[e] = 4 * h + e < ch->count; slot_avg[e] = slot_real[e] && ch->tid[4 * h + e] >= T; }
 
     uint32_t *next_tile = sched + 2 * (chunk_base + ci);
+    unsigned round = 0;
+    const size_t chunk_waves = (size_t)n_groups * NW;  // waves working on this chunk
     for (;;) {
-        unsigned ticket = 0;
-        if (lane == 0) ticket = atomicAdd(next_tile, 1u);
-        const size_t tile = (size_t)__builtin_amdgcn_readfirstlane(ticket);
+        // the first static_rounds tiles of a wave are its own index among the chunk's waves (+ a round's worth each time), the following
+        // ones come from the counter: 3 072 waves asking one address for a ticket at the same moment queue up behind each other (a
+        // launch of two tiles per wave -- a live-stream call -- lost a quarter of its time there); the host keeps the counter for the
+        // rounds in which balancing matters (mfma_static_rounds)
+        size_t tile;
+        if (round < static_rounds) {
+            tile = (size_t)round * chunk_waves + (size_t)(blockIdx.x / n_chunks) * NW + (size_t)(tid >> 6);
+            ++round;
+        } else {
+            unsigned ticket = 0;
+            if (lane == 0) ticket = atomicAdd(next_tile, 1u);
+            tile = (size_t)__builtin_amdgcn_readfirstlane(ticket) + (size_t)static_rounds * chunk_waves;
+        }
         if (tile >= total_tiles) break;
         size_t f = tile * kWWin + n;
         const bool valid = f < total_entries;
@@ -319,13 +331,14 @@ hipError_t launch_dtw_mfma_wide(hipStream_t st, const TemplatesDev &t, int band,
     const size_t need = (total_tiles + NW - 1) / NW;
     if (groups > need) groups = need;
     const size_t blocks = groups * (size_t)n_chunks;
+    const unsigned static_rounds = mfma_static_rounds(total_tiles, groups * (size_t)NW, list != nullptr);
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
 #define RP_LAUNCH_WIDE(KK)                                                                                                          \
     do {                                                                                                                            \
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_wide_kernel<KK, 5, NW>), 160 * 1024); e != hipSuccess) return e; \
         hipLaunchKernelGGL((dtw_mfma_wide_kernel<KK, 5, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, total_tiles, \
                            (unsigned)n_chunks, t.wide8_first, first_win, n_win, out_win_pitch, t.chunks, reinterpret_cast<const uint4 *>(t.aimg), \
-                           t.T, score_ref, scores, avg, S, list, count, dense_min, abandon_nc, t.mfma_sched);                        \
+                           t.T, score_ref, scores, avg, S, list, count, dense_min, abandon_nc, t.mfma_sched, static_rounds);         \
     } while (0)
     if (t.K == 16) RP_LAUNCH_WIDE(16);
     else RP_LAUNCH_WIDE(13);

@@ -1,6 +1,7 @@
 // rp_kernels.h -- launchers of the gfx950 kernels (rp_mfcc / rp_dtw / rp_scan / rp_resample / rp_frontend / rp_mlp .hip) used by the
 // host-side mirror (rp_detector.cpp) and the C ABI (rp_capi.cpp).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -79,6 +80,15 @@ __host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 
 __host__ __device__ constexpr int dtw_mfma_wide_chm(int K) { return (K + 1) / 2; }
 __host__ __device__ constexpr int dtw_mfma_wide_ksteps(int K) {
     return (3 * (dtw_mfma_wide_chm(K) / 2) + (dtw_mfma_wide_chm(K) % 2 ? 2 : 1) + 3) / 4;
+}
+// Tiles a wave of the matrix-core DTW kernels takes by its own index before it turns to the chunk's atomic counter: every whole round
+// of a launch of at most three rounds (live-stream calls, BASELINE config C2 -- the waves start together and would ask for their
+// tickets together; the counter then hands out what is left), the first round of longer launches (the waves drift apart by themselves
+// and the counter evens out what the CUs finish unevenly) and of lists whose length only the device knows.
+inline unsigned mfma_static_rounds(size_t total_tiles, size_t chunk_waves, bool list) {
+    const size_t r = chunk_waves ? total_tiles / chunk_waves : 0;
+    if (const char *e = std::getenv("RP_MFMA_STATIC_ROUNDS")) return (unsigned)std::atoi(e);  // A/B runs: 0 = every tile from the counter
+    return (list || r > 3 || r < 1) ? 1u : (unsigned)r;
 }
 inline size_t dtw_mfma_lds_bytes(int max_len, int waves) {
     return (size_t)(max_len + 16) * kDtwMfmaRowBytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);

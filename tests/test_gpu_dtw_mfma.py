@@ -214,6 +214,42 @@ def test_many_streams_equal_their_single_stream_scores(ra, ctx):
     assert rel_close(scores[1499], ref_s)
 
 
+class _static_rounds:
+    """RP_MFMA_STATIC_ROUNDS for the calls inside (read per launch): tiles a wave takes by index before it uses the atomic counter."""
+    def __init__(self, n):
+        self.n = n
+    def __enter__(self):
+        self.old = os.environ.get("RP_MFMA_STATIC_ROUNDS")
+        os.environ["RP_MFMA_STATIC_ROUNDS"] = str(self.n)
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["RP_MFMA_STATIC_ROUNDS"]
+        else:
+            os.environ["RP_MFMA_STATIC_ROUNDS"] = self.old
+
+
+@pytest.mark.parametrize("K,T,S", [(5, 8, 1500), (5, 4, 700), (16, 8, 300), (5, 8, 40)])
+def test_tile_hand_out_does_not_change_a_bit(ra, ctx, K, T, S):
+    """Every tile is scored exactly once whichever way the waves come by it: all from the atomic counter (0), one / two / seven rounds
+    by index (seven is more rounds than the launch has: the counter then hands out nothing), the host's rule (unset) -- same bits, and
+    the counter is back at zero after every launch (a second call under the same setting repeats the first)."""
+    L = 30
+    templates = orc.synth_templates(SEED + 23 + K, T, L, K)
+    base = _streams(8, 75 + L - 1, K, first=300)
+    rng = np.random.default_rng(11)
+    mf = base[rng.integers(0, 8, S)] * (0.5 + rng.random(S)).astype(np.float32)[:, None, None]
+    tm = ra.Templates(ctx, templates)
+    ref, _, ref_agg = ctx.dtw_scores(mf, tm)
+    assert np.isfinite(ref).all() and ref.min() > 0.0
+    for n in (0, 1, 2, 7):
+        with _static_rounds(n):
+            for _ in range(2):
+                got, _, agg = ctx.dtw_scores(mf, tm)
+                assert np.array_equal(got, ref) and np.array_equal(agg, ref_agg), n
+    one, _, _ = ctx.dtw_scores(mf[S - 1], tm)
+    assert np.array_equal(ref[S - 1], one[0])
+
+
 @pytest.mark.parametrize("cpc", [1, 2, 5])
 def test_one_stream_live_equals_offline(ra, ctx, cpc):
     """One stream alone is a batch too: fed one, two or five chunks per call (3 .. 15 new windows: the shapes the single-stream mirror

@@ -2,6 +2,8 @@
 // (src/detector.rs:290-302,377-454, src/mfcc/vad.rs) and the live-stream variants that carry their state between calls.
 #include "rp_device.h"
 
+#include <cstddef>
+
 namespace rp {
 
 // ------------------------------------------------------------------------- scan
@@ -301,12 +303,18 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(ScanWakewords ww, const
     const int lane = threadIdx.x;
     const size_t s = (size_t)blockIdx.x * 64 + lane;
     if (s >= S) return;
-    StreamState z = state[s];
+    // the 64-byte head of the state travels every call, the 200 bytes of the VAD window only in detectors that have a VAD (as one struct
+    // copy each way a call moved 34 MB in 264-byte strides for 65 536 streams: 0.019 of a 0.32 ms live call)
+    constexpr size_t kHead = offsetof(StreamState, vad_window);
+    static_assert(kHead == 64, "StreamState head");
+    StreamState *sp = state + s;
+    StreamState z;
+    __builtin_memcpy(&z, sp, kHead);
     const long long max_len = cfg.max_len;
     const size_t row0 = s * (size_t)n_new;
     const float *vv = vad_value ? vad_value + s * (size_t)n_new : nullptr;
     if (vv)
-        for (int i = 0; i < 50; ++i) vwin[i][lane] = z.vad_window[i];
+        for (int i = 0; i < 50; ++i) vwin[i][lane] = sp->vad_window[i];
     int nd = 0;
     for (int i = 0; i < n_new; ++i) {
         const long long f = f0 + i;
@@ -368,8 +376,8 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(ScanWakewords ww, const
         }
     }
     if (vv)
-        for (int i = 0; i < 50; ++i) z.vad_window[i] = vwin[i][lane];
-    state[s] = z;
+        for (int i = 0; i < 50; ++i) sp->vad_window[i] = vwin[i][lane];
+    __builtin_memcpy(sp, &z, kHead);
     n_det[s] = nd;
     for (int i = nd; i < max_det; ++i) {
         det[s * (size_t)max_det + i] = BatchDetection{};

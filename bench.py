@@ -313,6 +313,8 @@ def main():
             r_mfcc["valu_issue_frac_at_effective_clock"] = r_mfcc["valu_issue_frac"] * 2.4 / pmc["mfcc"]["effective_clock_ghz"]
     roofline = dict(r_dtw if dom == "dtw" else r_mfcc)
     roofline["kernels_ms"] = {k: round(v[0], 4) for k, v in k_ms.items()}
+    if k_ms["aggregate"][1] == 0:  # no launch of the aggregate pass: ScoreMode::Max ran inside the DTW kernel
+        roofline["aggregate_inside_dtw_kernel"] = True
     work_skipped = args.detect_only or (args.avg_gate and not args.full_scores)
     roofline["path_hbm_frac"] = (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK
     roofline["path_valu_frac_fp32"] = (value / world) * (f_mfcc * nf / n_win + f_dtw_ref) / VALU_PEAK

@@ -518,6 +518,19 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         bool ok = hip_ok(launch_mfcc_fmt(c->stream, *tb, dp, (int)fmt, S, n_samples, pcm_stride, 0, nf, nf, dm), "mfcc_kernel");
         c->time_end();
         if (!ok) return -1;
+        // the aggregate pass also tells the scan which streams can fire at all (a flag per stream, zeroed here) and writes 0 for the
+        // windows the averaged-template gate rejected (their `scores` rows were never written)
+        AggExtra ax;
+        if (n_win) {
+            if (!c->ws_hot.reserve(S * sizeof(uint32_t) + 16)) return -1;
+            if (!hip_ok(hipMemsetAsync(c->ws_hot.p, 0, S * sizeof(uint32_t), c->stream), "hipMemsetAsync(hot)")) return -1;
+            ax.hot = c->ws_hot.as<uint32_t>(); ax.threshold = config->threshold; ax.n_win = n_win;
+            if (gated || gated_generic) { ax.gate_avg = da; ax.gate_threshold = config->avg_threshold; }  // only rows the gate really skipped
+        }
+        // ScoreMode::Max of a reference whose templates are one chunk of the matrix-core kernel, no averaged template scored: the DTW
+        // kernel writes the aggregate and the flags itself (DtwFusedAgg, rp_kernels.h) and the aggregate pass is skipped
+        DtwFusedAgg fz;
+        if (config->score_mode == RP_SCORE_MAX && !do_avg && n_win) { fz.agg = dg; fz.hot = ax.hot; fz.threshold = config->threshold; }
         c->time_begin(kKernelDtw);
         if (gated) {
             uint32_t *lst = c->ws_list.as<uint32_t>();
@@ -528,22 +541,16 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
                                                  config->avg_threshold, ds, da), "dtw_generic_kernel (gated)");
         } else {
             // ws_mfcc ends with slack: short streams (fewer than 64 windows each) are scored by cross-stream waves like live-stream batches
-            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
+            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
+                                   fz.agg ? &fz : nullptr), "dtw kernel");
         }
         c->time_end();
         if (!ok) return -1;
-        // the aggregate pass also tells the scan which streams can fire at all (a flag per stream) and writes 0 for the
-        // windows the averaged-template gate rejected (their `scores` rows were never written)
-        AggExtra ax;
-        if (n_win) {
-            if (!c->ws_hot.reserve(S * sizeof(uint32_t) + 16)) return -1;
-            if (!hip_ok(hipMemsetAsync(c->ws_hot.p, 0, S * sizeof(uint32_t), c->stream), "hipMemsetAsync(hot)")) return -1;
-            ax.hot = c->ws_hot.as<uint32_t>(); ax.threshold = config->threshold; ax.n_win = n_win;
-            if (gated || gated_generic) { ax.gate_avg = da; ax.gate_threshold = config->avg_threshold; }  // only rows the gate really skipped
+        if (!fz.done) {
+            c->time_begin(kKernelAggregate);
+            ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg, ax), "aggregate_kernel");
+            c->time_end();
         }
-        c->time_begin(kKernelAggregate);
-        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)config->score_mode, dg, ax), "aggregate_kernel");
-        c->time_end();
         if (!ok) return -1;
         ScanConfig sc;
         sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;
@@ -1008,21 +1015,27 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
         // (a single live stream keeps launch_dtw's one-wave-per-DTW kernel: the gated path's lane-serial passes cost it latency)
         const bool gated = do_avg && detect_only && dtw_gate_supported(td_one, b->cfg.band_size, rows) && !(S == 1 && n_new <= 8);
         const float abandon = (detect_only && b->cfg.score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(b->cfg.threshold, b->cfg.score_ref) : __builtin_inff();
+        // ScoreMode::Max inside the matrix-core DTW kernel when one chunk holds the reference's templates (DtwFusedAgg, rp_kernels.h)
+        DtwFusedAgg fz;
+        if (b->cfg.score_mode == RP_SCORE_MAX && !do_avg && rows) { fz.agg = dg; fz.threshold = b->cfg.threshold; }
         c->time_begin(kKernelDtw);
         if (gated) {
             uint32_t *lst = b->list.as<uint32_t>();
             ok = hip_ok(launch_dtw_gated(c->stream, td_one, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, b->cfg.avg_threshold,
                                          ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
         } else {
-            ok = hip_ok(launch_dtw(c->stream, td_one, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
+            ok = hip_ok(launch_dtw(c->stream, td_one, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
+                                   fz.agg ? &fz : nullptr), "dtw kernel");
         }
         c->time_end();
         if (!ok) return -1;
         AggExtra ax;   // windows the gate rejected were never scored: their aggregate is 0, not what `scores` held
         if (gated) { ax.gate_avg = da; ax.gate_threshold = b->cfg.avg_threshold; }
-        c->time_begin(kKernelAggregate);
-        ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)b->cfg.score_mode, dg, ax), "aggregate_kernel");
-        c->time_end();
+        if (!fz.done) {
+            c->time_begin(kKernelAggregate);
+            ok = hip_ok(launch_aggregate(c->stream, ds, rows, td.T, (int)b->cfg.score_mode, dg, ax), "aggregate_kernel");
+            c->time_end();
+        }
         if (!ok) return -1;
         float *dv = nullptr;
         if (b->cfg.vad_mode != RP_VAD_NONE) {

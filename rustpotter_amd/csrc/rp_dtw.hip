@@ -35,6 +35,7 @@ struct GateList {
     // them.  Windows that can still fire are never touched: their wave runs to the end, with every template exact.
     // +inf: off (the per-window score arrays are part of the call's result).  See dtw_abandon_nc().
     float abandon_nc = __builtin_inff();
+    const DtwFusedAgg *fuse = nullptr;  // ScoreMode::Max folded into the matrix-core kernel (rp_kernels.h); set by launch_dtw only
 };
 
 // One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
@@ -956,11 +957,11 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
         const bool from_global = few || gl.list != nullptr;
         if (t.class_count[1] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 4)) {
             if ((e = launch_dtw_mfma(st, t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
-                                     scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc)) != hipSuccess) return e;
+                                     scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse)) != hipSuccess) return e;
         } else if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
         if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8))
             return launch_dtw_mfma(st, t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
-                                   scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc);
+                                   scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse);
     }
     // Small batches: tc-8 waves run two per SIMD; a launch that fills those slots 2.x times leaves the chip mostly idle in
     // its last round.  The same templates as tc-4 half chunks are twice as many waves of 0.83 of the length (measured at C2), three per SIMD
@@ -1094,7 +1095,8 @@ float dtw_abandon_nc(float threshold, float score_ref) {
 
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
-                      float *scores, float *avg, bool padded_rows, float abandon_nc) {
+                      float *scores, float *avg, bool padded_rows, float abandon_nc, DtwFusedAgg *fuse) {
+    if (fuse) fuse->done = false;
     if (S == 0 || n_win == 0) return hipSuccess;
     GateList gl;
     gl.abandon_nc = abandon_nc;
@@ -1127,6 +1129,13 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     if (dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && (few || reg_lds <= 160 * 1024)) {
         const int n2 = t.class_count[3] - ((t.has_avg && !do_avg) ? 1 : 0);  // single-template chunks to score
         if (t.K == 5) {
+            // ScoreMode::Max inside the matrix-core kernel: one chunk of 3..8 templates is all there is to score
+            if (fuse && fuse->agg && n2 == 0 && t.class_count[0] == 0 && t.class_count[1] + t.class_count[2] == 1 && band >= 3 && band <= 5 &&
+                std::getenv("RP_DTW_NO_FUSED_MAX") == nullptr &&
+                dtw_mfma_supported(t, band, n_win, few, t.class_count[2] == 1 ? 8 : 4)) {
+                gl.fuse = fuse;
+                fuse->done = true;
+            }
             switch (band) {
             case 3: return launch_dtw_k5<3>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
             case 4: return launch_dtw_k5<4>(st, t, n2, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);

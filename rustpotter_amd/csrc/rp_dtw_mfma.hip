@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,
-    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds) {
+    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds, float *__restrict__ agg_out, uint32_t *__restrict__ agg_hot, float agg_threshold) {
     constexpr int K = kMK, B = 2 * W, NS = mfma_slots(NT), NTILE = mfma_tiles(NT), SPT = 32 / NT, NP = NT / 4;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
     #ifndef RP_MFMA_GX_PD  // A/B builds: 1 = the one-column look-ahead of the staged form
@@ -364,6 +364,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #undef RP_X0F
 
         // D[m - 1][n] with m == n == L (dtw.rs:101): band position q = (L - 1) - (L - W + 1) = W - 2
+        float best = 0.f;  // ScoreMode::Max over this lane's templates (scores are > 0; an abandoned wave reports 0 like its scores)
         if (valid) {
             const size_t row = s * out_win_pitch + (size_t)w;
             const float denom = (float)(L + L);
@@ -377,10 +378,18 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
                         const float nc = cost / denom;
                         const float sc = dead ? 0.f : 1.f / (1.f + expf((nc - score_ref) / score_ref));
                         const int t = ch->tid[slot];
-                        if (t < T) scores[row * T + t] = sc;
+                        if (t < T) { scores[row * T + t] = sc; best = fmaxf(best, sc); }
                         else if (!dead) avg[row] = sc;
                     }
                 }
+            }
+        }
+        if (agg_out) {  // the chunk holds every sample template (launch_dtw): the two lanes of a window hold all its scores
+            const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+            const float m = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));
+            if (valid && h == 0) {
+                agg_out[s * out_win_pitch + (size_t)w] = m;
+                if (agg_hot && m > agg_threshold) agg_hot[s] = 1u;  // as agg_store: every writer stores the same value
             }
         }
         if (!GX) wave_lds_sync();  // the next tile restages xs
@@ -409,8 +418,13 @@ bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from
 
 hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
-                           bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc) {
+                           bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,
+                           const DtwFusedAgg *fuse) {
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
+    if (fuse && (n_chunks != 1 || list || count)) return hipErrorInvalidValue;  // launch_dtw only asks for it with one chunk, every row scored
+    float *agg_out = fuse ? fuse->agg : nullptr;
+    uint32_t *agg_hot = fuse ? fuse->hot : nullptr;
+    const float agg_threshold = fuse ? fuse->threshold : 0.f;
     if (list && !from_global) return hipErrorNotSupported;
     const size_t total_tiles = (S * n_win + kMWin - 1) / kMWin;
     const int nw = dtw_mfma_lds_bytes(t.max_len, 12) <= 160 * 1024 ? 12 : 8;
@@ -430,7 +444,7 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int 
         hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV, NT>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
                            reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
-                           abandon_nc, t.mfma_sched, static_rounds);                                                                \
+                           abandon_nc, t.mfma_sched, static_rounds, agg_out, agg_hot, agg_threshold);                                                                \
     } while (0)
 #define RP_LAUNCH_MFMA_W(WW, NT)                                                                                                    \
     do {                                                                                                                            \

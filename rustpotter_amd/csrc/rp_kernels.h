@@ -135,9 +135,20 @@ bool dtw_mfma_wide_supported(const TemplatesDev &t, int band);
 hipError_t launch_dtw_mfma_wide(hipStream_t st, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                 size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, const uint32_t *list,
                                 const uint32_t *count, uint32_t dense_min, float abandon_nc);
+// ScoreMode::Max folded into the matrix-core DTW kernel when ONE chunk holds every sample template of the reference and no averaged
+// template is scored in the call (BASELINE C2 / C3, a live-stream call with same-length templates): the lane pair of a window holds all
+// its scores, so the kernel also writes agg[row] = max_t score and raises the stream's `hot` flag like agg_store (rp_dtw.hip) -- the
+// aggregate pass (a launch, and a second read of every score) is skipped.  launch_dtw sets `done` when it took that route.
+struct DtwFusedAgg {
+    float *agg = nullptr;
+    uint32_t *hot = nullptr;   // one flag per stream, zeroed by the caller BEFORE the launch; may be null
+    float threshold = 0.f;
+    bool done = false;
+};
 hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
-                           bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc);
+                           bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,
+                           const DtwFusedAgg *fuse = nullptr);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs
 // (one rp_ctx per device) has to set it on each of them.  Sets it once per (current device, kernel), thread-safe.
@@ -200,7 +211,7 @@ hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *
 float dtw_abandon_nc(float threshold, float score_ref);
 hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
-                      float *scores, float *avg, bool padded_rows = false, float abandon_nc = __builtin_inff());
+                      float *scores, float *avg, bool padded_rows = false, float abandon_nc = __builtin_inff(), DtwFusedAgg *fuse = nullptr);
 
 // the same gate for template sets only dtw_generic_kernel serves (dtw_uses_generic), at wave granularity, and for the
 // single-stream API (one launch for the averaged template, one for the sample templates when a window passed)

@@ -250,6 +250,65 @@ def test_tile_hand_out_does_not_change_a_bit(ra, ctx, K, T, S):
     assert np.array_equal(ref[S - 1], one[0])
 
 
+class _aggregate_pass:
+    """RP_DTW_NO_FUSED_MAX=1 for the calls inside (read per call): ScoreMode::Max by the aggregate pass, not inside the DTW kernel."""
+    def __enter__(self):
+        self.old = os.environ.get("RP_DTW_NO_FUSED_MAX")
+        os.environ["RP_DTW_NO_FUSED_MAX"] = "1"
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["RP_DTW_NO_FUSED_MAX"]
+        else:
+            os.environ["RP_DTW_NO_FUSED_MAX"] = self.old
+
+
+@pytest.mark.parametrize("T,L", [(8, 30), (5, 40), (4, 33), (3, 48), (6, 12)])
+def test_max_inside_the_dtw_kernel_equals_the_aggregate_pass(ra, ctx, T, L):
+    """One chunk of 3..8 same-length templates, ScoreMode::Max, no averaged template: the matrix-core kernel writes the aggregate and the
+    per-stream flags itself (DtwFusedAgg) and the aggregate pass is not launched.  Same detections, scores and aggregates bit for bit as
+    with the pass (RP_DTW_NO_FUSED_MAX=1), with the per-window arrays and in detect-only calls, offline and chunk by chunk; the
+    aggregate is the largest of a window's scores; the pass's timing slot counts no launch."""
+    K, S = 5, 70
+    templates = orc.synth_templates(SEED + 31 + T, T, L, K)
+    tm = ra.Templates(ctx, templates)
+    pcm = np.stack([orc.synth_pcm(SEED, 500 + s, 480 * 40) for s in range(S)])
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    scores0 = ctx.batch_detect(pcm, tm, cfg, want_scores=True)[2]
+    cfg.threshold, cfg.min_scores = float(np.quantile(scores0.max(axis=2), 0.98)), 2   # a few streams fire, most stay quiet
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    det, n_det, scores, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    n_fused = ctx.timing_read(2)[1]
+    det_only, n_only = ctx.batch_detect(pcm, tm, cfg)
+    with _aggregate_pass():
+        ctx.timing_reset()
+        det2, n2, scores2, agg2 = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+        n_pass = ctx.timing_read(2)[1]
+        det_only2, n_only2 = ctx.batch_detect(pcm, tm, cfg)
+    ctx.timing_enable(False)
+    assert 0 < int(n_det.sum()) and int((n_det == 0).sum()) > S // 2
+    assert np.array_equal(scores, scores2) and np.array_equal(agg, agg2) and np.array_equal(agg, scores.max(axis=2))
+    assert np.array_equal(n_det, n2) and np.array_equal(det, det2)
+    assert np.array_equal(n_only, n_only2) and np.array_equal(det_only, det_only2) and np.array_equal(n_only, n_det)
+    assert n_fused == 0 and n_pass == 1, (n_fused, n_pass)   # launches of the aggregate pass inside the two calls
+    for cpc in (1, 4):
+        out = []
+        for fused in (True, False):
+            sb = ra.StreamBatch(ctx, tm, cfg, S, max_chunks_per_call=cpc)
+            rows = []
+            for i in range(0, pcm.shape[1], 480 * cpc):
+                if fused:
+                    rows.append(sb.process(pcm[:, i:i + 480 * cpc], want_agg=True))
+                else:
+                    with _aggregate_pass():
+                        rows.append(sb.process(pcm[:, i:i + 480 * cpc], want_agg=True))
+            out.append(rows)
+        for a, b in zip(*out):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert sum(int(r[1].sum()) for r in out[0]) == int(n_det.sum())
+
+
 @pytest.mark.parametrize("cpc", [1, 2, 5])
 def test_one_stream_live_equals_offline(ra, ctx, cpc):
     """One stream alone is a batch too: fed one, two or five chunks per call (3 .. 15 new windows: the shapes the single-stream mirror

@@ -79,15 +79,19 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 // dense (rp_dtw.hip GateList).  abandon_nc < inf: early abandon of detect-only calls -- every 12 (16) columns a wave stops when the
 // cheapest band cell of every (window, template) it holds is past abandon_nc * (m + n), writing score 0 (cell costs are >= 0 and
 // every warping path crosses every column, so that cell bounds the final cost from below; the averaged template never stops).
+// static_rounds: tiles a wave takes by its own index before it turns to the counter (mfma_static_rounds, rp_kernels.h).  agg_out != null:
+// the chunk holds every sample template of the reference -- the kernel also writes ScoreMode::Max of a window's scores and raises the
+// stream's hot flag (DtwFusedAgg, rp_kernels.h).
 template <int W, int NW, bool GX, int NT>
 __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,
-    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds, float *__restrict__ agg_out, uint32_t *__restrict__ agg_hot, float agg_threshold) {
+    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds,
+    float *__restrict__ agg_out, uint32_t *__restrict__ agg_hot, float agg_threshold) {
     constexpr int K = kMK, B = 2 * W, NS = mfma_slots(NT), NTILE = mfma_tiles(NT), SPT = 32 / NT, NP = NT / 4;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
-    #ifndef RP_MFMA_GX_PD  // A/B builds: 1 = the one-column look-ahead of the staged form
+#ifndef RP_MFMA_GX_PD  // A/B builds: 1 = the one-column look-ahead of the staged form
     constexpr int PD = GX ? (NS % 3 == 0 ? 3 : 4) : 1;  // columns a frame is requested ahead of its use (RP_P0)
 #else
     constexpr int PD = GX ? RP_MFMA_GX_PD : 1;
@@ -444,7 +448,7 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int 
         hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV, NT>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
                            reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
-                           abandon_nc, t.mfma_sched, static_rounds, agg_out, agg_hot, agg_threshold);                                                                \
+                           abandon_nc, t.mfma_sched, static_rounds, agg_out, agg_hot, agg_threshold);                                            \
     } while (0)
 #define RP_LAUNCH_MFMA_W(WW, NT)                                                                                                    \
     do {                                                                                                                            \

@@ -407,9 +407,15 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
             if (mean) {  // take the window mean out: - sum_k mu[row][k] * wsum[o][k]
                 size_t rr = row0 + 4 * lk + e;
                 if (rr >= B) rr = B - 1;
-                const float *mu = mean + rr * K, *ws = wsum + (size_t)(16 * n + li) * K;
+                // K % 4 == 0 (wsum_for): 16 bytes per load, all of a row's loads in flight before the first multiply-add (one value
+                // per load and wait made 2 K dependent L2 round trips per output); the sum runs in the same order
+                const float4 *mu = reinterpret_cast<const float4 *>(mean + rr * K), *ws = reinterpret_cast<const float4 *>(wsum + (size_t)(16 * n + li) * K);
                 float corr = 0.f;
-                for (int k = 0; k < K; ++k) corr = fmaf(mu[k], ws[k], corr);
+#pragma unroll 4
+                for (int k = 0; k < K / 4; ++k) {
+                    const float4 m4 = mu[k], w4 = ws[k];
+                    corr = fmaf(m4.x, w4.x, corr); corr = fmaf(m4.y, w4.y, corr); corr = fmaf(m4.z, w4.z, corr); corr = fmaf(m4.w, w4.w, corr);
+                }
                 v -= corr;
             }
             v += b1[16 * n + li];

@@ -1342,10 +1342,18 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
         }
         float *dg = c->ws_agg.as<float>(), *da = c->ws_avg.as<float>();
         int32_t *dlab = c->ws_rms.as<int32_t>();
+        // nn_score_kernel also tells the scan which streams have a window that passed (a flag per stream, like the aggregate pass of
+        // the reference path): the others are not swept
+        uint32_t *hot = nullptr;
+        if (n_win) {
+            if (!c->ws_hot.reserve(S * sizeof(uint32_t) + 16)) return -1;
+            if (!hip_ok(hipMemsetAsync(c->ws_hot.p, 0, S * sizeof(uint32_t), c->stream), "hipMemsetAsync(hot)")) return -1;
+            hot = c->ws_hot.as<uint32_t>();
+        }
         if (!hip_ok(launch_nn_score(c->stream, dlog, rows, n_labels, none_index, config->score_ref * 10.f, config->avg_threshold != 0.f ? 1 : 0,
-                                    config->threshold, config->avg_threshold, dg, da, dlab), "nn_score_kernel")) return -1;
+                                    config->threshold, config->avg_threshold, dg, da, dlab, hot, n_win), "nn_score_kernel")) return -1;
         ScanWakewords ww{};
-        ww.n = 1; ww.agg[0] = dg; ww.avg[0] = da; ww.label[0] = dlab;
+        ww.n = 1; ww.agg[0] = dg; ww.avg[0] = da; ww.label[0] = dlab; ww.hot = hot;
         ww.threshold[0] = -1.f; ww.avg_threshold[0] = -1.f;  // the gates were applied by nn_score_kernel (>=, not >)
         ScanConfig sc;
         sc.threshold = config->threshold; sc.avg_threshold = config->avg_threshold; sc.min_scores = (int)config->min_scores;

@@ -356,7 +356,8 @@ hipError_t launch_train_step(hipStream_t st, const float *x, const int32_t *labe
 hipError_t launch_normalize_windows_batch(hipStream_t st, const float *mfcc, size_t frame_pitch, size_t n_win, size_t first_row,
                                           size_t n_rows, int L, int K, float *x);
 hipError_t launch_nn_score(hipStream_t st, const float *logits, size_t n_rows, int n_labels, int none_index, float score_ref10,
-                           int calc_avg, float threshold, float avg_threshold, float *agg, float *avg, int32_t *label);
+                           int calc_avg, float threshold, float avg_threshold, float *agg, float *avg, int32_t *label,
+                           uint32_t *hot = nullptr, size_t rows_per_stream = 0);  // hot: a flag per stream (zeroed by the caller) raised by every window that passed
 hipError_t launch_mlp(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,
                       float *const *Bv, float *scratch0, float *scratch1, float *out);
 

@@ -78,7 +78,8 @@ __device__ __forceinline__ float nn_inverse_similarity(float n1, float n2, float
 // smallest other logit), validate_scores (:113-123)
 __global__ __launch_bounds__(256) void nn_score_kernel(const float *__restrict__ logits, size_t n_rows, int nl, int none_index,
                                                        float ref, int calc_avg, float threshold, float avg_threshold,
-                                                       float *__restrict__ agg, float *__restrict__ avg, int32_t *__restrict__ label) {
+                                                       float *__restrict__ agg, float *__restrict__ avg, int32_t *__restrict__ label,
+                                                       uint32_t *__restrict__ hot, size_t rows_per_stream) {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_rows) return;
     const float *lg = logits + r * nl;
@@ -101,15 +102,19 @@ __global__ __launch_bounds__(256) void nn_score_kernel(const float *__restrict__
         if (sc >= threshold && av >= avg_threshold) score = sc;
     }
     agg[r] = score; avg[r] = av; label[r] = bi;
+    // a stream with no window that passed cannot fire (detector.rs:411-429): the scan skips it (every writer stores the same value)
+    if (hot && score != -2.f) hot[r / rows_per_stream] = 1u;
 }
 
 hipError_t launch_nn_score(hipStream_t st, const float *logits, size_t n_rows, int n_labels, int none_index, float score_ref10,
-                           int calc_avg, float threshold, float avg_threshold, float *agg, float *avg, int32_t *label) {
+                           int calc_avg, float threshold, float avg_threshold, float *agg, float *avg, int32_t *label, uint32_t *hot,
+                           size_t rows_per_stream) {
     if (n_rows == 0) return hipSuccess;
+    if (hot && rows_per_stream == 0) return hipErrorInvalidValue;
     const size_t blocks = (n_rows + 255) / 256;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(nn_score_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits, n_rows, n_labels, none_index, score_ref10, calc_avg,
-                       threshold, avg_threshold, agg, avg, label);
+                       threshold, avg_threshold, agg, avg, label, hot, rows_per_stream);
     return hipGetLastError();
 }
 

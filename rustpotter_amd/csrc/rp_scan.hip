@@ -77,10 +77,19 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
         for (int j = 0; j < ww.n; ++j) {
             const float *a0 = ww.agg[j] + s0 * (size_t)(n_win > 0 ? n_win : 0);
             const float *v0 = ww.avg[j] ? ww.avg[j] + s0 * (size_t)(n_win > 0 ? n_win : 0) : nullptr;
-            for (size_t e = lane; e < total; e += 64) {
-                bool pass = a0[e] > ww.threshold[j];
-                if (pass && v0) pass = !(v0[e] < ww.avg_threshold[j]);
-                if (pass) mask |= 1ull << (e / (size_t)n_win);
+            // eight rows' loads in flight per wait (one load -> wait -> test per element made a block's 64 x n_win aggregates n_win
+            // dependent round trips: 0.17 ms for 4 096 streams x 202 windows in the batched model detector)
+            const float thr = ww.threshold[j], athr = ww.avg_threshold[j];
+            if (v0) {
+#pragma unroll 8
+                for (size_t e = lane; e < total; e += 64) {
+                    const float a = a0[e], v = v0[e];
+                    if (a > thr && !(v < athr)) mask |= 1ull << (e / (size_t)n_win);
+                }
+            } else {
+#pragma unroll 8
+                for (size_t e = lane; e < total; e += 64)
+                    if (a0[e] > thr) mask |= 1ull << (e / (size_t)n_win);
             }
         }
         if (mask) atomicOr(&candidates, mask);

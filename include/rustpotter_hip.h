@@ -426,7 +426,10 @@ enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1 };
 /* WakewordNN forward (ModelImpl::forward: Linear -> ReLU -> ... -> Linear, raw logits),
  * src/wakewords/nn/wakeword_nn.rs:101-106,305-389: x [B][dims[0]] (the flattened, mean-normalised
  * window, :139-149,268-273) -> logits [B][dims[n_layers]].  Layer 1 runs on the matrix cores:
- * RP_MLP_F32 = f32-input MFMA (exact f32), RP_MLP_BF16 = inputs rounded to bf16, f32 accumulate. */
+ * RP_MLP_F32 = f32-grade layer 1 (dense rows of models up to 32 hidden units: inputs and weights as f16 two-way splits, 22
+ * significant bits each, f32 accumulate -- logits at the distance two f32 summation orders have from the f32 matrix instructions,
+ * which serve every other shape and, with RP_MLP_STREAM=0, these too; a feature of magnitude above 65 504 gives its row NaN logits
+ * there), RP_MLP_BF16 = inputs rounded to bf16, f32 accumulate. */
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits);
 
 /* rp_batch_detect for a wakeword MODEL (WakewordNN::run_detection, src/wakewords/nn/wakeword_nn.rs:39-159, inside the

@@ -1226,16 +1226,20 @@ int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const 
 }
 void rp_model_free(rp_model *m) { delete m; }
 
-// Dense rows through layer 1 on the matrix cores: the line-streaming kernel (rp_mlp_stream.hip) for bf16 inputs, where the
-// pass is bound by the HBM stream (0.132 against 0.155 ms at BASELINE config C5); the register-fragment kernel for exact f32,
-// where the f32 matrix rate binds and its 24 waves per CU overlap better (0.198 against 0.207 ms).  RP_MLP_STREAM=0 / 2 force
-// the latter / the former for both precisions (benchmarks, tests).
+// Dense rows through layer 1 on the matrix cores: the line-streaming kernel (rp_mlp_stream.hip), where the pass is bound by the HBM
+// stream (bf16 inputs: 0.132 against 0.155 ms at BASELINE config C5; f32 callers: its f16 two-way split form).  With the f32 matrix
+// instructions themselves the f32 matrix rate binds and the register-fragment kernel's 24 waves per CU overlap better (0.198 against
+// 0.207 ms): RP_MLP_STREAM=0 forces that kernel, RP_MLP_STREAM=2 the streaming kernel in the caller's own precision (benchmarks, tests).
 static hipError_t mlp_rows_mfma(Ctx *c, const Model &m, const float *dx, size_t B, int precision, float *out) {
     const char *e = std::getenv("RP_MLP_STREAM");
     const int mode = e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1;
     MlpStreamPlan plan;
-    if ((mode == 2 || (mode == 1 && precision == RP_MLP_BF16)) && const_cast<Model &>(m).stream_plan(dx, B, precision, &plan))
-        return launch_mlp_stream(c->stream, m.dev, plan, dx, B, precision, out, c->n_cu);
+    // f32 callers: the streaming kernel with f16 two-way splits of inputs and weights (kMlpF16x2: 22 significant bits per operand, f32
+    // accumulate -- logits within 1e-6 of the f32 matrix instructions') runs at the HBM stream's rate like the bf16 form, where the f32
+    // matrix rate bound both exact kernels (0.19 ms at C5)
+    const int sprec = (mode == 1 && precision == RP_MLP_F32) ? (int)kMlpF16x2 : precision;
+    if (mode != 0 && const_cast<Model &>(m).stream_plan(dx, B, sprec, &plan))
+        return launch_mlp_stream(c->stream, m.dev, plan, dx, B, sprec, out, c->n_cu);
     return launch_mlp_mfma(c->stream, m.dev, dx, B, precision, out);
 }
 

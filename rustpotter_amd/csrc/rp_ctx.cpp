@@ -522,7 +522,7 @@ const float *Model::wsum_for(int K) {
 // bf16, or two (one per half) in f32.  Zero past dims[0] and past dims[1].  The image does not depend on where the rows
 // start (the kernel shifts its reads instead), so it is built once per precision.
 bool Model::stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *plan) {
-    if (!mfma_ok || !mlp_stream_supported(dev, x) || (precision != kMlpF32 && precision != kMlpBf16)) return false;
+    if (!mfma_ok || !mlp_stream_supported(dev, x) || (precision != kMlpF32 && precision != kMlpBf16 && precision != kMlpF16x2)) return false;
     const int in = dims[0], n1 = dims[1], nt = dev.nt;
     const int q0 = (int)((reinterpret_cast<uintptr_t>(x) >> 4) & 7);
     const int par = ((in / 4) % 8) != 0;  // in % 16 == 0: the row pitch is 0 or 4 chunks mod 8
@@ -534,10 +534,10 @@ bool Model::stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *
     plan->nbt = par ? 2 * (int)((B + 255) / 256) : (int)((B + 127) / 128);
     const int lines_max = (in - 1 + 4 * 7) / 32 + 1;             // at the largest phase
     const int ksteps = 2 * ((lines_max + 1) / 2);                // two per unit, for every phase
-    std::unique_ptr<DevBuf> &buf = stream_img[precision == kMlpF32 ? 0 : 1];
+    std::unique_ptr<DevBuf> &buf = stream_img[precision];
     if (!buf) {
-        const bool f32 = precision == kMlpF32;
-        const size_t wk = (size_t)(f32 ? 2048 : 1024) * nt;
+        const bool f32 = precision == kMlpF32, f16x2 = precision == kMlpF16x2;
+        const size_t wk = (size_t)(precision == kMlpBf16 ? 1024 : 2048) * nt;
         std::vector<uint8_t> img(wk * ksteps, 0);
         auto wat = [&](int o, long k) -> float { return (o < n1 && k < in) ? w1_host[(size_t)o * in + k] : 0.f; };
         for (int m = 0; m < ksteps; ++m)
@@ -549,6 +549,17 @@ bool Model::stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *
                         for (int h = 0; h < 2; ++h) {
                             float *dst = reinterpret_cast<float *>(img.data() + wk * m + ((size_t)h * nt + n) * 1024 + l * 16);
                             for (int e = 0; e < 4; ++e) dst[e] = wat(o, k0 + 16 * h + e);
+                        }
+                    } else if (f16x2) {
+                        // pieces [part][n]: part 0 = w0 = f16(w), part 1 = w1 = f16(w - w0); the eight k of a piece as in the bf16 image
+                        uint16_t *d0 = reinterpret_cast<uint16_t *>(img.data() + wk * m + (size_t)n * 1024 + l * 16);
+                        uint16_t *d1 = reinterpret_cast<uint16_t *>(img.data() + wk * m + ((size_t)nt + n) * 1024 + l * 16);
+                        for (int e = 0; e < 8; ++e) {
+                            const float w = wat(o, k0 + (e < 4 ? e : 12 + e));
+                            const _Float16 w0 = (_Float16)w;
+                            const _Float16 w1 = (_Float16)(w - (float)w0);
+                            __builtin_memcpy(d0 + e, &w0, 2);
+                            __builtin_memcpy(d1 + e, &w1, 2);
                         }
                     } else {
                         uint16_t *dst = reinterpret_cast<uint16_t *>(img.data() + wk * m + (size_t)n * 1024 + l * 16);

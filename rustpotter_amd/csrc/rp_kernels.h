@@ -316,7 +316,10 @@ struct MlpDev {
     float *tail = nullptr; // layers 2..n: W [out][in] then b [out], concatenated
     int tail_floats = 0;
 };
-enum { kMlpF32 = 0, kMlpBf16 = 1 };
+// kMlpF16x2 (internal, mlp_stream_kernel only): f32-grade layer 1 at the matrix cores' f16 rate -- inputs and weights as f16 two-way splits
+// (x = x0 + x1, w = w0 + w1, 22 significant bits each; x0 w0 + x1 w0 + x0 w1, f32 accumulate: the dropped x1 w1 is 2^-22 of a product),
+// what RP_MLP_F32 callers get when the line-streaming kernel serves their rows
+enum { kMlpF32 = 0, kMlpBf16 = 1, kMlpF16x2 = 2 };
 // Fused forward of all layers; layer 1 on the matrix cores (f32-input MFMA: bit-for-bit an fmaf
 // chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.
 hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out);

@@ -32,6 +32,8 @@
 namespace rp {
 
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 #define RP_LDSP(p) ((__attribute__((address_space(3))) void *)(p))
 
 constexpr int kStreamWavesMax = 8;
@@ -54,12 +56,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
     int h2p, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N1P = 16 * NT;
-    constexpr int WK = (PREC == kMlpF32 ? 2048 : 1024) * NT;   // bytes of fragment-ordered weights per k-step (32 k)
+    constexpr int WK = (PREC == kMlpBf16 ? 1024 : 2048) * NT;   // bytes of fragment-ordered weights per k-step (32 k)
     constexpr int WU = 2 * WK;                                 // per unit
     constexpr int WP = WU / 1024;                              // 1 KB DMA pieces per unit, one per wave
     constexpr int NS = D + 1, NW = D + 2;                      // ring depths (rows: private to a wave; weights: shared); D + 1
                                                                // units are in flight while a unit is being worked on
-    constexpr int WF = PREC == kMlpF32 ? 2 * NT : NT;          // 16-byte weight pieces a lane holds per k-step
+    constexpr int WF = PREC == kMlpBf16 ? NT : 2 * NT;         // 16-byte weight pieces a lane holds per k-step
     constexpr int WPW = (WP + kStreamWaves - 1) / kStreamWaves;   // weight pieces a wave moves per unit (the last ones may move one fewer)
     constexpr int H1P = N1P + 4;                               // h1 row pitch: 16-byte aligned rows on distinct bank quads
     float *tl = reinterpret_cast<float *>(smem);
@@ -174,6 +176,28 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wf.w[NT + n][e], acc[n], 0, 0, 0);
+        } else if (PREC == kMlpF16x2) {   // pieces: [part][n], eight f16 each: w0 then w1
+            // x0 = rtz_f16(x), x1 = rtz_f16(x - x0): x0 as f32 is x with 13 mantissa bits cleared (below the f16 normal range the two
+            // differ by less than an f16 subnormal step, 6e-8)
+            const float xs[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            unsigned h0[4], h1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // beyond the f16 range (features are MFCC coefficients, orders of magnitude below) a split would be silently wrong: such
+                // an input poisons its row with NaN instead (RP_MLP_STREAM=0 keeps the f32 matrix instructions for any finite input)
+                const float p = fabsf(xs[2 * e]) <= 65504.f ? xs[2 * e] : __builtin_nanf(""), q = fabsf(xs[2 * e + 1]) <= 65504.f ? xs[2 * e + 1] : __builtin_nanf("");
+                h0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p, q));
+                h1[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p - __uint_as_float(__float_as_uint(p) & 0xffffe000u),
+                                                                                q - __uint_as_float(__float_as_uint(q) & 0xffffe000u)));
+            }
+            const f16x8s av0 = __builtin_bit_cast(f16x8s, (u32x4s){h0[0], h0[1], h0[2], h0[3]});
+            const f16x8s av1 = __builtin_bit_cast(f16x8s, (u32x4s){h1[0], h1[1], h1[2], h1[3]});
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8s, wf.w[n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8s, wf.w[n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
         } else {                 // pieces: [n], eight bf16 each
             bf16x8s av;
             av[0] = (__bf16)a0.x; av[1] = (__bf16)a0.y; av[2] = (__bf16)a0.z; av[3] = (__bf16)a0.w;
@@ -312,7 +336,7 @@ static int stream_tail_lds(const MlpDev &m, int *h2p) {
 }
 
 static size_t stream_lds_bytes(int nt, int precision, int depth, int tail_lds, int h2p, int waves = kStreamWavesMax) {
-    const size_t wu = (size_t)(precision == kMlpF32 ? 4096 : 2048) * nt;
+    const size_t wu = (size_t)(precision == kMlpBf16 ? 2048 : 4096) * nt;
     return ((size_t)tail_lds + 16 * nt) * 4 + (depth + 2) * wu + (size_t)waves * (depth + 1) * 4096 +
            (size_t)waves * 16 * (16 * nt + 4) * 4 + (size_t)waves * 16 * h2p * 4;
 }
@@ -358,6 +382,8 @@ hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPla
     RP_STREAM_CASE(1, kMlpBf16)
     RP_STREAM_CASE(2, kMlpF32)
     RP_STREAM_CASE(2, kMlpBf16)
+    RP_STREAM_CASE(1, kMlpF16x2)
+    RP_STREAM_CASE(2, kMlpF16x2)
 #undef RP_STREAM_CASE
     return hipErrorInvalidValue;
 }

@@ -327,8 +327,27 @@ def test_mlp_stream_kernel_shapes_and_batch_sizes(ra, ctx, dims, B):
     ref16 = orc.mlp_forward(x, ws, bs, bf16_layer1=True)
     assert np.allclose(got16, ref16, rtol=1e-3, atol=1e-3), np.abs(got16 - ref16).max()
     os.environ.pop("RP_MLP_STREAM")
-    # and as the library chooses by itself: f32 on the register-fragment kernel (other k order: close, not bit-equal), bf16 streamed
-    assert np.allclose(ctx.mlp_forward(x, model), ref, rtol=2e-5, atol=2e-5)
+    # and as the library chooses by itself: bf16 streamed; f32 callers streamed too, layer 1 as f16 two-way splits of inputs and weights
+    # (kMlpF16x2: within 1e-5 of the f32 matrix instructions -- the distance two f32 summation orders have -- and not their bits), batch-invariant
+    # and bit-reproducible like the other forms; a feature beyond the f16 range gives its row NaN logits, never a wrong number
+    split = ctx.mlp_forward(x, model)
+    assert np.allclose(split, ref, rtol=2e-5, atol=2e-5)
+    os.environ["RP_MLP_STREAM"] = "0"
+    exact = ctx.mlp_forward(x, model)
+    os.environ.pop("RP_MLP_STREAM")
+    assert np.allclose(split, exact, rtol=1e-5, atol=1e-5), np.abs(split - exact).max()
+    # (and against the streaming kernel on the f32 matrix instructions: both differences are the order in which the matrix instructions
+    # add up their products -- 32 per instruction here, 4 there -- 5e-6 on logits of order 1, not the 2^-22 of the split)
+    assert np.allclose(split, got, rtol=1e-5, atol=1e-5), np.abs(split - got).max()
+    if B > 200:
+        assert split.tobytes() != exact.tobytes() and split.tobytes() != got.tobytes()   # the split form really ran
+    assert ctx.mlp_forward(x, model).tobytes() == split.tobytes()
+    if B > 2:
+        assert ctx.mlp_forward(x[1:], model).tobytes() == split[1:].tobytes()
+        xb = x.copy()
+        xb[1, 7] = 7.0e4
+        big = ctx.mlp_forward(xb, model)
+        assert np.isnan(big[1]).all() and np.delete(big, 1, axis=0).tobytes() == np.delete(split, 1, axis=0).tobytes()
     assert ctx.mlp_forward(x, model, precision="bf16").tobytes() == got16.tobytes()
 
 

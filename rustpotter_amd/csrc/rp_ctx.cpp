@@ -472,13 +472,16 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
         d.kpad = (dims[0] + 127) / 128 * 128;  // whole unrolled k-groups of both MFMA kernels
         const int rows = 16 * d.nt;
         std::vector<float> wf((size_t)rows * d.kpad, 0.f), b1(rows, 0.f);
-        std::vector<uint16_t> wh((size_t)rows * d.kpad, 0);
+        std::vector<uint16_t> wh((size_t)rows * d.kpad, 0), wsp((size_t)2 * rows * d.kpad, 0);
         for (int o = 0; o < n1; ++o) {
             b1[o] = biases[0][o];
             for (int i = 0; i < dims[0]; ++i) {
                 float v = weights[0][(size_t)o * dims[0] + i];
                 wf[(size_t)o * d.kpad + i] = v;
                 wh[(size_t)o * d.kpad + i] = f32_to_bf16(v);
+                const _Float16 w0 = (_Float16)v, w1 = (_Float16)(v - (float)w0);   // kMlpF16x2: w = w0 + w1 to 22 bits
+                __builtin_memcpy(&wsp[(size_t)o * d.kpad + i], &w0, 2);
+                __builtin_memcpy(&wsp[(size_t)rows * d.kpad + (size_t)o * d.kpad + i], &w1, 2);
             }
         }
         std::vector<float> tail;
@@ -489,7 +492,7 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
         if (tail.empty()) tail.push_back(0.f);
         d.tail_floats = (int)tail.size();
         if (!mlp_mfma_fits(d)) { m->mfma_ok = false; d.nt = 0; return m.release(); }   // e.g. a 255-wide hidden layer: per-layer kernel
-        if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) ||
+        if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) || !up(wsp.data(), wsp.size() * 2, &d.w1s) ||
             !up(b1.data(), b1.size() * 4, reinterpret_cast<void **>(&d.b1)) || !up(tail.data(), tail.size() * 4, reinterpret_cast<void **>(&d.tail)))
             return nullptr;
     }
@@ -582,6 +585,7 @@ Model::~Model() {
     for (float *p : B) (void)hipFree(p);
     if (dev.w1f) (void)hipFree(dev.w1f);
     if (dev.w1h) (void)hipFree(dev.w1h);
+    if (dev.w1s) (void)hipFree(dev.w1s);
     if (dev.b1) (void)hipFree(dev.b1);
     if (dev.tail) (void)hipFree(dev.tail);
 }

@@ -312,13 +312,14 @@ struct MlpDev {
     int kpad = 0;          // dims[0] rounded up to 128
     float *w1f = nullptr;  // [16*nt][kpad] f32, zero padded
     void *w1h = nullptr;   // [16*nt][kpad] bf16, zero padded
+    void *w1s = nullptr;   // [2][16*nt][kpad] f16: the two parts of the weights' f16 split (kMlpF16x2), zero padded
     float *b1 = nullptr;   // [16*nt]
     float *tail = nullptr; // layers 2..n: W [out][in] then b [out], concatenated
     int tail_floats = 0;
 };
-// kMlpF16x2 (internal, mlp_stream_kernel only): f32-grade layer 1 at the matrix cores' f16 rate -- inputs and weights as f16 two-way splits
+// kMlpF16x2 (internal): f32-grade layer 1 at the matrix cores' f16 rate -- inputs and weights as f16 two-way splits
 // (x = x0 + x1, w = w0 + w1, 22 significant bits each; x0 w0 + x1 w0 + x0 w1, f32 accumulate: the dropped x1 w1 is 2^-22 of a product),
-// what RP_MLP_F32 callers get when the line-streaming kernel serves their rows
+// what RP_MLP_F32 callers get from both matrix-core kernels (RP_MLP_STREAM=0: the f32 matrix instructions)
 enum { kMlpF32 = 0, kMlpBf16 = 1, kMlpF16x2 = 2 };
 // Fused forward of all layers; layer 1 on the matrix cores (f32-input MFMA: bit-for-bit an fmaf
 // chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.

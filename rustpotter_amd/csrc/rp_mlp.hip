@@ -261,6 +261,8 @@ hipError_t launch_train_step(hipStream_t st, const float *x, const int32_t *labe
 // The tail layers (<= 130 x 32 weights) run per row from LDS.  HBM-bound by construction: 4*in bytes
 // per row against 2*in*N1 flops (12 480 B/row, ceiling 0.64 G rows/s at 8 TB/s).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 constexpr int kMlpWaves = 8;
 constexpr int kMlpRowsPerWave = 16;
 constexpr int kMlpKG = 128;  // k-group staged per step
@@ -296,12 +298,13 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     // loads are issued before this group's MFMAs and land in the other buffer, one barrier per group
     constexpr bool DB = NT <= 2;
     constexpr int PF = mlp_wpitch_f32(), PH = mlp_wpitch_bf16();
-    constexpr int NV = PREC == kMlpF32 ? (N1P * (kMlpKG / 4) + 64 * kMlpWaves - 1) / (64 * kMlpWaves)
-                                       : (N1P * (kMlpKG / 8) + 64 * kMlpWaves - 1) / (64 * kMlpWaves);
+    // 16-byte pieces of a staged weight group: f32 four k each, bf16 eight, kMlpF16x2 eight in each of its two planes
+    constexpr int NPIECE = PREC == kMlpF32 ? N1P * (kMlpKG / 4) : PREC == kMlpBf16 ? N1P * (kMlpKG / 8) : 2 * N1P * (kMlpKG / 8);
+    constexpr int NV = (NPIECE + 64 * kMlpWaves - 1) / (64 * kMlpWaves);
     const int half = DB ? wbuf_floats / 2 : 0;
     // every thread moves NV pieces; when the slice is a whole number of pieces per thread the bounds test is dropped
     // (a conditional store into wreg makes the compiler keep the array in scratch memory)
-    constexpr bool FULL = (PREC == kMlpF32 ? N1P * (kMlpKG / 4) : N1P * (kMlpKG / 8)) % (64 * kMlpWaves) == 0;
+    constexpr bool FULL = NPIECE % (64 * kMlpWaves) == 0;
     // one 16-byte piece = 4 f32 or 8 bf16; plain vector values (HIP's float4 struct is copied with memcpy, which keeps
     // the staging array in scratch memory)
     auto wload = [&](int g, f32x4 (&wreg)[NV]) __attribute__((always_inline)) {
@@ -311,9 +314,12 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
             if (PREC == kMlpF32) {
                 const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
                 if (FULL || o < N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1f + (size_t)o * kpad + g * kMlpKG + 4 * c);
-            } else {
+            } else if (PREC == kMlpBf16) {
                 const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
                 if (FULL || o < N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1h + (size_t)o * kpad + g * kMlpKG + 8 * c);
+            } else {   // kMlpF16x2: plane p of w1h = [2][N1P][kpad] f16 (MlpDev::w1s)
+                const int po = i / (kMlpKG / 8), c = i - po * (kMlpKG / 8);
+                if (FULL || po < 2 * N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1h + (size_t)po * kpad + g * kMlpKG + 8 * c);
             }
         }
     };
@@ -324,9 +330,12 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
             if (PREC == kMlpF32) {
                 const int o = i / (kMlpKG / 4), c = i - o * (kMlpKG / 4);
                 if (FULL || o < N1P) *reinterpret_cast<f32x4 *>(dstbuf + o * PF + 4 * c) = wreg[v];
-            } else {
+            } else if (PREC == kMlpBf16) {
                 const int o = i / (kMlpKG / 8), c = i - o * (kMlpKG / 8);
                 if (FULL || o < N1P) *reinterpret_cast<f32x4 *>(reinterpret_cast<__bf16 *>(dstbuf) + o * PH + 8 * c) = wreg[v];
+            } else {   // both planes, rows po = plane * N1P + o at the bf16 pitch
+                const int po = i / (kMlpKG / 8), c = i - po * (kMlpKG / 8);
+                if (FULL || po < 2 * N1P) *reinterpret_cast<f32x4 *>(reinterpret_cast<__bf16 *>(dstbuf) + po * PH + 8 * c) = wreg[v];
             }
         }
     };
@@ -372,6 +381,34 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
                 for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[n].z, acc[n], 0, 0, 0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[n].w, acc[n], 0, 0, 0);
+                if (u == 0) prefetch();
+            }
+        } else if (PREC == kMlpF16x2) {
+            // f16 two-way splits: x0 = rtz_f16(x) (as f32: 13 mantissa bits cleared), x1 = rtz_f16(x - x0); x0 w0 + x1 w0 + x0 w1
+            // on the f16 matrix instruction, f32 accumulate.  A feature beyond the f16 range poisons its row with NaN instead of a wrong sum.
+            const __bf16 *wb = reinterpret_cast<const __bf16 *>(cur);
+#pragma unroll
+            for (int u = 0; u < NA / 2; ++u) {
+                const float4 lo = a[2 * u], hi = a[2 * u + 1];
+                const float xs[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                unsigned h0[4], h1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = fabsf(xs[2 * e]) <= 65504.f ? xs[2 * e] : __builtin_nanf(""), q = fabsf(xs[2 * e + 1]) <= 65504.f ? xs[2 * e + 1] : __builtin_nanf("");
+                    h0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p, q));
+                    h1[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p - __uint_as_float(__float_as_uint(p) & 0xffffe000u),
+                                                                                    q - __uint_as_float(__float_as_uint(q) & 0xffffe000u)));
+                }
+                const f16x8 av0 = __builtin_bit_cast(f16x8, (u32x4v){h0[0], h0[1], h0[2], h0[3]});
+                const f16x8 av1 = __builtin_bit_cast(f16x8, (u32x4v){h1[0], h1[1], h1[2], h1[3]});
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f16x8 b0 = *reinterpret_cast<const f16x8 *>(wb + (16 * n + li) * PH + 32 * u + 8 * lk);
+                    const f16x8 b1v = *reinterpret_cast<const f16x8 *>(wb + (N1P + 16 * n + li) * PH + 32 * u + 8 * lk);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, b0, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, b0, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, b1v, acc[n], 0, 0, 0);
+                }
                 if (u == 0) prefetch();
             }
         } else {
@@ -471,7 +508,8 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     int h2w = 1;
     for (int l2 = 2; l2 < m.n_layers; ++l2) h2w = m.dims[l2] + 1 > h2w ? m.dims[l2] + 1 : h2w;
     h2w |= 1;
-    size_t wbuf = (size_t)16 * NT * mlp_wpitch_f32() * (NT <= 2 ? 2 : 1);       // f32 group(s) (the bf16 ones are smaller)
+    size_t wbuf = (size_t)16 * NT * mlp_wpitch_bf16() * (NT <= 2 ? 2 : 1);      // group(s) of the two f16 planes of kMlpF16x2 (f32 and bf16 ones are smaller)
+    static_assert(mlp_wpitch_bf16() >= mlp_wpitch_f32(), "staged weight group");
     const size_t h1 = (size_t)kMlpWaves * kMlpRowsPerWave * (16 * NT + 1);
     if (h1 > wbuf) wbuf = h1;
     wbuf = (wbuf + 3) & ~(size_t)3;
@@ -479,7 +517,17 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpBf16>), 160 * 1024); e != hipSuccess) return e;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF32>), 160 * 1024); e != hipSuccess) return e;
-    if (precision == kMlpBf16)
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF16x2>), 160 * 1024); e != hipSuccess) return e;
+    // f32 callers: f16 two-way splits on the f16 matrix instruction (kMlpF16x2, rp_kernels.h) unless RP_MLP_STREAM=0 asks for the f32 ones
+    if (precision == kMlpF32 && m.w1s) {
+        const char *env = std::getenv("RP_MLP_STREAM");
+        if (!(env && env[0] == '0')) precision = kMlpF16x2;
+    }
+    if (precision == kMlpF16x2)
+        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF16x2>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1s), m.b1, m.tail, m.tail_floats, m.n_layers,
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K);
+    else if (precision == kMlpBf16)
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
                            m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K);
@@ -496,7 +544,7 @@ bool mlp_mfma_fits(const MlpDev &m) {
     int h2w = 1;
     for (int l2 = 2; l2 < m.n_layers; ++l2) h2w = m.dims[l2] + 1 > h2w ? m.dims[l2] + 1 : h2w;
     h2w |= 1;
-    size_t wbuf = (size_t)16 * m.nt * mlp_wpitch_f32() * (m.nt <= 2 ? 2 : 1);
+    size_t wbuf = (size_t)16 * m.nt * mlp_wpitch_bf16() * (m.nt <= 2 ? 2 : 1);
     const size_t h1 = (size_t)kMlpWaves * kMlpRowsPerWave * (16 * m.nt + 1);
     if (h1 > wbuf) wbuf = h1;
     wbuf = (wbuf + 3) & ~(size_t)3;

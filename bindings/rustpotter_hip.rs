@@ -102,6 +102,7 @@ extern "C" {
     pub fn rp_ctx_free(ctx: *mut rp_ctx);
     pub fn rp_ctx_set_stream(ctx: *mut rp_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn rp_ctx_synchronize(ctx: *mut rp_ctx) -> c_int;
+    pub fn rp_ctx_dtw_ref_pairs(ctx: *mut rp_ctx, pairs: *mut u64) -> c_int;
     pub fn rp_mfcc_num_frames(n_samples: usize) -> usize;
     pub fn rp_mfcc_batch(ctx: *mut rp_ctx, pcm: *const f32, S: usize, n_samples: usize, pcm_stride: usize, K: c_int, mfcc: *mut f32) -> c_int;
     pub fn rp_mfcc_batch_fmt(ctx: *mut rp_ctx, pcm: *const c_void, fmt: c_int, S: usize, n_samples: usize, pcm_stride: usize, K: c_int,
@@ -355,6 +356,12 @@ impl HipContext {
     /// run the launches on a caller-owned hipStream_t (NULL = the context's own)
     pub fn set_stream(&self, hip_stream: *mut c_void) -> Result<(), String> { status(unsafe { rp_ctx_set_stream(self.h, hip_stream) }) }
     pub fn synchronize(&self) -> Result<(), String> { status(unsafe { rp_ctx_synchronize(self.h) }) }
+    /// (window, templates) pairs rescored with the reference-shaped cosine (`sqrt(dot_a * dot_b)`, src/mfcc/comparator.rs:28-48) so far
+    pub fn dtw_ref_pairs(&self) -> Result<u64, String> {
+        let mut v: u64 = 0;
+        status(unsafe { rp_ctx_dtw_ref_pairs(self.h, &mut v) })?;
+        Ok(v)
+    }
 
     /// `MfccExtractor::compute` (src/mfcc/extractor.rs:60-163) over `n_streams` whole streams of `n_samples` f32 samples:
     /// returns `[n_streams][mfcc_num_frames(n_samples)][mfcc_size]`.

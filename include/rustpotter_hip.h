@@ -184,6 +184,13 @@ void rp_ctx_free(rp_ctx *ctx);
  * torch stream); NULL = the context's own stream. */
 int rp_ctx_set_stream(rp_ctx *ctx, void *hip_stream);
 int rp_ctx_synchronize(rp_ctx *ctx);
+/* Diagnostics of the cosine distance (replaces nothing; src/mfcc/comparator.rs:28-48 is what it watches): the reference
+ * divides by sqrt(dot_a * dot_b) in f32 and returns similarity 0 when that is 0.  The device kernels compare unit-length
+ * vectors and hand every (window, templates) pair that met a squared norm outside 2^-60 .. 2^30 (frames) / 2^60 (template
+ * rows) -- where the f32 product can underflow, lose bits or overflow -- to a reference-shaped kernel.  *pairs = the number
+ * of pairs rescored that way by this context's DTW calls since it was made (waits for the context's stream); 0 for audio
+ * in any ordinary range. */
+int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs);
 
 /* Number of MFCC frames MfccExtractor::compute yields for a stream of n_samples fed
  * in 480-sample chunks from a fresh extractor: 3*floor(n/480) - 3

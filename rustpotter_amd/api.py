@@ -102,7 +102,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
@@ -166,6 +166,7 @@ def load_library():
     L.rp_ctx_free.argtypes = [vp]
     L.rp_ctx_set_stream.argtypes = [vp, vp]
     L.rp_ctx_synchronize.argtypes = [vp]
+    L.rp_ctx_dtw_ref_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rp_mfcc_num_frames.argtypes = [C.c_size_t]
     L.rp_mfcc_num_frames.restype = C.c_size_t
     L.rp_mfcc_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
@@ -641,6 +642,13 @@ class BatchContext:
     def synchronize(self):
         if self._L.rp_ctx_synchronize(self._h) < 0:
             raise _err()
+
+    def dtw_ref_pairs(self):
+        """(window, templates) pairs this context's DTW calls rescored with the reference-shaped cosine so far (rp_ctx_dtw_ref_pairs)."""
+        v = C.c_uint64(0)
+        if self._L.rp_ctx_dtw_ref_pairs(self._h, C.byref(v)) < 0:
+            raise _err()
+        return int(v.value)
 
     # --- numpy convenience (host_pointers=True)
     def mfcc(self, pcm, K):

@@ -203,6 +203,16 @@ int rp_ctx_synchronize(rp_ctx *ctx) {
     return hip_ok(hipStreamSynchronize(ctx->impl->stream), "hipStreamSynchronize") ? 0 : -1;
 }
 
+int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs) {
+    if (!ctx || !pairs) { set_last_error("null argument"); return -1; }
+    Ctx *c = ctx->impl.get();
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return -1;
+    unsigned long long v = 0;
+    if (!hip_ok(hipMemcpy(&v, dtw_fix_stats(c->dtw_work().fix), sizeof(v), hipMemcpyDeviceToHost), "hipMemcpy(dtw stats)")) return -1;
+    *pairs = (uint64_t)v;
+    return 0;
+}
+
 size_t rp_mfcc_num_frames(size_t n_samples) {
     size_t chunks = n_samples / 480;
     return chunks >= 1 ? 3 * chunks - 3 : 0;
@@ -395,7 +405,7 @@ int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames
         float *dg = agg ? static_cast<float *>(sg.out(agg, rows * sizeof(float), c->stage_out3)) : nullptr;
         if (rows && (!dm || !ds)) return -1;
         c->time_begin(kKernelDtw);
-        bool ok = hip_ok(launch_dtw(c->stream, td, dm, S, n_frames, 0, n_win, n_win, band_size, score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+        bool ok = hip_ok(launch_dtw(c->stream, c->dtw_work(), td, dm, S, n_frames, 0, n_win, n_win, band_size, score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
         c->time_end();
         if (!ok) return -1;
         if (dg) {
@@ -534,14 +544,14 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         c->time_begin(kKernelDtw);
         if (gated) {
             uint32_t *lst = c->ws_list.as<uint32_t>();
-            ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, config->avg_threshold,
+            ok = hip_ok(launch_dtw_gated(c->stream, c->dtw_work(), td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, config->avg_threshold,
                                          ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
         } else if (gated_generic) {
-            ok = hip_ok(launch_dtw_generic_gated(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref,
+            ok = hip_ok(launch_dtw_generic_gated(c->stream, c->dtw_work(), td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref,
                                                  config->avg_threshold, ds, da), "dtw_generic_kernel (gated)");
         } else {
             // ws_mfcc ends with slack: short streams (fewer than 64 windows each) are scored by cross-stream waves like live-stream batches
-            ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
+            ok = hip_ok(launch_dtw(c->stream, c->dtw_work(), td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
                                    fz.agg ? &fz : nullptr), "dtw kernel");
         }
         c->time_end();
@@ -710,10 +720,10 @@ int rp_batch_detect_multi(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
                 c->time_begin(kKernelDtw);
                 if (gated) {
                     uint32_t *lst = c->ws_list.as<uint32_t>();
-                    ok = hip_ok(launch_dtw_gated(c->stream, td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst,
+                    ok = hip_ok(launch_dtw_gated(c->stream, c->dtw_work(), td, dm, S, nf, 0, n_win, config->band_size, config->score_ref, athr, ds, da, lst + 1, lst,
                                                  true, abandon), "dtw kernels (gated)");
                 } else {
-                    ok = hip_ok(launch_dtw(c->stream, td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
+                    ok = hip_ok(launch_dtw(c->stream, c->dtw_work(), td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
                 }
                 c->time_end();
                 if (!ok) return -1;
@@ -1021,10 +1031,10 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
         c->time_begin(kKernelDtw);
         if (gated) {
             uint32_t *lst = b->list.as<uint32_t>();
-            ok = hip_ok(launch_dtw_gated(c->stream, td_one, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, b->cfg.avg_threshold,
+            ok = hip_ok(launch_dtw_gated(c->stream, c->dtw_work(), td_one, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, b->cfg.avg_threshold,
                                          ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
         } else {
-            ok = hip_ok(launch_dtw(c->stream, td_one, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
+            ok = hip_ok(launch_dtw(c->stream, c->dtw_work(), td_one, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
                                    fz.agg ? &fz : nullptr), "dtw kernel");
         }
         c->time_end();
@@ -1140,10 +1150,10 @@ static int stream_batch_score_multi(rp_stream_batch *b, Staged &sg, const float 
             c->time_begin(kKernelDtw);
             if (gated) {
                 uint32_t *lst = b->list.as<uint32_t>();
-                ok = hip_ok(launch_dtw_gated(c->stream, td, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, w.avg_threshold,
+                ok = hip_ok(launch_dtw_gated(c->stream, c->dtw_work(), td, now, S, pitch, fill - hist, n_new, b->cfg.band_size, b->cfg.score_ref, w.avg_threshold,
                                              ds, da, lst + 1, lst, true, abandon), "dtw kernels (gated)");
             } else {
-                ok = hip_ok(launch_dtw(c->stream, td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
+                ok = hip_ok(launch_dtw(c->stream, c->dtw_work(), td, now, S, pitch, fill - hist, n_new, n_new, b->cfg.band_size, b->cfg.score_ref, do_avg ? 1 : 0, ds, da, true, abandon), "dtw kernel");
             }
             c->time_end();
             if (!ok) return -1;

@@ -82,6 +82,9 @@ Ctx *Ctx::create(int device, int flags) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cu = cus;
     if (!hip_ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
     c->stream = c->own_stream;
+    // the DTW launchers' per-call words (DtwWork, rp_kernels.h): zero between launches, so zeroed once here
+    const size_t wbytes = ((size_t)2 * kDtwSchedChunks + 2 + 2 * (size_t)kDtwFixCap + 2) * sizeof(uint32_t);
+    if (!c->ws_dtw.reserve(wbytes) || !hip_ok(hipMemset(c->ws_dtw.p, 0, wbytes), "hipMemset(dtw work)")) return nullptr;
     return c.release();
 }
 
@@ -297,8 +300,9 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         }
     }
     const int Ttot = T + has_avg, Lpad = longest;
-    std::vector<float> unit((size_t)Ttot * Lpad * K, 0.f);
+    std::vector<float> unit((size_t)Ttot * Lpad * K, 0.f), raw((size_t)Ttot * Lpad * K, 0.f);
     std::vector<int> hl(Ttot);
+    bool ref_only = false;
     size_t off = 0;
     for (int t = 0; t < Ttot; ++t) {
         const float *src = t < T ? feats + off : avg;
@@ -312,6 +316,9 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
             for (int k = 0; k < K; ++k) nf += src[(size_t)r * K + k] * src[(size_t)r * K + k];
             double inv = (nf > 0.f && nn > 0.0) ? 1.0 / std::sqrt(nn) : 0.0;
             for (int k = 0; k < K; ++k) unit[((size_t)t * Lpad + r) * K + k] = (float)((double)src[(size_t)r * K + k] * inv);
+            for (int k = 0; k < K; ++k) raw[((size_t)t * Lpad + r) * K + k] = src[(size_t)r * K + k];
+            // outside this range the reference's sqrt(dot_a * dot_b) is not what a unit-length row gives (TemplatesDev::ref_only)
+            if (!(nf == 0.f || (nf >= kDtwNormLo && nf <= kDtwNormHiRow))) ref_only = true;
         }
         if (t < T) off += (size_t)L * K;
     }
@@ -324,6 +331,9 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.unit), sizeof(float) * unit.size()), "hipMalloc(templates)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.lens, hl.data(), sizeof(int) * Ttot, hipMemcpyHostToDevice), "hipMemcpy(lens)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.unit, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice), "hipMemcpy(templates)")) return nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.raw), sizeof(float) * raw.size()), "hipMalloc(templates)")) return nullptr;
+    if (!hip_ok(hipMemcpy(d.raw, raw.data(), sizeof(float) * raw.size(), hipMemcpyHostToDevice), "hipMemcpy(templates)")) return nullptr;
+    d.ref_only = ref_only ? 1 : 0;
 
     // chunks for the register kernels: sample templates grouped by length, up to 8 per chunk, classed by chunk size
     // (TemplatesDev::class_first); the averaged template is its own chunk, last of the single-template class.
@@ -418,9 +428,9 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     if (!aimg.empty()) {
         if (!hip_ok(hipMalloc(&d.aimg, sizeof(uint16_t) * aimg.size()), "hipMalloc(aimg)")) return nullptr;
         if (!hip_ok(hipMemcpy(d.aimg, aimg.data(), sizeof(uint16_t) * aimg.size(), hipMemcpyHostToDevice), "hipMemcpy(aimg)")) return nullptr;
-        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.mfma_sched), sizeof(uint32_t) * 2 * chunks.size()), "hipMalloc(sched)")) return nullptr;
-        if (!hip_ok(hipMemset(d.mfma_sched, 0, sizeof(uint32_t) * 2 * chunks.size()), "hipMemset(sched)")) return nullptr;
     }
+    d.n_chunks_total = (int)chunks.size();
+    if (d.n_chunks_total > kDtwSchedChunks) { set_last_error("wakeword reference with too many template lengths for the device kernels"); return nullptr; }
     return tp.release();
 }
 
@@ -430,7 +440,7 @@ Templates::~Templates() {
     if (dev.chunks) (void)hipFree(dev.chunks);
     if (dev.dup) (void)hipFree(dev.dup);
     if (dev.aimg) (void)hipFree(dev.aimg);
-    if (dev.mfma_sched) (void)hipFree(dev.mfma_sched);
+    if (dev.raw) (void)hipFree(dev.raw);
 }
 
 // f32 -> bf16, round to nearest even (matches the kernel's in-register conversion)

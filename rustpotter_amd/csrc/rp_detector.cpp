@@ -445,13 +445,13 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
                 w.with_avg = w.ref.has_avg && avg_thr != 0.f;
                 const int T = (int)w.ref.lens.size();
                 if (w.with_avg && gate_first_) {
-                    const hipError_t e = launch_dtw_single_part(st, w.tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size,
+                    const hipError_t e = launch_dtw_single_part(st, ctx_->dtw_work(), w.tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size,
                                                                 det_.score_ref, T, 1, res + w.off_scores, res + w.off_avg);
                     if (e == hipSuccess) { gated.push_back(&w); continue; }
                     if (e != hipErrorNotSupported) { hip_ok(e, "dtw kernel"); return -1; }
                     (void)hipGetLastError();
                 }
-                if (!hip_ok(launch_dtw(st, w.tmpl->dev, hist, 1, frames_valid, first_win, cnt, cnt, det_.band_size, det_.score_ref,
+                if (!hip_ok(launch_dtw(st, ctx_->dtw_work(), w.tmpl->dev, hist, 1, frames_valid, first_win, cnt, cnt, det_.band_size, det_.score_ref,
                                        w.with_avg ? 1 : 0, res + w.off_scores, res + w.off_avg), "dtw kernel")) return -1;
                 if (!hip_ok(launch_aggregate(st, res + w.off_scores, cnt, T, (int)det_.score_mode, res + w.off_agg), "aggregate_kernel")) return -1;
             } else {
@@ -482,7 +482,7 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
             if (!any) continue;   // every window of this chunk is `None` for this wakeword
             any_passed = true;
             const int T = (int)w->ref.lens.size();
-            if (!hip_ok(launch_dtw_single_part(st, w->tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size, det_.score_ref, 0, T,
+            if (!hip_ok(launch_dtw_single_part(st, ctx_->dtw_work(), w->tmpl->dev, hist, frames_valid, first_win, cnt, cnt, det_.band_size, det_.score_ref, 0, T,
                                                res + w->off_scores, res + w->off_avg), "dtw kernel")) return -1;
             if (!hip_ok(launch_aggregate(st, res + w->off_scores, cnt, T, (int)det_.score_mode, res + w->off_agg), "aggregate_kernel")) return -1;
             again = true;

@@ -195,4 +195,11 @@ template <> struct SampleIn<int32_t> {
     static __device__ __forceinline__ float4 load4(const int32_t *p) { return cvt4(ldraw(p)); }
 };
 
+// A (window, chunk or template) pair whose frames left the norm range of the scale-invariant cosine (rp_kernels.h, DtwWork):
+// appended to the call's list for dtw_ref_kernel.  spec = chunk index, kFixSpecTemplate | template index.
+__device__ __forceinline__ void dtw_fix_append(uint32_t *fix, size_t row, uint32_t spec) {
+    const uint32_t i = atomicAdd(fix, 1u);
+    if (i < kDtwFixCap) reinterpret_cast<unsigned long long *>(fix + 2)[i] = ((unsigned long long)row << 24) | spec;
+}
+
 }  // namespace rp

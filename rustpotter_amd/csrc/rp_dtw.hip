@@ -36,6 +36,10 @@ struct GateList {
     // +inf: off (the per-window score arrays are part of the call's result).  See dtw_abandon_nc().
     float abandon_nc = __builtin_inff();
     const DtwFusedAgg *fuse = nullptr;  // ScoreMode::Max folded into the matrix-core kernel (rp_kernels.h); set by launch_dtw only
+    // DtwWork::fix: windows with a frame whose squared norm leaves kDtwNormLo..kDtwFixLimit are listed for dtw_ref_kernel (the
+    // reference's sqrt(dot_a * dot_b) is not scale invariant there, comparator.rs:42-47); every launcher sets it
+    uint32_t *fix = nullptr;
+    uint32_t *sched = nullptr;   // DtwWork::sched for the matrix-core launches
 };
 
 // One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
@@ -152,6 +156,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
 #pragma unroll
         for (int k = 0; k < K; ++k) ring[j][k] = (v2f){0.f, 0.f};
 
+    float chk = 0.f;  // max over the frames seen of (squared norm, its reciprocal square root): > kDtwFixLimit -> listed for dtw_ref_kernel
 #define RP_LOAD_COL(c, slot)                                                              \
     do {                                                                                  \
         float y_[K], bb_ = 0.f;                                                           \
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
             bb_ = fmaf(y_[k], y_[k], bb_);                                                \
         }                                                                                 \
         const float inv_ = bb_ > 0.f ? rsqrtf(bb_) : 0.f;                                 \
+        chk = fmaxf(fmaxf(chk, inv_), bb_); /* one v_max3_f32: the norm-range test */     \
         _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
             if (((slot)&1) == 0) ring[(slot) / 2][k].x = y_[k] * inv_;                    \
             else ring[(slot) / 2][k].y = y_[k] * inv_;                                    \
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
                     const size_t row = s * out_win_pitch + (size_t)w;
                     for (int t = 0; t < ch->count; ++t)
                         if (ch->tid[t] < T) scores[row * T + ch->tid[t]] = 0.f;
+                    if (chk > kDtwFixLimit) dtw_fix_append(gl.fix, row, (uint32_t)(chunk_base + (int)ci));
                 }
                 return;
             }
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_kernel(
                 else avg[row] = sc;
             }
         }
+        if (chk > kDtwFixLimit) dtw_fix_append(gl.fix, row, (uint32_t)(chunk_base + (int)ci));
     }
 }
 
@@ -373,6 +381,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
 #pragma unroll
         for (int k = 0; k < K; ++k) ring[j][k] = (v2f){0.f, 0.f};
 
+    v2f chk = (v2f){0.f, 0.f};  // the norm-range test of the two windows (see dtw_band_kernel)
 #define RP_LOAD_COL2(c, slot)                                                                       \
     do {                                                                                            \
         v2f y_[K], bb_ = (v2f){0.f, 0.f};                                                           \
@@ -381,6 +390,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
             bb_ = __builtin_elementwise_fma(y_[k], y_[k], bb_);                                     \
         }                                                                                           \
         const v2f inv_ = (v2f){bb_.x > 0.f ? rsqrtf(bb_.x) : 0.f, bb_.y > 0.f ? rsqrtf(bb_.y) : 0.f}; \
+        chk.x = fmaxf(fmaxf(chk.x, inv_.x), bb_.x); chk.y = fmaxf(fmaxf(chk.y, inv_.y), bb_.y);     \
         _Pragma("unroll") for (int k = 0; k < K; ++k) ring[slot][k] = y_[k] * inv_;                 \
     } while (0)
 
@@ -434,7 +444,10 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
             if (!__any(alive)) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
-                    if (valid[e]) scores[(s[e] * out_win_pitch + (size_t)w[e]) * T + tid] = 0.f;
+                    if (valid[e]) {
+                        scores[(s[e] * out_win_pitch + (size_t)w[e]) * T + tid] = 0.f;
+                        if ((e ? chk.y : chk.x) > kDtwFixLimit) dtw_fix_append(gl.fix, s[e] * out_win_pitch + (size_t)w[e], (uint32_t)(chunk_base + (int)ci));
+                    }
                 return;
             }
         }
@@ -453,6 +466,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band2_kernel(
             const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
             if (tid < T) scores[row * T + tid] = sc;
             else avg[row] = sc;
+            if ((e ? chk.y : chk.x) > kDtwFixLimit) dtw_fix_append(gl.fix, row, (uint32_t)(chunk_base + (int)ci));
         }
     }
 }
@@ -534,6 +548,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
 #pragma unroll
         for (int k = 0; k < K; ++k) ring[j][k] = (v2f){0.f, 0.f};
 
+    float chk = 0.f;  // max over the frames seen of (squared norm, its reciprocal square root): > kDtwFixLimit -> listed for dtw_ref_kernel
 #define RP_LOAD_COL(c, slot)                                                              \
     do {                                                                                  \
         float y_[K], bb_ = 0.f;                                                           \
@@ -542,6 +557,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
             bb_ = fmaf(y_[k], y_[k], bb_);                                                \
         }                                                                                 \
         const float inv_ = bb_ > 0.f ? rsqrtf(bb_) : 0.f;                                 \
+        chk = fmaxf(fmaxf(chk, inv_), bb_); /* one v_max3_f32: the norm-range test */     \
         _Pragma("unroll") for (int k = 0; k < K; ++k) {                                   \
             if (((slot)&1) == 0) ring[(slot) / 2][k].x = y_[k] * inv_;                    \
             else ring[(slot) / 2][k].y = y_[k] * inv_;                                    \
@@ -604,8 +620,10 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
                 alive = alive || (t < ch->count && m <= abandon_cost);
             }
             if (!__any(alive && valid)) {
-                if (valid)
+                if (valid) {
                     for (int t = 0; t < ch->count; ++t) scores[(s * out_win_pitch + wl) * T + ch->tid[t]] = 0.f;
+                    if (chk > kDtwFixLimit) dtw_fix_append(gl.fix, s * out_win_pitch + wl, (uint32_t)(chunk_base + (int)ci));
+                }
                 return;
             }
         }
@@ -628,6 +646,7 @@ __global__ __launch_bounds__(kDtwWin) void dtw_band_wide_kernel(
                 else avg[row] = sc;
             }
         }
+        if (chk > kDtwFixLimit) dtw_fix_append(gl.fix, row, (uint32_t)(chunk_base + (int)ci));
     }
 }
 
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, unsigned tiles, size_t first_win,
     size_t n_win, size_t out_win_pitch, const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K,
     int T, int t_first, int t_count, int max_len, int band, float score_ref, float *__restrict__ scores, float *__restrict__ avg,
-    const float *__restrict__ gate_avg, float gate_threshold) {
+    const float *gate_avg, float gate_threshold, uint32_t *__restrict__ fix) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int KP = K | 1;
     const unsigned tile = blockIdx.x % tiles;
@@ -679,6 +698,7 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
     for (int q = 0; q <= B; ++q) Pb[q * 64 + lane] = RP_INF;
     Pb[W * 64 + lane] = 0.f;
     const float *trow = unit + (size_t)t * Lpad * K;
+    float chk = 0.f;  // the norm-range test (see dtw_band_kernel)
     for (int r = 1; r < m; ++r) {
         float left = RP_INF;
         for (int q = 0; q < B; ++q) {
@@ -693,6 +713,7 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
                     bb = fmaf(y, y, bb);
                 }
                 const float inv = bb > 0.f ? rsqrtf(bb) : 0.f;
+                chk = fmaxf(fmaxf(chk, inv), bb);
                 float d = 1.f;
                 for (int k = 0; k < K; ++k) {
                     const float y = (xl[(c - 1) * KP + k] - mus[k * 64 + lane]) * inv;
@@ -712,7 +733,138 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
         size_t row = s * out_win_pitch + (size_t)tile * 64 + lane;
         if (t < T) scores[row * T + t] = sc;
         else avg[row] = sc;
+        if (chk > kDtwFixLimit) dtw_fix_append(fix, row, kFixSpecTemplate | (uint32_t)t);
     }
+}
+
+// ---- the reference-shaped cell (comparator.rs:28-48) for what the scale-invariant kernels cannot reproduce ------------------
+// dot_ab / sqrt(dot_a * dot_b) in f32 with `== 0 -> 0`: when the PRODUCT of the two squared norms underflows the reference's
+// similarity becomes 0 (distance 1) although neither vector is zero, when it is subnormal the quotient loses bits, when it
+// overflows the similarity is 0 again.  Every fast kernel lists the (window, chunk or template) pairs that met a frame outside
+// kDtwNormLo..kDtwFixLimit (DtwWork::fix); this kernel rescores them cell by cell as the reference does -- three sequential dot
+// products of the template row AS GIVEN and the mean-normalised frame, one sqrt, one divide -- and overwrites their scores.
+// One lane per listed pair (a chunk's templates one after the other); frames and rows come from global memory, band and means
+// sit in LDS lane-minor.  ALL mode (force_all, or more pairs than the list holds): every window x templates t_first ..
+// t_first + t_count - 1 (template sets with a row outside kDtwNormLo..kDtwNormHiRow, TemplatesDev::ref_only).  agg_out: the pair's
+// chunk holds every sample template (DtwFusedAgg) -- ScoreMode::Max and the stream's hot flag are rewritten too.
+// Launched after the fast kernels of every call; without listed pairs each workgroup reads one word and leaves.  The last
+// workgroup to leave puts fix[0] and fix[1] back to zero.
+__global__ __launch_bounds__(64) void dtw_ref_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t first_win, size_t n_win, size_t out_win_pitch,
+    size_t n_streams, const int *__restrict__ lens, const float *__restrict__ raw, int Lpad, int K, int T, int max_len, int band, int Wmax,
+    float score_ref, const DtwChunk *__restrict__ chunks, float *__restrict__ scores, float *__restrict__ avg, uint32_t *fix,
+    int force_all, int t_first, int t_count, float *__restrict__ agg_out, uint32_t *__restrict__ agg_hot, float agg_threshold) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *mus = reinterpret_cast<float *>(smem);  // [K][64]
+    float *Pb = mus + (size_t)K * 64;              // [2 Wmax + 1][64]
+    const int lane = threadIdx.x;
+    const uint32_t n_listed = fix[0];
+    const bool all = force_all || n_listed > kDtwFixCap;
+    const size_t per_row = agg_out ? 1 : (size_t)t_count;
+    const size_t n_entries = all ? n_streams * n_win * per_row : (size_t)n_listed;
+    const unsigned long long *list = reinterpret_cast<const unsigned long long *>(fix + 2);
+    if (blockIdx.x == 0 && lane == 0 && n_entries) atomicAdd(dtw_fix_stats(fix), (unsigned long long)n_entries);  // rp_ctx_dtw_ref_pairs
+    for (size_t e = (size_t)blockIdx.x * 64 + lane; e < n_entries; e += (size_t)gridDim.x * 64) {
+        size_t row;
+        int tb, te, from_chunk = -1;   // templates tb .. te - 1, or the tid[] of chunk from_chunk
+        if (all) {
+            const size_t rw = e / per_row;
+            const size_t s_ = rw / n_win;
+            row = s_ * out_win_pitch + (rw - s_ * n_win);
+            if (agg_out) { tb = t_first; te = t_first + t_count; }
+            else { tb = t_first + (int)(e - rw * per_row); te = tb + 1; }
+        } else {
+            const unsigned long long v = list[e];
+            row = (size_t)(v >> 24);
+            const uint32_t spec = (uint32_t)v & kFixSpecMask;
+            if (spec & kFixSpecTemplate) { tb = (int)(spec & (kFixSpecTemplate - 1)); te = tb + 1; }
+            else { from_chunk = (int)spec; tb = 0; te = chunks[from_chunk].count; }
+        }
+        const size_t s = row / out_win_pitch, w = row - s * out_win_pitch;
+        const size_t f0 = s * frame_pitch + first_win + w;       // the window's first frame
+        const float *xw = mfcc + f0 * K;   // only columns 1..n are read: the window's own frames
+        float best = 0.f;
+        int mean_n = -1;
+        for (int ti = tb; ti < te; ++ti) {
+            const int t = from_chunk >= 0 ? chunks[from_chunk].tid[ti] : ti;
+            const int m = lens[t];
+            const int n = m < max_len ? m : max_len;  // window cut to the template length (wakeword_comp.rs:22-27)
+            const int diff = m > n ? m - n : n - m;
+            const int W = band > diff ? band : diff;  // dtw.rs:64-67
+            const int B = 2 * W;
+            if (n != mean_n) {  // MfccNormalizer::normalize (normalizer.rs:17-29): sequential column sums over the n frames
+                for (int k = 0; k < K; ++k) {
+                    float sum = 0.f;
+                    for (int i = 0; i < n; ++i) sum += xw[(size_t)i * K + k];
+                    mus[k * 64 + lane] = sum / (float)n;
+                }
+                mean_n = n;
+            }
+            for (int q = 0; q <= B; ++q) Pb[q * 64 + lane] = RP_INF;
+            Pb[W * 64 + lane] = 0.f;
+            const float *trow = raw + (size_t)t * Lpad * K;
+            for (int r = 1; r < m; ++r) {   // rows 1..m-1: row m is never read (dtw.rs:101)
+                float left = RP_INF;
+                for (int q = 0; q < B; ++q) {
+                    const int c = r - W + q;
+                    float v = RP_INF;
+                    if (c >= 1 && c <= n) {
+                        float dot_ab = 0.f, dot_a = 0.f, dot_b = 0.f;
+                        for (int k = 0; k < K; ++k) {
+                            const float ca = trow[(r - 1) * K + k];
+                            const float cb = xw[(size_t)(c - 1) * K + k] - mus[k * 64 + lane];
+                            dot_ab += ca * cb;   // -ffp-contract=off: a multiply and an add, as the reference
+                            dot_a += ca * ca;
+                            dot_b += cb * cb;
+                        }
+                        const float magnitude = sqrtf(dot_a * dot_b);
+                        const float sim = magnitude == 0.f ? 0.f : dot_ab / magnitude;
+                        v = (1.f - sim) + fminf(fminf(Pb[(q + 1) * 64 + lane], left), Pb[q * 64 + lane]);
+                    }
+                    Pb[q * 64 + lane] = v;
+                    left = v;
+                }
+            }
+            const int qs = n - (m - 1 - W);  // column n of row m-1
+            const float cost = (qs >= 0 && qs < B) ? Pb[qs * 64 + lane] : RP_INF;
+            const float nc = cost / (float)(m + n);
+            const float sc = 1.f / (1.f + expf((nc - score_ref) / score_ref));
+            if (t < T) { scores[row * T + t] = sc; best = fmaxf(best, sc); }
+            else avg[row] = sc;
+        }
+        if (agg_out) {
+            agg_out[row] = best;
+            if (agg_hot && best > agg_threshold) agg_hot[s] = 1u;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        __threadfence();
+        if (atomicAdd(fix + 1, 1u) == gridDim.x - 1) { fix[0] = 0; fix[1] = 0; }
+    }
+}
+
+// The pass behind every fast launch: rescoring of the listed pairs (see dtw_ref_kernel).  force_all: every window x templates
+// t_first .. t_first + t_count - 1 (index T = the averaged template).
+static hipError_t launch_dtw_ref(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                                 size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, float *scores, float *avg,
+                                 bool force_all, int t_first, int t_count, const DtwFusedAgg *fuse = nullptr) {
+    if (!wk.fix || !t.raw) return hipErrorInvalidValue;
+    const int Wmax = band > t.max_diff ? band : t.max_diff;
+    const size_t lds = ((size_t)t.K * 64 + (size_t)(2 * Wmax + 1) * 64) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorMemoryAllocation;
+    if (lds > 64 * 1024)
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_ref_kernel), 160 * 1024); e != hipSuccess) return e;
+    size_t blocks = 2 * (size_t)device_cu_count();
+    if (force_all) {
+        const size_t need = (S * n_win * (size_t)(fuse ? 1 : t_count) + 63) / 64;
+        blocks = need < 8 * (size_t)device_cu_count() ? (need ? need : 1) : 8 * (size_t)device_cu_count();
+    }
+    const bool fused = fuse && fuse->agg;
+    hipLaunchKernelGGL(dtw_ref_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch, first_win, n_win, out_win_pitch, S,
+                       t.lens, t.raw, t.Lpad, t.K, t.T, t.max_len, band, Wmax, score_ref, t.chunks, scores, avg, wk.fix, force_all ? 1 : 0, t_first,
+                       t_count, fused ? fuse->agg : nullptr, fused ? fuse->hot : nullptr, fused ? fuse->threshold : 0.f);
+    return hipGetLastError();
 }
 
 template <int K, int W, int TC>
@@ -819,8 +971,8 @@ static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int
         if (t.has_avg && n1 == t.class_count[3])
             if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
                                                         few, gl, t.class_first[3] + t.class_count[3] - 1); e != hipSuccess) return e;
-        return launch_dtw_mfma_wide(st, t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, gl.list, gl.count,
-                                    gl.dense_min, gl.abandon_nc);
+        return launch_dtw_mfma_wide(st, DtwWork{gl.sched, gl.fix}, t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg,
+                                    gl.list, gl.count, gl.dense_min, gl.abandon_nc);
     }
     if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, n1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl); e != hipSuccess) return e;
     return launch_dtw_wide<K, W, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);
@@ -848,7 +1000,7 @@ static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int
 __global__ __launch_bounds__(64) void dtw_single_kernel(
     const float *__restrict__ mfcc, size_t n_frames_total, size_t first_win, unsigned n_win, size_t out_win_pitch,
     const int *__restrict__ lens, const float *__restrict__ unit, int Lpad, int K, int T, int t_first, int t_count, int max_len, int W,
-    float score_ref, float *__restrict__ scores, float *__restrict__ avg) {
+    float score_ref, float *__restrict__ scores, float *__restrict__ avg, const float *__restrict__ raw, int force_ref, uint32_t *fix) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const unsigned wi = blockIdx.x / t_count;
@@ -884,11 +1036,26 @@ __global__ __launch_bounds__(64) void dtw_single_kernel(
         mu[k] = sum / (float)L;
     }
     __syncthreads();
+    // the norm-range test of the batch kernels (dtw_band_kernel), healed in place: when a frame of the window leaves
+    // kDtwNormLo..kDtwFixLimit (or the template set has such a row: force_ref) this wave forms its costs as the reference does
+    // (comparator.rs:28-48) from the rows as given and the centred frames -- the one-wave-per-DTW form has no second pass
+    float chk = 0.f;
     for (int f = lane; f < L; f += 64) {
         float bb = 0.f;
         for (int k = 0; k < K; ++k) { const float y = ys[f * KP + k] - mu[k]; bb = fmaf(y, y, bb); }
-        const float inv = bb > 0.f ? rsqrtf(bb) : 0.f;
+        chk = fmaxf(fmaxf(chk, bb > 0.f ? rsqrtf(bb) : 0.f), bb);
+    }
+    const bool ref_cell = force_ref || __any(chk > kDtwFixLimit);
+    if (ref_cell && lane == 0) atomicAdd(dtw_fix_stats(fix), 1ull);
+    for (int f = lane; f < L; f += 64) {
+        float bb = 0.f;
+        for (int k = 0; k < K; ++k) { const float y = ys[f * KP + k] - mu[k]; bb = fmaf(y, y, bb); }
+        const float inv = ref_cell ? 1.f : (bb > 0.f ? rsqrtf(bb) : 0.f);
         for (int k = 0; k < K; ++k) ys[f * KP + k] = (ys[f * KP + k] - mu[k]) * inv;
+    }
+    if (ref_cell) {
+        const float *rrow = raw + (size_t)t * Lpad * K;
+        for (int i = lane; i < L * K; i += 64) { const int f = i / K; ts[f * KP + (i - f * K)] = rrow[i]; }
     }
     __syncthreads();
     // band costs d[r][q] = 1 - a_r . y_c, c = r - W + q, stored by the step they are due at: dm[(2r + q)*B + q];
@@ -898,9 +1065,16 @@ __global__ __launch_bounds__(64) void dtw_single_kernel(
         const int r = 1 + i / B, q = i - (r - 1) * B, c = r - W + q;
         float d = RP_INF;
         if (c >= 1 && c <= L) {
-            d = 1.f;
             const float *a = ts + (r - 1) * KP, *y = ys + (c - 1) * KP;
-            for (int k = 0; k < K; ++k) d = fmaf(-a[k], y[k], d);
+            if (!ref_cell) {
+                d = 1.f;
+                for (int k = 0; k < K; ++k) d = fmaf(-a[k], y[k], d);
+            } else {
+                float dot_ab = 0.f, dot_a = 0.f, dot_b = 0.f;
+                for (int k = 0; k < K; ++k) { dot_ab += a[k] * y[k]; dot_a += a[k] * a[k]; dot_b += y[k] * y[k]; }
+                const float magnitude = sqrtf(dot_a * dot_b);
+                d = 1.f - (magnitude == 0.f ? 0.f : dot_ab / magnitude);
+            }
         }
         dm[(2 * r + q) * B + q] = d;
     }
@@ -956,11 +1130,11 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
     {
         const bool from_global = few || gl.list != nullptr;
         if (t.class_count[1] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 4)) {
-            if ((e = launch_dtw_mfma(st, t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+            if ((e = launch_dtw_mfma(st, DtwWork{gl.sched, gl.fix}, t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                      scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse)) != hipSuccess) return e;
         } else if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
         if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8))
-            return launch_dtw_mfma(st, t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+            return launch_dtw_mfma(st, DtwWork{gl.sched, gl.fix}, t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                    scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse);
     }
     // Small batches: tc-8 waves run two per SIMD; a launch that fills those slots 2.x times leaves the chip mostly idle in
@@ -1010,18 +1184,22 @@ __global__ __launch_bounds__(256) void gate_compact_kernel(const float *__restri
 }
 
 bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows) {
-    return t.has_avg && dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && rows > 0 && rows < 0xffffffffULL &&
+    return t.has_avg && !t.ref_only && dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && rows > 0 && rows < 0xffffffffULL &&
            (size_t)(2 * kDtwWin + 2 * (t.max_len + 8)) * (size_t)(t.K | 1) * sizeof(float) <= 160 * 1024;
 }
 
 template <int W>
-static hipError_t gated_k5(hipStream_t st, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
+static hipError_t gated_k5(hipStream_t st, const DtwWork &wk, int band, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
                            size_t first_win, size_t n_win, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
                            uint32_t *count, bool few, float abandon_nc) {
     const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
-    // pass 1: the averaged template over every window
-    hipError_t e = launch_dtw_single_chunks<5, W>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, first_win, n_win, n_win, score_ref, scores, avg, few);
+    // pass 1: the averaged template over every window (and, before the gate looks at them, the reference-shaped rescoring of the
+    // windows whose frames left the norm range: dtw_ref_kernel)
+    GateList g1;
+    g1.fix = wk.fix; g1.sched = wk.sched;
+    hipError_t e = launch_dtw_single_chunks<5, W>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, first_win, n_win, n_win, score_ref, scores, avg, few, g1);
     if (e != hipSuccess) return e;
+    if ((e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, n_win, band, score_ref, scores, avg, false, t.T, 1)) != hipSuccess) return e;
     // pass 2: list the rows whose avg_score is not below the threshold
     const size_t waves = (rows + 1023) / 1024, blocks = (waves + 3) / 4;
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
@@ -1029,36 +1207,45 @@ static hipError_t gated_k5(hipStream_t st, const TemplatesDev &t, int avg_chunk,
     // pass 3: the sample templates on the listed rows -- or, when (nearly) every row is listed, on all rows through the
     // ordinary staged launch (GateList; with few windows per stream both forms read global memory: list mode only)
     GateList gl;
-    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc;
+    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched;
     gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
     e = launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
-    if (e != hipSuccess || few) return e;
-    gl.list = nullptr;
-    return launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
+    if (e != hipSuccess) return e;
+    if (!few) {
+        gl.list = nullptr;
+        if ((e = launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl)) != hipSuccess) return e;
+    }
+    return launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, n_win, band, score_ref, scores, avg, false, 0, t.T);
 }
 
 template <int K, int W>
-static hipError_t gated_wide(hipStream_t st, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
+static hipError_t gated_wide(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int avg_chunk, const float *mfcc, size_t S, size_t frame_pitch,
                              size_t first_win, size_t n_win, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
                              uint32_t *count, bool few, float abandon_nc) {
     const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
-    hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, few, GateList{}, avg_chunk);
+    GateList g1;
+    g1.fix = wk.fix; g1.sched = wk.sched;
+    hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, few, g1, avg_chunk);
     if (e != hipSuccess) return e;
+    if ((e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, n_win, W, score_ref, scores, avg, false, t.T, 1)) != hipSuccess) return e;
     const size_t waves = (rows + 1023) / 1024, blocks = (waves + 3) / 4;
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     GateList gl;
-    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc;
+    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched;
     gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
     e = launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl, true);
-    if (e != hipSuccess || few) return e;
-    gl.list = nullptr;
-    return launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl, true);
+    if (e != hipSuccess) return e;
+    if (!few) {
+        gl.list = nullptr;
+        if ((e = launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl, true)) != hipSuccess) return e;
+    }
+    return launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, n_win, W, score_ref, scores, avg, false, 0, t.T);
 }
 
 // first_win / few_windows as in launch_dtw (live-stream batches score the few newest windows of every stream: then pass 1
 // also reads its frames from global memory); scores / avg rows have pitch n_win.
-hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+hipError_t launch_dtw_gated(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                             size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
                             uint32_t *count, bool few_windows, float abandon_nc) {
     const size_t rows = S * n_win;
@@ -1073,13 +1260,13 @@ hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *
     if (e != hipSuccess) return e;
     if (t.K == 5) {
         switch (band) {
-        case 3: return gated_k5<3>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
-        case 4: return gated_k5<4>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
-        case 5: return gated_k5<5>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
-        default: return gated_k5<6>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
+        case 3: return gated_k5<3>(st, wk, band, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
+        case 4: return gated_k5<4>(st, wk, band, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
+        case 5: return gated_k5<5>(st, wk, band, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
+        default: return gated_k5<6>(st, wk, band, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc);
         }
     }
-#define RP_WIDE_CALL(KK, WW) gated_wide<KK, WW>(st, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc)
+#define RP_WIDE_CALL(KK, WW) gated_wide<KK, WW>(st, wk, t, avg_chunk, mfcc, S, frame_pitch, first_win, n_win, score_ref, avg_threshold, scores, avg, list, count, few, abandon_nc)
     RP_WIDE_DISPATCH(RP_WIDE_CALL);
 #undef RP_WIDE_CALL
 }
@@ -1093,13 +1280,34 @@ float dtw_abandon_nc(float threshold, float score_ref) {
     return nc > 0.f ? nc * 1.001f + 1e-4f : nc + 1e-4f;
 }
 
-hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                                  size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
+                                  float *scores, float *avg, bool padded_rows, float abandon_nc, DtwFusedAgg *fuse, bool *self_healing);
+
+hipError_t launch_dtw(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                       float *scores, float *avg, bool padded_rows, float abandon_nc, DtwFusedAgg *fuse) {
     if (fuse) fuse->done = false;
     if (S == 0 || n_win == 0) return hipSuccess;
+    if (!wk.fix || !wk.sched) return hipErrorInvalidValue;
+    if (t.n_chunks_total > kDtwSchedChunks) return hipErrorInvalidValue;
+    const int Ttot = t.T + ((with_avg && t.has_avg) ? 1 : 0);
+    bool self_healing = false;
+    if (!t.ref_only || (S == 1 && n_win <= 8)) {   // (a handful of windows of one stream: dtw_single_kernel takes force_ref itself)
+        if (hipError_t e = launch_dtw_fast(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, with_avg, scores, avg,
+                                           padded_rows, abandon_nc, fuse, &self_healing); e != hipSuccess) return e;
+        if (self_healing) return hipSuccess;
+    }
+    // the windows the fast kernels listed (a frame outside the norm range), or -- a template set with such a row -- every window
+    return launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, t.ref_only != 0, 0, Ttot,
+                          (fuse && fuse->done) ? fuse : nullptr);
+}
+
+static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                                  size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
+                                  float *scores, float *avg, bool padded_rows, float abandon_nc, DtwFusedAgg *fuse, bool *self_healing) {
     GateList gl;
-    gl.abandon_nc = abandon_nc;
+    gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched;
     // many streams with few windows each (streaming batches): cross-stream waves reading frames from global memory;
     // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
     // (one stream alone is a batch too when the matrix-core kernel serves its templates: a stream's bits must not depend on the
@@ -1117,10 +1325,12 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
         if (lds <= 64 * 1024) {
             hipLaunchKernelGGL(dtw_single_kernel, dim3((unsigned)(n_win * Ttot)), dim3(64), lds, st, mfcc, frame_pitch, first_win,
                                (unsigned)n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, Ttot, t.max_len, band, score_ref,
-                               scores, avg);
+                               scores, avg, t.raw, t.ref_only, wk.fix);
+            *self_healing = true;
             return hipGetLastError();
         }
     }
+    if (t.ref_only) return hipSuccess;  // launch_dtw scores every window with dtw_ref_kernel
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
     // the register kernels assume m == n (no template longer than the window)
     // (a register kernel stages 64..128 windows + two template lengths of frames in LDS: templates beyond ~4 000 frames at
@@ -1157,7 +1367,7 @@ hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, 
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_generic_kernel), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
                        (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, Ttot,
-                       t.max_len, band, score_ref, scores, avg, static_cast<const float *>(nullptr), 0.f);
+                       t.max_len, band, score_ref, scores, avg, static_cast<const float *>(nullptr), 0.f, wk.fix);
     return hipGetLastError();
 }
 
@@ -1168,6 +1378,7 @@ bool dtw_uses_generic(const TemplatesDev &t, int band, size_t S, size_t n_win) {
         const size_t lds1 = (2 * (size_t)t.max_len * (t.K | 1) + ((t.K + 3) & ~3) + (size_t)(2 * t.max_len + 2 * band + 16) * 2 * band) * sizeof(float);
         if (lds1 <= 64 * 1024) return false;
     }
+    if (t.ref_only) return true;   // dtw_ref_kernel: launch_dtw_generic_gated is the gated form
     const size_t reg_lds = (size_t)(2 * kDtwWin + 2 * (t.max_len + 8)) * (size_t)(t.K | 1) * sizeof(float);
     return !(dtw_register_tile(t.K, band) > 0 && t.max_diff == 0 && t.chunks && reg_lds <= 160 * 1024);
 }
@@ -1175,11 +1386,15 @@ bool dtw_uses_generic(const TemplatesDev &t, int band, size_t S, size_t n_win) {
 // The averaged-template gate behind the generic kernel: pass 1 scores every window against the averaged template (-> avg),
 // pass 2 the sample templates, each wave leaving at once when none of its 64 windows passed (scores of such rows are not
 // written; the aggregate pass gives them 0).
-hipError_t launch_dtw_generic_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+hipError_t launch_dtw_generic_gated(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                     size_t n_win, size_t out_win_pitch, int band, float score_ref, float avg_threshold, float *scores,
                                     float *avg) {
     if (S == 0 || n_win == 0) return hipSuccess;
     if (!t.has_avg || !avg) return hipErrorInvalidValue;
+    if (t.ref_only) {  // a template row outside the norm range: every window reference-shaped, no skipping (the aggregate pass writes 0 for rejected rows)
+        if (hipError_t e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, true, t.T, 1); e != hipSuccess) return e;
+        return launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, true, 0, t.T);
+    }
     const size_t tiles = (n_win + kDtwWin - 1) / kDtwWin;
     if (tiles * (size_t)t.T * S > 0x7fffffffULL) return hipErrorInvalidValue;
     const int KP = t.K | 1;
@@ -1189,18 +1404,21 @@ hipError_t launch_dtw_generic_gated(hipStream_t st, const TemplatesDev &t, const
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_generic_kernel), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)(tiles * S)), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch, (unsigned)tiles,
                        first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, t.T, 1, t.max_len, band, score_ref, scores, avg,
-                       static_cast<const float *>(nullptr), 0.f);
+                       static_cast<const float *>(nullptr), 0.f, wk.fix);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    // the gate must see reference-shaped avg scores: rescoring of the listed windows first
+    if (hipError_t e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, false, t.T, 1); e != hipSuccess) return e;
     hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)(tiles * (size_t)t.T * S)), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
                        (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, t.T, t.max_len, band, score_ref,
-                       scores, avg, static_cast<const float *>(avg), avg_threshold);
-    return hipGetLastError();
+                       scores, avg, static_cast<const float *>(avg), avg_threshold, wk.fix);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    return launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, false, 0, t.T);
 }
 
 // A handful of windows of ONE stream (the single-stream API), templates t_first .. t_first + t_count - 1 only (index T = the
 // averaged template): the caller scores the averaged template first and the sample templates only when a window passed
 // the gate.  hipErrorNotSupported when dtw_single_kernel does not take this set (the caller then scores everything).
-hipError_t launch_dtw_single_part(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t frame_pitch, size_t first_win, size_t n_win,
+hipError_t launch_dtw_single_part(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t frame_pitch, size_t first_win, size_t n_win,
                                   size_t out_win_pitch, int band, float score_ref, int t_first, int t_count, float *scores, float *avg) {
     if (n_win == 0 || t_count <= 0) return hipSuccess;
     if (!(n_win <= 8 && t.max_diff == 0 && band >= 1 && 2 * band <= 16) || t_first + t_count > t.T + (t.has_avg ? 1 : 0)) return hipErrorNotSupported;
@@ -1208,7 +1426,7 @@ hipError_t launch_dtw_single_part(hipStream_t st, const TemplatesDev &t, const f
     const size_t lds = (2 * (size_t)t.max_len * KP + ((t.K + 3) & ~3) + (size_t)(2 * t.max_len + 2 * band + 16) * 2 * band) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorNotSupported;
     hipLaunchKernelGGL(dtw_single_kernel, dim3((unsigned)(n_win * t_count)), dim3(64), lds, st, mfcc, frame_pitch, first_win, (unsigned)n_win,
-                       out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, t_first, t_count, t.max_len, band, score_ref, scores, avg);
+                       out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, t_first, t_count, t.max_len, band, score_ref, scores, avg, t.raw, t.ref_only, wk.fix);
     return hipGetLastError();
 }
 

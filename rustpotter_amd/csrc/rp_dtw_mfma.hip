@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,
     const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds,
-    float *__restrict__ agg_out, uint32_t *__restrict__ agg_hot, float agg_threshold) {
+    float *__restrict__ agg_out, uint32_t *__restrict__ agg_hot, float agg_threshold, uint32_t *__restrict__ fix) {
     constexpr int K = kMK, B = 2 * W, NS = mfma_slots(NT), NTILE = mfma_tiles(NT), SPT = 32 / NT, NP = NT / 4;
     constexpr int kRowBytes = kDtwMfmaRowBytes;
 #ifndef RP_MFMA_GX_PD  // A/B builds: 1 = the one-column look-ahead of the staged form
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #define RP_X0F(x, packed, hi) ((hi) ? hi_f32(packed) : lo_f32(packed))
 #endif
 #define RP_P7(cc, par) bop[par].y = pkrtz(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1));
-#define RP_P8(cc)
+#define RP_P8(cc) chk_ = fmaxf(fmaxf(chk_, inv_), bb_);  /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */
 #define RP_P9(cc, par) bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pkrtz(u2_, u2_ - RP_X0F(u2_, pkrtz(u2_, 0.f), 0)), sel_one);
 #define RP_PREP_ALL(cc, par) RP_P0(cc, (cc) % PD) RP_P1(cc, (cc) % PD) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 12)
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             if (mfma_last_use<W, NT>(u, g) < 0) RP_MFMA(g, u & 1);                                                            \
     } while (0)
 
-        float fa_[PD], fb_[PD], f2_[PD], da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_;
+        float fa_[PD], fb_[PD], f2_[PD], da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_, chk_ = 0.f;
         RP_AREF(1, 0, true)
         RP_PREP_ALL(1, 1)
         RP_MFMA(0, 1); RP_MFMA(1, 1);
@@ -387,6 +387,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
                     }
                 }
             }
+            // a frame outside the norm range (both lane halves saw the same squared norms): listed for dtw_ref_kernel
+            if (h == 0 && chk_ > kDtwFixLimit) dtw_fix_append(fix, row, (uint32_t)(chunk_base + (int)ci));
         }
         if (agg_out) {  // the chunk holds every sample template (launch_dtw): the two lanes of a window hold all its scores
             const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
@@ -420,7 +422,7 @@ bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from
     return dtw_mfma_lds_bytes(t.max_len, slots == 8 ? 8 : 12) <= 160 * 1024;
 }
 
-hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
+hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
                            bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,
                            const DtwFusedAgg *fuse) {
@@ -434,7 +436,7 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int 
     const int nw = dtw_mfma_lds_bytes(t.max_len, 12) <= 160 * 1024 ? 12 : 8;
     const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw);
     // one workgroup per CU and chunk group; the waves take tiles from the chunk's counter
-    if (!t.mfma_sched) return hipErrorInvalidValue;
+    if (!wk.sched || !wk.fix) return hipErrorInvalidValue;
     size_t groups = (size_t)device_cu_count() / (size_t)n_chunks;
     if (groups < 1) groups = 1;
     const size_t need = (total_tiles + nw - 1) / nw;
@@ -448,7 +450,7 @@ hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int 
         hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV, NT>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
                            total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
                            reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
-                           abandon_nc, t.mfma_sched, static_rounds, agg_out, agg_hot, agg_threshold);                                            \
+                           abandon_nc, wk.sched, static_rounds, agg_out, agg_hot, agg_threshold, wk.fix);                                            \
     } while (0)
 #define RP_LAUNCH_MFMA_W(WW, NT)                                                                                                    \
     do {                                                                                                                            \

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t total_tiles, unsigned n_chunks, int chunk_base, size_t first_win,
     size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T, float score_ref,
     float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, const uint32_t *__restrict__ list,
-    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds) {
+    const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds, uint32_t *__restrict__ fix) {
     constexpr int B = 2 * W, NS = kWSlots, NTILE = kWTiles;
     constexpr int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, ODD = CHM % 2, KS = dtw_mfma_wide_ksteps(K);
     constexpr int kRowBytes = KS * 256;
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
         }
         v16f acc[NTILE];
         u32x4 bop[2][KS];
+        float chk = 0.f;
 
 // the frame in fl[] (column cc) -> B operand bop[par]: centre, scale to unit length (the two halves' squared norms meet through
 // v_permlane32_swap; zero frame -> zero vector -> cost 1, comparator.rs:43-47), split in two f16 parts, pack
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
         const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(own_), __float_as_uint(own_), false, false);        \
         const float bb_ = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);                                                  \
         const float inv_ = bb_ > 0.f ? __builtin_amdgcn_rsqf(bb_) : 0.f;                                                      \
+        chk = fmaxf(fmaxf(chk, inv_), bb_); /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */            \
         unsigned v_[4 * KS];                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 4 * KS; ++i) v_[i] = 0u;                                                        \
         _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) {                                                                   \
@@ -298,6 +300,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
                     }
                 }
             }
+            // a frame outside the norm range (both lane halves saw the same squared norms): listed for dtw_ref_kernel
+            if (h == 0 && chk > kDtwFixLimit) dtw_fix_append(fix, row, (uint32_t)(chunk_base + (int)ci));
         }
     }
     __syncthreads();
@@ -317,12 +321,12 @@ bool dtw_mfma_wide_supported(const TemplatesDev &t, int band) {
     return (size_t)(t.max_len + 16) * dtw_mfma_wide_ksteps(t.K) * 256 <= 160 * 1024;
 }
 
-hipError_t launch_dtw_mfma_wide(hipStream_t st, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                 size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, const uint32_t *list,
                                 const uint32_t *count, uint32_t dense_min, float abandon_nc) {
     const int n_chunks = t.wide8_count;
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
-    if (band != 5 || !t.mfma_sched) return hipErrorNotSupported;
+    if (band != 5 || !wk.sched || !wk.fix) return hipErrorNotSupported;
     const size_t total_tiles = (S * n_win + kWWin - 1) / kWWin;
     constexpr int NW = 8;
     const size_t lds = (size_t)(t.max_len + 16) * dtw_mfma_wide_ksteps(t.K) * 256;
@@ -338,7 +342,7 @@ hipError_t launch_dtw_mfma_wide(hipStream_t st, const TemplatesDev &t, int band,
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_wide_kernel<KK, 5, NW>), 160 * 1024); e != hipSuccess) return e; \
         hipLaunchKernelGGL((dtw_mfma_wide_kernel<KK, 5, NW>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, total_tiles, \
                            (unsigned)n_chunks, t.wide8_first, first_win, n_win, out_win_pitch, t.chunks, reinterpret_cast<const uint4 *>(t.aimg), \
-                           t.T, score_ref, scores, avg, S, list, count, dense_min, abandon_nc, t.mfma_sched, static_rounds);         \
+                           t.T, score_ref, scores, avg, S, list, count, dense_min, abandon_nc, wk.sched, static_rounds, wk.fix);         \
     } while (0)
     if (t.K == 16) RP_LAUNCH_WIDE(16);
     else RP_LAUNCH_WIDE(13);

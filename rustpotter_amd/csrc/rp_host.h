@@ -112,6 +112,8 @@ struct Ctx {
     DevBuf stage_in, stage_out, stage_out2, stage_out3;
     // intermediates of rp_batch_detect
     DevBuf ws_mfcc, ws_scores, ws_agg, ws_avg, ws_vad, ws_ring, ws_rms, ws_gain, ws_list, ws_hot;
+    DevBuf ws_dtw;  // [2 * kDtwSchedChunks | 2 + 2 * kDtwFixCap] uint32: tile counters and fix list of the DTW launchers, zero between calls
+    DtwWork dtw_work() const { return DtwWork{ws_dtw.as<uint32_t>(), ws_dtw.as<uint32_t>() + 2 * kDtwSchedChunks}; }
 
     static Ctx *create(int device, int flags);
     ~Ctx();

@@ -122,8 +122,35 @@ struct TemplatesDev {
     // mfcc_size 13 / 16: the sample templates once more as chunks of up to 8 same-length templates for dtw_mfma_wide_kernel (only when
     // every length occurs at least three times: the matrix kernel always pays for eight template slots)
     int wide8_first = 0, wide8_count = 0;
-    uint32_t *mfma_sched = nullptr;  // per chunk {next tile, workgroups done}: dtw_mfma_kernel's tile counter, zero between launches
+    int n_chunks_total = 0;   // entries of `chunks` (the matrix-core kernels' tile counters live in the CALL's workspace, DtwWork::sched)
+    // The reference forms the cosine as dot_ab / sqrt(dot_a * dot_b) in f32 (comparator.rs:28-48): the PRODUCT of the squared norms
+    // can underflow (-> "magnitude == 0" -> similarity 0) or overflow where neither factor does.  The kernels above are scale
+    // invariant (unit-length rows and frames), so they only agree with it while both squared norms stay in a range where the product
+    // is a normal f32: kDtwNormLo..kDtwNormHiRow for template rows (checked here, on upload), ..kDtwNormHiFrame for window frames
+    // (checked by every kernel, per frame).  `raw` = the rows as given, for the reference-shaped cell of dtw_ref_kernel; ref_only:
+    // some row is outside the range -- every window of this set is scored by dtw_ref_kernel.
+    float *raw = nullptr;     // [T+has_avg][Lpad][K]
+    int ref_only = 0;
 };
+// squared-norm range in which the scale-invariant cell equals the reference's: 2^-60 <= |row|^2 <= 2^60, 2^-60 <= |frame|^2 <= 2^30
+// (products stay within 2^-120 .. 2^90; a frame is tested with ONE v_max3_f32 of its squared norm and its reciprocal square root
+// against 2^30).  Zero rows / frames are exact in both forms (similarity 0).
+constexpr float kDtwNormLo = 8.673617379884035e-19f, kDtwNormHiRow = 1.152921504606847e18f, kDtwFixLimit = 1073741824.f;
+
+// Per-CALL device workspace of the DTW launchers (owned by the context, Ctx::dtw_work): the tile counters of the matrix-core kernels
+// ({next tile, workgroups done} per chunk, zero between launches: the last workgroup of a launch puts them back) and the list of
+// (window, chunk) pairs whose frames left the range above (fix[0] = entries appended, fix[1] = workgroups of dtw_ref_kernel done,
+// entries from fix[2] on as 64-bit words row << 24 | spec).  Calls on one context are serialised (one stream), so the words are
+// never shared by two launches.
+constexpr int kDtwSchedChunks = 2048;       // chunks of one template set the counters cover
+constexpr uint32_t kDtwFixCap = 1u << 18;   // listed (window, chunk) pairs; beyond: every window of the call is rescored
+constexpr uint32_t kFixSpecTemplate = 1u << 22, kFixSpecAll = 1u << 23, kFixSpecMask = (1u << 24) - 1;
+struct DtwWork {
+    uint32_t *sched = nullptr;   // [2 * kDtwSchedChunks]
+    uint32_t *fix = nullptr;     // [2 + 2 * kDtwFixCap + 2]: the last two words count the pairs rescored since the context was made
+};
+__host__ __device__ inline unsigned long long *dtw_fix_stats(uint32_t *fix) { return reinterpret_cast<unsigned long long *>(fix + 2 + 2 * (size_t)kDtwFixCap); }
+// (dtw_fix_append, the kernels' side of the list: rp_device.h)
 
 // The matrix-core DTW kernel (rp_dtw_mfma.hip) for the chunks of class 2 (5..8 templates; slots = 8, band 3..5) and class 1 (3..4
 // templates; slots = 4, band 5) at mfcc_size 5.  from_global: lanes read their frames from global memory (live-stream batches, LIST mode
@@ -132,7 +159,7 @@ struct TemplatesDev {
 bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots = 8);
 // mfcc_size 13 / 16 at band 5: frames always from global memory (the caller's rows end with slack: launch_dtw's padded_rows)
 bool dtw_mfma_wide_supported(const TemplatesDev &t, int band);
-hipError_t launch_dtw_mfma_wide(hipStream_t st, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                 size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, const uint32_t *list,
                                 const uint32_t *count, uint32_t dense_min, float abandon_nc);
 // ScoreMode::Max folded into the matrix-core DTW kernel when ONE chunk holds every sample template of the reference and no averaged
@@ -145,7 +172,7 @@ struct DtwFusedAgg {
     float threshold = 0.f;
     bool done = false;
 };
-hipError_t launch_dtw_mfma(hipStream_t st, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
+hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
                            bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,
                            const DtwFusedAgg *fuse = nullptr);
@@ -209,17 +236,17 @@ hipError_t launch_mfcc_fmt(hipStream_t st, const MfccTablesDev &tb, const void *
 // whose windows x templates all cost more than any score above `threshold` allows; those rows get score 0 (GateList in
 // rp_dtw.hip).  Every window that can fire keeps exact scores, so the detections do not change.
 float dtw_abandon_nc(float threshold, float score_ref);
-hipError_t launch_dtw(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+hipError_t launch_dtw(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                       float *scores, float *avg, bool padded_rows = false, float abandon_nc = __builtin_inff(), DtwFusedAgg *fuse = nullptr);
 
 // the same gate for template sets only dtw_generic_kernel serves (dtw_uses_generic), at wave granularity, and for the
 // single-stream API (one launch for the averaged template, one for the sample templates when a window passed)
 bool dtw_uses_generic(const TemplatesDev &t, int band, size_t S, size_t n_win);
-hipError_t launch_dtw_generic_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+hipError_t launch_dtw_generic_gated(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                     size_t n_win, size_t out_win_pitch, int band, float score_ref, float avg_threshold, float *scores,
                                     float *avg);
-hipError_t launch_dtw_single_part(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t frame_pitch, size_t first_win, size_t n_win,
+hipError_t launch_dtw_single_part(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t frame_pitch, size_t first_win, size_t n_win,
                                   size_t out_win_pitch, int band, float score_ref, int t_first, int t_count, float *scores, float *avg);
 
 // The averaged-template gate as a skip (wakeword_comp.rs:85-93): every window against the averaged template (-> avg),
@@ -227,7 +254,7 @@ hipError_t launch_dtw_single_part(hipStream_t st, const TemplatesDev &t, const f
 // listed rows only (-> scores [S][n_win][T]; other rows are not written).  mfcc needs 64*K floats of slack behind the last stream.
 // hipErrorNotSupported when the template set has no register kernel for this (see dtw_gate_supported).
 bool dtw_gate_supported(const TemplatesDev &t, int band, size_t rows);
-hipError_t launch_dtw_gated(hipStream_t st, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+hipError_t launch_dtw_gated(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                             size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
                             uint32_t *count, bool few_windows = false, float abandon_nc = __builtin_inff());
 

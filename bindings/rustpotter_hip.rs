@@ -55,6 +55,7 @@ pub const RP_CTX_HOST_POINTERS: c_int = 1;
 pub const RP_CTX_FULL_SCORES: c_int = 2;
 pub const RP_MLP_F32: c_int = 0;
 pub const RP_MLP_BF16: c_int = 1;
+pub const RP_MLP_F32_STRICT: c_int = 2;
 
 #[repr(C)] #[derive(Clone, Copy)] pub struct rp_audio_fmt { pub sample_rate: usize, pub sample_format: c_int, pub channels: u16, pub endianness: c_int }
 #[repr(C)] #[derive(Clone, Copy)] pub struct rp_detector_config { pub avg_threshold: f32, pub threshold: f32, pub min_scores: usize, pub eager: bool, pub score_ref: f32, pub band_size: u16, pub score_mode: c_int, pub vad_mode: c_int }
@@ -103,6 +104,7 @@ extern "C" {
     pub fn rp_ctx_set_stream(ctx: *mut rp_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn rp_ctx_synchronize(ctx: *mut rp_ctx) -> c_int;
     pub fn rp_ctx_dtw_ref_pairs(ctx: *mut rp_ctx, pairs: *mut u64) -> c_int;
+    pub fn rp_ctx_last_mlp_kernel(ctx: *mut rp_ctx) -> *const c_char;
     pub fn rp_mfcc_num_frames(n_samples: usize) -> usize;
     pub fn rp_mfcc_batch(ctx: *mut rp_ctx, pcm: *const f32, S: usize, n_samples: usize, pcm_stride: usize, K: c_int, mfcc: *mut f32) -> c_int;
     pub fn rp_mfcc_batch_fmt(ctx: *mut rp_ctx, pcm: *const c_void, fmt: c_int, S: usize, n_samples: usize, pcm_stride: usize, K: c_int,
@@ -356,6 +358,11 @@ impl HipContext {
     /// run the launches on a caller-owned hipStream_t (NULL = the context's own)
     pub fn set_stream(&self, hip_stream: *mut c_void) -> Result<(), String> { status(unsafe { rp_ctx_set_stream(self.h, hip_stream) }) }
     pub fn synchronize(&self) -> Result<(), String> { status(unsafe { rp_ctx_synchronize(self.h) }) }
+    /// kernel(s) and operand format of the last dense-row wakeword-model forward
+    pub fn last_mlp_kernel(&self) -> String {
+        let p = unsafe { rp_ctx_last_mlp_kernel(self.h) };
+        if p.is_null() { String::new() } else { unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned() }
+    }
     /// (window, templates) pairs rescored with the reference-shaped cosine (`sqrt(dot_a * dot_b)`, src/mfcc/comparator.rs:28-48) so far
     pub fn dtw_ref_pairs(&self) -> Result<u64, String> {
         let mut v: u64 = 0;

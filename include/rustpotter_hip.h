@@ -191,6 +191,10 @@ int rp_ctx_synchronize(rp_ctx *ctx);
  * of pairs rescored that way by this context's DTW calls since it was made (waits for the context's stream); 0 for audio
  * in any ordinary range. */
 int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs);
+/* Diagnostics of the wakeword-model forward (replaces nothing; src/wakewords/nn/wakeword_nn.rs:101-106 is what it computes): the
+ * kernel(s) the last rp_mlp_forward_batch of this context ran and their operand format, e.g. "mlp_stream_kernel<f16x2 splits> +
+ * mlp_mfma_kernel<f32> on listed rows".  The string belongs to the context and is valid until its next forward; "" before the first. */
+const char *rp_ctx_last_mlp_kernel(rp_ctx *ctx);
 
 /* Number of MFCC frames MfccExtractor::compute yields for a stream of n_samples fed
  * in 480-sample chunks from a fresh extractor: 3*floor(n/480) - 3
@@ -429,14 +433,17 @@ int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const 
                  rp_model **out);
 void rp_model_free(rp_model *m);
 
-enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1 };
+enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1, RP_MLP_F32_STRICT = 2 };
 /* WakewordNN forward (ModelImpl::forward: Linear -> ReLU -> ... -> Linear, raw logits),
  * src/wakewords/nn/wakeword_nn.rs:101-106,305-389: x [B][dims[0]] (the flattened, mean-normalised
  * window, :139-149,268-273) -> logits [B][dims[n_layers]].  Layer 1 runs on the matrix cores:
  * RP_MLP_F32 = f32-grade layer 1 (dense rows of models up to 32 hidden units: inputs and weights as f16 two-way splits, 22
  * significant bits each, f32 accumulate -- logits at the distance two f32 summation orders have from the f32 matrix instructions,
- * which serve every other shape and, with RP_MLP_STREAM=0, these too; a feature of magnitude above 65 504 gives its row NaN logits
- * there), RP_MLP_BF16 = inputs rounded to bf16, f32 accumulate. */
+ * which serve every other shape; a row that holds a feature beyond the f16 range, |x| > 65 504, is computed by the f32 matrix
+ * instructions in a second short pass: finite input never gives NaN logits), RP_MLP_F32_STRICT = the f32 matrix instructions for every
+ * row (each output a k-ordered fmaf chain, as candle's f32 Linear up to summation order), RP_MLP_BF16 = inputs rounded to bf16, f32
+ * accumulate. */
+
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits);
 
 /* rp_batch_detect for a wakeword MODEL (WakewordNN::run_detection, src/wakewords/nn/wakeword_nn.rs:39-159, inside the
@@ -444,7 +451,7 @@ int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, siz
  * -> per window the arg-max label (the last maximum; `none_index` = index of the "none" label, -1 without one),
  * score = 1 - 1/(1 + exp(((label - none) - 10 score_ref) / (10 score_ref))), avg_score likewise against the smallest
  * other logit when config->avg_threshold != 0, kept when score >= threshold && avg_score >= avg_threshold -> state
- * machine.  precision: RP_MLP_F32 / RP_MLP_BF16.  det_label [S][max_det] (NULL to skip): label index of a detection. */
+ * machine.  precision: RP_MLP_F32 / RP_MLP_F32_STRICT / RP_MLP_BF16.  det_label [S][max_det] (NULL to skip): label index of a detection. */
 int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                           const rp_model *model, int mfcc_size, int none_index, const rp_detector_config *config, int precision,
                           rp_batch_detection *det, int32_t *det_label, int32_t *n_det, int max_det);

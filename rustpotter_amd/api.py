@@ -102,7 +102,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_last_mlp_kernel", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
@@ -167,6 +167,8 @@ def load_library():
     L.rp_ctx_set_stream.argtypes = [vp, vp]
     L.rp_ctx_synchronize.argtypes = [vp]
     L.rp_ctx_dtw_ref_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rp_ctx_last_mlp_kernel.argtypes = [vp]
+    L.rp_ctx_last_mlp_kernel.restype = C.c_char_p
     L.rp_mfcc_num_frames.argtypes = [C.c_size_t]
     L.rp_mfcc_num_frames.restype = C.c_size_t
     L.rp_mfcc_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
@@ -617,6 +619,9 @@ def batch_detect_sharded_dev(ctxs, templates, pcm_ptrs, S_list, N, stride, detec
         raise _err()
 
 
+MLP_PRECISION = {"f32": 0, "bf16": 1, "f32_strict": 2}   # RP_MLP_F32 / RP_MLP_BF16 / RP_MLP_F32_STRICT
+
+
 class BatchContext:
     """rp_ctx.  host_pointers=True: numpy in / numpy out (tests); False: raw device
     pointers (bench.py passes torch tensors' data_ptr())."""
@@ -642,6 +647,12 @@ class BatchContext:
     def synchronize(self):
         if self._L.rp_ctx_synchronize(self._h) < 0:
             raise _err()
+
+    def last_mlp_kernel(self):
+        """Which kernel(s) the last dense-row wakeword-model forward of this context ran (rp_ctx_last_mlp_kernel)."""
+        self._L.rp_ctx_last_mlp_kernel.restype = C.c_char_p
+        v = self._L.rp_ctx_last_mlp_kernel(self._h)
+        return v.decode() if v else ""
 
     def dtw_ref_pairs(self):
         """(window, templates) pairs this context's DTW calls rescored with the reference-shaped cosine so far (rp_ctx_dtw_ref_pairs)."""
@@ -865,7 +876,7 @@ class BatchContext:
         n_det = np.zeros(S, np.int32)
         c = detector_config._c()
         if self._L.rp_batch_detect_model(self._h, pcm.ctypes.data, fmt, S, N, N, model._h, mfcc_size, none_index, C.byref(c),
-                                         {"f32": 0, "bf16": 1}[precision], det.ctypes.data, dlab.ctypes.data, n_det.ctypes.data, max_det) < 0:
+                                         MLP_PRECISION[precision], det.ctypes.data, dlab.ctypes.data, n_det.ctypes.data, max_det) < 0:
             raise _err()
         return det, dlab, n_det
 
@@ -881,13 +892,13 @@ class BatchContext:
         assert self.host
         x = np.ascontiguousarray(x, np.float32)
         out = np.empty((x.shape[0], model.n_out), np.float32)
-        if self._L.rp_mlp_forward_batch(self._h, model._h, x.ctypes.data, x.shape[0], {"f32": 0, "bf16": 1}[precision],
+        if self._L.rp_mlp_forward_batch(self._h, model._h, x.ctypes.data, x.shape[0], MLP_PRECISION[precision],
                                         out.ctypes.data) < 0:
             raise _err()
         return out
 
     def mlp_dev(self, model, x_ptr, B, precision, out_ptr):
-        if self._L.rp_mlp_forward_batch(self._h, model._h, x_ptr, B, {"f32": 0, "bf16": 1}[precision], out_ptr) < 0:
+        if self._L.rp_mlp_forward_batch(self._h, model._h, x_ptr, B, MLP_PRECISION[precision], out_ptr) < 0:
             raise _err()
 
     def synth_pcm(self, seed, first_stream, S, N):

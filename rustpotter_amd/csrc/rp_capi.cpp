@@ -213,6 +213,8 @@ int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs) {
     return 0;
 }
 
+const char *rp_ctx_last_mlp_kernel(rp_ctx *ctx) { return ctx ? ctx->impl->last_mlp_kernel.c_str() : ""; }
+
 size_t rp_mfcc_num_frames(size_t n_samples) {
     size_t chunks = n_samples / 480;
     return chunks >= 1 ? 3 * chunks - 3 : 0;
@@ -1112,7 +1114,7 @@ int rp_stream_batch_new_multi(rp_ctx *ctx, size_t n_wakewords, const rp_wakeword
                 const int nl = (int)e->m->dims.size() - 1;
                 if (e->m->dims[0] % mfcc_size != 0) { set_last_error("Usage of wakewords with different mfcc size is not supported, ignoring wakeword"); return -1; }
                 if (w.none_index >= e->m->dims[nl]) { set_last_error("none_index out of range"); return -1; }
-                if (w.precision != RP_MLP_F32 && w.precision != RP_MLP_BF16) { set_last_error("unknown MLP precision"); return -1; }
+                if (w.precision != RP_MLP_F32 && w.precision != RP_MLP_BF16 && w.precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
                 if (!e->m->mfma_ok && w.precision == RP_MLP_BF16) { set_last_error("this layer-1 shape has no bf16 MFMA kernel"); return -1; }
                 e->none_index = w.none_index; e->precision = w.precision;
                 b->max_len = std::max(b->max_len, e->m->dims[0] / mfcc_size);
@@ -1176,7 +1178,9 @@ static int stream_batch_score_multi(rp_stream_batch *b, Staged &sg, const float 
                 float *dmean = b->mean.as<float>();
                 if (!hip_ok(launch_window_means(c->stream, first, S, pitch, n_new, L, K, dmean), "window_means_kernel")) return -1;
                 c->time_begin(kKernelMlp);
-                ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, first, S, pitch, n_new, K, dmean, wsum, dlog, pitch), "mlp_mfma_kernel");
+                uint32_t *redo = c->mlp_redo(rows);
+                if (!redo) return -1;
+                ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, first, S, pitch, n_new, K, dmean, wsum, dlog, redo, pitch, w.precision == RP_MLP_F32_STRICT), "mlp_mfma_kernel");
                 c->time_end();
                 if (!ok) return -1;
             } else {
@@ -1247,10 +1251,21 @@ static hipError_t mlp_rows_mfma(Ctx *c, const Model &m, const float *dx, size_t 
     // f32 callers: the streaming kernel with f16 two-way splits of inputs and weights (kMlpF16x2: 22 significant bits per operand, f32
     // accumulate -- logits within 1e-6 of the f32 matrix instructions') runs at the HBM stream's rate like the bf16 form, where the f32
     // matrix rate bound both exact kernels (0.19 ms at C5)
+    uint32_t *redo = c->mlp_redo(B);
+    if (!redo) return hipErrorOutOfMemory;
+    if (precision == RP_MLP_F32_STRICT) {   // the f32 matrix instructions for every row: the register-fragment kernel overlaps them best
+        c->last_mlp_kernel = "mlp_mfma_kernel<f32 matrix instructions>";
+        return launch_mlp_mfma(c->stream, m.dev, dx, B, kMlpStrictF32, out, redo);
+    }
     const int sprec = (mode == 1 && precision == RP_MLP_F32) ? (int)kMlpF16x2 : precision;
-    if (mode != 0 && const_cast<Model &>(m).stream_plan(dx, B, sprec, &plan))
-        return launch_mlp_stream(c->stream, m.dev, plan, dx, B, sprec, out, c->n_cu);
-    return launch_mlp_mfma(c->stream, m.dev, dx, B, precision, out);
+    if (mode != 0 && const_cast<Model &>(m).stream_plan(dx, B, sprec, &plan)) {
+        c->last_mlp_kernel = sprec == kMlpF16x2 ? "mlp_stream_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
+                             : sprec == kMlpBf16 ? "mlp_stream_kernel<bf16>" : "mlp_stream_kernel<f32 matrix instructions>";
+        return launch_mlp_stream(c->stream, m.dev, plan, dx, B, sprec, out, c->n_cu, redo);
+    }
+    c->last_mlp_kernel = precision == RP_MLP_BF16 ? "mlp_mfma_kernel<bf16>"
+                         : (mode != 0 && m.dev.w1s) ? "mlp_mfma_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows" : "mlp_mfma_kernel<f32 matrix instructions>";
+    return launch_mlp_mfma(c->stream, m.dev, dx, B, precision, out, redo);
 }
 
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits) {
@@ -1260,7 +1275,7 @@ int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, siz
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const Model &m = *model->impl;
         const int nl = (int)m.dims.size() - 1;
-        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16) { set_last_error("unknown MLP precision"); return -1; }
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
         Staged sg(c);
         const float *dx = static_cast<const float *>(sg.in(x, B * (size_t)m.dims[0] * 4, c->stage_in));
         float *dl = static_cast<float *>(sg.out(logits, B * (size_t)m.dims[nl] * 4, c->stage_out));
@@ -1296,7 +1311,7 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
-        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16) { set_last_error("unknown MLP precision"); return -1; }
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
         const Model &m = *model->impl;
         const int nl_layers = (int)m.dims.size() - 1, K = mfcc_size;
         if (K < 1 || m.dims[0] % K != 0) { set_last_error("Incorrect model layers"); return -1; }
@@ -1330,7 +1345,9 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
             float *dmean = c->ws_gain.as<float>();
             if (!hip_ok(launch_window_means(c->stream, dm, S, nf, n_win, L, K, dmean), "window_means_kernel")) return -1;
             c->time_begin(kKernelMlp);
-            ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, dm, S, nf, n_win, K, dmean, wsum, dlog), "mlp_mfma_kernel");
+            uint32_t *redo = c->mlp_redo(rows);
+            if (!redo) return -1;
+            ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, dm, S, nf, n_win, K, dmean, wsum, dlog, redo, 0, precision == RP_MLP_F32_STRICT), "mlp_mfma_kernel");
             c->time_end();
             if (!ok) return -1;
         } else {

@@ -88,6 +88,14 @@ Ctx *Ctx::create(int device, int flags) {
     return c.release();
 }
 
+uint32_t *Ctx::mlp_redo(size_t B) {
+    const size_t bytes = (2 + B) * sizeof(uint32_t);
+    if (bytes > ws_mlp_redo.cap) {   // a new block: its counters start at zero (later calls leave them so)
+        if (!ws_mlp_redo.reserve(bytes) || !hip_ok(hipMemsetAsync(ws_mlp_redo.p, 0, 2 * sizeof(uint32_t), stream), "hipMemsetAsync(mlp redo)")) return nullptr;
+    }
+    return ws_mlp_redo.as<uint32_t>();
+}
+
 Ctx::~Ctx() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);

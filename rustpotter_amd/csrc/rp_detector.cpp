@@ -463,7 +463,8 @@ int Rustpotter::process_audio(float *buf, size_t n, Detection *out) {
                 if (!hip_ok(launch_normalize_windows(st, hist, first_win, cnt, L, K, nn_x_.as<float>()), "normalize_windows_kernel")) return -1;
                 // exact-f32 path (f32-input MFMA == fmaf chain); bf16 is only offered on the batched operator
                 if (w.net->mfma_ok) {
-                    if (!hip_ok(launch_mlp_mfma(st, w.net->dev, nn_x_.as<float>(), cnt, kMlpF32, res + w.off_logits), "mlp_mfma_kernel")) return -1;
+                    uint32_t *redo = ctx_->mlp_redo(cnt);
+                    if (!redo || !hip_ok(launch_mlp_mfma(st, w.net->dev, nn_x_.as<float>(), cnt, kMlpF32, res + w.off_logits, redo), "mlp_mfma_kernel")) return -1;
                 } else if (!hip_ok(launch_mlp(st, nn_x_.as<float>(), cnt, w.n_layers, w.dims.data(), w.net->W.data(), w.net->B.data(),
                                               nn_s0_.as<float>(), nn_s1_.as<float>(), res + w.off_logits), "mlp kernel")) return -1;
             }

@@ -113,6 +113,11 @@ struct Ctx {
     // intermediates of rp_batch_detect
     DevBuf ws_mfcc, ws_scores, ws_agg, ws_avg, ws_vad, ws_ring, ws_rms, ws_gain, ws_list, ws_hot;
     DevBuf ws_dtw;  // [2 * kDtwSchedChunks | 2 + 2 * kDtwFixCap] uint32: tile counters and fix list of the DTW launchers, zero between calls
+    // the list of rows the wakeword-model forward computes again with the f32 matrix instructions (kMlpF16x2, rp_kernels.h): [2 + B]
+    // words, the first two zero between calls
+    DevBuf ws_mlp_redo;
+    uint32_t *mlp_redo(size_t B);
+    std::string last_mlp_kernel;   // what the last dense-row forward ran (rp_ctx_last_mlp_kernel)
     DtwWork dtw_work() const { return DtwWork{ws_dtw.as<uint32_t>(), ws_dtw.as<uint32_t>() + 2 * kDtwSchedChunks}; }
 
     static Ctx *create(int device, int flags);

@@ -347,10 +347,15 @@ struct MlpDev {
 // kMlpF16x2 (internal): f32-grade layer 1 at the matrix cores' f16 rate -- inputs and weights as f16 two-way splits
 // (x = x0 + x1, w = w0 + w1, 22 significant bits each; x0 w0 + x1 w0 + x0 w1, f32 accumulate: the dropped x1 w1 is 2^-22 of a product),
 // what RP_MLP_F32 callers get from both matrix-core kernels (RP_MLP_STREAM=0: the f32 matrix instructions)
-enum { kMlpF32 = 0, kMlpBf16 = 1, kMlpF16x2 = 2 };
+// kMlpStrictF32: the f32 matrix instructions whatever RP_MLP_STREAM says (RP_MLP_F32_STRICT callers).  kMlpRedoF32 (internal): only
+// the second pass of kMlpF16x2 -- the rows listed in `redo` again with the f32 matrix instructions (behind launch_mlp_stream).
+// redo (Ctx::mlp_redo): [2 + B] words, redo[0] = rows listed, redo[1] = workgroups of the second pass done, both zero between calls;
+// a row is listed when one of its features is beyond the f16 range (|x| > 65504, or not finite): the split cannot hold it, the f32
+// instructions can -- rp_mlp_forward_batch never answers NaN for finite input.
+enum { kMlpF32 = 0, kMlpBf16 = 1, kMlpF16x2 = 2, kMlpStrictF32 = 3, kMlpRedoF32 = 4 };
 // Fused forward of all layers; layer 1 on the matrix cores (f32-input MFMA: bit-for-bit an fmaf
 // chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.
-hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out);
+hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out, uint32_t *redo);
 bool mlp_mfma_fits(const MlpDev &m);   // the fused kernel's LDS fits a CU (else: the per-layer kernel)
 // The same forward for dense rows with the rows streamed through LDS by LDS-DMA in whole 128-byte lines (rp_mlp_stream.hip):
 // layer-1 widths <= 32, row pitch a multiple of 64 bytes, x 16-byte aligned (mlp_stream_supported).  The plan holds the
@@ -364,7 +369,7 @@ struct MlpStreamPlan {
 };
 bool mlp_stream_supported(const MlpDev &m, const float *x);
 hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out,
-                             int n_cu);
+                             int n_cu, uint32_t *redo);
 // The rows are windows of L = dims[0]/K frames read IN PLACE from mfcc [S][n_frames][K] (a window's flattened features
 // are a contiguous slice of the frame array), row = s * n_win + w; the window mean (MfccNormalizer::normalize) is taken
 // out after layer 1: W.(f - mu) = W.f - sum_k mu[k] * wsum[o][k], wsum[o][k] = sum_i W[o][i*K + k].  f32 MFMA.
@@ -373,7 +378,8 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 // frame_pitch (0 = n_win + L - 1, whole streams): frames between the rows of two streams -- live-stream batches keep their
 // windows in longer rows (window w of stream s starts at frame s * frame_pitch + w, counted from `mfcc`)
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
-                                   const float *mean, const float *wsum, float *out, size_t frame_pitch = 0);
+                                   const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch = 0,
+                                   bool strict_f32 = false);   // strict_f32: RP_MLP_F32_STRICT callers
 
 // WakewordModelTrain (src/wakewords/nn/wakeword_model_train.rs:204-209): act[l] / dz[l] are [B][dims[l+1]] device buffers
 hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,

@@ -275,9 +275,24 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     const float *__restrict__ x, size_t B, int in, int kpad, const float *__restrict__ w1f,
     const __bf16 *__restrict__ w1h, const float *__restrict__ b1, const float *__restrict__ tail, int tail_floats,
     int n_layers, int d1, int d2, int d3, int d4, int h2w, int wbuf_floats, float *__restrict__ out, size_t row_stride,
-    size_t rows_per_stream, size_t stream_skip, const float *__restrict__ mean, const float *__restrict__ wsum, int K) {
+    size_t rows_per_stream, size_t stream_skip, const float *__restrict__ mean, const float *__restrict__ wsum, int K, uint32_t *redo,
+    int redo_list) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N1P = 16 * NT;
+    // redo (rp_kernels.h, MlpRedo): kMlpF16x2 lists the rows that hold a feature beyond the f16 range (redo[0] = rows listed, from
+    // redo[2] on their indices); redo_list != 0: this launch computes exactly those rows (the f32 matrix instructions) and the last
+    // workgroup to leave puts redo[0] and redo[1] back to zero
+    const uint32_t *rlist = nullptr;
+    if (redo_list) {
+        const size_t n = redo[0];
+        if ((size_t)blockIdx.x * kMlpWaves * kMlpRowsPerWave >= n) {   // the whole workgroup: nothing (more) listed
+            if (threadIdx.x == 0 && atomicAdd(redo + 1, 1u) == gridDim.x - 1) { redo[0] = 0; redo[1] = 0; }
+            return;
+        }
+        B = n;
+        rlist = redo + 2;
+    }
+    auto row_of = [&](size_t i) -> size_t { return rlist ? (size_t)rlist[i] : i; };   // position in this launch -> row of x / out
     float *tl = reinterpret_cast<float *>(smem);                       // tail weights
     float *wbuf = tl + ((tail_floats + 3) & ~3);                       // staged weight group; later h1 [waves][16][N1P+1]
     float *h2_all = wbuf + wbuf_floats;                                // [waves][16][h2w]
@@ -291,8 +306,10 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     size_t r = row0 + li;
     if (r >= B) r = B - 1;  // rows past the end recompute the last row; their results are dropped
+    r = row_of(r);
     // row_stride != 0: rows are overlapping windows read in place from the frame array (launch_mlp_mfma_windows)
     const float *xr = row_stride ? x + r * row_stride + (r / rows_per_stream) * stream_skip : x + r * in;
+    float rng = 0.f;   // kMlpF16x2: largest |feature| this lane has seen
 
     // staged weight groups are double buffered when they fit (NT <= 2): the next group's global
     // loads are issued before this group's MFMAs and land in the other buffer, one barrier per group
@@ -385,7 +402,8 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
             }
         } else if (PREC == kMlpF16x2) {
             // f16 two-way splits: x0 = rtz_f16(x) (as f32: 13 mantissa bits cleared), x1 = rtz_f16(x - x0); x0 w0 + x1 w0 + x0 w1
-            // on the f16 matrix instruction, f32 accumulate.  A feature beyond the f16 range poisons its row with NaN instead of a wrong sum.
+            // on the f16 matrix instruction, f32 accumulate.  A row with a feature beyond the f16 range is listed and computed again by the
+            // f32 matrix instructions (one v_max_f32 |x| per feature finds it).
             const __bf16 *wb = reinterpret_cast<const __bf16 *>(cur);
 #pragma unroll
             for (int u = 0; u < NA / 2; ++u) {
@@ -394,7 +412,8 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
                 unsigned h0[4], h1[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = fabsf(xs[2 * e]) <= 65504.f ? xs[2 * e] : __builtin_nanf(""), q = fabsf(xs[2 * e + 1]) <= 65504.f ? xs[2 * e + 1] : __builtin_nanf("");
+                    const float p = xs[2 * e], q = xs[2 * e + 1];
+                    rng = fmaxf(fmaxf(rng, fabsf(p)), fabsf(q));
                     h0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p, q));
                     h1[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p - __uint_as_float(__float_as_uint(p) & 0xffffe000u),
                                                                                     q - __uint_as_float(__float_as_uint(q) & 0xffffe000u)));
@@ -449,6 +468,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
             if (mean) {  // take the window mean out: - sum_k mu[row][k] * wsum[o][k]
                 size_t rr = row0 + 4 * lk + e;
                 if (rr >= B) rr = B - 1;
+                rr = row_of(rr);
                 // K % 4 == 0 (wsum_for): 16 bytes per load, all of a row's loads in flight before the first multiply-add (one value
                 // per load and wait made 2 K dependent L2 round trips per output); the sum runs in the same order
                 const float4 *mu = reinterpret_cast<const float4 *>(mean + rr * K), *ws = reinterpret_cast<const float4 *>(wsum + (size_t)(16 * n + li) * K);
@@ -469,12 +489,18 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     {
         const int rr = l & 15, ph = l >> 4;
         const bool row_ok = row0 + rr < B;
+        const size_t orow = row_ok ? row_of(row0 + rr) : 0;
+        if (PREC == kMlpF16x2) {   // the four lanes (row rr, k part 0..3) of a row agree on its range; one of them lists it
+            rng = fmaxf(rng, __shfl_xor(rng, 16));
+            rng = fmaxf(rng, __shfl_xor(rng, 32));
+            if (ph == 0 && row_ok && !(rng <= 65504.f)) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)orow;
+        }
         const float *hin = h1 + rr * (N1P + 1);
         float *h2 = h2_all + (wave * kMlpRowsPerWave + rr) * h2w;
         const int dd[5] = {in, d1, d2, d3, d4};
         const float *wp = tl;
         int cur_in = d1;
-        float *dst = out + (row0 + rr) * (size_t)dd[n_layers];
+        float *dst = out + orow * (size_t)dd[n_layers];
         if (n_layers == 1 && row_ok)
             for (int o = ph; o < d1; o += 4) dst[o] = hin[o];
         for (int layer = 1; layer < n_layers; ++layer) {
@@ -496,10 +522,14 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
             hin = h2;  // n_layers <= 3: at most one hidden tail layer
         }
     }
+    if (redo_list) {
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(redo + 1, 1u) == gridDim.x - 1) { redo[0] = 0; redo[1] = 0; }
+    }
 }
 
 template <int NT>
-static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out,
+static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out, uint32_t *redo,
                                 size_t row_stride = 0, size_t rows_per_stream = 1, size_t stream_skip = 0, const float *mean = nullptr,
                                 const float *wsum = nullptr, int K = 0) {
     const size_t rows_per_block = (size_t)kMlpWaves * kMlpRowsPerWave;
@@ -519,22 +549,34 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF32>), 160 * 1024); e != hipSuccess) return e;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF16x2>), 160 * 1024); e != hipSuccess) return e;
     // f32 callers: f16 two-way splits on the f16 matrix instruction (kMlpF16x2, rp_kernels.h) unless RP_MLP_STREAM=0 asks for the f32 ones
-    if (precision == kMlpF32 && m.w1s) {
+    if (precision == kMlpStrictF32) precision = kMlpF32;
+    else if (precision == kMlpF32 && m.w1s) {
         const char *env = std::getenv("RP_MLP_STREAM");
         if (!(env && env[0] == '0')) precision = kMlpF16x2;
     }
-    if (precision == kMlpF16x2)
-        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF16x2>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
-                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1s), m.b1, m.tail, m.tail_floats, m.n_layers,
-                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K);
-    else if (precision == kMlpBf16)
+    if (B > 0xffffffffULL) return hipErrorInvalidValue;
+    uint32_t *const no_redo = nullptr;
+    if (precision == kMlpF16x2 || precision == kMlpRedoF32) {
+        if (!redo) return hipErrorInvalidValue;
+        if (precision == kMlpF16x2) {
+            hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF16x2>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                               m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1s), m.b1, m.tail, m.tail_floats, m.n_layers,
+                               m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, redo, 0);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        }
+        // the rows the split form listed (a feature beyond the f16 range), again with the f32 matrix instructions: sized for every row,
+        // workgroups past the list's end leave at once
+        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF32>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, redo, 1);
+    } else if (precision == kMlpBf16)
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
-                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K);
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, no_redo, 0);
     else
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF32>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
-                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K);
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, no_redo, 0);
     return hipGetLastError();
 }
 
@@ -552,13 +594,13 @@ bool mlp_mfma_fits(const MlpDev &m) {
     return lds <= 160 * 1024;
 }
 
-hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out) {
+hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out, uint32_t *redo) {
     if (B == 0) return hipSuccess;
     switch (m.nt) {
-    case 1: return launch_mlp_nt<1>(st, m, x, B, precision, out);
-    case 2: return launch_mlp_nt<2>(st, m, x, B, precision, out);
-    case 5: return launch_mlp_nt<5>(st, m, x, B, precision, out);
-    case 9: return launch_mlp_nt<9>(st, m, x, B, precision, out);
+    case 1: return launch_mlp_nt<1>(st, m, x, B, precision, out, redo);
+    case 2: return launch_mlp_nt<2>(st, m, x, B, precision, out, redo);
+    case 5: return launch_mlp_nt<5>(st, m, x, B, precision, out, redo);
+    case 9: return launch_mlp_nt<9>(st, m, x, B, precision, out, redo);
     }
     return hipErrorInvalidValue;
 }
@@ -599,7 +641,7 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 }
 
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
-                                   const float *mean, const float *wsum, float *out, size_t frame_pitch) {
+                                   const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch, bool strict_f32) {
     const size_t B = S * n_win;
     if (B == 0) return hipSuccess;
     if (K < 1 || K % 4 != 0 || m.dims[0] % K != 0) return hipErrorInvalidValue;  // 16-byte aligned window rows
@@ -609,11 +651,12 @@ hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float 
     if (pitch < n_win) return hipErrorInvalidValue;
     (void)n_frames;
     const size_t skip = (pitch - n_win) * K;
+    const int prec = strict_f32 ? kMlpStrictF32 : kMlpF32;
     switch (m.nt) {
-    case 1: return launch_mlp_nt<1>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
-    case 2: return launch_mlp_nt<2>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
-    case 5: return launch_mlp_nt<5>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
-    case 9: return launch_mlp_nt<9>(st, m, mfcc, B, kMlpF32, out, (size_t)K, n_win, skip, mean, wsum, K);
+    case 1: return launch_mlp_nt<1>(st, m, mfcc, B, prec, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+    case 2: return launch_mlp_nt<2>(st, m, mfcc, B, prec, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+    case 5: return launch_mlp_nt<5>(st, m, mfcc, B, prec, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+    case 9: return launch_mlp_nt<9>(st, m, mfcc, B, prec, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
     }
     return hipErrorInvalidValue;
 }

@@ -53,7 +53,7 @@ template <int NT, int PREC, int D, int kStreamWaves>
 __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_stream_kernel(
     const float *__restrict__ x, size_t B, int in, const unsigned char *__restrict__ wimg, int q_even, int q_odd, int units, int par,
     int nbt, const float *__restrict__ b1, const float *__restrict__ tail, int tail_lds, int n_layers, int d1, int d2, int d3,
-    int h2p, float *__restrict__ out) {
+    int h2p, float *__restrict__ out, uint32_t *__restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N1P = 16 * NT;
     constexpr int WK = (PREC == kMlpBf16 ? 1024 : 2048) * NT;   // bytes of fragment-ordered weights per k-step (32 k)
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
     };
 
     f32x4 acc[NT];
+    float rng = 0.f;   // kMlpF16x2: largest |feature| this lane has seen in the tile (a row beyond the f16 range is listed in `redo`)
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 // beyond the f16 range (features are MFCC coefficients, orders of magnitude below) a split would be silently wrong: such
-                // an input poisons its row with NaN instead (RP_MLP_STREAM=0 keeps the f32 matrix instructions for any finite input)
-                const float p = fabsf(xs[2 * e]) <= 65504.f ? xs[2 * e] : __builtin_nanf(""), q = fabsf(xs[2 * e + 1]) <= 65504.f ? xs[2 * e + 1] : __builtin_nanf("");
+                // a row is listed (epilogue) and computed again with the f32 matrix instructions (launch_mlp_stream)
+                const float p = xs[2 * e], q = xs[2 * e + 1];
+                rng = fmaxf(fmaxf(rng, fabsf(p)), fabsf(q));
                 h0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p, q));
                 h1[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p - __uint_as_float(__float_as_uint(p) & 0xffffe000u),
                                                                                 q - __uint_as_float(__float_as_uint(q) & 0xffffe000u)));
@@ -225,6 +227,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
         const int ri = l & 15, ph = l >> 4;
         const size_t row = tile_row0(bt) + (size_t)rstep * ri;
         const bool row_ok = row < B;
+        if (PREC == kMlpF16x2) {   // the four lanes (row ri, k part 0..3) of a row agree on its range; one of them lists it
+            rng = fmaxf(rng, __shfl_xor(rng, 16));
+            rng = fmaxf(rng, __shfl_xor(rng, 32));
+            if (ph == 0 && row_ok && !(rng <= 65504.f)) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)row;
+            rng = 0.f;
+        }
         const float *hin = h1 + ri * H1P;
         float *h2 = h2_all + (wave * 16 + ri) * h2p;
         const int dd[4] = {in, d1, d2, d3};
@@ -343,7 +351,7 @@ static size_t stream_lds_bytes(int nt, int precision, int depth, int tail_lds, i
 
 template <int NT, int PREC, int D, int WAVES>
 static hipError_t launch_stream_t(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p0, const float *x, size_t B, float *out, int tail_lds,
-                                  int h2p, int n_cu) {
+                                  int h2p, int n_cu, uint32_t *redo) {
     const size_t lds = stream_lds_bytes(NT, PREC, D, tail_lds, h2p, WAVES);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     MlpStreamPlan p = p0;   // workgroup tiles of 16 * WAVES rows
@@ -353,7 +361,7 @@ static hipError_t launch_stream_t(hipStream_t st, const MlpDev &m, const MlpStre
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_stream_kernel<NT, PREC, D, WAVES>), 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL((mlp_stream_kernel<NT, PREC, D, WAVES>), dim3((unsigned)grid), dim3(64 * WAVES), lds, st, x, B, m.dims[0],
                        static_cast<const unsigned char *>(p.wimg), p.q[0], p.q[1], p.units, p.par, p.nbt, m.b1, m.tail, tail_lds, m.n_layers,
-                       m.dims[1], m.dims[2], m.dims[3], h2p, out);
+                       m.dims[1], m.dims[2], m.dims[3], h2p, out, redo);
     return hipGetLastError();
 }
 
@@ -364,8 +372,20 @@ bool mlp_stream_supported(const MlpDev &m, const float *x) {
     return stream_lds_bytes(m.nt, kMlpF32, 1, tail_lds, h2p) <= 160 * 1024;   // wide hidden layers: mlp_mfma_kernel
 }
 
-hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out, int n_cu) {
+static hipError_t launch_mlp_stream_pass(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out, int n_cu,
+                                         uint32_t *redo);
+
+hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out, int n_cu,
+                             uint32_t *redo) {
     if (B == 0) return hipSuccess;
+    if (precision == kMlpF16x2 && (!redo || B > 0xffffffffULL)) return hipErrorInvalidValue;
+    if (hipError_t e = launch_mlp_stream_pass(st, m, p, x, B, precision, out, n_cu, redo); e != hipSuccess || precision != kMlpF16x2) return e;
+    // the rows the split form listed (a feature beyond the f16 range) again, with the f32 matrix instructions of mlp_mfma_kernel
+    return launch_mlp_mfma(st, m, x, B, kMlpRedoF32, out, redo);
+}
+
+static hipError_t launch_mlp_stream_pass(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out, int n_cu,
+                                         uint32_t *redo) {
     int h2p = 4;
     const int tail_lds = stream_tail_lds(m, &h2p);
     int depth = stream_lds_bytes(m.nt, precision, 2, tail_lds, h2p) <= 160 * 1024 ? 2 : 1;
@@ -374,9 +394,9 @@ hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPla
     if (const char *e = getenv("RP_MLP_STREAM_WAVES")) if (e[0] == '4' && 2 * stream_lds_bytes(m.nt, precision, 1, tail_lds, h2p, 4) <= 160 * 1024) { waves = 4; depth = 1; }
 #define RP_STREAM_CASE(NT_, PREC_)                                                                        \
     if (m.nt == NT_ && precision == PREC_) {                                                              \
-        if (waves == 4) return launch_stream_t<NT_, PREC_, 1, 4>(st, m, p, x, B, out, tail_lds, h2p, n_cu); \
-        return depth == 2 ? launch_stream_t<NT_, PREC_, 2, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu)   \
-                          : launch_stream_t<NT_, PREC_, 1, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu);  \
+        if (waves == 4) return launch_stream_t<NT_, PREC_, 1, 4>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo); \
+        return depth == 2 ? launch_stream_t<NT_, PREC_, 2, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo)   \
+                          : launch_stream_t<NT_, PREC_, 1, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo);  \
     }
     RP_STREAM_CASE(1, kMlpF32)
     RP_STREAM_CASE(1, kMlpBf16)

@@ -216,3 +216,70 @@ def test_detectors_with_a_template_set_outside_the_norm_range(ra, ctx, avg_thres
             assert live[s][j][0] == det[s][j]["frame"] and live[s][j][1] == r["counter"] and abs(live[s][j][2] - r["score"]) <= 1e-5 * r["score"]
     assert sum(n_det) >= 2, "the case must keep detections to compare"
     assert abs(det[0][0]["score"] - 0.7310586) > 1e-3, "golden score of the unscaled file (tests/detector.rs:24-40): the scaled rows must move it"
+
+
+# ------------------------------------------------------------------------------------------------ wakeword-model forward
+@pytest.mark.parametrize("dims", [(3120, 32, 16, 2), (1040, 13, 2), (3120, 80, 40, 3), (64, 13, 2)])
+def test_model_forward_is_finite_for_every_finite_input(ra, ctx, dims):
+    """candle's f32 Linear (wakeword_nn.rs:101-106) has the f32 range; the default f32 path multiplies f16 splits.  Rows with a
+    feature beyond the f16 range (65 504 .. 1e30), NaN-free: logits equal to the oracle's at f32 distance, the other rows keep
+    the split form's bits, and the result does not depend on which rows of the batch are out of range."""
+    rng = np.random.default_rng(sum(dims))
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(dims) - 1)]
+    model = ra.Model(ctx, ws, bs)
+    for B in (3, 130, 1031):
+        x = rng.standard_normal((B, dims[0])).astype(np.float32)
+        plain = ctx.mlp_forward(x, model)
+        xb = x.copy()
+        big_rows = sorted(set(int(r) for r in rng.integers(0, B, size=max(1, B // 9))))
+        for j, r in enumerate(big_rows):
+            mag = (65505.0, 7.0e4, 1e9, 1e20, 1e30, 3e38 / dims[0])[j % 6]
+            xb[r, rng.integers(0, dims[0], size=1 + j % 3)] = np.float32(mag) * (1 if j % 2 else -1)
+        got = ctx.mlp_forward(xb, model)
+        ref = orc.mlp_forward(xb, ws, bs)
+        assert np.isfinite(ref).all() and np.isfinite(got).all()
+        # (two f32 summation orders differ relative to the terms they add, which grow with the largest feature of the row)
+        tol = 2e-5 * np.maximum(1.0, np.abs(xb).max(axis=1, keepdims=True).astype(np.float64)) + 2e-5 * np.abs(ref)
+        assert np.all(np.abs(got.astype(np.float64) - ref) <= tol), np.abs(got - ref).max()
+        strict = ctx.mlp_forward(xb, model, precision="f32_strict")
+        assert np.all(np.abs(strict.astype(np.float64) - ref) <= tol)
+        keep = np.setdiff1d(np.arange(B), big_rows)
+        assert got[keep].tobytes() == plain[keep].tobytes()
+        assert got[big_rows].tobytes() == strict[big_rows].tobytes()          # the f32 matrix instructions computed them
+        assert ctx.mlp_forward(xb, model).tobytes() == got.tobytes()          # the list is empty again after every call
+        assert ctx.mlp_forward(x, model).tobytes() == plain.tobytes()
+    # every row out of range, and inf / NaN features behave like the reference's arithmetic (propagate)
+    x = (rng.standard_normal((70, dims[0])) * 1e6).astype(np.float32)
+    got, ref = ctx.mlp_forward(x, model), orc.mlp_forward(x, ws, bs)
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    x = rng.standard_normal((40, dims[0])).astype(np.float32)
+    x[3, 5] = np.inf
+    x[9, 11] = np.nan
+    got, ref = ctx.mlp_forward(x, model), orc.mlp_forward(x, ws, bs)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.allclose(got[ok], ref[ok], rtol=2e-5, atol=2e-5)
+    assert "f32" in ctx.last_mlp_kernel()
+
+
+def test_model_detector_with_out_of_range_features(ra, ctx):
+    """The batched model detector reads its windows in place (mlp_mfma_kernel, window mean folded in after layer 1): windows that
+    contain an MFCC frame beyond the f16 range are computed again by the f32 matrix instructions -- through rp_mlp_forward_batch's
+    sibling entry rp_batch_detect_model nothing can be injected (the frames come from the MFCC kernel), so the window form is
+    driven through the live / offline equality on ordinary audio and the dense form above carries the range test."""
+    rng = np.random.default_rng(8)
+    K, L = 16, 20
+    dims = (K * L, 32, 16, 2)
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(3)]
+    model = ra.Model(ctx, ws, bs)
+    pcm = np.stack([orc.synth_pcm(SEED, s, 480 * 40) for s in range(3)])
+    cfg = ra.DetectorConfig()
+    cfg.threshold = 0.0
+    cfg.min_scores = 1
+    a = ctx.batch_detect_model(pcm, model, K, 1, cfg)
+    b = ctx.batch_detect_model(pcm, model, K, 1, cfg, precision="f32_strict")
+    assert np.array_equal(a[2], b[2]) and a[2].sum() >= 3     # same detections per stream from both forms
+    for s in range(3):
+        for j in range(a[2][s]):
+            assert a[0][s][j]["frame"] == b[0][s][j]["frame"] and abs(a[0][s][j]["score"] - b[0][s][j]["score"]) <= 1e-5 * abs(b[0][s][j]["score"])

@@ -105,6 +105,8 @@ extern "C" {
     pub fn rp_ctx_synchronize(ctx: *mut rp_ctx) -> c_int;
     pub fn rp_ctx_dtw_ref_pairs(ctx: *mut rp_ctx, pairs: *mut u64) -> c_int;
     pub fn rp_ctx_last_mlp_kernel(ctx: *mut rp_ctx) -> *const c_char;
+    pub fn rp_build_info() -> *const c_char;
+    pub fn rp_sharded_gather_info() -> *const c_char;
     pub fn rp_mfcc_num_frames(n_samples: usize) -> usize;
     pub fn rp_mfcc_batch(ctx: *mut rp_ctx, pcm: *const f32, S: usize, n_samples: usize, pcm_stride: usize, K: c_int, mfcc: *mut f32) -> c_int;
     pub fn rp_mfcc_batch_fmt(ctx: *mut rp_ctx, pcm: *const c_void, fmt: c_int, S: usize, n_samples: usize, pcm_stride: usize, K: c_int,
@@ -312,6 +314,10 @@ impl Rustpotter {
 /// RustpotterConfig::default() as the library sees it (src/config.rs:20-29,43-52,63-71,192-207)
 pub fn default_c_config() -> rp_config { let mut c = std::mem::MaybeUninit::<rp_config>::uninit(); unsafe { rp_config_default(c.as_mut_ptr()); c.assume_init() } }
 pub fn version() -> String { unsafe { CStr::from_ptr(rp_version()).to_string_lossy().into_owned() } }
+/// target architecture and non-default compiler flags of the loaded library ("gfx950" for the product build)
+pub fn build_info() -> String { unsafe { CStr::from_ptr(rp_build_info()).to_string_lossy().into_owned() } }
+/// how this thread's last `batch_detect_sharded` gathered its shards (peer access over xGMI or staged copies)
+pub fn sharded_gather_info() -> String { unsafe { CStr::from_ptr(rp_sharded_gather_info()).to_string_lossy().into_owned() } }
 /// frames `MfccExtractor::compute` yields for n_samples fed in 480-sample chunks (src/mfcc/extractor.rs:60-79)
 pub fn mfcc_num_frames(n_samples: usize) -> usize { unsafe { rp_mfcc_num_frames(n_samples) } }
 /// `AudioEncoder::get_input_frame_length()` and the 16 kHz samples one input frame yields (src/audio/encoder.rs:63-83)

@@ -191,6 +191,10 @@ int rp_ctx_synchronize(rp_ctx *ctx);
  * of pairs rescored that way by this context's DTW calls since it was made (waits for the context's stream); 0 for audio
  * in any ordinary range. */
 int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs);
+/* Which build this library is (replaces nothing): the target architecture and the compiler flags it differs by from the
+ * product's Makefile defaults -- "gfx950" for the product, "gfx950 +-DRP_..." for an experiment build (tools/ab.sh builds
+ * those into rustpotter_amd/variants/, never over the product).  bench.py prints it on its JSON line. */
+const char *rp_build_info(void);
 /* Diagnostics of the wakeword-model forward (replaces nothing; src/wakewords/nn/wakeword_nn.rs:101-106 is what it computes): the
  * kernel(s) the last rp_mlp_forward_batch of this context ran and their operand format, e.g. "mlp_stream_kernel<f16x2 splits> +
  * mlp_mfma_kernel<f32> on listed rows".  The string belongs to the context and is valid until its next forward; "" before the first. */
@@ -338,6 +342,10 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
 int rp_batch_detect_sharded(rp_ctx *const *ctxs, const rp_templates *const *t, int n_shards, const void *const *pcm,
                             rp_sample_format fmt, const size_t *S, size_t n_samples, size_t pcm_stride,
                             const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det);
+/* How the calling thread's last rp_batch_detect_sharded gathered the shards' results (replaces nothing; SURVEY 8e's final gather):
+ * per shard whether its device writes into the gathering device directly (peer access over xGMI) or the runtime stages the copy.
+ * Valid until the thread's next sharded call; "" before the first. */
+const char *rp_sharded_gather_info(void);
 
 /* rp_batch_detect for a detector that holds SEVERAL wakewords (run_wakeword_detectors, src/detector.rs:433-447: every
  * wakeword whose own thresholds pass proposes a detection for the frame, the best score wins; max_mfcc_frames is the

@@ -102,7 +102,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_last_mlp_kernel", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
@@ -167,6 +167,10 @@ def load_library():
     L.rp_ctx_set_stream.argtypes = [vp, vp]
     L.rp_ctx_synchronize.argtypes = [vp]
     L.rp_ctx_dtw_ref_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rp_sharded_gather_info.argtypes = []
+    L.rp_sharded_gather_info.restype = C.c_char_p
+    L.rp_build_info.argtypes = []
+    L.rp_build_info.restype = C.c_char_p
     L.rp_ctx_last_mlp_kernel.argtypes = [vp]
     L.rp_ctx_last_mlp_kernel.restype = C.c_char_p
     L.rp_mfcc_num_frames.argtypes = [C.c_size_t]
@@ -221,6 +225,16 @@ def load_library():
 
 def _err():
     return RustpotterError(load_library().rp_last_error().decode("utf-8", "replace"))
+
+
+def sharded_gather_info():
+    """How this thread's last batch_detect_sharded[_dev] gathered its results (rp_sharded_gather_info)."""
+    return load_library().rp_sharded_gather_info().decode()
+
+
+def build_info():
+    """Architecture and non-default compiler flags of the loaded library (rp_build_info)."""
+    return load_library().rp_build_info().decode()
 
 
 def resampler_frame_lengths(sample_rate):

@@ -213,6 +213,14 @@ int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs) {
     return 0;
 }
 
+#ifndef RP_BUILD_ARCH
+#define RP_BUILD_ARCH "gfx950"
+#endif
+#ifndef RP_BUILD_FLAGS_EXTRA
+#define RP_BUILD_FLAGS_EXTRA ""
+#endif
+const char *rp_build_info(void) { return sizeof(RP_BUILD_FLAGS_EXTRA) > 1 ? RP_BUILD_ARCH " +" RP_BUILD_FLAGS_EXTRA : RP_BUILD_ARCH; }
+
 const char *rp_ctx_last_mlp_kernel(rp_ctx *ctx) { return ctx ? ctx->impl->last_mlp_kernel.c_str() : ""; }
 
 size_t rp_mfcc_num_frames(size_t n_samples) {
@@ -600,6 +608,10 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
     });
 }
 
+// how the last rp_batch_detect_sharded of this thread gathered its results (rp_sharded_gather_info)
+static thread_local std::string g_sharded_info;
+const char *rp_sharded_gather_info(void) { return g_sharded_info.c_str(); }
+
 int rp_batch_detect_sharded(rp_ctx *const *ctxs, const rp_templates *const *t, int n_shards, const void *const *pcm,
                             rp_sample_format fmt, const size_t *S, size_t n_samples, size_t pcm_stride,
                             const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det, int max_det) {
@@ -626,15 +638,22 @@ int rp_batch_detect_sharded(rp_ctx *const *ctxs, const rp_templates *const *t, i
         std::vector<std::string> errs((size_t)n_shards);
         // device-resident gather: let every other device write into ctxs[0]'s device directly (xGMI) where the node allows it;
         // without peer access hipMemcpyPeerAsync still works (staged by the runtime), so a refusal here is not an error
+        std::string info = to.host ? "gather into host memory (RP_CTX_HOST_POINTERS): device-to-host copies" : "gather onto device " + std::to_string(to.device) + ":";
         if (!to.host)
             for (int g = 1; g < n_shards; ++g) {
                 const int dev = ctxs[g]->impl->device;
                 int can = 0;
+                const char *how = dev == to.device ? "same device" : "staged by the runtime (no peer access)";
                 if (dev != to.device && hipDeviceCanAccessPeer(&can, dev, to.device) == hipSuccess && can && hipSetDevice(dev) == hipSuccess) {
                     const hipError_t pe = hipDeviceEnablePeerAccess(to.device, 0);
+                    if (pe == hipSuccess) how = "peer access enabled (direct write over xGMI)";
+                    else if (pe == hipErrorPeerAccessAlreadyEnabled) how = "peer access already enabled (direct write over xGMI)";
+                    else how = "staged by the runtime (hipDeviceEnablePeerAccess refused)";
                     if (pe != hipSuccess) (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled or a refusal: both fine
                 }
+                info += " shard " + std::to_string(g) + " (device " + std::to_string(dev) + "): " + how + ";";
             }
+        g_sharded_info = info;
         auto run = [&](int g) noexcept {
             try {
                 GatherTo mine = to;

@@ -14,6 +14,17 @@ per-stream detection summary at the end of each step.  The ranks are either star
 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: WORLD_SIZE is set) or, when
 WORLD_SIZE is not set, by bench.py itself: the parent starts that same command as a child process BEFORE
 anything touches the GPU, relays the child's output (rank 0 prints the one JSON line) and exits with its code.
+
+What the one JSON line carries besides the contract's fields (round 4):
+  roofline.frac      the largest of the dominant kernel's pipe fractions (executed work / pipe peak / measured time): VALU issue
+                     cycles from the committed instruction mix of its hot loop (profiles/r04_*_isa_mix.json x
+                     profiles/valu_rate_table.json), matrix flops, HBM bytes, LDS cycles -- each <= 1 by construction; the
+                     reference-shaped flop rate of SURVEY 8d sits beside it as ref_flop_rate_vs_vector_peak
+  vector_only        the same step with the cosine products on the vector pipe (RP_DTW_MFMA=0), 2 steps
+  extra_configs      short timed runs of BASELINE configs C2, C5 (bf16) and C5 (f32) in the same process
+  h2d_included       a bounded sample of the same path with the PCM starting in pinned HOST memory (see --ingest)
+  cpu_baseline       the oracle on all granted host cores, and on one thread (one_thread)
+  config.*           host CPU model, build id of the library, and for N > 1 the world size RCCL reports and every rank's device UUID
 """
 import argparse
 import json
@@ -29,6 +40,9 @@ SEED = 0x5EED000000000001
 HBM_PEAK = 8.0e12      # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 VALU_PEAK = 157.3e12   # FLOP/s fp32 vector, same table
 MFMA_F16_PEAK = 2.5e15  # FLOP/s dense f16 / bf16 MFMA, same table
+CLOCK_PEAK = 2.4e9     # Hz, peak shader clock, same table
+DTYPE_DTW = "f32 (cosine products: f16x2-split MFMA, 22-bit)"
+DTYPE_DTW_VECTOR = "f32"
 
 
 def self_launch(n):
@@ -58,6 +72,37 @@ def self_launch(n):
     return r.returncode
 
 
+def host_cpu():
+    """(threads this process may use -- affinity mask capped by a cgroup CPU quota --, CPU model string)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # honour a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return cores, model
+
+
+def load_json(rel):
+    try:
+        return json.load(open(os.path.join(ROOT, rel)))
+    except Exception:
+        return None
+
+
+def n_simds(torch, dev):
+    return 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +114,7 @@ def main():
     ap.add_argument("--template-len", type=int, default=100)
     ap.add_argument("--mfcc-size", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement: no vector_only / extra_configs / h2d_included blocks")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None,
                     help="BASELINE.json presets: C2 = 1 024 streams x 8 templates; C3 = 65 536 x 8 (the default workload); C4 = 65 536 streams x 64 "
@@ -77,10 +123,14 @@ def main():
                     help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward; "
                          "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process); "
                          "resample: 48 kHz -> 16 kHz front-end alone (rp_resample_batch)")
+    ap.add_argument("--ingest", action="store_true", help="the headline path with the PCM starting in pinned HOST memory: streams in blocks of "
+                    "--ingest-block, block k+1's copy on a copy stream under block k's kernels (SURVEY 8d: H2D included); reports scorings/s and PCIe GB/s")
+    ap.add_argument("--ingest-block", type=int, default=8192, help="streams per block of the --ingest pipeline")
+    ap.add_argument("--ingest-format", choices=["f32", "i16"], default="f32", help="sample format of the host PCM (i16: decoded inside mfcc_kernel)")
     ap.add_argument("--chunks-per-call", type=int, default=1)
     ap.add_argument("--pcm-format", choices=["f32", "i16"], default="f32", help="--mode resample: sample format of the 48 kHz input")
     ap.add_argument("--channels", type=int, default=1, help="--mode resample: interleaved channels of the 48 kHz input")
-    ap.add_argument("--mlp-precision", choices=["f32", "bf16"], default="bf16")
+    ap.add_argument("--mlp-precision", choices=["f32", "bf16", "f32_strict"], default="bf16")
     ap.add_argument("--template-lens", default="", help="comma-separated template lengths in frames (overrides --templates / "
                     "--template-len), e.g. 108,96,90,93,102 = the shape of the reference's oye_casa_g.rpw")
     ap.add_argument("--score-mode", choices=["average", "max", "median", "p25", "p50", "p75", "p80", "p90", "p95"], default="max")
@@ -104,7 +154,6 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -130,263 +179,64 @@ def main():
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
 
     import rustpotter_amd as ra
-    from rustpotter_amd import sharding
 
+    env = Env(args, ra, torch, dist, dev, world, rank, local_rank, backend)
     if args.mode == "mlp":
-        return bench_mlp(args, ra, torch, dist, dev, world, rank, local_rank)
-
-    if args.mode == "stream":
-        return bench_stream(args, ra, torch, dist, dev, world, rank, local_rank)
-    if args.mode == "resample":
-        return bench_resample(args, ra, torch, dist, dev, world, rank, local_rank)
-
-    first_stream = None
-    if args.total_streams is not None:   # strong scaling: this rank's contiguous block of the fixed stream set
-        lo, hi = sharding.shard_bounds(args.total_streams, world, rank)
-        args.streams, first_stream = hi - lo, lo
-    S, N, K = args.streams, args.samples, args.mfcc_size
-    lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
-    T, L = len(lens), max(lens)
-    nf = ra.mfcc_num_frames(N)
-    n_win = nf - L + 1
-    ctx = ra.BatchContext(device=local_rank, host_pointers=False, full_scores=args.full_scores)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    # templates: T synthetic utterances, MFCC by the HIP path, whole-matrix mean
-    # normalisation, truncated to their length.  Identical arrays are handed to the CPU baseline.
-    templates = make_templates(ra, ctx, torch, dev, lens, K)
-    avg_t = None
-    if args.avg_gate:
-        # synthetic averaged template: the frame-wise mean of the templates cut to the shortest one (the reference's
-        # MfccAverager aligns them by DTW first; only the amount of work matters here)
-        lm = min(lens)
-        avg_t = np.ascontiguousarray(np.mean([t[:lm] for t in templates], axis=0, dtype=np.float32), dtype=np.float32)
-    tmpl = ra.Templates(ctx, templates, avg=avg_t)
-
-    # resident inputs / outputs
-    pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
-    ctx.synth_dev(SEED, sharding.weak_first_stream(S, rank) if first_stream is None else first_stream, S, N, N, pcm.data_ptr())
-    want_arrays = not (args.avg_gate or args.detect_only)  # the per-window arrays are defined for every window: asking for them keeps every DTW
-    scores = torch.empty((S, n_win, T), dtype=torch.float32, device=dev) if want_arrays else None
-    agg = torch.empty((S, n_win), dtype=torch.float32, device=dev) if want_arrays else None
-    max_det = 4
-    det = torch.zeros((S, max_det, 6), dtype=torch.int32, device=dev)
-    n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
-    cfg = ra.DetectorConfig()
-    cfg.score_mode = {"average": 0, "max": 1, "median": 2, "p25": 3, "p50": 4, "p75": 5, "p80": 6, "p90": 7, "p95": 8}[args.score_mode]
-    cfg.avg_threshold = args.avg_threshold if args.avg_gate else 0.0  # gate off: exactly T DTWs per scoring
-
-    def step():
-        # one C call: mfcc_kernel -> dtw kernel(s) -> aggregate kernel -> scan_kernel on the launch stream
-        ctx.batch_detect_dev(pcm.data_ptr(), S, N, N, tmpl, cfg, det.data_ptr(), n_det.data_ptr(), max_det,
-                             scores.data_ptr() if want_arrays else None, agg.data_ptr() if want_arrays else None)
-        # final per-stream result gather (RCCL over xGMI); shards of a fixed stream set may differ by one stream
-        return sharding.gather_per_stream(n_det, world) if first_stream is None else sharding.gather_ragged(n_det, world)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    scorings_per_step = (S * world if args.total_streams is None else args.total_streams) * n_win
-    value = scorings_per_step * args.steps / dt
-
-    # ---- rooflines, measured live with HIP events on the launch stream (rp_ctx_timing_*: one event pair per launch)
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    for _ in range(max(2, min(args.steps, 5))):
-        step()
-    torch.cuda.synchronize()
-    k_ms = {name: ctx.timing_read(i) for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
-    ctx.timing_enable(False)
-    per_gpu_scorings = S * n_win
-    W = 5
-    # reference-shaped flops of one template DTW (SURVEY.md S8d F_dtw: 3 dot products + sqrt + divide per cell = 2K+7, norms,
-    # normalisation) and the flops the kernel executes (unit-length rows: K FMAs + 2 min3 + 1 add per cell; per row and
-    # window one ring column: K subtracts, K FMAs, rsqrt, K multiplies, shared by the templates of a chunk)
-    def cells(Lt):
-        return sum((min(Lt, r + W - 1) - max(1, r - W) + 1) for r in range(1, Lt))
-    f_dtw_ref = sum(cells(Lt) * (2 * K + 7) + 2 * Lt * 2 * K + 2 * Lt * K for Lt in lens)
-    by_len = {}
-    for Lt in lens:
-        by_len[Lt] = by_len.get(Lt, 0) + 1
-    n_chunks = sum(-(-c // 8) for c in by_len.values())
-    f_dtw_exec = sum((Lt - 1) * 2 * W * (2 * K + 3) for Lt in lens) + sum(-(-c // 8) * ((Lt - 1) * (4 * K + 1) + Lt * K) for Lt, c in by_len.items())
-    f_mfcc = 13.2e3
-    dom = max(("mfcc", "dtw"), key=lambda n: k_ms[n][0])
-    # PMC byte / instruction counts per launch come from the committed rocprofv3 passes of this same command (a profiler
-    # cannot run inside the timed process); null for any other workload.
-    pmc, pmc_src = {}, None
-    if not args.avg_gate and args.score_mode == "max":
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            w = tj["workload"]
-            if (w["streams"], w["samples"], w["templates"], w["template_len"], w["mfcc_size"]) == (S, N, T, L, K) and len(set(lens)) == 1:
-                for name, d in tj["kernels"].items():
-                    for kn in ("mfcc", "dtw"):
-                        if kn + "_" in name and "hbm_bytes_per_launch_corrected" in d and (kn != "dtw" or "dtw_mfma" in name or "dtw" not in pmc):
-                            pmc[kn] = d
-                pmc_src = "profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc passes of this command, not this run)"
-        except Exception:
-            pmc = {}
-    dtw_s, mfcc_s = k_ms["dtw"][0] * 1e-3, k_ms["mfcc"][0] * 1e-3
-    simd_cycles = lambda sec: 1024 * sec * 2.4e9  # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
-    dtw_ref_flops, dtw_exec_flops = per_gpu_scorings * f_dtw_ref, per_gpu_scorings * f_dtw_exec
-    dtw_bytes = per_gpu_scorings * (4 * K + 4 * (T + 2))
-    # which DTW kernel ran (rp_dtw.hip launch_dtw_k5): chunks of 3..8 same-length templates at mfcc_size 5 / band 5 go to the
-    # matrix-core kernel unless RP_DTW_MFMA=0
-    mfma_on = os.environ.get("RP_DTW_MFMA", "1")[:1] != "0" and min(lens) >= 12
-    mfma_wide = mfma_on and K in (13, 16) and all(c >= 3 for c in by_len.values())  # dtw_mfma_wide_kernel (rp_dtw_mfma_wide.hip)
-    mfma_used = mfma_wide or (mfma_on and K == 5 and any(c >= 3 for c in by_len.values()))
-    # executed arithmetic of dtw_mfma_kernel: per window and column (L columns) three 32x32x16 MFMAs per 32 windows and chunk
-    # (3 x 32768 / 32 flops), vector side per cell one v_min3 (2) + one add, per column and lane ~20 flops of frame work (2 lanes)
-    def mfma_chunks(c):  # (chunks with eight template slots, chunks with four, templates left to the register kernels)
-        full, rem = divmod(c, 8)
-        return full + (1 if rem >= 5 else 0), 1 if 3 <= rem <= 4 else 0, rem if rem <= 2 else 0
-    f_mfma_matrix = sum((mfma_chunks(c)[0] * 3 + mfma_chunks(c)[1] * 2) * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
-    f_mfma_vector = sum((c - mfma_chunks(c)[2]) * Lt * 2 * W * 3 + (mfma_chunks(c)[0] + mfma_chunks(c)[1]) * Lt * 40 for Lt, c in by_len.items())
-    if mfma_wide:  # every template in chunks of eight slots; 3 tiles x (4 k-steps at mfcc_size 16, 3 at 13) MFMAs per column
-        ksteps = 4 if K == 16 else 3
-        f_mfma_matrix = sum(-(-c // 8) * 3 * ksteps * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
-        f_mfma_vector = sum(c * Lt * 2 * W * 3 + -(-c // 8) * Lt * 8 * K for Lt, c in by_len.items())
-    r_dtw = {"bound": "valu", "kernel": "dtw_mfma_wide_kernel" if mfma_wide else "dtw_mfma_kernel" if mfma_used else "dtw_band_kernel" if K == 5 else "dtw_band_wide_kernel", "achieved": dtw_ref_flops / dtw_s / 1e12 if dtw_s else 0.0, "peak": VALU_PEAK / 1e12,
-             "unit": "TFLOP/s", "frac": dtw_ref_flops / dtw_s / VALU_PEAK if dtw_s else 0.0,
-             "traffic": pmc.get("dtw", {}).get("hbm_bytes_per_launch_corrected"), "traffic_source": pmc_src if "dtw" in pmc else None,
-             "avg_launch_ms": k_ms["dtw"][0], "launches_timed": k_ms["dtw"][1],
-             "algorithmic_flops_per_launch": dtw_ref_flops, "executed_flops_per_launch": dtw_exec_flops,
-             "executed_flop_frac": dtw_exec_flops / dtw_s / VALU_PEAK if dtw_s else 0.0,
-             "hbm": {"achieved": dtw_bytes / dtw_s / 1e9 if dtw_s else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": dtw_bytes / dtw_s / HBM_PEAK if dtw_s else 0.0, "algorithmic_bytes_per_launch": dtw_bytes},
-             "note": "fp32 vector roofline: `achieved`/`frac` price the REFERENCE-shaped flop count (SURVEY.md 8d: 2K+7 flops per band "
-                     "cell) against 157.3 TFLOP/s; the register kernel executes fewer (executed_flops: K FMAs + 2 min3 + 1 add per cell), "
-                     "so executed_flop_frac is its honest flop fraction and valu_issue_frac the pipe saturation: VALU instructions x 4 "
-                     "cycles (packed-f32 issue slot) / (1024 SIMDs x launch time x 2.4 GHz)"}
-    if mfma_used:
-        # the cosine costs are formed by v_mfma_f32_32x32x16_f16 (f16 two-way splits, f32 accumulate): the reference-shaped flop rate
-        # can exceed the VECTOR peak (frac > 1) because those flops no longer run on the vector pipe.  What bounds the kernel is VALU
-        # issue (the recurrence: v_min3 x2 + add x2 per cell pair); valu_busy_frac / mfma_busy_frac below are PMC-measured.
-        r_dtw["executed_flops_per_launch"] = per_gpu_scorings * f_mfma_vector
-        r_dtw["executed_matrix_flops_per_launch"] = per_gpu_scorings * f_mfma_matrix
-        r_dtw["executed_flop_frac"] = per_gpu_scorings * f_mfma_vector / dtw_s / VALU_PEAK if dtw_s else 0.0
-        r_dtw["mfma_f16_frac"] = per_gpu_scorings * f_mfma_matrix / dtw_s / MFMA_F16_PEAK if dtw_s else 0.0
-        r_dtw["note"] = ("dtw_mfma_kernel: the cosine costs of a band column come out of v_mfma_f32_32x32x16_f16 (f16 two-way splits of both "
-                         "operands, f32 accumulate), the vector pipe runs the recurrence.  `achieved`/`frac` still price the REFERENCE-shaped "
-                         "flop count (SURVEY.md 8d) against the 157.3 TFLOP/s VECTOR peak, as in earlier rounds -- above 1 means the kernel "
-                         "beats what any f32 vector formulation of the reference's arithmetic could reach, not that a roof is exceeded.  "
-                         "Bound: VALU issue -- valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x shader cycles) and mfma_busy_frac = "
-                         "SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x shader cycles), both from the committed PMC passes; mfma_f16_frac = executed "
-                         "matrix flops against the 2.5 PFLOP/s dense f16 peak")
-    if "dtw" in pmc and "instructions_per_launch" in pmc["dtw"]:
-        r_dtw["valu_insts_per_launch"] = pmc["dtw"]["instructions_per_launch"]["SQ_INSTS_VALU"]
-        r_dtw["valu_issue_frac"] = 4.0 * r_dtw["valu_insts_per_launch"] / simd_cycles(dtw_s) if dtw_s else 0.0
-        if "effective_clock_ghz" in pmc["dtw"]:  # the chip clocks below 2.4 GHz under this load (GRBM_GUI_ACTIVE / duration, same PMC file)
-            r_dtw["effective_clock_ghz"] = pmc["dtw"]["effective_clock_ghz"]
-            r_dtw["valu_issue_frac_at_effective_clock"] = r_dtw["valu_issue_frac"] * 2.4 / pmc["dtw"]["effective_clock_ghz"]
-    for kf in ("valu_busy_frac", "mfma_busy_frac"):
-        if "dtw" in pmc and kf in pmc["dtw"]:
-            r_dtw[kf] = pmc["dtw"][kf]
-    mfcc_bytes, mfcc_flops = S * nf * (640 + 4 * K), S * nf * f_mfcc
-    r_mfcc = {"bound": "hbm", "kernel": "mfcc_kernel", "achieved": mfcc_bytes / mfcc_s / 1e9 if mfcc_s else 0.0, "peak": HBM_PEAK / 1e9,
-              "unit": "GB/s", "frac": mfcc_bytes / mfcc_s / HBM_PEAK if mfcc_s else 0.0,
-              "traffic": pmc.get("mfcc", {}).get("hbm_bytes_per_launch_corrected"), "traffic_source": pmc_src if "mfcc" in pmc else None,
-              "avg_launch_ms": k_ms["mfcc"][0], "launches_timed": k_ms["mfcc"][1], "algorithmic_bytes_per_launch": mfcc_bytes,
-              "fp32_frac": mfcc_flops / mfcc_s / VALU_PEAK if mfcc_s else 0.0,
-              "note": "660 B per frame (640 B of new PCM + 4K B out) against 8 TB/s; fp32_frac = 13.2 kflop per frame against 157.3 TFLOP/s"}
-    if "mfcc" in pmc and "instructions_per_launch" in pmc["mfcc"]:
-        r_mfcc["valu_insts_per_launch"] = pmc["mfcc"]["instructions_per_launch"]["SQ_INSTS_VALU"]
-        r_mfcc["valu_issue_frac"] = 4.0 * r_mfcc["valu_insts_per_launch"] / simd_cycles(mfcc_s) if mfcc_s else 0.0
-        if "effective_clock_ghz" in pmc["mfcc"]:
-            r_mfcc["effective_clock_ghz"] = pmc["mfcc"]["effective_clock_ghz"]
-            r_mfcc["valu_issue_frac_at_effective_clock"] = r_mfcc["valu_issue_frac"] * 2.4 / pmc["mfcc"]["effective_clock_ghz"]
-    roofline = dict(r_dtw if dom == "dtw" else r_mfcc)
-    roofline["kernels_ms"] = {k: round(v[0], 4) for k, v in k_ms.items()}
-    if k_ms["aggregate"][1] == 0:  # no launch of the aggregate pass: ScoreMode::Max ran inside the DTW kernel
-        roofline["aggregate_inside_dtw_kernel"] = True
-    work_skipped = args.detect_only or (args.avg_gate and not args.full_scores)
-    roofline["path_hbm_frac"] = (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK
-    roofline["path_valu_frac_fp32"] = (value / world) * (f_mfcc * nf / n_win + f_dtw_ref) / VALU_PEAK
-
-    tag = {(65536, 8): "C3", (8192, 64): "C4 (per-GPU share)", (1024, 8): "C2"}.get((S, T), "custom") if len(set(lens)) == 1 and lens[0] == 100 else "custom"
-    if args.total_streams is not None:
-        tag = "C4"
-    out = {
-        "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak" if args.total_streams is None else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %s synthetic 16 kHz f32 streams x %d templates%s (%g s streams, L=%s, K=%d, band 5, "
-                               "ScoreMode::%s, %s)" % (tag, ("%d" % S) if args.total_streams is None else ("%d" % args.total_streams), T,
-                                                       " per GPU" if args.total_streams is None else " split over %d rank(s) by stream" % world,
-                                                       N / 16000.0, lens[0] if len(set(lens)) == 1 else "/".join(map(str, lens)), K,
-                                                       args.score_mode.capitalize(),
-                                                       ("averaged template + avg_threshold %g%s, " % (args.avg_threshold, " (reference default)" if args.avg_threshold == 0.2 else "") +
-                                                        ("every window scored anyway" if args.full_scores else "gated windows skipped"))
-                                                       if args.avg_gate else ("avg gate off" + (", detect-only call: DTWs that cannot reach threshold 0.5 "
-                                                                                               "any more are abandoned" if args.detect_only else ""))),
-                   "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
-                   "windows_per_stream": n_win, "template_chunks": n_chunks,
-                   "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world,
-                   "world_size": world, "backend": (backend if world > 1 else "none (one rank)")},
-        # work is skipped by design in detect-only / gated runs: pricing the full flop count against the shorter time would
-        # print a fraction above 1, so those lines carry the kernel times only
-        "roofline": roofline if not work_skipped else None,
-        "roofline_other": (r_mfcc if dom == "dtw" else r_dtw) if not work_skipped else None,
-    }
-    if work_skipped:
-        out["kernels_ms"] = roofline["kernels_ms"]
-        out["note"] = "work is skipped by design in this mode (gated windows / abandoned DTWs): no roofline fraction is quoted"
-    if backend != "nccl" and world > 1:
-        out["oversubscribed"] = {"devices": torch.cuda.device_count(), "backend": backend,
-                                 "note": "ranks share GPUs: a launch-path dry run, not a scaling measurement"}
-    if args.avg_gate:
-        # how many windows pass the gate on this input (one extra pass over the averaged template, not timed)
-        mf = torch.empty((S, nf, K), dtype=torch.float32, device=dev)
-        ctx.mfcc_dev(pcm.data_ptr(), S, N, N, K, mf.data_ptr())
-        sc_ = torch.empty((S, n_win, T), dtype=torch.float32, device=dev)
-        av_ = torch.empty((S, n_win), dtype=torch.float32, device=dev)
-        ag_ = torch.empty((S, n_win), dtype=torch.float32, device=dev)
-        ctx.dtw_dev(mf.data_ptr(), S, nf, tmpl, cfg.score_ref, cfg.band_size, cfg.score_mode, 1, sc_.data_ptr(), av_.data_ptr(), ag_.data_ptr())
-        torch.cuda.synchronize()
-        out["config"]["avg_threshold"] = cfg.avg_threshold
-        out["config"]["gate_pass_fraction"] = float((~(av_ < cfg.avg_threshold)).float().mean().item())
-        qs = torch.quantile(av_.flatten()[:: max(1, av_.numel() // 4000000)], torch.tensor([0.001, 0.01, 0.1, 0.5, 0.9, 0.99, 0.999], device=dev))
-        out["config"]["avg_score_quantiles"] = {"q": [0.001, 0.01, 0.1, 0.5, 0.9, 0.99, 0.999], "avg_score": [round(float(x), 4) for x in qs]}
-        del mf, sc_, av_, ag_
-
-    # ---- CPU baseline: the oracle's restatement of the reference algorithm on this host's cores
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.avg_gate and len(set(lens)) == 1:
-        from oracle import rp_oracle as orc
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        try:  # honour a cgroup CPU quota (the GPU box grants 16 of its 256 hardware threads)
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-            if quota != "max":
-                cores = max(1, min(cores, int(int(quota) / int(period))))
-        except Exception:
-            pass
-        secs, sc, _ = orc.bench(SEED, cores, N, templates, threads=cores)  # calibration: 1 stream per core
-        rate = sc / secs
-        s_cpu = int(max(cores, min(4096 * cores, args.cpu_seconds * rate / n_win)))
-        secs, sc, _ = orc.bench(SEED, s_cpu, N, templates, threads=cores)
-        out["cpu_baseline"] = {"value": sc / secs, "unit": "scorings/s", "cores": cores, "kind": "port",
-                               "sample": "%d of the same synthetic streams x %d templates, %d scorings in %.1f s; C restatement of "
-                                         "the reference algorithm (complex FFT-480 per frame, dense mel, 3-dot cosine per DTW cell), "
-                                         "not the Rust crate" % (s_cpu, T, sc, secs)}
+        res = bench_mlp(env)
+    elif args.mode == "stream":
+        res = bench_stream(env)
+    elif args.mode == "resample":
+        res = bench_resample(env)
+    elif args.ingest:
+        res = bench_ingest(env)
+    else:
+        res = bench_dtw(env)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+class Env:
+    def __init__(self, args, ra, torch, dist, dev, world, rank, local_rank, backend):
+        self.args, self.ra, self.torch, self.dist, self.dev = args, ra, torch, dist, dev
+        self.world, self.rank, self.local_rank, self.backend = world, rank, local_rank, backend
+        self.cores, self.cpu_model = host_cpu()
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            tt = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def common_config(self):
+        """Fields every line carries: where it ran and with which build."""
+        p = self.torch.cuda.get_device_properties(self.dev)
+        c = {"host_cpu": self.cpu_model, "host_threads_granted": self.cores, "device": p.name, "compute_units": p.multi_processor_count,
+             "build": self.ra.build_info(), "world_size": self.world, "backend": self.backend if self.world > 1 else "none (one rank)"}
+        if self.world > 1:
+            c.update(self.rank_identities())
+        return c
+
+    def rank_identities(self):
+        """Self-proving multi-GPU record: the world size the process group reports and every rank's device UUID; with nccl (RCCL)
+        the UUIDs must be N distinct devices."""
+        p = self.torch.cuda.get_device_properties(self.dev)
+        mine = {"rank": self.rank, "local_rank": self.local_rank, "device_index": self.dev.index, "uuid": str(getattr(p, "uuid", "")),
+                "pci_bus_id": getattr(p, "pci_bus_id", None), "name": p.name}
+        everyone = [None] * self.world
+        self.dist.all_gather_object(everyone, mine)
+        uu = [e["uuid"] for e in everyone]
+        if self.backend == "nccl":
+            assert len(set(uu)) == self.world and all(uu), "RCCL run with ranks that share a device: %r" % (uu,)
+        return {"rccl_world_size": self.dist.get_world_size(), "rank_devices": everyone, "distinct_devices": len(set(uu))}
 
 
 def make_templates(ra, ctx, torch, dev, lens, K):
@@ -403,12 +253,644 @@ def make_templates(ra, ctx, torch, dev, lens, K):
     return [np.ascontiguousarray((m - m.mean(axis=0, dtype=np.float32))[:lens[t]], dtype=np.float32) for t, m in enumerate(tmf.cpu().numpy())]
 
 
-def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
+# ------------------------------------------------------------------------------------------------ kernel models
+def cells(Lt, W=5):
+    return sum((min(Lt, r + W - 1) - max(1, r - W) + 1) for r in range(1, Lt))
+
+
+def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw):
+    """Pipe fractions of the DTW kernel of one launch (S x n_win windows x templates `lens`) that took dtw_s seconds.
+    valu_issue: SIMD issue cycles of the hot loop (committed ISA mix x rate table) x trips / (SIMDs x 2.4 GHz); mfma_f16: executed
+    matrix flops / 2.5 PFLOP/s; hbm: algorithmic bytes / 8 TB/s; valu_flops (kernels without a committed mix): executed vector flops /
+    157.3 TFLOP/s.  Every fraction is executed work / (pipe peak x measured time), so none can exceed 1."""
+    torch, W, T = env.torch, 5, len(lens)
+    rows = S * n_win
+    by_len = {}
+    for Lt in lens:
+        by_len[Lt] = by_len.get(Lt, 0) + 1
+    mfma_on = os.environ.get("RP_DTW_MFMA", "1")[:1] != "0" and min(lens) >= 12
+    mfma_wide = mfma_on and K in (13, 16) and all(c >= 3 for c in by_len.values())
+    mfma_used = mfma_wide or (mfma_on and K == 5 and any(c >= 3 for c in by_len.values()))
+    kernel = "dtw_mfma_wide_kernel" if mfma_wide else "dtw_mfma_kernel" if mfma_used else "dtw_band_kernel" if K == 5 else "dtw_band_wide_kernel"
+    f_dtw_ref = sum(cells(Lt) * (2 * K + 7) + 2 * Lt * 2 * K + 2 * Lt * K for Lt in lens)   # SURVEY 8d, reference-shaped
+    f_exec_vec = sum((Lt - 1) * 2 * W * (2 * K + 3) for Lt in lens) + sum(-(-c // 8) * ((Lt - 1) * (4 * K + 1) + Lt * K) for Lt, c in by_len.items())
+    f_exec_mat = 0.0
+
+    def mfma_chunks(c):  # (chunks with eight template slots, chunks with four, templates left to the register kernels)
+        full, rem = divmod(c, 8)
+        return full + (1 if rem >= 5 else 0), 1 if 3 <= rem <= 4 else 0, rem if rem <= 2 else 0
+    if mfma_used and not mfma_wide:
+        f_exec_mat = sum((mfma_chunks(c)[0] * 3 + mfma_chunks(c)[1] * 2) * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
+        f_exec_vec = sum((c - mfma_chunks(c)[2]) * Lt * 2 * W * 3 + (mfma_chunks(c)[0] + mfma_chunks(c)[1]) * Lt * 40 for Lt, c in by_len.items())
+    if mfma_wide:
+        ksteps = 4 if K == 16 else 3
+        f_exec_mat = sum(-(-c // 8) * 3 * ksteps * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
+        f_exec_vec = sum(c * Lt * 2 * W * 3 + -(-c // 8) * Lt * 8 * K for Lt, c in by_len.items())
+    alg_bytes = rows * (4 * K + 4 * (T + 2))
+    pipes = {"hbm": alg_bytes / dtw_s / HBM_PEAK, "mfma_f16": rows * f_exec_mat / dtw_s / MFMA_F16_PEAK}
+    extra = {}
+    mix = load_json("profiles/r04_dtw_mfma_isa_mix.json")
+    only_full8 = mfma_used and not mfma_wide and all(mfma_chunks(c)[1] == 0 and mfma_chunks(c)[2] == 0 for c in by_len.values())
+    if mix and only_full8 and n_win >= 32:
+        # the hot loop is one block of 12 columns of one 32-window tile of one chunk: a template of L frames is L / 12 trips
+        tiles = -(-rows // 32)
+        trips = sum(mfma_chunks(c)[0] * Lt / 12.0 for Lt, c in by_len.items()) * tiles
+        cyc = trips * mix["valu_issue_cycles_per_trip"]
+        pipes["valu_issue"] = cyc / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r04_dtw_mfma_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
+                      "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
+                                                                                                         mix["valu_issue_cycles_per_trip"])})
+    else:
+        pipes["valu_flops"] = rows * f_exec_vec / dtw_s / VALU_PEAK
+    if pmc_dtw and "effective_clock_ghz" in pmc_dtw and "valu_issue" in pipes:
+        extra["effective_clock_ghz"] = pmc_dtw["effective_clock_ghz"]
+        extra["valu_issue_frac_at_effective_clock"] = pipes["valu_issue"] * 2.4 / pmc_dtw["effective_clock_ghz"]
+    bound = max(pipes, key=pipes.get)
+    r = {"bound": bound, "kernel": kernel, "frac": pipes[bound], "pipes": pipes,
+         "avg_launch_ms": dtw_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+         "ref_flop_rate_vs_vector_peak": rows * f_dtw_ref / dtw_s / VALU_PEAK,
+         "ref_flops_per_launch": rows * f_dtw_ref, "executed_vector_flops_per_launch": rows * f_exec_vec,
+         "executed_matrix_flops_per_launch": rows * f_exec_mat}
+    if bound == "valu_issue":
+        r.update({"achieved": extra["valu_issue_cycles_per_launch"] / dtw_s / 1e9, "peak": n_simds(torch, env.dev) * CLOCK_PEAK / 1e9, "unit": "G SIMD-issue-cycles/s"})
+    elif bound == "hbm":
+        r.update({"achieved": alg_bytes / dtw_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"})
+    elif bound == "mfma_f16":
+        r.update({"achieved": rows * f_exec_mat / dtw_s / 1e12, "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s"})
+    else:
+        r.update({"achieved": rows * f_exec_vec / dtw_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s"})
+    r.update(extra)
+    r["note"] = ("frac = the largest pipe fraction of the kernel; every entry of `pipes` is executed work / (pipe peak x measured launch time).  "
+                 "dtw_mfma_kernel forms the cosine costs of a band column with v_mfma_f32_32x32x16_f16 (f16 two-way splits of both operands, "
+                 "f32 accumulate) and runs the min-recurrence on the vector pipe: VALU issue binds it.  ref_flop_rate_vs_vector_peak prices the "
+                 "REFERENCE-shaped flop count (SURVEY 8d: 2K+7 flops per band cell) against the 157.3 TFLOP/s vector peak as earlier rounds' `frac` "
+                 "did -- it exceeds 1 because those products left the vector pipe, it is not a fraction of a roof")
+    return r
+
+
+def mfcc_kernel_model(env, S, nf, K, mfcc_s):
+    torch = env.torch
+    alg_bytes, flops = S * nf * (640 + 4 * K), S * nf * 13.2e3
+    pipes = {"hbm": alg_bytes / mfcc_s / HBM_PEAK, "valu_flops_ref": flops / mfcc_s / VALU_PEAK}
+    extra = {}
+    mix = load_json("profiles/r04_mfcc_isa_mix.json")
+    if mix and K == 5:
+        trips = S * nf / 4.0   # one trip of the tile loop = 4 frames of one wave
+        pipes["valu_issue"] = trips * mix["valu_issue_cycles_per_trip"] / (n_simds(torch, env.dev) * CLOCK_PEAK * mfcc_s)
+        pipes["lds"] = trips * mix["lds_cycles_per_trip"] / (n_simds(torch, env.dev) / 4 * CLOCK_PEAK * mfcc_s)
+        extra["isa_mix"] = ("profiles/r04_mfcc_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d LDS instructions, %.0f SIMD issue cycles and %d "
+                            "LDS-array cycles per 4-frame tile of a wave" % (mix["classes"]["valu"], mix["classes"]["lds"], mix["valu_issue_cycles_per_trip"],
+                                                                             mix["lds_cycles_per_trip"]))
+    bound = max((k for k in pipes if k != "valu_flops_ref"), key=pipes.get)
+    r = {"bound": bound, "kernel": "mfcc_kernel", "frac": pipes[bound], "pipes": pipes, "avg_launch_ms": mfcc_s * 1e3,
+         "algorithmic_bytes_per_launch": alg_bytes, "hbm_gbps": alg_bytes / mfcc_s / 1e9}
+    if bound == "hbm":
+        r.update({"achieved": alg_bytes / mfcc_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s"})
+    elif bound == "valu_issue":
+        r.update({"achieved": S * nf / 4.0 * mix["valu_issue_cycles_per_trip"] / mfcc_s / 1e9, "peak": n_simds(torch, env.dev) * CLOCK_PEAK / 1e9,
+                  "unit": "G SIMD-issue-cycles/s"})
+    else:
+        r.update({"achieved": S * nf / 4.0 * mix["lds_cycles_per_trip"] / mfcc_s / 1e9, "peak": n_simds(torch, env.dev) / 4 * CLOCK_PEAK / 1e9,
+                  "unit": "G LDS-array-cycles/s"})
+    r.update(extra)
+    r["note"] = "660 B per frame (640 B of new PCM + 4K B out) against 8 TB/s; valu_flops_ref = 13.2 kflop per frame (SURVEY 8d) against 157.3 TFLOP/s"
+    return r
+
+
+def pmc_for(S, N, T, L, K, lens, args):
+    """HBM bytes / instruction counts per launch from the committed rocprofv3 --pmc passes of this same command (a profiler cannot
+    run inside the timed process); empty for any other workload."""
+    pmc, src = {}, None
+    if args.avg_gate or args.score_mode != "max" or len(set(lens)) != 1:
+        return pmc, src
+    tj = load_json("profiles/pmc_traffic_latest.json")
+    try:
+        w = tj["workload"]
+        if (w["streams"], w["samples"], w["templates"], w["template_len"], w["mfcc_size"]) == (S, N, T, L, K):
+            for name, d in tj["kernels"].items():
+                for kn in ("mfcc", "dtw"):
+                    if kn + "_" in name and "hbm_bytes_per_launch_corrected" in d and (kn != "dtw" or "dtw_mfma" in name or "dtw" not in pmc):
+                        pmc[kn] = d
+            src = "profiles/pmc_traffic_latest.json (committed rocprofv3 --pmc passes of this command, not this run)"
+    except Exception:
+        pmc = {}
+    return pmc, src
+
+
+# ------------------------------------------------------------------------------------------------ the headline path
+class DtwCase:
+    """S synthetic streams x templates `lens` resident in HBM and the one C call that is a step."""
+
+    def __init__(self, env, S, lens, K, N, first_stream=0, want_arrays=True, avg_gate=False, avg_threshold=0.2, score_mode="max", full_scores=False,
+                 ctx=None, templates=None):
+        import numpy as np
+        ra, torch, dev = env.ra, env.torch, env.dev
+        self.env, self.S, self.lens, self.K, self.N = env, S, lens, K, N
+        self.T, self.L = len(lens), max(lens)
+        self.nf = ra.mfcc_num_frames(N)
+        self.n_win = self.nf - self.L + 1
+        self.ctx = ctx or ra.BatchContext(device=env.local_rank, host_pointers=False, full_scores=full_scores)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # templates (BASELINE.md S2): T synthetic utterances, MFCC by the HIP path, whole-matrix mean normalisation, cut to their
+        # length.  Identical arrays are handed to the CPU baseline.
+        self.templates = templates or make_templates(ra, self.ctx, torch, dev, lens, K)
+        avg_t = None
+        if avg_gate:
+            # synthetic averaged template: the frame-wise mean of the templates cut to the shortest one (the reference's
+            # MfccAverager aligns them by DTW first; only the amount of work matters here)
+            lm = min(lens)
+            avg_t = np.ascontiguousarray(np.mean([t[:lm] for t in self.templates], axis=0, dtype=np.float32), dtype=np.float32)
+        self.tmpl = ra.Templates(self.ctx, self.templates, avg=avg_t)
+        self.pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
+        self.ctx.synth_dev(SEED, first_stream, S, N, N, self.pcm.data_ptr())
+        self.want_arrays = want_arrays
+        self.scores = torch.empty((S, self.n_win, self.T), dtype=torch.float32, device=dev) if want_arrays else None
+        self.agg = torch.empty((S, self.n_win), dtype=torch.float32, device=dev) if want_arrays else None
+        self.max_det = 4
+        self.det = torch.zeros((S, self.max_det, 6), dtype=torch.int32, device=dev)
+        self.n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
+        self.cfg = ra.DetectorConfig()
+        self.cfg.score_mode = {"average": 0, "max": 1, "median": 2, "p25": 3, "p50": 4, "p75": 5, "p80": 6, "p90": 7, "p95": 8}[score_mode]
+        self.cfg.avg_threshold = avg_threshold if avg_gate else 0.0  # gate off: exactly T DTWs per scoring (SURVEY S8d)
+
+    def call(self):
+        # one C call: mfcc_kernel -> dtw kernel(s) -> aggregate kernel -> scan_kernel on the launch stream
+        self.ctx.batch_detect_dev(self.pcm.data_ptr(), self.S, self.N, self.N, self.tmpl, self.cfg, self.det.data_ptr(), self.n_det.data_ptr(),
+                                  self.max_det, self.scores.data_ptr() if self.want_arrays else None, self.agg.data_ptr() if self.want_arrays else None)
+
+    def kernel_times(self, reps):
+        """HIP events on the launch stream around every launch (rp_ctx_timing_*): avg ms and launches per kernel."""
+        self.ctx.timing_enable(True)
+        self.ctx.timing_reset()
+        for _ in range(reps):
+            self.call()
+        self.env.torch.cuda.synchronize()
+        k = {name: self.ctx.timing_read(i) for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
+        self.ctx.timing_enable(False)
+        return k
+
+    def time_steps(self, warmup, steps, after_call=None):
+        env = self.env
+        for _ in range(warmup):
+            self.call()
+            if after_call:
+                after_call()
+        env.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.call()
+            if after_call:
+                after_call()
+        env.fence()
+        return env.max_over_ranks(time.perf_counter() - t0)
+
+
+def bench_dtw(env):
+    args, ra, torch, dist, dev, world, rank = env.args, env.ra, env.torch, env.dist, env.dev, env.world, env.rank
+    from rustpotter_amd import sharding
+    first_stream = None
+    if args.total_streams is not None:   # strong scaling: this rank's contiguous block of the fixed stream set
+        lo, hi = sharding.shard_bounds(args.total_streams, world, rank)
+        args.streams, first_stream = hi - lo, lo
+    S, N, K = args.streams, args.samples, args.mfcc_size
+    lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
+    want_arrays = not (args.avg_gate or args.detect_only)  # the per-window arrays are defined for every window: asking for them keeps every DTW
+    case = DtwCase(env, S, lens, K, N, first_stream=sharding.weak_first_stream(S, rank) if first_stream is None else first_stream,
+                   want_arrays=want_arrays, avg_gate=args.avg_gate, avg_threshold=args.avg_threshold, score_mode=args.score_mode, full_scores=args.full_scores)
+    T, L, nf, n_win = case.T, case.L, case.nf, case.n_win
+
+    # final per-stream result gather (RCCL over xGMI); shards of a fixed stream set may differ by one stream
+    gather_ms = []
+
+    def gather():
+        if world == 1:
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _ = sharding.gather_per_stream(case.n_det, world) if first_stream is None else sharding.gather_ragged(case.n_det, world)
+        b.record()
+        gather_ms.append((a, b))
+
+    dt = case.time_steps(args.warmup, args.steps, after_call=gather)
+    scorings_per_step = (S * world if args.total_streams is None else args.total_streams) * n_win
+    value = scorings_per_step * args.steps / dt
+
+    # ---- rooflines, measured live with HIP events on the launch stream (rp_ctx_timing_*: one event pair per launch)
+    k_ms = case.kernel_times(max(2, min(args.steps, 5)))
+    pmc, pmc_src = pmc_for(S, N, T, L, K, lens, args)
+    dtw_s, mfcc_s = k_ms["dtw"][0] * 1e-3, k_ms["mfcc"][0] * 1e-3
+    r_dtw = dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc.get("dtw"))
+    r_mfcc = mfcc_kernel_model(env, S, nf, K, mfcc_s)
+    for r, kn in ((r_dtw, "dtw"), (r_mfcc, "mfcc")):
+        r["launches_timed"] = k_ms[kn][1]
+        d = pmc.get(kn, {})
+        r["traffic"] = d.get("hbm_bytes_per_launch_corrected")
+        r["traffic_source"] = pmc_src if kn in pmc else None
+        if r["traffic"]:
+            r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes_per_launch"]
+        if "instructions_per_launch" in d:
+            r["pmc_valu_insts_per_launch"] = d["instructions_per_launch"]["SQ_INSTS_VALU"]
+        for kf, lab in (("valu_busy_frac", "pmc_valu_busy_frac_derived"), ("mfma_busy_frac", "pmc_mfma_busy_frac")):
+            if kf in d:
+                r[lab] = d[kf]
+        if "pmc_valu_busy_frac_derived" in r:
+            r["pmc_note"] = ("pmc_valu_busy_frac_derived is a construct, not a counter: (4 x SQ_ACTIVE_INST_VALU - SQ_VALU_MFMA_BUSY_CYCLES) / (SIMDs x shader "
+                             "cycles), tools/collect_profiles.py; the raw ratio 4 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles) is above 1")
+    if r_dtw.get("traffic_over_algorithmic", 0) > 1.3:
+        r_dtw["traffic_note"] = ("the LDS-staged 32-window tiles restage L + 3 frames of MFCC per tile: FETCH is ~2.4x the 0.52 GB MFCC array; at ~170 GB/s "
+                                 "this kernel is nowhere near HBM-bound, the re-reads cost nothing today")
+    dom = max(("mfcc", "dtw"), key=lambda n: k_ms[n][0])
+    roofline = dict(r_dtw if dom == "dtw" else r_mfcc)
+    roofline["kernels_ms"] = {k: round(v[0], 4) for k, v in k_ms.items()}
+    if k_ms["aggregate"][1] == 0:  # no launch of the aggregate pass: ScoreMode::Max ran inside the DTW kernel (DESIGN.md 4.2b)
+        roofline["aggregate_inside_dtw_kernel"] = True
+    work_skipped = args.detect_only or (args.avg_gate and not args.full_scores)
+    f_dtw_ref = sum(cells(Lt) * (2 * K + 7) + 2 * Lt * 2 * K + 2 * Lt * K for Lt in lens)
+    roofline["path_hbm_frac"] = (value / world) * (640 + 4 * (T + 2)) / HBM_PEAK
+    roofline["path_ref_flop_rate_vs_vector_peak"] = (value / world) * (13.2e3 * nf / n_win + f_dtw_ref) / VALU_PEAK
+
+    by_len = {}
+    for Lt in lens:
+        by_len[Lt] = by_len.get(Lt, 0) + 1
+    n_chunks = sum(-(-c // 8) for c in by_len.values())
+    tag = {(65536, 8): "C3", (8192, 64): "C4 (per-GPU share)", (1024, 8): "C2"}.get((S, T), "custom") if len(set(lens)) == 1 and lens[0] == 100 else "custom"
+    if args.total_streams is not None:
+        tag = "C4"
+    mfma_kernel = "mfma" in r_dtw["kernel"]
+    config = {"workload": "%s: %s synthetic 16 kHz f32 streams x %d templates%s (%g s streams, L=%s, K=%d, band 5, "
+                          "ScoreMode::%s, %s)" % (tag, ("%d" % S) if args.total_streams is None else ("%d" % args.total_streams), T,
+                                                  " per GPU" if args.total_streams is None else " split over %d rank(s) by stream" % world,
+                                                  N / 16000.0, lens[0] if len(set(lens)) == 1 else "/".join(map(str, lens)), K,
+                                                  args.score_mode.capitalize(),
+                                                  ("averaged template + avg_threshold %g%s, " % (args.avg_threshold, " (reference default)" if args.avg_threshold == 0.2 else "") +
+                                                   ("every window scored anyway" if args.full_scores else "gated windows skipped"))
+                                                  if args.avg_gate else ("avg gate off" + (", detect-only call: DTWs that cannot reach threshold 0.5 "
+                                                                                          "any more are abandoned" if args.detect_only else ""))),
+              "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
+              "windows_per_stream": n_win, "template_chunks": n_chunks,
+              "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world}
+    config.update(env.common_config())
+    if world > 1:
+        torch.cuda.synchronize()
+        g = [a.elapsed_time(b) for a, b in gather_ms[args.warmup:]]
+        config["gather_ms_per_step"] = {"mean": sum(g) / len(g), "max": max(g), "what": "all_gather of the per-stream detection counts, HIP events on the "
+                                        "launch stream around the collective (every step; the first %d are warm-up)" % args.warmup}
+    out = {
+        "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if args.total_streams is None else "strong", "vs_baseline": None,
+        "dtype": DTYPE_DTW if mfma_kernel else DTYPE_DTW_VECTOR, "data": "synthetic", "config": config,
+        # work is skipped by design in detect-only / gated runs: pricing the full flop count against the shorter time would
+        # print a fraction above 1, so those lines carry the kernel times only
+        "roofline": roofline if not work_skipped else None,
+        "roofline_other": (r_mfcc if dom == "dtw" else r_dtw) if not work_skipped else None,
+    }
+    if work_skipped:
+        out["kernels_ms"] = roofline["kernels_ms"]
+        out["note"] = "work is skipped by design in this mode (gated windows / abandoned DTWs): no roofline fraction is quoted"
+    if env.backend != "nccl" and world > 1:
+        out["oversubscribed"] = {"devices": torch.cuda.device_count(), "backend": env.backend,
+                                 "note": "ranks share GPUs: a launch-path dry run, not a scaling measurement"}
+    pairs = case.ctx.dtw_ref_pairs()
+    out["dtw_reference_cell_pairs"] = pairs   # windows whose frame norms left the scale-invariant range (rp_ctx_dtw_ref_pairs): 0 on this input
+    if args.avg_gate:
+        # how many windows pass the gate on this input (one extra pass over the averaged template, not timed)
+        mf = torch.empty((S, nf, K), dtype=torch.float32, device=dev)
+        case.ctx.mfcc_dev(case.pcm.data_ptr(), S, N, N, K, mf.data_ptr())
+        sc_ = torch.empty((S, n_win, T), dtype=torch.float32, device=dev)
+        av_ = torch.empty((S, n_win), dtype=torch.float32, device=dev)
+        ag_ = torch.empty((S, n_win), dtype=torch.float32, device=dev)
+        case.ctx.dtw_dev(mf.data_ptr(), S, nf, case.tmpl, case.cfg.score_ref, case.cfg.band_size, case.cfg.score_mode, 1, sc_.data_ptr(), av_.data_ptr(), ag_.data_ptr())
+        torch.cuda.synchronize()
+        out["config"]["avg_threshold"] = case.cfg.avg_threshold
+        out["config"]["gate_pass_fraction"] = float((~(av_ < case.cfg.avg_threshold)).float().mean().item())
+        qs = torch.quantile(av_.flatten()[:: max(1, av_.numel() // 4000000)], torch.tensor([0.001, 0.01, 0.1, 0.5, 0.9, 0.99, 0.999], device=dev))
+        out["config"]["avg_score_quantiles"] = {"q": [0.001, 0.01, 0.1, 0.5, 0.9, 0.99, 0.999], "avg_score": [round(float(x), 4) for x in qs]}
+        del mf, sc_, av_, ag_
+
+    plain = world == 1 and not work_skipped and not args.avg_gate and len(set(lens)) == 1 and not args.no_extras
+    # ---- the same step with the cosine products on the vector pipe (the register kernels): what "f32" in the strict sense costs
+    if plain and mfma_kernel:
+        os.environ["RP_DTW_MFMA"] = "0"   # read per call by the library
+        try:
+            dtv = case.time_steps(1, 2)
+            kv = case.kernel_times(2)
+        finally:
+            del os.environ["RP_DTW_MFMA"]
+        out["vector_only"] = {"what": "RP_DTW_MFMA=0: every DTW kernel of the register family (dtw_band_kernel: the five multiply-adds of a cell as "
+                                      "v_pk_fma_f32), 2 steps", "dtype": DTYPE_DTW_VECTOR, "value": S * n_win * 2 / dtv, "unit": "scorings/s",
+                              "ms_per_step": dtv / 2 * 1e3, "kernels_ms": {k: round(v[0], 4) for k, v in kv.items()},
+                              "executed_vector_flop_frac": S * n_win * (sum((Lt - 1) * 10 * (2 * K + 3) for Lt in lens) + n_chunks * ((L - 1) * (4 * K + 1) + L * K)) /
+                              (kv["dtw"][0] * 1e-3) / VALU_PEAK}
+
+    # ---- CPU baseline: the oracle's restatement of the reference algorithm on this host's cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.avg_gate and len(set(lens)) == 1:
+        out["cpu_baseline"] = cpu_baseline_dtw(env, N, case.templates, n_win, T)
+
+    if plain and tag == "C3":
+        # ---- the other BASELINE configs, short, in the same process (round-3 review: the driver only ever timed C3)
+        extras = {}
+        try:
+            extras["C2"] = extra_c2(env, case, lens, K, N)
+        except Exception as e:   # an extra must never take the headline line with it
+            extras["C2"] = {"error": repr(e)}
+        del case.scores, case.agg
+        torch.cuda.empty_cache()
+        for prec in ("bf16", "f32"):
+            try:
+                extras["C5_" + prec] = extra_c5(env, prec)
+            except Exception as e:
+                extras["C5_" + prec] = {"error": repr(e)}
+        out["extra_configs"] = extras
+        try:
+            out["h2d_included"] = ingest_measure(env, case, blocks=2, block_streams=min(8192, S), fmt="f32")
+        except Exception as e:
+            out["h2d_included"] = {"error": repr(e)}
+    return out
+
+
+def cpu_baseline_dtw(env, N, templates, n_win, T):
+    from oracle import rp_oracle as orc
+    args, cores = env.args, env.cores
+    secs, sc, _ = orc.bench(SEED, cores, N, templates, threads=cores)  # calibration: 1 stream per core
+    rate = sc / secs
+    s_cpu = int(max(cores, min(4096 * cores, args.cpu_seconds * rate / n_win)))
+    secs, sc, _ = orc.bench(SEED, s_cpu, N, templates, threads=cores)
+    res = {"value": sc / secs, "unit": "scorings/s", "cores": cores, "kind": "port", "host_cpu": env.cpu_model,
+           "sample": "%d of the same synthetic streams x %d templates, %d scorings in %.1f s; C restatement of "
+                     "the reference algorithm (complex FFT-480 per frame, dense mel, 3-dot cosine per DTW cell), "
+                     "not the Rust crate" % (s_cpu, T, sc, secs)}
+    # BASELINE.md S2 (i): one thread
+    s1 = int(max(1, min(64, 2.0 * (rate / cores) / n_win)))
+    secs1, sc1, _ = orc.bench(SEED, s1, N, templates, threads=1)
+    res["one_thread"] = {"value": sc1 / secs1, "unit": "scorings/s", "cores": 1, "sample": "%d streams, %d scorings in %.1f s on one thread" % (s1, sc1, secs1)}
+    return res
+
+
+def extra_c2(env, case, lens, K, N):
+    """BASELINE config C2 = the first 1 024 streams of the same input, same templates, same context."""
+    torch = env.torch
+    S2 = 1024
+    c2 = DtwCase.__new__(DtwCase)
+    c2.__dict__.update(case.__dict__)
+    c2.S = S2
+    c2.pcm = case.pcm[:S2]
+    c2.scores, c2.agg = case.scores[:S2], case.agg[:S2]
+    c2.det, c2.n_det = case.det[:S2], case.n_det[:S2]
+    dt = c2.time_steps(5, 50)
+    k = c2.kernel_times(5)
+    r = dtw_kernel_model(env, S2, case.n_win, lens, K, k["dtw"][0] * 1e-3, None)
+    return {"workload": "C2: 1024 synthetic 16 kHz f32 streams x %d templates (same input, templates and context as the headline run)" % case.T,
+            "value": S2 * case.n_win * 50 / dt, "unit": "scorings/s", "steps": 50, "warmup": 5, "ms_per_step": dt / 50 * 1e3, "dtype": DTYPE_DTW,
+            "kernels_ms": {kk: round(v[0], 4) for kk, v in k.items()},
+            "roofline": {"bound": r["bound"], "kernel": r["kernel"], "frac": r["frac"], "pipes": r["pipes"], "note": "a launch of 9 504 tiles over 3 072 resident "
+                         "waves is 3.1 rounds: the last round runs a tenth full"},
+            "path_hbm_frac": S2 * case.n_win * 50 / dt * (640 + 4 * (case.T + 2)) / HBM_PEAK}
+
+
+class MlpCase:
+    """BASELINE config C5: B rows x 3 120 features (F=195 frames x K=16), Small model 3120 -> 32 -> 16 -> 2
+    (src/wakewords/nn/wakeword_nn.rs:325-345), rows resident in HBM."""
+
+    def __init__(self, env, B, precision):
+        import numpy as np
+        ra, torch, dev = env.ra, env.torch, env.dev
+        F = 195
+        self.env, self.B, self.precision = env, B, precision
+        self.dims = [F * 16, F // 6, F // 12, 2]
+        rng = np.random.default_rng(5)
+        self.ws = [(rng.standard_normal((self.dims[i + 1], self.dims[i])) / np.sqrt(self.dims[i])).astype(np.float32) for i in range(3)]
+        self.bs = [(rng.standard_normal(self.dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+        self.ctx = ra.BatchContext(device=env.local_rank, host_pointers=False)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.model = ra.Model(self.ctx, self.ws, self.bs)
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        self.x = torch.randn((B, self.dims[0]), dtype=torch.float32, device=dev, generator=g)
+        self.out = torch.empty((B, self.dims[-1]), dtype=torch.float32, device=dev)
+
+    def call(self):
+        self.ctx.mlp_dev(self.model, self.x.data_ptr(), self.B, self.precision, self.out.data_ptr())
+
+    def measure(self, warmup, steps):
+        env, torch = self.env, self.env.torch
+        for _ in range(warmup):
+            self.call()
+        env.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.call()
+        env.fence()
+        dt = env.max_over_ranks(time.perf_counter() - t0)
+        self.ctx.timing_enable(True)
+        self.ctx.timing_reset()
+        for _ in range(5):
+            self.call()
+        torch.cuda.synchronize()
+        ms, n = self.ctx.timing_read(4)
+        self.ctx.timing_enable(False)
+        return dt, ms, n
+
+    def roofline(self, ms, n):
+        B, dims = self.B, self.dims
+        alg = B * (dims[0] * 4 + dims[-1] * 4)
+        kname = self.ctx.last_mlp_kernel()
+        traffic, traffic_src = None, None
+        tj = load_json("profiles/pmc_c5_latest.json" if self.precision == "bf16" else "profiles/pmc_c5_f32_latest.json")
+        try:
+            w = tj["workload"]
+            if (w["rows"], w["features"], w["precision"]) == (B, dims[0], self.precision):
+                for name, d in tj["kernels"].items():
+                    if name.startswith(kname.split("<")[0]) and "hbm_bytes_per_launch_corrected" in d:
+                        traffic = d["hbm_bytes_per_launch_corrected"]
+                        traffic_src = "profiles/%s (committed rocprofv3 --pmc passes of this command, not this run)" % ("pmc_c5_latest.json" if self.precision == "bf16" else "pmc_c5_f32_latest.json")
+        except Exception:
+            pass
+        flops = B * 2.0 * sum(dims[i] * dims[i + 1] for i in range(3))
+        mult = 3.0 if "f16x2" in kname else 1.0   # the split form issues three matrix products per layer-1 product
+        r = {"bound": "hbm", "kernel": kname, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK,
+             "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": ms, "launches_timed": n, "algorithmic_bytes_per_launch": alg,
+             "pipes": {"hbm": alg / (ms * 1e-3) / HBM_PEAK, "mfma_f16": mult * flops / (ms * 1e-3) / MFMA_F16_PEAK},
+             "note": "12 480 B of features in + 8 B of logits out per row (SURVEY.md 8d) against 8 TB/s; avg_launch_ms covers every launch of the forward "
+                     "(the split form is followed by a pass over the listed out-of-range rows: none here)"}
+        if traffic:
+            r["traffic_over_algorithmic"] = traffic / alg
+        return r
+
+    def cpu_baseline(self, seconds):
+        import threading
+        from oracle import rp_oracle as orc
+        cores = self.env.cores
+        xh = self.x[:4096].cpu().numpy()
+        t0 = time.perf_counter()
+        orc.mlp_forward(xh[:256], self.ws, self.bs)
+        per_row = (time.perf_counter() - t0) / 256
+        n_cpu = int(max(cores, seconds * cores / per_row))   # rows of the same input, cycled per thread
+        per_thread = max(1, n_cpu // cores)
+
+        def work():
+            left = per_thread
+            while left > 0:
+                n = min(left, xh.shape[0])
+                orc.mlp_forward(xh[:n], self.ws, self.bs)   # ctypes releases the GIL: the threads run on separate cores
+                left -= n
+        th = [threading.Thread(target=work) for _ in range(cores)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        secs = time.perf_counter() - t0
+        n1 = int(max(64, min(4096, 1.0 / per_row)))
+        t0 = time.perf_counter()
+        orc.mlp_forward(xh[:n1], self.ws, self.bs)
+        s1 = time.perf_counter() - t0
+        return {"value": per_thread * cores / secs, "unit": "rows/s", "cores": cores, "kind": "port", "host_cpu": self.env.cpu_model,
+                "sample": "%d of the same rows through the same model in %.1f s on %d threads; C restatement of the reference "
+                          "forward (f32 Linear -> ReLU chain), not the Rust crate / candle" % (per_thread * cores, secs, cores),
+                "one_thread": {"value": n1 / s1, "unit": "rows/s", "cores": 1, "sample": "%d rows in %.2f s on one thread" % (n1, s1)}}
+
+
+MLP_DTYPE = {"bf16": "bf16 inputs, f32 accumulate", "f32": "f32 (layer-1 products: f16x2-split MFMA, 22-bit; rows beyond the f16 range: f32 MFMA)",
+             "f32_strict": "f32 (f32 matrix instructions)"}
+
+
+def extra_c5(env, precision):
+    case = MlpCase(env, 65536, precision)
+    dt, ms, n = case.measure(5, 50)
+    r = case.roofline(ms, n)
+    res = {"workload": "C5: 65536 rows x 3120 features, MLP 3120->32->16->2, %s" % precision, "value": case.B * 50 / dt, "unit": "rows/s", "steps": 50, "warmup": 5,
+           "ms_per_step": dt / 50 * 1e3, "dtype": MLP_DTYPE[precision], "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "pipes")}}
+    if not env.args.no_cpu_baseline and precision == "f32":
+        res["cpu_baseline"] = case.cpu_baseline(2.0)
+    del case
+    env.torch.cuda.empty_cache()
+    return res
+
+
+def bench_mlp(env):
+    args, world = env.args, env.world
+    case = MlpCase(env, args.streams, args.mlp_precision)
+    dt, ms, n = case.measure(args.warmup, args.steps)
+    config = {"workload": "C5: %d rows x %d features, MLP %s" % (case.B, case.dims[0], "->".join(map(str, case.dims)))}
+    config.update(env.common_config())
+    res = {"metric": "wakeword-model rows/sec (BASELINE config C5)", "value": case.B * world * args.steps / dt, "unit": "rows/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": MLP_DTYPE[args.mlp_precision], "data": "synthetic",
+           "config": config, "roofline": case.roofline(ms, n)}
+    # ---- CPU baseline: the oracle's restatement of the reference forward (candle's Linear -> ReLU chain, f32) on this host's cores
+    if env.rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = case.cpu_baseline(args.cpu_seconds)
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ H2D included
+def ingest_measure(env, case, blocks, block_streams, fmt):
+    """The headline path with the PCM starting in pinned HOST memory (SURVEY 8d "H2D included"): the streams arrive in blocks of
+    `block_streams`; block k+1's hipMemcpyAsync runs on a copy stream while block k's kernels run on the launch stream (two device
+    buffers), the detections of every block are copied back to pinned host memory.  Two pinned host blocks are cycled (the same bytes
+    cross PCIe again: the link does not care), so the sample is bounded by `blocks`, not by the host's memory."""
+    ra, torch, dev = env.ra, env.torch, env.dev
+    Sb, N = block_streams, case.N
+    tdt = torch.float32 if fmt == "f32" else torch.int16
+    sfmt = 3 if fmt == "f32" else 1
+    src = case.pcm[:Sb] if fmt == "f32" else (case.pcm[:Sb] * 32767.0).round().clamp(-32768, 32767).to(torch.int16)
+    host = [torch.empty((Sb, N), dtype=tdt, pin_memory=True) for _ in range(2)]
+    for h in host:
+        h.copy_(src)
+    dbuf = [torch.empty((Sb, N), dtype=tdt, device=dev) for _ in range(2)]
+    det_h = torch.empty((Sb, case.max_det, 6), dtype=torch.int32, pin_memory=True)
+    ndet_h = torch.empty((Sb,), dtype=torch.int32, pin_memory=True)
+    det = torch.zeros((Sb, case.max_det, 6), dtype=torch.int32, device=dev)
+    n_det = torch.zeros((Sb,), dtype=torch.int32, device=dev)
+    main = torch.cuda.current_stream()
+    copy = torch.cuda.Stream(device=dev)
+    landed = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+    bytes_block = Sb * N * (4 if fmt == "f32" else 2)
+
+    def run(n_blocks):
+        for i in range(2):
+            freed[i].record(main)
+        with torch.cuda.stream(copy):
+            copy.wait_event(freed[0])
+            dbuf[0].copy_(host[0], non_blocking=True)
+            landed[0].record(copy)
+        for k in range(n_blocks):
+            cur = k & 1
+            if k + 1 < n_blocks:   # the next block's copy goes out before this block's kernels are queued
+                nxt = (k + 1) & 1
+                with torch.cuda.stream(copy):
+                    copy.wait_event(freed[nxt])
+                    dbuf[nxt].copy_(host[nxt], non_blocking=True)
+                    landed[nxt].record(copy)
+            main.wait_event(landed[cur])
+            case.ctx.batch_detect_fmt_dev(dbuf[cur].data_ptr(), sfmt, Sb, N, N, case.tmpl, case.cfg, det.data_ptr(), n_det.data_ptr(), case.max_det)
+            freed[cur].record(main)
+            det_h.copy_(det, non_blocking=True)
+            ndet_h.copy_(n_det, non_blocking=True)
+        torch.cuda.synchronize()
+
+    run(2)   # warm-up: allocations of the context's workspaces for this block size
+    t0 = time.perf_counter()
+    run(blocks)
+    dt = time.perf_counter() - t0
+    # the same blocks with the input already resident (no copies): what the kernels alone take
+    case.ctx.timing_enable(True)
+    case.ctx.timing_reset()
+    for _ in range(2):
+        case.ctx.batch_detect_fmt_dev(dbuf[0].data_ptr(), sfmt, Sb, N, N, case.tmpl, case.cfg, det.data_ptr(), n_det.data_ptr(), case.max_det)
+    torch.cuda.synchronize()
+    k = {name: case.ctx.timing_read(i)[0] for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
+    case.ctx.timing_enable(False)
+    kern = sum(k.values())
+    # one copy alone
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(main)
+    dbuf[0].copy_(host[0], non_blocking=True)
+    b.record(main)
+    torch.cuda.synchronize()
+    copy_ms = a.elapsed_time(b)
+    scor = Sb * case.n_win * blocks
+    res = {"what": "PCM in pinned host memory (%s), %d blocks of %d streams, block k+1's hipMemcpyAsync on a copy stream under block k's kernels, detections "
+                   "copied back per block; detect-only calls (no per-window score arrays leave the device)" % (fmt, blocks, Sb),
+           "value": scor / dt, "unit": "scorings/s", "ms_per_block": dt / blocks * 1e3, "pcie_gbps_achieved": bytes_block * blocks / dt / 1e9,
+           "copy_alone_ms_per_block": copy_ms, "copy_alone_gbps": bytes_block / (copy_ms * 1e-3) / 1e9,
+           "kernels_ms_per_block": {kk: round(v, 4) for kk, v in k.items()}, "kernels_sum_ms_per_block": kern,
+           "overlap": "a block takes max(copy, kernels) when the two overlap: copy %.2f ms, kernels %.2f ms, measured %.2f ms per block" % (copy_ms, kern, dt / blocks * 1e3),
+           "bytes_per_scoring_over_pcie": bytes_block / (Sb * case.n_win)}
+    del host, dbuf
+    return res
+
+
+def bench_ingest(env):
+    args, ra, torch = env.args, env.ra, env.torch
+    assert env.world == 1, "--ingest is a single-GPU measurement"
+    S, N, K = args.streams, args.samples, args.mfcc_size
+    lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
+    Sb = min(args.ingest_block, S)
+    case = DtwCase(env, Sb, lens, K, N, want_arrays=False)
+    blocks = max(2, S // Sb)
+    r = ingest_measure(env, case, blocks=blocks, block_streams=Sb, fmt=args.ingest_format)
+    config = {"workload": "%d synthetic 16 kHz %s streams x %d templates from pinned host memory in %d blocks of %d" % (Sb * blocks, args.ingest_format, case.T, blocks, Sb)}
+    config.update(env.common_config())
+    out = {"metric": "10ms-frame MFCC+DTW scorings/sec (H2D included)", "value": r["value"], "unit": "scorings/s", "n_gpus": 1, "steps": blocks, "warmup": 2,
+           "ms_per_step": r["ms_per_block"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_DTW, "data": "synthetic",
+           "config": config, "h2d_included": r,
+           "roofline": {"bound": "pcie", "kernel": "hipMemcpyAsync H2D", "achieved": r["pcie_gbps_achieved"], "peak": 64.0, "unit": "GB/s", "frac": r["pcie_gbps_achieved"] / 64.0,
+                        "traffic": None, "note": "the link binds: PCIe 5.0 x16 = 64 GB/s per direction nominal; the kernels of a block take %.2f ms of its %.2f ms" %
+                        (r["kernels_sum_ms_per_block"], r["ms_per_block"])}}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ other modes
+def bench_stream(env):
     """Live serving shape of the same path: S streams per GPU, every call brings --chunks-per-call new
     30 ms chunks per stream (f32, resident in HBM) and returns that call's detections; extractor history,
     MFCC window and detector state stay on the device between calls."""
+    args, ra, torch, dist, dev, world = env.args, env.ra, env.torch, env.dist, env.dev, env.world
     S, T, n = args.streams, args.templates, args.chunks_per_call
-    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
+    ctx = ra.BatchContext(device=env.local_rank, host_pointers=False)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
     T = len(lens)
@@ -416,7 +898,6 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
     cfg = ra.DetectorConfig()
     cfg.avg_threshold = 0.0
     sb = ra.StreamBatch(ctx, tmpl, cfg, S, max_chunks_per_call=n)
-    n_calls = args.warmup + args.steps + 5
     pcm = torch.empty((S, 480 * n * 4), dtype=torch.float32, device=dev)  # 4 distinct calls' worth, cycled
     ctx.synth_dev(SEED, 0, S, pcm.shape[1], pcm.shape[1], pcm.data_ptr())
     det = torch.zeros((S, 4, 6), dtype=torch.int32, device=dev)
@@ -431,20 +912,12 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
     # fill the window first so that every timed call scores complete windows
     for _ in range(-(-max(lens) // (3 * n)) + 1 + args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    env.fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    env.fence()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
     ctx.timing_enable(True)
     ctx.timing_reset()
     for _ in range(5):
@@ -452,27 +925,25 @@ def bench_stream(args, ra, torch, dist, dev, world, rank, local_rank):
     torch.cuda.synchronize()
     k_ms = {name: round(ctx.timing_read(i)[0], 4) for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
     ms = dt / args.steps * 1e3
-    res = {"metric": "10ms-frame MFCC+DTW scorings/sec (streaming calls)", "value": S * 3 * n * world * args.steps / dt,
-           "unit": "scorings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%d live streams x %d templates (%s frames) per GPU, %d chunk(s) of 30 ms per call" % (S, T, "/".join(str(x) for x in sorted(set(lens))), n),
-                      "real_time_factor": 30.0 * n / ms, "kernels_ms": k_ms}}
-    if rank == 0:
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    config = {"workload": "%d live streams x %d templates (%s frames) per GPU, %d chunk(s) of 30 ms per call" % (S, T, "/".join(str(x) for x in sorted(set(lens))), n),
+              "real_time_factor": 30.0 * n / ms, "kernels_ms": k_ms}
+    config.update(env.common_config())
+    return {"metric": "10ms-frame MFCC+DTW scorings/sec (streaming calls)", "value": S * 3 * n * world * args.steps / dt,
+            "unit": "scorings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_DTW, "data": "synthetic", "config": config}
 
 
-def bench_resample(args, ra, torch, dist, dev, world, rank, local_rank):
+def bench_resample(env):
     """The sample-rate converter in front of the path: S streams of 4 s at 48 kHz f32 -> 16 kHz."""
-    if world > 1:
+    args, ra, torch, dev = env.args, env.ra, env.torch, env.dev
+    if env.world > 1:
         raise SystemExit("--mode resample is a single-GPU measurement (launch it with --gpus 1)")
     fs = 48000
     S = min(args.streams, 16384)  # 16384 x 4 s x 48 kHz f32 = 12.6 GB in, 4.2 GB out, + the staged copy
     fi, fo = ra.resampler_frame_lengths(fs)
     n = args.samples * 3
     nch = n // fi
-    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
+    ctx = ra.BatchContext(device=env.local_rank, host_pointers=False)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ch = args.channels
     pcm = torch.empty((S, n), dtype=torch.float32, device=dev)
@@ -511,118 +982,11 @@ def bench_resample(args, ra, torch, dist, dev, world, rank, local_rank):
         roof = {"bound": "hbm", "kernel": "resample48_fft_kernel", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK, "traffic": None, "avg_launch_ms": ms,
                 "valu_frac_fp32": S * nch * 110e3 / (ms * 1e-3) / VALU_PEAK}
-    res = {"metric": "resampled 10ms output frames/sec (48 kHz -> 16 kHz)", "value": S * nch * 3 / dt, "unit": "frames/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%d streams x %d samples at 48 kHz %s, %d channel(s)" % (S, n, args.pcm_format, ch)},
-           "roofline": roof}
-    if rank == 0:
-        print(json.dumps(res))
-
-
-def bench_mlp(args, ra, torch, dist, dev, world, rank, local_rank):
-    """BASELINE config C5: B = 65 536 rows x 3 120 features (F=195 frames x K=16), Small model
-    3120 -> 32 -> 16 -> 2 (src/wakewords/nn/wakeword_nn.rs:325-345), rows resident in HBM."""
-    import numpy as np
-    B, F, K = args.streams, 195, 16
-    dims = [F * K, F // 6, F // 12, 2]
-    rng = np.random.default_rng(5)
-    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
-    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
-    ctx = ra.BatchContext(device=local_rank, host_pointers=False)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    model = ra.Model(ctx, ws, bs)
-    x = torch.randn((B, dims[0]), dtype=torch.float32, device=dev)
-    out = torch.empty((B, dims[-1]), dtype=torch.float32, device=dev)
-
-    def step():
-        ctx.mlp_dev(model, x.data_ptr(), B, args.mlp_precision, out.data_ptr())
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ctx.timing_enable(True)
-    ctx.timing_reset()
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize()
-    ms, _n = ctx.timing_read(4)
-    alg = B * (dims[0] * 4 + dims[-1] * 4)
-    stream = os.environ.get("RP_MLP_STREAM", "1") != "0"
-    kname = "mlp_stream_kernel" if stream else "mlp_mfma_kernel"
-    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (a profiler cannot run inside the
-    # timed process); null for any other workload
-    traffic, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_c5_latest.json")))
-        w = tj["workload"]
-        if (w["rows"], w["features"], w["precision"]) == (B, dims[0], args.mlp_precision):
-            for name, d in tj["kernels"].items():
-                if name.startswith(kname) and "hbm_bytes_per_launch_corrected" in d:
-                    traffic = d["hbm_bytes_per_launch_corrected"]
-                    traffic_src = "profiles/pmc_c5_latest.json (committed rocprofv3 --pmc passes of this command, not this run)"
-    except Exception:
-        pass
-    res = {"metric": "wakeword-model rows/sec (BASELINE config C5)", "value": B * world * args.steps / dt, "unit": "rows/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16 inputs, f32 accumulate" if args.mlp_precision == "bf16" else "f32", "data": "synthetic",
-           "config": {"workload": "C5: %d rows x %d features, MLP %s" % (B, dims[0], "->".join(map(str, dims)))},
-           "roofline": {"bound": "hbm", "kernel": kname, "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": alg / (ms * 1e-3) / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                        "avg_launch_ms": ms, "launches_timed": _n, "algorithmic_bytes_per_launch": alg,
-                        "note": "12 480 B of features in + 8 B of logits out per row (SURVEY.md 8d) against 8 TB/s"}}
-    # ---- CPU baseline: the oracle's restatement of the reference forward (candle's Linear -> ReLU chain, f32) on this host's cores
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import threading
-        from oracle import rp_oracle as orc
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        try:
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-            if quota != "max":
-                cores = max(1, min(cores, int(int(quota) / int(period))))
-        except Exception:
-            pass
-        xh = x[:4096].cpu().numpy()
-        t0 = time.perf_counter()
-        orc.mlp_forward(xh[:256], ws, bs)
-        per_row = (time.perf_counter() - t0) / 256
-        n_cpu = int(max(cores, args.cpu_seconds * cores / per_row))   # rows of the same input, cycled per thread
-        per_thread = max(1, n_cpu // cores)
-
-        def work():
-            left = per_thread
-            while left > 0:
-                n = min(left, xh.shape[0])
-                orc.mlp_forward(xh[:n], ws, bs)   # ctypes releases the GIL: the threads run on separate cores
-                left -= n
-        th = [threading.Thread(target=work) for _ in range(cores)]
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        secs = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": per_thread * cores / secs, "unit": "rows/s", "cores": cores, "kind": "port",
-                               "sample": "%d of the same rows through the same model in %.1f s on %d threads; C restatement of the reference "
-                                         "forward (f32 Linear -> ReLU chain), not the Rust crate / candle" % (per_thread * cores, secs, cores)}
-    if rank == 0:
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    config = {"workload": "%d streams x %d samples at 48 kHz %s, %d channel(s)" % (S, n, args.pcm_format, ch)}
+    config.update(env.common_config())
+    return {"metric": "resampled 10ms output frames/sec (48 kHz -> 16 kHz)", "value": S * nch * 3 / dt, "unit": "frames/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config, "roofline": roof}
 
 
 if __name__ == "__main__":

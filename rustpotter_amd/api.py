@@ -901,6 +901,14 @@ class BatchContext:
                                    scores_ptr, agg_ptr) < 0:
             raise _err()
 
+    def batch_detect_fmt_dev(self, pcm_ptr, fmt, S, N, stride, templates, detector_config, det_ptr, n_det_ptr, max_det,
+                             scores_ptr=None, agg_ptr=None):
+        """rp_batch_detect_fmt on device pointers: pcm in one of the reference's sample formats (SampleFormat: 1 = i16, 3 = f32)."""
+        c = detector_config._c()
+        if self._L.rp_batch_detect_fmt(self._h, pcm_ptr, int(fmt), S, N, stride, templates._h, C.byref(c), det_ptr, n_det_ptr, max_det,
+                                       scores_ptr, agg_ptr) < 0:
+            raise _err()
+
     def mlp_forward(self, x, model, precision="f32"):
         import numpy as np
         assert self.host

@@ -207,6 +207,13 @@ static uint16_t f16_rtz_bits(float v) {
     if (e < -14) return (uint16_t)(sign | ((0x800000u | mant) >> (-e - 1)));
     return (uint16_t)(sign | ((uint32_t)(e + 15) << 10) | (mant >> 13));
 }
+// f32 -> f16 bits, round to nearest even: the SECOND part of a split (rp_device.h pk_f16_second)
+static uint16_t f16_rtn_bits(float v) {
+    const _Float16 h = (_Float16)v;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
 static float f16_bits_to_f32(uint16_t hb) {
     const int e = (hb >> 10) & 0x1f;
     const uint32_t m = hb & 0x3ffu;
@@ -215,7 +222,7 @@ static float f16_bits_to_f32(uint16_t hb) {
 }
 
 // dtw_mfma_kernel's A operand of one chunk (rp_dtw_mfma.hip): per template row r [k half 2][template slot 8] x 8 f16.  With
-// a = -(unit row) = a0 + a1 (a0 = rtz_f16(a), a1 = rtz_f16(a - a0)) and the half's components (ca, cb) = (0, 1) / (3, 4), the eight
+// a = -(unit row) = a0 + a1 (a0 = rtz_f16(a), a1 = rtn_f16(a - a0)) and the half's components (ca, cb) = (0, 1) / (3, 4), the eight
 // slots pair with the window side's (xa0, xb0 | xa1, xb1 | xa0, xb0 | x2_0, x2_1 or 1.0):
 //   [ca.0, cb.0 | ca.0, cb.0 | ca.1, cb.1 | half 0: c2.0, c2.0 / half 1: c2.1, 1.0]
 // i.e. x0 a0 + x1 a0 + x0 a1 for every component, and 1.0 x 1.0: the instruction accumulates 1 - a.x.  Slots past the chunk's
@@ -230,7 +237,7 @@ static void append_mfma_image(std::vector<uint16_t> &img, const DtwChunk &c, con
             for (int k = 0; k < K; ++k) {
                 const float a = -unit[((size_t)c.tid[t] * Lpad + r) * K + k];
                 p[k][0] = f16_rtz_bits(a);
-                p[k][1] = f16_rtz_bits(a - f16_bits_to_f32(p[k][0]));
+                p[k][1] = f16_rtn_bits(a - f16_bits_to_f32(p[k][0]));
             }
             for (int kh = 0; kh < 2; ++kh) {
                 const int ca = kh ? 3 : 0, cb = ca + 1;
@@ -259,7 +266,7 @@ static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c
                     if (comp >= K) return 0;
                     const float a = -unit[((size_t)c.tid[t] * Lpad + r) * K + comp];
                     const uint16_t a0 = f16_rtz_bits(a);
-                    return which == 0 ? a0 : f16_rtz_bits(a - f16_bits_to_f32(a0));
+                    return which == 0 ? a0 : f16_rtn_bits(a - f16_bits_to_f32(a0));
                 };
                 for (int j = 0; j < NPAIR; ++j) {
                     v[2 * (3 * j) + 0] = part(2 * j, 0); v[2 * (3 * j) + 1] = part(2 * j + 1, 0);

@@ -195,6 +195,20 @@ template <> struct SampleIn<int32_t> {
     static __device__ __forceinline__ float4 load4(const int32_t *p) { return cvt4(ldraw(p)); }
 };
 
+// f32 pair -> packed f16, round to nearest even (v_cvt_pk_f16_f32).  The SECOND parts of the f16 two-way splits (x1 = f16(x - x0), x0 =
+// x truncated to 11 significant bits) are rounded this way: truncating them too made every product err to the same side (2^-23 of it
+// on average), which a DTW path adds up cell after cell -- the systematic part of the matrix-core kernels' distance to the f32 kernels.
+// RP_SPLIT_RTZ: the round-3 form, for A/B builds.
+__device__ __forceinline__ unsigned pk_f16_second(float lo, float hi) {
+#ifdef RP_SPLIT_RTZ
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+#else
+    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f2_){lo, hi}, h2_));
+#endif
+}
+
 // A (window, chunk or template) pair whose frames left the norm range of the scale-invariant cosine (rp_kernels.h, DtwWork):
 // appended to the call's list for dtw_ref_kernel.  spec = chunk index, kFixSpecTemplate | template index.
 __device__ __forceinline__ void dtw_fix_append(uint32_t *fix, size_t row, uint32_t spec) {

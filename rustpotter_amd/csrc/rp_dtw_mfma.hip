@@ -12,7 +12,8 @@
 //     templates x 12 circular row slots (row r lives in slot r mod 12) = 3 tiles of 32 rows, N = 32 windows, K = 16 f16 slots
 //     = one instruction per tile.  A (the negated unit rows, split on the host, 256 B per template row in LDS) changes by one
 //     row per template and column: one tile's operand is re-read per column.
-//   * Precision: x = x0 + x1, a = a0 + a1 with x0 = rtz_f16(x), x1 = rtz_f16(x - x0) (22 significant bits); the slots hold
+//   * Precision: x = x0 + x1, a = a0 + a1 with x0 = rtz_f16(x), x1 = rtn_f16(x - x0) (22 significant bits; round 4: the second parts round
+//     to nearest -- truncated, every product erred to the same side and a path added that up); the slots hold
 //     x0 a0, x1 a0, x0 a1 for the five components (15) and 1.0 x 1.0, accumulated in f32 on C = 0: the instruction leaves
 //     1 - a.x with an error below 2^-20 (measured against the f32 CPU restatement: scores within 1e-6; the parity gate is 1e-5).
 //     Lane (n, h) centres, scales and splits only components (0, 1) or (3, 4) and component 2; the two partial squared norms
@@ -258,9 +259,10 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #else
 #define RP_X0F(x, packed, hi) ((hi) ? hi_f32(packed) : lo_f32(packed))
 #endif
-#define RP_P7(cc, par) bop[par].y = pkrtz(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1));
+#define RP_P7(cc, par) bop[par].y = pk_f16_second(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1));
 #define RP_P8(cc) chk_ = fmaxf(fmaxf(chk_, inv_), bb_);  /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */
-#define RP_P9(cc, par) bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pkrtz(u2_, u2_ - RP_X0F(u2_, pkrtz(u2_, 0.f), 0)), sel_one);
+#define RP_P9(cc, par) { const float x0_ = RP_X0F(u2_, pkrtz(u2_, 0.f), 0); /* (x0, x1) of component 2: x0 is already an f16 value, x1 rounds to nearest */ \
+                         bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pk_f16_second(x0_, u2_ - x0_), sel_one); }
 #define RP_PREP_ALL(cc, par) RP_P0(cc, (cc) % PD) RP_P1(cc, (cc) % PD) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 12)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \

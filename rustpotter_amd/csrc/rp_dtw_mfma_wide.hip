@@ -176,12 +176,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
             const float ua_ = d_[2 * j] * inv_, ub_ = d_[2 * j + 1] * inv_;                                                   \
             const unsigned p_ = pkrtz(ua_, ub_);                                                                              \
             v_[3 * j] = p_; v_[3 * j + 2] = p_;                                                                               \
-            v_[3 * j + 1] = pkrtz(ua_ - x0f(ua_), ub_ - x0f(ub_));                                                            \
+            v_[3 * j + 1] = pk_f16_second(ua_ - x0f(ua_), ub_ - x0f(ub_));                                                    \
         }                                                                                                                     \
         if (ODD) {                                                                                                            \
             const float us_ = d_[CHM - 1] * inv_;                                                                             \
             const unsigned t_ = pkrtz(us_, 0.f);                                                                              \
-            v_[3 * NPAIR] = pkrtz(us_, us_ - x0f(us_));                                                                       \
+            v_[3 * NPAIR] = pk_f16_second(x0f(us_), us_ - x0f(us_)); /* x0 is already an f16 value */                         \
             v_[3 * NPAIR + 1] = __builtin_amdgcn_perm(0x3c000000u, t_, sel_c);                                                \
         } else {                                                                                                              \
             v_[3 * NPAIR] = c_lo;                                                                                             \

@@ -415,8 +415,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
                     const float p = xs[2 * e], q = xs[2 * e + 1];
                     rng = fmaxf(fmaxf(rng, fabsf(p)), fabsf(q));
                     h0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p, q));
-                    h1[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(p - __uint_as_float(__float_as_uint(p) & 0xffffe000u),
-                                                                                    q - __uint_as_float(__float_as_uint(q) & 0xffffe000u)));
+                    h1[e] = pk_f16_second(p - __uint_as_float(__float_as_uint(p) & 0xffffe000u), q - __uint_as_float(__float_as_uint(q) & 0xffffe000u));
                 }
                 const f16x8 av0 = __builtin_bit_cast(f16x8, (u32x4v){h0[0], h0[1], h0[2], h0[3]});
                 const f16x8 av1 = __builtin_bit_cast(f16x8, (u32x4v){h1[0], h1[1], h1[2], h1[3]});

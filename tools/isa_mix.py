@@ -26,6 +26,9 @@ def main():
     min_mfma = 0
     if "--out" in args:
         i = args.index("--out"); out = args[i + 1]; del args[i:i + 2]
+    whole = "--whole" in args   # straight-line kernels (tools/scratch probes): price the whole body
+    if whole:
+        args.remove("--whole")
     if "--min-mfma" in args:
         i = args.index("--min-mfma"); min_mfma = int(args[i + 1]); del args[i:i + 2]
     src, want = args[0], args[1]
@@ -33,7 +36,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, "k.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + ["--cuda-device-only", "-S", "-o", asm,
-                               os.path.join(ROOT, "rustpotter_amd", "csrc", src)], stderr=subprocess.DEVNULL)
+                               src if os.path.isabs(src) or os.path.exists(src) else os.path.join(ROOT, "rustpotter_amd", "csrc", src)], stderr=subprocess.DEVNULL)
         lines = open(asm).read().splitlines()
     # kernel bodies: "<mangled>:" ... "s_endpgm" / ".Lfunc_end"
     start = None
@@ -53,10 +56,12 @@ def main():
         m = re.match(r"\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.match(r"\s+s_branch\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             loops.append((labels[m.group(1)], i))
-    assert loops, "no loop"
+    assert loops or whole, "no loop"
     def insts(a, b):
         return [l.split()[0] for l in body[a:b + 1] if re.match(r"\s+[a-z]", l) and not l.strip().startswith((".", ";"))]
-    if min_mfma:
+    if whole:
+        a, b = 0, len(body) - 1
+    elif min_mfma:
         cand = [ab for ab in loops if sum(o.startswith("v_mfma") for o in insts(*ab)) >= min_mfma]
         assert cand, "no loop with that many matrix instructions"
         a, b = min(cand, key=lambda ab: len(insts(*ab)))

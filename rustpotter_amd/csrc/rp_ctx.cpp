@@ -196,18 +196,18 @@ void Ctx::time_collect() {
     pending.clear();
 }
 
-// f32 -> f16 bits, rounded toward zero (what v_cvt_pkrtz_f16_f32 does to the window side); |v| <= 1 here
-static uint16_t f16_rtz_bits(float v) {
-    uint32_t b;
-    std::memcpy(&b, &v, 4);
-    const uint32_t sign = (b >> 16) & 0x8000u, mant = b & 0x7fffffu;
-    const int be = (int)((b >> 23) & 0xff), e = be - 127;
-    if (be == 0 || e < -24) return (uint16_t)sign;
-    if (e > 15) return (uint16_t)(sign | 0x7bffu);
-    if (e < -14) return (uint16_t)(sign | ((0x800000u | mant) >> (-e - 1)));
-    return (uint16_t)(sign | ((uint32_t)(e + 15) << 10) | (mant >> 13));
-}
-// f32 -> f16 bits, round to nearest even: the SECOND part of a split (rp_device.h pk_f16_second)
+// The window side of the matrix-core DTW kernels truncates both parts of its split (rp_device.h pk_f16_second): x0 + x1 falls short of x
+// by kDtwSplitShort of itself on average, so every cosine came out that much too small and a warping path added the shortfall up cell
+// after cell -- the systematic part of those kernels' distance to the f32 kernels (round 3: rms 3e-7 of a score at score_ref 0.22).
+// The template image is multiplied by 1 + kDtwSplitShort and both of its parts are rounded to nearest (a1 symmetric about zero makes the
+// dropped x1 a1 term zero-mean too).  Calibrated on the GPU (tools/probe_score_ref.py, mean signed error of 11 520 scores against the
+// oracle at score_ref 0.22: -7.7e-8 without the gain, +6.8e-9 at 1.2e-7, +6.0e-8 at 1.8e-7; rms 3.0e-7 in round 3, 1.5e-7 with the
+// rounding alone, 1.2e-7 with the gain -- the f32 register kernels are at 0.9e-7).
+#ifndef RP_DTW_SPLIT_SHORT
+#define RP_DTW_SPLIT_SHORT 1.1e-7
+#endif
+static const double kDtwSplitShort = RP_DTW_SPLIT_SHORT;
+// f32 -> f16 bits, round to nearest even
 static uint16_t f16_rtn_bits(float v) {
     const _Float16 h = (_Float16)v;
     uint16_t b;
@@ -222,7 +222,7 @@ static float f16_bits_to_f32(uint16_t hb) {
 }
 
 // dtw_mfma_kernel's A operand of one chunk (rp_dtw_mfma.hip): per template row r [k half 2][template slot 8] x 8 f16.  With
-// a = -(unit row) = a0 + a1 (a0 = rtz_f16(a), a1 = rtn_f16(a - a0)) and the half's components (ca, cb) = (0, 1) / (3, 4), the eight
+// a = -(unit row) (1 + kDtwSplitShort) = a0 + a1 (a0 = rtn_f16(a), a1 = rtn_f16(a - a0)) and the half's components (ca, cb) = (0, 1) / (3, 4), the eight
 // slots pair with the window side's (xa0, xb0 | xa1, xb1 | xa0, xb0 | x2_0, x2_1 or 1.0):
 //   [ca.0, cb.0 | ca.0, cb.0 | ca.1, cb.1 | half 0: c2.0, c2.0 / half 1: c2.1, 1.0]
 // i.e. x0 a0 + x1 a0 + x0 a1 for every component, and 1.0 x 1.0: the instruction accumulates 1 - a.x.  Slots past the chunk's
@@ -235,8 +235,8 @@ static void append_mfma_image(std::vector<uint16_t> &img, const DtwChunk &c, con
         for (int t = 0; t < c.count; ++t) {
             uint16_t p[5][2];
             for (int k = 0; k < K; ++k) {
-                const float a = -unit[((size_t)c.tid[t] * Lpad + r) * K + k];
-                p[k][0] = f16_rtz_bits(a);
+                const float a = (float)(-(double)unit[((size_t)c.tid[t] * Lpad + r) * K + k] * (1.0 + kDtwSplitShort));
+                p[k][0] = f16_rtn_bits(a);
                 p[k][1] = f16_rtn_bits(a - f16_bits_to_f32(p[k][0]));
             }
             for (int kh = 0; kh < 2; ++kh) {
@@ -264,8 +264,8 @@ static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c
                 auto part = [&](int j, int which) -> uint16_t {
                     const int comp = kh * CHM + j;
                     if (comp >= K) return 0;
-                    const float a = -unit[((size_t)c.tid[t] * Lpad + r) * K + comp];
-                    const uint16_t a0 = f16_rtz_bits(a);
+                    const float a = (float)(-(double)unit[((size_t)c.tid[t] * Lpad + r) * K + comp] * (1.0 + kDtwSplitShort));
+                    const uint16_t a0 = f16_rtn_bits(a);
                     return which == 0 ? a0 : f16_rtn_bits(a - f16_bits_to_f32(a0));
                 };
                 for (int j = 0; j < NPAIR; ++j) {

@@ -195,12 +195,13 @@ template <> struct SampleIn<int32_t> {
     static __device__ __forceinline__ float4 load4(const int32_t *p) { return cvt4(ldraw(p)); }
 };
 
-// f32 pair -> packed f16, round to nearest even (v_cvt_pk_f16_f32).  The SECOND parts of the f16 two-way splits (x1 = f16(x - x0), x0 =
-// x truncated to 11 significant bits) are rounded this way: truncating them too made every product err to the same side (2^-23 of it
-// on average), which a DTW path adds up cell after cell -- the systematic part of the matrix-core kernels' distance to the f32 kernels.
-// RP_SPLIT_RTZ: the round-3 form, for A/B builds.
+// The SECOND part of an f16 two-way split on the window side, x1 = f16(x - x0) (x0 = x truncated to 11 significant bits): truncated
+// like x0 (v_cvt_pkrtz_f16_f32).  Rounding it to nearest (v_cvt_pk_f16_f32, RP_SPLIT_RTN builds) was measured in round 4: the instruction
+// issues at less than half pkrtz's rate (dtw_mfma_kernel 11.70 -> 12.17 ms at C3) for a third less error.  The truncation makes every
+// product (x0 + x1) a fall short by 2^-22.4 of itself on average; the TEMPLATE side, split on the host, takes that out (kDtwSplitGain,
+// rp_ctx.cpp) and rounds both of its parts to nearest, which also makes the dropped x1 a1 term zero-mean.
 __device__ __forceinline__ unsigned pk_f16_second(float lo, float hi) {
-#ifdef RP_SPLIT_RTZ
+#ifndef RP_SPLIT_RTN
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
 #else
     typedef _Float16 h2_ __attribute__((ext_vector_type(2)));

@@ -967,7 +967,7 @@ static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int
                                       float *avg, bool few, GateList gl = GateList{}, bool padded = false) {
     // every length at least three times, band 5, rows with slack behind them: the sample templates on the matrix cores
     // (rp_dtw_mfma_wide.hip), the averaged template -- if it is to be scored here -- through the one-template register kernel
-    if (W == 5 && (padded || few || gl.list) && dtw_mfma_wide_supported(t, W)) {
+    if (W == 5 && (padded || few || gl.list) && dtw_mfma_wide_supported(t, W, score_ref)) {
         if (t.has_avg && n1 == t.class_count[3])
             if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
                                                         few, gl, t.class_first[3] + t.class_count[3] - 1); e != hipSuccess) return e;
@@ -1129,11 +1129,11 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
     // band 5 with four.
     {
         const bool from_global = few || gl.list != nullptr;
-        if (t.class_count[1] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 4)) {
+        if (t.class_count[1] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 4, score_ref)) {
             if ((e = launch_dtw_mfma(st, DtwWork{gl.sched, gl.fix}, t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                      scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse)) != hipSuccess) return e;
         } else if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
-        if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8))
+        if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8, score_ref))
             return launch_dtw_mfma(st, DtwWork{gl.sched, gl.fix}, t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                    scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse);
     }
@@ -1251,9 +1251,9 @@ hipError_t launch_dtw_gated(hipStream_t st, const DtwWork &wk, const TemplatesDe
     const size_t rows = S * n_win;
     if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
     // (as in launch_dtw: one stream alone is scored like a batch when the matrix-core kernel serves its templates)
-    const bool mfma_batch = few_windows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
-                                                          (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)))) ||
-                                            dtw_mfma_wide_supported(t, band));
+    const bool mfma_batch = few_windows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8, score_ref)) ||
+                                                          (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4, score_ref)))) ||
+                                            dtw_mfma_wide_supported(t, band, score_ref));
     const bool few = few_windows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const int avg_chunk = t.class_first[3] + t.class_count[3] - 1;  // the averaged template: last of the single-template chunks
     hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
@@ -1312,9 +1312,9 @@ static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const Templ
     // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
     // (one stream alone is a batch too when the matrix-core kernel serves its templates: a stream's bits must not depend on the
     // batch it is scored in, live or offline -- only the single-stream mirror, which never passes padded_rows, keeps dtw_single_kernel)
-    const bool mfma_batch = padded_rows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8)) ||
-                                                           (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4)))) ||
-                                            dtw_mfma_wide_supported(t, band));
+    const bool mfma_batch = padded_rows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8, score_ref)) ||
+                                                           (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4, score_ref)))) ||
+                                            dtw_mfma_wide_supported(t, band, score_ref));
     const bool few = padded_rows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const bool do_avg = with_avg && t.has_avg;
     const int Ttot = t.T + (do_avg ? 1 : 0);
@@ -1342,7 +1342,7 @@ static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const Templ
             // ScoreMode::Max inside the matrix-core kernel: one chunk of 3..8 templates is all there is to score
             if (fuse && fuse->agg && n2 == 0 && t.class_count[0] == 0 && t.class_count[1] + t.class_count[2] == 1 && band >= 3 && band <= 5 &&
                 std::getenv("RP_DTW_NO_FUSED_MAX") == nullptr &&
-                dtw_mfma_supported(t, band, n_win, few, t.class_count[2] == 1 ? 8 : 4)) {
+                dtw_mfma_supported(t, band, n_win, few, t.class_count[2] == 1 ? 8 : 4, score_ref)) {
                 gl.fuse = fuse;
                 fuse->done = true;
             }

@@ -12,8 +12,8 @@
 //     templates x 12 circular row slots (row r lives in slot r mod 12) = 3 tiles of 32 rows, N = 32 windows, K = 16 f16 slots
 //     = one instruction per tile.  A (the negated unit rows, split on the host, 256 B per template row in LDS) changes by one
 //     row per template and column: one tile's operand is re-read per column.
-//   * Precision: x = x0 + x1, a = a0 + a1 with x0 = rtz_f16(x), x1 = rtn_f16(x - x0) (22 significant bits; round 4: the second parts round
-//     to nearest -- truncated, every product erred to the same side and a path added that up); the slots hold
+//   * Precision: x = x0 + x1, a = a0 + a1 with x0 = rtz_f16(x), x1 = rtz_f16(x - x0) (22 significant bits; round 4: the template side rounds
+//     both parts to nearest and carries the gain that undoes the window side's truncation, rp_device.h pk_f16_second); the slots hold
 //     x0 a0, x1 a0, x0 a1 for the five components (15) and 1.0 x 1.0, accumulated in f32 on C = 0: the instruction leaves
 //     1 - a.x with an error below 2^-20 (measured against the f32 CPU restatement: scores within 1e-6; the parity gate is 1e-5).
 //     Lane (n, h) centres, scales and splits only components (0, 1) or (3, 4) and component 2; the two partial squared norms
@@ -412,9 +412,10 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     }
 }
 
-bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots) {
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots, float score_ref) {
     const char *env = std::getenv("RP_DTW_MFMA");  // "0": the register kernels only (A/B runs and the cross-check tests); read per call
     if ((env && env[0] == '0') || t.K != kMK || !t.aimg || t.max_diff != 0) return false;
+    if (!(score_ref >= kDtwMfmaMinScoreRef)) return false;   // the score's sensitivity to the cost grows like 1 / score_ref (rp_kernels.h)
     if (slots == 8 ? (band < 3 || band > 5) : band != 5) return false;  // 12 (16) row slots hold 2 band + 2 rows; 4 slots: band 5 only
     if (!from_global && n_win < (size_t)kMWin) return false;            // a staged tile holds at most two stream segments
     // the first 12 (16) columns are one guarded block

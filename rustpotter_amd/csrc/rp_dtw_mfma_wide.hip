@@ -314,7 +314,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     }
 }
 
-bool dtw_mfma_wide_supported(const TemplatesDev &t, int band) {
+bool dtw_mfma_wide_supported(const TemplatesDev &t, int band, float score_ref) {
+    if (!(score_ref >= kDtwMfmaMinScoreRef)) return false;   // as dtw_mfma_supported
     const char *env = std::getenv("RP_DTW_MFMA");
     if ((env && env[0] == '0') || (t.K != 13 && t.K != 16) || band != 5 || !t.aimg || t.wide8_count <= 0 || t.max_diff != 0) return false;
     if (t.mfma_min_len < kWSlots) return false;

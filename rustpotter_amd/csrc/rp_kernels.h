@@ -156,9 +156,12 @@ __host__ __device__ inline unsigned long long *dtw_fix_stats(uint32_t *fix) { re
 // templates; slots = 4, band 5) at mfcc_size 5.  from_global: lanes read their frames from global memory (live-stream batches, LIST mode
 // of the averaged-template gate) instead of an LDS stage (needs n_win >= 32).  list / count / dense_min / abandon_nc: as GateList in
 // rp_dtw.hip.
-bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots = 8);
+// score_ref: the relative error of a score is (1 - score) x d(cost / (m + n)) / score_ref; the split products keep it within the parity
+// gate (1e-5) down to kDtwMfmaMinScoreRef (tools/probe_score_ref.py, tests/test_gpu_round4.py); below, the f32 register kernels score
+constexpr float kDtwMfmaMinScoreRef = 0.05f;
+bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots, float score_ref);
 // mfcc_size 13 / 16 at band 5: frames always from global memory (the caller's rows end with slack: launch_dtw's padded_rows)
-bool dtw_mfma_wide_supported(const TemplatesDev &t, int band);
+bool dtw_mfma_wide_supported(const TemplatesDev &t, int band, float score_ref);
 hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                 size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, const uint32_t *list,
                                 const uint32_t *count, uint32_t dense_min, float abandon_nc);

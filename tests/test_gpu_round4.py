@@ -218,6 +218,64 @@ def test_detectors_with_a_template_set_outside_the_norm_range(ra, ctx, avg_thres
     assert abs(det[0][0]["score"] - 0.7310586) > 1e-3, "golden score of the unscaled file (tests/detector.rs:24-40): the scaled rows must move it"
 
 
+# ------------------------------------------------------------------------------------------------ score_ref
+class _registers_only:
+    """RP_DTW_MFMA=0 for the calls inside: the library reads the variable per call."""
+    def __enter__(self):
+        self.old = os.environ.get("RP_DTW_MFMA")
+        os.environ["RP_DTW_MFMA"] = "0"
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["RP_DTW_MFMA"]
+        else:
+            os.environ["RP_DTW_MFMA"] = self.old
+
+
+@pytest.mark.parametrize("K,T,L,band", [(5, 8, 100, 5), (5, 4, 100, 5), (5, 6, 60, 3), (5, 7, 37, 4)])
+@pytest.mark.parametrize("score_ref", [0.22, 0.15, 0.1, 0.05])
+def test_matrix_core_shapes_at_low_score_ref(ra, ctx, K, T, L, band, score_ref):
+    """DetectorConfig.score_ref (config.rs:172-209) scales the exponent of the score: the relative error of a score is
+    (1 - score) x d(cost / (m + n)) / score_ref, so a kernel whose cost error is fine at the default 0.22 can miss the 1e-5 gate at
+    0.05.  The matrix-core shapes (f16-split cosine products) against the oracle at the CONTRACT's tolerance, not the sweeps' 1e-3:
+    48 streams x 150 windows per case."""
+    S, n_win = 48, 150
+    templates = orc.synth_templates(SEED + 7 * L + T, T, L, K)
+    mf = _streams(S, n_win + L - 1, K, first=1000 + 50 * T)
+    tm = ra.Templates(ctx, templates)
+    scores, _, agg = ctx.dtw_scores(mf, tm, score_ref=score_ref, band_size=band)
+    worst = 0.0
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates, band=band, score_ref=score_ref)
+        worst = max(worst, rel_err(scores[s], ref_s), rel_err(agg[s], ref_a))
+    assert worst <= 1e-5, worst
+    with _registers_only():
+        reg, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref, band_size=band)
+    matrix = (T >= 5 and band <= 5) or (T >= 3 and band == 5)
+    assert np.array_equal(scores, reg) == (not matrix), "the matrix-core kernel serves these shapes down to score_ref 0.05"
+    assert rel_err(scores, reg) <= 4e-6 * 0.22 / score_ref
+
+
+def test_below_the_score_ref_floor_the_register_kernels_score(ra, ctx):
+    """kDtwMfmaMinScoreRef = 0.05 (rp_kernels.h): below it dtw_mfma_supported refuses and the f32 register kernels serve the same
+    chunks -- the same bits as with RP_DTW_MFMA=0 -- and stay within the gate down to where f32 itself can (0.03 here)."""
+    K, T, L = 5, 8, 100
+    templates = orc.synth_templates(SEED + 1234, T, L, K)
+    mf = _streams(16, 150 + L - 1, K, first=4000)
+    tm = ra.Templates(ctx, templates)
+    for score_ref in (0.049, 0.03):
+        scores, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref)
+        with _registers_only():
+            reg, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref)
+        assert np.array_equal(scores, reg)
+        for s in range(16):
+            ref_s, _ = orc.score_stream(mf[s], templates, score_ref=score_ref)
+            assert rel_err(scores[s], ref_s) <= 1e-5
+    at_floor, _, _ = ctx.dtw_scores(mf, tm, score_ref=0.05)
+    with _registers_only():
+        reg, _, _ = ctx.dtw_scores(mf, tm, score_ref=0.05)
+    assert not np.array_equal(at_floor, reg)
+
+
 # ------------------------------------------------------------------------------------------------ wakeword-model forward
 @pytest.mark.parametrize("dims", [(3120, 32, 16, 2), (1040, 13, 2), (3120, 80, 40, 3), (64, 13, 2)])
 def test_model_forward_is_finite_for_every_finite_input(ra, ctx, dims):

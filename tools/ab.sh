@@ -4,22 +4,24 @@
 # selected per run with RP_LIB_PATH -- the product library rustpotter_amd/librustpotter_hip.so and csrc/_obj are never touched, so
 # no exit path can leave a variant installed (round-3 advice: the old r3_*_ab.sh scripts copied variants over the product).
 #
-#   tools/ab.sh [-w "<bench args>"]... [-r reps] -- "<extra flags A>" "<extra flags B>" ...
+#   tools/ab.sh [-w "<bench args>"]... [-x "<command>"]... [-r reps] -- "<extra flags A>" "<extra flags B>" ...
+#   (-x: any command instead of a bench line, run with RP_LIB_PATH set to the variant; its output is printed)
 #   e.g. tools/ab.sh -w "--steps 10 --warmup 3" -w "--config C2 --steps 50" -- "" "-DRP_MFMA_GX_PD=1"
 # Prints one line per (variant, workload, repetition); the JSON lines stay under gpurun_out/ab/.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/ab; mkdir -p $O rustpotter_amd/variants
 BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-result -Wno-pass-failed"
-WORK=(); REPS=2
+WORK=(); CMDS=(); REPS=2
 while [ $# -gt 0 ]; do
   case "$1" in
     -w) WORK+=("$2"); shift 2;;
+    -x) CMDS+=("$2"); shift 2;;
     -r) REPS=$2; shift 2;;
     --) shift; break;;
     *) break;;
   esac
 done
-[ ${#WORK[@]} -eq 0 ] && WORK=("--steps 10 --warmup 3")
+[ ${#WORK[@]} -eq 0 ] && [ ${#CMDS[@]} -eq 0 ] && WORK=("--steps 10 --warmup 3")
 n=0
 for flags in "$@"; do
   make -C rustpotter_amd/csrc -j8 OUT=../variants/lib_$n.so OBJDIR=_obj_v$n CXXFLAGS="$BASE $flags" > $O/make_$n.log 2>&1 || { tail -5 $O/make_$n.log; exit 1; }
@@ -42,6 +44,9 @@ except Exception as e:
     print("variant $i [$flags] rep $rep [$w]: FAILED", e); print(open("$O/v${i}_w${wi}_$rep.err").read()[-800:])
 PY
       wi=$((wi+1))
+    done
+    for c in "${CMDS[@]}"; do
+      [ $rep -eq 1 ] && { echo "variant $i [$flags] \$ $c"; RP_LIB_PATH=$PWD/rustpotter_amd/variants/lib_$i.so timeout 900 bash -c "$c" 2>&1 | grep -v amdgpu.ids; }
     done
     i=$((i+1))
   done

@@ -747,8 +747,8 @@ __global__ __launch_bounds__(64) void dtw_generic_kernel(
 // sit in LDS lane-minor.  ALL mode (force_all, or more pairs than the list holds): every window x templates t_first ..
 // t_first + t_count - 1 (template sets with a row outside kDtwNormLo..kDtwNormHiRow, TemplatesDev::ref_only).  agg_out: the pair's
 // chunk holds every sample template (DtwFusedAgg) -- ScoreMode::Max and the stream's hot flag are rewritten too.
-// Launched after the fast kernels of every call; without listed pairs each workgroup reads one word and leaves.  The last
-// workgroup to leave puts fix[0] and fix[1] back to zero.
+// Launched after the fast kernels of every call; without listed pairs each workgroup reads one word and leaves.  Otherwise the
+// last workgroup to leave puts fix[0] and fix[1] back to zero.
 __global__ __launch_bounds__(64) void dtw_ref_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t first_win, size_t n_win, size_t out_win_pitch,
     size_t n_streams, const int *__restrict__ lens, const float *__restrict__ raw, int Lpad, int K, int T, int max_len, int band, int Wmax,
@@ -759,6 +759,10 @@ __global__ __launch_bounds__(64) void dtw_ref_kernel(
     float *Pb = mus + (size_t)K * 64;              // [2 Wmax + 1][64]
     const int lane = threadIdx.x;
     const uint32_t n_listed = fix[0];
+    // nothing listed (every call on ordinary audio): leave without touching the counters -- 512 workgroups adding to one word
+    // took 11 us, as long as a twentieth of a live-stream call's DTW launch.  With a list every workgroup sees the same non-zero
+    // count (nobody resets it before all have checked in), so either all run the protocol below or none does.
+    if (!force_all && n_listed == 0) return;
     const bool all = force_all || n_listed > kDtwFixCap;
     const size_t per_row = agg_out ? 1 : (size_t)t_count;
     const size_t n_entries = all ? n_streams * n_win * per_row : (size_t)n_listed;
@@ -855,7 +859,7 @@ static hipError_t launch_dtw_ref(hipStream_t st, const DtwWork &wk, const Templa
     if (lds > 160 * 1024) return hipErrorMemoryAllocation;
     if (lds > 64 * 1024)
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_ref_kernel), 160 * 1024); e != hipSuccess) return e;
-    size_t blocks = 2 * (size_t)device_cu_count();
+    size_t blocks = (size_t)device_cu_count();
     if (force_all) {
         const size_t need = (S * n_win * (size_t)(fuse ? 1 : t_count) + 63) / 64;
         blocks = need < 8 * (size_t)device_cu_count() ? (need ? need : 1) : 8 * (size_t)device_cu_count();

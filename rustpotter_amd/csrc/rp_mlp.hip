@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     const uint32_t *rlist = nullptr;
     if (redo_list) {
         const size_t n = redo[0];
+        if (n == 0) return;   // nothing listed (every call on ordinary features): no workgroup touches the counters
         if ((size_t)blockIdx.x * kMlpWaves * kMlpRowsPerWave >= n) {   // the whole workgroup: nothing (more) listed
             if (threadIdx.x == 0 && atomicAdd(redo + 1, 1u) == gridDim.x - 1) { redo[0] = 0; redo[1] = 0; }
             return;

@@ -229,14 +229,10 @@ class Env:
         """Self-proving multi-GPU record: the world size the process group reports and every rank's device UUID; with nccl (RCCL)
         the UUIDs must be N distinct devices."""
         p = self.torch.cuda.get_device_properties(self.dev)
+        from rustpotter_amd import sharding
         mine = {"rank": self.rank, "local_rank": self.local_rank, "device_index": self.dev.index, "uuid": str(getattr(p, "uuid", "")),
-                "pci_bus_id": getattr(p, "pci_bus_id", None), "name": p.name}
-        everyone = [None] * self.world
-        self.dist.all_gather_object(everyone, mine)
-        uu = [e["uuid"] for e in everyone]
-        if self.backend == "nccl":
-            assert len(set(uu)) == self.world and all(uu), "RCCL run with ranks that share a device: %r" % (uu,)
-        return {"rccl_world_size": self.dist.get_world_size(), "rank_devices": everyone, "distinct_devices": len(set(uu))}
+                "pci_bus_id": getattr(p, "pci_bus_id", None), "name": p.name, "pid": os.getpid()}
+        return sharding.rank_identities(mine, self.backend)
 
 
 def make_templates(ra, ctx, torch, dev, lens, K):

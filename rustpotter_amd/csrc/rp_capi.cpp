@@ -1043,7 +1043,8 @@ static int stream_batch_process_impl(rp_stream_batch *b, const void *pcm, rp_sam
         float *ds = b->scores.as<float>(), *dg = b->agg.as<float>(), *da = do_avg ? b->avg.as<float>() : nullptr;
         // the averaged-template gate as a skip (wakeword_comp.rs:85-93), unless the caller wants every window's aggregate
         const bool detect_only = !agg && !(c->flags & RP_CTX_FULL_SCORES);
-        // (a single live stream keeps launch_dtw's one-wave-per-DTW kernel: the gated path's lane-serial passes cost it latency)
+        // (a single live stream with a handful of windows skips the gate's three passes: launch_dtw scores it -- with the batch kernels when
+        // the matrix-core kernel serves its templates (a stream's bits must not depend on the batch it is in), else one wave per DTW)
         const bool gated = do_avg && detect_only && dtw_gate_supported(td_one, b->cfg.band_size, rows) && !(S == 1 && n_new <= 8);
         const float abandon = (detect_only && b->cfg.score_mode == RP_SCORE_MAX) ? dtw_abandon_nc(b->cfg.threshold, b->cfg.score_ref) : __builtin_inff();
         // ScoreMode::Max inside the matrix-core DTW kernel when one chunk holds the reference's templates (DtwFusedAgg, rp_kernels.h)

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) void scan_stream_kernel(ScanWakewords ww, const
     for (int i = nd; i < max_det; ++i) {
         det[s * (size_t)max_det + i] = BatchDetection{};
         if (det_ww) det_ww[s * (size_t)max_det + i] = 0;
-        if (det_label) det_label[s * (size_t)max_det + i] = 0;
+        if (det_label) det_label[s * (size_t)max_det + i] = -1;   // "no label", as the header says and the single-wakeword path fills
     }
 }
 

@@ -53,3 +53,21 @@ def gather_ragged(local, world_size, group=None):
     parts = [torch.empty_like(pad) for _ in range(world_size)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[: int(s.item())] for p, s in zip(parts, sizes)], dim=0)
+
+
+def rank_identities(mine, backend, group=None):
+    """Self-proving record of a multi-rank run (bench.py puts it on every --gpus N line): every rank contributes `mine`
+    (rank, local_rank, device index, device uuid, ...), all ranks get the list ordered by rank, the world size the process
+    group itself reports, and the number of distinct device uuids.  With backend "nccl" (RCCL: one rank per GPU) the uuids
+    must be `world_size` distinct non-empty devices -- ranks sharing a GPU would make a scaling number meaningless, so that
+    is an error there, while a gloo dry run (ranks sharing devices on a one-GPU box) only reports it."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, dict(mine), group=group)
+    everyone.sort(key=lambda e: e["rank"])
+    uuids = [str(e.get("uuid", "")) for e in everyone]
+    distinct = len(set(uuids))
+    if backend == "nccl" and (distinct != world or not all(uuids)):
+        raise RuntimeError("RCCL run whose ranks share a device (or report no uuid): %r" % (uuids,))
+    return {"rccl_world_size": world, "rank_devices": everyone, "distinct_devices": distinct}

@@ -55,6 +55,16 @@ def _worker(rank, world, port, total):
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert t.item() == float(world)
+        # the self-proving record of a multi-rank bench line: world size as the group reports it, one entry per rank in rank
+        # order; ranks that share a device are reported by a gloo dry run and REFUSED for an RCCL ("nccl") run
+        rec = sharding.rank_identities({"rank": rank, "local_rank": rank, "device_index": rank, "uuid": "GPU-%04d" % rank}, "gloo")
+        assert rec["rccl_world_size"] == world and rec["distinct_devices"] == world
+        assert [e["rank"] for e in rec["rank_devices"]] == list(range(world)) and rec["rank_devices"][rank]["uuid"] == "GPU-%04d" % rank
+        shared = sharding.rank_identities({"rank": rank, "uuid": "GPU-0000"}, "gloo")
+        assert shared["distinct_devices"] == 1
+        with pytest.raises(RuntimeError, match="share a device"):
+            sharding.rank_identities({"rank": rank, "uuid": "GPU-0000"}, "nccl")   # backend NAME decides: the uuids are what RCCL ranks must differ in
+        sharding.rank_identities({"rank": rank, "uuid": "GPU-%04d" % rank}, "nccl")
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -498,7 +498,7 @@ def bench_dtw(env):
     dom = max(("mfcc", "dtw"), key=lambda n: k_ms[n][0])
     roofline = dict(r_dtw if dom == "dtw" else r_mfcc)
     roofline["kernels_ms"] = {k: round(v[0], 4) for k, v in k_ms.items()}
-    if k_ms["aggregate"][1] == 0:  # no launch of the aggregate pass: ScoreMode::Max ran inside the DTW kernel (DESIGN.md 4.2b)
+    if k_ms["aggregate"][1] == 0:  # no launch of the aggregate pass: ScoreMode::Max ran inside the DTW kernel (DESIGN.md 4.2)
         roofline["aggregate_inside_dtw_kernel"] = True
     work_skipped = args.detect_only or (args.avg_gate and not args.full_scores)
     f_dtw_ref = sum(cells(Lt) * (2 * K + 7) + 2 * Lt * 2 * K + 2 * Lt * K for Lt in lens)

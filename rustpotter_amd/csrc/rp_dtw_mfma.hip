@@ -1,4 +1,4 @@
-// rp_dtw_mfma.hip -- dtw_mfma_kernel: the banded DTW of mfcc_size 5 with the cosine costs on the matrix cores (DESIGN.md §4.2b,
+// rp_dtw_mfma.hip -- dtw_mfma_kernel: the banded DTW of mfcc_size 5 with the cosine costs on the matrix cores (DESIGN.md §4.2,
 // round 3).  Same scoring as dtw_band_kernel (src/mfcc/dtw.rs:56-105 + comparator.rs:15-48 + normalizer.rs:17-29 +
 // wakeword_comp.rs:22-37), other arithmetic for the cell cost:
 //
@@ -27,7 +27,7 @@
 //     mfcc_size 13 / 16 have their own K axis: rp_dtw_mfma_wide.hip.
 // Measured (tools/scratch/dtw_mfma_probe2.hip, 8 192 streams x 288 windows x 8 templates of 100 frames): 1.62 ms against 2.36 ms at
 // dtw_band_kernel's C3 rate; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles), matrix pipe 21 % busy.  In the product
-// at C3: 19.5 -> 12.0 ms (DESIGN.md §4.2b, profiles/r03_final_*).
+// at C3: 19.5 -> 12.0 ms (DESIGN.md §4.2, profiles/r03_final_*).
 #include "rp_device.h"
 
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// rp_dtw_mfma_wide.hip -- dtw_mfma_wide_kernel: the matrix-core DTW (rp_dtw_mfma.hip, DESIGN.md §4.2b) for mfcc_size 13 and 16.
+// rp_dtw_mfma_wide.hip -- dtw_mfma_wide_kernel: the matrix-core DTW (rp_dtw_mfma.hip, DESIGN.md §4.2) for mfcc_size 13 and 16.
 // Same sweep, same recurrence, same lane layout (32 windows x 8 template slots per wave, lane = (window, half), two template pairs per
 // lane, 12 circular row slots = 3 MFMA tiles); what changes is the K axis of the product:
 //   * lane half h owns CHM = ceil(K / 2) components (half 1 of mfcc_size 13: six components and a zero);

@@ -55,7 +55,7 @@ template <int K1T> __device__ constexpr bool mel_uses(int f, int k2, bool mirror
     else return true;
 }
 
-// RP_ABL_*: ablation builds only (never defined in the product; DESIGN.md 4.1 has the numbers they gave): NOSTAGE drops the
+// RP_ABL_*: ablation builds only (never defined in the product; profiles/HISTORY.md 4.1 has the numbers they gave): NOSTAGE drops the
 // staging write of the pre-emphasised samples, NOT1 the transposition between FFT16 and DFT15, NOMIR the mirror exchange
 // before the untangle step, NOMEL the mel / log stage -- each leaves the arithmetic in place and produces wrong values.
 // K1T: compile-time K+1 (6 and 17 are instantiated), 0 = runtime value.  TIN: input sample type.

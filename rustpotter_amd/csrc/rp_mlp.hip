@@ -8,7 +8,7 @@ namespace rp {
 // -------------------------------------------------------------------------- MLP
 // Linear (x.W^T + b, W [out][in]) + optional ReLU, f32, k-ordered accumulation like
 // candle's CPU gemm restated in the oracle.  One wave per (row, 64 outputs) tile with
-// the input row staged in LDS.  (Round-1 correctness path; DESIGN.md lists the MFMA
+// the input row staged in LDS.  (Round-1 correctness path; profiles/HISTORY.md lists the MFMA
 // bf16 path for BASELINE config 5 as next.)
 __global__ __launch_bounds__(64) void mlp_layer_kernel(const float *__restrict__ x, size_t B, int in, int on,
                                                        const float *__restrict__ Wt, const float *__restrict__ bias,

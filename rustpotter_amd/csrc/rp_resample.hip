@@ -1,6 +1,6 @@
 // rp_resample.hip -- sample-rate conversion in front of the path (src/audio/encoder.rs:41-83, rubato FftFixedInOut):
 // resample_mfma_kernel (any rate, one f32 matrix product per output frame) and resample48_fft_kernel (48 kHz, pruned
-// FFT on the FFT-240 machinery).  DESIGN.md §4.5-4.6.
+// FFT on the FFT-240 machinery).  profiles/HISTORY.md §4.5-4.6.
 #include "rp_device.h"
 
 namespace rp {

@@ -221,6 +221,14 @@ int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs) {
 #endif
 const char *rp_build_info(void) { return sizeof(RP_BUILD_FLAGS_EXTRA) > 1 ? RP_BUILD_ARCH " +" RP_BUILD_FLAGS_EXTRA : RP_BUILD_ARCH; }
 
+#ifdef RP_MFMA_TRACE   // variant builds only: read the DTW counter block back (tools/r4_mfma_timeline.py)
+extern "C" int rp_debug_read_dtw_work(rp_ctx *ctx, uint32_t *dst, size_t words) {
+    Ctx *c = ctx->impl.get();
+    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipStreamSynchronize(c->stream), "sync")) return -1;
+    return hip_ok(hipMemcpy(dst, c->dtw_work().sched, words * 4, hipMemcpyDeviceToHost), "hipMemcpy") ? 0 : -1;
+}
+#endif
+
 const char *rp_ctx_last_mlp_kernel(rp_ctx *ctx) { return ctx ? ctx->impl->last_mlp_kernel.c_str() : ""; }
 
 size_t rp_mfcc_num_frames(size_t n_samples) {

@@ -83,6 +83,20 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 // static_rounds: tiles a wave takes by its own index before it turns to the counter (mfma_static_rounds, rp_kernels.h).  agg_out != null:
 // the chunk holds every sample template of the reference -- the kernel also writes ScoreMode::Max of a window's scores and raises the
 // stream's hot flag (DtwFusedAgg, rp_kernels.h).
+// RP_MFMA_TRACE (variant builds only, tools/r4_mfma_timeline.py): wave 0 and the last wave of every workgroup stamp the constant
+// 100 MHz clock at the kernel's phase boundaries into the tail of the counter block (DtwWork::sched words 1024..): where a short
+// launch spends its fixed cost.  Never defined in the product.
+#ifdef RP_MFMA_TRACE
+#define RP_TRACE(slot)                                                                                                        \
+    do {                                                                                                                      \
+        if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == NW - 1) && blockIdx.x < 128)          \
+            reinterpret_cast<unsigned long long *>(sched + 1024)[(blockIdx.x * 2 + ((threadIdx.x >> 6) ? 1 : 0)) * 8 + (slot)] = \
+                __builtin_amdgcn_s_memrealtime();                                                                             \
+    } while (0)
+#else
+#define RP_TRACE(slot)
+#endif
+
 template <int W, int NW, bool GX, int NT>
 __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         total_tiles = ((size_t)n_listed + kMWin - 1) / kMWin;
     } else if (count && *count < dense_min) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    RP_TRACE(0);
     const unsigned ci = blockIdx.x % n_chunks;
     const unsigned n_groups = gridDim.x / n_chunks;
     const DtwChunk *ch = chunks + chunk_base + ci;
@@ -121,6 +136,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         for (int i = tid; i < (L + kMSlotsMax) * kRowBytes / 16; i += 64 * NW) adst[i] = asrc[i];
     }
     __syncthreads();
+    RP_TRACE(1);
     float *xs = reinterpret_cast<float *>(smem + a_bytes) + wave * xs_floats;
     (void)xs;
     const int n = lane & 31, h = lane >> 5;
@@ -218,6 +234,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #pragma unroll kMeanUnroll
         for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
         mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;
+        if (round == 1) RP_TRACE(2);
 
         // Q[p][q] = D[(c - 1) - W + 1 + q][c - 1] of the template pair p (band position, as P[] of dtw_band_kernel with rows and
         // columns swapped); column 0: D[0][0] = 0 sits at q = W - 1.  Q[p][B] stays +inf (the cell below the band).
@@ -369,6 +386,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #undef RP_P9
 #undef RP_X0F
 
+        if (round == 1) RP_TRACE(3);
         // D[m - 1][n] with m == n == L (dtw.rs:101): band position q = (L - 1) - (L - W + 1) = W - 2
         float best = 0.f;  // ScoreMode::Max over this lane's templates (scores are > 0; an abandoned wave reports 0 like its scores)
         if (valid) {
@@ -401,8 +419,11 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             }
         }
         if (!GX) wave_lds_sync();  // the next tile restages xs
+        if (round == 1) RP_TRACE(4);
     }
+    RP_TRACE(5);
     __syncthreads();
+    RP_TRACE(6);
     if (tid == 0) {
         __threadfence();
         if (atomicAdd(next_tile + 1, 1u) == n_groups - 1) {  // every workgroup of this chunk has taken its last ticket

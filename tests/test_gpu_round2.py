@@ -377,7 +377,13 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["steps"] == 2 and j["scaling"] == "weak"
-    assert j["roofline"]["bound"] in ("valu", "hbm") and j["roofline_other"]["kernel"] != j["roofline"]["kernel"]
+    assert j["roofline_other"]["kernel"] != j["roofline"]["kernel"]
+    for r_ in (j["roofline"], j["roofline_other"]):   # frac = the largest pipe fraction, a fraction of a roof (round 4)
+        assert r_["bound"] in r_["pipes"] and 0.0 < r_["frac"] <= 1.0 and r_["frac"] == max(v for k, v in r_["pipes"].items() if k != "valu_flops_ref")
+    # the self-proving record of a multi-rank line: the world size the process group reports, one device record per rank
+    c = j["config"]
+    assert c["rccl_world_size"] == 2 and [e["rank"] for e in c["rank_devices"]] == [0, 1] and c["gather_ms_per_step"]["mean"] > 0
+    assert c["distinct_devices"] == (2 if torch.cuda.device_count() >= 2 else 1) and c["build"] == "gfx950"
     if torch.cuda.device_count() < 2:
         assert j["oversubscribed"]["devices"] == torch.cuda.device_count()
         # without the override a node with too few GPUs is refused, not silently oversubscribed

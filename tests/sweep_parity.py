@@ -71,7 +71,8 @@ def make_case(rng, extreme=False, mfma=False):
                band_size=int(rng.integers(1, 9)), score_mode=str(rng.choice(MODES)),
                vad_mode=[None, None, None, "easy", "medium", "hard"][int(rng.integers(6))])
     if mfma:
-        cfg.update(band_size=int(rng.choice([3, 4, 5, 5, 5])) if K == 5 else 5)
+        # round 4: score_ref down to the matrix-core kernels' floor (0.05; the relative error of a score grows like 1 / score_ref)
+        cfg.update(band_size=int(rng.choice([3, 4, 5, 5, 5])) if K == 5 else 5, score_ref=float(rng.uniform(0.05, 0.3)))
         if rng.random() < 0.5:  # detect-only calls in ScoreMode::Max abandon hopeless DTWs: half of the cases take that path too
             cfg.update(score_mode="max")
     if extreme:  # see make_api_case
@@ -179,10 +180,11 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False):
         case = make_case(rng, extreme=extreme, mfma=mfma)
         ref = oracle_detections(case)
         offline, live, agg = device_detections(ra, ctx, case)
-        # extreme parameters: a small score_ref puts the scores at 1e-20, where the logistic turns 1e-7 of cost into 1e-5 of
-        # score (3e-4 seen with 2-coefficient frames and score_ref 0.01) -- the decisions (chunk, counter) stay exact, the
-        # scores are compared at 1e-3
-        ok = all(_same(o, r, 1e-3 if extreme else 1e-5) for o, r in zip(offline, ref)) and all(_same(l, o, 0.0) for l, o in zip(live, offline))
+        # extreme parameters: score_ref 0.01 puts the scores at 1e-20, where the logistic turns 1e-7 of cost into 1e-5 of
+        # score (3e-4 seen with 2-coefficient frames) -- the decisions (chunk, counter) stay exact, the scores are compared at
+        # 1e-3 there; from score_ref 0.05 up (round 4) the contract's 1e-5 holds for the extreme cases too
+        tol = 1e-3 if (extreme and case["cfg"]["score_ref"] < 0.05) else 1e-5
+        ok = all(_same(o, r, tol) for o, r in zip(offline, ref)) and all(_same(l, o, 0.0) for l, o in zip(live, offline))
         if not ok:
             thr = case["cfg"]["threshold"]
             near = agg.size and np.min(np.abs(agg - np.float32(thr))) < 1e-5 * thr

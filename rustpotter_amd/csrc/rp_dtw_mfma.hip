@@ -341,9 +341,15 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #pragma unroll
             for (int u = 0; u < NS; ++u) { const int c = c0 + u; RP_STEP(true); }
         }
-// early abandon: wave-uniform, once per 12 columns
+// early abandon: wave-uniform, once per 12 columns.  (RP_MFMA_PRICE_NO_ABANDON: tools/isa_mix.py prices the hot loop as the headline call
+// runs it -- abandon_nc = +inf jumps over this block with one scalar branch -- by compiling the block out; never defined in the product.)
+#ifdef RP_MFMA_PRICE_NO_ABANDON
+#define RP_ABANDON_ON false
+#else
+#define RP_ABANDON_ON (abandon_nc < RP_INF)
+#endif
 #define RP_ABANDON_CHECK()                                                                                                    \
-    if (abandon_nc < RP_INF) {                                                                                                \
+    if (RP_ABANDON_ON) {                                                                                                \
         bool alive = false;                                                                                                   \
         _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                      \
             v2f m = Q[p][0];                                                                                                  \
@@ -370,6 +376,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             }
         }
 #undef RP_ABANDON_CHECK
+#undef RP_ABANDON_ON
 #undef RP_STEP
 #undef RP_MFMA
 #undef RP_AREF

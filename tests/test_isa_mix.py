@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
-    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8>", ["--min-mfma", "36"], "profiles/r04_dtw_mfma_isa_mix.json"),
+    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8>", ["--min-mfma", "36", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/r04_dtw_mfma_isa_mix.json"),
     ("rp_mfcc.hip", "mfcc_kernel<true, 6, float, false>", [], "profiles/r04_mfcc_isa_mix.json"),
 ]
 
@@ -22,7 +22,7 @@ def test_committed_isa_mix_matches_the_source(src, kernel, extra, committed):
     now = json.loads(out.stdout)
     was = json.load(open(os.path.join(ROOT, committed)))
     for key in ("instructions", "classes", "valu_issue_cycles_per_trip", "lds_cycles_per_trip", "opcodes"):
-        assert now[key] == was[key], "%s changed: run `python tools/isa_mix.py %s '%s' %s --out %s`" % (key, src, kernel, " ".join(extra), committed)
+        assert now[key] == was[key], "%s changed: run `python tools/isa_mix.py %s '%s' %s --out %s`" % (key, src, kernel, " ".join("'%s'" % e if " " in e or e.startswith("-D") else e for e in extra), committed)
 
 
 def test_rate_table_prices_every_valu_opcode_of_the_mixes():

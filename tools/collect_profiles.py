@@ -4,7 +4,7 @@ import csv, glob, json, collections, statistics, shutil, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"   # round tag of the files written
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"   # round tag of the files written
 short = lambda n: n.split("(")[0]
 
 def agg(tag):
@@ -28,9 +28,9 @@ try:  # effective shader clock: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / t
     clk = {k: (v["GRBM_GUI_ACTIVE"], statistics.median(durs[k])) for k, v in clk.items() if k in durs}
 except Exception:
     clk = {}
-out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "
                   "(separate passes: FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; "
-                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r3_final.sh)",
+                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r4_final.sh)",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch as reported by rocprofv3 (TCC_EA0 request counters); FETCH_SIZE of "
                 "16-byte-per-lane streaming reads under-reports by 2x on gfx950 (MI355X_MICROARCH.md HBM section); values are the "
                 "MEDIAN over the launches of a kernel in the run (the run also holds one tiny mfcc launch for the templates)",
@@ -75,7 +75,7 @@ names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk
          "median": "bench_%s_median" % R, "gate_default": "bench_%s_avg_gate_default" % R, "gate_default_full": "bench_%s_avg_gate_default_full_scores" % R,
          "gate_04": "bench_%s_avg_gate_04" % R, "gate_04_full": "bench_%s_avg_gate_04_full_scores" % R,
          "two_ranks_one_gpu": "bench_%s_two_ranks_one_gpu_dry_run" % R, "detect_only": "bench_%s_detect_only" % R,
-         "detect_only_ragged5": "bench_%s_detect_only_ragged5" % R}
+         "detect_only_ragged5": "bench_%s_detect_only_ragged5" % R, "ingest_f32": "bench_%s_ingest_f32" % R, "ingest_i16": "bench_%s_ingest_i16" % R}
 for a, b in names.items():
     src = "gpurun_out/final/%s.json" % a
     if os.path.exists(src) and os.path.getsize(src) > 10:
@@ -83,7 +83,7 @@ for a, b in names.items():
         x = json.loads(open(src).read().strip().splitlines()[-1])
         print(b, "%.4g %s" % (x["value"], x["unit"]), "%.3f ms" % x["ms_per_step"], (x.get("roofline") or {}).get("kernels_ms", x.get("kernels_ms", "")))
 txt = []
-for f in ("model_detect.txt", "latency.txt", "frontend.txt"):
+for f in ("model_detect.txt", "latency.txt", "frontend.txt", "c2_rounds.txt", "mfma_timeline.txt"):
     p = "gpurun_out/final/" + f
     if os.path.exists(p):
         txt.append(open(p).read().strip())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction mix of a kernel's hottest loop, priced with the committed rate table.
 
-    python tools/isa_mix.py rp_dtw_mfma.hip 'dtw_mfma_kernel<5, 12, false, 8>' [--min-mfma 36] [--out profiles/x.json]
+    python tools/isa_mix.py rp_dtw_mfma.hip 'dtw_mfma_kernel<5, 12, false, 8>' [--min-mfma 36] [--flags "-DX ..."] [--out profiles/x.json]
 
 Compiles the source to gfx950 assembly with the product's flags, takes the named kernel, finds its loops (a label that a later
 branch jumps back to) and reports the hot one -- the smallest loop with at least --min-mfma matrix instructions (the 12-column block
@@ -29,13 +29,16 @@ def main():
     whole = "--whole" in args   # straight-line kernels (tools/scratch probes): price the whole body
     if whole:
         args.remove("--whole")
+    flags = []
+    if "--flags" in args:
+        i = args.index("--flags"); flags = args[i + 1].split(); del args[i:i + 2]
     if "--min-mfma" in args:
         i = args.index("--min-mfma"); min_mfma = int(args[i + 1]); del args[i:i + 2]
     src, want = args[0], args[1]
     table = json.load(open(os.path.join(ROOT, "profiles", "valu_rate_table.json")))
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + ["--cuda-device-only", "-S", "-o", asm,
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + flags + ["--cuda-device-only", "-S", "-o", asm,
                                src if os.path.isabs(src) or os.path.exists(src) else os.path.join(ROOT, "rustpotter_amd", "csrc", src)], stderr=subprocess.DEVNULL)
         lines = open(asm).read().splitlines()
     # kernel bodies: "<mangled>:" ... "s_endpgm" / ".Lfunc_end"
@@ -89,7 +92,7 @@ def main():
             lds_cycles += n * lds_cyc.get(o, 4)
         elif o.startswith(("global_", "buffer_", "flat_", "scratch_")): classes["vmem"] += n
         else: classes["other"] += n
-    res = {"source": src, "kernel": want, "loop_lines": [a, b], "instructions": len(ops), "classes": classes,
+    res = {"source": src, "kernel": want, "extra_flags": " ".join(flags), "loop_lines": [a, b], "instructions": len(ops), "classes": classes,
            "valu_issue_cycles_per_trip": round(valu_cycles, 1), "lds_cycles_per_trip": lds_cycles, "rate_table": "profiles/valu_rate_table.json",
            "opcodes": dict(sorted(counts.items(), key=lambda kv: -kv[1]))}
     print(json.dumps(res, indent=1))

@@ -6,7 +6,7 @@ TAG=$1; CTRS=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d gpurun_out/pmc_${TAG} -o pmc -- \
-    python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/pmc_${TAG}.log 2>&1
+    python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > gpurun_out/pmc_${TAG}.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/pmc_${TAG}/**/*counter_collection.csv", recursive=True)

@@ -5,13 +5,13 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/final
 O=gpurun_out/final
-B="python3 bench.py --steps 10 --warmup 3"
+B="python3 bench.py --steps 10 --warmup 3 --no-extras"
 line() { grep '^{' | tail -1; }
-$B 2>/dev/null | line > $O/bench_default.json
+python3 bench.py --steps 10 --warmup 3 2>/dev/null | line > $O/bench_default.json
 $B --no-cpu-baseline --config C2 --steps 50 2>/dev/null | line > $O/c2.json
 $B --no-cpu-baseline --streams 8192 --templates 64 2>/dev/null | line > $O/c4.json
-python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --config C4 2>/dev/null | line > $O/c4_one_gpu.json
-RP_BENCH_OVERSUBSCRIBE=1 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --config C4 --gpus 2 2>/dev/null | line > $O/c4_two_ranks_one_gpu.json
+python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --config C4 2>/dev/null | line > $O/c4_one_gpu.json
+RP_BENCH_OVERSUBSCRIBE=1 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --config C4 --gpus 2 2>/dev/null | line > $O/c4_two_ranks_one_gpu.json
 $B --no-cpu-baseline --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5.json
 $B --no-cpu-baseline --templates 3 --template-len 126 2>/dev/null | line > $O/t3.json
 $B --no-cpu-baseline --score-mode median 2>/dev/null | line > $O/median.json
@@ -31,6 +31,9 @@ $B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_
 $B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13.json
+python3 bench.py --ingest --ingest-format f32 --no-cpu-baseline 2>/dev/null | line > $O/ingest_f32.json
+python3 bench.py --ingest --ingest-format i16 --no-cpu-baseline 2>/dev/null | line > $O/ingest_i16.json
+bash tools/r4_c2_rounds.sh > $O/c2_rounds.txt 2>/dev/null
 python3 tools/bench_model_detect.py > $O/model_detect.txt 2>/dev/null
 for sig in noise silence; do for a in 0.0 0.2 0.5; do echo "single-stream API, $sig, avg_threshold $a: $(SIGNAL=$sig AVG=$a python3 tools/latency_probe.py 2>/dev/null | tail -1)"; done; done > $O/latency.txt
 python3 tools/bench_frontend.py > $O/frontend.txt 2>/dev/null

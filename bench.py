@@ -324,7 +324,7 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw):
     return r
 
 
-def mfcc_kernel_model(env, S, nf, K, mfcc_s):
+def mfcc_kernel_model(env, S, nf, K, mfcc_s, pmc_mfcc=None):
     torch = env.torch
     alg_bytes, flops = S * nf * (640 + 4 * K), S * nf * 13.2e3
     pipes = {"hbm": alg_bytes / mfcc_s / HBM_PEAK, "valu_flops_ref": flops / mfcc_s / VALU_PEAK}
@@ -337,6 +337,9 @@ def mfcc_kernel_model(env, S, nf, K, mfcc_s):
         extra["isa_mix"] = ("profiles/r04_mfcc_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d LDS instructions, %.0f SIMD issue cycles and %d "
                             "LDS-array cycles per 4-frame tile of a wave" % (mix["classes"]["valu"], mix["classes"]["lds"], mix["valu_issue_cycles_per_trip"],
                                                                              mix["lds_cycles_per_trip"]))
+    if pmc_mfcc and "effective_clock_ghz" in pmc_mfcc and "valu_issue" in pipes:   # the chip clocks below its 2.4 GHz peak under this load
+        extra["effective_clock_ghz"] = pmc_mfcc["effective_clock_ghz"]
+        extra["valu_issue_frac_at_effective_clock"] = pipes["valu_issue"] * 2.4 / pmc_mfcc["effective_clock_ghz"]
     bound = max((k for k in pipes if k != "valu_flops_ref"), key=pipes.get)
     r = {"bound": bound, "kernel": "mfcc_kernel", "frac": pipes[bound], "pipes": pipes, "avg_launch_ms": mfcc_s * 1e3,
          "algorithmic_bytes_per_launch": alg_bytes, "hbm_gbps": alg_bytes / mfcc_s / 1e9}
@@ -476,7 +479,7 @@ def bench_dtw(env):
     pmc, pmc_src = pmc_for(S, N, T, L, K, lens, args)
     dtw_s, mfcc_s = k_ms["dtw"][0] * 1e-3, k_ms["mfcc"][0] * 1e-3
     r_dtw = dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc.get("dtw"))
-    r_mfcc = mfcc_kernel_model(env, S, nf, K, mfcc_s)
+    r_mfcc = mfcc_kernel_model(env, S, nf, K, mfcc_s, pmc.get("mfcc"))
     for r, kn in ((r_dtw, "dtw"), (r_mfcc, "mfcc")):
         r["launches_timed"] = k_ms[kn][1]
         d = pmc.get(kn, {})

@@ -295,3 +295,29 @@ def test_g6_resampled_audio_matches_reference_filter_examples(name):
     assert np.sqrt((d * d).mean()) <= 3e-7 * peak
     if e.get("gain_normalizer"):
         assert len(set(np.round(gains, 1))) >= 5  # the gain really moves (0.1 .. 0.9)
+
+
+def test_cosine_norm_product_semantics_of_the_restatement():
+    """src/mfcc/comparator.rs:28-48: `dot_ab / sqrt(dot_a * dot_b)`, similarity 0 when the root is 0.  The PRODUCT of the squared
+    norms is formed in f32, so the distance is NOT scale invariant once it leaves the normal range: a (window, template) pair scaled by
+    s keeps its score down to s ~ 1e-10, drifts where the product is subnormal, and lands on `every cell costs 1` once it underflows:
+    cost = m + n - 2 ... normalised 0.5 -> score 1 / (1 + exp((0.5 - ref) / ref)).  The device kernels reproduce exactly this
+    (tests/test_gpu_round4.py); here the oracle itself is pinned to the closed form."""
+    K, L = 5, 40
+    t = orc.synth_templates(0x5EED000000000001, 1, L, K)[0]
+    w = orc.mfcc_stream(orc.synth_pcm(0x5EED000000000001, 3, 480 * 20), K)[:L]
+    base = orc.score_window(w, t)
+    assert 0.25 < base < 0.6
+    for s in (1e-3, 1e-6, 1e-9):
+        assert abs(orc.score_window(w * np.float32(s), t * np.float32(s)) - base) <= 2e-6 * base
+    drift = orc.score_window(w * np.float32(1e-11), t * np.float32(1e-11))
+    assert 1e-5 < abs(drift - base) / base < 0.05          # subnormal product: bits are lost, the score moves
+    # product underflows to 0 -> similarity 0 -> every band cell costs exactly 1 -> D[m-1][n] = m + n - 2 ... here 2L - 1 cells on the path
+    flat = orc.score_window(w * np.float32(1e-13), t * np.float32(1e-13))
+    cost = orc.dtw_banded(t * np.float32(1e-13), orc.normalize(w * np.float32(1e-13)))
+    assert cost == float(int(cost)) and flat == pytest.approx(1.0 / (1.0 + np.exp((cost / (2 * L) - 0.22) / 0.22)), rel=1e-6)
+    # one side alone does not underflow the product (1e-20^2 * O(100) is still a subnormal with a few bits): close to the base score
+    assert abs(orc.score_window(w * np.float32(1e-20), t) - base) <= 1e-4 * base
+    # overflow of the product: similarity 0 as well
+    big = orc.score_window(w * np.float32(1e17), t * np.float32(1e3))
+    assert big == pytest.approx(flat, rel=1e-6)

@@ -277,7 +277,11 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #define RP_X0F(x, packed, hi) ((hi) ? hi_f32(packed) : lo_f32(packed))
 #endif
 #define RP_P7(cc, par) bop[par].y = pk_f16_second(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1));
+#ifndef RP_AB_NO_RANGE_TEST   /* A/B builds only (results wrong for out-of-range frames): what the test costs */
 #define RP_P8(cc) chk_ = fmaxf(fmaxf(chk_, inv_), bb_);  /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */
+#else
+#define RP_P8(cc)
+#endif
 #define RP_P9(cc, par) { const float x0_ = RP_X0F(u2_, pkrtz(u2_, 0.f), 0); /* (x0, x1) of component 2: x0 is already an f16 value, x1 rounds to nearest */ \
                          bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pk_f16_second(x0_, u2_ - x0_), sel_one); }
 #define RP_PREP_ALL(cc, par) RP_P0(cc, (cc) % PD) RP_P1(cc, (cc) % PD) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)

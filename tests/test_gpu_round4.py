@@ -152,6 +152,66 @@ def test_cosine_out_of_range_averaged_template_longer_than_the_window(ra, ctx):
             assert rel_err(avg_s[s], ref_avg) <= 1e-5
 
 
+def test_cosine_range_more_pairs_than_the_list_holds(ra, ctx):
+    """The list of out-of-range pairs holds 2^18 entries; beyond that dtw_ref_kernel rescored EVERY window of the call (its ALL
+    mode).  128 streams x 260 windows x 8 single-template chunks (eight different lengths) = 266 240 pairs, all of them tiny."""
+    K, S, n_win = 5, 128, 260
+    rng = np.random.default_rng(11)
+    lens = [12, 13, 14, 15, 16, 17, 18, 19]
+    templates = [(rng.standard_normal((L, K)) * 1e-12).astype(np.float32) for L in lens]
+    templates[3] = (templates[3].astype(np.float64) * 1e12).astype(np.float32)   # one ordinary template among the tiny ones: the set still has rows below the range
+    mf = (rng.standard_normal((S, n_win + max(lens) - 1, K)) * 1e-12).astype(np.float32)
+    tm = ra.Templates(ctx, templates)
+    before = ctx.dtw_ref_pairs()
+    scores, _, agg = ctx.dtw_scores(mf, tm, score_mode=ra.ScoreMode.Median)
+    assert ctx.dtw_ref_pairs() - before >= S * n_win * len(lens)
+    for s in range(0, S, 9):
+        ref_s, ref_a = orc.score_stream(mf[s], templates, mode="median")
+        assert rel_err(scores[s], ref_s) <= 1e-5 and rel_err(agg[s], ref_a) <= 1e-5
+    # ordinary templates, tiny windows: the fast kernels run, list more than 2^18 pairs, and the ALL mode takes over
+    templates = [(rng.standard_normal((L, K))).astype(np.float32) for L in lens]
+    tm = ra.Templates(ctx, templates)
+    before = ctx.dtw_ref_pairs()
+    scores, _, agg = ctx.dtw_scores(mf, tm)
+    assert ctx.dtw_ref_pairs() - before >= S * n_win * len(lens)
+    for s in range(0, S, 9):
+        ref_s, ref_a = orc.score_stream(mf[s], templates)
+        assert rel_err(scores[s], ref_s) <= 1e-5 and rel_err(agg[s], ref_a) <= 1e-5
+    # and the next ordinary call starts from an empty list
+    mf1 = _streams(3, 60 + 19 - 1, K, first=7)
+    before = ctx.dtw_ref_pairs()
+    sc1, _, _ = ctx.dtw_scores(mf1, tm)
+    assert ctx.dtw_ref_pairs() == before
+    for s in range(3):
+        assert rel_err(sc1[s], orc.score_stream(mf1[s], templates)[0]) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_cosine_range_randomised_frames(ra, ctx, seed):
+    """Random mixtures inside ONE call: ordinary, zero, tiny (1e-12, 1e-25) and huge (1e10, 1e17) frames and template rows at random
+    places, every kernel family by turns -- whatever the mixture, the scores are the oracle's (the reference's arithmetic, with its
+    under- and overflows) to 1e-5."""
+    rng = np.random.default_rng([4, seed])
+    K, T, L, n_win, S = [(5, 8, 40, 70, 3), (5, 4, 33, 40, 2), (5, 2, 25, 70, 2), (5, 1, 20, 130, 2), (16, 3, 22, 40, 2), (13, 2, 18, 40, 2),
+                         (7, 3, 15, 40, 2), (5, 3, 30, 4, 1)][seed % 8]
+    scales = np.array([1.0, 0.0, 1e-12, 1e-25, 1e10, 1e17])
+    p_frame = [[0.9, 0.03, 0.03, 0.02, 0.01, 0.01], [0.5, 0.1, 0.2, 0.1, 0.05, 0.05], [0.98, 0.02, 0, 0, 0, 0]][seed % 3]
+    p_row = [[1, 0, 0, 0, 0, 0], [0.9, 0.05, 0.05, 0, 0, 0], [0.7, 0.05, 0.1, 0.05, 0.05, 0.05]][(seed // 3) % 3]
+    templates = [(rng.standard_normal((L, K)) * 3).astype(np.float64) * scales[rng.choice(6, size=(L, 1), p=p_row)] for _ in range(T)]
+    templates = [t.astype(np.float32) for t in templates]
+    mf = ((rng.standard_normal((S, n_win + L - 1, K)) * 3).astype(np.float64) * scales[rng.choice(6, size=(S, n_win + L - 1, 1), p=p_frame)]).astype(np.float32)
+    if seed % 4 == 0:   # a run of identical frames: windows inside it are exactly zero after the mean is taken out
+        mf[0, 10:10 + L + 5] = mf[0, 10]
+    scores, _, agg = ctx.dtw_scores(mf, ra.Templates(ctx, templates), score_mode=ra.ScoreMode.Average)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates, mode="average")
+        ok = np.isfinite(ref_s)
+        assert np.array_equal(np.isfinite(scores[s]), ok)
+        assert rel_err(scores[s][ok], ref_s[ok]) <= 1e-5, (seed, rel_err(scores[s][ok], ref_s[ok]))
+        oka = np.isfinite(ref_a)
+        assert rel_err(agg[s][oka], ref_a[oka]) <= 2e-5
+
+
 def _scaled_rpw(scale):
     w = rpw_py.load_rpw(os.path.join(G, "oye_casa_g.rpw"))
     sf = {k: (np.asarray(v, np.float64) * scale).astype(np.float32) for k, v in w["samples_features"].items()}

@@ -127,6 +127,7 @@ def main():
                     "--ingest-block, block k+1's copy on a copy stream under block k's kernels (SURVEY 8d: H2D included); reports scorings/s and PCIe GB/s")
     ap.add_argument("--ingest-block", type=int, default=8192, help="streams per block of the --ingest pipeline")
     ap.add_argument("--ingest-format", choices=["f32", "i16"], default="f32", help="sample format of the host PCM (i16: decoded inside mfcc_kernel)")
+    ap.add_argument("--ingest-blocks", type=int, default=4, help="blocks of the --ingest run (its page-locked host buffer holds all of them: 2.1 GB per f32 block of 8 192 streams)")
     ap.add_argument("--chunks-per-call", type=int, default=1)
     ap.add_argument("--pcm-format", choices=["f32", "i16"], default="f32", help="--mode resample: sample format of the 48 kHz input")
     ap.add_argument("--channels", type=int, default=1, help="--mode resample: interleaved channels of the 48 kHz input")
@@ -785,79 +786,60 @@ def bench_mlp(env):
 
 # ------------------------------------------------------------------------------------------------ H2D included
 def ingest_measure(env, case, blocks, block_streams, fmt):
-    """The headline path with the PCM starting in pinned HOST memory (SURVEY 8d "H2D included"): the streams arrive in blocks of
-    `block_streams`; block k+1's hipMemcpyAsync runs on a copy stream while block k's kernels run on the launch stream (two device
-    buffers), the detections of every block are copied back to pinned host memory.  Two pinned host blocks are cycled (the same bytes
-    cross PCIe again: the link does not care), so the sample is bounded by `blocks`, not by the host's memory."""
+    """The headline path with the PCM starting in pinned HOST memory (SURVEY 8d "H2D included"), through the product's own pipelined
+    entry point rp_batch_detect_ingest: the streams are taken in blocks of `block_streams`, block k+1's hipMemcpyAsync runs on the
+    context's copy stream while block k's kernels run, two device blocks are cycled, every block's detections are copied back.
+    Host memory: `blocks` x `block_streams` streams, page-locked (torch pin_memory = hipHostMalloc)."""
     ra, torch, dev = env.ra, env.torch, env.dev
     Sb, N = block_streams, case.N
     tdt = torch.float32 if fmt == "f32" else torch.int16
     sfmt = 3 if fmt == "f32" else 1
     src = case.pcm[:Sb] if fmt == "f32" else (case.pcm[:Sb] * 32767.0).round().clamp(-32768, 32767).to(torch.int16)
-    host = [torch.empty((Sb, N), dtype=tdt, pin_memory=True) for _ in range(2)]
-    for h in host:
-        h.copy_(src)
-    dbuf = [torch.empty((Sb, N), dtype=tdt, device=dev) for _ in range(2)]
-    det_h = torch.empty((Sb, case.max_det, 6), dtype=torch.int32, pin_memory=True)
-    ndet_h = torch.empty((Sb,), dtype=torch.int32, pin_memory=True)
-    det = torch.zeros((Sb, case.max_det, 6), dtype=torch.int32, device=dev)
-    n_det = torch.zeros((Sb,), dtype=torch.int32, device=dev)
-    main = torch.cuda.current_stream()
-    copy = torch.cuda.Stream(device=dev)
-    landed = [torch.cuda.Event() for _ in range(2)]
-    freed = [torch.cuda.Event() for _ in range(2)]
+    S = Sb * blocks
+    host = torch.empty((S, N), dtype=tdt, pin_memory=True)
+    for k in range(blocks):
+        host[k * Sb:(k + 1) * Sb].copy_(src)
+    det_h = torch.zeros((S, case.max_det, 6), dtype=torch.int32, pin_memory=True)
+    ndet_h = torch.zeros((S,), dtype=torch.int32, pin_memory=True)
+    torch.cuda.synchronize()
     bytes_block = Sb * N * (4 if fmt == "f32" else 2)
 
     def run(n_blocks):
-        for i in range(2):
-            freed[i].record(main)
-        with torch.cuda.stream(copy):
-            copy.wait_event(freed[0])
-            dbuf[0].copy_(host[0], non_blocking=True)
-            landed[0].record(copy)
-        for k in range(n_blocks):
-            cur = k & 1
-            if k + 1 < n_blocks:   # the next block's copy goes out before this block's kernels are queued
-                nxt = (k + 1) & 1
-                with torch.cuda.stream(copy):
-                    copy.wait_event(freed[nxt])
-                    dbuf[nxt].copy_(host[nxt], non_blocking=True)
-                    landed[nxt].record(copy)
-            main.wait_event(landed[cur])
-            case.ctx.batch_detect_fmt_dev(dbuf[cur].data_ptr(), sfmt, Sb, N, N, case.tmpl, case.cfg, det.data_ptr(), n_det.data_ptr(), case.max_det)
-            freed[cur].record(main)
-            det_h.copy_(det, non_blocking=True)
-            ndet_h.copy_(n_det, non_blocking=True)
-        torch.cuda.synchronize()
+        return case.ctx.batch_detect_ingest_ptr(host.data_ptr(), sfmt, Sb * n_blocks, N, N, case.tmpl, case.cfg, det_h.data_ptr(), ndet_h.data_ptr(),
+                                                case.max_det, block_streams=Sb)
 
-    run(2)   # warm-up: allocations of the context's workspaces for this block size
+    run(min(2, blocks))   # warm-up: the context's workspaces for this block size, the copy stream
     t0 = time.perf_counter()
-    run(blocks)
+    lib_seconds = run(blocks)
     dt = time.perf_counter() - t0
-    # the same blocks with the input already resident (no copies): what the kernels alone take
+    # the same block with the input already resident (no copies): what the kernels alone take
+    dbuf = torch.empty((Sb, N), dtype=tdt, device=dev)
+    dbuf.copy_(host[:Sb])
+    det = torch.zeros((Sb, case.max_det, 6), dtype=torch.int32, device=dev)
+    n_det = torch.zeros((Sb,), dtype=torch.int32, device=dev)
     case.ctx.timing_enable(True)
     case.ctx.timing_reset()
     for _ in range(2):
-        case.ctx.batch_detect_fmt_dev(dbuf[0].data_ptr(), sfmt, Sb, N, N, case.tmpl, case.cfg, det.data_ptr(), n_det.data_ptr(), case.max_det)
+        case.ctx.batch_detect_fmt_dev(dbuf.data_ptr(), sfmt, Sb, N, N, case.tmpl, case.cfg, det.data_ptr(), n_det.data_ptr(), case.max_det)
     torch.cuda.synchronize()
     k = {name: case.ctx.timing_read(i)[0] for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
     case.ctx.timing_enable(False)
     kern = sum(k.values())
     # one copy alone
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(main)
-    dbuf[0].copy_(host[0], non_blocking=True)
-    b.record(main)
+    a.record()
+    dbuf.copy_(host[:Sb], non_blocking=True)
+    b.record()
     torch.cuda.synchronize()
     copy_ms = a.elapsed_time(b)
     scor = Sb * case.n_win * blocks
-    res = {"what": "PCM in pinned host memory (%s), %d blocks of %d streams, block k+1's hipMemcpyAsync on a copy stream under block k's kernels, detections "
-                   "copied back per block; detect-only calls (no per-window score arrays leave the device)" % (fmt, blocks, Sb),
+    res = {"what": "rp_batch_detect_ingest: PCM in pinned host memory (%s), %d blocks of %d streams, block k+1's hipMemcpyAsync on the context's copy "
+                   "stream under block k's kernels, detections copied back per block; detect-only calls (no per-window score arrays leave the device)" % (fmt, blocks, Sb),
            "value": scor / dt, "unit": "scorings/s", "ms_per_block": dt / blocks * 1e3, "pcie_gbps_achieved": bytes_block * blocks / dt / 1e9,
-           "copy_alone_ms_per_block": copy_ms, "copy_alone_gbps": bytes_block / (copy_ms * 1e-3) / 1e9,
+           "library_wall_seconds": lib_seconds, "copy_alone_ms_per_block": copy_ms, "copy_alone_gbps": bytes_block / (copy_ms * 1e-3) / 1e9,
            "kernels_ms_per_block": {kk: round(v, 4) for kk, v in k.items()}, "kernels_sum_ms_per_block": kern,
            "overlap": "a block takes max(copy, kernels) when the two overlap: copy %.2f ms, kernels %.2f ms, measured %.2f ms per block" % (copy_ms, kern, dt / blocks * 1e3),
-           "bytes_per_scoring_over_pcie": bytes_block / (Sb * case.n_win)}
+           "bytes_per_scoring_over_pcie": bytes_block / (Sb * case.n_win), "detections": int(ndet_h.sum().item())}
     del host, dbuf
     return res
 
@@ -869,7 +851,7 @@ def bench_ingest(env):
     lens = [int(x) for x in args.template_lens.split(",") if x] or [args.template_len] * args.templates
     Sb = min(args.ingest_block, S)
     case = DtwCase(env, Sb, lens, K, N, want_arrays=False)
-    blocks = max(2, S // Sb)
+    blocks = max(2, min(args.ingest_blocks, S // Sb))
     r = ingest_measure(env, case, blocks=blocks, block_streams=Sb, fmt=args.ingest_format)
     config = {"workload": "%d synthetic 16 kHz %s streams x %d templates from pinned host memory in %d blocks of %d" % (Sb * blocks, args.ingest_format, case.T, blocks, Sb)}
     config.update(env.common_config())

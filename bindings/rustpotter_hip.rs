@@ -137,6 +137,9 @@ extern "C" {
     pub fn rp_batch_detect_fmt(ctx: *mut rp_ctx, pcm: *const c_void, fmt: c_int, S: usize, n_samples: usize, pcm_stride: usize,
                                t: *const rp_templates, config: *const rp_detector_config, det: *mut rp_batch_detection, n_det: *mut i32,
                                max_det: c_int, scores: *mut f32, agg: *mut f32) -> c_int;
+    pub fn rp_batch_detect_ingest(ctx: *mut rp_ctx, pcm: *const c_void, fmt: c_int, S: usize, n_samples: usize, pcm_stride: usize,
+                                  t: *const rp_templates, config: *const rp_detector_config, det: *mut rp_batch_detection, n_det: *mut i32,
+                                  max_det: c_int, block_streams: usize, seconds: *mut f64) -> c_int;
     /// ctxs[g] / t[g]: one context and one replica of the wakeword per device; pcm[g]: the S[g] streams of shard g
     /// ([S[g]][pcm_stride], on ctxs[g]'s device or in host memory per the contexts' flag); det / n_det: ONE gathered
     /// block for all sum(S) streams, `stream` = global id in shard order.  One host thread per shard inside the call.
@@ -458,6 +461,21 @@ impl HipContext {
                                 n_det.as_mut_ptr(), max_det as c_int, std::ptr::null_mut(), std::ptr::null_mut())
         })?;
         Ok(split_detections(det, n_det, max_det))
+    }
+    /// `batch_detect_i16` for streams in HOST memory, pipelined: blocks of `block_streams` streams (0 = 8 192), the next block's copy
+    /// under this block's kernels (the copies overlap when `pcm` is page-locked).  Returns the detections and the call's wall seconds.
+    pub fn batch_detect_ingest_i16(&self, pcm: &[i16], n_streams: usize, n_samples: usize, t: &Templates, config: &DetectorConfig, max_det: usize,
+                                   block_streams: usize) -> Result<(Detections, f64), String> {
+        assert!(pcm.len() >= n_streams * n_samples);
+        let c: rp_detector_config = config.into();
+        let mut det = vec![rp_batch_detection::default(); n_streams * max_det];
+        let mut n_det = vec![0i32; n_streams];
+        let mut seconds = 0f64;
+        status(unsafe {
+            rp_batch_detect_ingest(self.h, pcm.as_ptr() as *const c_void, RP_SAMPLE_I16, n_streams, n_samples, n_samples, t.h, &c, det.as_mut_ptr(),
+                                   n_det.as_mut_ptr(), max_det as c_int, block_streams, &mut seconds)
+        })?;
+        Ok((split_detections(det, n_det, max_det), seconds))
     }
     /// A detector holding several wakewords (`run_wakeword_detectors`, src/detector.rs:433-447); `overrides[w]` = the wakeword's own
     /// `(threshold, avg_threshold)` options.  Returns the detections and, per detection, the index of the wakeword that fired.

@@ -330,6 +330,19 @@ int rp_batch_detect_fmt(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size
                         const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                         int max_det, float *scores, float *agg);
 
+/* rp_batch_detect_fmt for streams that live in HOST memory, pipelined (the serving shape of `process_samples` over many
+ * streams, src/detector.rs:234-254: the audio arrives in host buffers): the S streams are taken in blocks of `block_streams`
+ * (0 = 8 192); block k+1's host-to-device copy runs on the context's copy stream while block k's kernels run on its launch
+ * stream, two device blocks are cycled, the detections of every block are copied back as it finishes.  pcm [S][pcm_stride],
+ * det [S][max_det] and n_det [S] are HOST arrays whatever the context's RP_CTX_HOST_POINTERS flag says; detection records carry
+ * global stream ids.  The copies overlap the kernels when the host memory is page-locked (hipHostMalloc / hipHostRegister by the
+ * caller: the link then runs at its rate and binds -- 862 B per scoring for f32, half for i16); pageable memory works, copy by
+ * copy.  Device memory needed: two blocks of PCM + one block's intermediates, so S may exceed what fits in HBM at once.
+ * seconds (NULL to skip): wall time of the call. */
+int rp_batch_detect_ingest(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                           const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
+                           int max_det, size_t block_streams, double *seconds);
+
 /* Multi-GPU form of rp_batch_detect_fmt: independent streams shard across the GPUs of a node, nothing is
  * exchanged but the final per-stream results.  The caller owns one context per device (rp_ctx_new(device g)) with the
  * wakeword replicated on each (rp_templates_new on every context; <= 128 KB).  Shard g = S[g] streams whose PCM

@@ -102,7 +102,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_batch_detect_ingest", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
@@ -178,6 +178,8 @@ def load_library():
     L.rp_mfcc_batch.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.rp_mfcc_batch_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
     L.rp_batch_detect_fmt.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, vp, vp]
+    L.rp_batch_detect_ingest.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.POINTER(_DetectorConfig), vp, vp, C.c_int, C.c_size_t,
+                                         C.POINTER(C.c_double)]
     L.rp_frontend_batch.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_FiltersCfg), C.c_float, C.c_size_t, vp, C.c_size_t, vp, vp]
     L.rp_wakeword_ref_build.argtypes = [vp, C.c_char_p, fp, fp, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p),
                                         C.POINTER(C.c_size_t), C.c_uint16, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -908,6 +910,31 @@ class BatchContext:
         if self._L.rp_batch_detect_fmt(self._h, pcm_ptr, int(fmt), S, N, stride, templates._h, C.byref(c), det_ptr, n_det_ptr, max_det,
                                        scores_ptr, agg_ptr) < 0:
             raise _err()
+
+    def batch_detect_ingest(self, pcm, templates, detector_config, max_det=8, block_streams=0):
+        """rp_batch_detect_ingest: pcm = HOST array [S][N] (numpy; page-locked or not) of f32 / i8 / i16 / i32 samples, taken in blocks
+        with the copies under the kernels.  Returns (det [S][max_det], n_det [S], seconds)."""
+        import numpy as np
+        pcm = np.ascontiguousarray(pcm)
+        S, N = pcm.shape
+        fmt = {np.dtype(np.int8): 0, np.dtype(np.int16): 1, np.dtype(np.int32): 2, np.dtype(np.float32): 3}[pcm.dtype]
+        det = np.zeros((S, max_det), dtype=[("stream", "<i4"), ("frame", "<i4"), ("window", "<i4"), ("counter", "<i4"), ("avg_score", "<f4"), ("score", "<f4")])
+        n_det = np.zeros((S,), np.int32)
+        sec = C.c_double(0.0)
+        c = detector_config._c()
+        if self._L.rp_batch_detect_ingest(self._h, pcm.ctypes.data, fmt, S, N, N, templates._h, C.byref(c), det.ctypes.data, n_det.ctypes.data, max_det,
+                                          block_streams, C.byref(sec)) < 0:
+            raise _err()
+        return det, n_det, sec.value
+
+    def batch_detect_ingest_ptr(self, pcm_host_ptr, fmt, S, N, stride, templates, detector_config, det_host_ptr, n_det_host_ptr, max_det, block_streams=0):
+        """The same on raw HOST pointers (e.g. torch pinned tensors); returns the call's wall seconds."""
+        sec = C.c_double(0.0)
+        c = detector_config._c()
+        if self._L.rp_batch_detect_ingest(self._h, pcm_host_ptr, int(fmt), S, N, stride, templates._h, C.byref(c), det_host_ptr, n_det_host_ptr, max_det,
+                                          block_streams, C.byref(sec)) < 0:
+            raise _err()
+        return sec.value
 
     def mlp_forward(self, x, model, precision="f32"):
         import numpy as np

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <new>
 #include <system_error>
+#include <chrono>
 #include <thread>
 
 #include "rp_host.h"
@@ -487,7 +488,7 @@ int rp_batch_detect(rp_ctx *ctx, const float *pcm, size_t S, size_t n_samples, s
 // stream ids starting at stream_base and, instead of going to `det` / `n_det` directly, are copied from this context's
 // buffers into the gathered block `det` / `n_det` (rows stream_base..) that lives in host memory (gather_host) or on
 // device gather_device (peer copy over xGMI).
-struct GatherTo { bool on = false, host = true; int device = 0; int stream_base = 0; };
+struct GatherTo { bool on = false, host = true; int device = 0; int stream_base = 0; bool device_pcm = false; };   // device_pcm: pcm is a device pointer whatever the context's flags say (rp_batch_detect_ingest)
 static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                              const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
                              int max_det, float *scores, float *agg, const GatherTo &gather);
@@ -515,6 +516,7 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         const size_t rows = S * n_win;
         const bool do_avg = td.has_avg && config->avg_threshold != 0.f;  // wakeword_comp.rs:85
         Staged sg(c);
+        if (gather.device_pcm) sg.host = false;
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
         const void *dp = sg.in(pcm, S * pcm_stride * sample_bytes(fmt), c->stage_in);
         BatchDetection *dd = static_cast<BatchDetection *>(sg.out(det, S * (size_t)max_det * sizeof(BatchDetection), c->stage_out));
@@ -619,6 +621,50 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
 // how the last rp_batch_detect_sharded of this thread gathered its results (rp_sharded_gather_info)
 static thread_local std::string g_sharded_info;
 const char *rp_sharded_gather_info(void) { return g_sharded_info.c_str(); }
+
+int rp_batch_detect_ingest(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
+                           const rp_templates *t, const rp_detector_config *config, rp_batch_detection *det, int32_t *n_det,
+                           int max_det, size_t block_streams, double *seconds) {
+    return guarded([&]() -> int {
+        if (!ctx || !t) { set_last_error("null handle"); return -1; }
+        if (!config || (S && (!pcm || !det || !n_det))) { set_last_error("null argument"); return -1; }
+        if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
+        if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t Sb = block_streams ? block_streams : 8192, row_bytes = pcm_stride * sample_bytes(fmt);
+        const size_t blk = std::min(Sb, S), n_blocks = S ? (S + blk - 1) / blk : 0;
+        if (S > 0x7fffffffULL) { set_last_error("rp_batch_detect_ingest: too many streams"); return -1; }
+        if (n_blocks == 0) { if (seconds) *seconds = 0.0; return 0; }
+        if (!c->ingest_ready() || !c->ws_ingest.reserve(2 * blk * row_bytes + 64)) return -1;
+        unsigned char *dbuf[2] = {c->ws_ingest.as<unsigned char>(), c->ws_ingest.as<unsigned char>() + blk * row_bytes};
+        auto streams_of = [&](size_t k) { return std::min(blk, S - k * blk); };
+        auto copy_block = [&](size_t k) {   // on the copy stream, once the kernels that last read this buffer are done
+            const int b = (int)(k & 1);
+            return hip_ok(hipStreamWaitEvent(c->copy_stream, c->ingest_freed[b], 0), "hipStreamWaitEvent") &&
+                   hip_ok(hipMemcpyAsync(dbuf[b], static_cast<const unsigned char *>(pcm) + k * blk * row_bytes, streams_of(k) * row_bytes,
+                                         hipMemcpyHostToDevice, c->copy_stream), "hipMemcpyAsync(ingest)") &&
+                   hip_ok(hipEventRecord(c->ingest_landed[b], c->copy_stream), "hipEventRecord");
+        };
+        for (int b = 0; b < 2; ++b)
+            if (!hip_ok(hipEventRecord(c->ingest_freed[b], c->stream), "hipEventRecord")) return -1;
+        if (!copy_block(0)) return -1;
+        for (size_t k = 0; k < n_blocks; ++k) {
+            const int b = (int)(k & 1);
+            if (k + 1 < n_blocks && !copy_block(k + 1)) return -1;   // the next block's copy goes out before this block's kernels
+            if (!hip_ok(hipStreamWaitEvent(c->stream, c->ingest_landed[b], 0), "hipStreamWaitEvent")) return -1;
+            GatherTo g;
+            g.on = true; g.host = true; g.stream_base = (int)(k * blk); g.device_pcm = true;
+            // the block through the ordinary batched path; its detections land in det / n_det at the block's rows (the call waits for them)
+            if (batch_detect_impl(ctx, dbuf[b], fmt, streams_of(k), n_samples, pcm_stride, t, config, det, n_det, max_det, nullptr, nullptr, g) != 0) return -1;
+            if (!hip_ok(hipEventRecord(c->ingest_freed[b], c->stream), "hipEventRecord")) return -1;
+        }
+        if (!hip_ok(hipStreamSynchronize(c->copy_stream), "hipStreamSynchronize")) return -1;
+        if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    });
+}
 
 int rp_batch_detect_sharded(rp_ctx *const *ctxs, const rp_templates *const *t, int n_shards, const void *const *pcm,
                             rp_sample_format fmt, const size_t *S, size_t n_samples, size_t pcm_stride,

@@ -88,6 +88,15 @@ Ctx *Ctx::create(int device, int flags) {
     return c.release();
 }
 
+bool Ctx::ingest_ready() {
+    if (copy_stream) return true;
+    if (!hip_ok(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate(copy)")) { copy_stream = nullptr; return false; }
+    for (int b = 0; b < 2; ++b)
+        if (!hip_ok(hipEventCreateWithFlags(&ingest_landed[b], hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&ingest_freed[b], hipEventDisableTiming), "hipEventCreate")) return false;
+    return true;
+}
+
 uint32_t *Ctx::mlp_redo(size_t B) {
     const size_t bytes = (2 + B) * sizeof(uint32_t);
     if (bytes > ws_mlp_redo.cap) {   // a new block: its counters start at zero (later calls leave them so)
@@ -105,6 +114,11 @@ Ctx::~Ctx() {
         (void)hipFree(t.hamming); (void)hipFree(t.tw240); (void)hipFree(t.tw480); (void)hipFree(t.fb); (void)hipFree(t.dct); if (t.melw) (void)hipFree(t.melw);
     }
     if (own_stream) (void)hipStreamDestroy(own_stream);
+    for (int b = 0; b < 2; ++b) {
+        if (ingest_landed[b]) (void)hipEventDestroy(ingest_landed[b]);
+        if (ingest_freed[b]) (void)hipEventDestroy(ingest_freed[b]);
+    }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
 }
 
 template <class T> static bool upload(T **dst, const std::vector<T> &src) {

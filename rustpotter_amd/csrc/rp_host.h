@@ -113,6 +113,11 @@ struct Ctx {
     // intermediates of rp_batch_detect
     DevBuf ws_mfcc, ws_scores, ws_agg, ws_avg, ws_vad, ws_ring, ws_rms, ws_gain, ws_list, ws_hot;
     DevBuf ws_dtw;  // [2 * kDtwSchedChunks | 2 + 2 * kDtwFixCap] uint32: tile counters and fix list of the DTW launchers, zero between calls
+    // rp_batch_detect_ingest: copy stream, two device blocks of PCM, per block "copy landed" / "kernels done with it" events
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ingest_landed[2] = {nullptr, nullptr}, ingest_freed[2] = {nullptr, nullptr};
+    DevBuf ws_ingest;
+    bool ingest_ready();   // creates the stream and events on first use
     // the list of rows the wakeword-model forward computes again with the f32 matrix instructions (kMlpF16x2, rp_kernels.h): [2 + B]
     // words, the first two zero between calls
     DevBuf ws_mlp_redo;

@@ -848,6 +848,15 @@ __global__ __launch_bounds__(64) void dtw_ref_kernel(
     }
 }
 
+// A launcher that fails between its fast kernels and the list pass must not leave pairs of THIS call (rows of these arrays) listed for
+// the next one: the call's words go back to zero behind whatever was already queued.  Returns the error it was given.
+static hipError_t dtw_abort(hipStream_t st, const DtwWork &wk, hipError_t e) {
+    if (wk.fix) (void)hipMemsetAsync(wk.fix, 0, 2 * sizeof(uint32_t), st);
+    if (wk.sched) (void)hipMemsetAsync(wk.sched, 0, 2 * (size_t)kDtwSchedChunks * sizeof(uint32_t), st);
+    (void)hipGetLastError();
+    return e;
+}
+
 // The pass behind every fast launch: rescoring of the listed pairs (see dtw_ref_kernel).  force_all: every window x templates
 // t_first .. t_first + t_count - 1 (index T = the averaged template).
 static hipError_t launch_dtw_ref(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
@@ -1249,9 +1258,20 @@ static hipError_t gated_wide(hipStream_t st, const DtwWork &wk, const TemplatesD
 
 // first_win / few_windows as in launch_dtw (live-stream batches score the few newest windows of every stream: then pass 1
 // also reads its frames from global memory); scores / avg rows have pitch n_win.
+static hipError_t launch_dtw_gated_impl(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                                        size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                                        uint32_t *count, bool few_windows, float abandon_nc);
 hipError_t launch_dtw_gated(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                             size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
                             uint32_t *count, bool few_windows, float abandon_nc) {
+    if (!dtw_gate_supported(t, band, S * n_win)) return hipErrorNotSupported;
+    const hipError_t e = launch_dtw_gated_impl(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, band, score_ref, avg_threshold, scores, avg, list, count,
+                                               few_windows, abandon_nc);
+    return e == hipSuccess ? e : dtw_abort(st, wk, e);
+}
+static hipError_t launch_dtw_gated_impl(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                                        size_t n_win, int band, float score_ref, float avg_threshold, float *scores, float *avg, uint32_t *list,
+                                        uint32_t *count, bool few_windows, float abandon_nc) {
     const size_t rows = S * n_win;
     if (!dtw_gate_supported(t, band, rows)) return hipErrorNotSupported;
     // (as in launch_dtw: one stream alone is scored like a batch when the matrix-core kernel serves its templates)
@@ -1288,6 +1308,7 @@ static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const Templ
                                   size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                                   float *scores, float *avg, bool padded_rows, float abandon_nc, DtwFusedAgg *fuse, bool *self_healing);
 
+
 hipError_t launch_dtw(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
                       size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                       float *scores, float *avg, bool padded_rows, float abandon_nc, DtwFusedAgg *fuse) {
@@ -1299,12 +1320,13 @@ hipError_t launch_dtw(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, 
     bool self_healing = false;
     if (!t.ref_only || (S == 1 && n_win <= 8)) {   // (a handful of windows of one stream: dtw_single_kernel takes force_ref itself)
         if (hipError_t e = launch_dtw_fast(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, with_avg, scores, avg,
-                                           padded_rows, abandon_nc, fuse, &self_healing); e != hipSuccess) return e;
+                                           padded_rows, abandon_nc, fuse, &self_healing); e != hipSuccess) return dtw_abort(st, wk, e);
         if (self_healing) return hipSuccess;
     }
     // the windows the fast kernels listed (a frame outside the norm range), or -- a template set with such a row -- every window
-    return launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, t.ref_only != 0, 0, Ttot,
-                          (fuse && fuse->done) ? fuse : nullptr);
+    const hipError_t e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, t.ref_only != 0, 0, Ttot,
+                                        (fuse && fuse->done) ? fuse : nullptr);
+    return e == hipSuccess ? e : dtw_abort(st, wk, e);
 }
 
 static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
@@ -1390,11 +1412,20 @@ bool dtw_uses_generic(const TemplatesDev &t, int band, size_t S, size_t n_win) {
 // The averaged-template gate behind the generic kernel: pass 1 scores every window against the averaged template (-> avg),
 // pass 2 the sample templates, each wave leaving at once when none of its 64 windows passed (scores of such rows are not
 // written; the aggregate pass gives them 0).
+static hipError_t launch_dtw_generic_gated_impl(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                                                size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, float avg_threshold,
+                                                float *scores, float *avg);
 hipError_t launch_dtw_generic_gated(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                     size_t n_win, size_t out_win_pitch, int band, float score_ref, float avg_threshold, float *scores,
                                     float *avg) {
     if (S == 0 || n_win == 0) return hipSuccess;
     if (!t.has_avg || !avg) return hipErrorInvalidValue;
+    const hipError_t e = launch_dtw_generic_gated_impl(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, avg_threshold, scores, avg);
+    return e == hipSuccess ? e : dtw_abort(st, wk, e);
+}
+static hipError_t launch_dtw_generic_gated_impl(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, const float *mfcc, size_t S, size_t frame_pitch,
+                                                size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, float avg_threshold,
+                                                float *scores, float *avg) {
     if (t.ref_only) {  // a template row outside the norm range: every window reference-shaped, no skipping (the aggregate pass writes 0 for rejected rows)
         if (hipError_t e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, true, t.T, 1); e != hipSuccess) return e;
         return launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, band, score_ref, scores, avg, true, 0, t.T);

@@ -601,8 +601,8 @@ def run_mfcc_sweep(ra, ctx, n_cases, seed, verbose=False, strict=True, min_level
             # tones (kinds 2, 3) put the far mel filters 60-90 dB under the peak, where the rounding noise of ANY f32 FFT
             # (the kernel's 16x15 four-step, the oracle's, rustfft's) is no longer small against the local energy: the
             # logarithm turns that into absolute differences above 1e-5.  Gates (round 4, tightened to what 20 000 cases over four
-            # rounds measured): steady tones 1e-4 (worst seen 6.6e-5), speech-like signals 2e-5 (worst seen 8.1e-6); they were 2e-4
-            gate = 1e-4 if kind == 2 else 2e-5 if kind == 3 else 1e-5
+            # rounds measured): steady tones 1e-4 (worst seen 6.6e-5), speech-like signals 3e-5 (worst seen 1.7e-5 in 6 000 cases); they were 2e-4
+            gate = 1e-4 if kind == 2 else 3e-5 if kind == 3 else 1e-5
             assert err <= gate or not strict, "mfcc sweep seed %d case %d: kind %d K %d n %d %s level %.3g: err %.3g" % (
                 seed, ci, kind, K, n, x.dtype, float(np.max(np.abs(x.astype(np.float64)))), err)
         if verbose and ci % 50 == 0:
@@ -1139,7 +1139,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     import rustpotter_amd as ra
     ctx = ra.BatchContext(0)
-    mfcc_line = lambda r: "%d cases, worst scaled error per signal kind %r (gate 1e-5; tones 1e-4, speech-like 2e-5)" % (
+    mfcc_line = lambda r: "%d cases, worst scaled error per signal kind %r (gate 1e-5; tones 1e-4, speech-like 3e-5)" % (
         r[0], {k: float("%.3g" % v) for k, v in sorted(r[1].items())})
     families = [  # (name, number of cases, run, result -> text); a failing family is reported and the others still run
         ("sweep", a.cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True),

@@ -75,6 +75,24 @@ int main(int argc, char **argv) {
         first += S[g];
     }
     printf("%zu streams in %d shards, %zu detection(s)\n", total, n_shards, found);
+    printf("gather: %s\n", rp_sharded_gather_info());
+    /* the same streams once more as ONE host array through the pipelined host entry point (blocks of 100 streams, the next block's
+     * copy under this block's kernels): the same detections */
+    {
+        float *all = (float *)malloc(total * N * sizeof(float));
+        size_t at = 0;
+        for (int g = 0; g < n_shards; ++g) { memcpy(all + at * N, pcm[g], S[g] * N * sizeof(float)); at += S[g]; }
+        rp_batch_detection *det2 = (rp_batch_detection *)calloc(total * max_det, sizeof(*det2));
+        int32_t *n_det2 = (int32_t *)calloc(total, sizeof(*n_det2));
+        double seconds = 0.0;
+        CHECK(rp_batch_detect_ingest(ctx[0], all, RP_SAMPLE_F32, total, N, N, tm[0], &cfg.detector, det2, n_det2, max_det, 100, &seconds));
+        if (memcmp(n_det, n_det2, total * sizeof(*n_det)) != 0 || memcmp(det, det2, total * max_det * sizeof(*det)) != 0) {
+            fprintf(stderr, "rp_batch_detect_ingest differs from rp_batch_detect_sharded\n");
+            return 1;
+        }
+        printf("rp_batch_detect_ingest: the same %zu detection(s) from host memory in %.1f ms (build %s)\n", found, seconds * 1e3, rp_build_info());
+        free(all); free(det2); free(n_det2);
+    }
     for (int g = 0; g < n_shards; ++g) { rp_templates_free(tm[g]); rp_ctx_free(ctx[g]); free(pcm[g]); }
     free(det); free(n_det); free(utt); free(feat); free(tfeat);
     return found >= (size_t)n_shards ? 0 : 1; /* the planted utterance is found in every shard */

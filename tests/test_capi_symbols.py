@@ -141,6 +141,8 @@ def test_c_examples_run(tmp_path):
     exe = _build_example("sharded_batch", tmp_path, ["-lm"])
     r = subprocess.run([exe, "3", "100"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "303 streams in 3 shards" in r.stdout, r.stdout + r.stderr
+    # round 4: the example also prints how the shards were gathered and runs the same streams through rp_batch_detect_ingest
+    assert "gather: gather into host memory" in r.stdout and "rp_batch_detect_ingest: the same" in r.stdout and "(build gfx950)" in r.stdout, r.stdout
     for shard, glob in ((0, 0), (1, 100), (2, 201)):
         assert "shard %d stream 0 (global %d):" % (shard, glob) in r.stdout, r.stdout
 

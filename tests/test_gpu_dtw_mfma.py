@@ -398,7 +398,8 @@ def test_wide_frames_with_a_rare_length_keep_the_register_kernels(ra, ctx):
 
 def test_full_size_against_the_register_kernels(ra):
     """BASELINE config C3 at FULL size (65 536 streams x 297 windows x 8 templates = 155.7 M scores): the matrix-core kernel against the
-    register kernels on every score -- the largest relative difference stays below 5e-6 (parity gate against the reference: 1e-5), no
+    register kernels on every score -- the largest relative difference stays below 2e-6 (measured 8.95e-7 in round 4, 1.4e-6 in round 3
+    before the template image rounded to nearest; parity gate against the reference: 1e-5), no
     score is further than that from the vector-only arithmetic, and the run is bit-reproducible."""
     import torch
     from test_gpu_parity import _full_size_run
@@ -417,5 +418,5 @@ def test_full_size_against_the_register_kernels(ra):
     for i in range(0, S, 8192):  # in slices: the difference of two 623 MB arrays
         a, b = scores[i:i + 8192], reg[i:i + 8192]
         worst = max(worst, float(((a - b).abs() / b).max()))
-    assert worst < 5e-6, worst
+    assert worst < 2e-6, worst
     print("largest relative difference over %d scores: %.3g" % (scores.numel(), worst))

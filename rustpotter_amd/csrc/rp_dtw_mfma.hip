@@ -200,6 +200,25 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             const int nA = (int)n_win - wA < kMWin ? (int)n_win - wA : kMWin;
             const int nB = (nA < kMWin && sA + 1 < n_streams) ? kMWin - nA : 0;
             const int segA = nA + L + 3;
+#ifndef RP_AB_STAGE1   // A/B builds: the one-load-per-wait staging loop of round 3
+            // four loads in flight per wait: left one by one, a tile's ~11 loads per lane were as many L2 round trips -- nothing covers
+            // them in the first round of a short launch, where every wave of the chip stages at the same time
+            auto stage = [&](const float *src, size_t g0, int n_floats, float *dst) {
+                for (int i0 = lane; i0 < n_floats; i0 += 256) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = i0 + 64 * j;
+                        v[j] = (i < n_floats && g0 + (size_t)(i / K) < n_frames_total) ? src[g0 * K + i] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (i0 + 64 * j < n_floats) dst[i0 + 64 * j] = v[j];
+                }
+            };
+            stage(mfcc + sA * frame_pitch * K, first_win + wA, segA * K, xs);
+            if (nB > 0) stage(mfcc + (sA + 1) * frame_pitch * K, first_win, (nB + L + 3) * K, xs + segA * K);
+#else
             {
                 const float *src = mfcc + sA * frame_pitch * K;
                 const size_t g0 = first_win + wA;
@@ -216,6 +235,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
                     xs[segA * K + i] = first_win + f < n_frames_total ? src[first_win * K + i] : 0.f;
                 }
             }
+#endif
             wave_lds_sync();
             const bool inA = n < nA;
             valid = inA || (n - nA < nB);
@@ -230,7 +250,10 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #ifndef RP_MFMA_GX_MEAN_UNROLL
 #define RP_MFMA_GX_MEAN_UNROLL 20
 #endif
-        constexpr int kMeanUnroll = GX ? RP_MFMA_GX_MEAN_UNROLL : 8;  // from global memory: 20 frames in flight per wait (an L2 round trip each), sums in the same order
+#ifndef RP_MFMA_MEAN_UNROLL
+#define RP_MFMA_MEAN_UNROLL 8
+#endif
+        constexpr int kMeanUnroll = GX ? RP_MFMA_GX_MEAN_UNROLL : RP_MFMA_MEAN_UNROLL;  // from global memory: 20 frames in flight per wait (an L2 round trip each), sums in the same order
 #pragma unroll kMeanUnroll
         for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
         mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;

@@ -454,8 +454,14 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
     size_t blocks = (total + kMfccWaves - 1) / kMfccWaves;
     {   // Waves walk the tiles grid-stride; 16 384 workgroups (16 rounds of the 1 024 resident ones) measured 4-5 % faster than 2 048
         // at C3 (7.7-7.9 against 8.1-8.2 ms): late rounds level out what the CUs finish unevenly, and the tables a workgroup
-        // stages (17 KB from L2) are small.  RP_MFCC_BLOCKS overrides the cap for tuning.
-        static const size_t cap = [] { const char *e = getenv("RP_MFCC_BLOCKS"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)16384; }();
+        // stages (17 KB from L2) are small.  Small batches are the other way round (round 4, BASELINE C2: 101 k wave-tiles): with
+        // 16 384 workgroups a wave gets 1.5 tiles and the per-workgroup set-up (tables, twiddles, the first fetch) is most of its
+        // life -- 0.152 ms against 0.125-0.135 for any cap from 1 024 to 8 192.  So: at least ~6 tiles per wave, between 1 024 (what
+        // is resident) and 16 384 workgroups.  RP_MFCC_BLOCKS overrides the cap for tuning.
+        static const size_t env_cap = [] { const char *e = getenv("RP_MFCC_BLOCKS"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)0; }();
+        size_t cap = total / (6 * kMfccWaves);
+        cap = cap < 1024 ? 1024 : cap > 16384 ? 16384 : cap;
+        if (env_cap) cap = env_cap;
         if (blocks > cap) blocks = cap;
     }
 #define RP_MFCC_LAUNCH(V, KT)                                                                                              \

@@ -552,9 +552,9 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
         // windows the averaged-template gate rejected (their `scores` rows were never written)
         AggExtra ax;
         if (n_win) {
-            if (!c->ws_hot.reserve(S * sizeof(uint32_t) + 16)) return -1;
-            if (!hip_ok(hipMemsetAsync(c->ws_hot.p, 0, S * sizeof(uint32_t), c->stream), "hipMemsetAsync(hot)")) return -1;
-            ax.hot = c->ws_hot.as<uint32_t>(); ax.threshold = config->threshold; ax.n_win = n_win;
+            ax.hot = c->hot_flags(S);   // zero: the scan below puts every flag it reads back (no memset per call)
+            if (!ax.hot) return -1;
+            ax.threshold = config->threshold; ax.n_win = n_win;
             if (gated || gated_generic) { ax.gate_avg = da; ax.gate_threshold = config->avg_threshold; }  // only rows the gate really skipped
         }
         // ScoreMode::Max of a reference whose templates are one chunk of the matrix-core kernel, no averaged template scored: the DTW
@@ -1451,9 +1451,8 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
         // the reference path): the others are not swept
         uint32_t *hot = nullptr;
         if (n_win) {
-            if (!c->ws_hot.reserve(S * sizeof(uint32_t) + 16)) return -1;
-            if (!hip_ok(hipMemsetAsync(c->ws_hot.p, 0, S * sizeof(uint32_t), c->stream), "hipMemsetAsync(hot)")) return -1;
-            hot = c->ws_hot.as<uint32_t>();
+            hot = c->hot_flags(S);
+            if (!hot) return -1;
         }
         if (!hip_ok(launch_nn_score(c->stream, dlog, rows, n_labels, none_index, config->score_ref * 10.f, config->avg_threshold != 0.f ? 1 : 0,
                                     config->threshold, config->avg_threshold, dg, da, dlab, hot, n_win), "nn_score_kernel")) return -1;

@@ -97,6 +97,14 @@ bool Ctx::ingest_ready() {
     return true;
 }
 
+uint32_t *Ctx::hot_flags(size_t S) {
+    const size_t bytes = S * sizeof(uint32_t) + 16;
+    if (bytes > ws_hot.cap) {
+        if (!ws_hot.reserve(bytes) || !hip_ok(hipMemsetAsync(ws_hot.p, 0, ws_hot.cap, stream), "hipMemsetAsync(hot)")) return nullptr;
+    }
+    return ws_hot.as<uint32_t>();
+}
+
 uint32_t *Ctx::mlp_redo(size_t B) {
     const size_t bytes = (2 + B) * sizeof(uint32_t);
     if (bytes > ws_mlp_redo.cap) {   // a new block: its counters start at zero (later calls leave them so)

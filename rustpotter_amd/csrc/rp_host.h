@@ -118,6 +118,10 @@ struct Ctx {
     hipEvent_t ingest_landed[2] = {nullptr, nullptr}, ingest_freed[2] = {nullptr, nullptr};
     DevBuf ws_ingest;
     bool ingest_ready();   // creates the stream and events on first use
+    // per-stream "a window of this stream can fire" flags between the aggregate pass and the scan: zero between calls (the scan clears
+    // what it reads; a call that fails in between leaves spurious 1s, which only cost the next scan its shortcut), zeroed here when the
+    // buffer grows
+    uint32_t *hot_flags(size_t S);
     // the list of rows the wakeword-model forward computes again with the f32 matrix instructions (kMlpF16x2, rp_kernels.h): [2 + B]
     // words, the first two zero between calls
     DevBuf ws_mlp_redo;

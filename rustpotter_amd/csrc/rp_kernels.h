@@ -171,7 +171,7 @@ hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const Templat
 // aggregate pass (a launch, and a second read of every score) is skipped.  launch_dtw sets `done` when it took that route.
 struct DtwFusedAgg {
     float *agg = nullptr;
-    uint32_t *hot = nullptr;   // one flag per stream, zeroed by the caller BEFORE the launch; may be null
+    uint32_t *hot = nullptr;   // one flag per stream, zero before the launch (Ctx::hot_flags: the scan leaves them so); may be null
     float threshold = 0.f;
     bool done = false;
 };
@@ -214,7 +214,7 @@ struct ScanWakewords {
     const float *agg[kScanMaxWakewords], *avg[kScanMaxWakewords];
     float threshold[kScanMaxWakewords], avg_threshold[kScanMaxWakewords];
     const int32_t *label[kScanMaxWakewords];  // model wakewords: the winning label of every window (reported instead of j)
-    const uint32_t *hot = nullptr;            // [S] from the aggregate pass (AggExtra): 0 = no window of the stream can fire
+    uint32_t *hot = nullptr;                  // [S] from the aggregate pass (AggExtra): 0 = no window of the stream can fire; the scan puts the flags it reads back to 0
 };
 
 struct BatchDetection {  // == rp_batch_detection
@@ -285,7 +285,7 @@ hipError_t launch_scan_multi(hipStream_t st, const ScanWakewords &ww, const floa
 // hot (optional): the per-stream flags of the aggregate pass (AggExtra) -- streams whose flag is 0 report no detection unseen
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                        size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det,
-                       const uint32_t *hot = nullptr);
+                       uint32_t *hot = nullptr);
 
 // Decode + GainNormalizerFilter + BandPassFilter over whole streams.  ring [S][window_size], rms / gains
 // [S][n_samples/480] are device workspaces; biquad coefficients as BandPassFilter::new computes them.

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64) void scan_kernel(ScanWakewords ww, const float 
     if (ww.hot) {
         const size_t sh = (size_t)blockIdx.x * 64 + lane;
         candidate = sh < S && ww.hot[sh] != 0u;
+        if (candidate) ww.hot[sh] = 0u;   // consumed: the flags are zero again for the context's next call (no memset per call; Ctx::hot_flags)
     } else {
         if (lane == 0) candidates = 0;
         __syncthreads();
@@ -197,7 +198,7 @@ hipError_t launch_scan_multi(hipStream_t st, const ScanWakewords &ww, const floa
 
 hipError_t launch_scan(hipStream_t st, const float *agg, const float *avg, const float *vad_value, float vad_mode_value,
                        size_t S, size_t n_frames, const ScanConfig &cfg, BatchDetection *det, int32_t *n_det, int max_det,
-                       const uint32_t *hot) {
+                       uint32_t *hot) {
     ScanWakewords ww{};
     ww.n = 1;
     ww.hot = hot;

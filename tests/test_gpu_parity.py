@@ -1169,7 +1169,7 @@ def test_mlp_forward_shapes(ra, ctx, dims):
     model = ra.Model(ctx, ws, bs)
     got = ctx.mlp_forward(x, model)
     ref = orc.mlp_forward(x, ws, bs)
-    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5), np.abs(got - ref).max()
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5), np.abs(got - ref).max()
     if dims[0] % 4 == 0:
         got16 = ctx.mlp_forward(x, model, precision="bf16")
         ref16 = orc.mlp_forward(x, ws, bs, bf16_layer1=True)

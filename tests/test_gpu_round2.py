@@ -554,7 +554,7 @@ def test_c3_sampled_streams_all_windows_vs_oracle(ra):
 def test_c5_full_size_model_forward(ra):
     """BASELINE config C5 at size: B = 65 536 rows x 3 120 features through the Small stack 3120 -> 32 -> 16 -> 2.
     Finite logits, bit-reproducible, a row's logits do not depend on the batch it is in, 256 sampled rows against the f32
-    oracle at 2e-5 (f32 MFMA) and against the bf16-rounding oracle at 1e-3 (bf16 MFMA)."""
+    oracle at 1e-5 (f32 callers) and against the bf16-rounding oracle at 1e-3 (bf16 MFMA)."""
     import torch
     B, dims = 65536, [3120, 32, 16, 2]
     rng = np.random.default_rng(5)
@@ -567,7 +567,7 @@ def test_c5_full_size_model_forward(ra):
     x = torch.randn((B, dims[0]), dtype=torch.float32, device="cuda", generator=gen)
     rows = np.unique(np.concatenate([[0, 1, 15, 16, 127, 128, B - 1], np.random.default_rng(2).integers(0, B, 256)]))
     xs = x[torch.from_numpy(rows).cuda()].contiguous()
-    for prec, tol, bf in (("f32", 2e-5, False), ("bf16", 1e-3, True)):
+    for prec, tol, bf in (("f32", 1e-5, False), ("bf16", 1e-3, True)):
         out = torch.empty((B, 2), dtype=torch.float32, device="cuda")
         out2 = torch.empty_like(out)
         ctx.mlp_dev(model, x.data_ptr(), B, prec, out.data_ptr())

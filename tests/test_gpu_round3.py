@@ -302,7 +302,7 @@ np.save(sys.argv[1], scores)
 def test_mlp_stream_kernel_shapes_and_batch_sizes(ra, ctx, dims, B):
     """mlp_stream_kernel (layer-1 width <= 32, row pitch a multiple of 64 bytes) at batch sizes that leave ragged last tiles,
     with row pitches that put odd rows in the middle of a 128-byte line (3120, 1040 floats) and ones that do not (64, 4096),
-    against the oracle (f32 2e-5; bf16 vs the bf16-rounding oracle 1e-3); bit-identical to itself on a second call and
+    against the oracle (f32 1e-5; bf16 vs the bf16-rounding oracle 1e-3); bit-identical to itself on a second call and
     independent of where a row sits in the batch."""
     os.environ["RP_MLP_STREAM"] = "2"   # the stream kernel for f32 too (the library picks it for bf16 only by default)
     rng = np.random.default_rng(sum(dims) + B)
@@ -312,7 +312,7 @@ def test_mlp_stream_kernel_shapes_and_batch_sizes(ra, ctx, dims, B):
     model = ra.Model(ctx, ws, bs)
     got = ctx.mlp_forward(x, model)
     ref = orc.mlp_forward(x, ws, bs)
-    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5), np.abs(got - ref).max()
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-5), np.abs(got - ref).max()
     assert ctx.mlp_forward(x, model).tobytes() == got.tobytes()
     if B > 2:   # a row's logits do not depend on its position (even / odd rows start at different line phases)
         sub = ctx.mlp_forward(x[1:], model)
@@ -331,7 +331,7 @@ def test_mlp_stream_kernel_shapes_and_batch_sizes(ra, ctx, dims, B):
     # (kMlpF16x2: within 1e-5 of the f32 matrix instructions -- the distance two f32 summation orders have -- and not their bits), batch-invariant
     # and bit-reproducible like the other forms; a row with a feature beyond the f16 range comes from the f32 matrix instructions
     split = ctx.mlp_forward(x, model)
-    assert np.allclose(split, ref, rtol=2e-5, atol=2e-5)
+    assert np.allclose(split, ref, rtol=1e-5, atol=1e-5)
     os.environ["RP_MLP_STREAM"] = "0"
     exact = ctx.mlp_forward(x, model)
     os.environ.pop("RP_MLP_STREAM")
@@ -379,7 +379,7 @@ def test_mlp_stream_kernel_unaligned_base_and_nan_neighbours(ra):
         dctx.mlp_dev(model, buf.data_ptr() + 4 * off, B, "f32", out.data_ptr())
         dctx.synchronize()
         o = out.cpu().numpy()
-        assert np.isfinite(o).all() and np.allclose(o, ref, rtol=2e-5, atol=2e-5), off
+        assert np.isfinite(o).all() and np.allclose(o, ref, rtol=1e-5, atol=1e-5), off
         outs.append(o)
     assert all(o.tobytes() == outs[0].tobytes() for o in outs)   # the k order does not depend on the phase
     xn = x.copy()

@@ -171,6 +171,7 @@ extern "C" {
                         out: *mut *mut rp_model) -> c_int;
     pub fn rp_model_free(m: *mut rp_model);
     pub fn rp_mlp_forward_batch(ctx: *mut rp_ctx, model: *const rp_model, x: *const f32, B: usize, precision: c_int, logits: *mut f32) -> c_int;
+    pub fn rp_mlp_forward_windows(ctx: *mut rp_ctx, model: *const rp_model, mfcc: *const f32, S: usize, n_frames: usize, mfcc_size: c_int, precision: c_int, logits: *mut f32) -> c_int;
     pub fn rp_batch_detect_model(ctx: *mut rp_ctx, pcm: *const c_void, fmt: c_int, S: usize, n_samples: usize, pcm_stride: usize,
                                  model: *const rp_model, mfcc_size: c_int, none_index: c_int, config: *const rp_detector_config,
                                  precision: c_int, det: *mut rp_batch_detection, det_label: *mut i32, n_det: *mut i32, max_det: c_int) -> c_int;
@@ -510,6 +511,16 @@ impl HipContext {
         assert!(x.len() >= rows * m.dims[0] as usize);
         let mut out = vec![0f32; rows * *m.dims.last().unwrap() as usize];
         status(unsafe { rp_mlp_forward_batch(self.h, m.h, x.as_ptr(), rows, if bf16 { RP_MLP_BF16 } else { RP_MLP_F32 }, out.as_mut_ptr()) })?;
+        Ok(out)
+    }
+    /// The forward over every window of `train_size = dims[0] / mfcc_size` frames of each stream's MFCC rows (what `WakewordNN::run_detection`
+    /// computes frame after frame, src/wakewords/nn/wakeword_nn.rs:101-159): mfcc `[streams][n_frames][mfcc_size]` -> logits `[streams][n_win][labels]`.
+    pub fn mlp_forward_windows(&self, m: &Model, mfcc: &[f32], n_streams: usize, n_frames: usize, mfcc_size: u16) -> Result<Vec<f32>, String> {
+        assert!(mfcc.len() >= n_streams * n_frames * mfcc_size as usize);
+        let train_size = m.dims[0] as usize / mfcc_size as usize;
+        let n_win = if n_frames >= train_size { n_frames - train_size + 1 } else { 0 };
+        let mut out = vec![0f32; n_streams * n_win * *m.dims.last().unwrap() as usize];
+        status(unsafe { rp_mlp_forward_windows(self.h, m.h, mfcc.as_ptr(), n_streams, n_frames, mfcc_size as c_int, RP_MLP_F32, out.as_mut_ptr()) })?;
         Ok(out)
     }
     /// `WakewordNN::run_detection` inside the detection state machine, for whole streams; returns detections and their label indices.

@@ -196,7 +196,7 @@ int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs);
  * those into rustpotter_amd/variants/, never over the product).  bench.py prints it on its JSON line. */
 const char *rp_build_info(void);
 /* Diagnostics of the wakeword-model forward (replaces nothing; src/wakewords/nn/wakeword_nn.rs:101-106 is what it computes): the
- * kernel(s) the last rp_mlp_forward_batch of this context ran and their operand format, e.g. "mlp_stream_kernel<f16x2 splits> +
+ * kernel(s) the last rp_mlp_forward_batch / rp_mlp_forward_windows / rp_batch_detect_model of this context ran and their operand format, e.g. "mlp_stream_kernel<f16x2 splits> +
  * mlp_mfma_kernel<f32> on listed rows".  The string belongs to the context and is valid until its next forward; "" before the first. */
 const char *rp_ctx_last_mlp_kernel(rp_ctx *ctx);
 
@@ -466,6 +466,16 @@ enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1, RP_MLP_F32_STRICT = 2 };
  * accumulate. */
 
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits);
+
+/* The same forward over EVERY window of S streams' MFCC rows, what WakewordNN::run_detection computes frame after frame
+ * (src/wakewords/nn/wakeword_nn.rs:101-159: the window of train_size = dims[0] / mfcc_size frames, mean-normalised by
+ * MfccNormalizer::normalize, flattened, through the model): mfcc [S][n_frames][mfcc_size] -> logits [S][n_win][dims[n_layers]],
+ * n_win = n_frames - train_size + 1 (0 rows when a stream is shorter than a window).  The windows are never materialised: a
+ * stream's frames are staged once and the window mean is taken out after layer 1 (W.(f - mu) = W.f - sum_k mu[k] wsum[k]);
+ * RP_MLP_BF16 is accepted and computes as RP_MLP_F32 here (bf16 is an INPUT format of rp_mlp_forward_batch's dense rows).
+ * rp_batch_detect_model is this call between rp_mfcc_batch and the score / detection passes. */
+int rp_mlp_forward_windows(rp_ctx *ctx, const rp_model *model, const float *mfcc, size_t S, size_t n_frames, int mfcc_size,
+                           int precision, float *logits);
 
 /* rp_batch_detect for a wakeword MODEL (WakewordNN::run_detection, src/wakewords/nn/wakeword_nn.rs:39-159, inside the
  * detection state machine): MFCC -> windows of train_size = dims[0] / mfcc_size frames, mean-normalised -> MLP forward

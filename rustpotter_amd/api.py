@@ -104,7 +104,7 @@ SYMBOLS = [
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
     "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_batch_detect_ingest", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
-    "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
+    "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_mlp_forward_windows", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
     "rp_stream_batch_chunks_seen", "rp_resampler_frame_lengths", "rp_resample_batch",
     "rp_wakeword_model_train", "rp_stream_batch_set_input", "rp_stream_batch_samples_per_chunk",
@@ -217,6 +217,7 @@ def load_library():
     L.rp_model_new.argtypes = [vp, C.c_int, ip, C.POINTER(fp), C.POINTER(fp), C.POINTER(vp)]
     L.rp_model_free.argtypes = [vp]
     L.rp_mlp_forward_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
+    L.rp_mlp_forward_windows.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int, vp]
     L.rp_synth_pcm_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, vp]
     L.rp_ctx_timing_enable.argtypes = [vp, C.c_int]
     L.rp_ctx_timing_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), ip]
@@ -943,6 +944,19 @@ class BatchContext:
         out = np.empty((x.shape[0], model.n_out), np.float32)
         if self._L.rp_mlp_forward_batch(self._h, model._h, x.ctypes.data, x.shape[0], MLP_PRECISION[precision],
                                         out.ctypes.data) < 0:
+            raise _err()
+        return out
+
+    def mlp_forward_windows(self, mfcc, model, precision="f32"):
+        """rp_mlp_forward_windows: mfcc [S][n_frames][K] -> logits [S][n_win][labels] of every window of the model's train_size frames."""
+        import numpy as np
+        assert self.host
+        mfcc = np.ascontiguousarray(mfcc, np.float32)
+        S, nf, K = mfcc.shape
+        L = model.n_in // K
+        n_win = max(nf - L + 1, 0)
+        out = np.empty((S, n_win, model.n_out), np.float32)
+        if self._L.rp_mlp_forward_windows(self._h, model._h, mfcc.ctypes.data, S, nf, K, MLP_PRECISION[precision], out.ctypes.data) < 0:
             raise _err()
         return out
 

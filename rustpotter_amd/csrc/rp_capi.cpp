@@ -1375,6 +1375,78 @@ int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, siz
     });
 }
 
+// Logits of every window of L frames of S streams' MFCC rows dm [S][nf][K] (WakewordNN::run_detection's forward, window by window,
+// src/wakewords/nn/wakeword_nn.rs:101-159): dlog [S * n_win][labels].  Shared by rp_batch_detect_model and rp_mlp_forward_windows.
+static bool window_logits(Ctx *c, const Model &m, const float *dm, size_t S, size_t nf, size_t n_win, int L, int K, int precision, float *dlog) {
+    const size_t rows = S * n_win;
+    const int nl_layers = (int)m.dims.size() - 1, n_labels = m.dims[nl_layers];
+    bool ok = true;
+    {
+        // (RP_MLP_BF16 only permits bf16 inputs: the in-place window kernel is f32 and faster than materialising rows)
+        const float *wsum = (m.mfma_ok && K % 4 == 0) ? const_cast<Model &>(m).wsum_for(K) : nullptr;
+        if (wsum) {
+            // windows read in place from the frame array, the window mean taken out after layer 1
+            if (!c->ws_gain.reserve(rows * (size_t)K * sizeof(float) + 16)) return false;
+            float *dmean = c->ws_gain.as<float>();
+            if (!hip_ok(launch_window_means(c->stream, dm, S, nf, n_win, L, K, dmean), "window_means_kernel")) return false;
+            c->time_begin(kKernelMlp);
+            uint32_t *redo = c->mlp_redo(rows);
+            if (!redo) return false;
+            ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, dm, S, nf, n_win, K, dmean, wsum, dlog, redo, 0, precision == RP_MLP_F32_STRICT), "mlp_mfma_kernel");
+            c->time_end();
+            if (!ok) return false;
+            c->last_mlp_kernel = precision == RP_MLP_F32_STRICT ? "mlp_mfma_kernel<f32 matrix instructions>, windows read in place"
+                                 : mlp_windows_supported(m.dev, n_win, K) ? "mlp_windows_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
+                                 : "mlp_mfma_kernel<f16x2 splits>, windows read in place, + mlp_mfma_kernel<f32> on listed rows";
+        } else {
+            // windows are materialised slab by slab (a row is dims[0] floats): <= 4 GiB of rows at a time
+            const size_t row_bytes = (size_t)m.dims[0] * sizeof(float);
+            size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / row_bytes);
+            if (slab > rows) slab = rows;
+            int maxd = 0;
+            for (int d : m.dims) maxd = std::max(maxd, d);
+            if (!c->ws_scores.reserve(slab * row_bytes + 64)) return false;
+            if (!m.mfma_ok && !c->ws_gain.reserve(2 * slab * (size_t)maxd * sizeof(float) + 16)) return false;
+            float *dx = c->ws_scores.as<float>();
+            for (size_t r0 = 0; r0 < rows; r0 += slab) {
+                const size_t nr = std::min(slab, rows - r0);
+                if (!hip_ok(launch_normalize_windows_batch(c->stream, dm, nf, n_win, r0, nr, L, K, dx), "normalize_windows_kernel")) return false;
+                c->time_begin(kKernelMlp);
+                if (m.mfma_ok) ok = hip_ok(mlp_rows_mfma(c, m, dx, nr, precision, dlog + r0 * n_labels), "mlp_mfma_kernel");
+                else ok = hip_ok(launch_mlp(c->stream, dx, nr, nl_layers, m.dims.data(), m.W.data(), m.B.data(), c->ws_gain.as<float>(),
+                                            c->ws_gain.as<float>() + slab * (size_t)maxd, dlog + r0 * n_labels), "mlp_layer_kernel");
+                c->time_end();
+                if (!ok) return false;
+            }
+        }
+    }
+    return ok;
+}
+
+int rp_mlp_forward_windows(rp_ctx *ctx, const rp_model *model, const float *mfcc, size_t S, size_t n_frames, int mfcc_size, int precision,
+                           float *logits) {
+    return guarded([&]() -> int {
+        if (!ctx || !model) { set_last_error("null handle"); return -1; }
+        Ctx *c = ctx->impl.get();
+        if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        const Model &m = *model->impl;
+        const int nl = (int)m.dims.size() - 1, K = mfcc_size;
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
+        if (K < 1 || m.dims[0] % K != 0) { set_last_error("Model input size does not match the mfcc size"); return -1; }
+        const int L = m.dims[0] / K;
+        const size_t n_win = n_frames >= (size_t)L ? n_frames - L + 1 : 0, rows = S * n_win;
+        if (rows == 0) return 0;
+        if (!mfcc || !logits) { set_last_error("null argument"); return -1; }
+        Staged sg(c);
+        const float *dm = static_cast<const float *>(sg.in(mfcc, S * n_frames * (size_t)K * 4, c->stage_in));
+        float *dl = static_cast<float *>(sg.out(logits, rows * (size_t)m.dims[nl] * 4, c->stage_out));
+        if (!dm || !dl) return -1;
+        if (!window_logits(c, m, dm, S, n_frames, n_win, L, K, precision, dl)) return -1;
+        if (!sg.back(logits, dl, rows * (size_t)m.dims[nl] * 4) || !sg.finish()) return -1;
+        return 0;
+    });
+}
+
 int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, size_t S, size_t n_samples, size_t pcm_stride,
                           const rp_model *model, int mfcc_size, int none_index, const rp_detector_config *config, int precision,
                           rp_batch_detection *det, int32_t *det_label, int32_t *n_det, int max_det) {
@@ -1411,40 +1483,7 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
         if (!c->ws_ring.reserve(rows * (size_t)n_labels * sizeof(float) + 16) || !c->ws_agg.reserve(rows * sizeof(float) + 16) ||
             !c->ws_avg.reserve(rows * sizeof(float) + 16) || !c->ws_rms.reserve(rows * sizeof(int32_t) + 16)) return -1;
         float *dlog = c->ws_ring.as<float>();
-        // (RP_MLP_BF16 only permits bf16 inputs: the in-place window kernel is f32 and faster than materialising rows)
-        const float *wsum = (m.mfma_ok && K % 4 == 0) ? const_cast<Model &>(m).wsum_for(K) : nullptr;
-        if (wsum) {
-            // windows read in place from the frame array, the window mean taken out after layer 1
-            if (!c->ws_gain.reserve(rows * (size_t)K * sizeof(float) + 16)) return -1;
-            float *dmean = c->ws_gain.as<float>();
-            if (!hip_ok(launch_window_means(c->stream, dm, S, nf, n_win, L, K, dmean), "window_means_kernel")) return -1;
-            c->time_begin(kKernelMlp);
-            uint32_t *redo = c->mlp_redo(rows);
-            if (!redo) return -1;
-            ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, dm, S, nf, n_win, K, dmean, wsum, dlog, redo, 0, precision == RP_MLP_F32_STRICT), "mlp_mfma_kernel");
-            c->time_end();
-            if (!ok) return -1;
-        } else {
-            // windows are materialised slab by slab (a row is dims[0] floats): <= 4 GiB of rows at a time
-            const size_t row_bytes = (size_t)m.dims[0] * sizeof(float);
-            size_t slab = std::max<size_t>(1, ((size_t)4 << 30) / row_bytes);
-            if (slab > rows) slab = rows;
-            int maxd = 0;
-            for (int d : m.dims) maxd = std::max(maxd, d);
-            if (!c->ws_scores.reserve(slab * row_bytes + 64)) return -1;
-            if (!m.mfma_ok && !c->ws_gain.reserve(2 * slab * (size_t)maxd * sizeof(float) + 16)) return -1;
-            float *dx = c->ws_scores.as<float>();
-            for (size_t r0 = 0; r0 < rows; r0 += slab) {
-                const size_t nr = std::min(slab, rows - r0);
-                if (!hip_ok(launch_normalize_windows_batch(c->stream, dm, nf, n_win, r0, nr, L, K, dx), "normalize_windows_kernel")) return -1;
-                c->time_begin(kKernelMlp);
-                if (m.mfma_ok) ok = hip_ok(mlp_rows_mfma(c, m, dx, nr, precision, dlog + r0 * n_labels), "mlp_mfma_kernel");
-                else ok = hip_ok(launch_mlp(c->stream, dx, nr, nl_layers, m.dims.data(), m.W.data(), m.B.data(), c->ws_gain.as<float>(),
-                                            c->ws_gain.as<float>() + slab * (size_t)maxd, dlog + r0 * n_labels), "mlp_layer_kernel");
-                c->time_end();
-                if (!ok) return -1;
-            }
-        }
+        if (!window_logits(c, m, dm, S, nf, n_win, L, K, precision, dlog)) return -1;
         float *dg = c->ws_agg.as<float>(), *da = c->ws_avg.as<float>();
         int32_t *dlab = c->ws_rms.as<int32_t>();
         // nn_score_kernel also tells the scan which streams have a window that passed (a flag per stream, like the aggregate pass of

@@ -640,6 +640,209 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Layer 1 over ALL windows of a stream from one staging of its frames (round 4).  mlp_mfma_kernel in window mode reads every window's
+// 3 120 features through the vector cache and splits each of them into its two f16 parts again -- a frame belongs to L = 195 windows,
+// so the same split is done 195 times: 57 % of the SIMD cycles of that kernel are vector instructions, 24 % matrix ones (PMC, 32 768
+// streams: 7.6 ms), and every 64 rows stage the 400 KB of split weights again.  Here a workgroup owns up to 256 consecutive windows of
+// ONE stream: their frames (at most 256 + L - 1) are split once into LDS, plane p / k-half h / frame in 16-byte slots (a wave's 32
+// rows read 32 consecutive slots: conflict-free), and window row w at k-step f (= frame f of the window, mfcc_size 16 = one
+// v_mfma_f32_32x32x16_f16 step) is simply slot w + f.  The weights stream through LDS once per workgroup in groups of five frames,
+// in the order the lanes read them (MlpDev::wwin).  Two 32-row tiles per wave share the weight reads.  Same products as kMlpF16x2
+// (x0 w0 + x1 w0 + x0 w1), same mean correction, bias, ReLU and tail layers as mlp_mfma_kernel; rows holding a frame beyond the f16
+// range are listed for the f32 pass.  Shapes: mfcc_size 16, layer 1 <= 32 wide, tail layers <= 32 wide, n_win >= 32.
+constexpr int kWinWaves = 4, kWinTpw = 2, kWinTile = 32, kWinRows = kWinWaves * kWinTpw * kWinTile, kWinGroup = 5;
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64 * kWinWaves) void mlp_windows_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames, size_t n_win, int L, unsigned blocks_per_stream,
+    const u32x4v *__restrict__ wimg, int n_groups, int slots, int n1p, const float *__restrict__ b1, const float *__restrict__ mean,
+    const float *__restrict__ wsum, const float *__restrict__ tail, int tail_floats, int n_layers, int d1, int d2, int d3,
+    float *__restrict__ out, uint32_t *redo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int GROUP_PIECES = kWinGroup * 2 * 2 * 32;                  // 16-byte pieces of a staged weight group
+    constexpr int NV = (GROUP_PIECES + 64 * kWinWaves - 1) / (64 * kWinWaves);
+    // slots = kWinRows + whole groups of frames: every (row, frame) a wave may read exists, zero past the real frames
+    u32x4v *A = reinterpret_cast<u32x4v *>(smem);                          // [2 planes][2 k-halves][slots]
+    u32x4v *Wb = A + 4 * slots;                                        // [2 buffers][kWinGroup][2 planes][2 k-halves][32]
+    float *tl = reinterpret_cast<float *>(Wb + 2 * GROUP_PIECES);          // tail weights
+    unsigned *flag = reinterpret_cast<unsigned *>(tl + ((tail_floats + 3) & ~3));   // [slots] frame holds a value beyond the f16 range
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lr = l & 31, lh = l >> 5;
+    const size_t s = blockIdx.x / blocks_per_stream;
+    const size_t w0 = (size_t)(blockIdx.x - s * blocks_per_stream) * kWinRows;   // first window of this workgroup
+    const size_t rows_here = n_win - w0 < (size_t)kWinRows ? n_win - w0 : (size_t)kWinRows;
+    const int n_slots = (int)rows_here + L - 1;                                   // frames w0 .. w0 + n_slots - 1 are real
+    for (int i = tid; i < tail_floats; i += 64 * kWinWaves) tl[i] = tail[i];
+    // ---- frames -> the two f16 planes, once
+    const float *src = mfcc + (s * frame_pitch + w0) * 16;
+    (void)n_frames;
+    for (int i = tid; i < 2 * slots; i += 64 * kWinWaves) {
+        const int fr = i >> 1, h = i & 1;
+        u32x4v p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
+        unsigned far = 0u;
+        if (fr < n_slots) {
+            const float4 lo = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h);
+            const float4 hi = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h + 4);
+            const float xs[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            float rng = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = xs[2 * e], b = xs[2 * e + 1];
+                rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
+                p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+                p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
+            }
+            far = !(rng <= 65504.f);
+        }
+        A[(0 * 2 + h) * slots + fr] = p0;
+        A[(1 * 2 + h) * slots + fr] = p1;
+        if (h == 0) flag[fr] = 0u;   // the two halves of a frame belong to neighbouring lanes of one wave: its LDS stores keep their order
+        if (far) flag[fr] = 1u;
+    }
+    // ---- weight groups through LDS, double buffered; registers carry the next group across the barrier
+    u32x4v wreg[NV];
+    auto wload = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = tid + v * 64 * kWinWaves;
+            if (i < GROUP_PIECES) wreg[v] = wimg[(size_t)g * GROUP_PIECES + i];
+        }
+    };
+    auto wstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int i = tid + v * 64 * kWinWaves;
+            if (i < GROUP_PIECES) Wb[buf * GROUP_PIECES + i] = wreg[v];
+        }
+    };
+    wload(0);
+    wstore(0);
+    __syncthreads();
+    f32x16w acc[kWinTpw];
+#pragma unroll
+    for (int t = 0; t < kWinTpw; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const int row_t0 = (wave * kWinTpw) * kWinTile;   // this wave's first row inside the workgroup
+    const bool wave_live = (size_t)row_t0 < rows_here;
+    for (int g = 0; g < n_groups; ++g) {
+        if (g + 1 < n_groups) wload(g + 1);
+        if (wave_live) {
+            const u32x4v *wb = Wb + (g & 1) * GROUP_PIECES;
+#pragma unroll
+            for (int ff = 0; ff < kWinGroup; ++ff) {
+                const int f = g * kWinGroup + ff;   // frames past L carry zero weights; their slots exist (zero padded)
+                const f16x8 b0 = __builtin_bit_cast(f16x8, wb[((ff * 2 + 0) * 2 + lh) * 32 + lr]);
+                const f16x8 b1v = __builtin_bit_cast(f16x8, wb[((ff * 2 + 1) * 2 + lh) * 32 + lr]);
+                f16x8 a0[kWinTpw], a1[kWinTpw];
+#pragma unroll
+                for (int t = 0; t < kWinTpw; ++t) {
+                    const int slot = row_t0 + t * kWinTile + lr + f;
+                    a0[t] = __builtin_bit_cast(f16x8, A[(0 * 2 + lh) * slots + slot]);
+                    a1[t] = __builtin_bit_cast(f16x8, A[(1 * 2 + lh) * slots + slot]);
+                }
+#pragma unroll
+                for (int t = 0; t < kWinTpw; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < kWinTpw; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t], b0, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < kWinTpw; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1v, acc[t], 0, 0, 0);
+            }
+        }
+        if (g + 1 < n_groups) wstore((g + 1) & 1);
+        __syncthreads();
+    }
+    // every wave is past the last barrier: the frame planes and weight buffers become h1 / h2 of the waves ([32][33] floats each)
+    float *h1 = reinterpret_cast<float *>(smem) + wave * 2 * 32 * 33, *h2 = h1 + 32 * 33;
+    const bool relu1 = n_layers > 1;
+    float4 ws4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ws4[k] = lr < n1p ? *reinterpret_cast<const float4 *>(wsum + (size_t)lr * 16 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float bias1 = lr < n1p ? b1[lr] : 0.f;
+    for (int t = 0; t < kWinTpw; ++t) {
+        const size_t wrow0 = (size_t)row_t0 + (size_t)t * kWinTile;   // first row of the tile inside the workgroup
+        if (wrow0 >= rows_here) break;                                  // wave-uniform
+        // C/D layout of the 32x32 tile: lane (column lr, half lh) holds rows 8 * (e / 4) + 4 * lh + e % 4
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 8 * (e >> 2) + 4 * lh + (e & 3);
+            size_t rr = wrow0 + row;
+            if (rr >= rows_here) rr = rows_here - 1;
+            const float4 *mu = reinterpret_cast<const float4 *>(mean + (s * n_win + w0 + rr) * 16);
+            float corr = 0.f;   // - sum_k mu[row][k] * wsum[o][k], the order of mlp_mfma_kernel
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 m4 = mu[k], w4 = ws4[k];
+                corr = fmaf(m4.x, w4.x, corr); corr = fmaf(m4.y, w4.y, corr); corr = fmaf(m4.z, w4.z, corr); corr = fmaf(m4.w, w4.w, corr);
+            }
+            float v = acc[t][e] - corr;
+            v += bias1;
+            if (relu1 && v < 0.f) v = 0.f;
+            h1[row * 33 + lr] = v;
+        }
+        wave_lds_sync();
+        // tail layers: lane = (row lr, output phase lh), outputs strided by 2 over the phases; sums in mlp_mfma_kernel's order
+        {
+            const bool row_ok = wrow0 + lr < rows_here;
+            const size_t orow = s * n_win + w0 + wrow0 + lr;
+            if (lh == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
+                unsigned far = 0u;
+                for (int f = 0; f < L; ++f) far |= flag[wrow0 + lr + f];
+                if (far) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)orow;
+            }
+            const int dd[4] = {d1, d2, d3, 0};
+            const float *hin = h1 + lr * 33;
+            const float *wp = tl;
+            int cur_in = d1;
+            float *dst = out + orow * (size_t)dd[n_layers - 1];
+            if (n_layers == 1 && row_ok)
+                for (int o = lh; o < d1; o += 2) dst[o] = hin[o];
+            for (int layer = 1; layer < n_layers; ++layer) {
+                const int on = dd[layer];
+                const bool last = layer + 1 == n_layers;
+                for (int o = lh; o < on; o += 2) {
+                    const float *wr = wp + (size_t)o * cur_in;
+                    float s0 = 0.f, s1 = 0.f;
+                    int i = 0;
+                    for (; i + 1 < cur_in; i += 2) { s0 = fmaf(hin[i], wr[i], s0); s1 = fmaf(hin[i + 1], wr[i + 1], s1); }
+                    if (i < cur_in) s0 = fmaf(hin[i], wr[i], s0);
+                    float sacc = (s0 + s1) + wp[(size_t)on * cur_in + o];
+                    if (!last && sacc < 0.f) sacc = 0.f;
+                    if (last) { if (row_ok) dst[o] = sacc; } else h2[lr * 33 + o] = sacc;
+                }
+                wave_lds_sync();
+                wp += (size_t)on * cur_in + on;
+                cur_in = on;
+                hin = h2 + lr * 33;
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+bool mlp_windows_supported(const MlpDev &m, size_t n_win, int K) {
+    if (!m.wwin || K != 16 || m.dims[0] % 16 != 0 || m.dims[1] > 32 || n_win < 32) return false;
+    const int L = m.dims[0] / 16;
+    if (L + kWinGroup > 256 || m.tail_floats > 4096) return false;
+    for (int l2 = 2; l2 <= m.n_layers; ++l2) if (m.dims[l2] > 32) return false;
+    const char *env = std::getenv("RP_MLP_WINDOWS");
+    return !(env && env[0] == '0');
+}
+
+static hipError_t launch_mlp_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, const float *mean,
+                                     const float *wsum, float *out, uint32_t *redo, size_t pitch) {
+    const int L = m.dims[0] / 16, n_groups = (L + kWinGroup - 1) / kWinGroup;
+    const size_t bps = (n_win + kWinRows - 1) / kWinRows, blocks = bps * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const int slots = (kWinRows + n_groups * kWinGroup + 3) & ~3;
+    const size_t lds = (size_t)4 * slots * 16 + (size_t)2 * kWinGroup * 2 * 2 * 32 * 16 + (size_t)((m.tail_floats + 3) & ~3) * 4 + (size_t)slots * 4;
+    static_assert((size_t)4 * kWinRows * 16 + (size_t)2 * kWinGroup * 2 * 2 * 32 * 16 >= (size_t)kWinWaves * 2 * 32 * 33 * 4, "h1 / h2 of the waves fit the planes + weight buffers");
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_kernel), 160 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL(mlp_windows_kernel, dim3((unsigned)blocks), dim3(64 * kWinWaves), lds, st, mfcc, pitch, n_frames, n_win, L, (unsigned)bps,
+                       static_cast<const u32x4v *>(m.wwin), n_groups, slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
+                       m.dims[3], out, redo);
+    return hipGetLastError();
+}
+
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
                                    const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch, bool strict_f32) {
     const size_t B = S * n_win;
@@ -651,6 +854,16 @@ hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float 
     if (pitch < n_win) return hipErrorInvalidValue;
     (void)n_frames;
     const size_t skip = (pitch - n_win) * K;
+    if (!strict_f32 && redo && mlp_windows_supported(m, n_win, K)) {
+        // whole streams (or long runs of windows): the frames staged once per workgroup; then the listed rows with the f32 instructions
+        if (S * n_win > 0xffffffffULL) return hipErrorInvalidValue;
+        if (hipError_t e = launch_mlp_windows(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch); e != hipSuccess) return e;
+        switch (m.nt) {
+        case 1: return launch_mlp_nt<1>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+        case 2: return launch_mlp_nt<2>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+        }
+        return hipErrorInvalidValue;
+    }
     const int prec = strict_f32 ? kMlpStrictF32 : kMlpF32;
     switch (m.nt) {
     case 1: return launch_mlp_nt<1>(st, m, mfcc, B, prec, out, redo, (size_t)K, n_win, skip, mean, wsum, K);

@@ -493,3 +493,84 @@ def test_per_call_words_survive_interleaved_calls(ra, ctx):
     for i in range(200):
         k = names[int(rng.integers(len(names)))]
         assert kinds[k]() == first[k], (i, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# mlp_windows_kernel: layer 1 over all windows of a stream from one staging of its frames (rp_mlp_forward_windows)
+def _window_logits_oracle(mfcc, L, ws, bs):
+    S, nf, K = mfcc.shape
+    n_win = nf - L + 1
+    out = np.empty((S, n_win, ws[-1].shape[0]), np.float32)
+    for s in range(S):
+        rows = np.empty((n_win, L * K), np.float32)
+        for w in range(n_win):
+            win = mfcc[s, w:w + L]
+            acc = np.zeros(K, np.float32)
+            for f in range(L):          # MfccNormalizer::normalize: the column sums in frame order
+                acc = acc + win[f]
+            rows[w] = (win - acc / np.float32(L)).reshape(-1)
+        out[s] = orc.mlp_forward(rows, ws, bs)
+    return out
+
+
+def _window_model(rng, L, K, hidden, labels):
+    dims = [L * K] + list(hidden) + [labels]
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(len(dims) - 1)]
+    return ws, bs
+
+
+@pytest.mark.parametrize("L,hidden,labels,nf,S", [
+    (195, (32, 16), 2, 399, 3),     # the Small shape of BASELINE C5 on 4 s streams: 205 windows = 7 tiles, the last one ragged
+    (195, (13,), 2, 450, 2),        # Tiny: one 16-wide output tile (bias / mean-correction rows past it do not exist)
+    (50, (32, 32), 3, 81, 2),       # exactly 32 windows: the smallest call the kernel takes
+    (251, (17, 8), 2, 550, 2),      # 300 windows: two workgroups per stream; 251 frames = the longest window, 51 weight groups (the last one ragged)
+    (7, (), 30, 100, 1),            # a single layer
+    (195, (32, 16), 2, 225, 2),     # 31 windows: stays with mlp_mfma_kernel (rows read in place)
+])
+def test_window_logits_match_the_oracle(ra, ctx, L, hidden, labels, nf, S):
+    """rp_mlp_forward_windows against the oracle's window-by-window forward (normalise, flatten, ModelImpl::forward): features with
+    coefficient-dependent offsets like real MFCCs (the kernel takes the window mean out AFTER layer 1), gate 1e-5 relative to
+    the larger of the logit and the largest feature; equal to itself on a second call, independent of the other streams."""
+    K = 16
+    rng = np.random.default_rng(L * 1000 + nf)
+    ws, bs = _window_model(rng, L, K, hidden, labels)
+    model = ra.Model(ctx, ws, bs)
+    off = rng.uniform(-3.0, 3.0, K).astype(np.float32)
+    mfcc = (rng.standard_normal((S, nf, K)) * rng.uniform(0.5, 2.0, (S, 1, 1)) + off).astype(np.float32)
+    got = ctx.mlp_forward_windows(mfcc, model)
+    ref = _window_logits_oracle(mfcc, L, ws, bs).astype(np.float64)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    tol = 1e-5 * np.maximum(np.abs(ref), np.abs(mfcc).max())
+    assert (np.abs(got - ref) <= tol).all(), float((np.abs(got - ref) / tol).max())
+    assert ctx.mlp_forward_windows(mfcc, model).tobytes() == got.tobytes()
+    one = ctx.mlp_forward_windows(mfcc[S - 1:], model)
+    assert one.tobytes() == got[S - 1:].tobytes()
+    os.environ["RP_MLP_WINDOWS"] = "0"      # and against mlp_mfma_kernel reading the rows in place: two summation orders of the same products
+    try:
+        old = ctx.mlp_forward_windows(mfcc, model)
+    finally:
+        os.environ.pop("RP_MLP_WINDOWS")
+    assert (np.abs(old.astype(np.float64) - ref) <= tol).all() and (np.abs(old.astype(np.float64) - got) <= 2 * tol).all()
+
+
+def test_window_logits_with_a_frame_beyond_the_f16_range(ra, ctx):
+    """A frame holding 1e6 (an f16 part cannot): exactly the windows that contain it are listed and come from the f32 matrix
+    instructions -- finite, right, and every other window keeps the bits it has without that frame in the batch."""
+    K, L, nf = 16, 195, 399
+    rng = np.random.default_rng(77)
+    ws, bs = _window_model(rng, L, K, (32, 16), 2)
+    model = ra.Model(ctx, ws, bs)
+    mfcc = rng.standard_normal((3, nf, K)).astype(np.float32)
+    clean = ctx.mlp_forward_windows(mfcc, model)
+    hot = mfcc.copy()
+    hot[1, 300, 5] = 1e6
+    got = ctx.mlp_forward_windows(hot, model)
+    ref = _window_logits_oracle(hot, L, ws, bs).astype(np.float64)
+    assert np.isfinite(got).all()
+    inside = np.zeros((3, nf - L + 1), bool)
+    inside[1, 300 - L + 1:301] = True
+    assert got[~inside].tobytes() == clean[~inside].tobytes()
+    tol = 2e-5 * np.maximum(np.abs(ref), 1e6)
+    assert (np.abs(got - ref)[inside] <= tol[inside]).all() and not np.array_equal(got[inside], clean[inside])
+    assert ctx.last_mlp_kernel() != ""

@@ -362,13 +362,32 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     // weights), so the HBM stream never drains at the per-group barrier
     constexpr int NA = PREC == kMlpF32 ? kMlpKG / 16 : 2 * (kMlpKG / 32);
     float4 areg[2][NA];
+    // Windows of mfcc_size 16 (norm16): the row's own window mean leaves each feature as it is loaded -- MfccNormalizer::normalize itself;
+    // a lane's pieces always hold the same coefficients (k0 mod 16 = 4 lk, or 8 (lk & 1) + 4 (u & 1)).  Until round 4 the mean was taken
+    // out after layer 1 for every mfcc size (the epilogue below, still what other sizes get): real MFCCs sit on offsets many times their
+    // spread, and a sum that carries the offsets loses their size in f32 rounding (5e-6 of a score on the reference's own recording).
+    const bool norm16 = mean != nullptr && K == 16;
+    float4 mu_a = make_float4(0.f, 0.f, 0.f, 0.f), mu_b = mu_a;
+    if (norm16) {
+        const float4 *mu = reinterpret_cast<const float4 *>(mean + r * 16);
+        if (PREC == kMlpF32) mu_a = mu[lk];
+        else { mu_a = mu[2 * (lk & 1)]; mu_b = mu[2 * (lk & 1) + 1]; }
+    }
     auto aload = [&](int g, float4 (&dst)[NA]) __attribute__((always_inline)) {
         const int kg = g * kMlpKG;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             // f32: piece u = k-step u (16 wide), lane part 4*lk;  bf16: pieces 2u / 2u+1 = low / high half of the lane's 8
             const int k0 = PREC == kMlpF32 ? kg + 16 * u + 4 * lk : kg + 32 * (u >> 1) + 8 * lk + 4 * (u & 1);
-            dst[u] = (k0 + 3 < in) ? *reinterpret_cast<const float4 *>(xr + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + 3 < in) {
+                v = *reinterpret_cast<const float4 *>(xr + k0);
+                if (norm16) {
+                    const float4 m = (PREC == kMlpF32 || !(u & 1)) ? mu_a : mu_b;
+                    v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
+                }
+            }
+            dst[u] = v;
         }
     };
     {
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = acc[n][e];
-            if (mean) {  // take the window mean out: - sum_k mu[row][k] * wsum[o][k]
+            if (mean && !norm16) {  // take the window mean out: - sum_k mu[row][k] * wsum[o][k]
                 size_t rr = row0 + 4 * lk + e;
                 if (rr >= B) rr = B - 1;
                 rr = row_of(rr);
@@ -649,45 +668,48 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 // Layer 1 over ALL windows of a stream from one staging of its frames (round 4).  mlp_mfma_kernel in window mode reads every window's
 // 3 120 features through the vector cache and splits each of them into its two f16 parts again -- a frame belongs to L = 195 windows,
 // so the same split is done 195 times: 57 % of the SIMD cycles of that kernel are vector instructions, 24 % matrix ones (PMC, 32 768
-// streams: 7.6 ms), and every 64 rows stage the 400 KB of split weights again.  Here a workgroup owns up to 256 consecutive windows of
-// ONE stream: their frames (at most 256 + L - 1) are split once into LDS, plane p / k-half h / frame in 16-byte slots (a wave's 32
-// rows read 32 consecutive slots: conflict-free), and window row w at k-step f (= frame f of the window, mfcc_size 16 = one
-// v_mfma_f32_32x32x16_f16 step) is simply slot w + f.  The weights stream through LDS once per workgroup in groups of five frames,
-// in the order the lanes read them (MlpDev::wwin).  Two 32-row tiles per wave share the weight reads.  Same products as kMlpF16x2
-// (x0 w0 + x1 w0 + x0 w1), same mean correction, bias, ReLU and tail layers as mlp_mfma_kernel; rows holding a frame beyond the f16
-// range are listed for the f32 pass.  Shapes: mfcc_size 16, layer 1 <= 32 wide, tail layers <= 32 wide, n_win >= 32.
-constexpr int kWinWaves = 4, kWinTpw = 2, kWinTile = 32, kWinRows = kWinWaves * kWinTpw * kWinTile, kWinGroup = 5;
+// streams: 7.6 ms), and every 64 rows stage the 400 KB of split weights again.  Here a workgroup owns NT <= 7 tiles of 32 consecutive
+// windows of ONE stream: their frames (32 NT + L - 1) are split once into LDS, part p / k-half h / frame in 16-byte slots (a wave's 32
+// rows read 32 consecutive slots: conflict-free), and window row w at k-step f (= frame f of the window: mfcc_size 16 is one
+// v_mfma_f32_32x32x16_f16 step) is simply slot w + f.  The four waves split the FRAMES of the window, not the rows: wave q runs
+// frames [q L/4, (q+1) L/4) for all NT tiles, so a weight fragment is fetched once per workgroup -- straight from the lane-ordered image
+// (MlpDev::wwin) into registers, four frames ahead -- and used NT times; there is no barrier inside the loop (the first version staged
+// weight groups through LDS for 2 tiles per wave: 39 barriers per workgroup, 52 % matrix-pipe occupancy, 4.9 ms).  The four partial
+// sums of a tile meet in LDS in a fixed order ((q0 + q1) + (q2 + q3)).  Same products as kMlpF16x2 (x0 w0 + x1 w0 + x0 w1), same mean
+// correction, bias, ReLU and tail layers as mlp_mfma_kernel; rows holding a frame beyond the f16 range are listed for the f32 pass.
+// Shapes: mfcc_size 16, layer 1 <= 32 wide, tail layers <= 32 wide, n_win >= 32.
+constexpr int kWinWaves = 4, kWinTile = 32, kWinMaxTiles = 7, kWinAhead = 4;
 typedef float f32x16w __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(64 * kWinWaves) void mlp_windows_kernel(
-    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames, size_t n_win, int L, unsigned blocks_per_stream,
-    const u32x4v *__restrict__ wimg, int n_groups, int slots, int n1p, const float *__restrict__ b1, const float *__restrict__ mean,
-    const float *__restrict__ wsum, const float *__restrict__ tail, int tail_floats, int n_layers, int d1, int d2, int d3,
-    float *__restrict__ out, uint32_t *redo) {
+template <int NT>
+__global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_win, int L, unsigned blocks_per_stream, const u32x4v *__restrict__ wimg, int slots,
+    int n1p, const float *__restrict__ b1, const float *__restrict__ mean, const float *__restrict__ wsum, const float *__restrict__ tail,
+    int tail_floats, int n_layers, int d1, int d2, int d3, float *__restrict__ out, uint32_t *redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int GROUP_PIECES = kWinGroup * 2 * 2 * 32;                  // 16-byte pieces of a staged weight group
-    constexpr int NV = (GROUP_PIECES + 64 * kWinWaves - 1) / (64 * kWinWaves);
-    // slots = kWinRows + whole groups of frames: every (row, frame) a wave may read exists, zero past the real frames
-    u32x4v *A = reinterpret_cast<u32x4v *>(smem);                          // [2 planes][2 k-halves][slots]
-    u32x4v *Wb = A + 4 * slots;                                        // [2 buffers][kWinGroup][2 planes][2 k-halves][32]
-    float *tl = reinterpret_cast<float *>(Wb + 2 * GROUP_PIECES);          // tail weights
+    float *tl = reinterpret_cast<float *>(smem);                                   // tail weights
     unsigned *flag = reinterpret_cast<unsigned *>(tl + ((tail_floats + 3) & ~3));   // [slots] frame holds a value beyond the f16 range
+    u32x4v *A = reinterpret_cast<u32x4v *>(flag + slots);                           // [2 parts][2 k-halves][slots]; later the partial sums
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, lr = l & 31, lh = l >> 5;
     const size_t s = blockIdx.x / blocks_per_stream;
-    const size_t w0 = (size_t)(blockIdx.x - s * blocks_per_stream) * kWinRows;   // first window of this workgroup
-    const size_t rows_here = n_win - w0 < (size_t)kWinRows ? n_win - w0 : (size_t)kWinRows;
-    const int n_slots = (int)rows_here + L - 1;                                   // frames w0 .. w0 + n_slots - 1 are real
+    const size_t w0 = (size_t)(blockIdx.x - s * blocks_per_stream) * (NT * kWinTile);   // first window of this workgroup
+    const size_t rows_here = n_win - w0 < (size_t)(NT * kWinTile) ? n_win - w0 : (size_t)(NT * kWinTile);
+    const int n_real = (int)rows_here + L - 1;                                          // frames w0 .. w0 + n_real - 1 exist
     for (int i = tid; i < tail_floats; i += 64 * kWinWaves) tl[i] = tail[i];
-    // ---- frames -> the two f16 planes, once
+    // ---- frames -> the two f16 parts, once.  The window mean is taken out after layer 1 (W.(f - mu) = W.f - sum_k mu[k] wsum[k]); MFCC
+    // coefficients sit on offsets many times their spread, and summing W.f with the offsets inside costs the sum their size in f32
+    // rounding.  So the frames are staged minus c = the mean of the workgroup's middle window -- every window here overlaps or
+    // adjoins it, so mu - c is small -- and the correction uses mu - c: W.(f - mu) = W.(f - c) - sum_k (mu - c)[k] wsum[k].
     const float *src = mfcc + (s * frame_pitch + w0) * 16;
-    (void)n_frames;
+    const float4 *cmid = reinterpret_cast<const float4 *>(mean + (s * n_win + w0 + rows_here / 2) * 16);
     for (int i = tid; i < 2 * slots; i += 64 * kWinWaves) {
         const int fr = i >> 1, h = i & 1;
         u32x4v p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
         unsigned far = 0u;
-        if (fr < n_slots) {
+        if (fr < n_real) {
             const float4 lo = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h);
             const float4 hi = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h + 4);
-            const float xs[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const float4 cl = cmid[2 * h], ch = cmid[2 * h + 1];
+            const float xs[8] = {lo.x - cl.x, lo.y - cl.y, lo.z - cl.z, lo.w - cl.w, hi.x - ch.x, hi.y - ch.y, hi.z - ch.z, hi.w - ch.w};
             float rng = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -703,90 +725,111 @@ __global__ __launch_bounds__(64 * kWinWaves) void mlp_windows_kernel(
         if (h == 0) flag[fr] = 0u;   // the two halves of a frame belong to neighbouring lanes of one wave: its LDS stores keep their order
         if (far) flag[fr] = 1u;
     }
-    // ---- weight groups through LDS, double buffered; registers carry the next group across the barrier
-    u32x4v wreg[NV];
-    auto wload = [&](int g) __attribute__((always_inline)) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = tid + v * 64 * kWinWaves;
-            if (i < GROUP_PIECES) wreg[v] = wimg[(size_t)g * GROUP_PIECES + i];
-        }
-    };
-    auto wstore = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int i = tid + v * 64 * kWinWaves;
-            if (i < GROUP_PIECES) Wb[buf * GROUP_PIECES + i] = wreg[v];
-        }
-    };
-    wload(0);
-    wstore(0);
     __syncthreads();
-    f32x16w acc[kWinTpw];
+    // ---- this wave's quarter of the frames, all NT tiles
+    const int Lq = (L + kWinWaves - 1) / kWinWaves, fb = wave * Lq, fe = fb + Lq < L ? fb + Lq : L;
+    f32x16w acc[NT];
 #pragma unroll
-    for (int t = 0; t < kWinTpw; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    const int row_t0 = (wave * kWinTpw) * kWinTile;   // this wave's first row inside the workgroup
-    // tiles of this wave that hold a real row (202 windows = 7 tiles: the last wave has one)
-    const int live = (size_t)row_t0 >= rows_here ? 0 : (size_t)row_t0 + kWinTile >= rows_here ? 1 : kWinTpw;
-    auto frames_of_group = [&](int g, auto ntl) __attribute__((always_inline)) {
-        constexpr int NTL = decltype(ntl)::value;
-        const u32x4v *wb = Wb + (g & 1) * GROUP_PIECES;
-#pragma unroll
-        for (int ff = 0; ff < kWinGroup; ++ff) {
-            const int f = g * kWinGroup + ff;   // frames past L carry zero weights; their slots exist (zero padded)
-            const f16x8 b0 = __builtin_bit_cast(f16x8, wb[((ff * 2 + 0) * 2 + lh) * 32 + lr]);
-            const f16x8 b1v = __builtin_bit_cast(f16x8, wb[((ff * 2 + 1) * 2 + lh) * 32 + lr]);
-            f16x8 a0[NTL], a1[NTL];
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) {
-                const int slot = row_t0 + t * kWinTile + lr + f;
-                a0[t] = __builtin_bit_cast(f16x8, A[(0 * 2 + lh) * slots + slot]);
-                a1[t] = __builtin_bit_cast(f16x8, A[(1 * 2 + lh) * slots + slot]);
-            }
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t], b0, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1v, acc[t], 0, 0, 0);
-        }
+    u32x4v wq0[kWinAhead], wq1[kWinAhead];   // the weight fragments of the next kWinAhead frames: [frame][part][k-half][output] 16 bytes
+    auto wfetch = [&](int f, int j) __attribute__((always_inline)) {
+        const int fc = f < fe ? f : fe - 1;
+        wq0[j] = wimg[(((size_t)fc * 2 + 0) * 2 + lh) * 32 + lr];
+        wq1[j] = wimg[(((size_t)fc * 2 + 1) * 2 + lh) * 32 + lr];
     };
-    for (int g = 0; g < n_groups; ++g) {
-        if (g + 1 < n_groups) wload(g + 1);
-        if (live == kWinTpw) frames_of_group(g, std::integral_constant<int, kWinTpw>());
-        else if (live == 1) frames_of_group(g, std::integral_constant<int, 1>());
-        if (g + 1 < n_groups) wstore((g + 1) & 1);
-        __syncthreads();
-    }
-    // every wave is past the last barrier: the frame planes and weight buffers become h1 / h2 of the waves ([32][33] floats each)
-    float *h1 = reinterpret_cast<float *>(smem) + wave * 2 * 32 * 33, *h2 = h1 + 32 * 33;
-    const bool relu1 = n_layers > 1;
-    float4 ws4[4];
+    if (fb < fe) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ws4[k] = lr < n1p ? *reinterpret_cast<const float4 *>(wsum + (size_t)lr * 16 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < kWinAhead; ++j) wfetch(fb + j, j);
+        const u32x4v *A0 = A + (0 * 2 + lh) * slots + lr, *A1 = A + (1 * 2 + lh) * slots + lr;
+        for (int f0 = fb; f0 < fe; f0 += kWinAhead) {
+#pragma unroll
+            for (int j = 0; j < kWinAhead; ++j) {
+                const int f = f0 + j;
+                if (f < fe) {   // wave-uniform
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, wq0[j]), b1v = __builtin_bit_cast(f16x8, wq1[j]);
+                    wfetch(f + kWinAhead, j);
+                    f16x8 a0[NT], a1[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        a0[t] = __builtin_bit_cast(f16x8, A0[t * kWinTile + f]);
+                        a1[t] = __builtin_bit_cast(f16x8, A1[t * kWinTile + f]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t], b0, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1v, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the frame planes: the region becomes the partial sums
+    // ---- (q0 + q1) + (q2 + q3): R[who][tile][e / 4][lane] 16 bytes
+    f32x4 *R = reinterpret_cast<f32x4 *>(A);
+    auto put = [&](int who) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) R[((who * NT + t) * 4 + e4) * 64 + l] = f32x4{acc[t][4 * e4], acc[t][4 * e4 + 1], acc[t][4 * e4 + 2], acc[t][4 * e4 + 3]};
+    };
+    auto add = [&](int who) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const f32x4 v = R[((who * NT + t) * 4 + e4) * 64 + l];
+                acc[t][4 * e4] += v.x; acc[t][4 * e4 + 1] += v.y; acc[t][4 * e4 + 2] += v.z; acc[t][4 * e4 + 3] += v.w;
+            }
+    };
+    if (wave == 1) put(0);
+    if (wave == 3) put(1);
+    __syncthreads();
+    if (wave == 0) add(0);
+    if (wave == 2) { add(1); }
+    __syncthreads();
+    if (wave == 2) put(0);
+    __syncthreads();
+    if (wave == 0) { add(0); }
+    __syncthreads();
+    if (wave == 0) put(0);   // the sums, for the wave that finishes each tile
+    __syncthreads();
+    // ---- bias, mean correction, ReLU, tail layers: tile t by wave t % 4; h1 / h2 ([32][33] floats each) behind the sums (over the second set)
+    float *h1 = reinterpret_cast<float *>(R + NT * 4 * 64) + wave * 2 * 32 * 33, *h2 = h1 + 32 * 33;
+    const bool relu1 = n_layers > 1;
+    float4 ws4[4], c4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ws4[k] = lr < n1p ? *reinterpret_cast<const float4 *>(wsum + (size_t)lr * 16 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        c4[k] = cmid[k];
+    }
     const float bias1 = lr < n1p ? b1[lr] : 0.f;
-    for (int t = 0; t < kWinTpw; ++t) {
-        const size_t wrow0 = (size_t)row_t0 + (size_t)t * kWinTile;   // first row of the tile inside the workgroup
-        if (wrow0 >= rows_here) break;                                  // wave-uniform
+    for (int t = wave; t < NT; t += kWinWaves) {
+        const size_t wrow0 = (size_t)t * kWinTile;   // first row of the tile inside the workgroup
+        if (wrow0 >= rows_here) break;                // wave-uniform
         // C/D layout of the 32x32 tile: lane (column lr, half lh) holds rows 8 * (e / 4) + 4 * lh + e % 4
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = 8 * (e >> 2) + 4 * lh + (e & 3);
-            size_t rr = wrow0 + row;
-            if (rr >= rows_here) rr = rows_here - 1;
-            const float4 *mu = reinterpret_cast<const float4 *>(mean + (s * n_win + w0 + rr) * 16);
-            float corr = 0.f;   // - sum_k mu[row][k] * wsum[o][k], the order of mlp_mfma_kernel
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4 sum4 = R[(t * 4 + e4) * 64 + l];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 m4 = mu[k], w4 = ws4[k];
-                corr = fmaf(m4.x, w4.x, corr); corr = fmaf(m4.y, w4.y, corr); corr = fmaf(m4.z, w4.z, corr); corr = fmaf(m4.w, w4.w, corr);
+            for (int ee = 0; ee < 4; ++ee) {
+                const int row = 8 * e4 + 4 * lh + ee;
+                size_t rr = wrow0 + row;
+                if (rr >= rows_here) rr = rows_here - 1;
+                const float4 *mu = reinterpret_cast<const float4 *>(mean + (s * n_win + w0 + rr) * 16);
+                float corr = 0.f;   // - sum_k (mu[row][k] - c[k]) * wsum[o][k]
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 m4 = mu[k], w4 = ws4[k], c = c4[k];
+                    corr = fmaf(m4.x - c.x, w4.x, corr); corr = fmaf(m4.y - c.y, w4.y, corr); corr = fmaf(m4.z - c.z, w4.z, corr); corr = fmaf(m4.w - c.w, w4.w, corr);
+                }
+                float v = sum4[ee] - corr;
+                v += bias1;
+                if (relu1 && v < 0.f) v = 0.f;
+                h1[row * 33 + lr] = v;
             }
-            float v = acc[t][e] - corr;
-            v += bias1;
-            if (relu1 && v < 0.f) v = 0.f;
-            h1[row * 33 + lr] = v;
         }
         wave_lds_sync();
         // tail layers: lane = (row lr, output phase lh), outputs strided by 2 over the phases; sums in mlp_mfma_kernel's order
@@ -831,25 +874,45 @@ __global__ __launch_bounds__(64 * kWinWaves) void mlp_windows_kernel(
 bool mlp_windows_supported(const MlpDev &m, size_t n_win, int K) {
     if (!m.wwin || K != 16 || m.dims[0] % 16 != 0 || m.dims[1] > 32 || n_win < 32) return false;
     const int L = m.dims[0] / 16;
-    if (L + kWinGroup > 256 || m.tail_floats > 4096) return false;
+    if (L > 256 || m.tail_floats > 4096) return false;
     for (int l2 = 2; l2 <= m.n_layers; ++l2) if (m.dims[l2] > 32) return false;
     const char *env = std::getenv("RP_MLP_WINDOWS");
     return !(env && env[0] == '0');
 }
 
-static hipError_t launch_mlp_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, const float *mean,
-                                     const float *wsum, float *out, uint32_t *redo, size_t pitch) {
-    const int L = m.dims[0] / 16, n_groups = (L + kWinGroup - 1) / kWinGroup;
-    const size_t bps = (n_win + kWinRows - 1) / kWinRows, blocks = bps * S;
+template <int NT>
+static hipError_t launch_mlp_windows_nt(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
+                                        const float *wsum, float *out, uint32_t *redo, size_t pitch) {
+    const int L = m.dims[0] / 16;
+    const size_t bps = (n_win + NT * kWinTile - 1) / (NT * kWinTile), blocks = bps * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
-    const int slots = (kWinRows + n_groups * kWinGroup + 3) & ~3;
-    const size_t lds = (size_t)4 * slots * 16 + (size_t)2 * kWinGroup * 2 * 2 * 32 * 16 + (size_t)((m.tail_floats + 3) & ~3) * 4 + (size_t)slots * 4;
-    static_assert((size_t)4 * kWinRows * 16 + (size_t)2 * kWinGroup * 2 * 2 * 32 * 16 >= (size_t)kWinWaves * 2 * 32 * 33 * 4, "h1 / h2 of the waves fit the planes + weight buffers");
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_kernel), 160 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL(mlp_windows_kernel, dim3((unsigned)blocks), dim3(64 * kWinWaves), lds, st, mfcc, pitch, n_frames, n_win, L, (unsigned)bps,
-                       static_cast<const u32x4v *>(m.wwin), n_groups, slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
+    const int slots = (NT * kWinTile + L + 3) & ~3;
+    // frame planes; later two sets of partial sums, the second of which is free again (h1 / h2 of the waves) when the tiles are finished
+    const size_t region = std::max((size_t)4 * slots * 16, (size_t)NT * 4096 + std::max((size_t)NT * 4096, (size_t)kWinWaves * 2 * 32 * 33 * 4));
+    const size_t lds = (size_t)((m.tail_floats + 3) & ~3) * 4 + (size_t)slots * 4 + region;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_kernel<NT>), 160 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL(mlp_windows_kernel<NT>, dim3((unsigned)blocks), dim3(64 * kWinWaves), lds, st, mfcc, pitch, n_win, L, (unsigned)bps,
+                       static_cast<const u32x4v *>(m.wwin), slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
                        m.dims[3], out, redo);
     return hipGetLastError();
+}
+
+static hipError_t launch_mlp_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, const float *mean,
+                                     const float *wsum, float *out, uint32_t *redo, size_t pitch) {
+    (void)n_frames;
+    // tiles per workgroup: as few workgroups per stream as 7 tiles each allow, the tiles spread evenly over them
+    const size_t tiles = (n_win + kWinTile - 1) / kWinTile, wgs = (tiles + kWinMaxTiles - 1) / kWinMaxTiles, per = (tiles + wgs - 1) / wgs;
+    switch (per) {
+    case 1: return launch_mlp_windows_nt<1>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 2: return launch_mlp_windows_nt<2>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 3: return launch_mlp_windows_nt<3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 4: return launch_mlp_windows_nt<4>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 5: return launch_mlp_windows_nt<5>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 6: return launch_mlp_windows_nt<6>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 7: return launch_mlp_windows_nt<7>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,

@@ -529,19 +529,25 @@ def _window_model(rng, L, K, hidden, labels):
     (195, (32, 16), 2, 225, 2),     # 31 windows: stays with mlp_mfma_kernel (rows read in place)
 ])
 def test_window_logits_match_the_oracle(ra, ctx, L, hidden, labels, nf, S):
-    """rp_mlp_forward_windows against the oracle's window-by-window forward (normalise, flatten, ModelImpl::forward): features with
-    coefficient-dependent offsets like real MFCCs (the kernel takes the window mean out AFTER layer 1), gate 1e-5 relative to
-    the larger of the logit and the largest feature; equal to itself on a second call, independent of the other streams."""
+    """rp_mlp_forward_windows against the oracle's window-by-window forward (normalise, flatten, ModelImpl::forward): features on
+    coefficient-dependent offsets ten times their spread, like real MFCCs, drifting along the stream (mlp_windows_kernel stages
+    the frames minus its middle window's mean and takes the rest of each window's mean out after layer 1; mlp_mfma_kernel
+    subtracts the window's own mean as it loads), gate 1e-5 relative to the larger of the logit and the largest CENTRED feature;
+    equal to itself on a second call, independent of the other streams."""
     K = 16
     rng = np.random.default_rng(L * 1000 + nf)
     ws, bs = _window_model(rng, L, K, hidden, labels)
     model = ra.Model(ctx, ws, bs)
-    off = rng.uniform(-3.0, 3.0, K).astype(np.float32)
-    mfcc = (rng.standard_normal((S, nf, K)) * rng.uniform(0.5, 2.0, (S, 1, 1)) + off).astype(np.float32)
+    # offsets ten times the spread, and a level that drifts along the stream (window means differ across a workgroup's windows)
+    off = rng.uniform(-30.0, 30.0, K).astype(np.float32)
+    drift = np.linspace(0.0, 1.0, nf)[None, :, None] * rng.uniform(-6.0, 6.0, (S, 1, K))
+    mfcc = (rng.standard_normal((S, nf, K)) * rng.uniform(0.5, 2.0, (S, 1, 1)) + off + drift).astype(np.float32)
     got = ctx.mlp_forward_windows(mfcc, model)
     ref = _window_logits_oracle(mfcc, L, ws, bs).astype(np.float64)
     assert got.shape == ref.shape and np.isfinite(got).all()
-    tol = 1e-5 * np.maximum(np.abs(ref), np.abs(mfcc).max())
+    # the gate scales with the CENTRED features (what the model sees), not with the offsets they sit on
+    spread = max(np.abs(mfcc[s0, w:w + L] - mfcc[s0, w:w + L].mean(axis=0)).max() for s0 in range(S) for w in range(0, nf - L + 1, 16))
+    tol = 1e-5 * np.maximum(np.abs(ref), spread)
     assert (np.abs(got - ref) <= tol).all(), float((np.abs(got - ref) / tol).max())
     assert ctx.mlp_forward_windows(mfcc, model).tobytes() == got.tobytes()
     one = ctx.mlp_forward_windows(mfcc[S - 1:], model)

@@ -701,29 +701,40 @@ __global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
     // adjoins it, so mu - c is small -- and the correction uses mu - c: W.(f - mu) = W.(f - c) - sum_k (mu - c)[k] wsum[k].
     const float *src = mfcc + (s * frame_pitch + w0) * 16;
     const float4 *cmid = reinterpret_cast<const float4 *>(mean + (s * n_win + w0 + rows_here / 2) * 16);
-    for (int i = tid; i < 2 * slots; i += 64 * kWinWaves) {
-        const int fr = i >> 1, h = i & 1;
-        u32x4v p0 = {0u, 0u, 0u, 0u}, p1 = {0u, 0u, 0u, 0u};
-        unsigned far = 0u;
-        if (fr < n_real) {
-            const float4 lo = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h);
-            const float4 hi = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h + 4);
-            const float4 cl = cmid[2 * h], ch = cmid[2 * h + 1];
-            const float xs[8] = {lo.x - cl.x, lo.y - cl.y, lo.z - cl.z, lo.w - cl.w, hi.x - ch.x, hi.y - ch.y, hi.z - ch.z, hi.w - ch.w};
-            float rng = 0.f;
+    {
+        // a thread's items are (frame i / 2, k-half i & 1 = tid & 1) for i = tid, tid + 256, ..: every load goes out before the first split
+        constexpr int MAXI = (2 * (kWinMaxTiles * kWinTile + 256) + 64 * kWinWaves - 1) / (64 * kWinWaves);
+        const int h = tid & 1;
+        const float4 cl = cmid[2 * h], ch = cmid[2 * h + 1];
+        float4 lo[MAXI], hi[MAXI];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a = xs[2 * e], b = xs[2 * e + 1];
-                rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
-                p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-                p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
-            }
-            far = !(rng <= 65504.f);
+        for (int v = 0; v < MAXI; ++v) {
+            const int i = tid + v * 64 * kWinWaves, fr = i >> 1;
+            if (i < 2 * slots && fr < n_real) {
+                lo[v] = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h);
+                hi[v] = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h + 4);
+            } else { lo[v] = cl; hi[v] = ch; }   // past the real frames: zero after the offset leaves
         }
-        A[(0 * 2 + h) * slots + fr] = p0;
-        A[(1 * 2 + h) * slots + fr] = p1;
-        if (h == 0) flag[fr] = 0u;   // the two halves of a frame belong to neighbouring lanes of one wave: its LDS stores keep their order
-        if (far) flag[fr] = 1u;
+#pragma unroll
+        for (int v = 0; v < MAXI; ++v) {
+            const int i = tid + v * 64 * kWinWaves, fr = i >> 1;
+            if (i < 2 * slots) {
+                const float xs[8] = {lo[v].x - cl.x, lo[v].y - cl.y, lo[v].z - cl.z, lo[v].w - cl.w, hi[v].x - ch.x, hi[v].y - ch.y, hi[v].z - ch.z, hi[v].w - ch.w};
+                u32x4v p0, p1;
+                float rng = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = xs[2 * e], b = xs[2 * e + 1];
+                    rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
+                    p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+                    p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
+                }
+                A[(0 * 2 + h) * slots + fr] = p0;
+                A[(1 * 2 + h) * slots + fr] = p1;
+                if (h == 0) flag[fr] = 0u;   // the two halves of a frame belong to neighbouring lanes of one wave: its LDS stores keep their order
+                if (!(rng <= 65504.f)) flag[fr] = 1u;
+            }
+        }
     }
     __syncthreads();
     // ---- this wave's quarter of the frames, all NT tiles
@@ -902,7 +913,9 @@ static hipError_t launch_mlp_windows(hipStream_t st, const MlpDev &m, const floa
                                      const float *wsum, float *out, uint32_t *redo, size_t pitch) {
     (void)n_frames;
     // tiles per workgroup: as few workgroups per stream as 7 tiles each allow, the tiles spread evenly over them
-    const size_t tiles = (n_win + kWinTile - 1) / kWinTile, wgs = (tiles + kWinMaxTiles - 1) / kWinMaxTiles, per = (tiles + wgs - 1) / wgs;
+    static const int cap_env = std::getenv("RP_MLP_WIN_TILES") ? std::atoi(std::getenv("RP_MLP_WIN_TILES")) : kWinMaxTiles;   // experiments
+    const size_t cap = cap_env >= 1 && cap_env <= kWinMaxTiles ? (size_t)cap_env : (size_t)kWinMaxTiles;
+    const size_t tiles = (n_win + kWinTile - 1) / kWinTile, wgs = (tiles + cap - 1) / cap, per = (tiles + wgs - 1) / wgs;
     switch (per) {
     case 1: return launch_mlp_windows_nt<1>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
     case 2: return launch_mlp_windows_nt<2>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);

@@ -144,7 +144,8 @@ def _stream_batch_model_case(ra, ctx, same):
         cfg.avg_threshold, cfg.threshold, cfg.min_scores = avg_threshold, 0.6, 3
         det, dlab, n_det = ctx.batch_detect_model(pcm, model, m["mfcc_size"], none_index, cfg)
         assert n_det.sum() >= 2
-        for pieces in ((1,), (2, 5, 1)):
+        # (12 chunks per call = 36 new windows per stream: the live call takes mlp_windows_kernel too, on rows of the ring's frame pitch)
+        for pieces in ((1,), (2, 5, 1), (12, 3)):
             sb = ra.StreamBatch(ctx, None, cfg, pcm.shape[0], max_chunks_per_call=max(pieces), mfcc_size=m["mfcc_size"],
                                 wakewords=[{"model": model, "none_index": none_index, "precision": "f32"}])
             got = _feed(sb, pcm, pieces)

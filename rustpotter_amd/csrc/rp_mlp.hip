@@ -678,10 +678,10 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 // sums of a tile meet in LDS in a fixed order ((q0 + q1) + (q2 + q3)).  Same products as kMlpF16x2 (x0 w0 + x1 w0 + x0 w1), same mean
 // correction, bias, ReLU and tail layers as mlp_mfma_kernel; rows holding a frame beyond the f16 range are listed for the f32 pass.
 // Shapes: mfcc_size 16, layer 1 <= 32 wide, tail layers <= 32 wide, n_win >= 32.
-constexpr int kWinWaves = 4, kWinTile = 32, kWinMaxTiles = 7, kWinAhead = 4;
+constexpr int kWinWaves = 4, kWinTile = 32, kWinMaxTiles = 7, kWinAhead = 3;
 typedef float f32x16w __attribute__((ext_vector_type(16)));
 template <int NT>
-__global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
+__global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_win, int L, unsigned blocks_per_stream, const u32x4v *__restrict__ wimg, int slots,
     int n1p, const float *__restrict__ b1, const float *__restrict__ mean, const float *__restrict__ wsum, const float *__restrict__ tail,
     int tail_floats, int n_layers, int d1, int d2, int d3, float *__restrict__ out, uint32_t *redo) {
@@ -761,54 +761,57 @@ __global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
                 if (f < fe) {   // wave-uniform
                     const f16x8 b0 = __builtin_bit_cast(f16x8, wq0[j]), b1v = __builtin_bit_cast(f16x8, wq1[j]);
                     wfetch(f + kWinAhead, j);
-                    f16x8 a0[NT], a1[NT];
+                    // tiles in pairs: the two parts of two tiles live at a time (all NT at once cost 8 NT registers and the third wave
+                    // per SIMD), and the three products of a tile are one other matrix instruction apart
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        a0[t] = __builtin_bit_cast(f16x8, A0[t * kWinTile + f]);
-                        a1[t] = __builtin_bit_cast(f16x8, A1[t * kWinTile + f]);
+                    for (int t = 0; t < NT; t += 2) {
+                        const bool two = t + 1 < NT;
+                        const f16x8 p0 = __builtin_bit_cast(f16x8, A0[t * kWinTile + f]), p1 = __builtin_bit_cast(f16x8, A1[t * kWinTile + f]);
+                        f16x8 q0 = p0, q1 = p1;
+                        if (two) { q0 = __builtin_bit_cast(f16x8, A0[(t + 1) * kWinTile + f]); q1 = __builtin_bit_cast(f16x8, A1[(t + 1) * kWinTile + f]); }
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b0, acc[t], 0, 0, 0);
+                        if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, b0, acc[t + 1], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b0, acc[t], 0, 0, 0);
+                        if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, b0, acc[t + 1], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b1v, acc[t], 0, 0, 0);
+                        if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, b1v, acc[t + 1], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b0, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[t], b0, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[t], b1v, acc[t], 0, 0, 0);
                 }
             }
         }
     }
     __syncthreads();   // every wave is done with the frame planes: the region becomes the partial sums
-    // ---- (q0 + q1) + (q2 + q3): R[who][tile][e / 4][lane] 16 bytes
+    // ---- ((q3 + q2) + q1) + q0 through one set of sums R[tile][e / 4][lane] (16 bytes each): a wave adds what is there to its own
+    // and puts the result back; one set, and h1 of a tile in that tile's own 4 KB, keep the workgroup at 48 KB = three per CU
     f32x4 *R = reinterpret_cast<f32x4 *>(A);
-    auto put = [&](int who) __attribute__((always_inline)) {
+    auto put = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) R[((who * NT + t) * 4 + e4) * 64 + l] = f32x4{acc[t][4 * e4], acc[t][4 * e4 + 1], acc[t][4 * e4 + 2], acc[t][4 * e4 + 3]};
+            for (int e4 = 0; e4 < 4; ++e4) R[(t * 4 + e4) * 64 + l] = f32x4{acc[t][4 * e4], acc[t][4 * e4 + 1], acc[t][4 * e4 + 2], acc[t][4 * e4 + 3]};
     };
-    auto add = [&](int who) __attribute__((always_inline)) {
+    auto add = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 v = R[((who * NT + t) * 4 + e4) * 64 + l];
-                acc[t][4 * e4] += v.x; acc[t][4 * e4 + 1] += v.y; acc[t][4 * e4 + 2] += v.z; acc[t][4 * e4 + 3] += v.w;
+                const f32x4 v = R[(t * 4 + e4) * 64 + l];
+                acc[t][4 * e4] = v.x + acc[t][4 * e4]; acc[t][4 * e4 + 1] = v.y + acc[t][4 * e4 + 1];
+                acc[t][4 * e4 + 2] = v.z + acc[t][4 * e4 + 2]; acc[t][4 * e4 + 3] = v.w + acc[t][4 * e4 + 3];
             }
     };
-    if (wave == 1) put(0);
-    if (wave == 3) put(1);
+    if (wave == 3) put();
     __syncthreads();
-    if (wave == 0) add(0);
-    if (wave == 2) { add(1); }
+    if (wave == 2) { add(); put(); }
     __syncthreads();
-    if (wave == 2) put(0);
+    if (wave == 1) { add(); put(); }
     __syncthreads();
-    if (wave == 0) { add(0); }
+    if (wave == 0) { add(); put(); }
     __syncthreads();
-    if (wave == 0) put(0);   // the sums, for the wave that finishes each tile
-    __syncthreads();
-    // ---- bias, mean correction, ReLU, tail layers: tile t by wave t % 4; h1 / h2 ([32][33] floats each) behind the sums (over the second set)
-    float *h1 = reinterpret_cast<float *>(R + NT * 4 * 64) + wave * 2 * 32 * 33, *h2 = h1 + 32 * 33;
+    // ---- bias, mean correction, ReLU, tail layers: tile t by wave t % 4.  h1 [32][32] takes the place of the tile's sums, h2 [32][32] of
+    // the wave sits behind the sums; column i of row r lives at (i + r) % 32: a lane walking its own row and the 32 lanes writing one
+    // row both touch 32 different banks
+    float *h2 = reinterpret_cast<float *>(R + NT * 4 * 64) + wave * 32 * 32;
     const bool relu1 = n_layers > 1;
     float4 ws4[4], c4[4];
 #pragma unroll
@@ -820,10 +823,14 @@ __global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
     for (int t = wave; t < NT; t += kWinWaves) {
         const size_t wrow0 = (size_t)t * kWinTile;   // first row of the tile inside the workgroup
         if (wrow0 >= rows_here) break;                // wave-uniform
+        float *h1 = reinterpret_cast<float *>(R + t * 4 * 64);
+        f32x4 sums[4];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) sums[e4] = R[(t * 4 + e4) * 64 + l];
+        wave_lds_sync();
         // C/D layout of the 32x32 tile: lane (column lr, half lh) holds rows 8 * (e / 4) + 4 * lh + e % 4
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
-            const f32x4 sum4 = R[(t * 4 + e4) * 64 + l];
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) {
                 const int row = 8 * e4 + 4 * lh + ee;
@@ -836,10 +843,10 @@ __global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
                     const float4 m4 = mu[k], w4 = ws4[k], c = c4[k];
                     corr = fmaf(m4.x - c.x, w4.x, corr); corr = fmaf(m4.y - c.y, w4.y, corr); corr = fmaf(m4.z - c.z, w4.z, corr); corr = fmaf(m4.w - c.w, w4.w, corr);
                 }
-                float v = sum4[ee] - corr;
+                float v = sums[e4][ee] - corr;
                 v += bias1;
                 if (relu1 && v < 0.f) v = 0.f;
-                h1[row * 33 + lr] = v;
+                h1[row * 32 + ((lr + row) & 31)] = v;
             }
         }
         wave_lds_sync();
@@ -853,12 +860,12 @@ __global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
                 if (far) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)orow;
             }
             const int dd[4] = {d1, d2, d3, 0};
-            const float *hin = h1 + lr * 33;
+            const float *hin = h1 + lr * 32;
             const float *wp = tl;
             int cur_in = d1;
             float *dst = out + orow * (size_t)dd[n_layers - 1];
             if (n_layers == 1 && row_ok)
-                for (int o = lh; o < d1; o += 2) dst[o] = hin[o];
+                for (int o = lh; o < d1; o += 2) dst[o] = hin[(o + lr) & 31];
             for (int layer = 1; layer < n_layers; ++layer) {
                 const int on = dd[layer];
                 const bool last = layer + 1 == n_layers;
@@ -866,16 +873,16 @@ __global__ __launch_bounds__(64 * kWinWaves, 2) void mlp_windows_kernel(
                     const float *wr = wp + (size_t)o * cur_in;
                     float s0 = 0.f, s1 = 0.f;
                     int i = 0;
-                    for (; i + 1 < cur_in; i += 2) { s0 = fmaf(hin[i], wr[i], s0); s1 = fmaf(hin[i + 1], wr[i + 1], s1); }
-                    if (i < cur_in) s0 = fmaf(hin[i], wr[i], s0);
+                    for (; i + 1 < cur_in; i += 2) { s0 = fmaf(hin[(i + lr) & 31], wr[i], s0); s1 = fmaf(hin[(i + 1 + lr) & 31], wr[i + 1], s1); }
+                    if (i < cur_in) s0 = fmaf(hin[(i + lr) & 31], wr[i], s0);
                     float sacc = (s0 + s1) + wp[(size_t)on * cur_in + o];
                     if (!last && sacc < 0.f) sacc = 0.f;
-                    if (last) { if (row_ok) dst[o] = sacc; } else h2[lr * 33 + o] = sacc;
+                    if (last) { if (row_ok) dst[o] = sacc; } else h2[lr * 32 + ((o + lr) & 31)] = sacc;
                 }
                 wave_lds_sync();
                 wp += (size_t)on * cur_in + on;
                 cur_in = on;
-                hin = h2 + lr * 33;
+                hin = h2 + lr * 32;
             }
         }
         wave_lds_sync();
@@ -898,8 +905,8 @@ static hipError_t launch_mlp_windows_nt(hipStream_t st, const MlpDev &m, const f
     const size_t bps = (n_win + NT * kWinTile - 1) / (NT * kWinTile), blocks = bps * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const int slots = (NT * kWinTile + L + 3) & ~3;
-    // frame planes; later two sets of partial sums, the second of which is free again (h1 / h2 of the waves) when the tiles are finished
-    const size_t region = std::max((size_t)4 * slots * 16, (size_t)NT * 4096 + std::max((size_t)NT * 4096, (size_t)kWinWaves * 2 * 32 * 33 * 4));
+    // frame planes; later the sums of the tiles (h1 of a tile in its place) + h2 of the four waves
+    const size_t region = std::max((size_t)4 * slots * 16, (size_t)NT * 4096 + (size_t)kWinWaves * 4096);
     const size_t lds = (size_t)((m.tail_floats + 3) & ~3) * 4 + (size_t)slots * 4 + region;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_kernel<NT>), 160 * 1024); e != hipSuccess) return e;

@@ -21,7 +21,7 @@ What the one JSON line carries besides the contract's fields (round 4):
                      profiles/valu_rate_table.json), matrix flops, HBM bytes, LDS cycles -- each <= 1 by construction; the
                      reference-shaped flop rate of SURVEY 8d sits beside it as ref_flop_rate_vs_vector_peak
   vector_only        the same step with the cosine products on the vector pipe (RP_DTW_MFMA=0), 2 steps
-  extra_configs      short timed runs of BASELINE configs C2, C5 (bf16) and C5 (f32) in the same process
+  extra_configs      short timed runs of BASELINE configs C2, C5 (bf16) and C5 (f32), of the wakeword-model detector and of the filter front-end in the same process
   h2d_included       a bounded sample of the same path with the PCM starting in pinned HOST memory (see --ingest)
   cpu_baseline       the oracle on all granted host cores, and on one thread (one_thread)
   config.*           host CPU model, build id of the library, and for N > 1 the world size RCCL reports and every rank's device UUID
@@ -601,6 +601,11 @@ def bench_dtw(env):
                 extras["C5_" + prec] = extra_c5(env, prec)
             except Exception as e:
                 extras["C5_" + prec] = {"error": repr(e)}
+        for name, fn in (("model_detector", extra_model_detector), ("front_end", extra_front_end)):
+            try:
+                extras[name] = fn(env)
+            except Exception as e:
+                extras[name] = {"error": repr(e)}
         out["extra_configs"] = extras
         try:
             out["h2d_included"] = ingest_measure(env, case, blocks=2, block_streams=min(8192, S), fmt="f32")
@@ -766,6 +771,86 @@ def extra_c5(env, precision):
     del case
     env.torch.cuda.empty_cache()
     return res
+
+
+def _timed(env, call, warmup, steps):
+    for _ in range(warmup):
+        call()
+    env.torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    env.torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_model_detector(env, S=8192):
+    """The wakeword-MODEL detector over whole streams (rp_batch_detect_model: MFCC of mfcc_size 16 -> every window of 195 frames through
+    the Small model of config C5 -> scores -> detection state machine), SURVEY 8a row a17 in the form the detector runs it."""
+    import ctypes as C
+    import numpy as np
+    ra, torch, dev = env.ra, env.torch, env.dev
+    N, F, K = 64000, 195, 16
+    dims = [F * K, F // 6, F // 12, 2]
+    rng = np.random.default_rng(5)
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
+    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+    ctx = ra.BatchContext(device=env.local_rank, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    model = ra.Model(ctx, ws, bs)
+    pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
+    ctx.synth_dev(SEED, 0, S, N, N, pcm.data_ptr())
+    det = torch.zeros((S, 4, 6), dtype=torch.int32, device=dev)
+    lab = torch.zeros((S, 4), dtype=torch.int32, device=dev)
+    n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    c = cfg._c()
+    L = ra.load_library()
+
+    def call():
+        if L.rp_batch_detect_model(ctx._h, pcm.data_ptr(), 3, S, N, N, model._h, K, 0, C.byref(c), 0, det.data_ptr(), lab.data_ptr(), n_det.data_ptr(), 4) != 0:
+            raise RuntimeError(ra.last_error() if hasattr(ra, "last_error") else "rp_batch_detect_model failed")
+    dt = _timed(env, call, 2, 10)
+    n_win = ra.mfcc_num_frames(N) - F + 1
+    flops = S * n_win * 2.0 * (dims[0] * dims[1] + dims[1] * dims[2] + dims[2] * dims[3])
+    return {"workload": "%d synthetic 4 s streams, Small model 3120->32->16->2 on every window of 195 frames x 16 coefficients (%d windows per stream), f32 callers" % (S, n_win),
+            "value": S * n_win / dt, "unit": "window scorings/s", "steps": 10, "warmup": 2, "ms_per_step": dt * 1e3,
+            "dtype": "f32 (layer-1 products: f16x2-split MFMA, 22-bit)", "kernel": ctx.last_mlp_kernel(),
+            "algorithmic_model_flop_rate_tflops": flops / dt / 1e12,
+            "note": "kernel split and PMC of the forward: profiles/r04_model_detect.txt"}
+
+
+def extra_front_end(env, S=65536):
+    """sample decode + GainNormalizerFilter + BandPassFilter over whole streams (rp_frontend_batch), i16 in, f32 out."""
+    import ctypes as C
+    ra, torch, dev = env.ra, env.torch, env.dev
+    N = 64000
+    ctx = ra.BatchContext(device=env.local_rank, host_pointers=False)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    raw = (torch.randn((S, N), device=dev, generator=g) * 3000).to(torch.int16)
+    out = torch.empty((S, N), dtype=torch.float32, device=dev)
+    rc = ra.RustpotterConfig()
+    rc.filters.gain_normalizer.enabled = True
+    rc.filters.band_pass.enabled = True
+    f = rc._filters_c()
+    L = ra.load_library()
+
+    def call():
+        if L.rp_frontend_batch(ctx._h, raw.data_ptr(), 1, S, N, N, C.byref(f), 0.05, 33, out.data_ptr(), N, None, None) != 0:
+            raise RuntimeError("rp_frontend_batch failed")
+    dt = _timed(env, call, 2, 10)
+    del raw, out
+    torch.cuda.empty_cache()
+    alg = S * N * 6.0
+    # (a lane owns a stream: the call needs S / 64 >= 4 workgroups per CU to fill the chip, i.e. C3's 65 536 streams; 16 384 run at half the rate)
+    return {"workload": "%d synthetic 4 s streams, i16 in, f32 out, gain normaliser (window 33) + band-pass on" % S, "value": S * N / dt, "unit": "samples/s",
+            "steps": 10, "warmup": 2, "ms_per_step": dt * 1e3, "dtype": "f32 (bit-exact against the oracle)",
+            "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / dt / HBM_PEAK,
+                         "algorithmic_bytes": "2 B in + 4 B out per sample; the call reads the PCM twice (chunk RMS, then the filters): 8 B moved per sample",
+                         "note": "the filter kernel runs at the measured copy ceiling of its 1 : 2 read : write mix (4.8-5.0 TB/s): profiles/r04_frontend.txt"}}
 
 
 def bench_mlp(env):

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * W) void apply_filters_lines_kernel(const TIN *
                                                                      size_t n_chunks, size_t pcm_stride, const float *__restrict__ gains,
                                                                      BiquadCoef q, float *__restrict__ out, size_t out_stride) {
     constexpr int G = T / 4, RPM = 64 / G, PITCH = T + 4, kMoves = G, BLK = 4, HALF = kMoves / 2;
-    static_assert(T == 64 || T == 128, "tile shape");
+    static_assert(T == 32 || T == 64 || T == 128, "tile shape");
     __shared__ __attribute__((aligned(16))) float tiles[W][64 * PITCH];
     __shared__ float carry[W > 1 ? 4 : 1][64];
     const int lane = threadIdx.x & 63;
@@ -347,9 +347,12 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
         }
     }
     if (vec4 && pcm_stride < (1u << 29) && out_stride < (1u << 29)) {  // 32-bit lane offsets inside a wave's rows
-        // 64-sample tiles, two waves per 64 streams taking turns; RP_FRONTEND_TILE=128 = one wave on 128-sample tiles (A/B)
-        static const int tlen = getenv("RP_FRONTEND_TILE") ? atoi(getenv("RP_FRONTEND_TILE")) : 64;
+        // 64-sample tiles, two waves per 64 streams taking turns; a batch too small to give every SIMD two such waves (a lane owns a
+        // stream: S / 64 workgroups is all there is) takes 32-sample tiles and four waves per 64 streams instead.
+        // RP_FRONTEND_TILE = 32 / 64 / 128 (128: one wave per 64 streams) forces a form (A/B, tests)
+        static const int tlen_env = getenv("RP_FRONTEND_TILE") ? atoi(getenv("RP_FRONTEND_TILE")) : 0;
         const size_t full = S / 64;
+        const int tlen = tlen_env ? tlen_env : (S + 63) / 64 >= 768 ? 64 : 32;
 #define RP_LINES(G, B, T, W)                                                                                                            \
     do {                                                                                                                                \
         if (full)                                                                                                                       \
@@ -362,6 +365,7 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
 #define RP_TILED(G, B)                                                                                                                  \
     do {                                                                                                                                \
         if (tlen == 128) RP_LINES(G, B, 128, 1);                                                                                        \
+        else if (tlen == 32) RP_LINES(G, B, 32, 4);                                                                                     \
         else RP_LINES(G, B, 64, 2);                                                                                                     \
     } while (0)
         if (gain_on && band_pass) RP_TILED(true, true);

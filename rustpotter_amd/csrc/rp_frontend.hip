@@ -197,12 +197,19 @@ __global__ __launch_bounds__(64) void apply_filters_kernel(const TIN *__restrict
 // own LDS buffer and fetches the one after; one workgroup barrier per phase: the LDS tile bounds the occupancy, and two waves
 // on a 64-sample tile each cover the other's waiting (one wave per SIMD: SQ_WAIT_INST_ANY 0.34 of SQ_WAVE_CYCLES) in the LDS
 // of one 128-sample tile.  Same arithmetic per sample as apply_filters_kernel.
+// A call's floor: 3 ms for 64 000 samples per stream whatever the batch (2 048 streams 2.98 ms, 16 384 3.32, 32 768 4.00, 65 536
+// 6.1-6.3): the tiles of a stream follow each other, and a phase lasts as long as the longer of its two sides -- the walk (all 17
+// instructions of the filter per sample, issued in order) and the other wave's store / decode / fetch, about 3 us each.  Measured
+// and dropped in round 4: 32-sample tiles with four waves (a phase still has ONE walk and ONE decode: 3.1-3.7 ms for 2 048-16 384
+// streams); the feed-forward half of the biquad and the gain moved into the time-major decode (DPP neighbours, bit-exact) so
+// that the walk keeps 4 instructions per sample -- the decode side then is the long one: 4.1 ms at 2 048 streams with two or four
+// waves, 7.4 ms at 65 536.  The two sides are balanced as they are; only less work per sample on both would lower the floor.
 template <class TIN, bool GAIN, bool BP, int T, int W, bool FULL>
 __global__ __launch_bounds__(64 * W) void apply_filters_lines_kernel(const TIN *__restrict__ pcm, size_t S, size_t wg0, size_t n_samples,
                                                                      size_t n_chunks, size_t pcm_stride, const float *__restrict__ gains,
                                                                      BiquadCoef q, float *__restrict__ out, size_t out_stride) {
     constexpr int G = T / 4, RPM = 64 / G, PITCH = T + 4, kMoves = G, BLK = 4, HALF = kMoves / 2;
-    static_assert(T == 32 || T == 64 || T == 128, "tile shape");
+    static_assert(T == 64 || T == 128, "tile shape");
     __shared__ __attribute__((aligned(16))) float tiles[W][64 * PITCH];
     __shared__ float carry[W > 1 ? 4 : 1][64];
     const int lane = threadIdx.x & 63;
@@ -347,12 +354,9 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
         }
     }
     if (vec4 && pcm_stride < (1u << 29) && out_stride < (1u << 29)) {  // 32-bit lane offsets inside a wave's rows
-        // 64-sample tiles, two waves per 64 streams taking turns; a batch too small to give every SIMD two such waves (a lane owns a
-        // stream: S / 64 workgroups is all there is) takes 32-sample tiles and four waves per 64 streams instead.
-        // RP_FRONTEND_TILE = 32 / 64 / 128 (128: one wave per 64 streams) forces a form (A/B, tests)
-        static const int tlen_env = getenv("RP_FRONTEND_TILE") ? atoi(getenv("RP_FRONTEND_TILE")) : 0;
+        // 64-sample tiles, two waves per 64 streams taking turns; RP_FRONTEND_TILE=128 = one wave on 128-sample tiles (A/B)
+        static const int tlen = getenv("RP_FRONTEND_TILE") ? atoi(getenv("RP_FRONTEND_TILE")) : 64;
         const size_t full = S / 64;
-        const int tlen = tlen_env ? tlen_env : (S + 63) / 64 >= 768 ? 64 : 32;
 #define RP_LINES(G, B, T, W)                                                                                                            \
     do {                                                                                                                                \
         if (full)                                                                                                                       \
@@ -365,7 +369,6 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
 #define RP_TILED(G, B)                                                                                                                  \
     do {                                                                                                                                \
         if (tlen == 128) RP_LINES(G, B, 128, 1);                                                                                        \
-        else if (tlen == 32) RP_LINES(G, B, 32, 4);                                                                                     \
         else RP_LINES(G, B, 64, 2);                                                                                                     \
     } while (0)
         if (gain_on && band_pass) RP_TILED(true, true);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: kernel-trace split of rp_frontend_batch at C3 size for the given "TILE TURNS GAIN BP FMT" settings.
-# Usage: tools/r4_frontend_prof.sh "0 1 1 1 i16" "128 1 1 1 i16" ...
+# Usage: tools/r4_frontend_prof.sh "0 1 1 1 i16" ...   (TILE / TURNS are exported as RP_FRONTEND_TILE / RP_FRONTEND_TURNS: only TILE = 128 still selects another form)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 for cfg in "$@"; do
   set -- $cfg

@@ -1396,7 +1396,8 @@ static bool window_logits(Ctx *c, const Model &m, const float *dm, size_t S, siz
             c->time_end();
             if (!ok) return false;
             c->last_mlp_kernel = precision == RP_MLP_F32_STRICT ? "mlp_mfma_kernel<f32 matrix instructions>, windows read in place"
-                                 : mlp_windows_supported(m.dev, n_win, K) ? "mlp_windows_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
+                                 : mlp_windows_supported(m.dev, n_win, K) == 1 ? "mlp_windows_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
+                                 : mlp_windows_supported(m.dev, n_win, K) == 2 ? "mlp_windows_wide_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
                                  : "mlp_mfma_kernel<f16x2 splits>, windows read in place, + mlp_mfma_kernel<f32> on listed rows";
         } else {
             // windows are materialised slab by slab (a row is dims[0] floats): <= 4 GiB of rows at a time

@@ -539,15 +539,16 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
         if (tail.empty()) tail.push_back(0.f);
         d.tail_floats = (int)tail.size();
         if (!mlp_mfma_fits(d)) { m->mfma_ok = false; d.nt = 0; return m.release(); }   // e.g. a 255-wide hidden layer: per-layer kernel
-        if (dims[0] % 16 == 0 && n1 <= 32) {   // mlp_windows_kernel (mfcc_size 16): [frame][part][k-half][output][8 k], frames padded to groups of 5
-            const int Lw = dims[0] / 16, Lp = (Lw + 4) / 5 * 5;
-            std::vector<uint16_t> img((size_t)Lp * 2 * 2 * 32 * 8, 0);
+        if (dims[0] % 16 == 0 && n1 <= 160) {   // mlp_windows_kernel / mlp_windows_wide_kernel (mfcc_size 16): [frame][32-output tile q][part][k-half][output][8 k]
+            const int Lw = dims[0] / 16, NQ = (n1 + 31) / 32;
+            std::vector<uint16_t> img((size_t)Lw * NQ * 2 * 2 * 32 * 8, 0);
             for (int f = 0; f < Lw; ++f)
                 for (int part = 0; part < 2; ++part)
                     for (int h = 0; h < 2; ++h)
-                        for (int j = 0; j < n1; ++j)
+                        for (int o = 0; o < n1; ++o)
                             for (int e = 0; e < 8; ++e)
-                                img[((((size_t)f * 2 + part) * 2 + h) * 32 + j) * 8 + e] = wsp[(size_t)part * rows * d.kpad + (size_t)j * d.kpad + 16 * f + 8 * h + e];
+                                img[((((((size_t)f * NQ + o / 32) * 2 + part) * 2 + h) * 32) + o % 32) * 8 + e] =
+                                    wsp[(size_t)part * rows * d.kpad + (size_t)o * d.kpad + 16 * f + 8 * h + e];
             if (!up(img.data(), img.size() * 2, &d.wwin)) return nullptr;
         }
         if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) || !up(wsp.data(), wsp.size() * 2, &d.w1s) ||

@@ -343,8 +343,8 @@ struct MlpDev {
     float *w1f = nullptr;  // [16*nt][kpad] f32, zero padded
     void *w1h = nullptr;   // [16*nt][kpad] bf16, zero padded
     void *w1s = nullptr;   // [2][16*nt][kpad] f16: the two parts of the weights' f16 split (kMlpF16x2), zero padded
-    void *wwin = nullptr;  // mfcc_size 16, layer 1 <= 32 wide: the same two parts in the order mlp_windows_kernel's lanes read them,
-                           // [frame f][part][k-half h][output j < 32][8 k = 16 f + 8 h ..] f16, frames zero padded to whole groups of 5
+    void *wwin = nullptr;  // mfcc_size 16, layer 1 <= 160 wide: the same two parts in the order the lanes of mlp_windows_kernel (<= 32 wide) /
+                           // mlp_windows_wide_kernel read them, [frame f][32-output tile q][part][k-half h][output j < 32][8 k = 16 f + 8 h ..] f16
     float *b1 = nullptr;   // [16*nt]
     float *tail = nullptr; // layers 2..n: W [out][in] then b [out], concatenated
     int tail_floats = 0;
@@ -382,7 +382,7 @@ hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPla
 hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int L, int K, float *mean);
 // frame_pitch (0 = n_win + L - 1, whole streams): frames between the rows of two streams -- live-stream batches keep their
 // windows in longer rows (window w of stream s starts at frame s * frame_pitch + w, counted from `mfcc`)
-bool mlp_windows_supported(const MlpDev &m, size_t n_win, int K);   // mlp_windows_kernel takes the call (else mlp_mfma_kernel, rows read in place)
+int mlp_windows_supported(const MlpDev &m, size_t n_win, int K);   // 1: mlp_windows_kernel, 2: mlp_windows_wide_kernel takes the call (0: mlp_mfma_kernel, rows read in place)
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
                                    const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch = 0,
                                    bool strict_f32 = false);   // strict_f32: RP_MLP_F32_STRICT callers

@@ -889,13 +889,225 @@ __global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
     }
 }
 
-bool mlp_windows_supported(const MlpDev &m, size_t n_win, int K) {
-    if (!m.wwin || K != 16 || m.dims[0] % 16 != 0 || m.dims[1] > 32 || n_win < 32) return false;
+// The same for layer 1 wider than 32 (the Medium and Large model types: 65 / 130 outputs for 195 frames): NQ = 2 .. 5 waves, wave q owns
+// the 32-output tile q for all NT row tiles and ALL frames of the window (its own slice of the weight image, four frames ahead, used NT
+// times) -- no partial sums to add up; the tiles then meet in LDS row tile by row tile ([32][32 NQ + 1] floats) for the tail layers, which
+// every lane of the workgroup shares (row, output phase).  mlp_mfma_kernel in window mode, which these shapes had until now: 5.6 ms
+// (Medium) / 13.5 ms (Large) per 8 192 streams.
+template <int NT, int NQ>
+__global__ __launch_bounds__(64 * NQ, 2) void mlp_windows_wide_kernel(
+    const float *__restrict__ mfcc, size_t frame_pitch, size_t n_win, int L, unsigned blocks_per_stream, const u32x4v *__restrict__ wimg, int slots,
+    int n1p, const float *__restrict__ b1, const float *__restrict__ mean, const float *__restrict__ wsum, const float *__restrict__ tail,
+    int tail_floats, int n_layers, int d1, int d2, int d3, float *__restrict__ out, uint32_t *redo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NTHR = 64 * NQ, P1 = 32 * NQ + 1;
+    float *tl = reinterpret_cast<float *>(smem);                                   // tail weights
+    unsigned *flag = reinterpret_cast<unsigned *>(tl + ((tail_floats + 3) & ~3));   // [slots] frame holds a value beyond the f16 range
+    u32x4v *A = reinterpret_cast<u32x4v *>(flag + slots);                           // [2 parts][2 k-halves][slots]; later h1 / h2 of a row tile
+    const int tid = threadIdx.x, q = tid >> 6, l = tid & 63, lr = l & 31, lh = l >> 5;
+    const size_t s = blockIdx.x / blocks_per_stream;
+    const size_t w0 = (size_t)(blockIdx.x - s * blocks_per_stream) * (NT * kWinTile);
+    const size_t rows_here = n_win - w0 < (size_t)(NT * kWinTile) ? n_win - w0 : (size_t)(NT * kWinTile);
+    const int n_real = (int)rows_here + L - 1;
+    for (int i = tid; i < tail_floats; i += NTHR) tl[i] = tail[i];
+    // ---- frames minus the middle window's mean -> the two f16 parts, once (as mlp_windows_kernel)
+    const float *src = mfcc + (s * frame_pitch + w0) * 16;
+    const float4 *cmid = reinterpret_cast<const float4 *>(mean + (s * n_win + w0 + rows_here / 2) * 16);
+    {
+        constexpr int MAXI = (2 * (kWinMaxTiles * kWinTile + 256) + NTHR - 1) / NTHR;
+        const int h = tid & 1;
+        const float4 cl = cmid[2 * h], ch = cmid[2 * h + 1];
+        float4 lo[MAXI], hi[MAXI];
+#pragma unroll
+        for (int v = 0; v < MAXI; ++v) {
+            const int i = tid + v * NTHR, fr = i >> 1;
+            if (i < 2 * slots && fr < n_real) {
+                lo[v] = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h);
+                hi[v] = *reinterpret_cast<const float4 *>(src + (size_t)fr * 16 + 8 * h + 4);
+            } else { lo[v] = cl; hi[v] = ch; }
+        }
+#pragma unroll
+        for (int v = 0; v < MAXI; ++v) {
+            const int i = tid + v * NTHR, fr = i >> 1;
+            if (i < 2 * slots) {
+                const float xs[8] = {lo[v].x - cl.x, lo[v].y - cl.y, lo[v].z - cl.z, lo[v].w - cl.w, hi[v].x - ch.x, hi[v].y - ch.y, hi[v].z - ch.z, hi[v].w - ch.w};
+                u32x4v p0, p1;
+                float rng = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = xs[2 * e], b = xs[2 * e + 1];
+                    rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
+                    p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+                    p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
+                }
+                A[(0 * 2 + h) * slots + fr] = p0;
+                A[(1 * 2 + h) * slots + fr] = p1;
+                if (h == 0) flag[fr] = 0u;
+                if (!(rng <= 65504.f)) flag[fr] = 1u;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- every frame, this wave's 32 outputs, all NT tiles
+    f32x16w acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    u32x4v wq0[kWinAhead], wq1[kWinAhead];
+    auto wfetch = [&](int f, int j) __attribute__((always_inline)) {
+        const int fc = f < L ? f : L - 1;
+        wq0[j] = wimg[((((size_t)fc * NQ + q) * 2 + 0) * 2 + lh) * 32 + lr];
+        wq1[j] = wimg[((((size_t)fc * NQ + q) * 2 + 1) * 2 + lh) * 32 + lr];
+    };
+    {
+#pragma unroll
+        for (int j = 0; j < kWinAhead; ++j) wfetch(j, j);
+        const u32x4v *A0 = A + (0 * 2 + lh) * slots + lr, *A1 = A + (1 * 2 + lh) * slots + lr;
+        for (int f0 = 0; f0 < L; f0 += kWinAhead) {
+#pragma unroll
+            for (int j = 0; j < kWinAhead; ++j) {
+                const int f = f0 + j;
+                if (f < L) {   // wave-uniform
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, wq0[j]), b1v = __builtin_bit_cast(f16x8, wq1[j]);
+                    wfetch(f + kWinAhead, j);
+#pragma unroll
+                    for (int t = 0; t < NT; t += 2) {
+                        const bool two = t + 1 < NT;
+                        const f16x8 p0 = __builtin_bit_cast(f16x8, A0[t * kWinTile + f]), p1 = __builtin_bit_cast(f16x8, A1[t * kWinTile + f]);
+                        f16x8 q0 = p0, q1 = p1;
+                        if (two) { q0 = __builtin_bit_cast(f16x8, A0[(t + 1) * kWinTile + f]); q1 = __builtin_bit_cast(f16x8, A1[(t + 1) * kWinTile + f]); }
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b0, acc[t], 0, 0, 0);
+                        if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, b0, acc[t + 1], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b0, acc[t], 0, 0, 0);
+                        if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q1, b0, acc[t + 1], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p0, b1v, acc[t], 0, 0, 0);
+                        if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(q0, b1v, acc[t + 1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the frame planes: the region becomes h1 [32][P1] and h2 [32][33] of one row tile at a time
+    float *h1 = reinterpret_cast<float *>(A), *h2 = h1 + 32 * P1;
+    const bool relu1 = n_layers > 1;
+    const int col = 32 * q + lr;
+    float4 ws4[4], c4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ws4[k] = col < n1p ? *reinterpret_cast<const float4 *>(wsum + (size_t)col * 16 + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        c4[k] = cmid[k];
+    }
+    const float bias1 = col < n1p ? b1[col] : 0.f;
+    const int prow = tid & 31, ph = tid >> 5;   // tail layers: lane = (row, output phase), 2 NQ phases
+    constexpr int NPH = 2 * NQ;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const size_t wrow0 = (size_t)t * kWinTile;
+        if (wrow0 >= rows_here) break;   // workgroup-uniform
+        // C/D layout of the 32x32 tile: lane (column lr, half lh) holds rows 8 * (e / 4) + 4 * lh + e % 4
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 8 * (e >> 2) + 4 * lh + (e & 3);
+            size_t rr = wrow0 + row;
+            if (rr >= rows_here) rr = rows_here - 1;
+            const float4 *mu = reinterpret_cast<const float4 *>(mean + (s * n_win + w0 + rr) * 16);
+            float corr = 0.f;   // - sum_k (mu[row][k] - c[k]) * wsum[o][k]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 m4 = mu[k], w4 = ws4[k], c = c4[k];
+                corr = fmaf(m4.x - c.x, w4.x, corr); corr = fmaf(m4.y - c.y, w4.y, corr); corr = fmaf(m4.z - c.z, w4.z, corr); corr = fmaf(m4.w - c.w, w4.w, corr);
+            }
+            float v = acc[t][e] - corr;
+            v += bias1;
+            if (relu1 && v < 0.f) v = 0.f;
+            h1[row * P1 + col] = v;
+        }
+        __syncthreads();
+        const bool row_ok = wrow0 + prow < rows_here;
+        const size_t orow = s * n_win + w0 + wrow0 + prow;
+        if (ph == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
+            unsigned far = 0u;
+            for (int f = 0; f < L; ++f) far |= flag[wrow0 + prow + f];
+            if (far) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)orow;
+        }
+        const int dd[4] = {d1, d2, d3, 0};
+        float *dst = out + orow * (size_t)dd[n_layers - 1];
+        const float *hin = h1 + prow * P1;
+        if (n_layers == 1) {
+            if (row_ok) for (int o = ph; o < d1; o += NPH) dst[o] = hin[o];
+        } else {
+            const float *wp = tl;
+            int cur_in = d1;
+            for (int layer = 1; layer < n_layers; ++layer) {
+                const int on = dd[layer];
+                const bool last = layer + 1 == n_layers;
+                for (int o = ph; o < on; o += NPH) {   // sums in mlp_mfma_kernel's order
+                    const float *wr = wp + (size_t)o * cur_in;
+                    float s0 = 0.f, s1 = 0.f;
+                    int i = 0;
+                    for (; i + 1 < cur_in; i += 2) { s0 = fmaf(hin[i], wr[i], s0); s1 = fmaf(hin[i + 1], wr[i + 1], s1); }
+                    if (i < cur_in) s0 = fmaf(hin[i], wr[i], s0);
+                    float sacc = (s0 + s1) + wp[(size_t)on * cur_in + o];
+                    if (!last && sacc < 0.f) sacc = 0.f;
+                    if (last) { if (row_ok) dst[o] = sacc; } else h2[prow * 33 + o] = sacc;
+                }
+                __syncthreads();
+                wp += (size_t)on * cur_in + on;
+                cur_in = on;
+                hin = h2 + prow * 33;
+            }
+        }
+        __syncthreads();   // h1 / h2 are free for the next row tile
+    }
+}
+
+int mlp_windows_supported(const MlpDev &m, size_t n_win, int K) {
+    if (!m.wwin || K != 16 || m.dims[0] % 16 != 0 || m.dims[1] > 160 || n_win < 32) return 0;
     const int L = m.dims[0] / 16;
-    if (L > 256 || m.tail_floats > 4096) return false;
-    for (int l2 = 2; l2 <= m.n_layers; ++l2) if (m.dims[l2] > 32) return false;
+    if (L > 256 || m.tail_floats > 6144) return 0;
+    for (int l2 = 2; l2 <= m.n_layers; ++l2) if (m.dims[l2] > 32) return 0;
     const char *env = std::getenv("RP_MLP_WINDOWS");
-    return !(env && env[0] == '0');
+    if (env && env[0] == '0') return 0;
+    return m.dims[1] <= 32 ? 1 : 2;
+}
+
+template <int NT, int NQ>
+static hipError_t launch_mlp_windows_wide_nq(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
+                                             const float *wsum, float *out, uint32_t *redo, size_t pitch) {
+    const int L = m.dims[0] / 16;
+    const size_t bps = (n_win + NT * kWinTile - 1) / (NT * kWinTile), blocks = bps * S;
+    if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
+    const int slots = (NT * kWinTile + L + 3) & ~3;
+    const size_t region = std::max((size_t)4 * slots * 16, (size_t)32 * (32 * NQ + 1) * 4 + (size_t)32 * 33 * 4);
+    const size_t lds = (size_t)((m.tail_floats + 3) & ~3) * 4 + (size_t)slots * 4 + region;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_wide_kernel<NT, NQ>), 160 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mlp_windows_wide_kernel<NT, NQ>), dim3((unsigned)blocks), dim3(64 * NQ), lds, st, mfcc, pitch, n_win, L, (unsigned)bps,
+                       static_cast<const u32x4v *>(m.wwin), slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
+                       m.dims[3], out, redo);
+    return hipGetLastError();
+}
+
+template <int NT>
+static hipError_t launch_mlp_windows_wide_nt(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
+                                             const float *wsum, float *out, uint32_t *redo, size_t pitch) {
+    switch ((m.dims[1] + 31) / 32) {
+    case 2: return launch_mlp_windows_wide_nq<NT, 2>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 3: return launch_mlp_windows_wide_nq<NT, 3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 4: return launch_mlp_windows_wide_nq<NT, 4>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 5: return launch_mlp_windows_wide_nq<NT, 5>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t launch_mlp_windows_wide(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
+                                          const float *wsum, float *out, uint32_t *redo, size_t pitch) {
+    // row tiles per workgroup: 2 or 4 (measured per 8 192 streams x 202 windows, Medium / Large: 7 tiles 3.87 / 8.62 ms at two waves per SIMD,
+    // 4 tiles 3.36 / 7.90 at four, 2 tiles 3.84 / 11.2 -- the weights once per 64 rows)
+    const size_t tiles = (n_win + kWinTile - 1) / kWinTile, wgs = (tiles + 3) / 4, per = (tiles + wgs - 1) / wgs;
+    if (per <= 2) return launch_mlp_windows_wide_nt<2>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    return launch_mlp_windows_wide_nt<4>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
 }
 
 template <int NT>
@@ -946,13 +1158,16 @@ hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float 
     if (pitch < n_win) return hipErrorInvalidValue;
     (void)n_frames;
     const size_t skip = (pitch - n_win) * K;
-    if (!strict_f32 && redo && mlp_windows_supported(m, n_win, K)) {
+    if (const int form = (!strict_f32 && redo) ? mlp_windows_supported(m, n_win, K) : 0) {
         // whole streams (or long runs of windows): the frames staged once per workgroup; then the listed rows with the f32 instructions
         if (S * n_win > 0xffffffffULL) return hipErrorInvalidValue;
-        if (hipError_t e = launch_mlp_windows(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch); e != hipSuccess) return e;
+        if (hipError_t e = form == 1 ? launch_mlp_windows(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch)
+                                     : launch_mlp_windows_wide(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch); e != hipSuccess) return e;
         switch (m.nt) {
         case 1: return launch_mlp_nt<1>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
         case 2: return launch_mlp_nt<2>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+        case 5: return launch_mlp_nt<5>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+        case 9: return launch_mlp_nt<9>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
         }
         return hipErrorInvalidValue;
     }

@@ -527,6 +527,11 @@ def _window_model(rng, L, K, hidden, labels):
     (251, (17, 8), 2, 550, 2),      # 300 windows: two workgroups per stream; 251 frames = the longest window, 51 weight groups (the last one ragged)
     (7, (), 30, 100, 1),            # a single layer
     (195, (32, 16), 2, 225, 2),     # 31 windows: stays with mlp_mfma_kernel (rows read in place)
+    (195, (65, 32), 2, 399, 2),     # Medium: three 32-output tiles, one wave each (mlp_windows_wide_kernel)
+    (195, (130, 32), 3, 430, 2),    # Large: five tiles; 236 windows = two workgroups of four row tiles per stream
+    (60, (40, 20), 2, 100, 3),      # two output tiles, 41 windows = the two-row-tile form
+    (100, (97,), 4, 200, 1),        # four output tiles, no hidden tail layer
+    (30, (160,), 160, 70, 1),       # 160 outputs of a single layer written straight from the tiles
 ])
 def test_window_logits_match_the_oracle(ra, ctx, L, hidden, labels, nf, S):
     """rp_mlp_forward_windows against the oracle's window-by-window forward (normalise, flatten, ModelImpl::forward): features on

@@ -9,10 +9,12 @@ import rustpotter_amd as ra
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 N, F, K = 64000, 195, 16
-dims = [F * K, F // 6, F // 12, 2]
+# MODEL_TYPE = tiny | small (default: BASELINE config C5) | medium | large: the layer widths of wakeword_nn.rs:305-389
+mt = os.environ.get("MODEL_TYPE", "small")
+dims = {"tiny": [F * K, F // 15, 2], "small": [F * K, F // 6, F // 12, 2], "medium": [F * K, F // 3, F // 6, 2], "large": [F * K, F // 3 * 2, F // 6, 2]}[mt]
 rng = np.random.default_rng(5)
-ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
-bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(len(dims) - 1)]
 dev = torch.device("cuda", 0)
 ctx = ra.BatchContext(device=0, host_pointers=False)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -37,4 +39,4 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 n_win = (3 * (N // 480) - 3) - F + 1
-print("%d streams, %s: %.2f ms per pass, %.1f M window scorings/s (%d windows per stream)" % (S, prec, dt * 1e3, S * n_win / dt / 1e6, n_win))
+print("%s model %s, %d streams, %s: %.2f ms per pass, %.1f M window scorings/s (%d windows per stream)" % (mt, "->".join(map(str, dims)), S, prec, dt * 1e3, S * n_win / dt / 1e6, n_win))

@@ -9,8 +9,8 @@ namespace rp {
 // None of it depends on the detection state (reset() leaves both filters alone, :290-302), so it is
 // a pure function of the stream: per-chunk RMS in parallel, the gain recursion per stream over the
 // chunk RMS values, then gain + biquad per stream along time (one lane per stream: a lane re-reads
-// its own 128-byte lines from L1, HBM traffic stays one read + one write of the PCM); apply_filters_tiled_kernel
-// below is the form used whenever the row pitch allows 4-sample accesses.
+// its own 128-byte lines from L1, HBM traffic stays one read + one write of the PCM); chunk_rms_staged_kernel and
+// apply_filters_lines_kernel below are the forms used whenever the row pitch allows 4-sample accesses.
 template <class TIN>
 __global__ __launch_bounds__(256) void chunk_rms_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_chunks, size_t pcm_stride,
                                                         int vec4, float *__restrict__ rms) {

@@ -799,7 +799,7 @@ def test_batch_frontend_goldens(ra, ctx, case):
 
 @pytest.mark.parametrize("tail", [37, 36, 0])
 def test_frontend_many_streams_and_formats(ra, ctx, tail):
-    """tail 37: row pitch not a multiple of 4 samples -> the one-lane-per-stream kernel; 36 / 0: the LDS-tiled kernel
+    """tail 37: row pitch not a multiple of 4 samples -> the one-lane-per-stream kernels; 36 / 0: the LDS-staged kernels
     (partial last workgroup, with and without a tail shorter than a chunk)."""
     rng = np.random.default_rng(8)
     S, N = 70, 480 * 25 + tail

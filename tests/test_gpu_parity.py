@@ -1281,13 +1281,13 @@ def test_randomised_parity_sweep(ra, ctx):
     (tests/sweep_parity.py; longer runs: `python tests/sweep_parity.py --cases 300`)."""
     import sweep_parity
     n, total, ties = sweep_parity.run_sweep(ra, ctx, 24, seed=7)
-    assert n == 24 and total >= 10 and ties <= 2
+    assert n == 24 and total >= 10 and ties == 0
     # live-stream batches with single streams reset at random call boundaries
     n, total = sweep_parity.run_live_reset_sweep(ra, ctx, 16, seed=7)
     assert n == 16
     # live-stream batches behind the resampler (8-96 kHz, stereo): bitwise the offline pass over the resampled recording
     n, total, ties = sweep_parity.run_live_rate_sweep(ra, ctx, 10, seed=7)
-    assert n == 10 and ties <= 1
+    assert n == 10 and ties == 0
     # 1-3 wakewords with their own thresholds in rp_batch_detect_multi
     n, total = sweep_parity.run_multi_sweep(ra, ctx, 16, seed=7)
     assert n == 16 and total >= 3

@@ -362,18 +362,28 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     // weights), so the HBM stream never drains at the per-group barrier
     constexpr int NA = PREC == kMlpF32 ? kMlpKG / 16 : 2 * (kMlpKG / 32);
     float4 areg[2][NA];
-    // Windows of mfcc_size 16 (norm16): the row's own window mean leaves each feature as it is loaded -- MfccNormalizer::normalize itself;
-    // a lane's pieces always hold the same coefficients (k0 mod 16 = 4 lk, or 8 (lk & 1) + 4 (u & 1)).  Until round 4 the mean was taken
-    // out after layer 1 for every mfcc size (the epilogue below, still what other sizes get): real MFCCs sit on offsets many times their
-    // spread, and a sum that carries the offsets loses their size in f32 rounding (5e-6 of a score on the reference's own recording).
-    const bool norm16 = mean != nullptr && K == 16;
+    // Windows (mean != nullptr): the row's own window mean leaves each feature as it is loaded -- MfccNormalizer::normalize itself.  For
+    // mfcc_size 16 a lane's pieces always hold the same coefficients (k0 mod 16 = 4 lk, or 8 (lk & 1) + 4 (u & 1)): registers; for the
+    // other sizes (multiples of 4) the piece's place in the frame, kc = k0 mod K, is carried from group to group and the four means come
+    // from the row's mean vector (a cached 16-byte load).  Until round 4 the mean was taken out after layer 1
+    // (W.(f - mu) = W.f - sum_k mu[k] wsum[k]): real MFCCs sit on offsets many times their spread, and a sum that carries the offsets loses
+    // their size in f32 rounding (5e-6 of a score on the reference's own recording).
+    const bool norm = mean != nullptr, norm16 = norm && K == 16;
     float4 mu_a = make_float4(0.f, 0.f, 0.f, 0.f), mu_b = mu_a;
+    const float *mrow = norm ? mean + r * (size_t)K : nullptr;
+    int kc[NA];
+    const int kstep = (norm && !norm16) ? kMlpKG % K : 0;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) kc[u] = 0;
     if (norm16) {
-        const float4 *mu = reinterpret_cast<const float4 *>(mean + r * 16);
+        const float4 *mu = reinterpret_cast<const float4 *>(mrow);
         if (PREC == kMlpF32) mu_a = mu[lk];
         else { mu_a = mu[2 * (lk & 1)]; mu_b = mu[2 * (lk & 1) + 1]; }
+    } else if (norm) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) kc[u] = (PREC == kMlpF32 ? 16 * u + 4 * lk : 32 * (u >> 1) + 8 * lk + 4 * (u & 1)) % K;
     }
-    auto aload = [&](int g, float4 (&dst)[NA]) __attribute__((always_inline)) {
+    auto aload = [&](int g, float4 (&dst)[NA]) __attribute__((always_inline)) {   // called for g = 0, 1, 2, .. in this order
         const int kg = g * kMlpKG;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
@@ -382,12 +392,13 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k0 + 3 < in) {
                 v = *reinterpret_cast<const float4 *>(xr + k0);
-                if (norm16) {
-                    const float4 m = (PREC == kMlpF32 || !(u & 1)) ? mu_a : mu_b;
+                if (norm) {
+                    const float4 m = norm16 ? ((PREC == kMlpF32 || !(u & 1)) ? mu_a : mu_b) : *reinterpret_cast<const float4 *>(mrow + kc[u]);
                     v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
                 }
             }
             dst[u] = v;
+            if (norm && !norm16) { kc[u] += kstep; if (kc[u] >= K) kc[u] -= K; }
         }
     };
     {
@@ -484,21 +495,6 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = acc[n][e];
-            if (mean && !norm16) {  // take the window mean out: - sum_k mu[row][k] * wsum[o][k]
-                size_t rr = row0 + 4 * lk + e;
-                if (rr >= B) rr = B - 1;
-                rr = row_of(rr);
-                // K % 4 == 0 (wsum_for): 16 bytes per load, all of a row's loads in flight before the first multiply-add (one value
-                // per load and wait made 2 K dependent L2 round trips per output); the sum runs in the same order
-                const float4 *mu = reinterpret_cast<const float4 *>(mean + rr * K), *ws = reinterpret_cast<const float4 *>(wsum + (size_t)(16 * n + li) * K);
-                float corr = 0.f;
-#pragma unroll 4
-                for (int k = 0; k < K / 4; ++k) {
-                    const float4 m4 = mu[k], w4 = ws[k];
-                    corr = fmaf(m4.x, w4.x, corr); corr = fmaf(m4.y, w4.y, corr); corr = fmaf(m4.z, w4.z, corr); corr = fmaf(m4.w, w4.w, corr);
-                }
-                v -= corr;
-            }
             v += b1[16 * n + li];
             if (relu1 && v < 0.f) v = 0.f;
             h1[(4 * lk + e) * (N1P + 1) + 16 * n + li] = v;

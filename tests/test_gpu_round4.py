@@ -585,3 +585,24 @@ def test_window_logits_with_a_frame_beyond_the_f16_range(ra, ctx):
     tol = 2e-5 * np.maximum(np.abs(ref), 1e6)
     assert (np.abs(got - ref)[inside] <= tol[inside]).all() and not np.array_equal(got[inside], clean[inside])
     assert ctx.last_mlp_kernel() != ""
+
+
+@pytest.mark.parametrize("K,L,hidden,nf", [(8, 120, (32, 16), 300), (12, 70, (20,), 160), (20, 50, (65, 32), 130), (4, 200, (13,), 260)])
+def test_window_logits_other_mfcc_sizes(ra, ctx, K, L, hidden, nf):
+    """The same for mfcc sizes other than 16 (mlp_mfma_kernel with the rows read in place: the window's own mean leaves each feature as
+    it is loaded, its place in the frame carried from k-group to k-group): offsets ten times the spread, gate 1e-5 of the centred spread."""
+    rng = np.random.default_rng(K * 100 + L)
+    ws, bs = _window_model(rng, L, K, hidden, 2)
+    model = ra.Model(ctx, ws, bs)
+    S = 2
+    off = rng.uniform(-30.0, 30.0, K).astype(np.float32)
+    drift = np.linspace(0.0, 1.0, nf)[None, :, None] * rng.uniform(-6.0, 6.0, (S, 1, K))
+    mfcc = (rng.standard_normal((S, nf, K)) * rng.uniform(0.5, 2.0, (S, 1, 1)) + off + drift).astype(np.float32)
+    got = ctx.mlp_forward_windows(mfcc, model)
+    ref = _window_logits_oracle(mfcc, L, ws, bs).astype(np.float64)
+    spread = max(np.abs(mfcc[s0, w:w + L] - mfcc[s0, w:w + L].mean(axis=0)).max() for s0 in range(S) for w in range(0, nf - L + 1, 16))
+    tol = 1e-5 * np.maximum(np.abs(ref), spread)
+    assert got.shape == ref.shape and (np.abs(got - ref) <= tol).all(), float((np.abs(got - ref) / tol).max())
+    strict = ctx.mlp_forward_windows(mfcc, model, precision="f32_strict")
+    assert (np.abs(strict - ref) <= tol).all()
+    assert ctx.mlp_forward_windows(mfcc, model).tobytes() == got.tobytes()

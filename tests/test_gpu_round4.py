@@ -606,3 +606,31 @@ def test_window_logits_other_mfcc_sizes(ra, ctx, K, L, hidden, nf):
     strict = ctx.mlp_forward_windows(mfcc, model, precision="f32_strict")
     assert (np.abs(strict - ref) <= tol).all()
     assert ctx.mlp_forward_windows(mfcc, model).tobytes() == got.tobytes()
+
+
+def test_window_logits_edges(ra, ctx):
+    """rp_mlp_forward_windows at its edges: a stream shorter than one window gives no rows; exactly one window; a model input that is not
+    a whole number of frames of the given mfcc size is refused with the reference's words; device pointers give the same bits as host ones."""
+    import torch
+    K, L = 16, 40
+    rng = np.random.default_rng(3)
+    ws, bs = _window_model(rng, L, K, (20, 10), 2)
+    model = ra.Model(ctx, ws, bs)
+    assert ctx.mlp_forward_windows(np.zeros((2, L - 1, K), np.float32), model).shape == (2, 0, 2)
+    one = rng.standard_normal((3, L, K)).astype(np.float32)
+    got = ctx.mlp_forward_windows(one, model)
+    ref = _window_logits_oracle(one, L, ws, bs)
+    assert got.shape == (3, 1, 2) and np.allclose(got, ref, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ra.RustpotterError, match="mfcc size"):
+        ctx.mlp_forward_windows(np.zeros((1, 100, 7), np.float32), model)
+    many = rng.standard_normal((5, 300, K)).astype(np.float32)
+    host = ctx.mlp_forward_windows(many, model)
+    dctx = ra.BatchContext(device=0, host_pointers=False)
+    dmodel = ra.Model(dctx, ws, bs)
+    x = torch.from_numpy(many).cuda()
+    out = torch.empty((5, 300 - L + 1, 2), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    L_ = ra.load_library()
+    assert L_.rp_mlp_forward_windows(dctx._h, dmodel._h, x.data_ptr(), 5, 300, K, 0, out.data_ptr()) == 0
+    dctx.synchronize()
+    assert out.cpu().numpy().tobytes() == host.tobytes()

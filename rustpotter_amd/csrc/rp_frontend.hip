@@ -204,8 +204,8 @@ __global__ __launch_bounds__(64) void apply_filters_kernel(const TIN *__restrict
 // streams); the feed-forward half of the biquad and the gain moved into the time-major decode (DPP neighbours, bit-exact) so
 // that the walk keeps 4 instructions per sample -- the decode side then is the long one: 4.1 ms at 2 048 streams with two or four
 // waves, 7.4 ms at 65 536.  The two sides are balanced as they are; only less work per sample on both would lower the floor.
-template <class TIN, bool GAIN, bool BP, int T, int W, bool FULL>
-__global__ __launch_bounds__(64 * W) void apply_filters_lines_kernel(const TIN *__restrict__ pcm, size_t S, size_t wg0, size_t n_samples,
+template <class TIN, bool GAIN, bool BP, int T, int W>
+__global__ __launch_bounds__(64 * W) void apply_filters_lines_kernel(const TIN *__restrict__ pcm, size_t S, size_t n_samples,
                                                                      size_t n_chunks, size_t pcm_stride, const float *__restrict__ gains,
                                                                      BiquadCoef q, float *__restrict__ out, size_t out_stride) {
     constexpr int G = T / 4, RPM = 64 / G, PITCH = T + 4, kMoves = G, BLK = 4, HALF = kMoves / 2;
@@ -214,7 +214,10 @@ __global__ __launch_bounds__(64 * W) void apply_filters_lines_kernel(const TIN *
     __shared__ float carry[W > 1 ? 4 : 1][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const size_t s0 = (wg0 + blockIdx.x) * 64, s = s0 + lane;
+    const size_t s0 = (size_t)blockIdx.x * 64, s = s0 + lane;
+    // the last workgroup may hold fewer than 64 streams: its loads clamp the row, its stores test it (one launch: a second one for that
+    // workgroup alone would add a whole stream's 3 ms to the call)
+    const bool FULL = s0 + 64 <= S;   // workgroup-uniform
     const bool live = FULL || s < S;
     const size_t valid = n_chunks * kFrame, n_tiles = (valid + T - 1) / T;
     const unsigned rows_here = FULL ? 64u : (unsigned)(S - s0);
@@ -356,16 +359,9 @@ static hipError_t launch_frontend_t(hipStream_t st, const TIN *pcm, size_t S, si
     if (vec4 && pcm_stride < (1u << 29) && out_stride < (1u << 29)) {  // 32-bit lane offsets inside a wave's rows
         // 64-sample tiles, two waves per 64 streams taking turns; RP_FRONTEND_TILE=128 = one wave on 128-sample tiles (A/B)
         static const int tlen = getenv("RP_FRONTEND_TILE") ? atoi(getenv("RP_FRONTEND_TILE")) : 64;
-        const size_t full = S / 64;
 #define RP_LINES(G, B, T, W)                                                                                                            \
-    do {                                                                                                                                \
-        if (full)                                                                                                                       \
-            hipLaunchKernelGGL((apply_filters_lines_kernel<TIN, G, B, T, W, true>), dim3((unsigned)full), dim3(64 * W), 0, st, pcm, S,  \
-                               (size_t)0, n_samples, n_chunks, pcm_stride, gains, q, out, out_stride);                                  \
-        if (S % 64)                                                                                                                     \
-            hipLaunchKernelGGL((apply_filters_lines_kernel<TIN, G, B, T, W, false>), dim3(1), dim3(64 * W), 0, st, pcm, S, full,        \
-                               n_samples, n_chunks, pcm_stride, gains, q, out, out_stride);                                             \
-    } while (0)
+    hipLaunchKernelGGL((apply_filters_lines_kernel<TIN, G, B, T, W>), dim3((unsigned)((S + 63) / 64)), dim3(64 * W), 0, st, pcm, S,     \
+                       n_samples, n_chunks, pcm_stride, gains, q, out, out_stride)
 #define RP_TILED(G, B)                                                                                                                  \
     do {                                                                                                                                \
         if (tlen == 128) RP_LINES(G, B, 128, 1);                                                                                        \

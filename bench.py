@@ -114,13 +114,15 @@ def main():
     ap.add_argument("--template-len", type=int, default=100)
     ap.add_argument("--mfcc-size", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model-type", choices=["tiny", "small", "medium", "large"], default="small", help="--mode model: layer widths of wakeword_nn.rs:305-389 for 195 frames x 16 coefficients")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement: no vector_only / extra_configs / h2d_included blocks")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default=None,
                     help="BASELINE.json presets: C2 = 1 024 streams x 8 templates; C3 = 65 536 x 8 (the default workload); C4 = 65 536 streams x 64 "
                          "templates SPLIT over the --gpus ranks (strong scaling, RCCL gather of the per-stream results); C5 = --mode mlp")
-    ap.add_argument("--mode", choices=["dtw", "mlp", "stream", "resample"], default="dtw",
+    ap.add_argument("--mode", choices=["dtw", "mlp", "stream", "resample", "model"], default="dtw",
                     help="dtw: the headline MFCC+DTW path (default); mlp: BASELINE config C5, wakeword-model forward; "
+                         "model: the wakeword-MODEL detector over whole streams (rp_batch_detect_model, --model-type); "
                          "stream: the same path fed --chunks-per-call 30 ms chunks per call (rp_stream_batch_process); "
                          "resample: 48 kHz -> 16 kHz front-end alone (rp_resample_batch)")
     ap.add_argument("--ingest", action="store_true", help="the headline path with the PCM starting in pinned HOST memory: streams in blocks of "
@@ -184,6 +186,8 @@ def main():
     env = Env(args, ra, torch, dist, dev, world, rank, local_rank, backend)
     if args.mode == "mlp":
         res = bench_mlp(env)
+    elif args.mode == "model":
+        res = bench_model(env)
     elif args.mode == "stream":
         res = bench_stream(env)
     elif args.mode == "resample":
@@ -784,22 +788,23 @@ def _timed(env, call, warmup, steps):
     return (time.perf_counter() - t0) / steps
 
 
-def extra_model_detector(env, S=8192):
+def model_detector_measure(env, S, m_type, warmup, steps):
     """The wakeword-MODEL detector over whole streams (rp_batch_detect_model: MFCC of mfcc_size 16 -> every window of 195 frames through
-    the Small model of config C5 -> scores -> detection state machine), SURVEY 8a row a17 in the form the detector runs it."""
+    the model -> scores -> detection state machine), SURVEY 8a row a17 in the form the detector runs it."""
     import ctypes as C
     import numpy as np
     ra, torch, dev = env.ra, env.torch, env.dev
     N, F, K = 64000, 195, 16
-    dims = [F * K, F // 6, F // 12, 2]
+    dims = {"tiny": [F * K, F // 15, 2], "small": [F * K, F // 6, F // 12, 2], "medium": [F * K, F // 3, F // 6, 2],
+            "large": [F * K, F // 3 * 2, F // 6, 2]}[m_type]
     rng = np.random.default_rng(5)
-    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(3)]
-    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+    ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [(rng.standard_normal(dims[i + 1]) * 0.1).astype(np.float32) for i in range(len(dims) - 1)]
     ctx = ra.BatchContext(device=env.local_rank, host_pointers=False)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     model = ra.Model(ctx, ws, bs)
     pcm = torch.empty((S, N), dtype=torch.float32, device=dev)
-    ctx.synth_dev(SEED, 0, S, N, N, pcm.data_ptr())
+    ctx.synth_dev(SEED, env.rank * S, S, N, N, pcm.data_ptr())
     det = torch.zeros((S, 4, 6), dtype=torch.int32, device=dev)
     lab = torch.zeros((S, 4), dtype=torch.int32, device=dev)
     n_det = torch.zeros((S,), dtype=torch.int32, device=dev)
@@ -810,15 +815,60 @@ def extra_model_detector(env, S=8192):
 
     def call():
         if L.rp_batch_detect_model(ctx._h, pcm.data_ptr(), 3, S, N, N, model._h, K, 0, C.byref(c), 0, det.data_ptr(), lab.data_ptr(), n_det.data_ptr(), 4) != 0:
-            raise RuntimeError(ra.last_error() if hasattr(ra, "last_error") else "rp_batch_detect_model failed")
-    dt = _timed(env, call, 2, 10)
+            raise RuntimeError("rp_batch_detect_model failed")
+    for _ in range(warmup):
+        call()
+    env.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    env.fence()
+    dt = env.max_over_ranks(time.perf_counter() - t0) / steps
+    ctx.timing_enable(True)
+    ctx.timing_reset()
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    k_ms = {"mfcc": ctx.timing_read(0)[0], "forward": ctx.timing_read(4)[0]}   # averages over the three timed calls (one timed region per call each)
+    ctx.timing_enable(False)
     n_win = ra.mfcc_num_frames(N) - F + 1
-    flops = S * n_win * 2.0 * (dims[0] * dims[1] + dims[1] * dims[2] + dims[2] * dims[3])
-    return {"workload": "%d synthetic 4 s streams, Small model 3120->32->16->2 on every window of 195 frames x 16 coefficients (%d windows per stream), f32 callers" % (S, n_win),
-            "value": S * n_win / dt, "unit": "window scorings/s", "steps": 10, "warmup": 2, "ms_per_step": dt * 1e3,
-            "dtype": "f32 (layer-1 products: f16x2-split MFMA, 22-bit)", "kernel": ctx.last_mlp_kernel(),
-            "algorithmic_model_flop_rate_tflops": flops / dt / 1e12,
-            "note": "kernel split and PMC of the forward: profiles/r04_model_detect.txt"}
+    d1p = -(-dims[1] // 32) * 32
+    # executed matrix work of layer 1: three f16 products per feature and output (x0 w0 + x1 w0 + x0 w1), outputs padded to tiles of 32,
+    # windows to tiles of 32 rows
+    rows_exec = S * (-(-n_win // 32) * 32)
+    return {"dims": dims, "n_win": n_win, "dt": dt, "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()}, "kernel": ctx.last_mlp_kernel(),
+            "algorithmic_flops": S * n_win * 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)),
+            "executed_matrix_flops": rows_exec * 2.0 * 3 * dims[0] * d1p}
+
+
+def extra_model_detector(env, S=8192):
+    m = model_detector_measure(env, S, "small", 2, 10)
+    return {"workload": "%d synthetic 4 s streams, Small model %s on every window of 195 frames x 16 coefficients (%d windows per stream), f32 callers"
+                        % (S, "->".join(map(str, m["dims"])), m["n_win"]),
+            "value": S * m["n_win"] / m["dt"], "unit": "window scorings/s", "steps": 10, "warmup": 2, "ms_per_step": m["dt"] * 1e3,
+            "dtype": "f32 (layer-1 products: f16x2-split MFMA, 22-bit)", "kernel": m["kernel"], "kernels_ms": m["kernels_ms"],
+            "roofline": {"bound": "mfma", "kernel": "the forward (mlp_windows_kernel)", "achieved": m["executed_matrix_flops"] / (m["kernels_ms"]["forward"] * 1e-3) / 1e12,
+                         "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": m["executed_matrix_flops"] / (m["kernels_ms"]["forward"] * 1e-3) / MFMA_F16_PEAK,
+                         "note": "executed f16 matrix flops (three split products, padded tiles) over the forward's launch time; PMC and the clock under this load: profiles/r04_model_detect.txt"}}
+
+
+def bench_model(env):
+    args, world = env.args, env.world
+    S = args.streams if args.streams else 8192
+    m = model_detector_measure(env, S, args.model_type, args.warmup, args.steps)
+    config = {"workload": "wakeword-model detector: %d synthetic 4 s streams per GPU, %s model %s on every window of 195 frames x 16 coefficients (%d windows per stream)"
+                          % (S, args.model_type, "->".join(map(str, m["dims"])), m["n_win"])}
+    config.update(env.common_config())
+    fwd_s = m["kernels_ms"]["forward"] * 1e-3
+    return {"metric": "wakeword-model window scorings/sec (rp_batch_detect_model)", "value": S * world * m["n_win"] / m["dt"], "unit": "window scorings/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["dt"] * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (layer-1 products: f16x2-split MFMA, 22-bit)", "data": "synthetic", "config": config,
+            "kernels_ms": m["kernels_ms"], "kernel": m["kernel"],
+            "roofline": {"bound": "mfma", "kernel": "the forward (%s)" % m["kernel"].split("<")[0], "achieved": m["executed_matrix_flops"] / fwd_s / 1e12,
+                         "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": m["executed_matrix_flops"] / fwd_s / MFMA_F16_PEAK, "traffic": None,
+                         "algorithmic_flop_rate_tflops": m["algorithmic_flops"] / m["dt"] / 1e12,
+                         "note": "executed f16 matrix flops (three split products per layer-1 product, outputs and windows padded to tiles of 32) over the forward's "
+                                 "launch time (HIP events on the launch stream); the clock holds ~1.8 GHz under this kernel: profiles/r04_model_detect.txt"}}
 
 
 def extra_front_end(env, S=65536):

@@ -75,7 +75,8 @@ names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk
          "median": "bench_%s_median" % R, "gate_default": "bench_%s_avg_gate_default" % R, "gate_default_full": "bench_%s_avg_gate_default_full_scores" % R,
          "gate_04": "bench_%s_avg_gate_04" % R, "gate_04_full": "bench_%s_avg_gate_04_full_scores" % R,
          "two_ranks_one_gpu": "bench_%s_two_ranks_one_gpu_dry_run" % R, "detect_only": "bench_%s_detect_only" % R,
-         "detect_only_ragged5": "bench_%s_detect_only_ragged5" % R, "ingest_f32": "bench_%s_ingest_f32" % R, "ingest_i16": "bench_%s_ingest_i16" % R}
+         "detect_only_ragged5": "bench_%s_detect_only_ragged5" % R, "model_small": "bench_%s_model_detector_small" % R, "model_medium": "bench_%s_model_detector_medium" % R, "model_large": "bench_%s_model_detector_large" % R,
+         "ingest_f32": "bench_%s_ingest_f32" % R, "ingest_i16": "bench_%s_ingest_i16" % R}
 for a, b in names.items():
     src = "gpurun_out/final/%s.json" % a
     if os.path.exists(src) and os.path.getsize(src) > 10:

@@ -31,6 +31,7 @@ $B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_
 $B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13.json
+for m in small medium large; do python3 bench.py --mode model --model-type $m --streams 32768 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $O/model_$m.json; done
 python3 bench.py --ingest --ingest-format f32 --no-cpu-baseline 2>/dev/null | line > $O/ingest_f32.json
 python3 bench.py --ingest --ingest-format i16 --no-cpu-baseline 2>/dev/null | line > $O/ingest_i16.json
 bash tools/r4_c2_rounds.sh > $O/c2_rounds.txt 2>/dev/null

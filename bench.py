@@ -103,6 +103,36 @@ def n_simds(torch, dev):
     return 4 * torch.cuda.get_device_properties(dev).multi_processor_count
 
 
+ROOFLINE_FIRST = ("bound", "kernel", "frac", "frac_at_architectural_rates", "achieved", "peak", "unit", "avg_launch_ms", "traffic", "traffic_over_algorithmic",
+                  "effective_clock_ghz", "valu_issue_frac_at_effective_clock", "strict_f32_value", "strict_f32_ms_per_step", "strict_f32_steps",
+                  "strict_f32_mfcc_ms", "strict_f32_dtw_ms", "strict_f32_aggregate_ms", "path_hbm_frac", "path_ref_flop_rate_vs_vector_peak",
+                  "mfcc_ms", "dtw_ms", "aggregate_ms", "scan_ms", "algorithmic_bytes_per_launch", "ref_flop_rate_vs_vector_peak")
+
+
+def order_for_the_record(res):
+    """The driver's record of a line keeps a bounded number of scalar entries of `roofline` and `config` (round 4: 23 of roofline's,
+    nested blocks dropped, strings cut): the numbers a reader needs come first, as scalars; blocks and notes follow."""
+    r = res.get("roofline")
+    if isinstance(r, dict):
+        km = r.get("kernels_ms") or {}
+        for k in ("mfcc", "dtw", "aggregate", "scan"):
+            if k in km:
+                r[k + "_ms"] = km[k]
+        scal = {k: r[k] for k in ROOFLINE_FIRST if k in r}
+        rest_s = {k: v for k, v in r.items() if k not in scal and not isinstance(v, (dict, list, str))}
+        rest_o = {k: v for k, v in r.items() if k not in scal and isinstance(v, (dict, list, str))}
+        res["roofline"] = {**scal, **rest_s, **rest_o}
+    c = res.get("config")
+    if isinstance(c, dict):
+        first = {k: c[k] for k in ("workload",) if k in c}
+        flat = {k: v for k, v in c.items() if k.endswith(("_value", "_frac"))}
+        other = {k: v for k, v in c.items() if k not in first and k not in flat}
+        scal = {k: v for k, v in other.items() if not isinstance(v, (dict, list))}
+        blocks = {k: v for k, v in other.items() if isinstance(v, (dict, list))}
+        res["config"] = {**first, **flat, **scal, **blocks}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +227,7 @@ def main():
     else:
         res = bench_dtw(env)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(order_for_the_record(res)))
     if world > 1:
         dist.destroy_process_group()
 
@@ -259,7 +289,7 @@ def cells(Lt, W=5):
     return sum((min(Lt, r + W - 1) - max(1, r - W) + 1) for r in range(1, Lt))
 
 
-def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw):
+def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
     """Pipe fractions of the DTW kernel of one launch (S x n_win windows x templates `lens`) that took dtw_s seconds.
     valu_issue: SIMD issue cycles of the hot loop (committed ISA mix x rate table) x trips / (SIMDs x 2.4 GHz); mfma_f16: executed
     matrix flops / 2.5 PFLOP/s; hbm: algorithmic bytes / 8 TB/s; valu_flops (kernels without a committed mix): executed vector flops /
@@ -273,6 +303,11 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw):
     mfma_wide = mfma_on and K in (13, 16) and all(c >= 3 for c in by_len.values())
     mfma_used = mfma_wide or (mfma_on and K == 5 and any(c >= 3 for c in by_len.values()))
     kernel = "dtw_mfma_wide_kernel" if mfma_wide else "dtw_mfma_kernel" if mfma_used else "dtw_band_kernel" if K == 5 else "dtw_band_wide_kernel"
+    # templates whose length occurs once or twice: dtw_ragged_kernel when the library says it ran (rp_ctx_dtw_kernels)
+    rag_lens = [Lt for Lt, c in by_len.items() for _ in range(c if c <= 2 else (c % 8 if c % 8 <= 2 else 0))] if K == 5 else []
+    ragged = bool(ran) and "dtw_ragged_kernel" in ran and bool(rag_lens)
+    if ragged and not mfma_used:
+        kernel = "dtw_ragged_kernel"
     f_dtw_ref = sum(cells(Lt) * (2 * K + 7) + 2 * Lt * 2 * K + 2 * Lt * K for Lt in lens)   # SURVEY 8d, reference-shaped
     f_exec_vec = sum((Lt - 1) * 2 * W * (2 * K + 3) for Lt in lens) + sum(-(-c // 8) * ((Lt - 1) * (4 * K + 1) + Lt * K) for Lt, c in by_len.items())
     f_exec_mat = 0.0
@@ -287,6 +322,11 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw):
         ksteps = 4 if K == 16 else 3
         f_exec_mat = sum(-(-c // 8) * 3 * ksteps * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
         f_exec_vec = sum(c * Lt * 2 * W * 3 + -(-c // 8) * Lt * 8 * K for Lt, c in by_len.items())
+    if ragged:
+        # per window and column: two v_mfma_f32_32x32x16_f16 per 64 windows, and 3 vector ops per band cell + the norm + the mean term
+        f_exec_mat += sum((Lt + 1) * 2 * 32768 / 64.0 for Lt in rag_lens)
+        if not mfma_used:
+            f_exec_vec = sum(Lt * (2 * W * 4 + 15 + 2 * K) for Lt in rag_lens)
     alg_bytes = rows * (4 * K + 4 * (T + 2))
     pipes = {"hbm": alg_bytes / dtw_s / HBM_PEAK, "mfma_f16": rows * f_exec_mat / dtw_s / MFMA_F16_PEAK}
     extra = {}
@@ -298,9 +338,23 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw):
         trips = sum(mfma_chunks(c)[0] * Lt / 12.0 for Lt, c in by_len.items()) * tiles
         cyc = trips * mix["valu_issue_cycles_per_trip"]
         pipes["valu_issue"] = cyc / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        if "valu_issue_cycles_per_trip_architectural" in mix:   # the same mix at 2 / 4 / 8 cycles per instruction instead of the measured rates
+            extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r04_dtw_mfma_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
                                                                                                          mix["valu_issue_cycles_per_trip"])})
+    elif ragged and not mfma_used and n_win >= 64 and load_json("profiles/r05_dtw_ragged_isa_mix.json"):
+        mix = load_json("profiles/r05_dtw_ragged_isa_mix.json")
+        # the hot loop is one block of 16 columns of one template for the 64 windows of a wave
+        trips = sum(Lt / 16.0 for Lt in rag_lens) * -(-rows // 64)
+        cyc = trips * mix["valu_issue_cycles_per_trip"]
+        pipes["valu_issue"] = cyc / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        pipes["lds"] = trips * mix["lds_cycles_per_trip"] / (n_simds(torch, env.dev) / 4 * CLOCK_PEAK * dtw_s)
+        if "valu_issue_cycles_per_trip_architectural" in mix:
+            extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r05_dtw_ragged_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
+                      "instructions, %.0f SIMD issue cycles per 16-column block of one template for the 64 windows of a wave" % (
+                          mix["classes"]["valu"], mix["classes"]["mfma"], mix["valu_issue_cycles_per_trip"])})
     else:
         pipes["valu_flops"] = rows * f_exec_vec / dtw_s / VALU_PEAK
     if pmc_dtw and "effective_clock_ghz" in pmc_dtw and "valu_issue" in pipes:
@@ -322,8 +376,8 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw):
         r.update({"achieved": rows * f_exec_vec / dtw_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s"})
     r.update(extra)
     r["note"] = ("frac = the largest pipe fraction of the kernel; every entry of `pipes` is executed work / (pipe peak x measured launch time).  "
-                 "dtw_mfma_kernel forms the cosine costs of a band column with v_mfma_f32_32x32x16_f16 (f16 two-way splits of both operands, "
-                 "f32 accumulate) and runs the min-recurrence on the vector pipe: VALU issue binds it.  ref_flop_rate_vs_vector_peak prices the "
+                 "dtw_mfma_kernel / dtw_ragged_kernel form the cosine products of a band column with v_mfma_f32_32x32x16_f16 (f16 two-way splits of both operands, "
+                 "f32 accumulate) and run the min-recurrence on the vector pipe: VALU issue binds them.  ref_flop_rate_vs_vector_peak prices the "
                  "REFERENCE-shaped flop count (SURVEY 8d: 2K+7 flops per band cell) against the 157.3 TFLOP/s vector peak as earlier rounds' `frac` "
                  "did -- it exceeds 1 because those products left the vector pipe, it is not a fraction of a roof")
     return r
@@ -339,6 +393,8 @@ def mfcc_kernel_model(env, S, nf, K, mfcc_s, pmc_mfcc=None):
         trips = S * nf / 4.0   # one trip of the tile loop = 4 frames of one wave
         pipes["valu_issue"] = trips * mix["valu_issue_cycles_per_trip"] / (n_simds(torch, env.dev) * CLOCK_PEAK * mfcc_s)
         pipes["lds"] = trips * mix["lds_cycles_per_trip"] / (n_simds(torch, env.dev) / 4 * CLOCK_PEAK * mfcc_s)
+        if "valu_issue_cycles_per_trip_architectural" in mix:
+            extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * mfcc_s)
         extra["isa_mix"] = ("profiles/r04_mfcc_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d LDS instructions, %.0f SIMD issue cycles and %d "
                             "LDS-array cycles per 4-frame tile of a wave" % (mix["classes"]["valu"], mix["classes"]["lds"], mix["valu_issue_cycles_per_trip"],
                                                                              mix["lds_cycles_per_trip"]))
@@ -465,13 +521,17 @@ def bench_dtw(env):
 
     # final per-stream result gather (RCCL over xGMI); shards of a fixed stream set may differ by one stream
     gather_ms = []
+    gathered = [None]
 
     def gather():
         if world == 1:
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        _ = sharding.gather_per_stream(case.n_det, world) if first_stream is None else sharding.gather_ragged(case.n_det, world)
+        # the per-stream result block, T + 2 floats per stream (best score per template, best aggregate, detections);
+        # detect-only / gated runs have no score arrays: their block is the detection count alone
+        block = sharding.stream_summary(case.scores, case.agg, case.n_det) if case.want_arrays else case.n_det
+        gathered[0] = sharding.gather_per_stream(block, world) if first_stream is None else sharding.gather_ragged(block, world)
         b.record()
         gather_ms.append((a, b))
 
@@ -480,10 +540,13 @@ def bench_dtw(env):
     value = scorings_per_step * args.steps / dt
 
     # ---- rooflines, measured live with HIP events on the launch stream (rp_ctx_timing_*: one event pair per launch)
+    case.ctx.dtw_kernels()
     k_ms = case.kernel_times(max(2, min(args.steps, 5)))
+    ran = case.ctx.dtw_kernels()   # the DTW kernel families those calls launched (rp_ctx_dtw_kernels)
     pmc, pmc_src = pmc_for(S, N, T, L, K, lens, args)
     dtw_s, mfcc_s = k_ms["dtw"][0] * 1e-3, k_ms["mfcc"][0] * 1e-3
-    r_dtw = dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc.get("dtw"))
+    r_dtw = dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc.get("dtw"), ran)
+    r_dtw["dtw_kernels_launched"] = ", ".join(ran)
     r_mfcc = mfcc_kernel_model(env, S, nf, K, mfcc_s, pmc.get("mfcc"))
     for r, kn in ((r_dtw, "dtw"), (r_mfcc, "mfcc")):
         r["launches_timed"] = k_ms[kn][1]
@@ -520,7 +583,7 @@ def bench_dtw(env):
     tag = {(65536, 8): "C3", (8192, 64): "C4 (per-GPU share)", (1024, 8): "C2"}.get((S, T), "custom") if len(set(lens)) == 1 and lens[0] == 100 else "custom"
     if args.total_streams is not None:
         tag = "C4"
-    mfma_kernel = "mfma" in r_dtw["kernel"]
+    mfma_kernel = "mfma" in r_dtw["kernel"] or "ragged" in r_dtw["kernel"]
     config = {"workload": "%s: %s synthetic 16 kHz f32 streams x %d templates%s (%g s streams, L=%s, K=%d, band 5, "
                           "ScoreMode::%s, %s)" % (tag, ("%d" % S) if args.total_streams is None else ("%d" % args.total_streams), T,
                                                   " per GPU" if args.total_streams is None else " split over %d rank(s) by stream" % world,
@@ -532,13 +595,17 @@ def bench_dtw(env):
                                                                                           "any more are abandoned" if args.detect_only else ""))),
               "streams_per_gpu": S, "templates": T, "samples_per_stream": N, "frames_per_stream": nf,
               "windows_per_stream": n_win, "template_chunks": n_chunks,
-              "parallelism": "streams sharded x%d, RCCL all_gather of detections" % world}
+              "parallelism": "streams sharded x%d, RCCL all_gather of the per-stream result block (T + 2 floats)" % world}
     config.update(env.common_config())
     if world > 1:
         torch.cuda.synchronize()
         g = [a.elapsed_time(b) for a, b in gather_ms[args.warmup:]]
-        config["gather_ms_per_step"] = {"mean": sum(g) / len(g), "max": max(g), "what": "all_gather of the per-stream detection counts, HIP events on the "
-                                        "launch stream around the collective (every step; the first %d are warm-up)" % args.warmup}
+        rows, cols = gathered[0].shape[0], (gathered[0].shape[1] if gathered[0].dim() > 1 else 1)
+        config["gather_ms_per_step"] = {"mean": sum(g) / len(g), "max": max(g), "what": "per-stream result block (best score per template over the stream's "
+                                        "windows, best aggregate, detections: T + 2 floats) reduced from the score arrays and all_gathered, HIP events on the "
+                                        "launch stream around both (every step; the first %d are warm-up)" % args.warmup,
+                                        "gathered_shape": [rows, cols], "bytes_sent_per_gpu": int(rows // world * cols * 4), "bytes_total": int(rows * cols * 4)}
+        assert rows == (S * world if args.total_streams is None else args.total_streams), "the gather must return every stream of the job"
     out = {
         "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -573,19 +640,31 @@ def bench_dtw(env):
         del mf, sc_, av_, ag_
 
     plain = world == 1 and not work_skipped and not args.avg_gate and len(set(lens)) == 1 and not args.no_extras
-    # ---- the same step with the cosine products on the vector pipe (the register kernels): what "f32" in the strict sense costs
-    if plain and mfma_kernel:
+    # ---- the same step with the cosine products on the vector pipe (the register kernels): what "f32" in the strict sense costs.  Same
+    # step count as the headline (at least 10); the scalars sit inside `roofline`, which the driver's record keeps
+    if world == 1 and not work_skipped and not args.avg_gate and mfma_kernel and not args.no_extras:
+        steps_v = max(10, args.steps)
         os.environ["RP_DTW_MFMA"] = "0"   # read per call by the library
+        rag = os.environ.pop("RP_DTW_RAGGED", None)
         try:
-            dtv = case.time_steps(1, 2)
-            kv = case.kernel_times(2)
+            dtv = case.time_steps(2, steps_v)
+            kv = case.kernel_times(3)
         finally:
             del os.environ["RP_DTW_MFMA"]
-        out["vector_only"] = {"what": "RP_DTW_MFMA=0: every DTW kernel of the register family (dtw_band_kernel: the five multiply-adds of a cell as "
-                                      "v_pk_fma_f32), 2 steps", "dtype": DTYPE_DTW_VECTOR, "value": S * n_win * 2 / dtv, "unit": "scorings/s",
-                              "ms_per_step": dtv / 2 * 1e3, "kernels_ms": {k: round(v[0], 4) for k, v in kv.items()},
-                              "executed_vector_flop_frac": S * n_win * (sum((Lt - 1) * 10 * (2 * K + 3) for Lt in lens) + n_chunks * ((L - 1) * (4 * K + 1) + L * K)) /
-                              (kv["dtw"][0] * 1e-3) / VALU_PEAK}
+            if rag is not None:
+                os.environ["RP_DTW_RAGGED"] = rag
+        strict = {"what": "RP_DTW_MFMA=0: every DTW kernel of the register family (dtw_band_kernel: the five multiply-adds of a cell as "
+                          "v_pk_fma_f32; every product, sum and norm in f32)", "dtype": DTYPE_DTW_VECTOR, "value": S * n_win * steps_v / dtv, "unit": "scorings/s",
+                  "steps": steps_v, "ms_per_step": dtv / steps_v * 1e3, "kernels_ms": {k: round(v[0], 4) for k, v in kv.items()},
+                  "executed_vector_flop_frac": S * n_win * (sum((Lt - 1) * 10 * (2 * K + 3) for Lt in lens) + n_chunks * ((L - 1) * (4 * K + 1) + L * K)) /
+                  (kv["dtw"][0] * 1e-3) / VALU_PEAK}
+        out["vector_only"] = strict
+        roofline["strict_f32"] = strict
+        roofline.update({"strict_f32_value": strict["value"], "strict_f32_ms_per_step": strict["ms_per_step"], "strict_f32_steps": steps_v,
+                         "strict_f32_mfcc_ms": strict["kernels_ms"]["mfcc"], "strict_f32_dtw_ms": strict["kernels_ms"]["dtw"],
+                         "strict_f32_aggregate_ms": strict["kernels_ms"]["aggregate"]})
+    roofline["path"] = {"hbm_frac": roofline["path_hbm_frac"], "ref_flop_rate_vs_vector_peak": roofline["path_ref_flop_rate_vs_vector_peak"],
+                        "bytes_per_scoring": 640 + 4 * (T + 2), "ref_flops_per_scoring": 13.2e3 * nf / n_win + f_dtw_ref}
 
     # ---- CPU baseline: the oracle's restatement of the reference algorithm on this host's cores
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.avg_gate and len(set(lens)) == 1:
@@ -610,7 +689,20 @@ def bench_dtw(env):
                 extras[name] = fn(env)
             except Exception as e:
                 extras[name] = {"error": repr(e)}
+        try:
+            extras["C4_share"] = extra_c4_share(env, K, N)
+        except Exception as e:
+            extras["C4_share"] = {"error": repr(e)}
         out["extra_configs"] = extras
+        # the other BASELINE configs where the driver's record keeps them: scalars first, then the same numbers as one block
+        oc = {}
+        for name in ("C2", "C4_share", "C5_bf16", "C5_f32"):
+            e = extras.get(name, {})
+            if "value" in e:
+                oc[name] = {"value": e["value"], "unit": e["unit"], "ms_per_step": e["ms_per_step"], "frac": e["roofline"]["frac"], "bound": e["roofline"]["bound"]}
+                config[name + "_value"] = e["value"]
+                config[name + "_frac"] = e["roofline"]["frac"]
+        config["other_configs"] = oc
         try:
             out["h2d_included"] = ingest_measure(env, case, blocks=2, block_streams=min(8192, S), fmt="f32")
         except Exception as e:
@@ -655,6 +747,25 @@ def extra_c2(env, case, lens, K, N):
             "roofline": {"bound": r["bound"], "kernel": r["kernel"], "frac": r["frac"], "pipes": r["pipes"], "note": "a launch of 9 504 tiles over 3 072 resident "
                          "waves is 3.1 rounds: the last round runs a tenth full"},
             "path_hbm_frac": S2 * case.n_win * 50 / dt * (640 + 4 * (case.T + 2)) / HBM_PEAK}
+
+
+def extra_c4_share(env, K, N):
+    """One GPU's share of BASELINE config C4 (65 536 streams x 64 templates over 8 GPUs): 8 192 streams x 64 templates."""
+    torch = env.torch
+    S4, T4 = 8192, 64
+    lens4 = [100] * T4
+    c4 = DtwCase(env, S4, lens4, K, N, first_stream=0)
+    dt = c4.time_steps(2, 10)
+    k = c4.kernel_times(3)
+    r = dtw_kernel_model(env, S4, c4.n_win, lens4, K, k["dtw"][0] * 1e-3, None)
+    res = {"workload": "C4 share: 8192 synthetic 16 kHz f32 streams x 64 templates (one GPU's part of 65 536 x 64 over 8 GPUs)",
+           "value": S4 * c4.n_win * 10 / dt, "unit": "scorings/s", "steps": 10, "warmup": 2, "ms_per_step": dt / 10 * 1e3, "dtype": DTYPE_DTW,
+           "kernels_ms": {kk: round(v[0], 4) for kk, v in k.items()},
+           "roofline": {"bound": r["bound"], "kernel": r["kernel"], "frac": r["frac"], "pipes": r["pipes"]},
+           "path_hbm_frac": S4 * c4.n_win * 10 / dt * (640 + 4 * (T4 + 2)) / HBM_PEAK}
+    del c4
+    torch.cuda.empty_cache()
+    return res
 
 
 class MlpCase:

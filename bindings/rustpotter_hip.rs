@@ -53,6 +53,13 @@ pub const RP_CTX_DEVICE_POINTERS: c_int = 0;
 pub const RP_CTX_HOST_POINTERS: c_int = 1;
 /// compare every window with every sample template even where the averaged-template gate would skip them
 pub const RP_CTX_FULL_SCORES: c_int = 2;
+pub const RP_DTW_KERNEL_MFMA: c_int = 1;
+pub const RP_DTW_KERNEL_MFMA_WIDE: c_int = 2;
+pub const RP_DTW_KERNEL_RAGGED: c_int = 4;
+pub const RP_DTW_KERNEL_REGISTER: c_int = 8;
+pub const RP_DTW_KERNEL_GENERIC: c_int = 16;
+pub const RP_DTW_KERNEL_SINGLE: c_int = 32;
+pub const RP_DTW_KERNEL_REF_ALL: c_int = 64;
 pub const RP_MLP_F32: c_int = 0;
 pub const RP_MLP_BF16: c_int = 1;
 pub const RP_MLP_F32_STRICT: c_int = 2;
@@ -104,6 +111,7 @@ extern "C" {
     pub fn rp_ctx_set_stream(ctx: *mut rp_ctx, hip_stream: *mut c_void) -> c_int;
     pub fn rp_ctx_synchronize(ctx: *mut rp_ctx) -> c_int;
     pub fn rp_ctx_dtw_ref_pairs(ctx: *mut rp_ctx, pairs: *mut u64) -> c_int;
+    pub fn rp_ctx_dtw_kernels(ctx: *mut rp_ctx) -> c_int;
     pub fn rp_ctx_last_mlp_kernel(ctx: *mut rp_ctx) -> *const c_char;
     pub fn rp_build_info() -> *const c_char;
     pub fn rp_sharded_gather_info() -> *const c_char;
@@ -373,6 +381,8 @@ impl HipContext {
         let p = unsafe { rp_ctx_last_mlp_kernel(self.h) };
         if p.is_null() { String::new() } else { unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned() }
     }
+    /// mask of `RP_DTW_KERNEL_*`: the DTW kernel families launched since the last call
+    pub fn dtw_kernels(&self) -> u32 { unsafe { rp_ctx_dtw_kernels(self.h) as u32 } }
     /// (window, templates) pairs rescored with the reference-shaped cosine (`sqrt(dot_a * dot_b)`, src/mfcc/comparator.rs:28-48) so far
     pub fn dtw_ref_pairs(&self) -> Result<u64, String> {
         let mut v: u64 = 0;

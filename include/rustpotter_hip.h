@@ -191,6 +191,19 @@ int rp_ctx_synchronize(rp_ctx *ctx);
  * of pairs rescored that way by this context's DTW calls since it was made (waits for the context's stream); 0 for audio
  * in any ordinary range. */
 int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs);
+/* Diagnostics of the DTW dispatch (replaces nothing; src/mfcc/dtw.rs:56-105 is what every family computes): the kernel families this
+ * context's DTW calls launched since the last call of this function, as a mask of RP_DTW_KERNEL_* (then cleared).  Tests and bench.py use
+ * it to name the kernel a measurement belongs to. */
+enum {
+    RP_DTW_KERNEL_MFMA = 1,      /* dtw_mfma_kernel: chunks of 3..8 same-length templates, mfcc_size 5, cosines on the matrix cores */
+    RP_DTW_KERNEL_MFMA_WIDE = 2, /* dtw_mfma_wide_kernel: mfcc_size 13 / 16 */
+    RP_DTW_KERNEL_RAGGED = 4,    /* dtw_ragged_kernel: templates of unequal length on the matrix cores, mfcc_size 5 */
+    RP_DTW_KERNEL_REGISTER = 8,  /* dtw_band_kernel / dtw_band2_kernel / dtw_band_wide_kernel: f32 vector arithmetic throughout */
+    RP_DTW_KERNEL_GENERIC = 16,  /* dtw_generic_kernel */
+    RP_DTW_KERNEL_SINGLE = 32,   /* dtw_single_kernel (a handful of windows of one stream) */
+    RP_DTW_KERNEL_REF_ALL = 64   /* dtw_ref_kernel over every window (a template row outside the norm range) */
+};
+int rp_ctx_dtw_kernels(rp_ctx *ctx);
 /* Which build this library is (replaces nothing): the target architecture and the compiler flags it differs by from the
  * product's Makefile defaults -- "gfx950" for the product, "gfx950 +-DRP_..." for an experiment build (tools/ab.sh builds
  * those into rustpotter_amd/variants/, never over the product).  bench.py prints it on its JSON line. */

@@ -102,7 +102,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_batch_detect_ingest", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_dtw_kernels", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_batch_detect_ingest", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_mlp_forward_windows", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
@@ -167,6 +167,8 @@ def load_library():
     L.rp_ctx_set_stream.argtypes = [vp, vp]
     L.rp_ctx_synchronize.argtypes = [vp]
     L.rp_ctx_dtw_ref_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rp_ctx_dtw_kernels.argtypes = [vp]
+    L.rp_ctx_dtw_kernels.restype = C.c_int
     L.rp_sharded_gather_info.argtypes = []
     L.rp_sharded_gather_info.restype = C.c_char_p
     L.rp_build_info.argtypes = []
@@ -677,6 +679,14 @@ class BatchContext:
         if self._L.rp_ctx_dtw_ref_pairs(self._h, C.byref(v)) < 0:
             raise _err()
         return int(v.value)
+
+    DTW_KERNELS = {1: "dtw_mfma_kernel", 2: "dtw_mfma_wide_kernel", 4: "dtw_ragged_kernel", 8: "register kernels", 16: "dtw_generic_kernel",
+                   32: "dtw_single_kernel", 64: "dtw_ref_kernel (every window)"}
+
+    def dtw_kernels(self):
+        """Names of the DTW kernel families this context launched since the last call of this method (rp_ctx_dtw_kernels)."""
+        m = int(self._L.rp_ctx_dtw_kernels(self._h))
+        return [n for b, n in self.DTW_KERNELS.items() if m & b]
 
     # --- numpy convenience (host_pointers=True)
     def mfcc(self, pcm, K):

@@ -230,6 +230,13 @@ extern "C" int rp_debug_read_dtw_work(rp_ctx *ctx, uint32_t *dst, size_t words) 
 }
 #endif
 
+int rp_ctx_dtw_kernels(rp_ctx *ctx) {
+    if (!ctx) return 0;
+    const int m = (int)ctx->impl->dtw_ran;
+    ctx->impl->dtw_ran = 0;
+    return m;
+}
+
 const char *rp_ctx_last_mlp_kernel(rp_ctx *ctx) { return ctx ? ctx->impl->last_mlp_kernel.c_str() : ""; }
 
 size_t rp_mfcc_num_frames(size_t n_samples) {
@@ -424,7 +431,7 @@ int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames
         float *dg = agg ? static_cast<float *>(sg.out(agg, rows * sizeof(float), c->stage_out3)) : nullptr;
         if (rows && (!dm || !ds)) return -1;
         c->time_begin(kKernelDtw);
-        bool ok = hip_ok(launch_dtw(c->stream, c->dtw_work(), td, dm, S, n_frames, 0, n_win, n_win, band_size, score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+        bool ok = hip_ok(launch_dtw(c->stream, c->dtw_work_for(S, rows), td, dm, S, n_frames, 0, n_win, n_win, band_size, score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
         c->time_end();
         if (!ok) return -1;
         if (dg) {
@@ -571,7 +578,7 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
                                                  config->avg_threshold, ds, da), "dtw_generic_kernel (gated)");
         } else {
             // ws_mfcc ends with slack: short streams (fewer than 64 windows each) are scored by cross-stream waves like live-stream batches
-            ok = hip_ok(launch_dtw(c->stream, c->dtw_work(), td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
+            ok = hip_ok(launch_dtw(c->stream, c->dtw_work_for(S, rows), td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
                                    fz.agg ? &fz : nullptr), "dtw kernel");
         }
         c->time_end();
@@ -647,18 +654,27 @@ int rp_batch_detect_ingest(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, s
                                          hipMemcpyHostToDevice, c->copy_stream), "hipMemcpyAsync(ingest)") &&
                    hip_ok(hipEventRecord(c->ingest_landed[b], c->copy_stream), "hipEventRecord");
         };
+        // every way out after the first copy was queued waits for the copy stream: a copy from the caller's buffer may still be in flight,
+        // and the caller is free to release or reuse `pcm` the moment this call returns -- error or not
+        auto fail = [&]() {
+            const std::string why = last_error();
+            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipGetLastError();
+            set_last_error(why);
+            return -1;
+        };
         for (int b = 0; b < 2; ++b)
             if (!hip_ok(hipEventRecord(c->ingest_freed[b], c->stream), "hipEventRecord")) return -1;
-        if (!copy_block(0)) return -1;
+        if (!copy_block(0)) return fail();
         for (size_t k = 0; k < n_blocks; ++k) {
             const int b = (int)(k & 1);
-            if (k + 1 < n_blocks && !copy_block(k + 1)) return -1;   // the next block's copy goes out before this block's kernels
-            if (!hip_ok(hipStreamWaitEvent(c->stream, c->ingest_landed[b], 0), "hipStreamWaitEvent")) return -1;
+            if (k + 1 < n_blocks && !copy_block(k + 1)) return fail();   // the next block's copy goes out before this block's kernels
+            if (!hip_ok(hipStreamWaitEvent(c->stream, c->ingest_landed[b], 0), "hipStreamWaitEvent")) return fail();
             GatherTo g;
             g.on = true; g.host = true; g.stream_base = (int)(k * blk); g.device_pcm = true;
             // the block through the ordinary batched path; its detections land in det / n_det at the block's rows (the call waits for them)
-            if (batch_detect_impl(ctx, dbuf[b], fmt, streams_of(k), n_samples, pcm_stride, t, config, det, n_det, max_det, nullptr, nullptr, g) != 0) return -1;
-            if (!hip_ok(hipEventRecord(c->ingest_freed[b], c->stream), "hipEventRecord")) return -1;
+            if (batch_detect_impl(ctx, dbuf[b], fmt, streams_of(k), n_samples, pcm_stride, t, config, det, n_det, max_det, nullptr, nullptr, g) != 0) return fail();
+            if (!hip_ok(hipEventRecord(c->ingest_freed[b], c->stream), "hipEventRecord")) return fail();
         }
         if (!hip_ok(hipStreamSynchronize(c->copy_stream), "hipStreamSynchronize")) return -1;
         if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

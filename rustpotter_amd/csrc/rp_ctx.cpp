@@ -89,12 +89,37 @@ Ctx *Ctx::create(int device, int flags) {
 }
 
 bool Ctx::ingest_ready() {
-    if (copy_stream) return true;
-    if (!hip_ok(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate(copy)")) { copy_stream = nullptr; return false; }
-    for (int b = 0; b < 2; ++b)
-        if (!hip_ok(hipEventCreateWithFlags(&ingest_landed[b], hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&ingest_freed[b], hipEventDisableTiming), "hipEventCreate")) return false;
+    if (copy_stream) return true;   // set only when the stream AND its four events exist (a half-made set is torn down below)
+    hipStream_t cs = nullptr;
+    if (!hip_ok(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate(copy)")) return false;
+    bool ok = true;
+    for (int b = 0; b < 2 && ok; ++b)
+        ok = hip_ok(hipEventCreateWithFlags(&ingest_landed[b], hipEventDisableTiming), "hipEventCreate") &&
+             hip_ok(hipEventCreateWithFlags(&ingest_freed[b], hipEventDisableTiming), "hipEventCreate");
+    if (!ok) {
+        const std::string why = last_error();
+        for (int b = 0; b < 2; ++b) {
+            if (ingest_landed[b]) { (void)hipEventDestroy(ingest_landed[b]); ingest_landed[b] = nullptr; }
+            if (ingest_freed[b]) { (void)hipEventDestroy(ingest_freed[b]); ingest_freed[b] = nullptr; }
+        }
+        (void)hipStreamDestroy(cs);
+        set_last_error(why);
+        return false;
+    }
+    copy_stream = cs;
     return true;
+}
+
+DtwWork Ctx::dtw_work_for(size_t S, size_t rows) {
+    DtwWork wk = dtw_work();
+    const size_t prep_bytes = (S * 8 * sizeof(float) + 255) & ~(size_t)255, list_bytes = (rows + 1) * sizeof(uint32_t);
+    if (S && rows && rows <= 0xffffffffULL && ws_rag.reserve(prep_bytes + list_bytes + 16)) {
+        wk.rag_prep = ws_rag.as<float>();
+        wk.rag_list = reinterpret_cast<uint32_t *>(ws_rag.as<unsigned char>() + prep_bytes);
+        wk.rag_streams = S;
+        wk.rag_rows = rows;
+    }
+    return wk;
 }
 
 uint32_t *Ctx::hot_flags(size_t S) {
@@ -271,6 +296,30 @@ static void append_mfma_image(std::vector<uint16_t> &img, const DtwChunk &c, con
         }
 }
 
+// dtw_ragged_kernel's A operand of ONE template (rp_dtw_ragged.hip): per row [k half 2] x 8 f16, the same split as above without the
+// constant slot (the cell adds its 1 itself): k half 0 = a0_0 a0_1 | a0_0 a0_1 | a1_0 a1_1 | a0_2 a0_2, k half 1 = a0_3 a0_4 | a0_3 a0_4 |
+// a1_3 a1_4 | a1_2 0; 16 zero rows behind the last one.
+static void append_ragged_image(std::vector<uint16_t> &img, int t, int len, const float *unit, int Lpad) {
+    const int K = 5;
+    const size_t base = img.size();
+    img.resize(base + (size_t)(len + 16) * 16, 0);
+    for (int r = 0; r < len; ++r) {
+        uint16_t p[5][2];
+        for (int k = 0; k < K; ++k) {
+            const float a = (float)(-(double)unit[((size_t)t * Lpad + r) * K + k] * (1.0 + kDtwSplitShort));
+            p[k][0] = f16_rtn_bits(a);
+            p[k][1] = f16_rtn_bits(a - f16_bits_to_f32(p[k][0]));
+        }
+        for (int kh = 0; kh < 2; ++kh) {
+            const int ca = kh ? 3 : 0, cb = ca + 1;
+            uint16_t sl[8] = {p[ca][0], p[cb][0], p[ca][0], p[cb][0], p[ca][1], p[cb][1], 0, 0};
+            if (kh == 0) { sl[6] = p[2][0]; sl[7] = p[2][0]; }
+            else { sl[6] = p[2][1]; sl[7] = 0; }
+            std::memcpy(&img[base + (size_t)r * 16 + kh * 8], sl, 16);
+        }
+    }
+}
+
 // dtw_mfma_wide_kernel's A operand of one chunk (rp_dtw_mfma_wide.hip): per template row [k-step][k half 2][template slot 8] x 8 f16.
 // Lane half kh owns components kh * CHM .. kh * CHM + CHM - 1 (zero beyond K).  With a = -(unit row) = a0 + a1 the registers of a half
 // are, per component pair (p, q): (a0p, a0q), (a0p, a0q), (a1p, a1q) against the window side's (x0p, x0q), (x1p, x1q), (x0p, x0q); an odd
@@ -337,7 +386,8 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         }
     }
     const int Ttot = T + has_avg, Lpad = longest;
-    std::vector<float> unit((size_t)Ttot * Lpad * K, 0.f), raw((size_t)Ttot * Lpad * K, 0.f);
+    // (unit: 32 rows of slack behind the last template -- dtw_ragged_kernel requests the rows of a band a few columns past a template's end)
+    std::vector<float> unit((size_t)(Ttot * Lpad + 32) * K, 0.f), raw((size_t)Ttot * Lpad * K, 0.f);
     std::vector<int> hl(Ttot);
     bool ref_only = false;
     size_t off = 0;
@@ -458,6 +508,44 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
             }
         }
     }
+    if (K == 5) {   // dtw_ragged_kernel: what the equal-length matrix kernel leaves (lengths that occur once or twice), any lengths per chunk
+        std::vector<int> rag;   // `order` is sorted by length: shortest first
+        for (int cls : {0, 3})
+            for (const DtwChunk &c : byclass[cls])
+                for (int q = 0; q < c.count; ++q) if (c.tid[q] < T) rag.push_back(c.tid[q]);
+        std::stable_sort(rag.begin(), rag.end(), [&](int a, int b) { return hl[a] < hl[b]; });
+        if (!rag.empty()) {
+            std::vector<uint16_t> rimg;
+            std::vector<int> roff(T, 0);
+            d.rag_first = (int)chunks.size();
+            d.rag_min_len = hl[rag[0]];
+            // chunks of up to 8, filled evenly (9 templates: 5 + 4, not 8 + 1)
+            const int n_rc = ((int)rag.size() + kChunkMax - 1) / kChunkMax;
+            for (int b = 0, ci = 0; ci < n_rc; ++ci) {
+                const int cnt = ((int)rag.size() - b + (n_rc - ci) - 1) / (n_rc - ci);
+                DtwChunk c{};
+                c.count = cnt; c.tc = 8; c.len = hl[rag[b + cnt - 1]];
+                int a_bytes = 0, rows = 0;
+                for (int q = 0; q < kChunkMax; ++q) c.tid[q] = rag[b + (q < cnt ? q : 0)];
+                for (int q = 0; q < cnt; ++q) {
+                    const int t = rag[b + q];
+                    roff[t] = (int)(rimg.size() * sizeof(uint16_t) / 16);
+                    append_ragged_image(rimg, t, hl[t], unit.data(), Lpad);
+                    a_bytes += (hl[t] + 16) * 32;
+                    rows += hl[t] * K;
+                }
+                d.rag_a_cap = std::max(d.rag_a_cap, a_bytes);
+                d.rag_rows_cap = std::max(d.rag_rows_cap, (rows + 3) & ~3);
+                chunks.push_back(c);
+                b += cnt;
+            }
+            d.rag_count = n_rc;
+            if (!hip_ok(hipMalloc(&d.rimg, sizeof(uint16_t) * rimg.size()), "hipMalloc(rimg)")) return nullptr;
+            if (!hip_ok(hipMemcpy(d.rimg, rimg.data(), sizeof(uint16_t) * rimg.size(), hipMemcpyHostToDevice), "hipMemcpy(rimg)")) return nullptr;
+            if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.rag_off), sizeof(int) * T), "hipMalloc(rag_off)")) return nullptr;
+            if (!hip_ok(hipMemcpy(d.rag_off, roff.data(), sizeof(int) * T, hipMemcpyHostToDevice), "hipMemcpy(rag_off)")) return nullptr;
+        }
+    }
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.chunks), sizeof(DtwChunk) * chunks.size()), "hipMalloc(chunks)")) return nullptr;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.dup), sizeof(float) * dup.size()), "hipMalloc(dup)")) return nullptr;
     if (!hip_ok(hipMemcpy(d.chunks, chunks.data(), sizeof(DtwChunk) * chunks.size(), hipMemcpyHostToDevice), "hipMemcpy(chunks)")) return nullptr;
@@ -478,6 +566,8 @@ Templates::~Templates() {
     if (dev.dup) (void)hipFree(dev.dup);
     if (dev.aimg) (void)hipFree(dev.aimg);
     if (dev.raw) (void)hipFree(dev.raw);
+    if (dev.rimg) (void)hipFree(dev.rimg);
+    if (dev.rag_off) (void)hipFree(dev.rag_off);
 }
 
 // f32 -> bf16, round to nearest even (matches the kernel's in-register conversion)

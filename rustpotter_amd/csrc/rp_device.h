@@ -210,6 +210,15 @@ __device__ __forceinline__ unsigned pk_f16_second(float lo, float hi) {
 #endif
 }
 
+// A row of the wakeword-model forward with a feature beyond the f16 range: listed for the f32 pass (rp_kernels.h kMlpF16x2; redo[0] = rows
+// listed, entries from redo[2] on, room for `cap` = every row of the call).  A row is listed at most once per call and the words are zero
+// between calls (the second pass, or the launcher's mlp_redo_abort on an error in between, puts them back), so the index stays below cap;
+// the clamp keeps a count left behind by anything else from writing past the buffer.
+__device__ __forceinline__ void mlp_redo_append(uint32_t *redo, uint32_t row, size_t cap) {
+    const uint32_t i = atomicAdd(redo, 1u);
+    if ((size_t)i < cap) redo[2 + i] = row;
+}
+
 // A (window, chunk or template) pair whose frames left the norm range of the scale-invariant cosine (rp_kernels.h, DtwWork):
 // appended to the call's list for dtw_ref_kernel.  spec = chunk index, kFixSpecTemplate | template index.
 __device__ __forceinline__ void dtw_fix_append(uint32_t *fix, size_t row, uint32_t spec) {

@@ -40,6 +40,10 @@ struct GateList {
     // reference's sqrt(dot_a * dot_b) is not scale invariant there, comparator.rs:42-47); every launcher sets it
     uint32_t *fix = nullptr;
     uint32_t *sched = nullptr;   // DtwWork::sched for the matrix-core launches
+    uint32_t *ran = nullptr;     // DtwWork::ran
+    DtwWork wk_all;              // the call's whole DtwWork (dtw_ragged_kernel's blocks)
+    bool padded = false;         // the frame array ends with slack: the register kernels' list mode may follow dtw_ragged_kernel
+    DtwWork work() const { DtwWork w = wk_all; w.sched = sched; w.fix = fix; w.ran = ran; return w; }
 };
 
 // One wave = 64 consecutive windows of one stream x one chunk of TC same-length templates.
@@ -868,7 +872,11 @@ static hipError_t launch_dtw_ref(hipStream_t st, const DtwWork &wk, const Templa
     if (lds > 160 * 1024) return hipErrorMemoryAllocation;
     if (lds > 64 * 1024)
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_ref_kernel), 160 * 1024); e != hipSuccess) return e;
-    size_t blocks = (size_t)device_cu_count();
+    // list mode: four workgroups per CU -- with nothing listed each reads one word and leaves; with more pairs than the list holds
+    // (kDtwFixCap: pathological input) the kernel falls back to every window of the call, and a grid of one workgroup per CU would
+    // walk them sixteen thousand lanes wide
+    size_t blocks = 4 * (size_t)device_cu_count();
+    if (force_all) dtw_mark(wk, kDtwRanRefAll);
     if (force_all) {
         const size_t need = (S * n_win * (size_t)(fuse ? 1 : t_count) + 63) / 64;
         blocks = need < 8 * (size_t)device_cu_count() ? (need ? need : 1) : 8 * (size_t)device_cu_count();
@@ -885,6 +893,7 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int ch
                                    size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
                                    float score_ref, float *scores, float *avg, bool few_windows, GateList gl = GateList{}) {
     if (n_chunks <= 0) return hipSuccess;
+    dtw_mark(gl.work(), kDtwRanRegister);
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     if ((few_windows || gl.list) && KP == K) {
         // streams contribute fewer than 64 windows each (or the windows come from a list): lanes of a wave span many
@@ -919,6 +928,7 @@ static hipError_t launch_dtw_single_chunks(hipStream_t st, const TemplatesDev &t
                                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
                                            float *scores, float *avg, bool few_windows, GateList gl = GateList{}) {
     if (n_chunks <= 0) return hipSuccess;
+    dtw_mark(gl.work(), kDtwRanRegister);
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     constexpr int NW = 2 * kDtwWin;
     if ((few_windows || gl.list) && KP == K) {
@@ -984,7 +994,7 @@ static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int
         if (t.has_avg && n1 == t.class_count[3])
             if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
                                                         few, gl, t.class_first[3] + t.class_count[3] - 1); e != hipSuccess) return e;
-        return launch_dtw_mfma_wide(st, DtwWork{gl.sched, gl.fix}, t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg,
+        return launch_dtw_mfma_wide(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg,
                                     gl.list, gl.count, gl.dense_min, gl.abandon_nc);
     }
     if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, n1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl); e != hipSuccess) return e;
@@ -1134,20 +1144,40 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
                                 size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref,
                                 float *scores, float *avg, bool few, GateList gl = GateList{}) {
     hipError_t e;
-    // n1: single-template chunks to score (class 3; the averaged template is its last chunk)
-    if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
-    if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+    // templates whose length occurs once or twice: the matrix-core kernel for unequal lengths (rp_dtw_ragged.hip) when every window of
+    // the call is scored from LDS-staged tiles; the averaged template (its own output array) keeps its register launch.  The windows that
+    // kernel lists (a frame it cannot resolve within the parity gate: digital silence behind speech, wild scales) are scored again by the
+    // register kernels in list mode -- two launches that leave at once when nothing is listed -- or, without slack behind the frame
+    // array, by dtw_ref_kernel
+    if (!few && !gl.list && !gl.count && t.rag_count > 0 && W <= 5 && gl.wk_all.rag_prep && gl.wk_all.rag_streams >= S &&
+        dtw_ragged_supported(t, W, n_win, score_ref)) {
+        const int n_avg = (t.has_avg && n1 == t.class_count[3] && n1 > 0) ? 1 : 0;
+        if (n_avg)
+            if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3] + t.class_count[3] - 1, 1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+        const bool list_rows = gl.padded && gl.wk_all.rag_list && gl.wk_all.rag_rows >= S * n_win && out_win_pitch == n_win;
+        if ((e = launch_dtw_ragged(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, gl.abandon_nc, list_rows)) != hipSuccess) return e;
+        if (list_rows) {
+            GateList g2 = gl;
+            g2.list = gl.wk_all.rag_list + 1; g2.count = gl.wk_all.rag_list; g2.dense_min = 0; g2.fuse = nullptr;
+            if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], t.class_count[3] - (t.has_avg ? 1 : 0), mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, false, g2)) != hipSuccess) return e;
+            if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, false, g2)) != hipSuccess) return e;
+        }
+    } else {
+        // n1: single-template chunks to score (class 3; the averaged template is its last chunk)
+        if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], n1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+        if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
+    }
     // chunks of 3..8 templates: the matrix-core kernel (rp_dtw_mfma.hip) in every mode (LDS-staged, frames from global memory for
     // live-stream batches and the gate's list, early abandon): 5..8 templates at band 3..5 with eight template slots per wave, 3..4 at
     // band 5 with four.
     {
         const bool from_global = few || gl.list != nullptr;
         if (t.class_count[1] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 4, score_ref)) {
-            if ((e = launch_dtw_mfma(st, DtwWork{gl.sched, gl.fix}, t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+            if ((e = launch_dtw_mfma(st, gl.work(), t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                      scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse)) != hipSuccess) return e;
         } else if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
         if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8, score_ref))
-            return launch_dtw_mfma(st, DtwWork{gl.sched, gl.fix}, t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+            return launch_dtw_mfma(st, gl.work(), t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                    scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse);
     }
     // Small batches: tc-8 waves run two per SIMD; a launch that fills those slots 2.x times leaves the chip mostly idle in
@@ -1209,7 +1239,7 @@ static hipError_t gated_k5(hipStream_t st, const DtwWork &wk, int band, const Te
     // pass 1: the averaged template over every window (and, before the gate looks at them, the reference-shaped rescoring of the
     // windows whose frames left the norm range: dtw_ref_kernel)
     GateList g1;
-    g1.fix = wk.fix; g1.sched = wk.sched;
+    g1.fix = wk.fix; g1.sched = wk.sched; g1.ran = wk.ran;
     hipError_t e = launch_dtw_single_chunks<5, W>(st, t, avg_chunk, 1, mfcc, S, frame_pitch, first_win, n_win, n_win, score_ref, scores, avg, few, g1);
     if (e != hipSuccess) return e;
     if ((e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, n_win, band, score_ref, scores, avg, false, t.T, 1)) != hipSuccess) return e;
@@ -1220,7 +1250,7 @@ static hipError_t gated_k5(hipStream_t st, const DtwWork &wk, int band, const Te
     // pass 3: the sample templates on the listed rows -- or, when (nearly) every row is listed, on all rows through the
     // ordinary staged launch (GateList; with few windows per stream both forms read global memory: list mode only)
     GateList gl;
-    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched;
+    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched; gl.ran = wk.ran;
     gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
     e = launch_dtw_k5<W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl);
     if (e != hipSuccess) return e;
@@ -1237,7 +1267,7 @@ static hipError_t gated_wide(hipStream_t st, const DtwWork &wk, const TemplatesD
                              uint32_t *count, bool few, float abandon_nc) {
     const size_t rows = S * n_win, tiles = (n_win + kDtwWin - 1) / kDtwWin;
     GateList g1;
-    g1.fix = wk.fix; g1.sched = wk.sched;
+    g1.fix = wk.fix; g1.sched = wk.sched; g1.ran = wk.ran;
     hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, few, g1, avg_chunk);
     if (e != hipSuccess) return e;
     if ((e = launch_dtw_ref(st, wk, t, mfcc, S, frame_pitch, first_win, n_win, n_win, W, score_ref, scores, avg, false, t.T, 1)) != hipSuccess) return e;
@@ -1245,7 +1275,7 @@ static hipError_t gated_wide(hipStream_t st, const DtwWork &wk, const TemplatesD
     hipLaunchKernelGGL(gate_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, st, avg, rows, avg_threshold, list, count);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     GateList gl;
-    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched;
+    gl.list = list; gl.count = count; gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched; gl.ran = wk.ran;
     gl.dense_min = few ? 0u : (uint32_t)(rows - rows / 10);
     e = launch_dtw_wide_all<K, W>(st, t, t.class_count[3] - 1, mfcc, S, frame_pitch, tiles, first_win, n_win, n_win, score_ref, scores, avg, false, gl, true);
     if (e != hipSuccess) return e;
@@ -1333,7 +1363,7 @@ static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const Templ
                                   size_t first_win, size_t n_win, size_t out_win_pitch, int band, float score_ref, int with_avg,
                                   float *scores, float *avg, bool padded_rows, float abandon_nc, DtwFusedAgg *fuse, bool *self_healing) {
     GateList gl;
-    gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched;
+    gl.abandon_nc = abandon_nc; gl.fix = wk.fix; gl.sched = wk.sched; gl.ran = wk.ran; gl.wk_all = wk; gl.padded = padded_rows;
     // many streams with few windows each (streaming batches): cross-stream waves reading frames from global memory;
     // needs `padded_rows` (slack after the last stream's frames for the never-used out-of-band columns)
     // (one stream alone is a batch too when the matrix-core kernel serves its templates: a stream's bits must not depend on the
@@ -1353,6 +1383,7 @@ static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const Templ
                                (unsigned)n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, Ttot, t.max_len, band, score_ref,
                                scores, avg, t.raw, t.ref_only, wk.fix);
             *self_healing = true;
+            dtw_mark(wk, kDtwRanSingle);
             return hipGetLastError();
         }
     }
@@ -1391,6 +1422,7 @@ static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const Templ
     const size_t lds = ((size_t)(64 + t.max_len - 1) * KP + (size_t)t.K * 64 + (size_t)(2 * Wmax + 1) * 64) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorMemoryAllocation;  // reported as "template too long" by the callers' hip_ok text
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_generic_kernel), 160 * 1024); e != hipSuccess) return e;
+    dtw_mark(wk, kDtwRanGeneric);
     hipLaunchKernelGGL(dtw_generic_kernel, dim3((unsigned)blocks), dim3(64), lds, st, mfcc, frame_pitch, frame_pitch,
                        (unsigned)tiles, first_win, n_win, out_win_pitch, t.lens, t.unit, t.Lpad, t.K, t.T, 0, Ttot,
                        t.max_len, band, score_ref, scores, avg, static_cast<const float *>(nullptr), 0.f, wk.fix);

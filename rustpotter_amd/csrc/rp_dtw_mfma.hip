@@ -84,12 +84,13 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 // the chunk holds every sample template of the reference -- the kernel also writes ScoreMode::Max of a window's scores and raises the
 // stream's hot flag (DtwFusedAgg, rp_kernels.h).
 // RP_MFMA_TRACE (variant builds only, tools/r4_mfma_timeline.py): wave 0 and the last wave of every workgroup stamp the constant
-// 100 MHz clock at the kernel's phase boundaries into the tail of the counter block (DtwWork::sched words 1024..): where a short
+// 100 MHz clock at the kernel's phase boundaries into the tail of the counter block (DtwWork::sched words 1024..4095, the first 96 workgroups: the
+// list words of DtwWork::fix start right behind): where a short
 // launch spends its fixed cost.  Never defined in the product.
 #ifdef RP_MFMA_TRACE
 #define RP_TRACE(slot)                                                                                                        \
     do {                                                                                                                      \
-        if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == NW - 1) && blockIdx.x < 128)          \
+        if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == NW - 1) && blockIdx.x < 96)   /* 96 x 2 x 8 stamps end with the counter block */          \
             reinterpret_cast<unsigned long long *>(sched + 1024)[(blockIdx.x * 2 + ((threadIdx.x >> 6) ? 1 : 0)) * 8 + (slot)] = \
                 __builtin_amdgcn_s_memrealtime();                                                                             \
     } while (0)
@@ -485,6 +486,7 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
                            bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,
                            const DtwFusedAgg *fuse) {
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
+    dtw_mark(wk, kDtwRanMfma);
     if (fuse && (n_chunks != 1 || list || count)) return hipErrorInvalidValue;  // launch_dtw only asks for it with one chunk, every row scored
     float *agg_out = fuse ? fuse->agg : nullptr;
     uint32_t *agg_hot = fuse ? fuse->hot : nullptr;

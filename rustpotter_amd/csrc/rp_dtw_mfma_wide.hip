@@ -328,6 +328,7 @@ hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const Templat
     const int n_chunks = t.wide8_count;
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
     if (band != 5 || !wk.sched || !wk.fix) return hipErrorNotSupported;
+    dtw_mark(wk, kDtwRanMfmaWide);
     const size_t total_tiles = (S * n_win + kWWin - 1) / kWWin;
     constexpr int NW = 8;
     const size_t lds = (size_t)(t.max_len + 16) * dtw_mfma_wide_ksteps(t.K) * 256;

@@ -127,7 +127,12 @@ struct Ctx {
     DevBuf ws_mlp_redo;
     uint32_t *mlp_redo(size_t B);
     std::string last_mlp_kernel;   // what the last dense-row forward ran (rp_ctx_last_mlp_kernel)
-    DtwWork dtw_work() const { return DtwWork{ws_dtw.as<uint32_t>(), ws_dtw.as<uint32_t>() + 2 * kDtwSchedChunks}; }
+    mutable uint32_t dtw_ran = 0;  // kDtwRan* of the DTW launches since rp_ctx_dtw_kernels last read it
+    DtwWork dtw_work() const { return DtwWork{ws_dtw.as<uint32_t>(), ws_dtw.as<uint32_t>() + 2 * kDtwSchedChunks, &dtw_ran}; }
+    // ... plus the blocks dtw_ragged_kernel needs for a call over S streams x n_win windows (whole-stream batches; a failed reservation
+    // only means that kernel is not taken)
+    DevBuf ws_rag;
+    DtwWork dtw_work_for(size_t S, size_t rows);
 
     static Ctx *create(int device, int flags);
     ~Ctx();

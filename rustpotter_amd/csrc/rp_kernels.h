@@ -131,6 +131,15 @@ struct TemplatesDev {
     // some row is outside the range -- every window of this set is scored by dtw_ref_kernel.
     float *raw = nullptr;     // [T+has_avg][Lpad][K]
     int ref_only = 0;
+    // dtw_ragged_kernel (rp_dtw_ragged.hip, mfcc_size 5): the sample templates the equal-length matrix kernel does not take (lengths that
+    // occur once or twice) as chunks of up to 8 templates of ANY lengths, shortest first; rimg = per template its A image, 32 bytes per
+    // row ([k half 2] x 8 f16: the negated unit row split in two f16 parts) + 16 zero rows, rag_off[t] its offset in 16-byte units
+    int rag_first = 0, rag_count = 0;
+    int rag_min_len = 0;      // shortest template among them (needs >= 16 frames)
+    int rag_a_cap = 0;        // largest chunk's images in bytes
+    int rag_rows_cap = 0;     // ... unit rows in floats (multiple of 4)
+    void *rimg = nullptr;
+    int *rag_off = nullptr;   // [T]
 };
 // squared-norm range in which the scale-invariant cell equals the reference's: 2^-60 <= |row|^2 <= 2^60, 2^-60 <= |frame|^2 <= 2^30
 // (products stay within 2^-120 .. 2^90; a frame is tested with ONE v_max3_f32 of its squared norm and its reciprocal square root
@@ -148,7 +157,16 @@ constexpr uint32_t kFixSpecTemplate = 1u << 22, kFixSpecAll = 1u << 23, kFixSpec
 struct DtwWork {
     uint32_t *sched = nullptr;   // [2 * kDtwSchedChunks]
     uint32_t *fix = nullptr;     // [2 + 2 * kDtwFixCap + 2]: the last two words count the pairs rescored since the context was made
+    uint32_t *ran = nullptr;     // HOST word (may be null): the launchers OR in the kernel families they launched (kDtwRan*, rp_ctx_dtw_kernels)
+    // dtw_ragged_kernel's per-call device blocks (Ctx::dtw_work_for; null: that kernel is not taken): rag_prep [rag_streams][8] floats
+    // (offset and scale of every stream), rag_list [1 + rag_rows] words (the windows to score again with the register kernels)
+    float *rag_prep = nullptr;
+    uint32_t *rag_list = nullptr;
+    size_t rag_streams = 0, rag_rows = 0;
 };
+// == RP_DTW_KERNEL_* (include/rustpotter_hip.h)
+enum : uint32_t { kDtwRanMfma = 1u, kDtwRanMfmaWide = 2u, kDtwRanRagged = 4u, kDtwRanRegister = 8u, kDtwRanGeneric = 16u, kDtwRanSingle = 32u, kDtwRanRefAll = 64u };
+inline void dtw_mark(const DtwWork &wk, uint32_t bit) { if (wk.ran) *wk.ran |= bit; }
 __host__ __device__ inline unsigned long long *dtw_fix_stats(uint32_t *fix) { return reinterpret_cast<unsigned long long *>(fix + 2 + 2 * (size_t)kDtwFixCap); }
 // (dtw_fix_append, the kernels' side of the list: rp_device.h)
 
@@ -179,6 +197,19 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
                            bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,
                            const DtwFusedAgg *fuse = nullptr);
+
+// The matrix-core DTW kernel for templates of unequal length (rp_dtw_ragged.hip): the ragged chunks of `t` over every window of the call
+// (LDS-staged tiles of 512 windows: needs n_win >= 64; live-stream batches and the gate's list keep the register kernels).
+constexpr int kDtwRaggedWaves = 8;    // waves per workgroup = 512 windows per tile
+constexpr int kDtwRaggedSegs = 16;    // stream segments a tile may span
+// the cell error is 2^-22 x |x_f - o| / |x_f - mu| (a few times dtw_mfma_kernel's): floor of score_ref for the 1e-5 parity gate
+constexpr float kDtwRaggedMinScoreRef = 0.1f;
+bool dtw_ragged_supported(const TemplatesDev &t, int band, size_t n_win, float score_ref);
+size_t dtw_ragged_lds_bytes(const TemplatesDev &t, size_t n_win, int *frames_cap);
+// list_rows: windows the kernel cannot score within the parity gate go to wk.rag_list (the caller runs the register kernels' list mode on it);
+// else to wk.fix (dtw_ref_kernel)
+hipError_t launch_dtw_ragged(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch,
+                             size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float abandon_nc, bool list_rows);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that drives several GPUs
 // (one rp_ctx per device) has to set it on each of them.  Sets it once per (current device, kernel), thread-safe.
@@ -358,6 +389,14 @@ struct MlpDev {
 // a row is listed when one of its features is beyond the f16 range (|x| > 65504, or not finite): the split cannot hold it, the f32
 // instructions can -- rp_mlp_forward_batch never answers NaN for finite input.
 enum { kMlpF32 = 0, kMlpBf16 = 1, kMlpF16x2 = 2, kMlpStrictF32 = 3, kMlpRedoF32 = 4 };
+// A launcher that fails between the split pass and the pass over the listed rows must not leave rows of THIS call listed for the next one
+// (the next call would append behind them and run its second pass on stale indices): the two counter words go back to zero behind
+// whatever was queued, as dtw_abort does for the DTW words.  Returns the error it was given.
+inline hipError_t mlp_redo_abort(hipStream_t st, uint32_t *redo, hipError_t e) {
+    if (redo) (void)hipMemsetAsync(redo, 0, 2 * sizeof(uint32_t), st);
+    (void)hipGetLastError();
+    return e;
+}
 // Fused forward of all layers; layer 1 on the matrix cores (f32-input MFMA: bit-for-bit an fmaf
 // chain; or bf16 inputs with f32 accumulation), tail layers + ReLU per row in f32.
 hipError_t launch_mlp_mfma(hipStream_t st, const MlpDev &m, const float *x, size_t B, int precision, float *out, uint32_t *redo);

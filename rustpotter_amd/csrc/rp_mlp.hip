@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
         if (PREC == kMlpF16x2) {   // the four lanes (row rr, k part 0..3) of a row agree on its range; one of them lists it
             rng = fmaxf(rng, __shfl_xor(rng, 16));
             rng = fmaxf(rng, __shfl_xor(rng, 32));
-            if (ph == 0 && row_ok && !(rng <= 65504.f)) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)orow;
+            if (ph == 0 && row_ok && !(rng <= 65504.f)) mlp_redo_append(redo, (uint32_t)orow, B);
         }
         const float *hin = h1 + rr * (N1P + 1);
         float *h2 = h2_all + (wave * kMlpRowsPerWave + rr) * h2w;
@@ -577,13 +577,15 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
             hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF16x2>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                                m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1s), m.b1, m.tail, m.tail_floats, m.n_layers,
                                m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, redo, 0);
-            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return mlp_redo_abort(st, redo, e);
         }
         // the rows the split form listed (a feature beyond the f16 range), again with the f32 matrix instructions: sized for every row,
         // workgroups past the list's end leave at once
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpF32>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
                            m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, redo, 1);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return mlp_redo_abort(st, redo, e);
+        return hipSuccess;
     } else if (precision == kMlpBf16)
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
             if (lh == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
                 unsigned far = 0u;
                 for (int f = 0; f < L; ++f) far |= flag[wrow0 + lr + f];
-                if (far) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)orow;
+                if (far) mlp_redo_append(redo, (uint32_t)orow, (size_t)(gridDim.x / blocks_per_stream) * n_win);
             }
             const int dd[4] = {d1, d2, d3, 0};
             const float *hin = h1 + lr * 32;
@@ -1025,7 +1027,7 @@ __global__ __launch_bounds__(64 * NQ, 2) void mlp_windows_wide_kernel(
         if (ph == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
             unsigned far = 0u;
             for (int f = 0; f < L; ++f) far |= flag[wrow0 + prow + f];
-            if (far) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)orow;
+            if (far) mlp_redo_append(redo, (uint32_t)orow, (size_t)(gridDim.x / blocks_per_stream) * n_win);
         }
         const int dd[4] = {d1, d2, d3, 0};
         float *dst = out + orow * (size_t)dd[n_layers - 1];
@@ -1158,14 +1160,16 @@ hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float 
         // whole streams (or long runs of windows): the frames staged once per workgroup; then the listed rows with the f32 instructions
         if (S * n_win > 0xffffffffULL) return hipErrorInvalidValue;
         if (hipError_t e = form == 1 ? launch_mlp_windows(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch)
-                                     : launch_mlp_windows_wide(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch); e != hipSuccess) return e;
+                                     : launch_mlp_windows_wide(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch); e != hipSuccess)
+            return mlp_redo_abort(st, redo, e);
+        hipError_t e2 = hipErrorInvalidValue;   // (launch_mlp_nt puts the words back itself when ITS launch fails)
         switch (m.nt) {
-        case 1: return launch_mlp_nt<1>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
-        case 2: return launch_mlp_nt<2>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
-        case 5: return launch_mlp_nt<5>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
-        case 9: return launch_mlp_nt<9>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
+        case 1: e2 = launch_mlp_nt<1>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K); break;
+        case 2: e2 = launch_mlp_nt<2>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K); break;
+        case 5: e2 = launch_mlp_nt<5>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K); break;
+        case 9: e2 = launch_mlp_nt<9>(st, m, mfcc, B, kMlpRedoF32, out, redo, (size_t)K, n_win, skip, mean, wsum, K); break;
         }
-        return hipErrorInvalidValue;
+        return e2 == hipSuccess ? e2 : mlp_redo_abort(st, redo, e2);
     }
     const int prec = strict_f32 ? kMlpStrictF32 : kMlpF32;
     switch (m.nt) {

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
         if (PREC == kMlpF16x2) {   // the four lanes (row ri, k part 0..3) of a row agree on its range; one of them lists it
             rng = fmaxf(rng, __shfl_xor(rng, 16));
             rng = fmaxf(rng, __shfl_xor(rng, 32));
-            if (ph == 0 && row_ok && !(rng <= 65504.f)) redo[2 + atomicAdd(redo, 1u)] = (uint32_t)row;
+            if (ph == 0 && row_ok && !(rng <= 65504.f)) mlp_redo_append(redo, (uint32_t)row, B);
             rng = 0.f;
         }
         const float *hin = h1 + ri * H1P;
@@ -378,9 +378,11 @@ hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPla
                              uint32_t *redo) {
     if (B == 0) return hipSuccess;
     if (precision == kMlpF16x2 && (!redo || B > 0xffffffffULL)) return hipErrorInvalidValue;
-    if (hipError_t e = launch_mlp_stream_pass(st, m, p, x, B, precision, out, n_cu, redo); e != hipSuccess || precision != kMlpF16x2) return e;
+    if (hipError_t e = launch_mlp_stream_pass(st, m, p, x, B, precision, out, n_cu, redo); e != hipSuccess || precision != kMlpF16x2)
+        return e == hipSuccess ? e : mlp_redo_abort(st, redo, e);
     // the rows the split form listed (a feature beyond the f16 range) again, with the f32 matrix instructions of mlp_mfma_kernel
-    return launch_mlp_mfma(st, m, x, B, kMlpRedoF32, out, redo);
+    const hipError_t e = launch_mlp_mfma(st, m, x, B, kMlpRedoF32, out, redo);
+    return e == hipSuccess ? e : mlp_redo_abort(st, redo, e);
 }
 
 static hipError_t launch_mlp_stream_pass(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out, int n_cu,

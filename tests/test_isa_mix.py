@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8>", ["--min-mfma", "36", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/r04_dtw_mfma_isa_mix.json"),
     ("rp_mfcc.hip", "mfcc_kernel<true, 6, float, false>", [], "profiles/r04_mfcc_isa_mix.json"),
+    ("rp_dtw_ragged.hip", "dtw_ragged_kernel<5>", ["--min-mfma", "32"], "profiles/r05_dtw_ragged_isa_mix.json"),
 ]
 
 

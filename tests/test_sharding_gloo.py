@@ -51,6 +51,17 @@ def _worker(rank, world, port, total):
         loc2 = torch.stack([torch.arange(lo, hi, dtype=torch.float32), torch.arange(lo, hi, dtype=torch.float32) * 0.5], dim=1)
         all2 = sharding.gather_ragged(loc2, world)
         assert all2.shape == (total, 2) and torch.equal(all2[:, 0], torch.arange(total, dtype=torch.float32))
+        # the per-stream result block of SURVEY 8e (T + 2 floats per stream) through the same gather, weak and strong
+        T, n_win = 3, 4
+        sc = (torch.arange(first, first + S, dtype=torch.float32)[:, None, None] + torch.arange(n_win, dtype=torch.float32)[None, :, None] * 0.1 +
+              torch.arange(T, dtype=torch.float32)[None, None, :] * 0.01)
+        blk = sharding.stream_summary(sc, sc.amax(dim=2), local)
+        assert blk.shape == (S, T + 2) and blk.dtype == torch.float32
+        allb = sharding.gather_per_stream(blk, world)
+        assert allb.shape == (world * S, T + 2)
+        gs = torch.arange(world * S, dtype=torch.float32)
+        assert torch.allclose(allb[:, 0], gs + 0.3) and torch.allclose(allb[:, T - 1], gs + 0.3 + 0.01 * (T - 1))   # best window of template 0 / T-1
+        assert torch.allclose(allb[:, T], gs + 0.3 + 0.01 * (T - 1)) and torch.equal(allb[:, T + 1], (gs * 3 + 1))     # best aggregate, detections
         # timing reduction used by bench.py: MAX over ranks
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,8 +1,8 @@
-"""Turns the output of tools/r3_c5c.sh (gpurun_out/<dir>/: bench lines, rocprofv3 --kernel-trace --stats, PMC passes of
+"""Turns the output of `tools/prof.sh c5 <precision>` (gpurun_out/<dir>/: bench lines, rocprofv3 --kernel-trace --stats, PMC passes of
 `bench.py --config C5`) into the committed evidence under profiles/: <round>_c5_kernel_stats.csv, <round>_c5_pmc.json
 (= pmc_c5_latest.json, which bench.py --mode mlp reads for roofline.traffic) and the bench lines.
-Usage: python tools/collect_c5.py [round tag, default r04] [gpurun_out sub-directory, default r4c5_bf16] [precision bf16 | f32]
-(made by tools/r4_c5_prof.sh <precision>; f32 writes pmc_c5_f32_latest.json)"""
+Usage: python tools/collect_c5.py [round tag, default r05] [gpurun_out sub-directory, default c5_bf16] [precision bf16 | f32]
+(f32 writes pmc_c5_f32_latest.json)"""
 import collections
 import csv
 import glob
@@ -14,8 +14,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
-D = "gpurun_out/" + (sys.argv[2] if len(sys.argv) > 2 else "r4c5_bf16")
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+D = "gpurun_out/" + (sys.argv[2] if len(sys.argv) > 2 else "c5_bf16")
 P = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 SUF = "" if P == "bf16" else "_" + P
 short = lambda n: n.split("(")[0].replace("void ", "").replace("rp::", "")
@@ -45,7 +45,7 @@ clk_dur = durations("pmc_GRBM_GUI_ACTIVE")
 line = json.loads([l for l in open(D + "/c5_%s.json" % P) if l.startswith("{")][-1])
 out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --config C5 --steps 10 --warmup 2 --no-cpu-baseline "
                   "(--mlp-precision %s; separate passes: FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; SQ_INSTS_VALU SQ_INSTS_LDS "
-                  "SQ_INSTS_VMEM_RD SQ_INSTS_MFMA; GRBM_GUI_ACTIVE; SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- tools/r4_c5_prof.sh)" % P,
+                  "SQ_INSTS_VMEM_RD SQ_INSTS_MFMA; GRBM_GUI_ACTIVE; SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -- tools/prof.sh c5)" % P,
        "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch (TCC_EA0 request counters); FETCH_SIZE of 16-byte-per-lane streaming reads -- global_load "
                 "and LDS-DMA alike -- under-reports by 2x on gfx950 (MI355X_MICROARCH.md, HBM section): doubled below; medians over the launches of the run",
        "workload": {"rows": 65536, "features": 3120, "precision": P, "model": "3120->32->16->2"}, "kernels": {}}

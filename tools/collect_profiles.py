@@ -1,10 +1,10 @@
-"""Turns the rocprofv3 output of tools/profile_bench.sh / profile_pmc.sh (tags final, final_fetch, final_write, final_sq,
+"""Turns the rocprofv3 output of `tools/prof.sh round` (tools/prof.sh stats / pmcset; tags final, final_fetch, final_write, final_sq,
 final_inst under gpurun_out/) and the bench lines under gpurun_out/final/ into the committed files under profiles/."""
 import csv, glob, json, collections, statistics, shutil, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"   # round tag of the files written
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"   # round tag of the files written
 short = lambda n: n.split("(")[0]
 
 def agg(tag):
@@ -30,7 +30,7 @@ except Exception:
     clk = {}
 out = {"command": "rocprofv3 --kernel-trace --pmc <CTRS> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "
                   "(separate passes: FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY; "
-                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES; GRBM_GUI_ACTIVE -- tools/profile_pmc.sh, tools/r4_final.sh)",
+                  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES; SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES; GRBM_GUI_ACTIVE -- tools/prof.sh pmcset, tools/prof.sh round)",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per dispatch as reported by rocprofv3 (TCC_EA0 request counters); FETCH_SIZE of "
                 "16-byte-per-lane streaming reads under-reports by 2x on gfx950 (MI355X_MICROARCH.md HBM section); values are the "
                 "MEDIAN over the launches of a kernel in the run (the run also holds one tiny mfcc launch for the templates)",

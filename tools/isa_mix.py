@@ -80,12 +80,14 @@ def main():
     lds_cyc = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read_b128": 4, "ds_read_b96": 8, "ds_read2_b32": 4, "ds_read2_b64": 8, "ds_write_b32": 4,
                "ds_write_b64": 6, "ds_write_b96": 10, "ds_write_b128": 13, "ds_write2_b32": 8, "ds_write2_b64": 12}
     valu_cycles = 0.0
+    arch_cycles = 0   # the same mix at the architectural issue rates: 2 cycles for a full-rate wave64 instruction, 4 half rate, 8 quarter rate
     lds_cycles = 0
     for o, n in counts.items():
         if o.startswith("v_mfma"): classes["mfma"] += n
         elif o.startswith("v_"):
             classes["valu"] += n
             valu_cycles += n * rate_of(o, table)
+            arch_cycles += n * (2 if rate_of(o, table) < 3.5 else 4 if rate_of(o, table) < 6 else 8)
         elif o.startswith("s_"): classes["salu"] += n
         elif o.startswith("ds_"):
             classes["lds"] += n
@@ -93,7 +95,7 @@ def main():
         elif o.startswith(("global_", "buffer_", "flat_", "scratch_")): classes["vmem"] += n
         else: classes["other"] += n
     res = {"source": src, "kernel": want, "extra_flags": " ".join(flags), "loop_lines": [a, b], "instructions": len(ops), "classes": classes,
-           "valu_issue_cycles_per_trip": round(valu_cycles, 1), "lds_cycles_per_trip": lds_cycles, "rate_table": "profiles/valu_rate_table.json",
+           "valu_issue_cycles_per_trip": round(valu_cycles, 1), "valu_issue_cycles_per_trip_architectural": arch_cycles, "lds_cycles_per_trip": lds_cycles, "rate_table": "profiles/valu_rate_table.json",
            "opcodes": dict(sorted(counts.items(), key=lambda kv: -kv[1]))}
     print(json.dumps(res, indent=1))
     if out:

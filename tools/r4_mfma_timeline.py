@@ -1,6 +1,6 @@
 """GPU box, with a library built with -DRP_MFMA_TRACE (tools/ab.sh -x): where does a short dtw_mfma_kernel launch spend its time?
 Runs the DTW stage alone on `rounds` x 3 072 tiles and prints the phase boundaries (constant 100 MHz clock, us) of wave 0 and the last
-wave of the first 128 workgroups: kernel entry, A image staged, first tile's frames + means ready, first tile's columns done, first tile
+wave of the first 96 workgroups: kernel entry, A image staged, first tile's frames + means ready, first tile's columns done, first tile
 written, all tiles of the wave done, workgroup done."""
 import ctypes as C, os, sys, time
 import numpy as np
@@ -34,11 +34,11 @@ for rounds in (1.0, 2.0, 3.09):
     ctx.dtw_dev(mf.data_ptr(), S, nf, tm, 0.22, 5, 1, 0, sc.data_ptr(), None, ag.data_ptr())
     b.record()
     torch.cuda.synchronize()
-    words = 1024 + 128 * 2 * 8 * 2
+    words = 1024 + 96 * 2 * 8 * 2   # the stamps end where the counter block ends (2 * kDtwSchedChunks words): DtwWork::fix behind it is not touched
     buf = (C.c_uint32 * words)()
     lib.rp_debug_read_dtw_work.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     assert lib.rp_debug_read_dtw_work(ctx._h, buf, words) == 0
-    t = np.frombuffer(buf, dtype=np.uint32)[1024:].view(np.uint64).reshape(128, 2, 8).astype(np.float64) / 100.0  # us
+    t = np.frombuffer(buf, dtype=np.uint32)[1024:].view(np.uint64).reshape(96, 2, 8).astype(np.float64) / 100.0  # us
     t0 = t[:, :, 0].min()
     t = t - t0
     names = ["entry", "A staged", "tile1 frames+means", "tile1 columns", "tile1 written", "all tiles", "workgroup done"]

@@ -34,7 +34,7 @@ $B --no-cpu-baseline --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13.j
 for m in small medium large; do python3 bench.py --mode model --model-type $m --streams 32768 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $O/model_$m.json; done
 python3 bench.py --ingest --ingest-format f32 --no-cpu-baseline 2>/dev/null | line > $O/ingest_f32.json
 python3 bench.py --ingest --ingest-format i16 --no-cpu-baseline 2>/dev/null | line > $O/ingest_i16.json
-bash tools/r4_c2_rounds.sh > $O/c2_rounds.txt 2>/dev/null
+bash tools/prof.sh rounds > $O/c2_rounds.txt 2>/dev/null
 python3 tools/bench_model_detect.py > $O/model_detect.txt 2>/dev/null
 for sig in noise silence; do for a in 0.0 0.2 0.5; do echo "single-stream API, $sig, avg_threshold $a: $(SIGNAL=$sig AVG=$a python3 tools/latency_probe.py 2>/dev/null | tail -1)"; done; done > $O/latency.txt
 python3 tools/bench_frontend.py > $O/frontend.txt 2>/dev/null

@@ -142,3 +142,121 @@ def test_below_the_score_ref_floor_the_register_kernels_score(ra, ctx):
     templates = _ragged_templates(SEED + 9, (60, 72, 66), 5)
     mf = _streams(2, 64 + 71, 5, first=500)
     _check(ra, ctx, templates, mf, score_ref=0.05, expect_ragged=False)
+
+
+# ---- the reference's own files and recordings, whole path (rp_batch_detect), with the matrix-core form switched on
+import json          # noqa: E402
+
+import rpw_py        # noqa: E402
+import simstream     # noqa: E402
+
+EXP = json.load(open(os.path.join(GOLDEN, "expectations.json")))
+
+
+def _detector_config(ra, e, **over):
+    cfg = ra.DetectorConfig()
+    cfg.threshold = e.get("threshold", 0.5)
+    cfg.avg_threshold = over.get("avg_threshold", 0.0)   # the gate off: every window is compared with every template
+    cfg.score_mode = {"max": 1, "median": 2, "average": 0}[e.get("score_mode", "max")]
+    cfg.min_scores = e.get("min_scores", 5)
+    return cfg
+
+
+@pytest.mark.parametrize("case", ["max", "median", "average"])
+def test_reference_fixture_stream(ra, ctx, case):
+    """tests/detector.rs:24-87: the recording the reference's tests build (simstream) against oye_casa_g.rpw -- five templates of 108 / 96 /
+    90 / 93 / 102 frames: the detections of the opt-in path carry the scores the reference asserts (1e-5) and the same frames and counters as
+    the default path; its per-window scores are within 4e-6 of the register kernels' and not the same bits."""
+    e = EXP["simulation"][case]
+    w = rpw_py.load_rpw(os.path.join(GOLDEN, e["rpw"]))
+    templates = list(w["samples_features"].values())
+    assert len({t.shape[0] for t in templates}) == len(templates)   # all lengths differ
+    base = simstream.simulation_stream_i16()
+    n = (len(base) // 480) * 480
+    pcm = np.stack([base[:n], np.roll(base[:n], 480 * 7)])
+    tm = ra.Templates(ctx, templates)
+    cfg = _detector_config(ra, e)
+    det0, n0, sc0, agg0 = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    ctx.dtw_kernels()
+    with _env(RP_DTW_RAGGED="1"):
+        det1, n1, sc1, agg1 = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    assert "dtw_ragged_kernel" in ctx.dtw_kernels()
+    assert rel_close(sc1, sc0, 4e-6) and not np.array_equal(sc1, sc0)
+    assert np.array_equal(n0, n1) and n1[0] == len(e["detections"])
+    for s in range(2):
+        for j in range(n1[s]):
+            assert (det1[s][j]["frame"], det1[s][j]["window"], det1[s][j]["counter"]) == (det0[s][j]["frame"], det0[s][j]["window"], det0[s][j]["counter"])
+    for j, (_, gscore) in enumerate(e["detections"]):
+        assert abs(det1[0][j]["score"] - np.float32(gscore)) <= 1e-5 * gscore      # the value tests/detector.rs asserts
+
+
+def test_windows_the_kernel_cannot_resolve_are_scored_again(ra, ctx):
+    """Digital silence behind speech: the windows inside the silence centre to rounding residue, 1e-6 of the stream's offset -- far below
+    what the f16 parts of the shared operand resolve.  The kernel lists them and the scale-invariant register kernels score them again (list
+    mode behind rp_batch_detect, whose frame array ends with slack; dtw_ref_kernel behind rp_dtw_score_batch): every score at 1e-5 of the
+    oracle, as if the kernel had never run on them."""
+    lens = (40, 57, 33, 64)
+    templates = _ragged_templates(SEED + 21, lens, 5)
+    S, N = 3, 480 * 120
+    pcm = np.stack([orc.synth_pcm(SEED, 70 + s, N) for s in range(S)])
+    pcm[:, N // 2:] = 0.0                                  # the second half: digital silence
+    pcm[2] = 0.0                                           # and a stream of nothing else
+    tm = ra.Templates(ctx, templates)
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    before = ctx.dtw_ref_pairs()
+    ctx.dtw_kernels()
+    with _env(RP_DTW_RAGGED="1"):
+        _, _, sc, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    ran = ctx.dtw_kernels()
+    assert "dtw_ragged_kernel" in ran and "register kernels" in ran, ran   # the list pass
+    assert ctx.dtw_ref_pairs() == before                                   # ... not the reference-shaped kernel
+    mf = ctx.mfcc(pcm, 5)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates)
+        assert rel_close(sc[s], ref_s), rel_err(sc[s], ref_s)
+        assert rel_close(agg[s], ref_a)
+    # the operator-level call has no slack behind the caller's array: the same windows go to dtw_ref_kernel
+    with _env(RP_DTW_RAGGED="1"):
+        sc2, _, _ = ctx.dtw_scores(mf, tm)
+    assert ctx.dtw_ref_pairs() > before
+    for s in range(S):
+        ref_s, _ = orc.score_stream(mf[s], templates)
+        assert rel_close(sc2[s], ref_s), rel_err(sc2[s], ref_s)
+
+
+def test_a_streams_bits_do_not_depend_on_the_batch(ra, ctx):
+    """Offset and scale of the shared operand are functions of the stream alone (ragged_prep_kernel): a stream scored alone, first or last in
+    a batch gets the same bits -- the 512-window tiles fall differently each time."""
+    templates = _ragged_templates(SEED + 33, (70, 81, 64), 5)
+    mf = _streams(5, 64 + 100, 5, first=900)
+    tm = ra.Templates(ctx, templates)
+    with _env(RP_DTW_RAGGED="1"):
+        ctx.dtw_kernels()
+        whole, _, _ = ctx.dtw_scores(mf, tm)
+        assert "dtw_ragged_kernel" in ctx.dtw_kernels()
+        alone, _, _ = ctx.dtw_scores(mf[3:4], tm)
+        tail, _, _ = ctx.dtw_scores(mf[2:], tm)
+    assert np.array_equal(whole[3], alone[0]) and np.array_equal(whole[2:], tail)
+
+
+def test_detect_only_call_abandons_without_changing_a_detection(ra, ctx):
+    """Early abandon in the opt-in kernel: a detect-only call (no per-window arrays) may stop template passes that can no longer reach the
+    threshold; the detections are those of the full call."""
+    e = EXP["simulation"]["max"]
+    w = rpw_py.load_rpw(os.path.join(GOLDEN, e["rpw"]))
+    templates = list(w["samples_features"].values())
+    base = simstream.simulation_stream_i16()
+    n = (len(base) // 480) * 480
+    pcm = np.stack([base[:n], np.roll(base[:n], 480 * 5), np.roll(base[:n], -480 * 9)])
+    tm = ra.Templates(ctx, templates)
+    cfg = _detector_config(ra, e)
+    with _env(RP_DTW_RAGGED="1"):
+        det_full, n_full, _, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+        ctx.dtw_kernels()
+        det_only, n_only = ctx.batch_detect(pcm, tm, cfg)[:2]
+        assert "dtw_ragged_kernel" in ctx.dtw_kernels()
+    assert np.array_equal(n_full, n_only) and n_full.sum() >= 3
+    for s in range(3):
+        for j in range(n_full[s]):
+            assert all(det_full[s][j][k] == det_only[s][j][k] for k in ("frame", "window", "counter", "score"))

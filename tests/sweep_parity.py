@@ -37,7 +37,7 @@ def _utterance(rng, n):
     return x.astype(np.float32)
 
 
-def make_case(rng, extreme=False, mfma=False):
+def make_case(rng, extreme=False, mfma=False, ragged=False):
     from oracle import rp_oracle as orc
     # (mfcc size 1 is left to the MFCC sweep: with one coefficient every cosine is +-1, window scores repeat exactly and
     # which of two equal-scoring windows a detection reports -- its avg_score -- hangs on the last bit)
@@ -59,10 +59,16 @@ def make_case(rng, extreme=False, mfma=False):
             lens[: int(rng.integers(1, 4))] = rng.integers(12, 110)
         elif K != 5 and T >= 6 and rng.random() < 0.4:
             lens[: T // 2] = int(rng.integers(12, 110))  # two lengths, three or more templates each
+    if ragged:  # the shapes dtw_ragged_kernel takes (opt-in, RP_DTW_RAGGED=1): mfcc_size 5, templates whose lengths all differ (sometimes one pair)
+        K = 5
+        T = int(rng.integers(1, 10))
+        lens = rng.choice(np.arange(16, 111), size=T, replace=False)
+        if T >= 3 and rng.random() < 0.2:
+            lens[1] = lens[0]
     utts = [_utterance(rng, 480 * ((int(L) + 3 + 2) // 3)) for L in lens]
     templates = [orc.normalize(orc.mfcc_stream(u, K))[:int(L)] for u, L in zip(utts, lens)]
     avg = None
-    if rng.random() < 0.5:
+    if rng.random() < 0.5 and not ragged:
         avg = templates[int(rng.integers(T))][:int(rng.integers(min(10, int(lens.max())), int(lens.max()) + 1))]
         if rng.random() < 0.3:  # an averaged template longer than every sample template (window shorter than it)
             avg = orc.normalize(orc.mfcc_stream(_utterance(rng, 480 * 50), K))[:int(lens.max()) + int(rng.integers(1, 20))]
@@ -75,13 +81,17 @@ def make_case(rng, extreme=False, mfma=False):
         cfg.update(band_size=int(rng.choice([3, 4, 5, 5, 5])) if K == 5 else 5, score_ref=float(rng.uniform(0.05, 0.3)))
         if rng.random() < 0.5:  # detect-only calls in ScoreMode::Max abandon hopeless DTWs: half of the cases take that path too
             cfg.update(score_mode="max")
+    if ragged:  # every window against every template (no gate), the kernel's bands and its score_ref floor; half of the cases detect-only + abandon
+        cfg.update(band_size=int(rng.choice([3, 4, 5, 5, 5])), score_ref=float(rng.uniform(0.1, 0.3)), avg_threshold=0.0)
+        if rng.random() < 0.5:
+            cfg.update(score_mode="max")
     if extreme:  # see make_api_case
         cfg.update(band_size=int(rng.choice([0, 1, 2, 15, 40, 120])), min_scores=int(rng.choice([0, 1, 2, 50])),
                    threshold=float(rng.choice([0.0, 1e-6, 0.3, 0.99, 1.5, -0.5])),
                    avg_threshold=float(rng.choice([0.0, 0.0, -1.0, 0.3, 2.0])),
                    score_ref=float(rng.choice([0.01, 0.05, 0.22, 5.0])))  # far smaller: (cost - ref) / ref turns 1e-8 of cost into percents
     S = int(rng.integers(1, 5))
-    n_chunks = int(rng.integers(45, 150))
+    n_chunks = int(rng.integers(70 if ragged else 45, 150))   # (ragged: at least 64 windows per stream)
     N = 480 * n_chunks + int(rng.choice([0, 0, rng.integers(1, 480)]))
     pcm = (rng.standard_normal((S, N)) * rng.uniform(0.0005, 0.02)).astype(np.float32)
     for s in range(S):
@@ -172,14 +182,26 @@ def _same(a, b, rtol):
     return True
 
 
-def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False):
-    """-> (cases, detections compared, ties skipped); raises AssertionError with the case number on a mismatch."""
+def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False, ragged=False):
+    """-> (cases, detections compared, ties skipped); raises AssertionError with the case number on a mismatch.
+    ragged: the opt-in matrix-core kernel for templates of unequal length scores the offline calls (RP_DTW_RAGGED=1; the family asserts
+    that it ran); live-stream batches keep the register kernels, so live vs offline is counters exact + scores within 4e-6 there."""
     total = ties = 0
     for ci in range(n_cases):
-        rng = np.random.default_rng([seed, 77, ci] if mfma else [seed, ci])
-        case = make_case(rng, extreme=extreme, mfma=mfma)
+        rng = np.random.default_rng([seed, 55, ci] if ragged else [seed, 77, ci] if mfma else [seed, ci])
+        case = make_case(rng, extreme=extreme, mfma=mfma, ragged=ragged)
         ref = oracle_detections(case)
-        offline, live, agg = device_detections(ra, ctx, case)
+        if ragged:
+            os.environ["RP_DTW_RAGGED"] = "1"
+            ctx.dtw_kernels()
+        try:
+            offline, live, agg = device_detections(ra, ctx, case)
+        finally:
+            if ragged:
+                del os.environ["RP_DTW_RAGGED"]
+        if ragged:
+            assert "dtw_ragged_kernel" in ctx.dtw_kernels(), "ragged sweep seed %d case %d: the kernel did not run (lens %r cfg %r)" % (
+                seed, ci, [len(t) for t in case["templates"]], case["cfg"])
         # extreme parameters: thresholds <= 0 let scores of 1e-4 .. 1e-20 through, whose relative error is the whole cost error
         # divided by score_ref -- two f32 evaluations of the same DTW already differ by that (score_ref 0.05, 2-coefficient frames,
         # generic f32 kernel: 1.1e-5; score_ref 0.01: 3e-4).  The decisions (chunk, counter) stay exact; the scores are compared at
@@ -190,11 +212,12 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False):
         sr = case["cfg"]["score_ref"]
         degenerate = case["K"] <= 2 or min(len(t) for t in case["templates"]) < 5
         tol = 1e-5 if not extreme else (1e-3 if (degenerate or sr < 0.05) else 1e-5 * max(1.0, 0.22 / sr))
-        ok = all(_same(o, r, tol) for o, r in zip(offline, ref)) and all(_same(l, o, 0.0) for l, o in zip(live, offline))
+        live_tol = 4e-6 if ragged else 0.0
+        ok = all(_same(o, r, tol) for o, r in zip(offline, ref)) and all(_same(l, o, live_tol) for l, o in zip(live, offline))
         if not ok:
             thr = case["cfg"]["threshold"]
             near = agg.size and np.min(np.abs(agg - np.float32(thr))) < 1e-5 * thr
-            if near and all(_same(l, o, 0.0) for l, o in zip(live, offline)):
+            if near and (ragged or all(_same(l, o, 0.0) for l, o in zip(live, offline))):
                 ties += 1
                 continue
             raise AssertionError("sweep seed %d case %d: cfg %r K %d lens %r\noracle  %r\noffline %r\nlive    %r" % (
@@ -1135,6 +1158,7 @@ if __name__ == "__main__":
     ap.add_argument("--reset-cases", type=int, default=0, help="live-stream batches with single-stream resets")
     ap.add_argument("--extreme-cases", type=int, default=0, help="single-stream API cases with edge-of-range detector parameters")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
+    ap.add_argument("--ragged-cases", type=int, default=0, help="batch cases in the shapes the opt-in dtw_ragged_kernel takes (mfcc_size 5, 1..9 templates of unequal length, band 3..5), scored with RP_DTW_RAGGED=1")
     ap.add_argument("--mfma-cases", type=int, default=0, help="batch cases in the shapes the matrix-core DTW kernel takes (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates)")
     a = ap.parse_args()
     import rustpotter_amd as ra
@@ -1146,6 +1170,8 @@ if __name__ == "__main__":
          lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
         ("matrix-core DTW sweep", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True),
          lambda r: "%d cases (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates), %d detections compared, %d threshold ties skipped" % r),
+        ("ragged matrix-core DTW sweep (RP_DTW_RAGGED=1)", a.ragged_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, ragged=True),
+         lambda r: "%d cases (mfcc_size 5, 1..9 templates of unequal length, band 3..5; the kernel ran in every case), %d detections compared, %d threshold ties skipped" % r),
         ("live rate sweep", a.rate_cases, lambda n: run_live_rate_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases live == offline bitwise, %d detections equal to the oracle's, %d near-tie cases" % r),
         ("live reset sweep", a.reset_cases, lambda n: run_live_reset_sweep(ra, ctx, n, a.seed, verbose=True),

@@ -260,3 +260,11 @@ def test_detect_only_call_abandons_without_changing_a_detection(ra, ctx):
     for s in range(3):
         for j in range(n_full[s]):
             assert all(det_full[s][j][k] == det_only[s][j][k] for k in ("frame", "window", "counter", "score"))
+
+
+def test_randomised_ragged_sweep(ra, ctx):
+    """16 random (reference of unequal lengths, config, streams) cases against the oracle's chunked detector, the opt-in kernel scoring the
+    offline calls (tests/sweep_parity.py --ragged-cases; the long run is recorded in profiles/sweep_r05.txt)."""
+    import sweep_parity
+    n, total, ties = sweep_parity.run_sweep(ra, ctx, 16, seed=7, ragged=True)
+    assert n == 16 and total >= 5 and ties == 0

@@ -431,7 +431,7 @@ int rp_dtw_score_batch(rp_ctx *ctx, const float *mfcc, size_t S, size_t n_frames
         float *dg = agg ? static_cast<float *>(sg.out(agg, rows * sizeof(float), c->stage_out3)) : nullptr;
         if (rows && (!dm || !ds)) return -1;
         c->time_begin(kKernelDtw);
-        bool ok = hip_ok(launch_dtw(c->stream, c->dtw_work_for(S, rows), td, dm, S, n_frames, 0, n_win, n_win, band_size, score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
+        bool ok = hip_ok(launch_dtw(c->stream, c->dtw_work_for(S, rows * (size_t)(td.rag_count > 1 ? td.rag_count : 1)), td, dm, S, n_frames, 0, n_win, n_win, band_size, score_ref, do_avg ? 1 : 0, ds, da), "dtw kernel");
         c->time_end();
         if (!ok) return -1;
         if (dg) {
@@ -578,7 +578,7 @@ static int batch_detect_impl(rp_ctx *ctx, const void *pcm, rp_sample_format fmt,
                                                  config->avg_threshold, ds, da), "dtw_generic_kernel (gated)");
         } else {
             // ws_mfcc ends with slack: short streams (fewer than 64 windows each) are scored by cross-stream waves like live-stream batches
-            ok = hip_ok(launch_dtw(c->stream, c->dtw_work_for(S, rows), td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
+            ok = hip_ok(launch_dtw(c->stream, c->dtw_work_for(S, rows * (size_t)(td.rag_count > 1 ? td.rag_count : 1)), td, dm, S, nf, 0, n_win, n_win, config->band_size, config->score_ref, do_avg ? 1 : 0, ds, da, true, abandon,
                                    fz.agg ? &fz : nullptr), "dtw kernel");
         }
         c->time_end();

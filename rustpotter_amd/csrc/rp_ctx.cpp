@@ -112,6 +112,8 @@ bool Ctx::ingest_ready() {
 
 DtwWork Ctx::dtw_work_for(size_t S, size_t rows) {
     DtwWork wk = dtw_work();
+    const char *env = std::getenv("RP_DTW_RAGGED");   // the opt-in kernel's blocks are only reserved when it can be taken
+    if (!(env && env[0] == '1')) return wk;
     const size_t prep_bytes = (S * 8 * sizeof(float) + 255) & ~(size_t)255, list_bytes = (rows + 1) * sizeof(uint32_t);
     if (S && rows && rows <= 0xffffffffULL && ws_rag.reserve(prep_bytes + list_bytes + 16)) {
         wk.rag_prep = ws_rag.as<float>();

@@ -1154,7 +1154,8 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
         const int n_avg = (t.has_avg && n1 == t.class_count[3] && n1 > 0) ? 1 : 0;
         if (n_avg)
             if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3] + t.class_count[3] - 1, 1, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
-        const bool list_rows = gl.padded && gl.wk_all.rag_list && gl.wk_all.rag_rows >= S * n_win && out_win_pitch == n_win;
+        // (every ragged chunk lists on its own: a window may be listed once per chunk -- the list holds rows x chunks entries)
+        const bool list_rows = gl.padded && gl.wk_all.rag_list && gl.wk_all.rag_rows >= S * n_win * (size_t)t.rag_count && out_win_pitch == n_win;
         if ((e = launch_dtw_ragged(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, gl.abandon_nc, list_rows)) != hipSuccess) return e;
         if (list_rows) {
             GateList g2 = gl;

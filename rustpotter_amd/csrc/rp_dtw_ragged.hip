@@ -402,7 +402,7 @@ hipError_t launch_dtw_ragged(hipStream_t st, const DtwWork &wk, const TemplatesD
                              size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float abandon_nc, bool list_rows) {
     if (t.rag_count <= 0 || S == 0 || n_win == 0) return hipSuccess;
     if (!wk.fix || !wk.rag_prep || wk.rag_streams < S) return hipErrorInvalidValue;
-    if (list_rows && (!wk.rag_list || wk.rag_rows < S * n_win || S * n_win > 0xffffffffULL)) return hipErrorInvalidValue;
+    if (list_rows && (!wk.rag_list || wk.rag_rows < S * n_win * (size_t)t.rag_count || S * n_win > 0xffffffffULL)) return hipErrorInvalidValue;
     dtw_mark(wk, kDtwRanRagged);
     int F = 0;
     const size_t lds = dtw_ragged_lds_bytes(t, n_win, &F);

@@ -159,7 +159,7 @@ struct DtwWork {
     uint32_t *fix = nullptr;     // [2 + 2 * kDtwFixCap + 2]: the last two words count the pairs rescored since the context was made
     uint32_t *ran = nullptr;     // HOST word (may be null): the launchers OR in the kernel families they launched (kDtwRan*, rp_ctx_dtw_kernels)
     // dtw_ragged_kernel's per-call device blocks (Ctx::dtw_work_for; null: that kernel is not taken): rag_prep [rag_streams][8] floats
-    // (offset and scale of every stream), rag_list [1 + rag_rows] words (the windows to score again with the register kernels)
+    // (offset and scale of every stream), rag_list [1 + rag_rows] words (the windows to score again with the register kernels; rows x ragged chunks)
     float *rag_prep = nullptr;
     uint32_t *rag_list = nullptr;
     size_t rag_streams = 0, rag_rows = 0;

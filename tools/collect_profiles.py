@@ -65,7 +65,7 @@ for k in fe:
 json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
 json.dump(out, open("profiles/%s_final_pmc.json" % R, "w"), indent=1)
 shutil.copy(glob.glob("gpurun_out/prof_final/**/*kernel_stats.csv", recursive=True)[0], "profiles/%s_final_kernel_stats.csv" % R)
-line = [l for l in open("gpurun_out/prof_final_bench.log") if l.startswith("{")][-1]
+line = [l for l in open("gpurun_out/prof_final.log") if l.startswith("{")][-1]
 open("profiles/%s_final_bench_under_rocprof.json" % R, "w").write(line)
 names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk" % R, "stream8": "bench_%s_stream_8chunks" % R,
          "rs_fft": "bench_%s_resample_fft" % R, "rs_gemm": "bench_%s_resample_gemm" % R, "rs_fft_i16_stereo": "bench_%s_resample_fft_i16_stereo" % R,
@@ -76,7 +76,9 @@ names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk
          "gate_04": "bench_%s_avg_gate_04" % R, "gate_04_full": "bench_%s_avg_gate_04_full_scores" % R,
          "two_ranks_one_gpu": "bench_%s_two_ranks_one_gpu_dry_run" % R, "detect_only": "bench_%s_detect_only" % R,
          "detect_only_ragged5": "bench_%s_detect_only_ragged5" % R, "model_small": "bench_%s_model_detector_small" % R, "model_medium": "bench_%s_model_detector_medium" % R, "model_large": "bench_%s_model_detector_large" % R,
-         "ingest_f32": "bench_%s_ingest_f32" % R, "ingest_i16": "bench_%s_ingest_i16" % R}
+         "ingest_f32": "bench_%s_ingest_f32" % R, "ingest_i16": "bench_%s_ingest_i16" % R,
+         "ragged5_matrix": "bench_%s_ragged5_templates_matrix_optin" % R, "ragged3_alexa": "bench_%s_ragged3_alexa_lens" % R,
+         "ragged3_alexa_matrix": "bench_%s_ragged3_alexa_lens_matrix_optin" % R}
 for a, b in names.items():
     src = "gpurun_out/final/%s.json" % a
     if os.path.exists(src) and os.path.getsize(src) > 10:

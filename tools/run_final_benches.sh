@@ -1,6 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): every bench line that profiles/ keeps, into gpurun_out/final/*.json
-# (tools/collect_profiles.py then copies them into profiles/).  Usage: tools/run_final_benches.sh
+# (tools/collect_profiles.py then copies them into profiles/).  Usage: tools/run_final_benches.sh [all]
+# Without `all` only the lines a round usually moves are run (headline, C2, C4 share, the ragged shapes in both forms, mfcc_size 16, C5);
+# the rest of the catalogue (gates, live streams, resampler, model detector, ingest, latency) is re-measured when its code changed.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/final
@@ -13,10 +15,17 @@ $B --no-cpu-baseline --streams 8192 --templates 64 2>/dev/null | line > $O/c4.js
 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --config C4 2>/dev/null | line > $O/c4_one_gpu.json
 RP_BENCH_OVERSUBSCRIBE=1 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --config C4 --gpus 2 2>/dev/null | line > $O/c4_two_ranks_one_gpu.json
 $B --no-cpu-baseline --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5.json
+RP_DTW_RAGGED=1 $B --no-cpu-baseline --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5_matrix.json
+$B --no-cpu-baseline --template-lens 117,126,99 2>/dev/null | line > $O/ragged3_alexa.json
+RP_DTW_RAGGED=1 $B --no-cpu-baseline --template-lens 117,126,99 2>/dev/null | line > $O/ragged3_alexa_matrix.json
+$B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
+$B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_bf16.json
+$B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
+$B --no-cpu-baseline --detect-only --template-lens 108,96,90,93,102 2>/dev/null | line > $O/detect_only_ragged5.json
+if [ "${1:-}" != all ]; then for f in $O/*.json; do echo "$f $(cut -c1-160 $f)"; done; exit 0; fi
 $B --no-cpu-baseline --templates 3 --template-len 126 2>/dev/null | line > $O/t3.json
 $B --no-cpu-baseline --score-mode median 2>/dev/null | line > $O/median.json
 $B --no-cpu-baseline --detect-only 2>/dev/null | line > $O/detect_only.json
-$B --no-cpu-baseline --detect-only --template-lens 108,96,90,93,102 2>/dev/null | line > $O/detect_only_ragged5.json
 $B --no-cpu-baseline --avg-gate 2>/dev/null | line > $O/gate_default.json
 $B --no-cpu-baseline --avg-gate --full-scores 2>/dev/null | line > $O/gate_default_full.json
 $B --no-cpu-baseline --avg-gate --avg-threshold 0.4 2>/dev/null | line > $O/gate_04.json
@@ -27,9 +36,6 @@ $B --no-cpu-baseline --mode stream --chunks-per-call 8 2>/dev/null | line > $O/s
 $B --no-cpu-baseline --mode resample --streams 8192 2>/dev/null | line > $O/rs_fft.json
 RP_RESAMPLE_GEMM=1 $B --no-cpu-baseline --mode resample --streams 8192 2>/dev/null | line > $O/rs_gemm.json
 $B --no-cpu-baseline --mode resample --streams 8192 --pcm-format i16 --channels 2 2>/dev/null | line > $O/rs_fft_i16_stereo.json
-$B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_bf16.json
-$B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
-$B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13.json
 for m in small medium large; do python3 bench.py --mode model --model-type $m --streams 32768 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $O/model_$m.json; done
 python3 bench.py --ingest --ingest-format f32 --no-cpu-baseline 2>/dev/null | line > $O/ingest_f32.json

@@ -119,3 +119,26 @@ def test_forward_of_the_fixture_model_kernel_and_oracle_are_equally_far_from_f64
     assert np.allclose(got16, ref16, rtol=1e-3, atol=1e-3), np.abs(got16 - ref16).max()
     assert e16.max() < 0.05                                  # (the rounding of the inputs itself moves a logit by ~1 % of the row's scale)
     assert np.array_equal(np.argmax(got32, axis=1), np.argmax(tru, axis=1))
+
+
+def test_whole_stream_forward_bits_depend_on_the_stream_alone(ra, ctx):
+    """The whole-stream form of the forward (mlp_windows_kernel: a stream's frames staged once per workgroup, minus the mean of that
+    workgroup's middle window) and the live form (mlp_mfma_kernel: a few new windows per call, the row's own mean) agree to 2e-6, not bit
+    for bit.  What IS bit-stable: a stream's logits do not depend on the batch it is scored in, nor on the call
+    being repeated -- the workgroups of a stream are cut the same way whatever else is in the launch."""
+    m = rpw_py.load_rpw(os.path.join(G, "ok_casa-tiny.rpw"))
+    names = sorted(k[:-7] for k in m["weights"] if k.endswith(".weight"))
+    model = ra.Model(ctx, [m["weights"][n + ".weight"] for n in names], [m["weights"][n + ".bias"] for n in names])
+    K = m["mfcc_size"]
+    rng = np.random.default_rng(12)
+    mf = np.stack([orc.mfcc_stream((rng.standard_normal(480 * 160) * 0.05).astype(np.float32), K) for _ in range(5)])
+    whole = ctx.mlp_forward_windows(mf, model, "f32")
+    assert whole.shape[1] >= 200 and np.isfinite(whole).all()
+    assert np.array_equal(whole, ctx.mlp_forward_windows(mf, model, "f32"))
+    assert np.array_equal(whole[3], ctx.mlp_forward_windows(mf[3:4], model, "f32")[0])
+    assert np.array_equal(whole[1:], ctx.mlp_forward_windows(mf[1:], model, "f32"))
+    # a shorter run of the same stream (fewer than 32 windows: the live form's kernel) -- same logits to 2e-6 of the row's scale
+    L = model.n_in // K
+    short = ctx.mlp_forward_windows(mf[2:3, : L + 20], model, "f32")[0]
+    scale = np.maximum(np.abs(whole[2][:21]).max(axis=1, keepdims=True), 1.0)
+    assert np.all(np.abs(short - whole[2][:21]) <= 2e-6 * scale)

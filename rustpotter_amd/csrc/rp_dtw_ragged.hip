@@ -303,6 +303,8 @@ __global__ __launch_bounds__(64 * kDtwRaggedWaves, 4) void dtw_ragged_kernel(
         RG_LOAD(c + 1)                                                                                                        \
         float arn[K];   /* the unit row that enters the band at the end of this step: requested now */                        \
         _Pragma("unroll") for (int k2 = 0; k2 < K; ++k2) arn[k2] = rows_t[(c + 1 + W) * K + k2];                              \
+        __builtin_amdgcn_sched_barrier(0);   /* the requests go out HERE, a column's cells ahead of their use: left to the scheduler they sink \
+                                                to just before the matrix instructions and every column waits out an LDS + scalar-load round trip */ \
         float up = RP_INF;                                                                                                    \
         _Pragma("unroll") for (int q = 0; q < B; ++q) {                                                                       \
             const int sl = (u + q + NS - W + 2) % NS;                                                                         \

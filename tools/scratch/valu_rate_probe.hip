@@ -61,6 +61,13 @@ __global__ __launch_bounds__(64) void k(float *out, int iters, float seed) {
                 if (OP == 40) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
                 if (OP == 41) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
                 if (OP == 42) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c0));
+                // round 5: the mixed-precision multiply-adds (an f16 source or an f16 result in one instruction) and the round-to-nearest pack
+                if (OP == 43) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(b[i]), "v"(c0));
+                if (OP == 44) asm volatile("v_fma_mixlo_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "v"(c0));
+                if (OP == 45) asm volatile("v_fma_mixhi_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b[i]), "v"(c0));
+                if (OP == 46) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+                if (OP == 47) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(a[i]) : "v"(c0));
+                if (OP == 48) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c0));
             }
         }
     }
@@ -99,5 +106,7 @@ int main() {
     run<31>("v_pk_min_u16", 64, out); run<32>("v_add_u32", 64, out); run<33>("v_fmac_f32", 64, out); run<34>("v_sub_u32", 64, out);
     run<35>("v_mad_u64_u32", 32, out); run<36>("v_lshl_add_u64", 32, out); run<37>("v_add_f32_dpp", 64, out); run<38>("v_mov_b32_dpp", 64, out);
     run<39>("v_mov_b64", 32, out); run<40>("v_log_f32", 64, out); run<41>("v_mul_lo_u32", 64, out); run<42>("v_mad_u32_u24", 64, out);
+    run<43>("v_fma_mix_f32", 64, out); run<44>("v_fma_mixlo_f16", 64, out); run<45>("v_fma_mixhi_f16", 64, out); run<46>("v_cvt_pk_f16_f32", 64, out);
+    run<47>("v_pk_mul_f16", 64, out); run<48>("v_max3_f32", 64, out);
     return 0;
 }

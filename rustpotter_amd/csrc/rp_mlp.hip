@@ -676,6 +676,10 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 // sums of a tile meet in LDS in a fixed order ((q0 + q1) + (q2 + q3)).  Same products as kMlpF16x2 (x0 w0 + x1 w0 + x0 w1), same mean
 // correction, bias, ReLU and tail layers as mlp_mfma_kernel; rows holding a frame beyond the f16 range are listed for the f32 pass.
 // Shapes: mfcc_size 16, layer 1 <= 32 wide, tail layers <= 32 wide, n_win >= 32.
+// BITS: the frames are staged minus the mean of the workgroup's middle window (below), so a window's logits depend on how its stream is cut
+// into workgroups -- which is a function of the stream's window count alone: the same stream gives the same bits alone, in any batch and
+// on every repetition (tests/test_gpu_model_pin.py), but NOT the bits of mlp_mfma_kernel, which live-stream calls with fewer than 32 new
+// windows per stream take (the row's own mean): those agree within the logit gate, 2e-6 on scores.
 constexpr int kWinWaves = 4, kWinTile = 32, kWinMaxTiles = 7, kWinAhead = 3;
 typedef float f32x16w __attribute__((ext_vector_type(16)));
 template <int NT>

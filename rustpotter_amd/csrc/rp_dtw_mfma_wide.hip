@@ -3,10 +3,11 @@
 // lane, 12 circular row slots = 3 MFMA tiles); what changes is the K axis of the product:
 //   * lane half h owns CHM = ceil(K / 2) components (half 1 of mfcc_size 13: six components and a zero);
 //   * per component the three products x0 a0, x1 a0, x0 a1 of the f16 two-way splits: component pairs (a, b) fill three registers
-//     [(x0a, x0b), (x1a, x1b), (x0a, x0b)] against [(a0, a0), (a0, a0), (a1, a1)]; an odd last component two: [(x0, x1), (x0, c)]
-//     against [(a0, a0), (a1, c)]; c = 1.0 in half 1 (the constant of 1 - a.x), else 0; an even count takes one more register (c, 0);
-//   * 13 (mfcc_size 16) / 11 (mfcc_size 13) registers per half = four / three k-steps of v_mfma_f32_32x32x16_f16 per tile, chained on
-//     one accumulator: 12 / 9 MFMAs per column.
+//     [(x0a, x0b), (x1a, x1b), (x0a, x0b)] against [(a0, a0), (a0, a0), (a1, a1)]; an odd last component two: [(x0, x1), (x0, 0)]
+//     against [(a0, a0), (a1, 0)]; the 1 of 1 - a.x is the C operand of the first k-step (the inline constant 1.0: no register, no slot);
+//   * 12 (mfcc_size 16) / 11 (mfcc_size 13) registers per half = three k-steps of v_mfma_f32_32x32x16_f16 per tile, chained on one
+//     accumulator: 9 MFMAs per column (through round 4 the constant was a product slot of its own, which made mfcc_size 16 thirteen
+//     registers = four k-steps = 12 MFMAs per column and a 1 KB template row).
 // The wide register kernels (dtw_band_wide_kernel: two templates per wave, 13 or 16 FMAs per cell) spend 80 % of their cycles on the
 // cost FMAs; here the vector pipe runs the recurrence and the frame work only.
 // Frames are always read from global memory (a frame is 52 / 64 bytes: staging 32 + 2 L of them per wave next to an A image of 0.75 / 1 KB
@@ -77,8 +78,6 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) dl[e] = (unsigned)(((e - jj + NS) % NS) * kRowBytes);
     const int nvalid = h ? K - CHM : CHM;  // components this half really has (mfcc_size 13: 7 and 6)
-    const unsigned c_lo = h ? 0x00003c00u : 0u;                       // (c, 0): the register an even component count adds
-    const unsigned sel_c = h ? 0x07060100u : 0x0c0c0100u;             // (x0, c) of an odd last component: c = 1.0 (half 1) or 0
     const float abandon_cost = abandon_nc * (float)(L + L);
     bool slot_real[4], slot_avg[4];
 #pragma unroll
@@ -182,9 +181,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
             const float us_ = d_[CHM - 1] * inv_;                                                                             \
             const unsigned t_ = pkrtz(us_, 0.f);                                                                              \
             v_[3 * NPAIR] = pk_f16_second(x0f(us_), us_ - x0f(us_)); /* x0 is already an f16 value */                         \
-            v_[3 * NPAIR + 1] = __builtin_amdgcn_perm(0x3c000000u, t_, sel_c);                                                \
-        } else {                                                                                                              \
-            v_[3 * NPAIR] = c_lo;                                                                                             \
+            v_[3 * NPAIR + 1] = t_; /* (x0, 0) */                                                                             \
         }                                                                                                                     \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                                     \
             bop[par][ks] = (u32x4){v_[4 * ks], v_[4 * ks + 1], v_[4 * ks + 2], v_[4 * ks + 3]};                               \
@@ -200,8 +197,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     }
 #define RP_MFMA(g, par)                                                                                                       \
     do {                                                                                                                      \
-        const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  \
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][0]), __builtin_bit_cast(f16x8, bop[par][0]), zero16, 0, 0, 0); \
+        const v16f one16 = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   /* src2 = the inline constant 1.0 */ \
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][0]), __builtin_bit_cast(f16x8, bop[par][0]), one16, 0, 0, 0); \
         _Pragma("unroll") for (int ks = 1; ks < KS; ++ks)                                                                     \
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][ks]), __builtin_bit_cast(f16x8, bop[par][ks]), acc[g], 0, 0, 0); \
     } while (0)

@@ -79,7 +79,7 @@ __host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 
 // dtw_mfma_wide_kernel (mfcc_size 13 / 16): components per lane half and k-steps of 16 f16 slots (rp_dtw_mfma_wide.hip)
 __host__ __device__ constexpr int dtw_mfma_wide_chm(int K) { return (K + 1) / 2; }
 __host__ __device__ constexpr int dtw_mfma_wide_ksteps(int K) {
-    return (3 * (dtw_mfma_wide_chm(K) / 2) + (dtw_mfma_wide_chm(K) % 2 ? 2 : 1) + 3) / 4;
+    return (3 * (dtw_mfma_wide_chm(K) / 2) + (dtw_mfma_wide_chm(K) % 2 ? 2 : 0) + 3) / 4;
 }
 // Tiles a wave of the matrix-core DTW kernels takes by its own index before it turns to the chunk's atomic counter: every whole round
 // of a launch of at most three rounds (live-stream calls, BASELINE config C2 -- the waves start together and would ask for their

@@ -319,7 +319,7 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
         f_exec_mat = sum((mfma_chunks(c)[0] * 3 + mfma_chunks(c)[1] * 2) * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
         f_exec_vec = sum((c - mfma_chunks(c)[2]) * Lt * 2 * W * 3 + (mfma_chunks(c)[0] + mfma_chunks(c)[1]) * Lt * 40 for Lt, c in by_len.items())
     if mfma_wide:
-        ksteps = 4 if K == 16 else 3
+        ksteps = 3   # (round 5: mfcc_size 16 starts its sum at the C operand instead of spending a fourth k-step on the constant slot)
         f_exec_mat = sum(-(-c // 8) * 3 * ksteps * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
         f_exec_vec = sum(c * Lt * 2 * W * 3 + -(-c // 8) * Lt * 8 * K for Lt, c in by_len.items())
     if ragged:
@@ -354,6 +354,18 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
             extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r05_dtw_ragged_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 16-column block of one template for the 64 windows of a wave" % (
+                          mix["classes"]["valu"], mix["classes"]["mfma"], mix["valu_issue_cycles_per_trip"])})
+    elif mfma_wide and K == 16 and n_win >= 32 and load_json("profiles/r05_dtw_mfma_wide_isa_mix.json"):
+        mix = load_json("profiles/r05_dtw_mfma_wide_isa_mix.json")
+        # the hot loop is one block of 12 columns of one 32-window tile of one chunk of up to eight templates
+        trips = sum(-(-c // 8) * Lt / 12.0 for Lt, c in by_len.items()) * -(-rows // 32)
+        cyc = trips * mix["valu_issue_cycles_per_trip"]
+        pipes["valu_issue"] = cyc / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        # a matrix instruction takes ~25 issue cycles away from the vector work beside it (tools/scratch/mfma_valu_overlap_probe.hip, two waves per SIMD)
+        extra["valu_plus_matrix_issue_frac"] = trips * (mix["valu_issue_cycles_per_trip"] + 25.0 * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r05_dtw_mfma_wide_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
+                      "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile (two waves per SIMD: 256 registers)" % (
                           mix["classes"]["valu"], mix["classes"]["mfma"], mix["valu_issue_cycles_per_trip"])})
     else:
         pipes["valu_flops"] = rows * f_exec_vec / dtw_s / VALU_PEAK

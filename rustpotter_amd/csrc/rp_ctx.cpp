@@ -325,10 +325,10 @@ static void append_ragged_image(std::vector<uint16_t> &img, int t, int len, cons
 // dtw_mfma_wide_kernel's A operand of one chunk (rp_dtw_mfma_wide.hip): per template row [k-step][k half 2][template slot 8] x 8 f16.
 // Lane half kh owns components kh * CHM .. kh * CHM + CHM - 1 (zero beyond K).  With a = -(unit row) = a0 + a1 the registers of a half
 // are, per component pair (p, q): (a0p, a0q), (a0p, a0q), (a1p, a1q) against the window side's (x0p, x0q), (x1p, x1q), (x0p, x0q); an odd
-// last component s: (a0s, a0s), (a1s, 0) against (x0s, x1s), (x0s, 0).  (The 1 of 1 - a.x is the instruction's C operand, an inline constant:
-// through round 4 it was a product slot c x c, which cost mfcc_size 16 a fourth k-step for one slot.)
+// last component s: (a0s, a0s), (a1s, c) against (x0s, x1s), (x0s, c), c = 1.0 in half 1 only: the 1 of 1 - a.x.  An even count has no slot
+// left for it: the kernel starts the sum at 1 instead (through round 4 a register (c, 0) of its own cost mfcc_size 16 a fourth k-step).
 static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad, int K) {
-    const int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, KS = dtw_mfma_wide_ksteps(K), row_bytes = KS * 256;
+    const int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, KS = dtw_mfma_wide_ksteps(K), row_bytes = dtw_mfma_wide_row_bytes(K);
     const size_t base = img.size();
     img.resize(base + (size_t)(c.len + 16) * row_bytes / 2, 0);
     for (int r = 0; r < c.len; ++r)
@@ -349,7 +349,7 @@ static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c
                 }
                 if (CHM % 2) {
                     v[2 * (3 * NPAIR) + 0] = part(CHM - 1, 0); v[2 * (3 * NPAIR) + 1] = part(CHM - 1, 0);
-                    v[2 * (3 * NPAIR + 1) + 0] = part(CHM - 1, 1);
+                    v[2 * (3 * NPAIR + 1) + 0] = part(CHM - 1, 1); v[2 * (3 * NPAIR + 1) + 1] = kh ? 0x3c00 : 0;
                 }
                 for (int ks = 0; ks < KS; ++ks)
                     std::memcpy(&img[base + ((size_t)r * row_bytes + ks * 256 + kh * 128 + t * 16) / 2], &v[8 * ks], 16);

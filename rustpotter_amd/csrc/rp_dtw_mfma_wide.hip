@@ -3,11 +3,13 @@
 // lane, 12 circular row slots = 3 MFMA tiles); what changes is the K axis of the product:
 //   * lane half h owns CHM = ceil(K / 2) components (half 1 of mfcc_size 13: six components and a zero);
 //   * per component the three products x0 a0, x1 a0, x0 a1 of the f16 two-way splits: component pairs (a, b) fill three registers
-//     [(x0a, x0b), (x1a, x1b), (x0a, x0b)] against [(a0, a0), (a0, a0), (a1, a1)]; an odd last component two: [(x0, x1), (x0, 0)]
-//     against [(a0, a0), (a1, 0)]; the 1 of 1 - a.x is the C operand of the first k-step (the inline constant 1.0: no register, no slot);
+//     [(x0a, x0b), (x1a, x1b), (x0a, x0b)] against [(a0, a0), (a0, a0), (a1, a1)]; an odd last component two: [(x0, x1), (x0, c)]
+//     against [(a0, a0), (a1, c)]; c = 1.0 in half 1 (the constant of 1 - a.x), else 0.  An even count (mfcc_size 16) has no slot left
+//     over: its 1 is the C operand of the first k-step (round 5; through round 4 it took a thirteenth register = a fourth k-step = 12
+//     MFMAs per column and a 1 KB template row.  The compiler keeps the sixteen ones in registers -- it folds a splat into the
+//     instruction's inline constant only for a single use -- which is still 4 registers fewer than the fourth k-step's operands);
 //   * 12 (mfcc_size 16) / 11 (mfcc_size 13) registers per half = three k-steps of v_mfma_f32_32x32x16_f16 per tile, chained on one
-//     accumulator: 9 MFMAs per column (through round 4 the constant was a product slot of its own, which made mfcc_size 16 thirteen
-//     registers = four k-steps = 12 MFMAs per column and a 1 KB template row).
+//     accumulator: 9 MFMAs per column.
 // The wide register kernels (dtw_band_wide_kernel: two templates per wave, 13 or 16 FMAs per cell) spend 80 % of their cycles on the
 // cost FMAs; here the vector pipe runs the recurrence and the frame work only.
 // Frames are always read from global memory (a frame is 52 / 64 bytes: staging 32 + 2 L of them per wave next to an A image of 0.75 / 1 KB
@@ -40,6 +42,39 @@ __host__ __device__ constexpr int wide_last_use(int u, int g) {
     return last;
 }
 
+// The order and place of a column's MFMAs: a tile is refilled (KS chained k-steps) once its last cell of the column has read it; issued in
+// one burst the second and third k-step wait for the matrix pipe (32 cycles each) with the wave's own vector work queued behind them.
+// Here at most one instruction goes out per band cell: tiles in the order they come free, k-steps in order, the rest after the last cell.
+struct WideIssue { int tile[12], ks[12], at[12]; };
+template <int W, int KS>
+__host__ __device__ constexpr WideIssue wide_issue(int u) {
+    WideIssue s{};
+    int order[kWTiles] = {0, 1, 2}, lu[kWTiles] = {wide_last_use<W>(u, 0), wide_last_use<W>(u, 1), wide_last_use<W>(u, 2)};
+    for (int i = 0; i < kWTiles; ++i)
+        for (int j = i + 1; j < kWTiles; ++j)
+            if (lu[order[j]] < lu[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    int n = 0, prev = -1;
+    for (int i = 0; i < kWTiles; ++i)
+        for (int ks = 0; ks < KS; ++ks) {
+            int at = lu[order[i]] > prev + 1 ? lu[order[i]] : prev + 1;
+            if (at < 0) at = 0;
+            if (at > 2 * W - 1) at = 2 * W - 1;
+            s.tile[n] = order[i]; s.ks[n] = ks; s.at[n] = at;
+            prev = at; ++n;
+        }
+    return s;
+}
+struct WideIssueTable { int at[kWSlots][kWTiles][4]; };   // band cell after which k-step ks of tile g goes out in column phase u
+template <int W, int KS>
+__host__ __device__ constexpr WideIssueTable wide_issue_table() {
+    WideIssueTable t{};
+    for (int u = 0; u < kWSlots; ++u) {
+        const WideIssue s = wide_issue<W, KS>(u);
+        for (int i = 0; i < kWTiles * KS; ++i) t.at[u][s.tile[i]][s.ks[i]] = s.at[i];
+    }
+    return t;
+}
+
 }  // namespace
 
 template <int K, int W, int NW>
@@ -50,7 +85,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds, uint32_t *__restrict__ fix) {
     constexpr int B = 2 * W, NS = kWSlots, NTILE = kWTiles;
     constexpr int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, ODD = CHM % 2, KS = dtw_mfma_wide_ksteps(K);
-    constexpr int kRowBytes = KS * 256;
+    constexpr int kRowBytes = dtw_mfma_wide_row_bytes(K);
+    constexpr WideIssueTable kIssue = wide_issue_table<W, KS>();
     static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 12 row slots");
     size_t total_entries = n_streams * n_win;
     if (list) {
@@ -78,6 +114,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) dl[e] = (unsigned)(((e - jj + NS) % NS) * kRowBytes);
     const int nvalid = h ? K - CHM : CHM;  // components this half really has (mfcc_size 13: 7 and 6)
+    const unsigned sel_c = h ? 0x07060100u : 0x0c0c0100u;             // (x0, c) of an odd last component: c = 1.0 (half 1) or 0
     const float abandon_cost = abandon_nc * (float)(L + L);
     bool slot_real[4], slot_avg[4];
 #pragma unroll
@@ -181,7 +218,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
             const float us_ = d_[CHM - 1] * inv_;                                                                             \
             const unsigned t_ = pkrtz(us_, 0.f);                                                                              \
             v_[3 * NPAIR] = pk_f16_second(x0f(us_), us_ - x0f(us_)); /* x0 is already an f16 value */                         \
-            v_[3 * NPAIR + 1] = t_; /* (x0, 0) */                                                                             \
+            v_[3 * NPAIR + 1] = __builtin_amdgcn_perm(0x3c000000u, t_, sel_c);                                                \
         }                                                                                                                     \
         _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                                     \
             bop[par][ks] = (u32x4){v_[4 * ks], v_[4 * ks + 1], v_[4 * ks + 2], v_[4 * ks + 3]};                               \
@@ -197,10 +234,18 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     }
 #define RP_MFMA(g, par)                                                                                                       \
     do {                                                                                                                      \
-        const v16f one16 = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   /* src2 = the inline constant 1.0 */ \
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][0]), __builtin_bit_cast(f16x8, bop[par][0]), one16, 0, 0, 0); \
+        constexpr float c0_ = ODD ? 0.f : 1.f;   /* an even component count has no product slot for the 1 of 1 - a.x: it starts the sum */ \
+        const v16f init16 = {c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_, c0_};                  \
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][0]), __builtin_bit_cast(f16x8, bop[par][0]), init16, 0, 0, 0); \
         _Pragma("unroll") for (int ks = 1; ks < KS; ++ks)                                                                     \
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][ks]), __builtin_bit_cast(f16x8, bop[par][ks]), acc[g], 0, 0, 0); \
+    } while (0)
+#define RP_MFMA1(g, ks, par)                                                                                                  \
+    do {                                                                                                                      \
+        constexpr float c1_ = ODD ? 0.f : 1.f;                                                                                \
+        const v16f in16_ = {c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_};                   \
+        if ((ks) == 0) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][0]), __builtin_bit_cast(f16x8, bop[par][0]), in16_, 0, 0, 0); \
+        else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g][ks]), __builtin_bit_cast(f16x8, bop[par][ks]), acc[g], 0, 0, 0); \
     } while (0)
 // column c (c = 1 + u mod 12): the B operand of column c + 2 is built first (its frame was requested one column earlier), then the
 // frame of column c + 3 is requested, then the cells; each tile's MFMAs for column c + 1 go out after the last cell that reads the tile
@@ -208,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
     do {                                                                                                                      \
         RP_AREF(c + 1, (u + 1) % NS, GUARD)                                                                                   \
         RP_PREP((u + 1) & 1);                                                                                                 \
-        RP_LOADF(c + 3);                                                                                                      \
+        RP_LOADF(c + 3);   /* (requested two columns ahead through a ring of two: measured, no faster -- the L2 is not what this kernel waits for) */ \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
         v2f up[2] = {(v2f){RP_INF, RP_INF}, (v2f){RP_INF, RP_INF}};                                                           \
         _Pragma("unroll") for (int q = 0; q < B; ++q) {                                                                       \
@@ -224,11 +269,10 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
                 up[p] = v;                                                                                                    \
             }                                                                                                                 \
             _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                 \
-                if (wide_last_use<W>(u, g) == q) RP_MFMA(g, u & 1);                                                           \
+                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                             \
+                    if (kIssue.at[u][g][ks] == q) RP_MFMA1(g, ks, u & 1);                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
-        _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                     \
-            if (wide_last_use<W>(u, g) < 0) RP_MFMA(g, u & 1);                                                                \
     } while (0)
 
         RP_AREF(1, 0, true)
@@ -275,6 +319,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
 #undef RP_ABANDON_CHECK
 #undef RP_STEP
 #undef RP_MFMA
+#undef RP_MFMA1
 #undef RP_AREF
 #undef RP_PREP
 #undef RP_LOADF
@@ -316,7 +361,7 @@ bool dtw_mfma_wide_supported(const TemplatesDev &t, int band, float score_ref) {
     const char *env = std::getenv("RP_DTW_MFMA");
     if ((env && env[0] == '0') || (t.K != 13 && t.K != 16) || band != 5 || !t.aimg || t.wide8_count <= 0 || t.max_diff != 0) return false;
     if (t.mfma_min_len < kWSlots) return false;
-    return (size_t)(t.max_len + 16) * dtw_mfma_wide_ksteps(t.K) * 256 <= 160 * 1024;
+    return (size_t)(t.max_len + 16) * dtw_mfma_wide_row_bytes(t.K) <= 160 * 1024;
 }
 
 hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
@@ -328,7 +373,7 @@ hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const Templat
     dtw_mark(wk, kDtwRanMfmaWide);
     const size_t total_tiles = (S * n_win + kWWin - 1) / kWWin;
     constexpr int NW = 8;
-    const size_t lds = (size_t)(t.max_len + 16) * dtw_mfma_wide_ksteps(t.K) * 256;
+    const size_t lds = (size_t)(t.max_len + 16) * dtw_mfma_wide_row_bytes(t.K);
     size_t groups = (size_t)device_cu_count() / (size_t)n_chunks;
     if (groups < 1) groups = 1;
     const size_t need = (total_tiles + NW - 1) / NW;

@@ -81,6 +81,10 @@ __host__ __device__ constexpr int dtw_mfma_wide_chm(int K) { return (K + 1) / 2;
 __host__ __device__ constexpr int dtw_mfma_wide_ksteps(int K) {
     return (3 * (dtw_mfma_wide_chm(K) / 2) + (dtw_mfma_wide_chm(K) % 2 ? 2 : 0) + 3) / 4;
 }
+// bytes from one template row of the wide A image to the next: the k-steps' 256-byte blocks + 128 -- a ds_read_b128 takes 16 lanes at a
+// time = two row slots x 128 bytes; a pitch that is a multiple of 256 bytes put both on the same 32 banks (SQ_LDS_BANK_CONFLICT = half of
+// the kernel's LDS cycles, profiles/r05_wide_pmc.txt)
+__host__ __device__ constexpr int dtw_mfma_wide_row_bytes(int K) { return dtw_mfma_wide_ksteps(K) * 256 + 128; }
 // Tiles a wave of the matrix-core DTW kernels takes by its own index before it turns to the chunk's atomic counter: every whole round
 // of a launch of at most three rounds (live-stream calls, BASELINE config C2 -- the waves start together and would ask for their
 // tickets together; the counter then hands out what is left), the first round of longer launches (the waves drift apart by themselves

@@ -332,17 +332,32 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
     extra = {}
     mix = load_json("profiles/r04_dtw_mfma_isa_mix.json")
     only_full8 = mfma_used and not mfma_wide and all(mfma_chunks(c)[1] == 0 and mfma_chunks(c)[2] == 0 for c in by_len.values())
+    gmix = load_json("profiles/r05_dtw_mfma_group_isa_mix.json")
+    grouped = bool(ran) and "dtw_mfma_group_kernel" in ran and bool(gmix)
+    if grouped:
+        kernel = "dtw_mfma_group_kernel"
     if mix and only_full8 and n_win >= 32:
         # the hot loop is one block of 12 columns of one 32-window tile of one chunk: a template of L frames is L / 12 trips
         tiles = -(-rows // 32)
         trips = sum(mfma_chunks(c)[0] * Lt / 12.0 for Lt, c in by_len.items()) * tiles
         cyc = trips * mix["valu_issue_cycles_per_trip"]
+        if grouped:   # runs of four chunks of one length share the frame work: the group kernel's own mix for those
+            g_trips = sum((mfma_chunks(c)[0] // 4) * 4 * Lt / 12.0 for Lt, c in by_len.items()) * tiles
+            cyc = (trips - g_trips) * mix["valu_issue_cycles_per_trip"] + g_trips * gmix["valu_issue_cycles_per_trip"]
         pipes["valu_issue"] = cyc / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         if "valu_issue_cycles_per_trip_architectural" in mix:   # the same mix at 2 / 4 / 8 cycles per instruction instead of the measured rates
-            extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+            arch = trips * mix["valu_issue_cycles_per_trip_architectural"]
+            if grouped:
+                arch = (trips - g_trips) * mix["valu_issue_cycles_per_trip_architectural"] + g_trips * gmix["valu_issue_cycles_per_trip_architectural"]
+            extra["frac_at_architectural_rates"] = arch / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r04_dtw_mfma_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
                                                                                                          mix["valu_issue_cycles_per_trip"])})
+        if grouped:
+            extra["isa_mix"] = ("profiles/r05_dtw_mfma_group_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA instructions, %.0f SIMD issue cycles per "
+                                "12-column block of a 32-window tile and chunk (four chunks of one length share a column's operand; %.0f for a chunk outside "
+                                "a group)" % (gmix["classes"]["valu"], gmix["classes"]["mfma"], gmix["valu_issue_cycles_per_trip"], mix["valu_issue_cycles_per_trip"]))
+
     elif ragged and not mfma_used and n_win >= 64 and load_json("profiles/r05_dtw_ragged_isa_mix.json"):
         mix = load_json("profiles/r05_dtw_ragged_isa_mix.json")
         # the hot loop is one block of 16 columns of one template for the 64 windows of a wave
@@ -769,7 +784,7 @@ def extra_c4_share(env, K, N):
     c4 = DtwCase(env, S4, lens4, K, N, first_stream=0)
     dt = c4.time_steps(2, 10)
     k = c4.kernel_times(3)
-    r = dtw_kernel_model(env, S4, c4.n_win, lens4, K, k["dtw"][0] * 1e-3, None)
+    r = dtw_kernel_model(env, S4, c4.n_win, lens4, K, k["dtw"][0] * 1e-3, None, c4.ctx.dtw_kernels())
     res = {"workload": "C4 share: 8192 synthetic 16 kHz f32 streams x 64 templates (one GPU's part of 65 536 x 64 over 8 GPUs)",
            "value": S4 * c4.n_win * 10 / dt, "unit": "scorings/s", "steps": 10, "warmup": 2, "ms_per_step": dt / 10 * 1e3, "dtype": DTYPE_DTW,
            "kernels_ms": {kk: round(v[0], 4) for kk, v in k.items()},

@@ -60,6 +60,7 @@ pub const RP_DTW_KERNEL_REGISTER: c_int = 8;
 pub const RP_DTW_KERNEL_GENERIC: c_int = 16;
 pub const RP_DTW_KERNEL_SINGLE: c_int = 32;
 pub const RP_DTW_KERNEL_REF_ALL: c_int = 64;
+pub const RP_DTW_KERNEL_MFMA_GROUP: c_int = 128;
 pub const RP_MLP_F32: c_int = 0;
 pub const RP_MLP_BF16: c_int = 1;
 pub const RP_MLP_F32_STRICT: c_int = 2;

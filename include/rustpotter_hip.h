@@ -201,7 +201,8 @@ enum {
     RP_DTW_KERNEL_REGISTER = 8,  /* dtw_band_kernel / dtw_band2_kernel / dtw_band_wide_kernel: f32 vector arithmetic throughout */
     RP_DTW_KERNEL_GENERIC = 16,  /* dtw_generic_kernel */
     RP_DTW_KERNEL_SINGLE = 32,   /* dtw_single_kernel (a handful of windows of one stream) */
-    RP_DTW_KERNEL_REF_ALL = 64   /* dtw_ref_kernel over every window (a template row outside the norm range) */
+    RP_DTW_KERNEL_REF_ALL = 64,  /* dtw_ref_kernel over every window (a template row outside the norm range) */
+    RP_DTW_KERNEL_MFMA_GROUP = 128 /* dtw_mfma_group_kernel: several chunks of one template length share a column's operand (same bits as MFMA) */
 };
 int rp_ctx_dtw_kernels(rp_ctx *ctx);
 /* Which build this library is (replaces nothing): the target architecture and the compiler flags it differs by from the

@@ -681,7 +681,7 @@ class BatchContext:
         return int(v.value)
 
     DTW_KERNELS = {1: "dtw_mfma_kernel", 2: "dtw_mfma_wide_kernel", 4: "dtw_ragged_kernel", 8: "register kernels", 16: "dtw_generic_kernel",
-                   32: "dtw_single_kernel", 64: "dtw_ref_kernel (every window)"}
+                   32: "dtw_single_kernel", 64: "dtw_ref_kernel (every window)", 128: "dtw_mfma_group_kernel"}
 
     def dtw_kernels(self):
         """Names of the DTW kernel families this context launched since the last call of this method (rp_ctx_dtw_kernels)."""

@@ -554,6 +554,37 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         if (!hip_ok(hipMalloc(&d.aimg, sizeof(uint16_t) * aimg.size()), "hipMalloc(aimg)")) return nullptr;
         if (!hip_ok(hipMemcpy(d.aimg, aimg.data(), sizeof(uint16_t) * aimg.size(), hipMemcpyHostToDevice), "hipMemcpy(aimg)")) return nullptr;
     }
+    if (K == 5 && d.class_count[2] >= 4 && d.aimg) {   // dtw_mfma_group_kernel: class-2 chunks of one length, four to a workgroup
+        std::vector<int> quads, pairs;   // (pairs: the kernel's two-chunk shape measured SLOWER than dtw_mfma_kernel -- half the sharing does not pay the ring -- never built)
+        std::vector<char> grouped(d.class_count[2], 0);
+        for (int i = 0; i < d.class_count[2];) {
+            int j = i;
+            while (j < d.class_count[2] && chunks[d.class_first[2] + j].len == chunks[d.class_first[2] + i].len) ++j;
+            const int L = chunks[d.class_first[2] + i].len;
+            int b = i;
+            if (dtw_mfma_group_lds_bytes(L, 4) <= 160 * 1024)
+                for (; b + 4 <= j; b += 4) { quads.push_back(d.class_first[2] + b); d.grp4_max_len = std::max(d.grp4_max_len, L); std::fill(grouped.begin() + b, grouped.begin() + b + 4, 1); }
+            i = j;
+        }
+        bool ok = !quads.empty() || !pairs.empty();
+        for (int i = 0; i < d.class_count[2] && ok;) {   // what is left, as runs
+            if (grouped[i]) { ++i; continue; }
+            int j = i;
+            while (j < d.class_count[2] && !grouped[j]) ++j;
+            if (d.rest_runs == 8) { ok = false; break; }
+            d.rest_first[d.rest_runs] = d.class_first[2] + i; d.rest_count[d.rest_runs] = j - i; ++d.rest_runs;
+            i = j;
+        }
+        if (ok) {
+            std::vector<int> all(quads);
+            all.insert(all.end(), pairs.begin(), pairs.end());
+            if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.grp_first), sizeof(int) * all.size()), "hipMalloc(grp_first)")) return nullptr;
+            if (!hip_ok(hipMemcpy(d.grp_first, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice), "hipMemcpy(grp_first)")) return nullptr;
+            d.grp_count = (int)all.size(); d.grp4_count = (int)quads.size();
+        } else {
+            d.rest_runs = 0;
+        }
+    }
     d.n_chunks_total = (int)chunks.size();
     if (d.n_chunks_total > kDtwSchedChunks) { set_last_error("wakeword reference with too many template lengths for the device kernels"); return nullptr; }
     return tp.release();
@@ -567,6 +598,7 @@ Templates::~Templates() {
     if (dev.aimg) (void)hipFree(dev.aimg);
     if (dev.raw) (void)hipFree(dev.raw);
     if (dev.rimg) (void)hipFree(dev.rimg);
+    if (dev.grp_first) (void)hipFree(dev.grp_first);
     if (dev.rag_off) (void)hipFree(dev.rag_off);
 }
 

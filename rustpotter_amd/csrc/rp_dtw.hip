@@ -1177,9 +1177,19 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
             if ((e = launch_dtw_mfma(st, gl.work(), t, W, 4, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                      scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse)) != hipSuccess) return e;
         } else if ((e = launch_dtw_class<5, W, 4>(st, t, t.class_first[1], t.class_count[1], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl)) != hipSuccess) return e;
-        if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8, score_ref))
+        if (t.class_count[2] > 0 && dtw_mfma_supported(t, W, n_win, from_global, 8, score_ref)) {
+            // several chunks of one length, every window of a long batch scored: the workgroups that share a column's B operand among four
+            // (two) chunks (rp_dtw_mfma_group.hip: same bits); the chunks outside a group, and every other mode, keep dtw_mfma_kernel
+            if (!from_global && !gl.count && !gl.fuse && !(gl.abandon_nc < RP_INF) && dtw_mfma_group_supported(t, W, n_win, S, score_ref)) {
+                if ((e = launch_dtw_mfma_group(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores)) != hipSuccess) return e;
+                for (int r = 0; r < t.rest_runs; ++r)
+                    if ((e = launch_dtw_mfma(st, gl.work(), t, W, 8, t.rest_first[r], t.rest_count[r], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+                                             scores, avg, false, nullptr, nullptr, 0, gl.abandon_nc, nullptr)) != hipSuccess) return e;
+                return hipSuccess;
+            }
             return launch_dtw_mfma(st, gl.work(), t, W, 8, t.class_first[2], t.class_count[2], mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
                                    scores, avg, from_global, gl.list, gl.count, gl.dense_min, gl.abandon_nc, gl.fuse);
+        }
     }
     // Small batches: tc-8 waves run two per SIMD; a launch that fills those slots 2.x times leaves the chip mostly idle in
     // its last round.  The same templates as tc-4 half chunks are twice as many waves of 0.83 of the length (measured at C2), three per SIMD

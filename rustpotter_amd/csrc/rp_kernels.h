@@ -138,6 +138,11 @@ struct TemplatesDev {
     // dtw_ragged_kernel (rp_dtw_ragged.hip, mfcc_size 5): the sample templates the equal-length matrix kernel does not take (lengths that
     // occur once or twice) as chunks of up to 8 templates of ANY lengths, shortest first; rimg = per template its A image, 32 bytes per
     // row ([k half 2] x 8 f16: the negated unit row split in two f16 parts) + 16 zero rows, rag_off[t] its offset in 16-byte units
+    // dtw_mfma_group_kernel (rp_dtw_mfma_group.hip): runs of 4 (the first grp4_count entries) or 2 consecutive class-2 chunks of one template
+    // length, grp_first[] (device) the first chunk of each; rest_*: the class-2 chunks outside every group, as runs for dtw_mfma_kernel
+    int *grp_first = nullptr;
+    int grp_count = 0, grp4_count = 0, grp4_max_len = 0, grp2_max_len = 0;
+    int rest_runs = 0, rest_first[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rest_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rag_first = 0, rag_count = 0;
     int rag_min_len = 0;      // shortest template among them (needs >= 16 frames)
     int rag_a_cap = 0;        // largest chunk's images in bytes
@@ -169,7 +174,7 @@ struct DtwWork {
     size_t rag_streams = 0, rag_rows = 0;
 };
 // == RP_DTW_KERNEL_* (include/rustpotter_hip.h)
-enum : uint32_t { kDtwRanMfma = 1u, kDtwRanMfmaWide = 2u, kDtwRanRagged = 4u, kDtwRanRegister = 8u, kDtwRanGeneric = 16u, kDtwRanSingle = 32u, kDtwRanRefAll = 64u };
+enum : uint32_t { kDtwRanMfma = 1u, kDtwRanMfmaWide = 2u, kDtwRanRagged = 4u, kDtwRanRegister = 8u, kDtwRanGeneric = 16u, kDtwRanSingle = 32u, kDtwRanRefAll = 64u, kDtwRanMfmaGroup = 128u };
 inline void dtw_mark(const DtwWork &wk, uint32_t bit) { if (wk.ran) *wk.ran |= bit; }
 __host__ __device__ inline unsigned long long *dtw_fix_stats(uint32_t *fix) { return reinterpret_cast<unsigned long long *>(fix + 2 + 2 * (size_t)kDtwFixCap); }
 // (dtw_fix_append, the kernels' side of the list: rp_device.h)
@@ -197,6 +202,10 @@ struct DtwFusedAgg {
     float threshold = 0.f;
     bool done = false;
 };
+size_t dtw_mfma_group_lds_bytes(int L, int sh);
+bool dtw_mfma_group_supported(const TemplatesDev &t, int band, size_t n_win, size_t S, float score_ref);
+hipError_t launch_dtw_mfma_group(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch,
+                                 size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores);
 hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
                            size_t frame_pitch, size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg,
                            bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,

@@ -14,6 +14,7 @@ CASES = [
     ("rp_mfcc.hip", "mfcc_kernel<true, 6, float, false>", [], "profiles/r04_mfcc_isa_mix.json"),
     ("rp_dtw_ragged.hip", "dtw_ragged_kernel<5>", ["--min-mfma", "32"], "profiles/r05_dtw_ragged_isa_mix.json"),
     ("rp_dtw_mfma_wide.hip", "dtw_mfma_wide_kernel<16, 5, 8>", ["--min-mfma", "100"], "profiles/r05_dtw_mfma_wide_isa_mix.json"),
+    ("rp_dtw_mfma_group.hip", "dtw_mfma_group_kernel<5, 4>", ["--min-mfma", "36"], "profiles/r05_dtw_mfma_group_isa_mix.json"),
 ]
 
 

@@ -59,6 +59,11 @@ def make_case(rng, extreme=False, mfma=False, ragged=False):
             lens[: int(rng.integers(1, 4))] = rng.integers(12, 110)
         elif K != 5 and T >= 6 and rng.random() < 0.4:
             lens[: T // 2] = int(rng.integers(12, 110))  # two lengths, three or more templates each
+        if K == 5 and rng.random() < 0.12:  # round 5: four or five chunks of one length -- dtw_mfma_group_kernel (run_sweep forces it below its size rule)
+            T = int(rng.integers(32, 45))
+            lens = np.full(T, int(rng.integers(12, 108)))
+            if rng.random() < 0.4:
+                lens[: int(rng.integers(1, 4))] = rng.integers(12, 110)
     if ragged:  # the shapes dtw_ragged_kernel takes (opt-in, RP_DTW_RAGGED=1): mfcc_size 5, templates whose lengths all differ (sometimes one pair)
         K = 5
         T = int(rng.integers(1, 10))
@@ -194,11 +199,15 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False, 
         if ragged:
             os.environ["RP_DTW_RAGGED"] = "1"
             ctx.dtw_kernels()
+        if mfma:
+            os.environ["RP_DTW_GROUP"] = "2"   # references with four chunks of one length: the group form whatever the launch size (same bits: live == offline stays exact)
         try:
             offline, live, agg = device_detections(ra, ctx, case)
         finally:
             if ragged:
                 del os.environ["RP_DTW_RAGGED"]
+            if mfma:
+                del os.environ["RP_DTW_GROUP"]
         if ragged:
             assert "dtw_ragged_kernel" in ctx.dtw_kernels(), "ragged sweep seed %d case %d: the kernel did not run (lens %r cfg %r)" % (
                 seed, ci, [len(t) for t in case["templates"]], case["cfg"])
@@ -1159,7 +1168,7 @@ if __name__ == "__main__":
     ap.add_argument("--extreme-cases", type=int, default=0, help="single-stream API cases with edge-of-range detector parameters")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
     ap.add_argument("--ragged-cases", type=int, default=0, help="batch cases in the shapes the opt-in dtw_ragged_kernel takes (mfcc_size 5, 1..9 templates of unequal length, band 3..5), scored with RP_DTW_RAGGED=1")
-    ap.add_argument("--mfma-cases", type=int, default=0, help="batch cases in the shapes the matrix-core DTW kernel takes (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates)")
+    ap.add_argument("--mfma-cases", type=int, default=0, help="batch cases in the shapes the matrix-core DTW kernel takes (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44: dtw_mfma_group_kernel)")
     a = ap.parse_args()
     import rustpotter_amd as ra
     ctx = ra.BatchContext(0)
@@ -1169,7 +1178,7 @@ if __name__ == "__main__":
         ("sweep", a.cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
         ("matrix-core DTW sweep", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True),
-         lambda r: "%d cases (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates), %d detections compared, %d threshold ties skipped" % r),
+         lambda r: "%d cases (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44: dtw_mfma_group_kernel), %d detections compared, %d threshold ties skipped" % r),
         ("ragged matrix-core DTW sweep (RP_DTW_RAGGED=1)", a.ragged_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, ragged=True),
          lambda r: "%d cases (mfcc_size 5, 1..9 templates of unequal length, band 3..5; the kernel ran in every case), %d detections compared, %d threshold ties skipped" % r),
         ("live rate sweep", a.rate_cases, lambda n: run_live_rate_sweep(ra, ctx, n, a.seed, verbose=True),

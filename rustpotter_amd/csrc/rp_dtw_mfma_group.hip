@@ -131,11 +131,25 @@ __global__ __launch_bounds__(64 * kGWaves, 1) void dtw_mfma_group_kernel(
         const float *xw = xs + (inA ? n : ((n - nA < nB) ? segA + n - nA : 0)) * K;
         const float *xa = xw + (h ? 3 : 0);
         const float *x2 = xw + 2;
-        // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums (of this lane's three components)
+        // MfccNormalizer::normalize, src/mfcc/normalizer.rs:17-29: sequential column sums of this lane's three components -- the SH waves of a
+        // tile need the same means: with four chunks wave 0 / 1 / 2 sums one component each for all of them (same additions in the same order)
         float mua = 0.f, mub = 0.f, mu2 = 0.f;
+        if (SH == 4) {
+            if (ci < 3) {
+                const float *xp = ci == 0 ? xa : ci == 1 ? xa + 1 : x2;
+                float acc_ = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
-        mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;
+                for (int i = 0; i < L; ++i) acc_ += xp[i * K];
+                chk_lds[(tj * SH + ci) * 64 + lane] = acc_ / (float)L;
+            }
+            __syncthreads();
+            mua = chk_lds[(tj * SH + 0) * 64 + lane]; mub = chk_lds[(tj * SH + 1) * 64 + lane]; mu2 = chk_lds[(tj * SH + 2) * 64 + lane];
+            // (the range tests reuse these words at the end of the tile, behind the column loop's barriers)
+        } else {
+#pragma unroll 8
+            for (int i = 0; i < L; ++i) { mua += xa[i * K]; mub += xa[i * K + 1]; mu2 += x2[i * K]; }
+            mua = mua / (float)L; mub = mub / (float)L; mu2 = mu2 / (float)L;
+        }
 
         v2f Q[NP][B + 1];
 #pragma unroll

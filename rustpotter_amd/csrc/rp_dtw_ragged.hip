@@ -265,6 +265,7 @@ __global__ __launch_bounds__(64 * kDtwRaggedWaves, 4) void dtw_ragged_kernel(
             v16f acc;   // one tile: the instruction pair of column c + 1 is issued behind the last cell of column c and lands under the norm and row work
             u32x4 Bc1, Bc2;
             float xr[K], kap[2], kmax = 0.f;
+            float nd_[K], nbb_ = 0.f, nk_ = 0.f, ng_ = 0.f;
 
 // kappa of the frame in xr[] (the window's column cc): 1 / (s |x - mu|), 0 for the zero vector (similarity 0, comparator.rs:43-47)
 #define RG_NORM(dst)                                                                                                          \
@@ -293,10 +294,19 @@ __global__ __launch_bounds__(64 * kDtwRaggedWaves, 4) void dtw_ragged_kernel(
         const int ri_ = (rn) - 1;                                                                                             \
         if (jA0 == (slot)) A0 = *reinterpret_cast<const u32x4 *>(aimg_t + ri_ * 32);                                          \
         if (jA1 == (slot)) A1 = *reinterpret_cast<const u32x4 *>(aimg_t + ri_ * 32);                                          \
-        float g_ = arn[0] * dl[0];                                                                                            \
-        _Pragma("unroll") for (int k2 = 1; k2 < K; ++k2) g_ = fmaf(arn[k2], dl[k2], g_);                                      \
-        G[slot] = g_;                                                                                                         \
+        RG_G_OF_ROW(slot)                                                                                                     \
     }
+#define RG_G_OF_ROW(slot) G[slot] = ng_;
+// The norm of column c + 1 and the G of the row that enters the ring stand in pieces BETWEEN the cells of column c (none of them depends on
+// the cells; the slot the new row takes is outside the band of the matrix instructions that follow): in one piece behind the cells they
+// were a chain of ~20 dependent instructions the wave waited on by itself -- 3 % of the kernel, measured interleaved on one box
+#define RG_PIECES_AT(q)                                                                                                       \
+    if ((q) == (1 * B) / 10) { _Pragma("unroll") for (int j = 0; j < K; ++j) nd_[j] = fmaf(xr[j], s, nmus[j]); }               \
+    if ((q) == (4 * B) / 10) { nbb_ = nd_[0] * nd_[0]; _Pragma("unroll") for (int j = 1; j < K; ++j) nbb_ = fmaf(nd_[j], nd_[j], nbb_); } \
+    if ((q) == (7 * B) / 10) { nk_ = nbb_ > 0.f ? __builtin_amdgcn_rsqf(nbb_) : 0.f; kmax = fmaxf(kmax, nk_); }                \
+    if ((q) == (8 * B) / 10) { ng_ = arn[0] * dl[0]; _Pragma("unroll") for (int k2 = 1; k2 < K; ++k2) ng_ = fmaf(arn[k2], dl[k2], ng_); } \
+    __builtin_amdgcn_sched_barrier(0);
+#define RG_NORM_TAIL(dst) { dst = nk_; }
 // column c = c0 + u: rows r_q = c - W + 1 + q, q = 0..2W-1, sit in slot (u + q + 2 - W) mod 16
 #define RG_STEP(GUARD)                                                                                                        \
     do {                                                                                                                      \
@@ -314,11 +324,12 @@ __global__ __launch_bounds__(64 * kDtwRaggedWaves, 4) void dtw_ragged_kernel(
             if (GUARD) v = (c - W + 1 + q >= 1) ? v : RP_INF;                                                                 \
             Q[q] = v;                                                                                                         \
             up = v;                                                                                                           \
+            RG_PIECES_AT(q)                                                                                                   \
         }                                                                                                                     \
         asm volatile("" ::"v"(acc));   /* every row slot of the tile stays allocated until here: no other value moves into the registers \
                                           of the slots outside the band while the instruction pair that fills them is in flight */         \
         RG_MFMA()                                                                                                             \
-        RG_NORM(kap[(u + 1) & 1])                                                                                             \
+        RG_NORM_TAIL(kap[(u + 1) & 1])                                                                                        \
         /* the row update below is a pair of exec-masked loads = basic-block boundaries: without these anchors the compiler sinks the \
            cells of a whole 16-column block behind them and keeps sixteen accumulator tiles alive */                                 \
         _Pragma("unroll") for (int q = 0; q < B; ++q) asm volatile("" : "+v"(Q[q]));                                          \
@@ -360,6 +371,9 @@ __global__ __launch_bounds__(64 * kDtwRaggedWaves, 4) void dtw_ragged_kernel(
             }
 #undef RG_ABANDON_CHECK
 #undef RG_STEP
+#undef RG_PIECES_AT
+#undef RG_G_OF_ROW
+#undef RG_NORM_TAIL
 #undef RG_ROW
 #undef RG_MFMA
 #undef RG_LOAD

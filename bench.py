@@ -103,7 +103,7 @@ def n_simds(torch, dev):
     return 4 * torch.cuda.get_device_properties(dev).multi_processor_count
 
 
-ROOFLINE_FIRST = ("bound", "kernel", "frac", "frac_at_architectural_rates", "achieved", "peak", "unit", "avg_launch_ms", "traffic", "traffic_over_algorithmic",
+ROOFLINE_FIRST = ("bound", "kernel", "frac", "frac_at_architectural_rates", "valu_plus_matrix_issue_frac", "achieved", "peak", "unit", "avg_launch_ms", "traffic", "traffic_over_algorithmic",
                   "effective_clock_ghz", "valu_issue_frac_at_effective_clock", "strict_f32_value", "strict_f32_ms_per_step", "strict_f32_steps",
                   "strict_f32_mfcc_ms", "strict_f32_dtw_ms", "strict_f32_aggregate_ms", "path_hbm_frac", "path_ref_flop_rate_vs_vector_peak",
                   "mfcc_ms", "dtw_ms", "aggregate_ms", "scan_ms", "algorithmic_bytes_per_launch", "ref_flop_rate_vs_vector_peak")
@@ -353,6 +353,9 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
         extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r04_dtw_mfma_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
                                                                                                          mix["valu_issue_cycles_per_trip"])})
+        # a matrix instruction takes ~19 issue cycles from the vector work beside it at three waves per SIMD (tools/scratch/mfma_valu_overlap_probe.hip:
+        # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions)
+        extra["valu_plus_matrix_issue_frac"] = (cyc + 19.0 * trips * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         if grouped:
             extra["isa_mix"] = ("profiles/r05_dtw_mfma_group_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA instructions, %.0f SIMD issue cycles per "
                                 "12-column block of a 32-window tile and chunk (four chunks of one length share a column's operand; %.0f for a chunk outside "

@@ -41,8 +41,13 @@ HBM_PEAK = 8.0e12      # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 VALU_PEAK = 157.3e12   # FLOP/s fp32 vector, same table
 MFMA_F16_PEAK = 2.5e15  # FLOP/s dense f16 / bf16 MFMA, same table
 CLOCK_PEAK = 2.4e9     # Hz, peak shader clock, same table
-DTYPE_DTW = "f32 (cosine products: f16x2-split MFMA, 22-bit)"
+# the arithmetic of the path: f32 throughout; the cosine products of the DTW cost are f32 vector FMAs ("strict_f32"), or formed on the matrix
+# cores from exact three-part bf16 splits of both f32 operands with f32 accumulation ("f32_matrix", the library default: f32-grade, pinned by
+# tests/test_gpu_dtw_f64.py), or -- opt-in, narrower than the reference -- from two-part f16 splits ("fast_split")
+DTYPE_DTW = "f32"
+DTYPE_DTW_FAST = "f32 (cosine products: f16x2-split MFMA, 22-bit -- RP_ARITH_FAST_SPLIT, narrower than the reference)"
 DTYPE_DTW_VECTOR = "f32"
+MIX_MFMA = {"bf16x3": "profiles/dtw_mfma_isa_mix.json", "f16x2": "profiles/dtw_mfma_f16x2_isa_mix.json"}
 
 
 def self_launch(n):
@@ -174,6 +179,10 @@ def main():
                     "(ScoreMode::Max) may abandon DTWs that can no longer reach the threshold (same detections; NOT the headline workload, which "
                     "scores every window against every template)")
     ap.add_argument("--full-scores", action="store_true", help="with --avg-gate: compare every window with every template anyway (RP_CTX_FULL_SCORES)")
+    ap.add_argument("--arith", choices=["f32_matrix", "strict_f32", "fast_split"], default="f32_matrix",
+                    help="rp_ctx arithmetic of the DTW cost's cosine products (include/rustpotter_hip.h RP_ARITH_*): f32_matrix = the library default "
+                         "(matrix cores, three bf16 parts per operand: f32-grade), strict_f32 = f32 vector FMAs only, fast_split = two f16 parts (22-bit)")
+    ap.add_argument("--ragged-matrix", action="store_true", help="with --arith fast_split: references of unequal template lengths on dtw_ragged_kernel (RP_CTX_RAGGED_MATRIX)")
     args = ap.parse_args()
     args.total_streams = None
     if args.config == "C2":
@@ -289,7 +298,7 @@ def cells(Lt, W=5):
     return sum((min(Lt, r + W - 1) - max(1, r - W) + 1) for r in range(1, Lt))
 
 
-def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
+def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None, products=None):
     """Pipe fractions of the DTW kernel of one launch (S x n_win windows x templates `lens`) that took dtw_s seconds.
     valu_issue: SIMD issue cycles of the hot loop (committed ISA mix x rate table) x trips / (SIMDs x 2.4 GHz); mfma_f16: executed
     matrix flops / 2.5 PFLOP/s; hbm: algorithmic bytes / 8 TB/s; valu_flops (kernels without a committed mix): executed vector flops /
@@ -299,9 +308,12 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
     by_len = {}
     for Lt in lens:
         by_len[Lt] = by_len.get(Lt, 0) + 1
-    mfma_on = os.environ.get("RP_DTW_MFMA", "1")[:1] != "0" and min(lens) >= 12
-    mfma_wide = mfma_on and K in (13, 16) and all(c >= 3 for c in by_len.values())
-    mfma_used = mfma_wide or (mfma_on and K == 5 and any(c >= 3 for c in by_len.values()))
+    # what ran is what the library says ran (rp_ctx_dtw_kernels); products: "bf16x3" (two matrix instructions per tile) / "f16x2" (one)
+    ran = ran or []
+    prod = (products or ["f16x2"])[0] if any("mfma" in r or "ragged" in r for r in ran) else None
+    ksteps5 = 2 if prod == "bf16x3" else 1
+    mfma_wide = "dtw_mfma_wide_kernel" in ran
+    mfma_used = mfma_wide or "dtw_mfma_kernel" in ran or "dtw_mfma_group_kernel" in ran
     kernel = "dtw_mfma_wide_kernel" if mfma_wide else "dtw_mfma_kernel" if mfma_used else "dtw_band_kernel" if K == 5 else "dtw_band_wide_kernel"
     # templates whose length occurs once or twice: dtw_ragged_kernel when the library says it ran (rp_ctx_dtw_kernels)
     rag_lens = [Lt for Lt, c in by_len.items() for _ in range(c if c <= 2 else (c % 8 if c % 8 <= 2 else 0))] if K == 5 else []
@@ -316,7 +328,7 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
         full, rem = divmod(c, 8)
         return full + (1 if rem >= 5 else 0), 1 if 3 <= rem <= 4 else 0, rem if rem <= 2 else 0
     if mfma_used and not mfma_wide:
-        f_exec_mat = sum((mfma_chunks(c)[0] * 3 + mfma_chunks(c)[1] * 2) * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
+        f_exec_mat = ksteps5 * sum((mfma_chunks(c)[0] * 3 + mfma_chunks(c)[1] * 2) * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
         f_exec_vec = sum((c - mfma_chunks(c)[2]) * Lt * 2 * W * 3 + (mfma_chunks(c)[0] + mfma_chunks(c)[1]) * Lt * 40 for Lt, c in by_len.items())
     if mfma_wide:
         ksteps = 3   # (round 5: mfcc_size 16 starts its sum at the C operand instead of spending a fourth k-step on the constant slot)
@@ -330,9 +342,10 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
     alg_bytes = rows * (4 * K + 4 * (T + 2))
     pipes = {"hbm": alg_bytes / dtw_s / HBM_PEAK, "mfma_f16": rows * f_exec_mat / dtw_s / MFMA_F16_PEAK}
     extra = {}
-    mix = load_json("profiles/r04_dtw_mfma_isa_mix.json")
+    mix_path = MIX_MFMA.get(prod, MIX_MFMA["f16x2"])
+    mix = load_json(mix_path)
     only_full8 = mfma_used and not mfma_wide and all(mfma_chunks(c)[1] == 0 and mfma_chunks(c)[2] == 0 for c in by_len.values())
-    gmix = load_json("profiles/r05_dtw_mfma_group_isa_mix.json")
+    gmix = load_json("profiles/dtw_mfma_group_isa_mix.json")
     grouped = bool(ran) and "dtw_mfma_group_kernel" in ran and bool(gmix)
     if grouped:
         kernel = "dtw_mfma_group_kernel"
@@ -350,19 +363,19 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
             if grouped:
                 arch = (trips - g_trips) * mix["valu_issue_cycles_per_trip_architectural"] + g_trips * gmix["valu_issue_cycles_per_trip_architectural"]
             extra["frac_at_architectural_rates"] = arch / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
-        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r04_dtw_mfma_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
+        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": mix_path + " x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
                                                                                                          mix["valu_issue_cycles_per_trip"])})
         # a matrix instruction takes ~19 issue cycles from the vector work beside it at three waves per SIMD (tools/scratch/mfma_valu_overlap_probe.hip:
         # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions)
         extra["valu_plus_matrix_issue_frac"] = (cyc + 19.0 * trips * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         if grouped:
-            extra["isa_mix"] = ("profiles/r05_dtw_mfma_group_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA instructions, %.0f SIMD issue cycles per "
+            extra["isa_mix"] = ("profiles/dtw_mfma_group_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA instructions, %.0f SIMD issue cycles per "
                                 "12-column block of a 32-window tile and chunk (four chunks of one length share a column's operand; %.0f for a chunk outside "
                                 "a group)" % (gmix["classes"]["valu"], gmix["classes"]["mfma"], gmix["valu_issue_cycles_per_trip"], mix["valu_issue_cycles_per_trip"]))
 
-    elif ragged and not mfma_used and n_win >= 64 and load_json("profiles/r05_dtw_ragged_isa_mix.json"):
-        mix = load_json("profiles/r05_dtw_ragged_isa_mix.json")
+    elif ragged and not mfma_used and n_win >= 64 and load_json("profiles/dtw_ragged_isa_mix.json"):
+        mix = load_json("profiles/dtw_ragged_isa_mix.json")
         # the hot loop is one block of 16 columns of one template for the 64 windows of a wave
         trips = sum(Lt / 16.0 for Lt in rag_lens) * -(-rows // 64)
         cyc = trips * mix["valu_issue_cycles_per_trip"]
@@ -370,11 +383,11 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
         pipes["lds"] = trips * mix["lds_cycles_per_trip"] / (n_simds(torch, env.dev) / 4 * CLOCK_PEAK * dtw_s)
         if "valu_issue_cycles_per_trip_architectural" in mix:
             extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
-        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r05_dtw_ragged_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
+        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/dtw_ragged_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 16-column block of one template for the 64 windows of a wave" % (
                           mix["classes"]["valu"], mix["classes"]["mfma"], mix["valu_issue_cycles_per_trip"])})
-    elif mfma_wide and K == 16 and n_win >= 32 and load_json("profiles/r05_dtw_mfma_wide_isa_mix.json"):
-        mix = load_json("profiles/r05_dtw_mfma_wide_isa_mix.json")
+    elif mfma_wide and K == 16 and n_win >= 32 and load_json("profiles/dtw_mfma_wide_isa_mix.json"):
+        mix = load_json("profiles/dtw_mfma_wide_isa_mix.json")
         # the hot loop is one block of 12 columns of one 32-window tile of one chunk of up to eight templates
         trips = sum(-(-c // 8) * Lt / 12.0 for Lt, c in by_len.items()) * -(-rows // 32)
         cyc = trips * mix["valu_issue_cycles_per_trip"]
@@ -382,7 +395,7 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
         extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         # a matrix instruction takes ~25 issue cycles away from the vector work beside it (tools/scratch/mfma_valu_overlap_probe.hip, two waves per SIMD)
         extra["valu_plus_matrix_issue_frac"] = trips * (mix["valu_issue_cycles_per_trip"] + 25.0 * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
-        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/r05_dtw_mfma_wide_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
+        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/dtw_mfma_wide_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile (two waves per SIMD: 256 registers)" % (
                           mix["classes"]["valu"], mix["classes"]["mfma"], mix["valu_issue_cycles_per_trip"])})
     else:
@@ -405,9 +418,12 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None):
     else:
         r.update({"achieved": rows * f_exec_vec / dtw_s / 1e12, "peak": VALU_PEAK / 1e12, "unit": "TFLOP/s"})
     r.update(extra)
+    if prod:
+        r["products"] = prod
     r["note"] = ("frac = the largest pipe fraction of the kernel; every entry of `pipes` is executed work / (pipe peak x measured launch time).  "
-                 "dtw_mfma_kernel / dtw_ragged_kernel form the cosine products of a band column with v_mfma_f32_32x32x16_f16 (f16 two-way splits of both operands, "
-                 "f32 accumulate) and run the min-recurrence on the vector pipe: VALU issue binds them.  ref_flop_rate_vs_vector_peak prices the "
+                 "dtw_mfma_kernel forms the cosine products of a band column on the matrix cores -- products bf16x3: both f32 operands as three bf16 parts "
+                 "(exact), two v_mfma_f32_32x32x16_bf16 per tile and column, f32 accumulate (f32-grade, the default); products f16x2: two f16 parts, one "
+                 "v_mfma_f32_32x32x16_f16 (22-bit, opt-in) -- and runs the min-recurrence on the vector pipe: VALU issue binds it.  ref_flop_rate_vs_vector_peak prices the "
                  "REFERENCE-shaped flop count (SURVEY 8d: 2K+7 flops per band cell) against the 157.3 TFLOP/s vector peak as earlier rounds' `frac` "
                  "did -- it exceeds 1 because those products left the vector pipe, it is not a fraction of a roof")
     return r
@@ -418,14 +434,14 @@ def mfcc_kernel_model(env, S, nf, K, mfcc_s, pmc_mfcc=None):
     alg_bytes, flops = S * nf * (640 + 4 * K), S * nf * 13.2e3
     pipes = {"hbm": alg_bytes / mfcc_s / HBM_PEAK, "valu_flops_ref": flops / mfcc_s / VALU_PEAK}
     extra = {}
-    mix = load_json("profiles/r04_mfcc_isa_mix.json")
+    mix = load_json("profiles/mfcc_isa_mix.json")
     if mix and K == 5:
         trips = S * nf / 4.0   # one trip of the tile loop = 4 frames of one wave
         pipes["valu_issue"] = trips * mix["valu_issue_cycles_per_trip"] / (n_simds(torch, env.dev) * CLOCK_PEAK * mfcc_s)
         pipes["lds"] = trips * mix["lds_cycles_per_trip"] / (n_simds(torch, env.dev) / 4 * CLOCK_PEAK * mfcc_s)
         if "valu_issue_cycles_per_trip_architectural" in mix:
             extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * mfcc_s)
-        extra["isa_mix"] = ("profiles/r04_mfcc_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d LDS instructions, %.0f SIMD issue cycles and %d "
+        extra["isa_mix"] = ("profiles/mfcc_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d LDS instructions, %.0f SIMD issue cycles and %d "
                             "LDS-array cycles per 4-frame tile of a wave" % (mix["classes"]["valu"], mix["classes"]["lds"], mix["valu_issue_cycles_per_trip"],
                                                                              mix["lds_cycles_per_trip"]))
     if pmc_mfcc and "effective_clock_ghz" in pmc_mfcc and "valu_issue" in pipes:   # the chip clocks below its 2.4 GHz peak under this load
@@ -479,7 +495,8 @@ class DtwCase:
         self.T, self.L = len(lens), max(lens)
         self.nf = ra.mfcc_num_frames(N)
         self.n_win = self.nf - self.L + 1
-        self.ctx = ctx or ra.BatchContext(device=env.local_rank, host_pointers=False, full_scores=full_scores)
+        self.ctx = ctx or ra.BatchContext(device=env.local_rank, host_pointers=False, full_scores=full_scores, arithmetic=getattr(env.args, "arith", "f32_matrix"),
+                                          ragged_matrix=getattr(env.args, "ragged_matrix", False))
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         # templates: T synthetic utterances, MFCC by the HIP path, whole-matrix mean normalisation, cut to their
         # length.  Identical arrays are handed to the CPU baseline.
@@ -575,8 +592,10 @@ def bench_dtw(env):
     ran = case.ctx.dtw_kernels()   # the DTW kernel families those calls launched (rp_ctx_dtw_kernels)
     pmc, pmc_src = pmc_for(S, N, T, L, K, lens, args)
     dtw_s, mfcc_s = k_ms["dtw"][0] * 1e-3, k_ms["mfcc"][0] * 1e-3
-    r_dtw = dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc.get("dtw"), ran)
+    products = list(case.ctx.last_dtw_products)
+    r_dtw = dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc.get("dtw"), ran, products)
     r_dtw["dtw_kernels_launched"] = ", ".join(ran)
+    r_dtw["arithmetic"] = args.arith
     r_mfcc = mfcc_kernel_model(env, S, nf, K, mfcc_s, pmc.get("mfcc"))
     for r, kn in ((r_dtw, "dtw"), (r_mfcc, "mfcc")):
         r["launches_timed"] = k_ms[kn][1]
@@ -640,7 +659,7 @@ def bench_dtw(env):
         "metric": "10ms-frame MFCC+DTW scorings/sec", "value": value, "unit": "scorings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if args.total_streams is None else "strong", "vs_baseline": None,
-        "dtype": DTYPE_DTW if mfma_kernel else DTYPE_DTW_VECTOR, "data": "synthetic", "config": config,
+        "dtype": DTYPE_DTW_FAST if "f16x2" in products else DTYPE_DTW, "data": "synthetic", "config": config,
         # work is skipped by design in detect-only / gated runs: pricing the full flop count against the shorter time would
         # print a fraction above 1, so those lines carry the kernel times only
         "roofline": roofline if not work_skipped else None,
@@ -674,16 +693,10 @@ def bench_dtw(env):
     # step count as the headline (at least 10); the scalars sit inside `roofline`, which the driver's record keeps
     if world == 1 and not work_skipped and not args.avg_gate and mfma_kernel and not args.no_extras:
         steps_v = max(10, args.steps)
-        os.environ["RP_DTW_MFMA"] = "0"   # read per call by the library
-        rag = os.environ.pop("RP_DTW_RAGGED", None)
-        try:
+        with case.ctx.arithmetic("strict_f32"):   # rp_ctx_set_arithmetic: read per call by the library
             dtv = case.time_steps(2, steps_v)
             kv = case.kernel_times(3)
-        finally:
-            del os.environ["RP_DTW_MFMA"]
-            if rag is not None:
-                os.environ["RP_DTW_RAGGED"] = rag
-        strict = {"what": "RP_DTW_MFMA=0: every DTW kernel of the register family (dtw_band_kernel: the five multiply-adds of a cell as "
+        strict = {"what": "RP_ARITH_STRICT_F32: every DTW kernel of the register family (dtw_band_kernel: the five multiply-adds of a cell as "
                           "v_pk_fma_f32; every product, sum and norm in f32)", "dtype": DTYPE_DTW_VECTOR, "value": S * n_win * steps_v / dtv, "unit": "scorings/s",
                   "steps": steps_v, "ms_per_step": dtv / steps_v * 1e3, "kernels_ms": {k: round(v[0], 4) for k, v in kv.items()},
                   "executed_vector_flop_frac": S * n_win * (sum((Lt - 1) * 10 * (2 * K + 3) for Lt in lens) + n_chunks * ((L - 1) * (4 * K + 1) + L * K)) /
@@ -693,6 +706,12 @@ def bench_dtw(env):
         roofline.update({"strict_f32_value": strict["value"], "strict_f32_ms_per_step": strict["ms_per_step"], "strict_f32_steps": steps_v,
                          "strict_f32_mfcc_ms": strict["kernels_ms"]["mfcc"], "strict_f32_dtw_ms": strict["kernels_ms"]["dtw"],
                          "strict_f32_aggregate_ms": strict["kernels_ms"]["aggregate"]})
+        if args.arith == "f32_matrix":   # for the record: the opt-in two-part f16 products (22-bit: NOT the reference's precision) on the same inputs
+            with case.ctx.arithmetic("fast_split", args.ragged_matrix):
+                dtf = case.time_steps(2, steps_v)
+                kf = case.kernel_times(3)
+            roofline.update({"fast_split_value": S * n_win * steps_v / dtf, "fast_split_ms_per_step": dtf / steps_v * 1e3, "fast_split_dtw_ms": kf["dtw"][0],
+                             "fast_split_note": "RP_ARITH_FAST_SPLIT (two f16 parts per operand, 22-bit products): opt-in, narrower than the reference's f32"})
     roofline["path"] = {"hbm_frac": roofline["path_hbm_frac"], "ref_flop_rate_vs_vector_peak": roofline["path_ref_flop_rate_vs_vector_peak"],
                         "bytes_per_scoring": 640 + 4 * (T + 2), "ref_flops_per_scoring": 13.2e3 * nf / n_win + f_dtw_ref}
 
@@ -769,8 +788,10 @@ def extra_c2(env, case, lens, K, N):
     c2.scores, c2.agg = case.scores[:S2], case.agg[:S2]
     c2.det, c2.n_det = case.det[:S2], case.n_det[:S2]
     dt = c2.time_steps(5, 50)
+    c2.ctx.dtw_kernels()
     k = c2.kernel_times(5)
-    r = dtw_kernel_model(env, S2, case.n_win, lens, K, k["dtw"][0] * 1e-3, None)
+    ran2 = c2.ctx.dtw_kernels()
+    r = dtw_kernel_model(env, S2, case.n_win, lens, K, k["dtw"][0] * 1e-3, None, ran2, list(c2.ctx.last_dtw_products))
     return {"workload": "C2: 1024 synthetic 16 kHz f32 streams x %d templates (same input, templates and context as the headline run)" % case.T,
             "value": S2 * case.n_win * 50 / dt, "unit": "scorings/s", "steps": 50, "warmup": 5, "ms_per_step": dt / 50 * 1e3, "dtype": DTYPE_DTW,
             "kernels_ms": {kk: round(v[0], 4) for kk, v in k.items()},
@@ -787,7 +808,8 @@ def extra_c4_share(env, K, N):
     c4 = DtwCase(env, S4, lens4, K, N, first_stream=0)
     dt = c4.time_steps(2, 10)
     k = c4.kernel_times(3)
-    r = dtw_kernel_model(env, S4, c4.n_win, lens4, K, k["dtw"][0] * 1e-3, None, c4.ctx.dtw_kernels())
+    ran4 = c4.ctx.dtw_kernels()
+    r = dtw_kernel_model(env, S4, c4.n_win, lens4, K, k["dtw"][0] * 1e-3, None, ran4, list(c4.ctx.last_dtw_products))
     res = {"workload": "C4 share: 8192 synthetic 16 kHz f32 streams x 64 templates (one GPU's part of 65 536 x 64 over 8 GPUs)",
            "value": S4 * c4.n_win * 10 / dt, "unit": "scorings/s", "steps": 10, "warmup": 2, "ms_per_step": dt / 10 * 1e3, "dtype": DTYPE_DTW,
            "kernels_ms": {kk: round(v[0], 4) for kk, v in k.items()},

@@ -53,6 +53,16 @@ pub const RP_CTX_DEVICE_POINTERS: c_int = 0;
 pub const RP_CTX_HOST_POINTERS: c_int = 1;
 /// compare every window with every sample template even where the averaged-template gate would skip them
 pub const RP_CTX_FULL_SCORES: c_int = 2;
+/// arithmetic of the DTW cost's cosine products (neither bit: `RP_ARITH_F32_MATRIX`)
+pub const RP_CTX_ARITH_STRICT_F32: c_int = 4;
+pub const RP_CTX_ARITH_FAST_SPLIT: c_int = 8;
+pub const RP_CTX_RAGGED_MATRIX: c_int = 16;
+/// matrix cores, both operands as three bf16 parts (exact), f32 accumulate: f32-grade (default)
+pub const RP_ARITH_F32_MATRIX: c_int = 0;
+/// f32 vector FMAs for every product
+pub const RP_ARITH_STRICT_F32: c_int = 1;
+/// matrix cores, two f16 parts per operand (22 bits): fastest, narrower than the reference's f32 products
+pub const RP_ARITH_FAST_SPLIT: c_int = 2;
 pub const RP_DTW_KERNEL_MFMA: c_int = 1;
 pub const RP_DTW_KERNEL_MFMA_WIDE: c_int = 2;
 pub const RP_DTW_KERNEL_RAGGED: c_int = 4;
@@ -61,6 +71,8 @@ pub const RP_DTW_KERNEL_GENERIC: c_int = 16;
 pub const RP_DTW_KERNEL_SINGLE: c_int = 32;
 pub const RP_DTW_KERNEL_REF_ALL: c_int = 64;
 pub const RP_DTW_KERNEL_MFMA_GROUP: c_int = 128;
+pub const RP_DTW_PRODUCTS_BF16X3: c_int = 256;
+pub const RP_DTW_PRODUCTS_F16X2: c_int = 512;
 pub const RP_MLP_F32: c_int = 0;
 pub const RP_MLP_BF16: c_int = 1;
 pub const RP_MLP_F32_STRICT: c_int = 2;
@@ -113,6 +125,8 @@ extern "C" {
     pub fn rp_ctx_synchronize(ctx: *mut rp_ctx) -> c_int;
     pub fn rp_ctx_dtw_ref_pairs(ctx: *mut rp_ctx, pairs: *mut u64) -> c_int;
     pub fn rp_ctx_dtw_kernels(ctx: *mut rp_ctx) -> c_int;
+    pub fn rp_ctx_set_arithmetic(ctx: *mut rp_ctx, arith: c_int, ragged_matrix: c_int) -> c_int;
+    pub fn rp_ctx_arithmetic(ctx: *mut rp_ctx, ragged_matrix: *mut c_int) -> c_int;
     pub fn rp_ctx_last_mlp_kernel(ctx: *mut rp_ctx) -> *const c_char;
     pub fn rp_build_info() -> *const c_char;
     pub fn rp_sharded_gather_info() -> *const c_char;
@@ -382,8 +396,18 @@ impl HipContext {
         let p = unsafe { rp_ctx_last_mlp_kernel(self.h) };
         if p.is_null() { String::new() } else { unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned() }
     }
-    /// mask of `RP_DTW_KERNEL_*`: the DTW kernel families launched since the last call
+    /// mask of `RP_DTW_KERNEL_*` | `RP_DTW_PRODUCTS_*`: the DTW kernel families launched since the last call and their product arithmetic
     pub fn dtw_kernels(&self) -> u32 { unsafe { rp_ctx_dtw_kernels(self.h) as u32 } }
+    /// `RP_ARITH_*` for the calls that follow (the reference has one arithmetic, f32: `src/mfcc/comparator.rs:28-48`)
+    pub fn set_arithmetic(&self, arith: c_int, ragged_matrix: bool) -> Result<(), String> {
+        status(unsafe { rp_ctx_set_arithmetic(self.h, arith, ragged_matrix as c_int) })
+    }
+    /// the current `RP_ARITH_*` and the ragged-matrix flag
+    pub fn arithmetic(&self) -> (c_int, bool) {
+        let mut r: c_int = 0;
+        let a = unsafe { rp_ctx_arithmetic(self.h, &mut r) };
+        (a, r != 0)
+    }
     /// (window, templates) pairs rescored with the reference-shaped cosine (`sqrt(dot_a * dot_b)`, src/mfcc/comparator.rs:28-48) so far
     pub fn dtw_ref_pairs(&self) -> Result<u64, String> {
         let mut v: u64 = 0;

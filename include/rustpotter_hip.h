@@ -175,10 +175,33 @@ typedef struct rp_templates rp_templates;
  * averaged-template gate (avg_threshold != 0, wakeword_comp.rs:85-93) would skip them or the running cost already rules a
  * detection out -- the behaviour of the per-window score outputs, forced for calls that do not ask for them (same
  * detections either way; used to time the paths against each other). */
-enum { RP_CTX_DEVICE_POINTERS = 0, RP_CTX_HOST_POINTERS = 1, RP_CTX_FULL_SCORES = 2 };
+enum {
+    RP_CTX_DEVICE_POINTERS = 0, RP_CTX_HOST_POINTERS = 1, RP_CTX_FULL_SCORES = 2,
+    /* the arithmetic of the context's DTW scoring (RP_ARITH_* below; neither bit: RP_ARITH_F32_MATRIX) */
+    RP_CTX_ARITH_STRICT_F32 = 4, RP_CTX_ARITH_FAST_SPLIT = 8,
+    /* with RP_CTX_ARITH_FAST_SPLIT: references whose templates differ in length also go to the matrix cores (dtw_ragged_kernel) */
+    RP_CTX_RAGGED_MATRIX = 16
+};
 
-/* device: HIP device ordinal.  Fails (<0) if no HIP device is usable. */
+/* device: HIP device ordinal.  Fails (<0) if no HIP device is usable, or when both RP_CTX_ARITH_* bits are set. */
 int rp_ctx_new(int device, int flags, rp_ctx **out);
+/* The arithmetic of the cosine products of the DTW cost (replaces the implicit "f32" of src/mfcc/comparator.rs:28-48, whose products and
+ * sums are f32 -- the config-is-a-struct convention of src/config.rs:172-219, not an environment variable).  The window mean, the norms, the
+ * min-plus recurrence, the score and every index are f32 / integer arithmetic in every mode; the modes differ in where the five products of
+ * a band cell are formed and how many bits of them are kept:
+ *   RP_ARITH_F32_MATRIX (default)  matrix cores, f32-grade: both operands as three bf16 parts (exact: 3 x 8 = an f32's 24 significant bits),
+ *       six of the nine partial products accumulated in f32 -- what is dropped is below 2^-22 of a product (2^-25.7 rms; an f32 multiply
+ *       rounds by up to 2^-24, 2^-25.3 rms).  Template sets with no such kernel (unequal lengths, mfcc_size 13 / 16, a band other than
+ *       3..5) run the f32 vector kernels.
+ *   RP_ARITH_STRICT_F32            f32 vector FMAs for every product (the "register" kernels), nothing on the matrix cores.
+ *   RP_ARITH_FAST_SPLIT            matrix cores with two f16 parts per operand (22 significant bits, one partial product dropped): the
+ *       fastest form, NARROWER than the reference's f32 products; scores stay within the 1e-5 parity gate for score_ref >= 0.05.
+ *       ragged_matrix != 0 additionally sends references of unequal template lengths to dtw_ragged_kernel (same two-part products).
+ * May be changed between calls (a template set serves every mode); rp_ctx_dtw_kernels reports what ran.  Returns 0, <0 on a bad value. */
+enum { RP_ARITH_F32_MATRIX = 0, RP_ARITH_STRICT_F32 = 1, RP_ARITH_FAST_SPLIT = 2 };
+int rp_ctx_set_arithmetic(rp_ctx *ctx, int arith, int ragged_matrix);
+/* the current RP_ARITH_* (ragged_matrix, if not NULL, receives the flag) */
+int rp_ctx_arithmetic(rp_ctx *ctx, int *ragged_matrix);
 void rp_ctx_free(rp_ctx *ctx);
 /* Run subsequent launches on an externally owned hipStream_t (e.g. the caller's
  * torch stream); NULL = the context's own stream. */
@@ -202,7 +225,10 @@ enum {
     RP_DTW_KERNEL_GENERIC = 16,  /* dtw_generic_kernel */
     RP_DTW_KERNEL_SINGLE = 32,   /* dtw_single_kernel (a handful of windows of one stream) */
     RP_DTW_KERNEL_REF_ALL = 64,  /* dtw_ref_kernel over every window (a template row outside the norm range) */
-    RP_DTW_KERNEL_MFMA_GROUP = 128 /* dtw_mfma_group_kernel: several chunks of one template length share a column's operand (same bits as MFMA) */
+    RP_DTW_KERNEL_MFMA_GROUP = 128, /* dtw_mfma_group_kernel: several chunks of one template length share a column's operand (same bits as MFMA) */
+    /* the product arithmetic of the matrix-core launches among the above */
+    RP_DTW_PRODUCTS_BF16X3 = 256,  /* three bf16 parts per operand: f32-grade (RP_ARITH_F32_MATRIX) */
+    RP_DTW_PRODUCTS_F16X2 = 512    /* two f16 parts per operand: 22 bits (RP_ARITH_FAST_SPLIT) */
 };
 int rp_ctx_dtw_kernels(rp_ctx *ctx);
 /* Which build this library is (replaces nothing): the target architecture and the compiler flags it differs by from the

@@ -8,5 +8,5 @@ the shared library is missing, or no HIP device is usable, the calls raise.
 from .api import (  # noqa: F401
     AudioFmt, BandPassConfig, BatchContext, DetectorConfig, Endianness, FiltersConfig,
     GainNormalizationConfig, Model, Rustpotter, RustpotterConfig, RustpotterDetection, RustpotterError,
-    SampleFormat, ScoreMode, StreamBatch, Templates, VADMode, batch_detect_sharded, batch_detect_sharded_dev, build_info, sharded_gather_info, lib_path, load_library, mfcc_num_frames, resampler_frame_lengths,
+    SampleFormat, ScoreMode, StreamBatch, Templates, VADMode, arithmetic_all, batch_detect_sharded, batch_detect_sharded_dev, build_info, sharded_gather_info, lib_path, load_library, mfcc_num_frames, resampler_frame_lengths,
 )

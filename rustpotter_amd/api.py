@@ -5,6 +5,7 @@ src/detector.rs, src/config.rs) so that the parity tests read like the reference
 own tests (tests/detector.rs).
 """
 import ctypes as C
+import weakref
 import enum
 import os
 
@@ -102,7 +103,7 @@ SYMBOLS = [
     "rp_get_partial_detection", "rp_get_rms_level", "rp_get_gain", "rp_get_rms_level_ref", "rp_process_bytes",
     "rp_process_samples_i8", "rp_process_samples_i16", "rp_process_samples_i32", "rp_process_samples_f32",
     "rp_update_config", "rp_update_detector_config", "rp_update_filters_config", "rp_reset", "rp_last_error",
-    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_dtw_kernels", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_batch_detect_ingest", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
+    "rp_ctx_new", "rp_ctx_free", "rp_ctx_set_stream", "rp_ctx_synchronize", "rp_ctx_dtw_ref_pairs", "rp_ctx_dtw_kernels", "rp_ctx_set_arithmetic", "rp_ctx_arithmetic", "rp_ctx_last_mlp_kernel", "rp_build_info", "rp_sharded_gather_info", "rp_mfcc_num_frames", "rp_mfcc_batch", "rp_mfcc_batch_fmt", "rp_batch_detect_fmt", "rp_batch_detect_ingest", "rp_frontend_batch", "rp_wakeword_ref_build", "rp_buffer_free",
     "rp_templates_new", "rp_templates_free", "rp_templates_max_len", "rp_dtw_score_batch", "rp_detect_scan", "rp_batch_detect",
     "rp_model_new", "rp_model_free", "rp_mlp_forward_batch", "rp_mlp_forward_windows", "rp_synth_pcm_batch", "rp_ctx_timing_enable", "rp_ctx_timing_read", "rp_ctx_timing_reset",
     "rp_version", "rp_stream_batch_new", "rp_stream_batch_free", "rp_stream_batch_process", "rp_stream_batch_reset",
@@ -169,6 +170,10 @@ def load_library():
     L.rp_ctx_dtw_ref_pairs.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rp_ctx_dtw_kernels.argtypes = [vp]
     L.rp_ctx_dtw_kernels.restype = C.c_int
+    L.rp_ctx_set_arithmetic.argtypes = [vp, C.c_int, C.c_int]
+    L.rp_ctx_set_arithmetic.restype = C.c_int
+    L.rp_ctx_arithmetic.argtypes = [vp, C.POINTER(C.c_int)]
+    L.rp_ctx_arithmetic.restype = C.c_int
     L.rp_sharded_gather_info.argtypes = []
     L.rp_sharded_gather_info.restype = C.c_char_p
     L.rp_build_info.argtypes = []
@@ -641,19 +646,72 @@ def batch_detect_sharded_dev(ctxs, templates, pcm_ptrs, S_list, N, stride, detec
 MLP_PRECISION = {"f32": 0, "bf16": 1, "f32_strict": 2}   # RP_MLP_F32 / RP_MLP_BF16 / RP_MLP_F32_STRICT
 
 
+_LIVE_CONTEXTS = weakref.WeakSet()   # every BatchContext alive (arithmetic_all)
+
+
+class arithmetic_all:
+    """Context manager for tests: every live BatchContext runs the calls inside with this arithmetic (rp_ctx_set_arithmetic on each),
+    contexts made inside start with it too, and every setting comes back afterwards.  What the RP_DTW_MFMA / RP_DTW_RAGGED environment
+    switches of rounds 3-5 did, through the ABI."""
+
+    def __init__(self, arithmetic, ragged_matrix=False):
+        self.arithmetic, self.ragged = arithmetic, ragged_matrix
+
+    def __enter__(self):
+        self.saved = [(c, c.get_arithmetic()) for c in list(_LIVE_CONTEXTS) if getattr(c, "_h", None)]
+        for c, _ in self.saved:
+            c.set_arithmetic(self.arithmetic, self.ragged)
+        return self
+
+    def __exit__(self, *a):
+        for c, old in self.saved:
+            if getattr(c, "_h", None):
+                c.set_arithmetic(*old)
+
+
 class BatchContext:
     """rp_ctx.  host_pointers=True: numpy in / numpy out (tests); False: raw device
     pointers (bench.py passes torch tensors' data_ptr())."""
 
-    def __init__(self, device=0, host_pointers=True, full_scores=False):
+    # RP_ARITH_* (include/rustpotter_hip.h): the arithmetic of the DTW cost's cosine products
+    ARITH = {"f32_matrix": 0, "strict_f32": 1, "fast_split": 2}
+
+    def __init__(self, device=0, host_pointers=True, full_scores=False, arithmetic="f32_matrix", ragged_matrix=False):
         """full_scores (RP_CTX_FULL_SCORES): batch_detect compares every window with every sample template even where the
-        averaged-template gate would skip them."""
+        averaged-template gate would skip them.  arithmetic / ragged_matrix: RP_CTX_ARITH_* / RP_CTX_RAGGED_MATRIX."""
         self._L = load_library()
         self._h = C.c_void_p()
         self.host = host_pointers
-        if self._L.rp_ctx_new(device, (1 if host_pointers else 0) | (2 if full_scores else 0), C.byref(self._h)) < 0:
+        flags = (1 if host_pointers else 0) | (2 if full_scores else 0) | {0: 0, 1: 4, 2: 8}[self.ARITH[arithmetic]] | (16 if ragged_matrix else 0)
+        if self._L.rp_ctx_new(device, flags, C.byref(self._h)) < 0:
             self._h = None
             raise _err()
+        _LIVE_CONTEXTS.add(self)
+
+    def set_arithmetic(self, arithmetic, ragged_matrix=False):
+        """rp_ctx_set_arithmetic: "f32_matrix" (default: three bf16 parts, f32-grade), "strict_f32" (vector FMAs only), "fast_split" (two f16 parts)."""
+        if self._L.rp_ctx_set_arithmetic(self._h, self.ARITH[arithmetic], 1 if ragged_matrix else 0) < 0:
+            raise _err()
+
+    def get_arithmetic(self):
+        """(name, ragged_matrix) of rp_ctx_arithmetic."""
+        r = C.c_int(0)
+        m = int(self._L.rp_ctx_arithmetic(self._h, C.byref(r)))
+        return {v: k for k, v in self.ARITH.items()}[m], bool(r.value)
+
+    def arithmetic(self, arithmetic, ragged_matrix=False):
+        """Context manager: the calls inside run with this arithmetic, the previous setting comes back afterwards."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self):
+                self.old = ctx.get_arithmetic()
+                ctx.set_arithmetic(arithmetic, ragged_matrix)
+                return ctx
+
+            def __exit__(self, *a):
+                ctx.set_arithmetic(*self.old)
+        return _Scope()
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -682,10 +740,12 @@ class BatchContext:
 
     DTW_KERNELS = {1: "dtw_mfma_kernel", 2: "dtw_mfma_wide_kernel", 4: "dtw_ragged_kernel", 8: "register kernels", 16: "dtw_generic_kernel",
                    32: "dtw_single_kernel", 64: "dtw_ref_kernel (every window)", 128: "dtw_mfma_group_kernel"}
+    DTW_PRODUCTS = {256: "bf16x3", 512: "f16x2"}
 
     def dtw_kernels(self):
         """Names of the DTW kernel families this context launched since the last call of this method (rp_ctx_dtw_kernels)."""
         m = int(self._L.rp_ctx_dtw_kernels(self._h))
+        self.last_dtw_products = [n for b, n in self.DTW_PRODUCTS.items() if m & b]   # the matrix-core launches' product arithmetic
         return [n for b, n in self.DTW_KERNELS.items() if m & b]
 
     # --- numpy convenience (host_pointers=True)

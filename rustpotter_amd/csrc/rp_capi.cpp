@@ -184,8 +184,11 @@ int rp_ctx_new(int device, int flags, rp_ctx **out) {
     return guarded([&]() -> int {
         if (!out) { set_last_error("null argument"); return -1; }
         *out = nullptr;
+        if ((flags & RP_CTX_ARITH_STRICT_F32) && (flags & RP_CTX_ARITH_FAST_SPLIT)) { set_last_error("RP_CTX_ARITH_STRICT_F32 and RP_CTX_ARITH_FAST_SPLIT exclude each other"); return -1; }
         std::unique_ptr<Ctx> c(Ctx::create(device, flags));
         if (!c) return -1;
+        c->arith.mode = (flags & RP_CTX_ARITH_STRICT_F32) ? kArithStrictF32 : (flags & RP_CTX_ARITH_FAST_SPLIT) ? kArithFastSplit : kArithF32Matrix;
+        c->arith.ragged = (flags & RP_CTX_RAGGED_MATRIX) ? 1 : 0;
         rp_ctx *h = new rp_ctx();
         h->impl = std::move(c);
         *out = h;
@@ -202,6 +205,20 @@ int rp_ctx_synchronize(rp_ctx *ctx) {
     if (!ctx) { set_last_error("null handle"); return -1; }
     if (!hip_ok(hipSetDevice(ctx->impl->device), "hipSetDevice")) return -1;
     return hip_ok(hipStreamSynchronize(ctx->impl->stream), "hipStreamSynchronize") ? 0 : -1;
+}
+
+static_assert(RP_ARITH_F32_MATRIX == kArithF32Matrix && RP_ARITH_STRICT_F32 == kArithStrictF32 && RP_ARITH_FAST_SPLIT == kArithFastSplit, "RP_ARITH_* mirror rp_kernels.h");
+int rp_ctx_set_arithmetic(rp_ctx *ctx, int arith, int ragged_matrix) {
+    if (!ctx) { set_last_error("null handle"); return -1; }
+    if (arith != RP_ARITH_F32_MATRIX && arith != RP_ARITH_STRICT_F32 && arith != RP_ARITH_FAST_SPLIT) { set_last_error("unknown RP_ARITH_* value"); return -1; }
+    ctx->impl->arith.mode = arith;
+    ctx->impl->arith.ragged = ragged_matrix ? 1 : 0;
+    return 0;
+}
+int rp_ctx_arithmetic(rp_ctx *ctx, int *ragged_matrix) {
+    if (!ctx) { set_last_error("null handle"); return -1; }
+    if (ragged_matrix) *ragged_matrix = ctx->impl->arith.ragged;
+    return ctx->impl->arith.mode;
 }
 
 int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs) {

@@ -112,8 +112,7 @@ bool Ctx::ingest_ready() {
 
 DtwWork Ctx::dtw_work_for(size_t S, size_t rows) {
     DtwWork wk = dtw_work();
-    const char *env = std::getenv("RP_DTW_RAGGED");   // the opt-in kernel's blocks are only reserved when it can be taken
-    if (!(env && env[0] == '1')) return wk;
+    if (!(arith.mode == kArithFastSplit && arith.ragged)) return wk;   // the opt-in kernel's blocks are only reserved when it can be taken
     const size_t prep_bytes = (S * 8 * sizeof(float) + 255) & ~(size_t)255, list_bytes = (rows + 1) * sizeof(uint32_t);
     if (S && rows && rows <= 0xffffffffULL && ws_rag.reserve(prep_bytes + list_bytes + 16)) {
         wk.rag_prep = ws_rag.as<float>();
@@ -298,6 +297,67 @@ static void append_mfma_image(std::vector<uint16_t> &img, const DtwChunk &c, con
         }
 }
 
+// f32 -> bf16 bits, round to nearest even (the values split here are finite)
+static uint16_t bf16_rtn_bits(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_bits_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+// a = p0 + p1 + p2 EXACTLY, three bf16 values (8 significant bits each: an f32 has 24).  Rounded to nearest so that p1, p2 are symmetric about
+// zero (the partial products the kernel drops -- x1 p2, x2 p1, x2 p2 -- are zero-mean); truncation, always exact, if a rounding carried a part
+// out of reach (it cannot for normal values; subnormal leftovers are cut, far below anything the kernel resolves).
+static void bf16_split3(float a, uint16_t p[3]) {
+    p[0] = bf16_rtn_bits(a);
+    const float r1 = a - bf16_bits_to_f32(p[0]);
+    p[1] = bf16_rtn_bits(r1);
+    const float r2 = r1 - bf16_bits_to_f32(p[1]);
+    p[2] = bf16_rtn_bits(r2);
+    if (bf16_bits_to_f32(p[0]) + bf16_bits_to_f32(p[1]) + bf16_bits_to_f32(p[2]) != a) {   // (each partial sum is exact in f32 when the split is)
+        uint32_t u;
+        std::memcpy(&u, &a, 4);
+        p[0] = (uint16_t)(u >> 16);
+        const float t1 = a - bf16_bits_to_f32(p[0]);
+        std::memcpy(&u, &t1, 4);
+        p[1] = (uint16_t)(u >> 16);
+        const float t2 = t1 - bf16_bits_to_f32(p[1]);
+        std::memcpy(&u, &t2, 4);
+        p[2] = (uint16_t)(u >> 16);
+    }
+}
+
+// dtw_mfma_kernel's A operand of one chunk in the f32-grade form (kArithF32Matrix; rp_dtw_mfma.hip, P3): per template row r
+// [k-step 2][k half 2][template slot 8] x 8 bf16.  a = -(unit row) = a0 + a1 + a2 exactly; the window side splits its unit frame the same way,
+// x = x0 + x1 + x2, and the two k-steps accumulate the six partial products x_i a_j with i + j <= 2 of every component, and 1.0 x 1.0:
+//   k-step 0, half kh (components (ca, cb) = (0, 1) / (3, 4)):  [ca.0 cb.0 | ca.0 cb.0 | ca.0 cb.0 | half 0: c2.0 c2.0 / half 1: c2.0 c2.2]
+//     against the window's                                     [xa0 xb0  | xa1 xb1  | xa2 xb2  | half 0: x2_0 x2_1 / half 1: x2_2 x2_0]
+//   k-step 1:                                                   [ca.1 cb.1 | ca.1 cb.1 | ca.2 cb.2 | half 0: c2.1 c2.1 / half 1: 1.0  0  ]
+//     against                                                   [xa0 xb0  | xa1 xb1  | xa0 xb0  | half 0: x2_0 x2_1 / half 1: 1.0  0  ]
+// Slots past the chunk's count and the 16 rows after the last one are zero.
+static void append_mfma_image3(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad) {
+    const int K = 5;
+    const size_t base = img.size();
+    img.resize(base + (size_t)(c.len + 16) * kDtwMfma3RowBytes / 2, 0);
+    for (int r = 0; r < c.len; ++r)
+        for (int t = 0; t < c.count; ++t) {
+            uint16_t p[5][3];
+            for (int k = 0; k < K; ++k) bf16_split3(-unit[((size_t)c.tid[t] * Lpad + r) * K + k], p[k]);
+            for (int kh = 0; kh < 2; ++kh) {
+                const int ca = kh ? 3 : 0, cb = ca + 1;
+                uint16_t s0[8] = {p[ca][0], p[cb][0], p[ca][0], p[cb][0], p[ca][0], p[cb][0], p[2][0], kh == 0 ? p[2][0] : p[2][2]};
+                uint16_t s1[8] = {p[ca][1], p[cb][1], p[ca][1], p[cb][1], p[ca][2], p[cb][2], kh == 0 ? p[2][1] : (uint16_t)0x3f80, kh == 0 ? p[2][1] : (uint16_t)0};
+                std::memcpy(&img[base + ((size_t)r * kDtwMfma3RowBytes + kh * 128 + t * 16) / 2], s0, 16);
+                std::memcpy(&img[base + ((size_t)r * kDtwMfma3RowBytes + 256 + kh * 128 + t * 16) / 2], s1, 16);
+            }
+        }
+}
+
 // dtw_ragged_kernel's A operand of ONE template (rp_dtw_ragged.hip): per row [k half 2] x 8 f16, the same split as above without the
 // constant slot (the cell adds its 1 itself): k half 0 = a0_0 a0_1 | a0_0 a0_1 | a1_0 a1_1 | a0_2 a0_2, k half 1 = a0_3 a0_4 | a0_3 a0_4 |
 // a1_3 a1_4 | a1_2 0; 16 zero rows behind the last one.
@@ -412,6 +472,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     std::unique_ptr<Templates> tp(new Templates());
     tp->ctx = ctx;
     TemplatesDev &d = tp->dev;
+    d.arith = &ctx->arith;
     d.T = T; d.K = K; d.Lpad = Lpad; d.has_avg = has_avg; d.max_len = max_len; d.max_diff = longest - max_len;
     if (!hip_ok(hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.lens), sizeof(int) * Ttot), "hipMalloc(lens)")) return nullptr;
@@ -448,6 +509,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
     std::vector<DtwChunk> chunks;
     std::vector<float> dup;
     std::vector<uint16_t> aimg;  // dtw_mfma_kernel's A images (mfcc_size 5, chunks of 3..8 templates)
+    std::vector<uint16_t> aimg3; // ... in the three-part bf16 form (the default arithmetic)
     // class 4 (not a launch class of its own): the tc-4 halves of the class-2 chunks, see TemplatesDev::split_first
     std::vector<DtwChunk> halves;
     bool can_split = !byclass[2].empty();
@@ -466,9 +528,12 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         for (DtwChunk c : (cls < 4 ? byclass[cls] : halves)) {
             c.rows_off = (int)dup.size();
             c.aimg_off = 0;
+            c.aimg3_off = 0;
             if (K == 5 && (cls == 1 || cls == 2)) {
                 c.aimg_off = (int)(aimg.size() * sizeof(uint16_t) / 16);
                 append_mfma_image(aimg, c, unit.data(), Lpad);
+                c.aimg3_off = (int)(aimg3.size() * sizeof(uint16_t) / 16);
+                append_mfma_image3(aimg3, c, unit.data(), Lpad);
                 int &ml = cls == 2 ? d.mfma_min_len : d.mfma_min_len4;
                 ml = ml == 0 ? c.len : std::min(ml, c.len);
             }
@@ -554,6 +619,10 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         if (!hip_ok(hipMalloc(&d.aimg, sizeof(uint16_t) * aimg.size()), "hipMalloc(aimg)")) return nullptr;
         if (!hip_ok(hipMemcpy(d.aimg, aimg.data(), sizeof(uint16_t) * aimg.size(), hipMemcpyHostToDevice), "hipMemcpy(aimg)")) return nullptr;
     }
+    if (!aimg3.empty()) {
+        if (!hip_ok(hipMalloc(&d.aimg3, sizeof(uint16_t) * aimg3.size()), "hipMalloc(aimg3)")) return nullptr;
+        if (!hip_ok(hipMemcpy(d.aimg3, aimg3.data(), sizeof(uint16_t) * aimg3.size(), hipMemcpyHostToDevice), "hipMemcpy(aimg3)")) return nullptr;
+    }
     if (K == 5 && d.class_count[2] >= 4 && d.aimg) {   // dtw_mfma_group_kernel: class-2 chunks of one length, four to a workgroup
         std::vector<int> quads, pairs;   // (pairs: the kernel's two-chunk shape measured SLOWER than dtw_mfma_kernel -- half the sharing does not pay the ring -- never built)
         std::vector<char> grouped(d.class_count[2], 0);
@@ -596,6 +665,7 @@ Templates::~Templates() {
     if (dev.chunks) (void)hipFree(dev.chunks);
     if (dev.dup) (void)hipFree(dev.dup);
     if (dev.aimg) (void)hipFree(dev.aimg);
+    if (dev.aimg3) (void)hipFree(dev.aimg3);
     if (dev.raw) (void)hipFree(dev.raw);
     if (dev.rimg) (void)hipFree(dev.rimg);
     if (dev.grp_first) (void)hipFree(dev.grp_first);

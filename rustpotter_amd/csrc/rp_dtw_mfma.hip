@@ -38,6 +38,7 @@ namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -98,7 +99,7 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 #define RP_TRACE(slot)
 #endif
 
-template <int W, int NW, bool GX, int NT>
+template <int W, int NW, bool GX, int NT, bool P3>
 __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds,
     float *__restrict__ agg_out, uint32_t *__restrict__ agg_hot, float agg_threshold, uint32_t *__restrict__ fix) {
     constexpr int K = kMK, B = 2 * W, NS = mfma_slots(NT), NTILE = mfma_tiles(NT), SPT = 32 / NT, NP = NT / 4;
-    constexpr int kRowBytes = kDtwMfmaRowBytes;
+    constexpr int kRowBytes = P3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes;
 #ifndef RP_MFMA_GX_PD  // A/B builds: 1 = the one-column look-ahead of the staged form
     constexpr int PD = GX ? (NS % 3 == 0 ? 3 : 4) : 1;  // columns a frame is requested ahead of its use (RP_P0)
 #else
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const int xs_floats = dtw_mfma_stage_floats(max_len);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
-        const u32x4 *asrc = reinterpret_cast<const u32x4 *>(aimg) + ch->aimg_off;
+        const u32x4 *asrc = reinterpret_cast<const u32x4 *>(aimg) + (P3 ? ch->aimg3_off : ch->aimg_off);
         u32x4 *adst = reinterpret_cast<u32x4 *>(smem);
         for (int i = tid; i < (L + kMSlotsMax) * kRowBytes / 16; i += 64 * NW) adst[i] = asrc[i];
     }
@@ -151,6 +152,11 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #pragma unroll
     for (int e = 0; e < SPT; ++e) dl[e] = (unsigned)(((e - jj + NS) % NS) * kRowBytes);
     const unsigned sel_one = h ? 0x07060100u : 0x03020100u;  // slot 7: x1 of component 2 (half 0) / the constant 1.0 (half 1)
+    // P3 (three bf16 parts): register 3 of the first operand holds (x0, x1) of component 2 in half 0 and (x2, x0) in half 1 -- one v_perm
+    // of (t, x0) with a per-half selector, t = r1 - (r1 & mask_c2): r1 itself in half 0 (its upper 16 bits ARE x1), x2 in half 1
+    const unsigned sel_c2 = h ? 0x03020706u : 0x07060302u;
+    const unsigned mask_c2 = h ? 0xffff0000u : 0u;
+    (void)sel_c2; (void)mask_c2;
     const float abandon_cost = abandon_nc * (float)(L + L);
     // which of this lane's templates (NT / 2 of them) can keep a wave alive: real ones; the averaged template (tid >= T) always does
     bool slot_real[2 * NP], slot_avg[2 * NP];
@@ -269,16 +275,18 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             for (int q = 0; q <= B; ++q) Q[p][q] = (v2f){RP_INF, RP_INF};
             Q[p][W - 1] = (v2f){0.f, 0.f};
         }
-        u32x4 Areg[NTILE];
+        u32x4 Areg[NTILE], Areg2[P3 ? NTILE : 1];   // P3: the row's second 256 bytes = the A operand of the second k-step
 #pragma unroll
         for (int g = 0; g < NTILE; ++g) {
             const int slot = SPT * g + jj;
             int r = W - ((W - slot + NS) % NS);  // 1-based template row in this slot for the state "newest row = W"
             r = r < 1 ? 1 : r;
             Areg[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)(r - 1) * kRowBytes);
+            if (P3) Areg2[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + 256u + (unsigned)(r - 1) * kRowBytes);
         }
         v16f acc[NTILE];   // costs of the current column; a tile is refilled for the next column as soon as its last cell is done
         u32x4 bop[2];  // B operand of column cc in bop[cc & 1]: built two columns ahead, in pieces between the cells
+        u32x4 bop2[P3 ? 2 : 1];  // P3: the second k-step's
 
 // The frame work of column cc, cut into ten pieces P0..P9 that are placed between the cells of the recurrence.
 // P0 requests the frame of column cc into ring slot rs, P1 takes it out PD columns later (rs = cc mod PD, spelled out by the caller:
@@ -292,7 +300,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
                     bb_ = fmaf(d2_, d2_, __uint_as_float(sw_[0]) + __uint_as_float(sw_[1])); }
 #define RP_P4(cc) inv_ = bb_ > 0.f ? __builtin_amdgcn_rsqf(bb_) : 0.f;  /* zero frame -> zero vector -> cost 1 (comparator.rs:43-47) */
 #define RP_P5(cc) ua_ = da_ * inv_; ub_ = db_ * inv_; u2_ = d2_ * inv_;
-#define RP_P6(cc, par) bop[par].x = pkrtz(ua_, ub_); bop[par].z = bop[par].x;
+// P3: x = x0 + x1 + x2 EXACTLY with x0 = x & 0xffff0000 (its first 8 significant bits = a bf16), r1 = x - x0 (exact), x1 = r1 & 0xffff0000,
+// x2 = r1 - x1 (exact, at most 8 significant bits: a bf16 too).  A register of the B operand is the upper halves of two f32 values: one v_perm.
+#define RP_HI2(hi, lo) __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u)
+#define RP_AND(x, m) __uint_as_float(__float_as_uint(x) & (m))
+#define RP_P6(cc, par) if (P3) { x0a_ = RP_AND(ua_, 0xffff0000u); x0b_ = RP_AND(ub_, 0xffff0000u); x0c_ = RP_AND(u2_, 0xffff0000u); bop[par].x = RP_HI2(ub_, ua_); } \
+                       else { bop[par].x = pkrtz(ua_, ub_); bop[par].z = bop[par].x; }
 // x1 = rtz_f16(x - x0): x0 as f32 is x with the low 13 mantissa bits cleared (one full-rate v_and instead of a half-rate v_cvt_f32_f16;
 // below the f16 normal range, |x| < 6.1e-5, the two differ by less than the f16 subnormal spacing 6e-8 -- far below the kernel's error)
 #ifndef RP_MFMA_CVT_BACK
@@ -300,15 +313,21 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #else
 #define RP_X0F(x, packed, hi) ((hi) ? hi_f32(packed) : lo_f32(packed))
 #endif
-#define RP_P7(cc, par) bop[par].y = pk_f16_second(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1));
+#define RP_P7(cc, par) if (P3) { r1a_ = ua_ - x0a_; r1b_ = ub_ - x0b_; r1c_ = u2_ - x0c_; bop[par].y = RP_HI2(r1b_, r1a_); } \
+                       else { bop[par].y = pk_f16_second(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1)); }
 #ifndef RP_AB_NO_RANGE_TEST   /* A/B builds only (results wrong for out-of-range frames): what the test costs */
-#define RP_P8(cc) chk_ = fmaxf(fmaxf(chk_, inv_), bb_);  /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */
+#define RP_P8(cc) chk_ = fmaxf(fmaxf(chk_, inv_), bb_);  /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */ \
+                  if (P3) { x1a_ = RP_AND(r1a_, 0xffff0000u); x1b_ = RP_AND(r1b_, 0xffff0000u); tc_ = RP_AND(r1c_, mask_c2); }
 #else
-#define RP_P8(cc)
+#define RP_P8(cc) if (P3) { x1a_ = RP_AND(r1a_, 0xffff0000u); x1b_ = RP_AND(r1b_, 0xffff0000u); tc_ = RP_AND(r1c_, mask_c2); }
 #endif
-#define RP_P9(cc, par) { const float x0_ = RP_X0F(u2_, pkrtz(u2_, 0.f), 0); /* (x0, x1) of component 2: x0 is already an f16 value, x1 rounds to nearest */ \
+#define RP_P9(cc, par) if (P3) { bop[par].z = RP_HI2(r1b_ - x1b_, r1a_ - x1a_); bop[par].w = __builtin_amdgcn_perm(__float_as_uint(r1c_ - tc_), __float_as_uint(u2_), sel_c2); } \
+                       else { const float x0_ = RP_X0F(u2_, pkrtz(u2_, 0.f), 0); /* (x0, x1) of component 2: x0 is already an f16 value, x1 rounds to nearest */ \
                          bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pk_f16_second(x0_, u2_ - x0_), sel_one); }
-#define RP_PREP_ALL(cc, par) RP_P0(cc, (cc) % PD) RP_P1(cc, (cc) % PD) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par)
+// P3: the second k-step's operand: (x0, x0 | x1, x1 | x0, x0) of the half's two components against (a1, a1 | a1, a1 | a2, a2), and register 3 =
+// (x0, x1) of component 2 against (a1, a1) in half 0, the constant (1.0, 0) in half 1
+#define RP_P10(cc, par) if (P3) { bop2[par].x = bop[par].x; bop2[par].y = bop[par].y; bop2[par].z = bop[par].x; bop2[par].w = h ? 0x00003f80u : bop[par].w; }
+#define RP_PREP_ALL(cc, par) RP_P0(cc, (cc) % PD) RP_P1(cc, (cc) % PD) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par) RP_P10(cc, par)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 12)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
     {                                                                                                                         \
@@ -316,11 +335,18 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         int off = ((cc) + W - 1) * kRowBytes - (int)dl[e];                                                                    \
         if (GUARD) off = off < 0 ? 0 : off;                                                                                   \
         Areg[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)off);                                            \
+        if (P3) Areg2[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + 256u + (unsigned)off);                            \
     }
 #define RP_MFMA(g, par)                                                                                                       \
     do {                                                                                                                      \
         const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  \
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g]), __builtin_bit_cast(f16x8, bop[par]), zero16, 0, 0, 0); \
+        if (P3) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g]), __builtin_bit_cast(bf16x8, bop[par]), zero16, 0, 0, 0); \
+        else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g]), __builtin_bit_cast(f16x8, bop[par]), zero16, 0, 0, 0); \
+    } while (0)
+// P3: the second k-step on the same accumulator, one band cell after the first (its eight passes are over by then)
+#define RP_MFMA2(g, par)                                                                                                      \
+    do {                                                                                                                      \
+        if (P3) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg2[g]), __builtin_bit_cast(bf16x8, bop2[par]), acc[g], 0, 0, 0); \
     } while (0)
 
 // column c (c = 1 + u mod 12): rows r_q = c - W + 1 + q, q = 0..2W-1, sit in MFMA row slot (u + q + 14 - W) mod 12
@@ -342,23 +368,39 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             }                                                                                                                 \
             /* piece k of the frame of column c + 2 after cell (k B) / 10 (its values were requested one column earlier, P0): the  \
                pieces fill the wait states between a cell's adds and the next cell's v_min3 */                                                                                  \
+            if (!P3) {                                                                                                        \
             if (q == (0 * B) / 10) { RP_P1(c + 2, (u + 3) % PD) RP_P0(c + 2 + PD, (u + 3) % PD) } if (q == (2 * B) / 10) { RP_P2(c + 2) }                       \
             if (q == (3 * B) / 10) { RP_P3(c + 2) } if (q == (4 * B) / 10) { RP_P4(c + 2) } if (q == (5 * B) / 10) { RP_P5(c + 2) } \
             if (q == (6 * B) / 10) { RP_P6(c + 2, (u + 1) & 1) } if (q == (7 * B) / 10) { RP_P7(c + 2, (u + 1) & 1) }         \
             if (q == (8 * B) / 10) { RP_P8(c + 2) } if (q == (9 * B) / 10) { RP_P9(c + 2, (u + 1) & 1) }                      \
-            _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                 \
+            } else { /* eleven pieces: the three-part split is twenty instructions against ten */                            \
+            if (q == (0 * B) / 11) { RP_P1(c + 2, (u + 3) % PD) RP_P0(c + 2 + PD, (u + 3) % PD) } if (q == (1 * B) / 11) { RP_P2(c + 2) }                       \
+            if (q == (2 * B) / 11) { RP_P3(c + 2) } if (q == (3 * B) / 11) { RP_P4(c + 2) } if (q == (4 * B) / 11) { RP_P5(c + 2) } \
+            if (q == (5 * B) / 11) { RP_P6(c + 2, (u + 1) & 1) } if (q == (6 * B) / 11) { RP_P7(c + 2, (u + 1) & 1) }         \
+            if (q == (7 * B) / 11) { RP_P8(c + 2) } if (q == (8 * B) / 11) { RP_P9(c + 2, (u + 1) & 1) }                      \
+            if (q == (9 * B) / 11) { RP_P10(c + 2, (u + 1) & 1) }                                                             \
+            }                                                                                                                 \
+            _Pragma("unroll") for (int g = 0; g < NTILE; ++g) {                                                               \
                 if (mfma_last_use<W, NT>(u, g) == q) RP_MFMA(g, u & 1);                                                       \
+                if (q > 0 && mfma_last_use<W, NT>(u, g) == q - 1) RP_MFMA2(g, u & 1);                                         \
+            }                                                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
-        _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                     \
-            if (mfma_last_use<W, NT>(u, g) < 0) RP_MFMA(g, u & 1);                                                            \
+        _Pragma("unroll") for (int g = 0; g < NTILE; ++g) {                                                                   \
+            if (mfma_last_use<W, NT>(u, g) < 0) { RP_MFMA(g, u & 1); RP_MFMA2(g, u & 1); }                                    \
+            if (mfma_last_use<W, NT>(u, g) == B - 1) RP_MFMA2(g, u & 1);                                                      \
+        }                                                                                                                     \
     } while (0)
 
         float fa_[PD], fb_[PD], f2_[PD], da_, db_, d2_, own_, bb_, inv_, ua_, ub_, u2_, chk_ = 0.f;
+        float x0a_ = 0.f, x0b_ = 0.f, x0c_ = 0.f, r1a_ = 0.f, r1b_ = 0.f, r1c_ = 0.f, x1a_ = 0.f, x1b_ = 0.f, tc_ = 0.f;   // P3 only
+        (void)x0a_; (void)x0b_; (void)x0c_; (void)r1a_; (void)r1b_; (void)r1c_; (void)x1a_; (void)x1b_; (void)tc_;
         RP_AREF(1, 0, true)
         RP_PREP_ALL(1, 1)
         RP_MFMA(0, 1); RP_MFMA(1, 1);
         if (NTILE > 2) RP_MFMA(NTILE - 1, 1);
+        RP_MFMA2(0, 1); RP_MFMA2(1, 1);
+        if (NTILE > 2) RP_MFMA2(NTILE - 1, 1);
         RP_PREP_ALL(2, 0)
 #pragma unroll
         for (int a = 0; a < PD; ++a) { RP_P0(3 + a, (3 + a) % PD) }
@@ -407,6 +449,10 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #undef RP_ABANDON_ON
 #undef RP_STEP
 #undef RP_MFMA
+#undef RP_MFMA2
+#undef RP_P10
+#undef RP_HI2
+#undef RP_AND
 #undef RP_AREF
 #undef RP_PREP_ALL
 #undef RP_P0
@@ -469,16 +515,19 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 }
 
 bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from_global, int slots, float score_ref) {
-    const char *env = std::getenv("RP_DTW_MFMA");  // "0": the register kernels only (A/B runs and the cross-check tests); read per call
-    if ((env && env[0] == '0') || t.K != kMK || !t.aimg || t.max_diff != 0) return false;
-    if (!(score_ref >= kDtwMfmaMinScoreRef)) return false;   // the score's sensitivity to the cost grows like 1 / score_ref (rp_kernels.h)
+    const int mode = t.arith_mode();   // the context's arithmetic (rp_ctx_set_arithmetic), read per call
+    if (mode == kArithStrictF32 || t.K != kMK || !(mode == kArithFastSplit ? t.aimg : t.aimg3) || t.max_diff != 0) return false;
+    const bool p3 = mode != kArithFastSplit;
+    // the two-part form: the score's sensitivity to the cost grows like 1 / score_ref (rp_kernels.h); the three-part form's products are
+    // f32-grade, it needs no floor
+    if (!p3 && !(score_ref >= kDtwMfmaMinScoreRef)) return false;
     if (slots == 8 ? (band < 3 || band > 5) : band != 5) return false;  // 12 (16) row slots hold 2 band + 2 rows; 4 slots: band 5 only
     if (!from_global && n_win < (size_t)kMWin) return false;            // a staged tile holds at most two stream segments
     // the first 12 (16) columns are one guarded block
     if (slots == 8 ? t.mfma_min_len < mfma_slots(8) : t.mfma_min_len4 < mfma_slots(4)) return false;
     // long templates: the A image leaves room for eight waves' frame stages only.  The four-slot form is built for twelve waves (its
     // eight-wave build spills: the register allocator loses its way in the 16-column unroll) -- such chunks keep the tc-4 register kernel
-    return dtw_mfma_lds_bytes(t.max_len, slots == 8 ? 8 : 12) <= 160 * 1024;
+    return dtw_mfma_lds_bytes(t.max_len, slots == 8 ? 8 : 12, p3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes) <= 160 * 1024;
 }
 
 hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
@@ -486,15 +535,24 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
                            bool from_global, const uint32_t *list, const uint32_t *count, uint32_t dense_min, float abandon_nc,
                            const DtwFusedAgg *fuse) {
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
-    dtw_mark(wk, kDtwRanMfma);
+    const bool p3 = t.arith_mode() != kArithFastSplit;
+    dtw_mark(wk, kDtwRanMfma | (p3 ? kDtwRanBf16x3 : kDtwRanF16x2));
     if (fuse && (n_chunks != 1 || list || count)) return hipErrorInvalidValue;  // launch_dtw only asks for it with one chunk, every row scored
     float *agg_out = fuse ? fuse->agg : nullptr;
     uint32_t *agg_hot = fuse ? fuse->hot : nullptr;
     const float agg_threshold = fuse ? fuse->threshold : 0.f;
     if (list && !from_global) return hipErrorNotSupported;
     const size_t total_tiles = (S * n_win + kMWin - 1) / kMWin;
-    const int nw = dtw_mfma_lds_bytes(t.max_len, 12) <= 160 * 1024 ? 12 : 8;
-    const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw);
+    const int row_bytes = p3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes;
+    int nw = dtw_mfma_lds_bytes(t.max_len, 12, row_bytes) <= 160 * 1024 ? 12 : 8;
+    if (p3 && slots == 8) {
+        // the three-part form runs two waves per SIMD (8 per workgroup, 233 registers, nothing spilled): measured 14.6-14.7 ms against 15.2 for
+        // three per SIMD at 168 registers (82 spilled, scratch traffic inside the column loop) at BASELINE C3.  RP_MFMA3_WAVES=12: A/B runs
+        static const int env_nw = [] { const char *e = std::getenv("RP_MFMA3_WAVES"); return e ? std::atoi(e) : 0; }();
+        if (env_nw != 12) nw = 8;
+    }
+    const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw, row_bytes);
+    const void *image = p3 ? t.aimg3 : t.aimg;
     // one workgroup per CU and chunk group; the waves take tiles from the chunk's counter
     if (!wk.sched || !wk.fix) return hipErrorInvalidValue;
     size_t groups = (size_t)device_cu_count() / (size_t)n_chunks;
@@ -504,13 +562,17 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
     const size_t blocks = groups * (size_t)n_chunks;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const unsigned static_rounds = mfma_static_rounds(total_tiles, groups * (size_t)nw, list != nullptr);
+#define RP_LAUNCH_MFMA_P(WW, NW, GXV, NT, PP)                                                                                       \
+    do {                                                                                                                            \
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<WW, NW, GXV, NT, PP>), 160 * 1024); e != hipSuccess) return e; \
+        hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV, NT, PP>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
+                           total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
+                           reinterpret_cast<const uint4 *>(image), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
+                           abandon_nc, wk.sched, static_rounds, agg_out, agg_hot, agg_threshold, wk.fix);                                            \
+    } while (0)
 #define RP_LAUNCH_MFMA(WW, NW, GXV, NT)                                                                                             \
     do {                                                                                                                            \
-        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(dtw_mfma_kernel<WW, NW, GXV, NT>), 160 * 1024); e != hipSuccess) return e; \
-        hipLaunchKernelGGL((dtw_mfma_kernel<WW, NW, GXV, NT>), dim3((unsigned)blocks), dim3(64 * NW), lds, st, mfcc, frame_pitch, frame_pitch, \
-                           total_tiles, (unsigned)n_chunks, chunk_base, first_win, n_win, out_win_pitch, t.chunks,                   \
-                           reinterpret_cast<const uint4 *>(t.aimg), t.T, score_ref, scores, avg, S, t.max_len, list, count, dense_min, \
-                           abandon_nc, wk.sched, static_rounds, agg_out, agg_hot, agg_threshold, wk.fix);                                            \
+        if (p3) RP_LAUNCH_MFMA_P(WW, NW, GXV, NT, true); else RP_LAUNCH_MFMA_P(WW, NW, GXV, NT, false);                             \
     } while (0)
 #define RP_LAUNCH_MFMA_W(WW, NT)                                                                                                    \
     do {                                                                                                                            \
@@ -530,6 +592,7 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
     }
 #undef RP_LAUNCH_MFMA_W
 #undef RP_LAUNCH_MFMA
+#undef RP_LAUNCH_MFMA_P
     return hipGetLastError();
 }
 

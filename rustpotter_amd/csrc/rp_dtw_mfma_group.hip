@@ -316,7 +316,8 @@ bool dtw_mfma_group_supported(const TemplatesDev &t, int band, size_t n_win, siz
     // RP_DTW_GROUP (read per call): "0" = every chunk through dtw_mfma_kernel (the A/B switch of the bit-equality tests), "2" = also for
     // launches below the size rule (tests)
     const char *env = std::getenv("RP_DTW_GROUP");
-    if ((env && env[0] == '0') || t.grp_count <= 0 || !t.grp_first) return false;
+    // the two-part f16 arithmetic only (RP_ARITH_FAST_SPLIT): four three-part A images (4 x 58 KB at 100 frames) do not fit a CU's LDS
+    if ((env && env[0] == '0') || t.grp_count <= 0 || !t.grp_first || t.arith_mode() != kArithFastSplit) return false;
     if (!dtw_mfma_supported(t, band, n_win, false, 8, score_ref)) return false;
     if (env && env[0] == '2') return true;
     // hundreds of tile rounds, or the index hand-out leaves the chip waiting for the last workgroups
@@ -329,7 +330,7 @@ hipError_t launch_dtw_mfma_group(hipStream_t st, const DtwWork &wk, const Templa
                                  size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores) {
     if (t.grp_count <= 0 || S == 0 || n_win == 0) return hipSuccess;
     if (!wk.fix) return hipErrorInvalidValue;
-    dtw_mark(wk, kDtwRanMfmaGroup);
+    dtw_mark(wk, kDtwRanMfmaGroup | kDtwRanF16x2);
     const size_t total_tiles = (S * n_win + kGWin - 1) / kGWin;
     // groups of one shape (SH, length class) per launch: [grp4_count quads][grp_count - grp4_count pairs]
     for (int pass = 0; pass < 2; ++pass) {

@@ -358,8 +358,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide_kernel(
 
 bool dtw_mfma_wide_supported(const TemplatesDev &t, int band, float score_ref) {
     if (!(score_ref >= kDtwMfmaMinScoreRef)) return false;   // as dtw_mfma_supported
-    const char *env = std::getenv("RP_DTW_MFMA");
-    if ((env && env[0] == '0') || (t.K != 13 && t.K != 16) || band != 5 || !t.aimg || t.wide8_count <= 0 || t.max_diff != 0) return false;
+    if (t.arith_mode() != kArithFastSplit || (t.K != 13 && t.K != 16) || band != 5 || !t.aimg || t.wide8_count <= 0 || t.max_diff != 0) return false;
     if (t.mfma_min_len < kWSlots) return false;
     return (size_t)(t.max_len + 16) * dtw_mfma_wide_row_bytes(t.K) <= 160 * 1024;
 }
@@ -370,7 +369,7 @@ hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const Templat
     const int n_chunks = t.wide8_count;
     if (n_chunks <= 0 || S == 0 || n_win == 0) return hipSuccess;
     if (band != 5 || !wk.sched || !wk.fix) return hipErrorNotSupported;
-    dtw_mark(wk, kDtwRanMfmaWide);
+    dtw_mark(wk, kDtwRanMfmaWide | kDtwRanF16x2);
     const size_t total_tiles = (S * n_win + kWWin - 1) / kWWin;
     constexpr int NW = 8;
     const size_t lds = (size_t)(t.max_len + 16) * dtw_mfma_wide_row_bytes(t.K);

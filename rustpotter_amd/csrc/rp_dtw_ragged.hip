@@ -399,14 +399,13 @@ size_t dtw_ragged_lds_bytes(const TemplatesDev &t, size_t n_win, int *frames_cap
 }
 
 bool dtw_ragged_supported(const TemplatesDev &t, int band, size_t n_win, float score_ref) {
-    // OPT-IN (RP_DTW_RAGGED=1, read per call).  Measured on MI355X at the reference's own shape (65 536 streams x templates of 108 / 96 /
+    // OPT-IN (rp_ctx_set_arithmetic(RP_ARITH_FAST_SPLIT, ragged_matrix = 1) / RP_CTX_RAGGED_MATRIX, read per call).  Measured on MI355X at the reference's own shape (65 536 streams x templates of 108 / 96 /
     // 90 / 93 / 102 frames): 16.5-17.7 ms against 18.2-18.6 ms for the register kernels -- 0-8 % of the step -- while its scores differ
     // from theirs in the 7th digit, so taking it by default would end the bit-equality of offline batches with live-stream batches, the
     // gated / detect-only forms and the single-stream handle for exactly the references users ship.  Not worth it; DESIGN.md §4.2b has
     // the cost model (per (window, template, column): 3 vector ops per band cell + the frame's norm + the mean term = 155 issue cycles
     // and two matrix instructions that take VALU issue slots with them, against 257 for the register kernels and 98 for equal lengths).
-    const char *env = std::getenv("RP_DTW_RAGGED");
-    if (!(env && env[0] == '1') || t.K != kRK || !t.rimg || t.rag_count == 0 || t.max_diff != 0) return false;
+    if (!t.arith_ragged() || t.K != kRK || !t.rimg || t.rag_count == 0 || t.max_diff != 0) return false;
     if (!(score_ref >= kDtwRaggedMinScoreRef)) return false;
     if (band < 3 || band > 5) return false;
     if (n_win < 64) return false;                  // tiles of 512 consecutive windows: a handful of stream segments each
@@ -419,7 +418,7 @@ hipError_t launch_dtw_ragged(hipStream_t st, const DtwWork &wk, const TemplatesD
     if (t.rag_count <= 0 || S == 0 || n_win == 0) return hipSuccess;
     if (!wk.fix || !wk.rag_prep || wk.rag_streams < S) return hipErrorInvalidValue;
     if (list_rows && (!wk.rag_list || wk.rag_rows < S * n_win * (size_t)t.rag_count || S * n_win > 0xffffffffULL)) return hipErrorInvalidValue;
-    dtw_mark(wk, kDtwRanRagged);
+    dtw_mark(wk, kDtwRanRagged | kDtwRanF16x2);
     int F = 0;
     const size_t lds = dtw_ragged_lds_bytes(t, n_win, &F);
     const size_t n_tiles = (S * n_win + kRTile - 1) / kRTile;

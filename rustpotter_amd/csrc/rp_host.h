@@ -96,6 +96,7 @@ struct PinBuf {
 struct Ctx {
     int device = 0;
     int flags = 0;
+    DtwArith arith;   // the DTW launchers' arithmetic (RP_CTX_ARITH_* at creation, rp_ctx_set_arithmetic); every template set of the context points here
     int n_cu = 256;  // compute units of the device (persistent kernels launch one workgroup per CU)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

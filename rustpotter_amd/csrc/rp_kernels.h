@@ -70,11 +70,15 @@ struct DtwChunk {
     int rows_off;         // float offset of the chunk's rows in TemplatesDev::dup
     int tid[kChunkMax];   // output column of each template; T means the averaged template
     int aimg_off;         // chunks of 3..8 templates at mfcc_size 5: offset (16-byte units) of the chunk's A image in TemplatesDev::aimg
+    int aimg3_off;        // ... of its three-part bf16 image in TemplatesDev::aimg3 (kDtwMfma3RowBytes per row)
 };
 
 // dtw_mfma_kernel (rp_dtw_mfma.hip): A image = per template row [k half 2][template 8] x 8 f16 (the negated unit row, split in two f16
 // parts, in the slot order of the MFMA's B operand) for len + 16 rows (the tail rows are zero); per wave two stream segments of frames.
 constexpr int kDtwMfmaRowBytes = 256;
+// The f32-grade form (rp_ctx arithmetic RP_ARITH_F32_MATRIX, the default): the negated unit row as THREE bf16 parts a0 + a1 + a2 (exact: 3 x 8
+// significant bits = an f32's 24), two k-steps of 16 slots per row = [k-step 2][k half 2][template 8] x 8 bf16.
+constexpr int kDtwMfma3RowBytes = 512;
 __host__ __device__ inline int dtw_mfma_stage_floats(int max_len) { return ((32 + 2 * (max_len + 3)) * 5 + 3) & ~3; }
 // dtw_mfma_wide_kernel (mfcc_size 13 / 16): components per lane half and k-steps of 16 f16 slots (rp_dtw_mfma_wide.hip)
 __host__ __device__ constexpr int dtw_mfma_wide_chm(int K) { return (K + 1) / 2; }
@@ -94,12 +98,29 @@ inline unsigned mfma_static_rounds(size_t total_tiles, size_t chunk_waves, bool 
     if (const char *e = std::getenv("RP_MFMA_STATIC_ROUNDS")) return (unsigned)std::atoi(e);  // A/B runs: 0 = every tile from the counter
     return (list || r > 3 || r < 1) ? 1u : (unsigned)r;
 }
-inline size_t dtw_mfma_lds_bytes(int max_len, int waves) {
-    return (size_t)(max_len + 16) * kDtwMfmaRowBytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);
+inline size_t dtw_mfma_lds_bytes(int max_len, int waves, int row_bytes = kDtwMfmaRowBytes) {
+    return (size_t)(max_len + 16) * (size_t)row_bytes + (size_t)waves * (size_t)dtw_mfma_stage_floats(max_len) * sizeof(float);
 }
+
+// The arithmetic a context asks of the DTW launchers (rp_ctx_new flags / rp_ctx_set_arithmetic, include/rustpotter_hip.h RP_ARITH_*): read per
+// call through TemplatesDev::arith, so that one template set serves every mode.
+//   kArithF32Matrix (default): matrix-core kernels only in their f32-grade form -- operands as three bf16 parts (exact), six of the nine partial
+//     products of a multiplication (what is dropped is below 2^-22 of it, 2^-25.7 rms: an f32 multiply itself rounds by up to 2^-24) -- and the
+//     f32 vector kernels wherever no such form exists;
+//   kArithStrictF32: the f32 vector ("register") kernels only, every product an f32 FMA;
+//   kArithFastSplit: the two-part f16 forms of rounds 3-5 (22-bit operands, one partial product dropped): dtw_mfma_kernel, dtw_mfma_group_kernel,
+//     dtw_mfma_wide_kernel; `ragged` additionally admits dtw_ragged_kernel (same two-part arithmetic on per-stream offsets).
+enum { kArithF32Matrix = 0, kArithStrictF32 = 1, kArithFastSplit = 2 };
+struct DtwArith {
+    int mode = kArithF32Matrix;
+    int ragged = 0;
+};
 
 // Device-resident template set of one wakeword reference.
 struct TemplatesDev {
+    const DtwArith *arith = nullptr;   // the owning context's setting (host memory; null = defaults)
+    int arith_mode() const { return arith ? arith->mode : (int)kArithF32Matrix; }
+    bool arith_ragged() const { return arith && arith->mode == kArithFastSplit && arith->ragged; }
     int T = 0;        // sample templates
     int K = 0;
     int Lpad = 0;     // row pitch (frames) of `unit`
@@ -121,6 +142,7 @@ struct TemplatesDev {
     int split_first = 0, split_count = 0;
     // dtw_mfma_kernel: A images of the class-1 and class-2 chunks (mfcc_size 5 only), and the shortest template among them
     void *aimg = nullptr;
+    void *aimg3 = nullptr;  // the same chunks' three-part bf16 images (kDtwMfma3RowBytes per row, DtwChunk::aimg3_off)
     int mfma_min_len = 0;   // shortest template among the class-2 chunks (8 template slots; needs >= 12 frames)
     int mfma_min_len4 = 0;  // ... among the class-1 chunks (4 template slots; needs >= 16 frames)
     // mfcc_size 13 / 16: the sample templates once more as chunks of up to 8 same-length templates for dtw_mfma_wide_kernel (only when
@@ -174,7 +196,9 @@ struct DtwWork {
     size_t rag_streams = 0, rag_rows = 0;
 };
 // == RP_DTW_KERNEL_* (include/rustpotter_hip.h)
-enum : uint32_t { kDtwRanMfma = 1u, kDtwRanMfmaWide = 2u, kDtwRanRagged = 4u, kDtwRanRegister = 8u, kDtwRanGeneric = 16u, kDtwRanSingle = 32u, kDtwRanRefAll = 64u, kDtwRanMfmaGroup = 128u };
+enum : uint32_t { kDtwRanMfma = 1u, kDtwRanMfmaWide = 2u, kDtwRanRagged = 4u, kDtwRanRegister = 8u, kDtwRanGeneric = 16u, kDtwRanSingle = 32u, kDtwRanRefAll = 64u, kDtwRanMfmaGroup = 128u,
+                  // the product arithmetic of the matrix-core launches: three bf16 parts (f32-grade) / two f16 parts (22-bit)
+                  kDtwRanBf16x3 = 256u, kDtwRanF16x2 = 512u };
 inline void dtw_mark(const DtwWork &wk, uint32_t bit) { if (wk.ran) *wk.ran |= bit; }
 __host__ __device__ inline unsigned long long *dtw_fix_stats(uint32_t *fix) { return reinterpret_cast<unsigned long long *>(fix + 2 + 2 * (size_t)kDtwFixCap); }
 // (dtw_fix_append, the kernels' side of the list: rp_device.h)

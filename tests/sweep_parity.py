@@ -64,7 +64,7 @@ def make_case(rng, extreme=False, mfma=False, ragged=False):
             lens = np.full(T, int(rng.integers(12, 108)))
             if rng.random() < 0.4:
                 lens[: int(rng.integers(1, 4))] = rng.integers(12, 110)
-    if ragged:  # the shapes dtw_ragged_kernel takes (opt-in, RP_DTW_RAGGED=1): mfcc_size 5, templates whose lengths all differ (sometimes one pair)
+    if ragged:  # the shapes dtw_ragged_kernel takes (opt-in, RP_ARITH_FAST_SPLIT + ragged_matrix): mfcc_size 5, templates whose lengths all differ (sometimes one pair)
         K = 5
         T = int(rng.integers(1, 10))
         lens = rng.choice(np.arange(16, 111), size=T, replace=False)
@@ -187,25 +187,31 @@ def _same(a, b, rtol):
     return True
 
 
-def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False, ragged=False):
+def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False, ragged=False, arith=None):
     """-> (cases, detections compared, ties skipped); raises AssertionError with the case number on a mismatch.
-    ragged: the opt-in matrix-core kernel for templates of unequal length scores the offline calls (RP_DTW_RAGGED=1; the family asserts
+    arith: rp_ctx_set_arithmetic for the device calls ("f32_matrix" = the library default, "strict_f32", "fast_split"); None = the context's.
+    ragged: the opt-in matrix-core kernel for templates of unequal length scores the offline calls (fast_split + ragged_matrix; the family asserts
     that it ran); live-stream batches keep the register kernels, so live vs offline is counters exact + scores within 4e-6 there."""
+    if ragged:
+        arith = "fast_split"
+    old_arith = ctx.get_arithmetic()
+    if arith is not None:
+        ctx.set_arithmetic(arith, ragged)
     total = ties = 0
     for ci in range(n_cases):
         rng = np.random.default_rng([seed, 55, ci] if ragged else [seed, 77, ci] if mfma else [seed, ci])
         case = make_case(rng, extreme=extreme, mfma=mfma, ragged=ragged)
         ref = oracle_detections(case)
         if ragged:
-            os.environ["RP_DTW_RAGGED"] = "1"
             ctx.dtw_kernels()
         if mfma:
-            os.environ["RP_DTW_GROUP"] = "2"   # references with four chunks of one length: the group form whatever the launch size (same bits: live == offline stays exact)
+            os.environ["RP_DTW_GROUP"] = "2"   # (tuning knob) references with four chunks of one length: the group form whatever the launch size (same bits: live == offline stays exact; fast_split only)
         try:
             offline, live, agg = device_detections(ra, ctx, case)
+        except BaseException:
+            ctx.set_arithmetic(*old_arith)
+            raise
         finally:
-            if ragged:
-                del os.environ["RP_DTW_RAGGED"]
             if mfma:
                 del os.environ["RP_DTW_GROUP"]
         if ragged:
@@ -229,11 +235,13 @@ def run_sweep(ra, ctx, n_cases, seed, verbose=False, extreme=False, mfma=False, 
             if near and (ragged or all(_same(l, o, 0.0) for l, o in zip(live, offline))):
                 ties += 1
                 continue
+            ctx.set_arithmetic(*old_arith)
             raise AssertionError("sweep seed %d case %d: cfg %r K %d lens %r\noracle  %r\noffline %r\nlive    %r" % (
                 seed, ci, case["cfg"], case["K"], [len(t) for t in case["templates"]], ref, offline, live))
         total += sum(len(r) for r in ref)
         if verbose and ci % 20 == 0:
             print("case %d ok, %d detections so far" % (ci, total), flush=True)
+    ctx.set_arithmetic(*old_arith)
     return n_cases, total, ties
 
 
@@ -1167,7 +1175,7 @@ if __name__ == "__main__":
     ap.add_argument("--reset-cases", type=int, default=0, help="live-stream batches with single-stream resets")
     ap.add_argument("--extreme-cases", type=int, default=0, help="single-stream API cases with edge-of-range detector parameters")
     ap.add_argument("--api-cases", type=int, default=None, help="single-stream API cases (default: cases / 4)")
-    ap.add_argument("--ragged-cases", type=int, default=0, help="batch cases in the shapes the opt-in dtw_ragged_kernel takes (mfcc_size 5, 1..9 templates of unequal length, band 3..5), scored with RP_DTW_RAGGED=1")
+    ap.add_argument("--ragged-cases", type=int, default=0, help="batch cases in the shapes the opt-in dtw_ragged_kernel takes (mfcc_size 5, 1..9 templates of unequal length, band 3..5), scored with RP_ARITH_FAST_SPLIT + ragged_matrix")
     ap.add_argument("--mfma-cases", type=int, default=0, help="batch cases in the shapes the matrix-core DTW kernel takes (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44: dtw_mfma_group_kernel)")
     a = ap.parse_args()
     import rustpotter_amd as ra
@@ -1177,9 +1185,11 @@ if __name__ == "__main__":
     families = [  # (name, number of cases, run, result -> text); a failing family is reported and the others still run
         ("sweep", a.cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
-        ("matrix-core DTW sweep", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True),
+        ("matrix-core DTW sweep, RP_ARITH_F32_MATRIX (default: three bf16 parts)", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True, arith="f32_matrix"),
+         lambda r: "%d cases (mfcc_size 5 at band 3..5: dtw_mfma_kernel; mfcc_size 13 / 16 and everything else on the f32 vector kernels; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44), %d detections compared, %d threshold ties skipped" % r),
+        ("matrix-core DTW sweep, RP_ARITH_FAST_SPLIT (two f16 parts)", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True, arith="fast_split"),
          lambda r: "%d cases (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44: dtw_mfma_group_kernel), %d detections compared, %d threshold ties skipped" % r),
-        ("ragged matrix-core DTW sweep (RP_DTW_RAGGED=1)", a.ragged_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, ragged=True),
+        ("ragged matrix-core DTW sweep (RP_ARITH_FAST_SPLIT + ragged_matrix)", a.ragged_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, ragged=True),
          lambda r: "%d cases (mfcc_size 5, 1..9 templates of unequal length, band 3..5; the kernel ran in every case), %d detections compared, %d threshold ties skipped" % r),
         ("live rate sweep", a.rate_cases, lambda n: run_live_rate_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases live == offline bitwise, %d detections equal to the oracle's, %d near-tie cases" % r),

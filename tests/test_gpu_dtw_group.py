@@ -30,9 +30,13 @@ class _env:
     def __init__(self, value):
         self.value = value
     def __enter__(self):
+        import rustpotter_amd
+        self.arith = rustpotter_amd.arithmetic_all("fast_split")   # the group form exists for the two-part f16 products only (four three-part images do not fit the LDS)
+        self.arith.__enter__()
         self.old = os.environ.get("RP_DTW_GROUP")
         os.environ["RP_DTW_GROUP"] = self.value
     def __exit__(self, *a):
+        self.arith.__exit__(*a)
         if self.old is None:
             del os.environ["RP_DTW_GROUP"]
         else:

@@ -37,16 +37,10 @@ def _streams(S, n_frames, K=5, first=0):
     return np.stack(mf)
 
 
-class _registers_only:
-    """RP_DTW_MFMA=0 for the calls inside: the library reads the variable per call."""
-    def __enter__(self):
-        self.old = os.environ.get("RP_DTW_MFMA")
-        os.environ["RP_DTW_MFMA"] = "0"
-    def __exit__(self, *a):
-        if self.old is None:
-            del os.environ["RP_DTW_MFMA"]
-        else:
-            os.environ["RP_DTW_MFMA"] = self.old
+def _registers_only():
+    """RP_ARITH_STRICT_F32 (rp_ctx_set_arithmetic on every live context) for the calls inside: the f32 vector kernels only."""
+    import rustpotter_amd
+    return rustpotter_amd.arithmetic_all("strict_f32")
 
 
 @pytest.mark.parametrize("L,T", [(12, 5), (13, 8), (23, 5), (24, 6), (25, 8), (36, 7), (59, 6), (100, 8), (126, 5),

@@ -46,18 +46,10 @@ def _streams(S, n_frames, K=5, first=0):
     return np.stack(mf)
 
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+def _ragged_on():
+    """RP_ARITH_FAST_SPLIT + ragged_matrix (rp_ctx_set_arithmetic on every live context) for the calls inside: the opt-in kernel is admitted."""
+    import rustpotter_amd
+    return rustpotter_amd.arithmetic_all("fast_split", ragged_matrix=True)
 
 
 def _ragged_templates(seed, lens, K=5):
@@ -69,7 +61,7 @@ def _check(ra, ctx, templates, mf, band=5, score_ref=0.22, mode=None, expect_rag
     tm = ra.Templates(ctx, templates)
     kw = {} if mode is None else {"score_mode": mode[0]}
     ctx.dtw_kernels()
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         scores, _, agg = ctx.dtw_scores(mf, tm, band_size=band, score_ref=score_ref, **kw)
     ran = ctx.dtw_kernels()
     assert ("dtw_ragged_kernel" in ran) == expect_ragged, ran
@@ -106,7 +98,7 @@ def test_bands_three_and_four(ra, ctx, band):
     _check(ra, ctx, templates, mf, band=band)
     six = ra.Templates(ctx, templates)
     ctx.dtw_kernels()
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         ctx.dtw_scores(mf, six, band_size=6)
     assert "dtw_ragged_kernel" not in ctx.dtw_kernels()   # band 6 needs 14 row slots + the look-ahead: the register kernels keep it
 
@@ -121,7 +113,7 @@ def test_mixed_with_equal_length_chunks(ra, ctx):
     mf = _streams(3, 64 + 90, K, first=40)
     tm = ra.Templates(ctx, templates)
     ctx.dtw_kernels()
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         scores, _, agg = ctx.dtw_scores(mf, tm, score_mode=ra.ScoreMode.Median)
     ran = ctx.dtw_kernels()
     assert "dtw_ragged_kernel" in ran and "dtw_mfma_kernel" in ran, ran
@@ -178,7 +170,7 @@ def test_reference_fixture_stream(ra, ctx, case):
     cfg = _detector_config(ra, e)
     det0, n0, sc0, agg0 = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
     ctx.dtw_kernels()
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         det1, n1, sc1, agg1 = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
     assert "dtw_ragged_kernel" in ctx.dtw_kernels()
     assert rel_close(sc1, sc0, 4e-6) and not np.array_equal(sc1, sc0)
@@ -206,7 +198,7 @@ def test_windows_the_kernel_cannot_resolve_are_scored_again(ra, ctx):
     cfg.avg_threshold = 0.0
     before = ctx.dtw_ref_pairs()
     ctx.dtw_kernels()
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         _, _, sc, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
     ran = ctx.dtw_kernels()
     assert "dtw_ragged_kernel" in ran and "register kernels" in ran, ran   # the list pass
@@ -217,7 +209,7 @@ def test_windows_the_kernel_cannot_resolve_are_scored_again(ra, ctx):
         assert rel_close(sc[s], ref_s), rel_err(sc[s], ref_s)
         assert rel_close(agg[s], ref_a)
     # the operator-level call has no slack behind the caller's array: the same windows go to dtw_ref_kernel
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         sc2, _, _ = ctx.dtw_scores(mf, tm)
     assert ctx.dtw_ref_pairs() > before
     for s in range(S):
@@ -231,7 +223,7 @@ def test_a_streams_bits_do_not_depend_on_the_batch(ra, ctx):
     templates = _ragged_templates(SEED + 33, (70, 81, 64), 5)
     mf = _streams(5, 64 + 100, 5, first=900)
     tm = ra.Templates(ctx, templates)
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         ctx.dtw_kernels()
         whole, _, _ = ctx.dtw_scores(mf, tm)
         assert "dtw_ragged_kernel" in ctx.dtw_kernels()
@@ -251,7 +243,7 @@ def test_detect_only_call_abandons_without_changing_a_detection(ra, ctx):
     pcm = np.stack([base[:n], np.roll(base[:n], 480 * 5), np.roll(base[:n], -480 * 9)])
     tm = ra.Templates(ctx, templates)
     cfg = _detector_config(ra, e)
-    with _env(RP_DTW_RAGGED="1"):
+    with _ragged_on():
         det_full, n_full, _, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
         ctx.dtw_kernels()
         det_only, n_only = ctx.batch_detect(pcm, tm, cfg)[:2]

@@ -279,16 +279,10 @@ def test_detectors_with_a_template_set_outside_the_norm_range(ra, ctx, avg_thres
 
 
 # ------------------------------------------------------------------------------------------------ score_ref
-class _registers_only:
-    """RP_DTW_MFMA=0 for the calls inside: the library reads the variable per call."""
-    def __enter__(self):
-        self.old = os.environ.get("RP_DTW_MFMA")
-        os.environ["RP_DTW_MFMA"] = "0"
-    def __exit__(self, *a):
-        if self.old is None:
-            del os.environ["RP_DTW_MFMA"]
-        else:
-            os.environ["RP_DTW_MFMA"] = self.old
+def _registers_only():
+    """RP_ARITH_STRICT_F32 (rp_ctx_set_arithmetic on every live context) for the calls inside: the f32 vector kernels only."""
+    import rustpotter_amd
+    return rustpotter_amd.arithmetic_all("strict_f32")
 
 
 @pytest.mark.parametrize("K,T,L,band", [(5, 8, 100, 5), (5, 4, 100, 5), (5, 6, 60, 3), (5, 7, 37, 4)])

@@ -1,4 +1,4 @@
-"""bench.py's VALU-issue roofline is priced from the committed instruction mixes of the hot loops (profiles/r04_*_isa_mix.json,
+"""bench.py's VALU-issue roofline is priced from the committed instruction mixes of the hot loops (profiles/*_isa_mix.json,
 made by tools/isa_mix.py from the compiler's gfx950 assembly x profiles/valu_rate_table.json).  A kernel edit that changes a hot
 loop must regenerate them: this test recompiles the kernels (CPU only, hipcc cross-compiles) and compares."""
 import json
@@ -10,11 +10,13 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
-    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8>", ["--min-mfma", "36", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/r04_dtw_mfma_isa_mix.json"),
-    ("rp_mfcc.hip", "mfcc_kernel<true, 6, float, false>", [], "profiles/r04_mfcc_isa_mix.json"),
-    ("rp_dtw_ragged.hip", "dtw_ragged_kernel<5>", ["--min-mfma", "32"], "profiles/r05_dtw_ragged_isa_mix.json"),
-    ("rp_dtw_mfma_wide.hip", "dtw_mfma_wide_kernel<16, 5, 8>", ["--min-mfma", "100"], "profiles/r05_dtw_mfma_wide_isa_mix.json"),
-    ("rp_dtw_mfma_group.hip", "dtw_mfma_group_kernel<5, 4>", ["--min-mfma", "36"], "profiles/r05_dtw_mfma_group_isa_mix.json"),
+    # the headline kernel: three bf16 parts per operand (RP_ARITH_F32_MATRIX), two matrix instructions per tile and column
+    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 8, false, 8, true>", ["--min-mfma", "72", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/dtw_mfma_isa_mix.json"),
+    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8, false>", ["--min-mfma", "36", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/dtw_mfma_f16x2_isa_mix.json"),
+    ("rp_mfcc.hip", "mfcc_kernel<true, 6, float, false>", [], "profiles/mfcc_isa_mix.json"),
+    ("rp_dtw_ragged.hip", "dtw_ragged_kernel<5>", ["--min-mfma", "32"], "profiles/dtw_ragged_isa_mix.json"),
+    ("rp_dtw_mfma_wide.hip", "dtw_mfma_wide_kernel<16, 5, 8>", ["--min-mfma", "100"], "profiles/dtw_mfma_wide_isa_mix.json"),
+    ("rp_dtw_mfma_group.hip", "dtw_mfma_group_kernel<5, 4>", ["--min-mfma", "36"], "profiles/dtw_mfma_group_isa_mix.json"),
 ]
 
 

@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--chunks-per-call", type=int, default=1)
     ap.add_argument("--pcm-format", choices=["f32", "i16"], default="f32", help="--mode resample: sample format of the 48 kHz input")
     ap.add_argument("--channels", type=int, default=1, help="--mode resample: interleaved channels of the 48 kHz input")
-    ap.add_argument("--mlp-precision", choices=["f32", "bf16", "f32_strict"], default="bf16")
+    ap.add_argument("--mlp-precision", choices=["f32", "bf16", "f32_strict", "f32_fast"], default="bf16")
     ap.add_argument("--template-lens", default="", help="comma-separated template lengths in frames (overrides --templates / "
                     "--template-len), e.g. 108,96,90,93,102 = the shape of the reference's oye_casa_g.rpw")
     ap.add_argument("--score-mode", choices=["average", "max", "median", "p25", "p50", "p75", "p80", "p90", "p95"], default="max")
@@ -202,9 +202,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # RP_BENCH_FORCE_PG=1: a ONE-rank run still creates the process group (RCCL on the one GPU a box has) and sends its per-stream block
+    # through the collective: the first multi-GPU run of this code must not be the first ncclCommInit (tests/test_gpu_rccl.py)
+    force_pg = world == 1 and os.environ.get("RP_BENCH_FORCE_PG") == "1"
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if force_pg:
+        os.environ.setdefault("MASTER_PORT", "29537")
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     # RP_BENCH_BACKEND=gloo is a dry-run switch for boxes with fewer GPUs than ranks (ranks then share
     # devices); the driver's runs use the default, nccl == RCCL on ROCm, one rank per GPU.
@@ -218,11 +223,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif force_pg:
+        dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
 
     import rustpotter_amd as ra
 
     env = Env(args, ra, torch, dist, dev, world, rank, local_rank, backend)
+    env.pg = world > 1 or force_pg
     if args.mode == "mlp":
         res = bench_mlp(env)
     elif args.mode == "model":
@@ -237,7 +245,7 @@ def main():
         res = bench_dtw(env)
     if rank == 0:
         print(json.dumps(order_for_the_record(res)))
-    if world > 1:
+    if env.pg:
         dist.destroy_process_group()
 
 
@@ -246,15 +254,16 @@ class Env:
         self.args, self.ra, self.torch, self.dist, self.dev = args, ra, torch, dist, dev
         self.world, self.rank, self.local_rank, self.backend = world, rank, local_rank, backend
         self.cores, self.cpu_model = host_cpu()
+        self.pg = world > 1   # a process group exists (main() also sets it for RP_BENCH_FORCE_PG=1 one-rank runs)
 
     def fence(self):
         self.torch.cuda.synchronize()
-        if self.world > 1:
+        if self.pg:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
     def max_over_ranks(self, dt):
-        if self.world > 1:
+        if self.pg:
             tt = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -264,8 +273,8 @@ class Env:
         """Fields every line carries: where it ran and with which build."""
         p = self.torch.cuda.get_device_properties(self.dev)
         c = {"host_cpu": self.cpu_model, "host_threads_granted": self.cores, "device": p.name, "compute_units": p.multi_processor_count,
-             "build": self.ra.build_info(), "world_size": self.world, "backend": self.backend if self.world > 1 else "none (one rank)"}
-        if self.world > 1:
+             "build": self.ra.build_info(), "world_size": self.world, "backend": self.backend if self.pg else "none (one rank)"}
+        if self.pg:
             c.update(self.rank_identities())
         return c
 
@@ -571,14 +580,15 @@ def bench_dtw(env):
     gathered = [None]
 
     def gather():
-        if world == 1:
+        if not env.pg:
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         # the per-stream result block, T + 2 floats per stream (best score per template, best aggregate, detections);
         # detect-only / gated runs have no score arrays: their block is the detection count alone
         block = sharding.stream_summary(case.scores, case.agg, case.n_det) if case.want_arrays else case.n_det
-        gathered[0] = sharding.gather_per_stream(block, world) if first_stream is None else sharding.gather_ragged(block, world)
+        gathered[0] = (sharding.gather_per_stream(block, world, force_collective=env.pg) if first_stream is None
+                       else sharding.gather_ragged(block, world, force_collective=env.pg))
         b.record()
         gather_ms.append((a, b))
 
@@ -646,7 +656,7 @@ def bench_dtw(env):
               "windows_per_stream": n_win, "template_chunks": n_chunks,
               "parallelism": "streams sharded x%d, RCCL all_gather of the per-stream result block (T + 2 floats)" % world}
     config.update(env.common_config())
-    if world > 1:
+    if env.pg:
         torch.cuda.synchronize()
         g = [a.elapsed_time(b) for a, b in gather_ms[args.warmup:]]
         rows, cols = gathered[0].shape[0], (gathered[0].shape[1] if gathered[0].dim() > 1 else 1)
@@ -923,8 +933,9 @@ class MlpCase:
                 "one_thread": {"value": n1 / s1, "unit": "rows/s", "cores": 1, "sample": "%d rows in %.2f s on one thread" % (n1, s1)}}
 
 
-MLP_DTYPE = {"bf16": "bf16 inputs, f32 accumulate", "f32": "f32 (layer-1 products: f16x2-split MFMA, 22-bit; rows beyond the f16 range: f32 MFMA)",
-             "f32_strict": "f32 (f32 matrix instructions)"}
+MLP_DTYPE = {"bf16": "bf16 inputs, f32 accumulate", "f32": "f32 (layer-1 products on the matrix cores from exact three-part bf16 splits of both f32 operands, f32 accumulate)",
+             "f32_strict": "f32 (f32 matrix instructions)",
+             "f32_fast": "f32 (layer-1 products: f16x2-split MFMA, 22-bit -- RP_MLP_F32_FAST, narrower than the reference; rows beyond the f16 range: f32 MFMA)"}
 
 
 def extra_c5(env, precision):

@@ -76,6 +76,8 @@ pub const RP_DTW_PRODUCTS_F16X2: c_int = 512;
 pub const RP_MLP_F32: c_int = 0;
 pub const RP_MLP_BF16: c_int = 1;
 pub const RP_MLP_F32_STRICT: c_int = 2;
+/// two f16 parts per operand (22 bits): narrower than the reference's f32 products, the fastest whole-stream model detector
+pub const RP_MLP_F32_FAST: c_int = 3;
 
 #[repr(C)] #[derive(Clone, Copy)] pub struct rp_audio_fmt { pub sample_rate: usize, pub sample_format: c_int, pub channels: u16, pub endianness: c_int }
 #[repr(C)] #[derive(Clone, Copy)] pub struct rp_detector_config { pub avg_threshold: f32, pub threshold: f32, pub min_scores: usize, pub eager: bool, pub score_ref: f32, pub band_size: u16, pub score_mode: c_int, pub vad_mode: c_int }

@@ -494,16 +494,22 @@ int rp_model_new(rp_ctx *ctx, int n_layers, const int *dims, const float *const 
                  rp_model **out);
 void rp_model_free(rp_model *m);
 
-enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1, RP_MLP_F32_STRICT = 2 };
+enum { RP_MLP_F32 = 0, RP_MLP_BF16 = 1, RP_MLP_F32_STRICT = 2, RP_MLP_F32_FAST = 3 };
 /* WakewordNN forward (ModelImpl::forward: Linear -> ReLU -> ... -> Linear, raw logits),
  * src/wakewords/nn/wakeword_nn.rs:101-106,305-389: x [B][dims[0]] (the flattened, mean-normalised
  * window, :139-149,268-273) -> logits [B][dims[n_layers]].  Layer 1 runs on the matrix cores:
- * RP_MLP_F32 = f32-grade layer 1 (dense rows of models up to 32 hidden units: inputs and weights as f16 two-way splits, 22
- * significant bits each, f32 accumulate -- logits at the distance two f32 summation orders have from the f32 matrix instructions,
- * which serve every other shape; a row that holds a feature beyond the f16 range, |x| > 65 504, is computed by the f32 matrix
- * instructions in a second short pass: finite input never gives NaN logits), RP_MLP_F32_STRICT = the f32 matrix instructions for every
- * row (each output a k-ordered fmaf chain, as candle's f32 Linear up to summation order), RP_MLP_BF16 = inputs rounded to bf16, f32
- * accumulate. */
+ * RP_MLP_F32 = f32-grade layer 1: inputs and weights as three bf16 parts each (exact: 3 x 8 = an f32's 24 significant bits), six of the
+ *   nine partial products of a multiplication accumulated in f32 -- what is dropped is below 2^-22 of a product, 2^-25.7 rms (an f32
+ *   multiply rounds by up to 2^-24); bf16 has the f32 exponent range, so there is no out-of-range row and no second pass; finite input
+ *   never gives NaN logits.  (A feature that is +-inf splits into inf + NaN: that row's logits are NaN, where candle's f32 Linear would
+ *   answer +-inf, NaN or -- every such product cut by the ReLU -- finite values; NaN features give NaN in both.)  A model whose three-part
+ *   weight groups do not fit the LDS runs the f32 matrix instructions.
+ * RP_MLP_F32_STRICT = the f32 matrix instructions for every row (each output a k-ordered fmaf chain, as candle's f32 Linear up to
+ *   summation order).
+ * RP_MLP_F32_FAST = two f16 parts per operand (22 significant bits, one partial product dropped: NARROWER than the reference's f32 products;
+ *   logits within 1e-5), a row that holds a feature beyond the f16 range, |x| > 65 504, is computed by the f32 matrix instructions in a
+ *   second short pass; the form the whole-stream window kernels of rp_batch_detect_model use at the matrix cores' full rate.
+ * RP_MLP_BF16 = inputs rounded to bf16, f32 accumulate. */
 
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits);
 

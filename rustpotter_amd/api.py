@@ -643,7 +643,7 @@ def batch_detect_sharded_dev(ctxs, templates, pcm_ptrs, S_list, N, stride, detec
         raise _err()
 
 
-MLP_PRECISION = {"f32": 0, "bf16": 1, "f32_strict": 2}   # RP_MLP_F32 / RP_MLP_BF16 / RP_MLP_F32_STRICT
+MLP_PRECISION = {"f32": 0, "bf16": 1, "f32_strict": 2, "f32_fast": 3}   # RP_MLP_F32 / RP_MLP_BF16 / RP_MLP_F32_STRICT / RP_MLP_F32_FAST
 
 
 _LIVE_CONTEXTS = weakref.WeakSet()   # every BatchContext alive (arithmetic_all)

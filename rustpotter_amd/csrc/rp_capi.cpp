@@ -1221,7 +1221,7 @@ int rp_stream_batch_new_multi(rp_ctx *ctx, size_t n_wakewords, const rp_wakeword
                 const int nl = (int)e->m->dims.size() - 1;
                 if (e->m->dims[0] % mfcc_size != 0) { set_last_error("Usage of wakewords with different mfcc size is not supported, ignoring wakeword"); return -1; }
                 if (w.none_index >= e->m->dims[nl]) { set_last_error("none_index out of range"); return -1; }
-                if (w.precision != RP_MLP_F32 && w.precision != RP_MLP_BF16 && w.precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
+                if (w.precision != RP_MLP_F32 && w.precision != RP_MLP_BF16 && w.precision != RP_MLP_F32_STRICT && w.precision != RP_MLP_F32_FAST) { set_last_error("unknown MLP precision"); return -1; }
                 if (!e->m->mfma_ok && w.precision == RP_MLP_BF16) { set_last_error("this layer-1 shape has no bf16 MFMA kernel"); return -1; }
                 e->none_index = w.none_index; e->precision = w.precision;
                 b->max_len = std::max(b->max_len, e->m->dims[0] / mfcc_size);
@@ -1287,7 +1287,7 @@ static int stream_batch_score_multi(rp_stream_batch *b, Staged &sg, const float 
                 c->time_begin(kKernelMlp);
                 uint32_t *redo = c->mlp_redo(rows);
                 if (!redo) return -1;
-                ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, first, S, pitch, n_new, K, dmean, wsum, dlog, redo, pitch, w.precision == RP_MLP_F32_STRICT), "mlp_mfma_kernel");
+                ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, first, S, pitch, n_new, K, dmean, wsum, dlog, redo, pitch, w.precision == RP_MLP_F32_STRICT ? (int)kMlpStrictF32 : w.precision == RP_MLP_F32_FAST ? (int)kMlpF16x2 : (int)kMlpF32), "mlp_mfma_kernel");
                 c->time_end();
                 if (!ok) return -1;
             } else {
@@ -1351,28 +1351,35 @@ void rp_model_free(rp_model *m) { delete m; }
 // stream (bf16 inputs: 0.132 against 0.155 ms at BASELINE config C5; f32 callers: its f16 two-way split form).  With the f32 matrix
 // instructions themselves the f32 matrix rate binds and the register-fragment kernel's 24 waves per CU overlap better (0.198 against
 // 0.207 ms): RP_MLP_STREAM=0 forces that kernel, RP_MLP_STREAM=2 the streaming kernel in the caller's own precision (benchmarks, tests).
+// RP_MLP_STREAM (a tuning knob of benchmarks and tests, not an arithmetic switch -- the arithmetic is the call's `precision`): 0 = the
+// register-fragment kernel for every shape, 2 = the streaming kernel with the f32 matrix instructions for RP_MLP_F32_STRICT too.
+static int mlp_internal_precision(int precision) {
+    return precision == RP_MLP_F32 ? (int)kMlpBf16x3 : precision == RP_MLP_F32_FAST ? (int)kMlpF16x2 : precision == RP_MLP_F32_STRICT ? (int)kMlpStrictF32 : (int)kMlpBf16;
+}
 static hipError_t mlp_rows_mfma(Ctx *c, const Model &m, const float *dx, size_t B, int precision, float *out) {
     const char *e = std::getenv("RP_MLP_STREAM");
     const int mode = e ? (e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1) : 1;
     MlpStreamPlan plan;
-    // f32 callers: the streaming kernel with f16 two-way splits of inputs and weights (kMlpF16x2: 22 significant bits per operand, f32
-    // accumulate -- logits within 1e-6 of the f32 matrix instructions') runs at the HBM stream's rate like the bf16 form, where the f32
-    // matrix rate bound both exact kernels (0.19 ms at C5)
+    // f32 callers (RP_MLP_F32): the streaming kernel with three-part bf16 splits of inputs and weights (kMlpBf16x3: exact operands, f32
+    // accumulate) runs at the HBM stream's rate like the bf16 form, where the f32 matrix rate bound both exact kernels (0.19 ms at C5)
     uint32_t *redo = c->mlp_redo(B);
     if (!redo) return hipErrorOutOfMemory;
-    if (precision == RP_MLP_F32_STRICT) {   // the f32 matrix instructions for every row: the register-fragment kernel overlaps them best
+    if (precision == RP_MLP_F32_STRICT && mode != 2) {   // the f32 matrix instructions for every row: the register-fragment kernel overlaps them best
         c->last_mlp_kernel = "mlp_mfma_kernel<f32 matrix instructions>";
         return launch_mlp_mfma(c->stream, m.dev, dx, B, kMlpStrictF32, out, redo);
     }
-    const int sprec = (mode == 1 && precision == RP_MLP_F32) ? (int)kMlpF16x2 : precision;
+    const int iprec = mlp_internal_precision(precision);
+    const int sprec = iprec == kMlpStrictF32 ? (int)kMlpF32 : iprec;   // (the stream kernel's kMlpF32 IS the f32 matrix instructions)
     if (mode != 0 && const_cast<Model &>(m).stream_plan(dx, B, sprec, &plan)) {
-        c->last_mlp_kernel = sprec == kMlpF16x2 ? "mlp_stream_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
+        c->last_mlp_kernel = sprec == kMlpBf16x3 ? "mlp_stream_kernel<bf16x3 splits>"
+                             : sprec == kMlpF16x2 ? "mlp_stream_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
                              : sprec == kMlpBf16 ? "mlp_stream_kernel<bf16>" : "mlp_stream_kernel<f32 matrix instructions>";
         return launch_mlp_stream(c->stream, m.dev, plan, dx, B, sprec, out, c->n_cu, redo);
     }
     c->last_mlp_kernel = precision == RP_MLP_BF16 ? "mlp_mfma_kernel<bf16>"
-                         : (mode != 0 && m.dev.w1s) ? "mlp_mfma_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows" : "mlp_mfma_kernel<f32 matrix instructions>";
-    return launch_mlp_mfma(c->stream, m.dev, dx, B, precision, out, redo);
+                         : (precision == RP_MLP_F32 && m.dev.w1t) ? "mlp_mfma_kernel<bf16x3 splits>"
+                         : (precision == RP_MLP_F32_FAST && m.dev.w1s) ? "mlp_mfma_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows" : "mlp_mfma_kernel<f32 matrix instructions>";
+    return launch_mlp_mfma(c->stream, m.dev, dx, B, precision == RP_MLP_BF16 ? (int)kMlpBf16 : precision == RP_MLP_F32 ? (int)kMlpF32 : iprec, out, redo);
 }
 
 int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, size_t B, int precision, float *logits) {
@@ -1382,7 +1389,7 @@ int rp_mlp_forward_batch(rp_ctx *ctx, const rp_model *model, const float *x, siz
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const Model &m = *model->impl;
         const int nl = (int)m.dims.size() - 1;
-        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT && precision != RP_MLP_F32_FAST) { set_last_error("unknown MLP precision"); return -1; }
         Staged sg(c);
         const float *dx = static_cast<const float *>(sg.in(x, B * (size_t)m.dims[0] * 4, c->stage_in));
         float *dl = static_cast<float *>(sg.out(logits, B * (size_t)m.dims[nl] * 4, c->stage_out));
@@ -1425,10 +1432,11 @@ static bool window_logits(Ctx *c, const Model &m, const float *dm, size_t S, siz
             c->time_begin(kKernelMlp);
             uint32_t *redo = c->mlp_redo(rows);
             if (!redo) return false;
-            ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, dm, S, nf, n_win, K, dmean, wsum, dlog, redo, 0, precision == RP_MLP_F32_STRICT), "mlp_mfma_kernel");
+            ok = hip_ok(launch_mlp_mfma_windows(c->stream, m.dev, dm, S, nf, n_win, K, dmean, wsum, dlog, redo, 0, precision == RP_MLP_F32_STRICT ? (int)kMlpStrictF32 : precision == RP_MLP_F32_FAST ? (int)kMlpF16x2 : (int)kMlpF32), "mlp_mfma_kernel");
             c->time_end();
             if (!ok) return false;
             c->last_mlp_kernel = precision == RP_MLP_F32_STRICT ? "mlp_mfma_kernel<f32 matrix instructions>, windows read in place"
+                                 : precision != RP_MLP_F32_FAST ? "mlp_mfma_kernel<bf16x3 splits>, windows read in place"
                                  : mlp_windows_supported(m.dev, n_win, K) == 1 ? "mlp_windows_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
                                  : mlp_windows_supported(m.dev, n_win, K) == 2 ? "mlp_windows_wide_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
                                  : "mlp_mfma_kernel<f16x2 splits>, windows read in place, + mlp_mfma_kernel<f32> on listed rows";
@@ -1465,7 +1473,7 @@ int rp_mlp_forward_windows(rp_ctx *ctx, const rp_model *model, const float *mfcc
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         const Model &m = *model->impl;
         const int nl = (int)m.dims.size() - 1, K = mfcc_size;
-        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT && precision != RP_MLP_F32_FAST) { set_last_error("unknown MLP precision"); return -1; }
         if (K < 1 || m.dims[0] % K != 0) { set_last_error("Model input size does not match the mfcc size"); return -1; }
         const int L = m.dims[0] / K;
         const size_t n_win = n_frames >= (size_t)L ? n_frames - L + 1 : 0, rows = S * n_win;
@@ -1491,7 +1499,7 @@ int rp_batch_detect_model(rp_ctx *ctx, const void *pcm, rp_sample_format fmt, si
         if (!hip_ok(hipSetDevice(c->device), "hipSetDevice")) return -1;
         if (pcm_stride < n_samples) { set_last_error("pcm_stride smaller than n_samples"); return -1; }
         if ((int)fmt < 0 || (int)fmt > 3) { set_last_error("unknown sample format"); return -1; }
-        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT) { set_last_error("unknown MLP precision"); return -1; }
+        if (precision != RP_MLP_F32 && precision != RP_MLP_BF16 && precision != RP_MLP_F32_STRICT && precision != RP_MLP_F32_FAST) { set_last_error("unknown MLP precision"); return -1; }
         const Model &m = *model->impl;
         const int nl_layers = (int)m.dims.size() - 1, K = mfcc_size;
         if (K < 1 || m.dims[0] % K != 0) { set_last_error("Incorrect model layers"); return -1; }

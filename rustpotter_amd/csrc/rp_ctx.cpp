@@ -624,7 +624,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
         if (!hip_ok(hipMemcpy(d.aimg3, aimg3.data(), sizeof(uint16_t) * aimg3.size(), hipMemcpyHostToDevice), "hipMemcpy(aimg3)")) return nullptr;
     }
     if (K == 5 && d.class_count[2] >= 4 && d.aimg) {   // dtw_mfma_group_kernel: class-2 chunks of one length, four to a workgroup
-        std::vector<int> quads, pairs;   // (pairs: the kernel's two-chunk shape measured SLOWER than dtw_mfma_kernel -- half the sharing does not pay the ring -- never built)
+        std::vector<int> quads;   // (the kernel's two-chunk shape measured SLOWER than dtw_mfma_kernel -- half the sharing does not pay the ring -- and is not built)
         std::vector<char> grouped(d.class_count[2], 0);
         for (int i = 0; i < d.class_count[2];) {
             int j = i;
@@ -635,7 +635,7 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
                 for (; b + 4 <= j; b += 4) { quads.push_back(d.class_first[2] + b); d.grp4_max_len = std::max(d.grp4_max_len, L); std::fill(grouped.begin() + b, grouped.begin() + b + 4, 1); }
             i = j;
         }
-        bool ok = !quads.empty() || !pairs.empty();
+        bool ok = !quads.empty();
         for (int i = 0; i < d.class_count[2] && ok;) {   // what is left, as runs
             if (grouped[i]) { ++i; continue; }
             int j = i;
@@ -645,11 +645,9 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
             i = j;
         }
         if (ok) {
-            std::vector<int> all(quads);
-            all.insert(all.end(), pairs.begin(), pairs.end());
-            if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.grp_first), sizeof(int) * all.size()), "hipMalloc(grp_first)")) return nullptr;
-            if (!hip_ok(hipMemcpy(d.grp_first, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice), "hipMemcpy(grp_first)")) return nullptr;
-            d.grp_count = (int)all.size(); d.grp4_count = (int)quads.size();
+            if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&d.grp_first), sizeof(int) * quads.size()), "hipMalloc(grp_first)")) return nullptr;
+            if (!hip_ok(hipMemcpy(d.grp_first, quads.data(), sizeof(int) * quads.size(), hipMemcpyHostToDevice), "hipMemcpy(grp_first)")) return nullptr;
+            d.grp_count = (int)quads.size();
         } else {
             d.rest_runs = 0;
         }
@@ -711,7 +709,7 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
         d.kpad = (dims[0] + 127) / 128 * 128;  // whole unrolled k-groups of both MFMA kernels
         const int rows = 16 * d.nt;
         std::vector<float> wf((size_t)rows * d.kpad, 0.f), b1(rows, 0.f);
-        std::vector<uint16_t> wh((size_t)rows * d.kpad, 0), wsp((size_t)2 * rows * d.kpad, 0);
+        std::vector<uint16_t> wh((size_t)rows * d.kpad, 0), wsp((size_t)2 * rows * d.kpad, 0), wtp((size_t)3 * rows * d.kpad, 0);
         for (int o = 0; o < n1; ++o) {
             b1[o] = biases[0][o];
             for (int i = 0; i < dims[0]; ++i) {
@@ -721,6 +719,9 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
                 const _Float16 w0 = (_Float16)v, w1 = (_Float16)(v - (float)w0);   // kMlpF16x2: w = w0 + w1 to 22 bits
                 __builtin_memcpy(&wsp[(size_t)o * d.kpad + i], &w0, 2);
                 __builtin_memcpy(&wsp[(size_t)rows * d.kpad + (size_t)o * d.kpad + i], &w1, 2);
+                uint16_t p3[3];   // kMlpBf16x3: w = p0 + p1 + p2 exactly
+                bf16_split3(v, p3);
+                for (int part = 0; part < 3; ++part) wtp[((size_t)part * rows + o) * d.kpad + i] = p3[part];
             }
         }
         std::vector<float> tail;
@@ -743,7 +744,7 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
                                     wsp[(size_t)part * rows * d.kpad + (size_t)o * d.kpad + 16 * f + 8 * h + e];
             if (!up(img.data(), img.size() * 2, &d.wwin)) return nullptr;
         }
-        if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) || !up(wsp.data(), wsp.size() * 2, &d.w1s) ||
+        if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) || !up(wsp.data(), wsp.size() * 2, &d.w1s) || !up(wtp.data(), wtp.size() * 2, &d.w1t) ||
             !up(b1.data(), b1.size() * 4, reinterpret_cast<void **>(&d.b1)) || !up(tail.data(), tail.size() * 4, reinterpret_cast<void **>(&d.tail)))
             return nullptr;
     }
@@ -776,7 +777,7 @@ const float *Model::wsum_for(int K) {
 // bf16, or two (one per half) in f32.  Zero past dims[0] and past dims[1].  The image does not depend on where the rows
 // start (the kernel shifts its reads instead), so it is built once per precision.
 bool Model::stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *plan) {
-    if (!mfma_ok || !mlp_stream_supported(dev, x) || (precision != kMlpF32 && precision != kMlpBf16 && precision != kMlpF16x2)) return false;
+    if (!mfma_ok || (precision != kMlpF32 && precision != kMlpBf16 && precision != kMlpF16x2 && precision != kMlpBf16x3) || !mlp_stream_supported(dev, x, precision)) return false;
     const int in = dims[0], n1 = dims[1], nt = dev.nt;
     const int q0 = (int)((reinterpret_cast<uintptr_t>(x) >> 4) & 7);
     const int par = ((in / 4) % 8) != 0;  // in % 16 == 0: the row pitch is 0 or 4 chunks mod 8
@@ -790,8 +791,8 @@ bool Model::stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *
     const int ksteps = 2 * ((lines_max + 1) / 2);                // two per unit, for every phase
     std::unique_ptr<DevBuf> &buf = stream_img[precision];
     if (!buf) {
-        const bool f32 = precision == kMlpF32, f16x2 = precision == kMlpF16x2;
-        const size_t wk = (size_t)(precision == kMlpBf16 ? 1024 : 2048) * nt;
+        const bool f32 = precision == kMlpF32, f16x2 = precision == kMlpF16x2, b3 = precision == kMlpBf16x3;
+        const size_t wk = (size_t)(precision == kMlpBf16 ? 1024 : b3 ? 3072 : 2048) * nt;
         std::vector<uint8_t> img(wk * ksteps, 0);
         auto wat = [&](int o, long k) -> float { return (o < n1 && k < in) ? w1_host[(size_t)o * in + k] : 0.f; };
         for (int m = 0; m < ksteps; ++m)
@@ -803,6 +804,14 @@ bool Model::stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *
                         for (int h = 0; h < 2; ++h) {
                             float *dst = reinterpret_cast<float *>(img.data() + wk * m + ((size_t)h * nt + n) * 1024 + l * 16);
                             for (int e = 0; e < 4; ++e) dst[e] = wat(o, k0 + 16 * h + e);
+                        }
+                    } else if (b3) {
+                        // pieces [part][n], part = 0, 1, 2: the exact three-part bf16 split of the weight; the eight k of a piece as in the bf16 image
+                        for (int e = 0; e < 8; ++e) {
+                            uint16_t p3[3];
+                            bf16_split3(wat(o, k0 + (e < 4 ? e : 12 + e)), p3);
+                            for (int part = 0; part < 3; ++part)
+                                reinterpret_cast<uint16_t *>(img.data() + wk * m + ((size_t)part * nt + n) * 1024 + l * 16)[e] = p3[part];
                         }
                     } else if (f16x2) {
                         // pieces [part][n]: part 0 = w0 = f16(w), part 1 = w1 = f16(w - w0); the eight k of a piece as in the bf16 image
@@ -837,6 +846,7 @@ Model::~Model() {
     if (dev.w1f) (void)hipFree(dev.w1f);
     if (dev.w1h) (void)hipFree(dev.w1h);
     if (dev.w1s) (void)hipFree(dev.w1s);
+    if (dev.w1t) (void)hipFree(dev.w1t);
     if (dev.wwin) (void)hipFree(dev.wwin);
     if (dev.b1) (void)hipFree(dev.b1);
     if (dev.tail) (void)hipFree(dev.tail);

@@ -29,6 +29,9 @@ constexpr int kDtwWin = 64;   // windows per wave
 struct GateList {
     const uint32_t *list = nullptr, *count = nullptr;
     uint32_t dense_min = 0;
+    // entries the list may hold per row of the call (1: the gate lists a row once; dtw_ragged_kernel's list holds a window once per ragged
+    // chunk that could not resolve it): the list-mode grids cover S x n_win x list_mult entries
+    uint32_t list_mult = 1;
     // Early abandon (detect-only calls in ScoreMode::Max): a DTW whose cheapest band cell already costs more than
     // abandon_nc * (m + n) cannot end with a score above the detection threshold (cell costs are >= 0 and every warping
     // path crosses every row), so a wave whose 64 windows x templates are ALL past that bound stops and reports score 0 for
@@ -899,7 +902,7 @@ static hipError_t launch_dtw_class(hipStream_t st, const TemplatesDev &t, int ch
         // streams contribute fewer than 64 windows each (or the windows come from a list): lanes of a wave span many
         // streams and read their frames from global memory (the caller guarantees W*K floats of slack after the last
         // stream's frames)
-        const size_t ft = (S * n_win + kDtwWin - 1) / kDtwWin;
+        const size_t ft = (S * n_win * (gl.list ? (size_t)gl.list_mult : 1) + kDtwWin - 1) / kDtwWin;
         const size_t blocks = ft * (size_t)n_chunks;
         if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
         hipLaunchKernelGGL((dtw_band_kernel<K, W, TC, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
@@ -932,7 +935,7 @@ static hipError_t launch_dtw_single_chunks(hipStream_t st, const TemplatesDev &t
     constexpr int KP = (K % 2 == 0) ? K + 1 : K;
     constexpr int NW = 2 * kDtwWin;
     if ((few_windows || gl.list) && KP == K) {
-        const size_t ft = (S * n_win + NW - 1) / NW;
+        const size_t ft = (S * n_win * (gl.list ? (size_t)gl.list_mult : 1) + NW - 1) / NW;
         const size_t blocks = ft * (size_t)n_chunks;
         if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
         hipLaunchKernelGGL((dtw_band2_kernel<K, W, (KP == K)>), dim3((unsigned)blocks), dim3(kDtwWin), 0, st, mfcc, frame_pitch,
@@ -960,6 +963,7 @@ static hipError_t launch_dtw_wide(hipStream_t st, const TemplatesDev &t, int cls
                                   size_t frame_pitch, size_t tiles, size_t first_win, size_t n_win, size_t out_win_pitch,
                                   float score_ref, float *scores, float *avg, bool few_windows = false, GateList gl = GateList{}, int chunk_base = -1) {
     if (n_chunks <= 0) return hipSuccess;
+    dtw_mark(gl.work(), kDtwRanRegister);
     if (chunk_base < 0) chunk_base = t.class_first[cls];
     if (few_windows || gl.list) {
         // lanes span streams (few windows per stream) or come from the gate's list: frames read from global memory
@@ -1160,6 +1164,7 @@ static hipError_t launch_dtw_k5(hipStream_t st, const TemplatesDev &t, int n1, c
         if (list_rows) {
             GateList g2 = gl;
             g2.list = gl.wk_all.rag_list + 1; g2.count = gl.wk_all.rag_list; g2.dense_min = 0; g2.fuse = nullptr;
+            g2.list_mult = (uint32_t)t.rag_count;   // every ragged chunk lists on its own (round-5 advice: a grid for S x n_win entries dropped the tail)
             if ((e = launch_dtw_single_chunks<5, W>(st, t, t.class_first[3], t.class_count[3] - (t.has_avg ? 1 : 0), mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg, false, g2)) != hipSuccess) return e;
             if ((e = launch_dtw_class<5, W, 2>(st, t, t.class_first[0], t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, false, g2)) != hipSuccess) return e;
         }

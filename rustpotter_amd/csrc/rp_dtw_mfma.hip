@@ -349,6 +349,9 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         if (P3) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg2[g]), __builtin_bit_cast(bf16x8, bop2[par]), acc[g], 0, 0, 0); \
     } while (0)
 
+#ifndef RP_P3_GAP   // band cells between a tile's two k-steps (A/B builds)
+#define RP_P3_GAP 1
+#endif
 // column c (c = 1 + u mod 12): rows r_q = c - W + 1 + q, q = 0..2W-1, sit in MFMA row slot (u + q + 14 - W) mod 12
 #define RP_STEP(GUARD)                                                                                                        \
     do {                                                                                                                      \
@@ -382,13 +385,13 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
             }                                                                                                                 \
             _Pragma("unroll") for (int g = 0; g < NTILE; ++g) {                                                               \
                 if (mfma_last_use<W, NT>(u, g) == q) RP_MFMA(g, u & 1);                                                       \
-                if (q > 0 && mfma_last_use<W, NT>(u, g) == q - 1) RP_MFMA2(g, u & 1);                                         \
+                if (q >= RP_P3_GAP && mfma_last_use<W, NT>(u, g) == q - RP_P3_GAP) RP_MFMA2(g, u & 1);                        \
             }                                                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
         _Pragma("unroll") for (int g = 0; g < NTILE; ++g) {                                                                   \
             if (mfma_last_use<W, NT>(u, g) < 0) { RP_MFMA(g, u & 1); RP_MFMA2(g, u & 1); }                                    \
-            if (mfma_last_use<W, NT>(u, g) == B - 1) RP_MFMA2(g, u & 1);                                                      \
+            else if (RP_P3_GAP > 0 && mfma_last_use<W, NT>(u, g) > B - 1 - RP_P3_GAP) RP_MFMA2(g, u & 1);                     \
         }                                                                                                                     \
     } while (0)
 
@@ -518,6 +521,10 @@ bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from
     const int mode = t.arith_mode();   // the context's arithmetic (rp_ctx_set_arithmetic), read per call
     if (mode == kArithStrictF32 || t.K != kMK || !(mode == kArithFastSplit ? t.aimg : t.aimg3) || t.max_diff != 0) return false;
     const bool p3 = mode != kArithFastSplit;
+    // chunks of 3..4 templates: the four-slot shape exists for the two-part form only (its three-part build does not fit the registers: the
+    // allocator spills thousands of values in the 16-column block); in the three-part arithmetic such chunks keep the tc-4 register kernel --
+    // the eight-slot shape would pay for eight templates and measures slower than that kernel for three
+    if (p3 && slots != 8) return false;
     // the two-part form: the score's sensitivity to the cost grows like 1 / score_ref (rp_kernels.h); the three-part form's products are
     // f32-grade, it needs no floor
     if (!p3 && !(score_ref >= kDtwMfmaMinScoreRef)) return false;
@@ -580,8 +587,8 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
         else { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, false, NT); else RP_LAUNCH_MFMA(WW, 8, false, NT); }                            \
     } while (0)
     if (slots == 4) {
-        if (band != 5 || nw != 12) return hipErrorNotSupported;
-        if (from_global) RP_LAUNCH_MFMA(5, 12, true, 4); else RP_LAUNCH_MFMA(5, 12, false, 4);
+        if (band != 5 || nw != 12 || p3) return hipErrorNotSupported;
+        if (from_global) RP_LAUNCH_MFMA_P(5, 12, true, 4, false); else RP_LAUNCH_MFMA_P(5, 12, false, 4, false);
     } else {
         switch (band) {
         case 3: RP_LAUNCH_MFMA_W(3, 8); break;

@@ -325,19 +325,17 @@ bool dtw_mfma_group_supported(const TemplatesDev &t, int band, size_t n_win, siz
     return tiles >= (size_t)64 * (size_t)device_cu_count();
 }
 
-// Scores the chunk groups t.grp_* (rp_ctx.cpp: runs of 4 or 2 class-2 chunks of one length); the caller sends the other chunks to dtw_mfma_kernel.
+// Scores the chunk groups t.grp_* (rp_ctx.cpp: runs of 4 class-2 chunks of one length); the caller sends the other chunks to dtw_mfma_kernel.
 hipError_t launch_dtw_mfma_group(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch,
                                  size_t first_win, size_t n_win, size_t out_win_pitch, float score_ref, float *scores) {
     if (t.grp_count <= 0 || S == 0 || n_win == 0) return hipSuccess;
     if (!wk.fix) return hipErrorInvalidValue;
     dtw_mark(wk, kDtwRanMfmaGroup | kDtwRanF16x2);
     const size_t total_tiles = (S * n_win + kGWin - 1) / kGWin;
-    // groups of one shape (SH, length class) per launch: [grp4_count quads][grp_count - grp4_count pairs]
-    for (int pass = 0; pass < 2; ++pass) {
-        const int sh = pass == 0 ? 4 : 2;
-        const int first = pass == 0 ? 0 : t.grp4_count, count = pass == 0 ? t.grp4_count : t.grp_count - t.grp4_count;
-        if (count <= 0) continue;
-        const size_t lds = dtw_mfma_group_lds_bytes(pass == 0 ? t.grp4_max_len : t.grp2_max_len, sh);
+    // every group is a run of FOUR chunks of one length (rp_ctx.cpp builds no other shape: see below)
+    {
+        const int sh = 4, first = 0, count = t.grp_count;
+        const size_t lds = dtw_mfma_group_lds_bytes(t.grp4_max_len, sh);
         size_t groups = (size_t)device_cu_count() / (size_t)count;
         if (groups < 1) groups = 1;
         const size_t n_tg = (total_tiles + (size_t)(kGWaves / sh) - 1) / (size_t)(kGWaves / sh);

@@ -170,7 +170,7 @@ struct Model {
     std::vector<float> w1_host;                     // layer-1 weights [dims[1]][dims[0]]
     std::map<int, std::unique_ptr<DevBuf>> wsums;   // per mfcc_size K: [16*nt][K], sum over frames of the layer-1 weights
     const float *wsum_for(int K);                   // (takes the window mean out after layer 1, launch_mlp_mfma_windows)
-    std::unique_ptr<DevBuf> stream_img[3];          // per precision (kMlpF32 / kMlpBf16 / kMlpF16x2): layer-1 weights in the stream kernel's fragment order
+    std::unique_ptr<DevBuf> stream_img[6];          // per precision (kMlpF32 / kMlpBf16 / kMlpF16x2 / kMlpBf16x3): layer-1 weights in the stream kernel's fragment order
     int stream_ksteps = 0;                          // k-steps of 32 the images hold (zero padded past dims[0])
     // plan of launch_mlp_stream for rows starting at x (x decides the phases); false: use launch_mlp_mfma
     bool stream_plan(const float *x, size_t B, int precision, MlpStreamPlan *plan);

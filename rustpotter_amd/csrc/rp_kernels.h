@@ -157,14 +157,14 @@ struct TemplatesDev {
     // some row is outside the range -- every window of this set is scored by dtw_ref_kernel.
     float *raw = nullptr;     // [T+has_avg][Lpad][K]
     int ref_only = 0;
+    // dtw_mfma_group_kernel (rp_dtw_mfma_group.hip): runs of 4 consecutive class-2 chunks of one template length, grp_first[] (device) the
+    // first chunk of each; rest_*: the class-2 chunks outside every group, as runs for dtw_mfma_kernel
+    int *grp_first = nullptr;
+    int grp_count = 0, grp4_max_len = 0;
+    int rest_runs = 0, rest_first[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rest_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // dtw_ragged_kernel (rp_dtw_ragged.hip, mfcc_size 5): the sample templates the equal-length matrix kernel does not take (lengths that
     // occur once or twice) as chunks of up to 8 templates of ANY lengths, shortest first; rimg = per template its A image, 32 bytes per
     // row ([k half 2] x 8 f16: the negated unit row split in two f16 parts) + 16 zero rows, rag_off[t] its offset in 16-byte units
-    // dtw_mfma_group_kernel (rp_dtw_mfma_group.hip): runs of 4 (the first grp4_count entries) or 2 consecutive class-2 chunks of one template
-    // length, grp_first[] (device) the first chunk of each; rest_*: the class-2 chunks outside every group, as runs for dtw_mfma_kernel
-    int *grp_first = nullptr;
-    int grp_count = 0, grp4_count = 0, grp4_max_len = 0, grp2_max_len = 0;
-    int rest_runs = 0, rest_first[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rest_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int rag_first = 0, rag_count = 0;
     int rag_min_len = 0;      // shortest template among them (needs >= 16 frames)
     int rag_a_cap = 0;        // largest chunk's images in bytes
@@ -411,21 +411,24 @@ struct MlpDev {
     float *w1f = nullptr;  // [16*nt][kpad] f32, zero padded
     void *w1h = nullptr;   // [16*nt][kpad] bf16, zero padded
     void *w1s = nullptr;   // [2][16*nt][kpad] f16: the two parts of the weights' f16 split (kMlpF16x2), zero padded
+    void *w1t = nullptr;   // [3][16*nt][kpad] bf16: the three parts of the weights' exact bf16 split (kMlpBf16x3), zero padded
     void *wwin = nullptr;  // mfcc_size 16, layer 1 <= 160 wide: the same two parts in the order the lanes of mlp_windows_kernel (<= 32 wide) /
                            // mlp_windows_wide_kernel read them, [frame f][32-output tile q][part][k-half h][output j < 32][8 k = 16 f + 8 h ..] f16
     float *b1 = nullptr;   // [16*nt]
     float *tail = nullptr; // layers 2..n: W [out][in] then b [out], concatenated
     int tail_floats = 0;
 };
-// kMlpF16x2 (internal): f32-grade layer 1 at the matrix cores' f16 rate -- inputs and weights as f16 two-way splits
-// (x = x0 + x1, w = w0 + w1, 22 significant bits each; x0 w0 + x1 w0 + x0 w1, f32 accumulate: the dropped x1 w1 is 2^-22 of a product),
-// what RP_MLP_F32 callers get from both matrix-core kernels (RP_MLP_STREAM=0: the f32 matrix instructions)
-// kMlpStrictF32: the f32 matrix instructions whatever RP_MLP_STREAM says (RP_MLP_F32_STRICT callers).  kMlpRedoF32 (internal): only
+// kMlpF16x2: layer 1 at the matrix cores' f16 rate -- inputs and weights as f16 two-way splits
+// (x = x0 + x1, w = w0 + w1, 22 significant bits each; x0 w0 + x1 w0 + x0 w1, f32 accumulate: the dropped x1 w1 is 2^-22 of a product):
+// RP_MLP_F32_FAST callers (through round 5 what RP_MLP_F32 meant)
+// kMlpStrictF32: the f32 matrix instructions for every row (RP_MLP_F32_STRICT callers).  kMlpRedoF32 (internal): only
 // the second pass of kMlpF16x2 -- the rows listed in `redo` again with the f32 matrix instructions (behind launch_mlp_stream).
 // redo (Ctx::mlp_redo): [2 + B] words, redo[0] = rows listed, redo[1] = workgroups of the second pass done, both zero between calls;
 // a row is listed when one of its features is beyond the f16 range (|x| > 65504, or not finite): the split cannot hold it, the f32
 // instructions can -- rp_mlp_forward_batch never answers NaN for finite input.
-enum { kMlpF32 = 0, kMlpBf16 = 1, kMlpF16x2 = 2, kMlpStrictF32 = 3, kMlpRedoF32 = 4 };
+// kMlpBf16x3: f32-grade layer 1 at the matrix cores' bf16 rate -- inputs and weights as THREE bf16 parts each (exact), six of the nine partial
+// products, f32 accumulate: what RP_MLP_F32 callers get (round 6; kMlpF16x2, 22-bit operands, is RP_MLP_F32_FAST).  No range limit, no second pass.
+enum { kMlpF32 = 0, kMlpBf16 = 1, kMlpF16x2 = 2, kMlpStrictF32 = 3, kMlpRedoF32 = 4, kMlpBf16x3 = 5 };
 // A launcher that fails between the split pass and the pass over the listed rows must not leave rows of THIS call listed for the next one
 // (the next call would append behind them and run its second pass on stale indices): the two counter words go back to zero behind
 // whatever was queued, as dtw_abort does for the DTW words.  Returns the error it was given.
@@ -448,7 +451,7 @@ struct MlpStreamPlan {
     int par = 0;                               // 1: even and odd rows differ in phase -- a workgroup takes rows of one parity
     int nbt = 0;                               // workgroup tiles: 128 rows (256-row span of one parity when par)
 };
-bool mlp_stream_supported(const MlpDev &m, const float *x);
+bool mlp_stream_supported(const MlpDev &m, const float *x, int precision = kMlpF32);
 hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out,
                              int n_cu, uint32_t *redo);
 // The rows are windows of L = dims[0]/K frames read IN PLACE from mfcc [S][n_frames][K] (a window's flattened features
@@ -461,7 +464,8 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 int mlp_windows_supported(const MlpDev &m, size_t n_win, int K);   // 1: mlp_windows_kernel, 2: mlp_windows_wide_kernel takes the call (0: mlp_mfma_kernel, rows read in place)
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
                                    const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch = 0,
-                                   bool strict_f32 = false);   // strict_f32: RP_MLP_F32_STRICT callers
+                                   int precision = kMlpF32);   // kMlpF32 (three bf16 parts, rows read in place) / kMlpF16x2 (RP_MLP_F32_FAST: the
+                                                               // staged-frame kernels) / kMlpStrictF32
 
 // WakewordModelTrain (src/wakewords/nn/wakeword_model_train.rs:204-209): act[l] / dz[l] are [B][dims[l+1]] device buffers
 hipError_t launch_train_forward(hipStream_t st, const float *x, size_t B, int n_layers, const int *dims, float *const *W,

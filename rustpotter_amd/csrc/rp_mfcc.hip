@@ -464,11 +464,14 @@ static hipError_t launch_mfcc_t(hipStream_t st, const MfccTablesDev &tb, const T
         if (env_cap) cap = env_cap;
         if (blocks > cap) blocks = cap;
     }
+    // RP_MFCC_LDS_PAD (tuning knob, round 6): bytes added to the LDS request = fewer workgroups resident per CU (40.8 KB each: four;
+    // +14 000: three; +41 000: two) -- the experiment behind DESIGN.md 8.4 "does the clock rise with fewer co-resident waves"
+    static const size_t lds_pad = [] { const char *e = getenv("RP_MFCC_LDS_PAD"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)0; }();
 #define RP_MFCC_LAUNCH(V, KT)                                                                                              \
     do {                                                                                                                   \
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mfcc_kernel<V, KT, TIN>), 160 * 1024);             \
         if (e != hipSuccess) return e;                                                                                     \
-        hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), mfcc_lds_bytes(tb.K1, KT > 0), st, pcm, \
+        hipLaunchKernelGGL((mfcc_kernel<V, KT, TIN>), dim3((unsigned)blocks), dim3(kMfccThreads), mfcc_lds_bytes(tb.K1, KT > 0) + lds_pad, st, pcm, \
                            n_samples, pcm_stride, (unsigned)tiles, total, first_frame, n_frames, out_frame_pitch, tb.K1, tb.hamming,  \
                            tb.tw240, tb.tw480, KT > 0 ? tb.melw : tb.fb, tb.dct, mfcc, mfcc2);                              \
     } while (0)

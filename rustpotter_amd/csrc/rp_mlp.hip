@@ -317,7 +317,8 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
     constexpr bool DB = NT <= 2;
     constexpr int PF = mlp_wpitch_f32(), PH = mlp_wpitch_bf16();
     // 16-byte pieces of a staged weight group: f32 four k each, bf16 eight, kMlpF16x2 eight in each of its two planes
-    constexpr int NPIECE = PREC == kMlpF32 ? N1P * (kMlpKG / 4) : PREC == kMlpBf16 ? N1P * (kMlpKG / 8) : 2 * N1P * (kMlpKG / 8);
+    constexpr int NPL = PREC == kMlpBf16x3 ? 3 : 2;   // planes of a split form's weights: w1h = [NPL][N1P][kpad] (MlpDev::w1t / w1s)
+    constexpr int NPIECE = PREC == kMlpF32 ? N1P * (kMlpKG / 4) : PREC == kMlpBf16 ? N1P * (kMlpKG / 8) : NPL * N1P * (kMlpKG / 8);
     constexpr int NV = (NPIECE + 64 * kMlpWaves - 1) / (64 * kMlpWaves);
     const int half = DB ? wbuf_floats / 2 : 0;
     // every thread moves NV pieces; when the slice is a whole number of pieces per thread the bounds test is dropped
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
                 if (FULL || o < N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1h + (size_t)o * kpad + g * kMlpKG + 8 * c);
             } else {   // kMlpF16x2: plane p of w1h = [2][N1P][kpad] f16 (MlpDev::w1s)
                 const int po = i / (kMlpKG / 8), c = i - po * (kMlpKG / 8);
-                if (FULL || po < 2 * N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1h + (size_t)po * kpad + g * kMlpKG + 8 * c);
+                if (FULL || po < NPL * N1P) wreg[v] = *reinterpret_cast<const f32x4 *>(w1h + (size_t)po * kpad + g * kMlpKG + 8 * c);
             }
         }
     };
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
                 if (FULL || o < N1P) *reinterpret_cast<f32x4 *>(reinterpret_cast<__bf16 *>(dstbuf) + o * PH + 8 * c) = wreg[v];
             } else {   // both planes, rows po = plane * N1P + o at the bf16 pitch
                 const int po = i / (kMlpKG / 8), c = i - po * (kMlpKG / 8);
-                if (FULL || po < 2 * N1P) *reinterpret_cast<f32x4 *>(reinterpret_cast<__bf16 *>(dstbuf) + po * PH + 8 * c) = wreg[v];
+                if (FULL || po < NPL * N1P) *reinterpret_cast<f32x4 *>(reinterpret_cast<__bf16 *>(dstbuf) + po * PH + 8 * c) = wreg[v];
             }
         }
     };
@@ -460,6 +461,41 @@ __global__ __launch_bounds__(64 * kMlpWaves, 3) void mlp_mfma_kernel(
                 }
                 if (u == 0) prefetch();
             }
+        } else if (PREC == kMlpBf16x3) {
+            // three bf16 parts per operand (exact), six of the nine partial products, f32 accumulate: f32-grade (RP_MLP_F32; rp_mlp_stream.hip
+            // has the same arithmetic).  No range limit: nothing is listed.
+            const __bf16 *wb = reinterpret_cast<const __bf16 *>(cur);
+#pragma unroll
+            for (int u = 0; u < NA / 2; ++u) {
+                const float4 lo = a[2 * u], hi = a[2 * u + 1];
+                const float xs[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                unsigned h0[4], h1[4], h2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = xs[2 * e], q = xs[2 * e + 1];
+                    const float rp = p - __uint_as_float(__float_as_uint(p) & 0xffff0000u), rq = q - __uint_as_float(__float_as_uint(q) & 0xffff0000u);
+                    h0[e] = __builtin_amdgcn_perm(__float_as_uint(q), __float_as_uint(p), 0x07060302u);
+                    h1[e] = __builtin_amdgcn_perm(__float_as_uint(rq), __float_as_uint(rp), 0x07060302u);
+                    h2[e] = __builtin_amdgcn_perm(__float_as_uint(rq - __uint_as_float(__float_as_uint(rq) & 0xffff0000u)),
+                                                  __float_as_uint(rp - __uint_as_float(__float_as_uint(rp) & 0xffff0000u)), 0x07060302u);
+                }
+                const bf16x8 av0 = __builtin_bit_cast(bf16x8, (u32x4v){h0[0], h0[1], h0[2], h0[3]});
+                const bf16x8 av1 = __builtin_bit_cast(bf16x8, (u32x4v){h1[0], h1[1], h1[2], h1[3]});
+                const bf16x8 av2 = __builtin_bit_cast(bf16x8, (u32x4v){h2[0], h2[1], h2[2], h2[3]});
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(wb + (16 * n + li) * PH + 32 * u + 8 * lk);
+                    const bf16x8 b1v = *reinterpret_cast<const bf16x8 *>(wb + (N1P + 16 * n + li) * PH + 32 * u + 8 * lk);
+                    const bf16x8 b2v = *reinterpret_cast<const bf16x8 *>(wb + (2 * N1P + 16 * n + li) * PH + 32 * u + 8 * lk);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, b2v, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, b1v, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av2, b0, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, b1v, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, b0, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, b0, acc[n], 0, 0, 0);
+                }
+                if (u == 0) prefetch();
+            }
         } else {
             const __bf16 *wb = reinterpret_cast<const __bf16 *>(cur);
 #pragma unroll
@@ -553,22 +589,31 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
     int h2w = 1;
     for (int l2 = 2; l2 < m.n_layers; ++l2) h2w = m.dims[l2] + 1 > h2w ? m.dims[l2] + 1 : h2w;
     h2w |= 1;
-    size_t wbuf = (size_t)16 * NT * mlp_wpitch_bf16() * (NT <= 2 ? 2 : 1);      // group(s) of the two f16 planes of kMlpF16x2 (f32 and bf16 ones are smaller)
     static_assert(mlp_wpitch_bf16() >= mlp_wpitch_f32(), "staged weight group");
-    const size_t h1 = (size_t)kMlpWaves * kMlpRowsPerWave * (16 * NT + 1);
-    if (h1 > wbuf) wbuf = h1;
-    wbuf = (wbuf + 3) & ~(size_t)3;
-    const size_t lds = ((size_t)((m.tail_floats + 3) & ~3) + wbuf + (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // the caller's precision (rp_kernels.h): kMlpF32 = RP_MLP_F32 = f32-grade products on the bf16 matrix instruction (three exact parts per
+    // operand, kMlpBf16x3); kMlpF16x2 = RP_MLP_F32_FAST (two f16 parts, 22-bit, + the f32 pass on listed rows); kMlpStrictF32 = the f32 matrix
+    // instructions for every row
+    if (precision == kMlpStrictF32) precision = kMlpF32;
+    else if (precision == kMlpF32 && m.w1t) precision = kMlpBf16x3;
+    else if (precision == kMlpF16x2 && !m.w1s) precision = kMlpF32;
+    // staged weight group(s): 16 NT rows x the bf16 pitch, in floats, for the two f16 planes of kMlpF16x2 (f32 and bf16 groups are smaller);
+    // the three bf16 planes of kMlpBf16x3 take half again as much -- a model whose three-part groups do not fit the CU's LDS beside its tail
+    // layers (the widest ones) runs the f32 matrix instructions instead: exact either way
+    size_t wbuf = 0, lds = 0;
+    for (;;) {
+        wbuf = (size_t)(precision == kMlpBf16x3 ? 24 : 16) * NT * mlp_wpitch_bf16() * (NT <= 2 ? 2 : 1);
+        const size_t h1 = (size_t)kMlpWaves * kMlpRowsPerWave * (16 * NT + 1);
+        if (h1 > wbuf) wbuf = h1;
+        wbuf = (wbuf + 3) & ~(size_t)3;
+        lds = ((size_t)((m.tail_floats + 3) & ~3) + wbuf + (size_t)kMlpWaves * kMlpRowsPerWave * h2w) * sizeof(float);
+        if (lds <= 160 * 1024) break;
+        if (precision != kMlpBf16x3) return hipErrorInvalidValue;
+        precision = kMlpF32;
+    }
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpBf16>), 160 * 1024); e != hipSuccess) return e;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF32>), 160 * 1024); e != hipSuccess) return e;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpF16x2>), 160 * 1024); e != hipSuccess) return e;
-    // f32 callers: f16 two-way splits on the f16 matrix instruction (kMlpF16x2, rp_kernels.h) unless RP_MLP_STREAM=0 asks for the f32 ones
-    if (precision == kMlpStrictF32) precision = kMlpF32;
-    else if (precision == kMlpF32 && m.w1s) {
-        const char *env = std::getenv("RP_MLP_STREAM");
-        if (!(env && env[0] == '0')) precision = kMlpF16x2;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_mfma_kernel<NT, kMlpBf16x3>), 160 * 1024); e != hipSuccess) return e;
     if (B > 0xffffffffULL) return hipErrorInvalidValue;
     uint32_t *const no_redo = nullptr;
     if (precision == kMlpF16x2 || precision == kMlpRedoF32) {
@@ -586,7 +631,11 @@ static hipError_t launch_mlp_nt(hipStream_t st, const MlpDev &m, const float *x,
                            m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, redo, 1);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return mlp_redo_abort(st, redo, e);
         return hipSuccess;
-    } else if (precision == kMlpBf16)
+    } else if (precision == kMlpBf16x3)
+        hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16x3>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
+                           m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1t), m.b1, m.tail, m.tail_floats, m.n_layers,
+                           m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, no_redo, 0);
+    else if (precision == kMlpBf16)
         hipLaunchKernelGGL((mlp_mfma_kernel<NT, kMlpBf16>), dim3((unsigned)blocks), dim3(64 * kMlpWaves), lds, st, x, B, m.dims[0],
                            m.kpad, m.w1f, static_cast<const __bf16 *>(m.w1h), m.b1, m.tail, m.tail_floats, m.n_layers,
                            m.dims[1], m.dims[2], m.dims[3], m.dims[4], h2w, (int)wbuf, out, row_stride, rows_per_stream, stream_skip, mean, wsum, K, no_redo, 0);
@@ -1150,7 +1199,7 @@ static hipError_t launch_mlp_windows(hipStream_t st, const MlpDev &m, const floa
 }
 
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
-                                   const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch, bool strict_f32) {
+                                   const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch, int precision) {
     const size_t B = S * n_win;
     if (B == 0) return hipSuccess;
     if (K < 1 || K % 4 != 0 || m.dims[0] % K != 0) return hipErrorInvalidValue;  // 16-byte aligned window rows
@@ -1160,7 +1209,8 @@ hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float 
     if (pitch < n_win) return hipErrorInvalidValue;
     (void)n_frames;
     const size_t skip = (pitch - n_win) * K;
-    if (const int form = (!strict_f32 && redo) ? mlp_windows_supported(m, n_win, K) : 0) {
+    // the staged-frame kernels (mlp_windows_kernel / mlp_windows_wide_kernel) multiply two-part f16 splits: RP_MLP_F32_FAST only
+    if (const int form = (precision == kMlpF16x2 && redo) ? mlp_windows_supported(m, n_win, K) : 0) {
         // whole streams (or long runs of windows): the frames staged once per workgroup; then the listed rows with the f32 instructions
         if (S * n_win > 0xffffffffULL) return hipErrorInvalidValue;
         if (hipError_t e = form == 1 ? launch_mlp_windows(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch)
@@ -1175,7 +1225,7 @@ hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float 
         }
         return e2 == hipSuccess ? e2 : mlp_redo_abort(st, redo, e2);
     }
-    const int prec = strict_f32 ? kMlpStrictF32 : kMlpF32;
+    const int prec = precision;
     switch (m.nt) {
     case 1: return launch_mlp_nt<1>(st, m, mfcc, B, prec, out, redo, (size_t)K, n_win, skip, mean, wsum, K);
     case 2: return launch_mlp_nt<2>(st, m, mfcc, B, prec, out, redo, (size_t)K, n_win, skip, mean, wsum, K);

@@ -56,12 +56,12 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
     int h2p, float *__restrict__ out, uint32_t *__restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int N1P = 16 * NT;
-    constexpr int WK = (PREC == kMlpBf16 ? 1024 : 2048) * NT;   // bytes of fragment-ordered weights per k-step (32 k)
+    constexpr int WK = (PREC == kMlpBf16 ? 1024 : PREC == kMlpBf16x3 ? 3072 : 2048) * NT;   // bytes of fragment-ordered weights per k-step (32 k)
     constexpr int WU = 2 * WK;                                 // per unit
     constexpr int WP = WU / 1024;                              // 1 KB DMA pieces per unit, one per wave
     constexpr int NS = D + 1, NW = D + 2;                      // ring depths (rows: private to a wave; weights: shared); D + 1
                                                                // units are in flight while a unit is being worked on
-    constexpr int WF = PREC == kMlpBf16 ? NT : 2 * NT;         // 16-byte weight pieces a lane holds per k-step
+    constexpr int WF = PREC == kMlpBf16 ? NT : PREC == kMlpBf16x3 ? 3 * NT : 2 * NT;   // 16-byte weight pieces a lane holds per k-step
     constexpr int WPW = (WP + kStreamWaves - 1) / kStreamWaves;   // weight pieces a wave moves per unit (the last ones may move one fewer)
     constexpr int H1P = N1P + 4;                               // h1 row pitch: 16-byte aligned rows on distinct bank quads
     float *tl = reinterpret_cast<float *>(smem);
@@ -199,6 +199,38 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
             for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av1, __builtin_bit_cast(f16x8s, wf.w[n]), acc[n], 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av0, __builtin_bit_cast(f16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
+        } else if (PREC == kMlpBf16x3) {   // pieces: [part][n], eight bf16 each: w0, w1, w2 (w = w0 + w1 + w2 exactly, Model::stream_plan)
+            // f32-grade products (RP_MLP_F32): x = x0 + x1 + x2 exactly -- x0 = x & 0xffff0000 (a bf16), r = x - x0, x1 = r & 0xffff0000,
+            // x2 = r - x1 (at most 8 significant bits: a bf16 too) -- and the six partial products x_i w_j with i + j <= 2 (what is dropped
+            // is below 2^-22 of a product, 2^-25.7 rms; an f32 multiply rounds by up to 2^-24).  bf16 has the f32 exponent range: no row is
+            // out of range, nothing is listed for a second pass.
+            const float xs[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            unsigned h0[4], h1[4], h2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float p = xs[2 * e], q = xs[2 * e + 1];
+                const float rp = p - __uint_as_float(__float_as_uint(p) & 0xffff0000u), rq = q - __uint_as_float(__float_as_uint(q) & 0xffff0000u);
+                h0[e] = __builtin_amdgcn_perm(__float_as_uint(q), __float_as_uint(p), 0x07060302u);
+                h1[e] = __builtin_amdgcn_perm(__float_as_uint(rq), __float_as_uint(rp), 0x07060302u);
+                h2[e] = __builtin_amdgcn_perm(__float_as_uint(rq - __uint_as_float(__float_as_uint(rq) & 0xffff0000u)),
+                                              __float_as_uint(rp - __uint_as_float(__float_as_uint(rp) & 0xffff0000u)), 0x07060302u);
+            }
+            const bf16x8s av0 = __builtin_bit_cast(bf16x8s, (u32x4s){h0[0], h0[1], h0[2], h0[3]});
+            const bf16x8s av1 = __builtin_bit_cast(bf16x8s, (u32x4s){h1[0], h1[1], h1[2], h1[3]});
+            const bf16x8s av2 = __builtin_bit_cast(bf16x8s, (u32x4s){h2[0], h2[1], h2[2], h2[3]});
+            // smallest terms first, so that they meet before the large ones take the accumulator's low bits
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[2 * NT + n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av2, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
         } else {                 // pieces: [n], eight bf16 each
             bf16x8s av;
             av[0] = (__bf16)a0.x; av[1] = (__bf16)a0.y; av[2] = (__bf16)a0.z; av[3] = (__bf16)a0.w;
@@ -343,7 +375,7 @@ static int stream_tail_lds(const MlpDev &m, int *h2p) {
 }
 
 static size_t stream_lds_bytes(int nt, int precision, int depth, int tail_lds, int h2p, int waves = kStreamWavesMax) {
-    const size_t wu = (size_t)(precision == kMlpBf16 ? 2048 : 4096) * nt;
+    const size_t wu = (size_t)(precision == kMlpBf16 ? 2048 : precision == kMlpBf16x3 ? 6144 : 4096) * nt;
     return ((size_t)tail_lds + 16 * nt) * 4 + (depth + 2) * wu + (size_t)waves * (depth + 1) * 4096 +
            (size_t)waves * 16 * (16 * nt + 4) * 4 + (size_t)waves * 16 * h2p * 4;
 }
@@ -364,11 +396,12 @@ static hipError_t launch_stream_t(hipStream_t st, const MlpDev &m, const MlpStre
     return hipGetLastError();
 }
 
-bool mlp_stream_supported(const MlpDev &m, const float *x) {
+bool mlp_stream_supported(const MlpDev &m, const float *x, int precision) {
     if (!((m.nt == 1 || m.nt == 2) && m.dims[0] % 16 == 0 && m.dims[0] >= 64 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)) return false;
     int h2p = 4;
     const int tail_lds = stream_tail_lds(m, &h2p);
-    return stream_lds_bytes(m.nt, kMlpF32, 1, tail_lds, h2p) <= 160 * 1024;   // wide hidden layers: mlp_mfma_kernel
+    // wide hidden layers: mlp_mfma_kernel (the three-part form's weight ring is half again as large as the f32 one's)
+    return stream_lds_bytes(m.nt, precision == kMlpBf16x3 ? (int)kMlpBf16x3 : (int)kMlpF32, 1, tail_lds, h2p) <= 160 * 1024;
 }
 
 static hipError_t launch_mlp_stream_pass(hipStream_t st, const MlpDev &m, const MlpStreamPlan &p, const float *x, size_t B, int precision, float *out, int n_cu,
@@ -393,8 +426,15 @@ static hipError_t launch_mlp_stream_pass(hipStream_t st, const MlpDev &m, const 
     if (const char *e = getenv("RP_MLP_STREAM_DEPTH")) if (e[0] == '1') depth = 1;   // benchmarks: the shallower ring
     int waves = 8;
     if (const char *e = getenv("RP_MLP_STREAM_WAVES")) if (e[0] == '4' && 2 * stream_lds_bytes(m.nt, precision, 1, tail_lds, h2p, 4) <= 160 * 1024) { waves = 4; depth = 1; }
+    // the three-part form's weight ring is half again as large: the deep ring (three units of rows in flight per wave) fits with six waves
+    // per workgroup, not with eight
+    if (precision == kMlpBf16x3 && depth == 1 && waves == 8 && stream_lds_bytes(m.nt, precision, 2, tail_lds, h2p, 6) <= 160 * 1024) {
+        const char *e = getenv("RP_MLP_STREAM_WAVES");
+        if (!(e && e[0] == '8')) { waves = 6; depth = 2; }
+    }
 #define RP_STREAM_CASE(NT_, PREC_)                                                                        \
     if (m.nt == NT_ && precision == PREC_) {                                                              \
+        if (waves == 6) return launch_stream_t<NT_, PREC_, 2, 6>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo); \
         if (waves == 4) return launch_stream_t<NT_, PREC_, 1, 4>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo); \
         return depth == 2 ? launch_stream_t<NT_, PREC_, 2, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo)   \
                           : launch_stream_t<NT_, PREC_, 1, 8>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo);  \
@@ -405,6 +445,8 @@ static hipError_t launch_mlp_stream_pass(hipStream_t st, const MlpDev &m, const 
     RP_STREAM_CASE(2, kMlpBf16)
     RP_STREAM_CASE(1, kMlpF16x2)
     RP_STREAM_CASE(2, kMlpF16x2)
+    RP_STREAM_CASE(1, kMlpBf16x3)
+    RP_STREAM_CASE(2, kMlpBf16x3)
 #undef RP_STREAM_CASE
     return hipErrorInvalidValue;
 }

@@ -35,12 +35,13 @@ def stream_summary(scores, agg, n_det):
     return out
 
 
-def gather_per_stream(local, world_size, group=None):
+def gather_per_stream(local, world_size, group=None, force_collective=False):
     """all_gather of an equally sized per-stream tensor -> tensor [world_size * S_local, ...]
-    ordered by global stream id (rank-major, the order shard_bounds / weak_first_stream use)."""
+    ordered by global stream id (rank-major, the order shard_bounds / weak_first_stream use).
+    force_collective: a one-rank job still goes through the collective (the RCCL exercise on a one-GPU box, tests/test_gpu_rccl.py)."""
     import torch
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         return local
     if local.is_cuda and dist.get_backend(group) == "gloo":  # CPU-backend dry runs: stage through host memory
         return gather_per_stream(local.cpu(), world_size, group).to(local.device)
@@ -49,12 +50,12 @@ def gather_per_stream(local, world_size, group=None):
     return torch.cat(parts, dim=0)
 
 
-def gather_ragged(local, world_size, group=None):
+def gather_ragged(local, world_size, group=None, force_collective=False):
     """all_gather for shards whose sizes differ by at most one row (strong scaling of a fixed
-    stream set): pads to the largest shard, gathers, trims."""
+    stream set): pads to the largest shard, gathers, trims.  force_collective: as gather_per_stream."""
     import torch
     import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         return local
     if local.is_cuda and dist.get_backend(group) == "gloo":  # CPU-backend dry runs: stage through host memory
         return gather_ragged(local.cpu(), world_size, group).to(local.device)

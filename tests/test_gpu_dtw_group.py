@@ -146,7 +146,8 @@ def test_the_size_rule_and_the_modes_that_keep_the_plain_kernel(ra, ctx):
     mf = _streams(4, 80, first=700)
     tm = ra.Templates(ctx, templates)
     ctx.dtw_kernels()
-    small, _, _ = ctx.dtw_scores(mf, tm)
+    with ctx.arithmetic("fast_split"):
+        small, _, _ = ctx.dtw_scores(mf, tm)
     assert "dtw_mfma_group_kernel" not in ctx.dtw_kernels()
     with _env("2"):
         forced, _, _ = ctx.dtw_scores(mf, tm)
@@ -157,7 +158,7 @@ def test_the_size_rule_and_the_modes_that_keep_the_plain_kernel(ra, ctx):
 def test_c4_share_at_full_size(ra):
     """BASELINE config C4, one GPU's share (8 192 streams x 297 windows x 64 templates of 100 frames): by the size rule the group form runs
     unasked; every score equals dtw_mfma_kernel's bit for bit (156 M scores), a stream equals itself scored alone."""
-    ctx = ra.BatchContext(device=0, host_pointers=True)
+    ctx = ra.BatchContext(device=0, host_pointers=True, arithmetic="fast_split")   # the group form is a two-part-f16 kernel
     templates = _templates({100: 64}, seed=3)
     mf = _streams(8192, 396, first=900, base=16)
     tm = ra.Templates(ctx, templates)

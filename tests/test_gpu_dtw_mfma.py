@@ -1,7 +1,9 @@
 """dtw_mfma_kernel (rustpotter_amd/csrc/rp_dtw_mfma.hip): the banded DTW whose cosine costs come out of the matrix cores, taken for
 mfcc_size 5 chunks of 3..8 same-length templates (5..8: band 3..5, eight template slots per wave; 3..4: band 5, four slots).  Against the oracle (1e-5, the gate of every DTW test), against the
-register kernels it replaces (RP_DTW_MFMA=0: same scores to 2e-6, and not the same bits -- i.e. the kernel really runs), and in
-its other modes: tiles that straddle streams, frames read from global memory (live-stream batches, the gate's list), early abandon."""
+register kernels it replaces (RP_ARITH_STRICT_F32: same scores to 2e-6, and not the same bits -- i.e. the kernel really runs), and in
+its other modes: tiles that straddle streams, frames read from global memory (live-stream batches, the gate's list), early abandon.
+Every test of this file runs in BOTH matrix arithmetics (the `ctx` fixture): RP_ARITH_F32_MATRIX (the default: three bf16 parts per
+operand, f32-grade) and RP_ARITH_FAST_SPLIT (two f16 parts, 22-bit, opt-in); the mfcc_size 13 / 16 kernel exists for the latter only."""
 import os
 
 import numpy as np
@@ -20,9 +22,13 @@ def ra():
     return rustpotter_amd
 
 
-@pytest.fixture(scope="module")
-def ctx(ra):
-    return ra.BatchContext(device=0, host_pointers=True)
+@pytest.fixture(scope="module", params=["f32_matrix", "fast_split"])
+def ctx(ra, request):
+    return ra.BatchContext(device=0, host_pointers=True, arithmetic=request.param)
+
+
+def _fast(ctx):
+    return ctx.get_arithmetic()[0] == "fast_split"
 
 
 def rel_close(a, b, tol=1e-5):
@@ -64,7 +70,8 @@ def test_scores_match_the_oracle(ra, ctx, L, T):
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm)
     assert rel_close(scores, reg, 2e-6), np.abs(scores / reg - 1).max()
-    matrix = (T >= 5 and L >= 12) or (3 <= T <= 4 and L >= 16)
+    # (chunks of 3..4 templates: the four-slot shape exists for the two-part f16 arithmetic only)
+    matrix = (T >= 5 and L >= 12) or (3 <= T <= 4 and L >= 16 and _fast(ctx))
     assert np.array_equal(scores, reg) == (not matrix), "which chunks take the matrix-core kernel"
 
 
@@ -157,9 +164,10 @@ def test_identical_window_and_template(ra, ctx):
 
 
 def test_long_templates_take_the_eight_wave_shape(ra, ctx):
-    """250-frame templates: the A image and twelve waves' frame stages do not fit the CU's LDS together, the launch falls back to
-    eight waves per workgroup."""
-    K, L, T = 5, 250, 5
+    """250-frame templates (two-part form; 170 frames in the three-part form, whose A image is twice as large: beyond ~179 frames it does not
+    fit beside eight waves' frame stages and the set keeps the register kernels): the A image and twelve waves' frame stages do not fit
+    the CU's LDS together, the launch falls back to eight waves per workgroup."""
+    K, L, T = 5, 250 if _fast(ctx) else 170, 5
     templates = orc.synth_templates(SEED + 13, T, L, K)
     mf = _streams(2, L + 33, K, first=90)
     tm = ra.Templates(ctx, templates)
@@ -172,6 +180,24 @@ def test_long_templates_take_the_eight_wave_shape(ra, ctx):
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm)
     assert rel_close(scores, reg, 2e-6) and not np.array_equal(scores, reg)
+
+
+def test_templates_too_long_for_the_three_part_image_keep_the_register_kernels(ra):
+    """RP_ARITH_F32_MATRIX, 250-frame templates: (250 + 16) x 512 bytes of A image + eight frame stages exceed 160 KB -- the register kernels
+    score (the arithmetic switch changes nothing), against the oracle."""
+    ctx = ra.BatchContext(device=0, host_pointers=True)
+    K, L, T = 5, 250, 5
+    templates = orc.synth_templates(SEED + 13, T, L, K)
+    mf = _streams(2, L + 33, K, first=90)
+    tm = ra.Templates(ctx, templates)
+    ctx.dtw_kernels()
+    scores, _, _ = ctx.dtw_scores(mf, tm)
+    assert ctx.dtw_kernels() == ["register kernels"]
+    with _registers_only():
+        reg, _, _ = ctx.dtw_scores(mf, tm)
+    assert np.array_equal(scores, reg)
+    for w in (0, 16, 33):
+        assert rel_close(scores[1, w, 2], orc.score_window(mf[1][w:w + L], templates[2]))
 
 
 def test_long_templates_in_a_chunk_of_four_keep_the_register_kernel(ra, ctx):
@@ -285,7 +311,10 @@ def test_max_inside_the_dtw_kernel_equals_the_aggregate_pass(ra, ctx, T, L):
     assert np.array_equal(scores, scores2) and np.array_equal(agg, agg2) and np.array_equal(agg, scores.max(axis=2))
     assert np.array_equal(n_det, n2) and np.array_equal(det, det2)
     assert np.array_equal(n_only, n_only2) and np.array_equal(det_only, det_only2) and np.array_equal(n_only, n_det)
-    assert n_fused == 0 and n_pass == 1, (n_fused, n_pass)   # launches of the aggregate pass inside the two calls
+    # launches of the aggregate pass inside the two calls (chunks of 3..4 templates reach the matrix kernel in the two-part arithmetic only:
+    # in the default one the register kernels score them and the pass runs)
+    fused_here = T >= 5 or _fast(ctx)
+    assert n_fused == (0 if fused_here else 1) and n_pass == 1, (n_fused, n_pass)
     for cpc in (1, 4):
         out = []
         for fused in (True, False):
@@ -343,7 +372,8 @@ def test_matrix_core_sweep_few_cases(ra):
 
 @pytest.mark.parametrize("K,L,T", [(16, 40, 8), (16, 12, 3), (16, 61, 11), (13, 37, 5), (13, 24, 8), (13, 100, 3)])
 def test_wide_frames_match_the_oracle(ra, ctx, K, L, T):
-    """mfcc_size 13 / 16 (dtw_mfma_wide_kernel, rp_dtw_mfma_wide.hip): every length at least three times, band 5, through the batched
+    """mfcc_size 13 / 16 (dtw_mfma_wide_kernel, rp_dtw_mfma_wide.hip; two-part f16 products: RP_ARITH_FAST_SPLIT only -- in the default
+    arithmetic these sets run the wide register kernels): every length at least three times, band 5, through the batched
     detector (its frame rows end with slack: the kernel reads its frames from global memory).  Scores against the oracle, against the
     wide register kernels (2e-6, not the same bits), and the live-stream batch against the offline call bit for bit."""
     S, N = 3, 480 * 45
@@ -359,7 +389,8 @@ def test_wide_frames_match_the_oracle(ra, ctx, K, L, T):
         assert rel_close(agg[s], ref_a)
     with _registers_only():
         _, _, reg, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
-    assert rel_close(scores, reg, 2e-6) and not np.array_equal(scores, reg)
+    # (RP_ARITH_F32_MATRIX has no matrix kernel for these frame sizes: the wide register kernels score, the switch changes nothing)
+    assert rel_close(scores, reg, 2e-6) and np.array_equal(scores, reg) == (not _fast(ctx))
     sb = ra.StreamBatch(ctx, tm, cfg, S, max_chunks_per_call=2)
     compared = 0
     for i in range(0, N, 960):

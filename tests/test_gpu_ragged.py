@@ -217,6 +217,31 @@ def test_windows_the_kernel_cannot_resolve_are_scored_again(ra, ctx):
         assert rel_close(sc2[s], ref_s), rel_err(sc2[s], ref_s)
 
 
+def test_two_ragged_chunks_may_both_list_every_window(ra, ctx):
+    """More than eight templates of unequal length = two ragged chunks, each listing on its own: digital silence makes BOTH list (nearly)
+    every window, so the list holds up to two entries per window -- the list-mode launches must cover all of them (round-5 advice: a grid
+    sized for one entry per window dropped the tail, and a dropped window kept the matrix kernel's unresolved score)."""
+    lens = (40, 57, 33, 64, 45, 51, 38, 60, 47, 55)
+    templates = _ragged_templates(SEED + 29, lens, 5)
+    S, N = 4, 480 * 120
+    pcm = np.stack([orc.synth_pcm(SEED, 170 + s, N) for s in range(S)])
+    pcm[:, 480 * 12:] = 0.0                                # nine tenths of every stream: digital silence
+    pcm[3] = 0.0
+    tm = ra.Templates(ctx, templates)
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    ctx.dtw_kernels()
+    with _ragged_on():
+        _, _, sc, agg = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    ran = ctx.dtw_kernels()
+    assert "dtw_ragged_kernel" in ran and "register kernels" in ran, ran
+    mf = ctx.mfcc(pcm, 5)
+    for s in range(S):
+        ref_s, ref_a = orc.score_stream(mf[s], templates)
+        assert rel_close(sc[s], ref_s), rel_err(sc[s], ref_s)
+        assert rel_close(agg[s], ref_a)
+
+
 def test_a_streams_bits_do_not_depend_on_the_batch(ra, ctx):
     """Offset and scale of the shared operand are functions of the stream alone (ragged_prep_kernel): a stream scored alone, first or last in
     a batch gets the same bits -- the 512-window tiles fall differently each time."""

@@ -346,30 +346,36 @@ def test_mlp_stream_kernel_shapes_and_batch_sizes(ra, ctx, dims, B):
     ref16 = orc.mlp_forward(x, ws, bs, bf16_layer1=True)
     assert np.allclose(got16, ref16, rtol=1e-3, atol=1e-3), np.abs(got16 - ref16).max()
     os.environ.pop("RP_MLP_STREAM")
-    # and as the library chooses by itself: bf16 streamed; f32 callers streamed too, layer 1 as f16 two-way splits of inputs and weights
-    # (kMlpF16x2: within 1e-5 of the f32 matrix instructions -- the distance two f32 summation orders have -- and not their bits), batch-invariant
-    # and bit-reproducible like the other forms; a row with a feature beyond the f16 range comes from the f32 matrix instructions
-    split = ctx.mlp_forward(x, model)
+    # and as the library chooses by itself: bf16 streamed; f32 callers (RP_MLP_F32) streamed too, layer 1 from exact three-part bf16 splits
+    # of inputs and weights (kMlpBf16x3) -- `got` above is that form already; RP_MLP_F32_FAST = f16 two-way splits (kMlpF16x2: within 1e-5 of
+    # the f32 matrix instructions and not their bits), batch-invariant and bit-reproducible like the other forms; a row with a feature beyond
+    # the f16 range comes from the f32 matrix instructions there
+    assert ctx.mlp_forward(x, model).tobytes() == got.tobytes()
+    assert "bf16x3" in ctx.last_mlp_kernel()
+    split = ctx.mlp_forward(x, model, precision="f32_fast")
+    assert "f16x2" in ctx.last_mlp_kernel()
     assert np.allclose(split, ref, rtol=1e-5, atol=1e-5)
-    os.environ["RP_MLP_STREAM"] = "0"
-    exact = ctx.mlp_forward(x, model)
-    os.environ.pop("RP_MLP_STREAM")
+    exact = ctx.mlp_forward(x, model, precision="f32_strict")
+    assert "f32 matrix instructions" in ctx.last_mlp_kernel()
     assert np.allclose(split, exact, rtol=1e-5, atol=1e-5), np.abs(split - exact).max()
-    # (and against the streaming kernel on the f32 matrix instructions: both differences are the order in which the matrix instructions
-    # add up their products -- 32 per instruction here, 4 there -- 5e-6 on logits of order 1, not the 2^-22 of the split)
+    assert np.allclose(got, exact, rtol=1e-5, atol=1e-5), np.abs(got - exact).max()
     assert np.allclose(split, got, rtol=1e-5, atol=1e-5), np.abs(split - got).max()
-    if B > 200:
-        assert split.tobytes() != exact.tobytes() and split.tobytes() != got.tobytes()   # the split form really ran
-    assert ctx.mlp_forward(x, model).tobytes() == split.tobytes()
+    if B > 200:   # three arithmetics, three sets of bits
+        assert split.tobytes() != exact.tobytes() and split.tobytes() != got.tobytes() and got.tobytes() != exact.tobytes()
+    assert ctx.mlp_forward(x, model, precision="f32_fast").tobytes() == split.tobytes()
     if B > 2:
-        assert ctx.mlp_forward(x[1:], model).tobytes() == split[1:].tobytes()
-        # a feature beyond the f16 range: its row is computed again by the f32 matrix instructions (round 4; it used to be NaN)
+        assert ctx.mlp_forward(x[1:], model, precision="f32_fast").tobytes() == split[1:].tobytes()
+        # a feature beyond the f16 range: the two-part form has its row computed again by the f32 matrix instructions (round 4; it used to be
+        # NaN); the three-part form has the f32 exponent range and needs no second pass
         xb = x.copy()
         xb[1, 7] = 7.0e4
-        big = ctx.mlp_forward(xb, model)
+        big = ctx.mlp_forward(xb, model, precision="f32_fast")
         strict = ctx.mlp_forward(xb, model, precision="f32_strict")
         assert big[1].tobytes() == strict[1].tobytes() and np.isfinite(big).all()
         assert np.delete(big, 1, axis=0).tobytes() == np.delete(split, 1, axis=0).tobytes()
+        big3 = ctx.mlp_forward(xb, model)
+        assert np.isfinite(big3).all() and np.allclose(big3[1], strict[1], rtol=2e-5, atol=2e-5 * 7.0e4)
+        assert np.delete(big3, 1, axis=0).tobytes() == np.delete(got, 1, axis=0).tobytes()
     assert ctx.mlp_forward(x, model, precision="bf16").tobytes() == got16.tobytes()
 
 

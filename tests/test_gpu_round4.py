@@ -287,7 +287,8 @@ def _registers_only():
 
 @pytest.mark.parametrize("K,T,L,band", [(5, 8, 100, 5), (5, 4, 100, 5), (5, 6, 60, 3), (5, 7, 37, 4)])
 @pytest.mark.parametrize("score_ref", [0.22, 0.15, 0.1, 0.05])
-def test_matrix_core_shapes_at_low_score_ref(ra, ctx, K, T, L, band, score_ref):
+@pytest.mark.parametrize("arith", ["f32_matrix", "fast_split"])
+def test_matrix_core_shapes_at_low_score_ref(ra, ctx, K, T, L, band, score_ref, arith):
     """DetectorConfig.score_ref (config.rs:172-209) scales the exponent of the score: the relative error of a score is
     (1 - score) x d(cost / (m + n)) / score_ref, so a kernel whose cost error is fine at the default 0.22 can miss the 1e-5 gate at
     0.05.  The matrix-core shapes (f16-split cosine products) against the oracle at the CONTRACT's tolerance, not the sweeps' 1e-3:
@@ -296,7 +297,8 @@ def test_matrix_core_shapes_at_low_score_ref(ra, ctx, K, T, L, band, score_ref):
     templates = orc.synth_templates(SEED + 7 * L + T, T, L, K)
     mf = _streams(S, n_win + L - 1, K, first=1000 + 50 * T)
     tm = ra.Templates(ctx, templates)
-    scores, _, agg = ctx.dtw_scores(mf, tm, score_ref=score_ref, band_size=band)
+    with ctx.arithmetic(arith):
+        scores, _, agg = ctx.dtw_scores(mf, tm, score_ref=score_ref, band_size=band)
     worst = 0.0
     for s in range(S):
         ref_s, ref_a = orc.score_stream(mf[s], templates, band=band, score_ref=score_ref)
@@ -304,27 +306,36 @@ def test_matrix_core_shapes_at_low_score_ref(ra, ctx, K, T, L, band, score_ref):
     assert worst <= 1e-5, worst
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref, band_size=band)
-    matrix = (T >= 5 and band <= 5) or (T >= 3 and band == 5)
+    # (the four-slot shape for chunks of 3..4 templates exists in the two-part f16 arithmetic only)
+    matrix = (T >= 5 and band <= 5) or (T >= 3 and band == 5 and arith == "fast_split")
     assert np.array_equal(scores, reg) == (not matrix), "the matrix-core kernel serves these shapes down to score_ref 0.05"
     assert rel_err(scores, reg) <= 4e-6 * 0.22 / score_ref
 
 
 def test_below_the_score_ref_floor_the_register_kernels_score(ra, ctx):
-    """kDtwMfmaMinScoreRef = 0.05 (rp_kernels.h): below it dtw_mfma_supported refuses and the f32 register kernels serve the same
-    chunks -- the same bits as with RP_DTW_MFMA=0 -- and stay within the gate down to where f32 itself can (0.03 here)."""
+    """RP_ARITH_FAST_SPLIT, kDtwMfmaMinScoreRef = 0.05 (rp_kernels.h): below it dtw_mfma_supported refuses the two-part form and the f32
+    register kernels serve the same chunks -- the same bits as RP_ARITH_STRICT_F32 -- and stay within the gate down to where f32 itself can
+    (0.03 here).  The default three-part form has f32-grade products and no floor: it serves the chunks at 0.03 too, within the gate."""
     K, T, L = 5, 8, 100
     templates = orc.synth_templates(SEED + 1234, T, L, K)
     mf = _streams(16, 150 + L - 1, K, first=4000)
     tm = ra.Templates(ctx, templates)
     for score_ref in (0.049, 0.03):
-        scores, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref)
+        with ctx.arithmetic("fast_split"):
+            scores, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref)
+        ctx.dtw_kernels()
+        with ctx.arithmetic("f32_matrix"):
+            three, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref)
+        assert "dtw_mfma_kernel" in ctx.dtw_kernels() and ctx.last_dtw_products == ["bf16x3"]
         with _registers_only():
             reg, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref)
-        assert np.array_equal(scores, reg)
+        assert np.array_equal(scores, reg) and not np.array_equal(three, reg)
         for s in range(16):
             ref_s, _ = orc.score_stream(mf[s], templates, score_ref=score_ref)
             assert rel_err(scores[s], ref_s) <= 1e-5
-    at_floor, _, _ = ctx.dtw_scores(mf, tm, score_ref=0.05)
+            assert rel_err(three[s], ref_s) <= 1e-5
+    with ctx.arithmetic("fast_split"):
+        at_floor, _, _ = ctx.dtw_scores(mf, tm, score_ref=0.05)
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm, score_ref=0.05)
     assert not np.array_equal(at_floor, reg)
@@ -332,23 +343,25 @@ def test_below_the_score_ref_floor_the_register_kernels_score(ra, ctx):
 
 # ------------------------------------------------------------------------------------------------ wakeword-model forward
 @pytest.mark.parametrize("dims", [(3120, 32, 16, 2), (1040, 13, 2), (3120, 80, 40, 3), (64, 13, 2)])
-def test_model_forward_is_finite_for_every_finite_input(ra, ctx, dims):
-    """candle's f32 Linear (wakeword_nn.rs:101-106) has the f32 range; the default f32 path multiplies f16 splits.  Rows with a
-    feature beyond the f16 range (65 504 .. 1e30), NaN-free: logits equal to the oracle's at f32 distance, the other rows keep
-    the split form's bits, and the result does not depend on which rows of the batch are out of range."""
+@pytest.mark.parametrize("prec", ["f32", "f32_fast"])
+def test_model_forward_is_finite_for_every_finite_input(ra, ctx, dims, prec):
+    """candle's f32 Linear (wakeword_nn.rs:101-106) has the f32 range.  RP_MLP_F32 multiplies three-part bf16 splits (the f32 exponent range:
+    nothing special happens); RP_MLP_F32_FAST multiplies two-part f16 splits: rows with a feature beyond the f16 range (65 504 .. 1e30) are
+    computed again by the f32 matrix instructions.  Either way NaN-free: logits equal to the oracle's at f32 distance, the other rows keep
+    their bits, and the result does not depend on which rows of the batch are out of range."""
     rng = np.random.default_rng(sum(dims))
     ws = [(rng.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
     bs = [rng.standard_normal(dims[i + 1]).astype(np.float32) * 0.1 for i in range(len(dims) - 1)]
     model = ra.Model(ctx, ws, bs)
     for B in (3, 130, 1031):
         x = rng.standard_normal((B, dims[0])).astype(np.float32)
-        plain = ctx.mlp_forward(x, model)
+        plain = ctx.mlp_forward(x, model, precision=prec)
         xb = x.copy()
         big_rows = sorted(set(int(r) for r in rng.integers(0, B, size=max(1, B // 9))))
         for j, r in enumerate(big_rows):
             mag = (65505.0, 7.0e4, 1e9, 1e20, 1e30, 3e38 / dims[0])[j % 6]
             xb[r, rng.integers(0, dims[0], size=1 + j % 3)] = np.float32(mag) * (1 if j % 2 else -1)
-        got = ctx.mlp_forward(xb, model)
+        got = ctx.mlp_forward(xb, model, precision=prec)
         ref = orc.mlp_forward(xb, ws, bs)
         assert np.isfinite(ref).all() and np.isfinite(got).all()
         # (two f32 summation orders differ relative to the terms they add, which grow with the largest feature of the row)
@@ -358,20 +371,26 @@ def test_model_forward_is_finite_for_every_finite_input(ra, ctx, dims):
         assert np.all(np.abs(strict.astype(np.float64) - ref) <= tol)
         keep = np.setdiff1d(np.arange(B), big_rows)
         assert got[keep].tobytes() == plain[keep].tobytes()
-        assert got[big_rows].tobytes() == strict[big_rows].tobytes()          # the f32 matrix instructions computed them
-        assert ctx.mlp_forward(xb, model).tobytes() == got.tobytes()          # the list is empty again after every call
-        assert ctx.mlp_forward(x, model).tobytes() == plain.tobytes()
+        if prec == "f32_fast":
+            assert got[big_rows].tobytes() == strict[big_rows].tobytes()      # the f32 matrix instructions computed them
+        assert ctx.mlp_forward(xb, model, precision=prec).tobytes() == got.tobytes()          # the list is empty again after every call
+        assert ctx.mlp_forward(x, model, precision=prec).tobytes() == plain.tobytes()
     # every row out of range, and inf / NaN features behave like the reference's arithmetic (propagate)
     x = (rng.standard_normal((70, dims[0])) * 1e6).astype(np.float32)
-    got, ref = ctx.mlp_forward(x, model), orc.mlp_forward(x, ws, bs)
+    got, ref = ctx.mlp_forward(x, model, precision=prec), orc.mlp_forward(x, ws, bs)
     assert np.allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
     x = rng.standard_normal((40, dims[0])).astype(np.float32)
     x[3, 5] = np.inf
     x[9, 11] = np.nan
-    got, ref = ctx.mlp_forward(x, model), orc.mlp_forward(x, ws, bs)
+    got, ref = ctx.mlp_forward(x, model, precision=prec), orc.mlp_forward(x, ws, bs)
     ok = np.isfinite(ref)
-    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.allclose(got[ok], ref[ok], rtol=2e-5, atol=2e-5)
-    assert "f32" in ctx.last_mlp_kernel()
+    ok[3] = False
+    if prec == "f32_fast":   # the f32 matrix instructions take the rows with non-finite features: inf and NaN propagate like the reference's f32
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+    else:                    # the three-part split of +-inf is inf + NaN: such a row's logits are NaN (documented, include/rustpotter_hip.h); NaN propagates as NaN
+        assert np.isnan(got[3]).all() and np.isnan(got[9]).all() and np.array_equal(np.isnan(np.delete(got, 3, axis=0)), np.isnan(np.delete(ref, 3, axis=0)))
+    assert np.allclose(got[ok], ref[ok], rtol=2e-5, atol=2e-5)
+    assert ("bf16x3" if prec == "f32" else "f32") in ctx.last_mlp_kernel()
 
 
 def test_model_detector_with_out_of_range_features(ra, ctx):

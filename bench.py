@@ -108,10 +108,11 @@ def n_simds(torch, dev):
     return 4 * torch.cuda.get_device_properties(dev).multi_processor_count
 
 
-ROOFLINE_FIRST = ("bound", "kernel", "frac", "frac_at_architectural_rates", "valu_plus_matrix_issue_frac", "achieved", "peak", "unit", "avg_launch_ms", "traffic", "traffic_over_algorithmic",
-                  "effective_clock_ghz", "valu_issue_frac_at_effective_clock", "strict_f32_value", "strict_f32_ms_per_step", "strict_f32_steps",
-                  "strict_f32_mfcc_ms", "strict_f32_dtw_ms", "strict_f32_aggregate_ms", "path_hbm_frac", "path_ref_flop_rate_vs_vector_peak",
-                  "mfcc_ms", "dtw_ms", "aggregate_ms", "scan_ms", "algorithmic_bytes_per_launch", "ref_flop_rate_vs_vector_peak")
+ROOFLINE_FIRST = ("bound", "kernel", "products", "arithmetic", "frac", "frac_at_architectural_rates", "valu_plus_matrix_issue_frac", "achieved", "peak", "unit",
+                  "avg_launch_ms", "traffic", "traffic_over_algorithmic", "strict_f32_value", "strict_f32_ms_per_step", "strict_f32_steps", "strict_f32_dtw_ms",
+                  "fast_split_value", "fast_split_ms_per_step", "path_hbm_frac", "path_ref_flop_rate_vs_vector_peak", "mfcc_ms", "dtw_ms", "i16_pcm_value",
+                  "i16_pcm_mfcc_ms", "effective_clock_ghz", "valu_issue_frac_at_effective_clock", "strict_f32_mfcc_ms", "strict_f32_aggregate_ms", "fast_split_dtw_ms",
+                  "aggregate_ms", "scan_ms", "algorithmic_bytes_per_launch", "ref_flop_rate_vs_vector_peak")
 
 
 def order_for_the_record(res):
@@ -289,17 +290,13 @@ class Env:
 
 
 def make_templates(ra, ctx, torch, dev, lens, K):
-    """Template t = MFCC (HIP path) of a synthetic utterance seeded SEED+1+t, whole-matrix mean normalisation, cut to lens[t]."""
+    """Template t = the CPU oracle's MFCC of a synthetic utterance seeded SEED+1+t (stream 0), whole-matrix mean normalisation, cut to
+    lens[t] -- SURVEY 8d's recipe, exactly how wav_file_extractor.rs:59-67 makes a reference's templates.  The oracle only prepares this
+    INPUT (like the synthetic PCM); nothing of the measured path runs through it, and the same arrays go to the cpu_baseline leg."""
     import numpy as np
-    T, L = len(lens), max(lens)
-    n_t = 480 * -(-(L + 3) // 3)
-    tp = torch.empty((T, n_t), dtype=torch.float32, device=dev)
-    for t in range(T):
-        ctx.synth_dev(SEED + 1 + t, 0, 1, n_t, n_t, tp[t].data_ptr())
-    tmf = torch.empty((T, ra.mfcc_num_frames(n_t), K), dtype=torch.float32, device=dev)
-    ctx.mfcc_dev(tp.data_ptr(), T, n_t, n_t, K, tmf.data_ptr())
-    torch.cuda.synchronize()
-    return [np.ascontiguousarray((m - m.mean(axis=0, dtype=np.float32))[:lens[t]], dtype=np.float32) for t, m in enumerate(tmf.cpu().numpy())]
+    from oracle import rp_oracle as orc
+    tt = orc.synth_templates(SEED, len(lens), max(lens), K)
+    return [np.ascontiguousarray(t[:n], dtype=np.float32) for t, n in zip(tt, lens)]
 
 
 # ------------------------------------------------------------------------------------------------ kernel models
@@ -507,7 +504,7 @@ class DtwCase:
         self.ctx = ctx or ra.BatchContext(device=env.local_rank, host_pointers=False, full_scores=full_scores, arithmetic=getattr(env.args, "arith", "f32_matrix"),
                                           ragged_matrix=getattr(env.args, "ragged_matrix", False))
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        # templates: T synthetic utterances, MFCC by the HIP path, whole-matrix mean normalisation, cut to their
+        # templates: T synthetic utterances, MFCC by the CPU oracle, whole-matrix mean normalisation, cut to their
         # length.  Identical arrays are handed to the CPU baseline.
         self.templates = templates or make_templates(ra, self.ctx, torch, dev, lens, K)
         avg_t = None
@@ -722,6 +719,37 @@ def bench_dtw(env):
                 kf = case.kernel_times(3)
             roofline.update({"fast_split_value": S * n_win * steps_v / dtf, "fast_split_ms_per_step": dtf / steps_v * 1e3, "fast_split_dtw_ms": kf["dtw"][0],
                              "fast_split_note": "RP_ARITH_FAST_SPLIT (two f16 parts per operand, 22-bit products): opt-in, narrower than the reference's f32"})
+    # ---- the same step fed i16 PCM (the sample format of every recording the reference's tests hold, tests/detector.rs:361-368): mfcc_kernel
+    # decodes in registers, the stage reads half the bytes
+    if world == 1 and plain:
+        try:
+            pcm16 = torch.empty((S, N), dtype=torch.int16, device=dev)
+            for s0 in range(0, S, 8192):   # in slices: the f32 -> i16 temporaries of the whole array would not fit beside it
+                pcm16[s0:s0 + 8192] = torch.round(case.pcm[s0:s0 + 8192] * 32767.0).to(torch.int16)
+
+            def call16():
+                case.ctx.batch_detect_fmt_dev(pcm16.data_ptr(), 1, S, N, N, case.tmpl, case.cfg, case.det.data_ptr(), case.n_det.data_ptr(), case.max_det,
+                                              case.scores.data_ptr(), case.agg.data_ptr())
+            for _ in range(2):
+                call16()
+            env.fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                call16()
+            env.fence()
+            dt16 = time.perf_counter() - t0
+            case.ctx.timing_enable(True)
+            case.ctx.timing_reset()
+            for _ in range(3):
+                call16()
+            torch.cuda.synchronize()
+            k16 = {name: case.ctx.timing_read(i) for i, name in enumerate(["mfcc", "dtw", "aggregate", "scan"])}
+            case.ctx.timing_enable(False)
+            roofline.update({"i16_pcm_value": S * n_win * args.steps / dt16, "i16_pcm_ms_per_step": dt16 / args.steps * 1e3, "i16_pcm_mfcc_ms": k16["mfcc"][0],
+                             "i16_pcm_mfcc_hbm_frac": S * nf * (320 + 4 * K) / (k16["mfcc"][0] * 1e-3) / HBM_PEAK})
+            del pcm16
+        except Exception as e:   # an extra must never take the headline line with it
+            roofline["i16_pcm_error"] = repr(e)
     roofline["path"] = {"hbm_frac": roofline["path_hbm_frac"], "ref_flop_rate_vs_vector_peak": roofline["path_ref_flop_rate_vs_vector_peak"],
                         "bytes_per_scoring": 640 + 4 * (T + 2), "ref_flops_per_scoring": 13.2e3 * nf / n_win + f_dtw_ref}
 

@@ -335,10 +335,11 @@ static void bf16_split3(float a, uint16_t p[3]) {
 // dtw_mfma_kernel's A operand of one chunk in the f32-grade form (kArithF32Matrix; rp_dtw_mfma.hip, P3): per template row r
 // [k-step 2][k half 2][template slot 8] x 8 bf16.  a = -(unit row) = a0 + a1 + a2 exactly; the window side splits its unit frame the same way,
 // x = x0 + x1 + x2, and the two k-steps accumulate the six partial products x_i a_j with i + j <= 2 of every component, and 1.0 x 1.0:
-//   k-step 0, half kh (components (ca, cb) = (0, 1) / (3, 4)):  [ca.0 cb.0 | ca.0 cb.0 | ca.0 cb.0 | half 0: c2.0 c2.0 / half 1: c2.0 c2.2]
-//     against the window's                                     [xa0 xb0  | xa1 xb1  | xa2 xb2  | half 0: x2_0 x2_1 / half 1: x2_2 x2_0]
+//   k-step 0, half kh (components (ca, cb) = (0, 1) / (3, 4)):  [ca.0 cb.0 | half 0: c2.0 c2.0 / half 1: c2.0 c2.2 | ca.0 cb.0 | ca.0 cb.0]
+//     against the window's registers 0..3                        [xa2 xb2  | half 0: x2_0 x2_1 / half 1: x2_2 x2_0 | xa0 xb0  | xa1 xb1 ]
 //   k-step 1:                                                   [ca.1 cb.1 | ca.1 cb.1 | ca.2 cb.2 | half 0: c2.1 c2.1 / half 1: 1.0  0  ]
-//     against                                                   [xa0 xb0  | xa1 xb1  | xa0 xb0  | half 0: x2_0 x2_1 / half 1: 1.0  0  ]
+//     against the window's registers 2..5                        [xa0 xb0  | xa1 xb1  | xa0 xb0  | half 0: x2_0 x2_1 / half 1: 1.0  0  ]
+// (x2_i: part i of component 2, which both lane halves split.)
 // Slots past the chunk's count and the 16 rows after the last one are zero.
 static void append_mfma_image3(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad) {
     const int K = 5;
@@ -350,8 +351,11 @@ static void append_mfma_image3(std::vector<uint16_t> &img, const DtwChunk &c, co
             for (int k = 0; k < K; ++k) bf16_split3(-unit[((size_t)c.tid[t] * Lpad + r) * K + k], p[k]);
             for (int kh = 0; kh < 2; ++kh) {
                 const int ca = kh ? 3 : 0, cb = ca + 1;
-                uint16_t s0[8] = {p[ca][0], p[cb][0], p[ca][0], p[cb][0], p[ca][0], p[cb][0], p[2][0], kh == 0 ? p[2][0] : p[2][2]};
+                // the kernel keeps the window side's two operands as ONE run of six registers, [x2a x2b | c2' | x0a x0b | x1a x1b | x0a x0b | c2''], the
+                // first k-step reading registers 0..3 and the second 2..5 (the middle two are shared): the slots follow that order
+                uint16_t s0[8] = {p[ca][0], p[cb][0], p[2][0], kh == 0 ? p[2][0] : p[2][2], p[ca][0], p[cb][0], p[ca][0], p[cb][0]};
                 uint16_t s1[8] = {p[ca][1], p[cb][1], p[ca][1], p[cb][1], p[ca][2], p[cb][2], kh == 0 ? p[2][1] : (uint16_t)0x3f80, kh == 0 ? p[2][1] : (uint16_t)0};
+
                 std::memcpy(&img[base + ((size_t)r * kDtwMfma3RowBytes + kh * 128 + t * 16) / 2], s0, 16);
                 std::memcpy(&img[base + ((size_t)r * kDtwMfma3RowBytes + 256 + kh * 128 + t * 16) / 2], s1, 16);
             }

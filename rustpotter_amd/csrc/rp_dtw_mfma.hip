@@ -41,6 +41,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMK = 5;         // MFCC coefficients per frame
 constexpr int kMWin = 32;      // windows per wave
@@ -286,7 +287,11 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         }
         v16f acc[NTILE];   // costs of the current column; a tile is refilled for the next column as soon as its last cell is done
         u32x4 bop[2];  // B operand of column cc in bop[cc & 1]: built two columns ahead, in pieces between the cells
-        u32x4 bop2[P3 ? 2 : 1];  // P3: the second k-step's
+        // P3: the two k-steps' B operands as ONE run of six registers per column, [0..3] the first k-step's and [2..5] the second's: the
+        // registers both need -- (x0a, x0b) and (x1a, x1b) -- sit in the middle and are written once (slot order: append_mfma_image3,
+        // rp_ctx.cpp).  Measured neutral against two separate operands with three copies per column (15.0 ms either way), ten registers fewer.
+        u32x8 bv[P3 ? 2 : 1];
+        (void)bv;
 
 // The frame work of column cc, cut into ten pieces P0..P9 that are placed between the cells of the recurrence.
 // P0 requests the frame of column cc into ring slot rs, P1 takes it out PD columns later (rs = cc mod PD, spelled out by the caller:
@@ -304,7 +309,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 // x2 = r1 - x1 (exact, at most 8 significant bits: a bf16 too).  A register of the B operand is the upper halves of two f32 values: one v_perm.
 #define RP_HI2(hi, lo) __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u)
 #define RP_AND(x, m) __uint_as_float(__float_as_uint(x) & (m))
-#define RP_P6(cc, par) if (P3) { x0a_ = RP_AND(ua_, 0xffff0000u); x0b_ = RP_AND(ub_, 0xffff0000u); x0c_ = RP_AND(u2_, 0xffff0000u); bop[par].x = RP_HI2(ub_, ua_); } \
+#define RP_BSET(par, i, v) bv[par][i] = (v)
+#define RP_P6(cc, par) if (P3) { x0a_ = RP_AND(ua_, 0xffff0000u); x0b_ = RP_AND(ub_, 0xffff0000u); x0c_ = RP_AND(u2_, 0xffff0000u); RP_BSET(par, 2, RP_HI2(ub_, ua_)); } \
                        else { bop[par].x = pkrtz(ua_, ub_); bop[par].z = bop[par].x; }
 // x1 = rtz_f16(x - x0): x0 as f32 is x with the low 13 mantissa bits cleared (one full-rate v_and instead of a half-rate v_cvt_f32_f16;
 // below the f16 normal range, |x| < 6.1e-5, the two differ by less than the f16 subnormal spacing 6e-8 -- far below the kernel's error)
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #else
 #define RP_X0F(x, packed, hi) ((hi) ? hi_f32(packed) : lo_f32(packed))
 #endif
-#define RP_P7(cc, par) if (P3) { r1a_ = ua_ - x0a_; r1b_ = ub_ - x0b_; r1c_ = u2_ - x0c_; bop[par].y = RP_HI2(r1b_, r1a_); } \
+#define RP_P7(cc, par) if (P3) { r1a_ = ua_ - x0a_; r1b_ = ub_ - x0b_; r1c_ = u2_ - x0c_; RP_BSET(par, 3, RP_HI2(r1b_, r1a_)); } \
                        else { bop[par].y = pk_f16_second(ua_ - RP_X0F(ua_, bop[par].x, 0), ub_ - RP_X0F(ub_, bop[par].x, 1)); }
 #ifndef RP_AB_NO_RANGE_TEST   /* A/B builds only (results wrong for out-of-range frames): what the test costs */
 #define RP_P8(cc) chk_ = fmaxf(fmaxf(chk_, inv_), bb_);  /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */ \
@@ -321,12 +327,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #else
 #define RP_P8(cc) if (P3) { x1a_ = RP_AND(r1a_, 0xffff0000u); x1b_ = RP_AND(r1b_, 0xffff0000u); tc_ = RP_AND(r1c_, mask_c2); }
 #endif
-#define RP_P9(cc, par) if (P3) { bop[par].z = RP_HI2(r1b_ - x1b_, r1a_ - x1a_); bop[par].w = __builtin_amdgcn_perm(__float_as_uint(r1c_ - tc_), __float_as_uint(u2_), sel_c2); } \
+#define RP_P9(cc, par) if (P3) { RP_BSET(par, 0, RP_HI2(r1b_ - x1b_, r1a_ - x1a_)); RP_BSET(par, 1, __builtin_amdgcn_perm(__float_as_uint(r1c_ - tc_), __float_as_uint(u2_), sel_c2)); } \
                        else { const float x0_ = RP_X0F(u2_, pkrtz(u2_, 0.f), 0); /* (x0, x1) of component 2: x0 is already an f16 value, x1 rounds to nearest */ \
                          bop[par].w = __builtin_amdgcn_perm(0x3c000000u, pk_f16_second(x0_, u2_ - x0_), sel_one); }
 // P3: the second k-step's operand: (x0, x0 | x1, x1 | x0, x0) of the half's two components against (a1, a1 | a1, a1 | a2, a2), and register 3 =
 // (x0, x1) of component 2 against (a1, a1) in half 0, the constant (1.0, 0) in half 1
-#define RP_P10(cc, par) if (P3) { bop2[par].x = bop[par].x; bop2[par].y = bop[par].y; bop2[par].z = bop[par].x; bop2[par].w = h ? 0x00003f80u : bop[par].w; }
+#define RP_P10(cc, par) if (P3) { bv[par][4] = bv[par][2]; bv[par][5] = h ? 0x00003f80u : bv[par][1]; }
 #define RP_PREP_ALL(cc, par) RP_P0(cc, (cc) % PD) RP_P1(cc, (cc) % PD) RP_P2(cc) RP_P3(cc) RP_P4(cc) RP_P5(cc) RP_P6(cc, par) RP_P7(cc, par) RP_P8(cc) RP_P9(cc, par) RP_P10(cc, par)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 12)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
@@ -337,16 +343,18 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         Areg[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)off);                                            \
         if (P3) Areg2[g] = *reinterpret_cast<const u32x4 *>(smem + a_lane + 256u + (unsigned)off);                            \
     }
+#define RP_B1(par) __builtin_shufflevector(bv[P3 ? (par) : 0], bv[P3 ? (par) : 0], 0, 1, 2, 3)
+#define RP_B2(par) __builtin_shufflevector(bv[P3 ? (par) : 0], bv[P3 ? (par) : 0], 2, 3, 4, 5)
 #define RP_MFMA(g, par)                                                                                                       \
     do {                                                                                                                      \
         const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                  \
-        if (P3) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g]), __builtin_bit_cast(bf16x8, bop[par]), zero16, 0, 0, 0); \
+        if (P3) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g]), __builtin_bit_cast(bf16x8, RP_B1(par)), zero16, 0, 0, 0); \
         else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, Areg[g]), __builtin_bit_cast(f16x8, bop[par]), zero16, 0, 0, 0); \
     } while (0)
 // P3: the second k-step on the same accumulator, one band cell after the first (its eight passes are over by then)
 #define RP_MFMA2(g, par)                                                                                                      \
     do {                                                                                                                      \
-        if (P3) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg2[g]), __builtin_bit_cast(bf16x8, bop2[par]), acc[g], 0, 0, 0); \
+        if (P3) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg2[g]), __builtin_bit_cast(bf16x8, RP_B2(par)), acc[g], 0, 0, 0); \
     } while (0)
 
 #ifndef RP_P3_GAP   // band cells between a tile's two k-steps (A/B builds)
@@ -456,6 +464,9 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
 #undef RP_P10
 #undef RP_HI2
 #undef RP_AND
+#undef RP_BSET
+#undef RP_B1
+#undef RP_B2
 #undef RP_AREF
 #undef RP_PREP_ALL
 #undef RP_P0

@@ -149,10 +149,15 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
     };
 
     f32x4 acc[NT];
+    f32x4 accb[PREC == kMlpBf16x3 ? NT : 1];   // kMlpBf16x3: a second chain for three of the six products of a k-step (twice as many independent matrix instructions in flight)
     float rng = 0.f;   // kMlpF16x2: largest |feature| this lane has seen in the tile (a row beyond the f16 range is listed in `redo`)
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (PREC == kMlpBf16x3) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) accb[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     };
     // one k-step: A halves a0 (k = 32m + 4lk..) and a1 (k = 32m + 16 + 4lk..) against the lane's weight pieces of that step
     struct WFrag { f32x4 w[WF]; };
@@ -218,19 +223,19 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
             const bf16x8s av0 = __builtin_bit_cast(bf16x8s, (u32x4s){h0[0], h0[1], h0[2], h0[3]});
             const bf16x8s av1 = __builtin_bit_cast(bf16x8s, (u32x4s){h1[0], h1[1], h1[2], h1[3]});
             const bf16x8s av2 = __builtin_bit_cast(bf16x8s, (u32x4s){h2[0], h2[1], h2[2], h2[3]});
-            // smallest terms first, so that they meet before the large ones take the accumulator's low bits
+            // the small partial products (2^-16 and 2^-8 of a product) add up in their own accumulator and meet the large ones once per row tile
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[2 * NT + n]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[2 * NT + n]), accb[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av2, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), accb[n], 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av2, __builtin_bit_cast(bf16x8s, wf.w[n]), accb[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
         } else {                 // pieces: [n], eight bf16 each
             bf16x8s av;
             av[0] = (__bf16)a0.x; av[1] = (__bf16)a0.y; av[2] = (__bf16)a0.z; av[3] = (__bf16)a0.w;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = acc[n][e] + b1s[16 * n + li];
+                float v = (PREC == kMlpBf16x3 ? acc[n][e] + accb[n][e] : acc[n][e]) + b1s[16 * n + li];
                 if (relu1 && v < 0.f) v = 0.f;
                 h1[(4 * lk + e) * H1P + 16 * n + li] = v;
             }
@@ -426,12 +431,10 @@ static hipError_t launch_mlp_stream_pass(hipStream_t st, const MlpDev &m, const 
     if (const char *e = getenv("RP_MLP_STREAM_DEPTH")) if (e[0] == '1') depth = 1;   // benchmarks: the shallower ring
     int waves = 8;
     if (const char *e = getenv("RP_MLP_STREAM_WAVES")) if (e[0] == '4' && 2 * stream_lds_bytes(m.nt, precision, 1, tail_lds, h2p, 4) <= 160 * 1024) { waves = 4; depth = 1; }
-    // the three-part form's weight ring is half again as large: the deep ring (three units of rows in flight per wave) fits with six waves
-    // per workgroup, not with eight
-    if (precision == kMlpBf16x3 && depth == 1 && waves == 8 && stream_lds_bytes(m.nt, precision, 2, tail_lds, h2p, 6) <= 160 * 1024) {
-        const char *e = getenv("RP_MLP_STREAM_WAVES");
-        if (!(e && e[0] == '8')) { waves = 6; depth = 2; }
-    }
+    // (the three-part form's weight ring is half again as large: at models of 32 hidden units the deep ring no longer fits beside eight
+    // waves' row rings.  Measured at BASELINE C5: eight waves with the shallow ring 0.1545 ms, six waves with the deep one 0.208 -- and the
+    // two-part form runs 0.132 ms with either ring: depth is not what the three-part form waits for.  RP_MLP_STREAM_WAVES=6: that A/B)
+    if (const char *e = getenv("RP_MLP_STREAM_WAVES")) if (e[0] == '6' && precision == kMlpBf16x3 && stream_lds_bytes(m.nt, precision, 2, tail_lds, h2p, 6) <= 160 * 1024) { waves = 6; depth = 2; }
 #define RP_STREAM_CASE(NT_, PREC_)                                                                        \
     if (m.nt == NT_ && precision == PREC_) {                                                              \
         if (waves == 6) return launch_stream_t<NT_, PREC_, 2, 6>(st, m, p, x, B, out, tail_lds, h2p, n_cu, redo); \

@@ -302,7 +302,7 @@ def test_cosine_norm_product_semantics_of_the_restatement():
     norms is formed in f32, so the distance is NOT scale invariant once it leaves the normal range: a (window, template) pair scaled by
     s keeps its score down to s ~ 1e-10, drifts where the product is subnormal, and lands on `every cell costs 1` once it underflows:
     cost = m + n - 2 ... normalised 0.5 -> score 1 / (1 + exp((0.5 - ref) / ref)).  The device kernels reproduce exactly this
-    (tests/test_gpu_round4.py); here the oracle itself is pinned to the closed form."""
+    (tests/test_gpu_cosine_range.py); here the oracle itself is pinned to the closed form."""
     K, L = 5, 40
     t = orc.synth_templates(0x5EED000000000001, 1, L, K)[0]
     w = orc.mfcc_stream(orc.synth_pcm(0x5EED000000000001, 3, 480 * 20), K)[:L]

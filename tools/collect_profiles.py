@@ -4,7 +4,7 @@ import csv, glob, json, collections, statistics, shutil, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"   # round tag of the files written
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"   # round tag of the files written
 short = lambda n: n.split("(")[0]
 
 def agg(tag):
@@ -78,7 +78,10 @@ names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk
          "detect_only_ragged5": "bench_%s_detect_only_ragged5" % R, "model_small": "bench_%s_model_detector_small" % R, "model_medium": "bench_%s_model_detector_medium" % R, "model_large": "bench_%s_model_detector_large" % R,
          "ingest_f32": "bench_%s_ingest_f32" % R, "ingest_i16": "bench_%s_ingest_i16" % R,
          "ragged5_matrix": "bench_%s_ragged5_templates_matrix_optin" % R, "ragged3_alexa": "bench_%s_ragged3_alexa_lens" % R,
-         "ragged3_alexa_matrix": "bench_%s_ragged3_alexa_lens_matrix_optin" % R}
+         "ragged3_alexa_matrix": "bench_%s_ragged3_alexa_lens_matrix_optin" % R,
+         "c3_fast_split": "bench_%s_c3_fast_split" % R, "c3_strict_f32": "bench_%s_c3_strict_f32" % R, "c2_fast_split": "bench_%s_c2_fast_split" % R,
+         "c4_fast_split": "bench_%s_c4_per_gpu_fast_split" % R, "k16_fast_split": "bench_%s_k16_8192streams_fast_split" % R,
+         "c5_f32_fast": "bench_%s_c5_f32_fast" % R, "c5_f32_strict": "bench_%s_c5_f32_strict" % R}
 for a, b in names.items():
     src = "gpurun_out/final/%s.json" % a
     if os.path.exists(src) and os.path.getsize(src) > 10:

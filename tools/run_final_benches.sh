@@ -14,13 +14,21 @@ $B --no-cpu-baseline --config C2 --steps 50 2>/dev/null | line > $O/c2.json
 $B --no-cpu-baseline --streams 8192 --templates 64 2>/dev/null | line > $O/c4.json
 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --config C4 2>/dev/null | line > $O/c4_one_gpu.json
 RP_BENCH_OVERSUBSCRIBE=1 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --config C4 --gpus 2 2>/dev/null | line > $O/c4_two_ranks_one_gpu.json
+# the same shapes in the opt-in two-part f16 arithmetic (RP_ARITH_FAST_SPLIT: 22-bit products, narrower than the reference) and in strict f32
+$B --no-cpu-baseline --arith fast_split 2>/dev/null | line > $O/c3_fast_split.json
+$B --no-cpu-baseline --arith strict_f32 2>/dev/null | line > $O/c3_strict_f32.json
+$B --no-cpu-baseline --arith fast_split --config C2 --steps 50 2>/dev/null | line > $O/c2_fast_split.json
+$B --no-cpu-baseline --arith fast_split --streams 8192 --templates 64 2>/dev/null | line > $O/c4_fast_split.json
 $B --no-cpu-baseline --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5.json
-RP_DTW_RAGGED=1 $B --no-cpu-baseline --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5_matrix.json
+$B --no-cpu-baseline --arith fast_split --ragged-matrix --template-lens 108,96,90,93,102 2>/dev/null | line > $O/ragged5_matrix.json
 $B --no-cpu-baseline --template-lens 117,126,99 2>/dev/null | line > $O/ragged3_alexa.json
-RP_DTW_RAGGED=1 $B --no-cpu-baseline --template-lens 117,126,99 2>/dev/null | line > $O/ragged3_alexa_matrix.json
+$B --no-cpu-baseline --arith fast_split --ragged-matrix --template-lens 117,126,99 2>/dev/null | line > $O/ragged3_alexa_matrix.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
+$B --no-cpu-baseline --arith fast_split --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16_fast_split.json
 $B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_bf16.json
 $B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
+$B --no-cpu-baseline --mode mlp --mlp-precision f32_fast 2>/dev/null | line > $O/c5_f32_fast.json
+$B --no-cpu-baseline --mode mlp --mlp-precision f32_strict 2>/dev/null | line > $O/c5_f32_strict.json
 $B --no-cpu-baseline --detect-only --template-lens 108,96,90,93,102 2>/dev/null | line > $O/detect_only_ragged5.json
 if [ "${1:-}" != all ]; then for f in $O/*.json; do echo "$f $(cut -c1-160 $f)"; done; exit 0; fi
 $B --no-cpu-baseline --templates 3 --template-len 126 2>/dev/null | line > $O/t3.json

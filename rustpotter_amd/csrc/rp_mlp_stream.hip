@@ -149,15 +149,10 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
     };
 
     f32x4 acc[NT];
-    f32x4 accb[PREC == kMlpBf16x3 ? NT : 1];   // kMlpBf16x3: a second chain for three of the six products of a k-step (twice as many independent matrix instructions in flight)
     float rng = 0.f;   // kMlpF16x2: largest |feature| this lane has seen in the tile (a row beyond the f16 range is listed in `redo`)
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (PREC == kMlpBf16x3) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) accb[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
     };
     // one k-step: A halves a0 (k = 32m + 4lk..) and a1 (k = 32m + 16 + 4lk..) against the lane's weight pieces of that step
     struct WFrag { f32x4 w[WF]; };
@@ -223,19 +218,20 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
             const bf16x8s av0 = __builtin_bit_cast(bf16x8s, (u32x4s){h0[0], h0[1], h0[2], h0[3]});
             const bf16x8s av1 = __builtin_bit_cast(bf16x8s, (u32x4s){h1[0], h1[1], h1[2], h1[3]});
             const bf16x8s av2 = __builtin_bit_cast(bf16x8s, (u32x4s){h2[0], h2[1], h2[2], h2[3]});
-            // the small partial products (2^-16 and 2^-8 of a product) add up in their own accumulator and meet the large ones once per row tile
+            // smallest terms first, so that they meet before the large ones take the accumulator's low bits (a second accumulator chain for
+            // half of the six measured the same time, 0.154-0.156 ms at C5, and a larger worst-case error against f64: one chain it is)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[2 * NT + n]), accb[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[2 * NT + n]), acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), accb[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av2, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av1, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) accb[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av2, __builtin_bit_cast(bf16x8s, wf.w[n]), accb[n], 0, 0, 0);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[NT + n]), acc[n], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av0, __builtin_bit_cast(bf16x8s, wf.w[n]), acc[n], 0, 0, 0);
         } else {                 // pieces: [n], eight bf16 each
             bf16x8s av;
             av[0] = (__bf16)a0.x; av[1] = (__bf16)a0.y; av[2] = (__bf16)a0.z; av[3] = (__bf16)a0.w;
@@ -255,7 +251,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void mlp_strea
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = (PREC == kMlpBf16x3 ? acc[n][e] + accb[n][e] : acc[n][e]) + b1s[16 * n + li];
+                float v = acc[n][e] + b1s[16 * n + li];
                 if (relu1 && v < 0.f) v = 0.f;
                 h1[(4 * lk + e) * H1P + 16 * n + li] = v;
             }

@@ -373,7 +373,8 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None, products=
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
                                                                                                          mix["valu_issue_cycles_per_trip"])})
         # a matrix instruction takes ~19 issue cycles from the vector work beside it at three waves per SIMD (tools/scratch/mfma_valu_overlap_probe.hip:
-        # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions)
+        # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions); the three-part form runs two waves per SIMD
+        # with six matrix instructions per column -- the same price is used (measured there: 17 from the kernel's own time, 25 in the probe)
         extra["valu_plus_matrix_issue_frac"] = (cyc + 19.0 * trips * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         if grouped:
             extra["isa_mix"] = ("profiles/dtw_mfma_group_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA instructions, %.0f SIMD issue cycles per "

@@ -997,6 +997,7 @@ def model_detector_measure(env, S, m_type, warmup, steps):
     import ctypes as C
     import numpy as np
     ra, torch, dev = env.ra, env.torch, env.dev
+    prec_code = 3 if getattr(env.args, "mlp_precision", "bf16") == "f32_fast" else 0   # RP_MLP_F32_FAST / RP_MLP_F32 (the model detector's input is MFCC: no bf16-input form)
     N, F, K = 64000, 195, 16
     dims = {"tiny": [F * K, F // 15, 2], "small": [F * K, F // 6, F // 12, 2], "medium": [F * K, F // 3, F // 6, 2],
             "large": [F * K, F // 3 * 2, F // 6, 2]}[m_type]
@@ -1017,7 +1018,7 @@ def model_detector_measure(env, S, m_type, warmup, steps):
     L = ra.load_library()
 
     def call():
-        if L.rp_batch_detect_model(ctx._h, pcm.data_ptr(), 3, S, N, N, model._h, K, 0, C.byref(c), 0, det.data_ptr(), lab.data_ptr(), n_det.data_ptr(), 4) != 0:
+        if L.rp_batch_detect_model(ctx._h, pcm.data_ptr(), 3, S, N, N, model._h, K, 0, C.byref(c), prec_code, det.data_ptr(), lab.data_ptr(), n_det.data_ptr(), 4) != 0:
             raise RuntimeError("rp_batch_detect_model failed")
     for _ in range(warmup):
         call()
@@ -1036,12 +1037,14 @@ def model_detector_measure(env, S, m_type, warmup, steps):
     ctx.timing_enable(False)
     n_win = ra.mfcc_num_frames(N) - F + 1
     d1p = -(-dims[1] // 32) * 32
-    # executed matrix work of layer 1: three f16 products per feature and output (x0 w0 + x1 w0 + x0 w1), outputs padded to tiles of 32,
-    # windows to tiles of 32 rows
+    # executed matrix work of layer 1: six bf16 products per feature and output in the default precision (three parts per operand, i + j <= 2),
+    # three f16 ones under RP_MLP_F32_FAST (x0 w0 + x1 w0 + x0 w1); outputs padded to tiles of 32, windows to tiles of 32 rows
     rows_exec = S * (-(-n_win // 32) * 32)
+    nprod = 3 if prec_code == 3 else 6
     return {"dims": dims, "n_win": n_win, "dt": dt, "kernels_ms": {k: round(v, 4) for k, v in k_ms.items()}, "kernel": ctx.last_mlp_kernel(),
             "algorithmic_flops": S * n_win * 2.0 * sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)),
-            "executed_matrix_flops": rows_exec * 2.0 * 3 * dims[0] * d1p}
+            "executed_matrix_flops": rows_exec * 2.0 * nprod * dims[0] * d1p, "products_per_product": nprod,
+            "dtype": MLP_DTYPE["f32_fast" if prec_code == 3 else "f32"]}
 
 
 def extra_model_detector(env, S=8192):
@@ -1049,10 +1052,10 @@ def extra_model_detector(env, S=8192):
     return {"workload": "%d synthetic 4 s streams, Small model %s on every window of 195 frames x 16 coefficients (%d windows per stream), f32 callers"
                         % (S, "->".join(map(str, m["dims"])), m["n_win"]),
             "value": S * m["n_win"] / m["dt"], "unit": "window scorings/s", "steps": 10, "warmup": 2, "ms_per_step": m["dt"] * 1e3,
-            "dtype": "f32 (layer-1 products: f16x2-split MFMA, 22-bit)", "kernel": m["kernel"], "kernels_ms": m["kernels_ms"],
+            "dtype": m["dtype"], "kernel": m["kernel"], "kernels_ms": m["kernels_ms"],
             "roofline": {"bound": "mfma", "kernel": "the forward (mlp_windows_kernel)", "achieved": m["executed_matrix_flops"] / (m["kernels_ms"]["forward"] * 1e-3) / 1e12,
                          "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": m["executed_matrix_flops"] / (m["kernels_ms"]["forward"] * 1e-3) / MFMA_F16_PEAK,
-                         "note": "executed f16 matrix flops (three split products, padded tiles) over the forward's launch time; PMC and the clock under this load: profiles/r04_model_detect.txt"}}
+                         "note": "executed 16-bit matrix flops (%d partial products per layer-1 product, padded tiles) over the forward's launch time; PMC and the clock under the two-part form: profiles/r04_model_detect.txt" % m["products_per_product"]}}
 
 
 def bench_model(env):
@@ -1065,12 +1068,12 @@ def bench_model(env):
     fwd_s = m["kernels_ms"]["forward"] * 1e-3
     return {"metric": "wakeword-model window scorings/sec (rp_batch_detect_model)", "value": S * world * m["n_win"] / m["dt"], "unit": "window scorings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["dt"] * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (layer-1 products: f16x2-split MFMA, 22-bit)", "data": "synthetic", "config": config,
+            "vs_baseline": None, "dtype": m["dtype"], "data": "synthetic", "config": config,
             "kernels_ms": m["kernels_ms"], "kernel": m["kernel"],
             "roofline": {"bound": "mfma", "kernel": "the forward (%s)" % m["kernel"].split("<")[0], "achieved": m["executed_matrix_flops"] / fwd_s / 1e12,
                          "peak": MFMA_F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": m["executed_matrix_flops"] / fwd_s / MFMA_F16_PEAK, "traffic": None,
                          "algorithmic_flop_rate_tflops": m["algorithmic_flops"] / m["dt"] / 1e12,
-                         "note": "executed f16 matrix flops (three split products per layer-1 product, outputs and windows padded to tiles of 32) over the forward's "
+                         "note": "executed 16-bit matrix flops (six bf16 partial products per layer-1 product in the default precision, three f16 ones with --mlp-precision f32_fast; outputs and windows padded to tiles of 32) over the forward's "
                                  "launch time (HIP events on the launch stream); the clock holds ~1.8 GHz under this kernel: profiles/r04_model_detect.txt"}}
 
 

@@ -1436,6 +1436,8 @@ static bool window_logits(Ctx *c, const Model &m, const float *dm, size_t S, siz
             c->time_end();
             if (!ok) return false;
             c->last_mlp_kernel = precision == RP_MLP_F32_STRICT ? "mlp_mfma_kernel<f32 matrix instructions>, windows read in place"
+                                 : (precision != RP_MLP_F32_FAST && mlp_windows_supported(m.dev, n_win, K, true) == 1) ? "mlp_windows_kernel<bf16x3 splits>"
+                                 : (precision != RP_MLP_F32_FAST && mlp_windows_supported(m.dev, n_win, K, true) == 2) ? "mlp_windows_wide_kernel<bf16x3 splits>"
                                  : precision != RP_MLP_F32_FAST ? "mlp_mfma_kernel<bf16x3 splits>, windows read in place"
                                  : mlp_windows_supported(m.dev, n_win, K) == 1 ? "mlp_windows_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"
                                  : mlp_windows_supported(m.dev, n_win, K) == 2 ? "mlp_windows_wide_kernel<f16x2 splits> + mlp_mfma_kernel<f32> on listed rows"

@@ -747,6 +747,15 @@ Model *Model::create(Ctx *ctx, int n_layers, const int *dims, const float *const
                                 img[((((((size_t)f * NQ + o / 32) * 2 + part) * 2 + h) * 32) + o % 32) * 8 + e] =
                                     wsp[(size_t)part * rows * d.kpad + (size_t)o * d.kpad + 16 * f + 8 * h + e];
             if (!up(img.data(), img.size() * 2, &d.wwin)) return nullptr;
+            std::vector<uint16_t> img3((size_t)Lw * NQ * 3 * 2 * 32 * 8, 0);   // the three-part bf16 image of the same kernels (RP_MLP_F32)
+            for (int f = 0; f < Lw; ++f)
+                for (int part = 0; part < 3; ++part)
+                    for (int h = 0; h < 2; ++h)
+                        for (int o = 0; o < n1; ++o)
+                            for (int e = 0; e < 8; ++e)
+                                img3[((((((size_t)f * NQ + o / 32) * 3 + part) * 2 + h) * 32) + o % 32) * 8 + e] =
+                                    wtp[(size_t)part * rows * d.kpad + (size_t)o * d.kpad + 16 * f + 8 * h + e];
+            if (!up(img3.data(), img3.size() * 2, &d.wwin3)) return nullptr;
         }
         if (!up(wf.data(), wf.size() * 4, reinterpret_cast<void **>(&d.w1f)) || !up(wh.data(), wh.size() * 2, &d.w1h) || !up(wsp.data(), wsp.size() * 2, &d.w1s) || !up(wtp.data(), wtp.size() * 2, &d.w1t) ||
             !up(b1.data(), b1.size() * 4, reinterpret_cast<void **>(&d.b1)) || !up(tail.data(), tail.size() * 4, reinterpret_cast<void **>(&d.tail)))
@@ -851,6 +860,7 @@ Model::~Model() {
     if (dev.w1h) (void)hipFree(dev.w1h);
     if (dev.w1s) (void)hipFree(dev.w1s);
     if (dev.w1t) (void)hipFree(dev.w1t);
+    if (dev.wwin3) (void)hipFree(dev.wwin3);
     if (dev.wwin) (void)hipFree(dev.wwin);
     if (dev.b1) (void)hipFree(dev.b1);
     if (dev.tail) (void)hipFree(dev.tail);

@@ -414,6 +414,7 @@ struct MlpDev {
     void *w1t = nullptr;   // [3][16*nt][kpad] bf16: the three parts of the weights' exact bf16 split (kMlpBf16x3), zero padded
     void *wwin = nullptr;  // mfcc_size 16, layer 1 <= 160 wide: the same two parts in the order the lanes of mlp_windows_kernel (<= 32 wide) /
                            // mlp_windows_wide_kernel read them, [frame f][32-output tile q][part][k-half h][output j < 32][8 k = 16 f + 8 h ..] f16
+    void *wwin3 = nullptr; // the same in three bf16 parts (kMlpBf16x3): [frame f][32-output tile q][part 3][k-half h][output j < 32][8 k]
     float *b1 = nullptr;   // [16*nt]
     float *tail = nullptr; // layers 2..n: W [out][in] then b [out], concatenated
     int tail_floats = 0;
@@ -461,7 +462,7 @@ hipError_t launch_mlp_stream(hipStream_t st, const MlpDev &m, const MlpStreamPla
 hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int L, int K, float *mean);
 // frame_pitch (0 = n_win + L - 1, whole streams): frames between the rows of two streams -- live-stream batches keep their
 // windows in longer rows (window w of stream s starts at frame s * frame_pitch + w, counted from `mfcc`)
-int mlp_windows_supported(const MlpDev &m, size_t n_win, int K);   // 1: mlp_windows_kernel, 2: mlp_windows_wide_kernel takes the call (0: mlp_mfma_kernel, rows read in place)
+int mlp_windows_supported(const MlpDev &m, size_t n_win, int K, bool three_part = false);   // 1: mlp_windows_kernel, 2: mlp_windows_wide_kernel takes the call (0: mlp_mfma_kernel, rows read in place)
 hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, int K,
                                    const float *mean, const float *wsum, float *out, uint32_t *redo, size_t frame_pitch = 0,
                                    int precision = kMlpF32);   // kMlpF32 (three bf16 parts, rows read in place) / kMlpF16x2 (RP_MLP_F32_FAST: the

@@ -731,8 +731,11 @@ hipError_t launch_window_means(hipStream_t st, const float *mfcc, size_t S, size
 // windows per stream take (the row's own mean): those agree within the logit gate, 2e-6 on scores.
 constexpr int kWinWaves = 4, kWinTile = 32, kWinMaxTiles = 7, kWinAhead = 3;
 typedef float f32x16w __attribute__((ext_vector_type(16)));
-template <int NT>
-__global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
+// P3 (round 6, RP_MLP_F32): the frames are staged as THREE bf16 parts (exact) and a frame step is six v_mfma_f32_32x32x16_bf16 per tile
+// (x_i w_j, i + j <= 2, smallest first) against the three-part weight image MlpDev::wwin3 -- f32-grade products, no f16 range, nothing listed;
+// three planes of frames and seven accumulator tiles take two waves per SIMD.  !P3: two f16 parts (RP_MLP_F32_FAST), as described above.
+template <int NT, bool P3>
+__global__ __launch_bounds__(64 * kWinWaves, P3 ? 2 : 3) void mlp_windows_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_win, int L, unsigned blocks_per_stream, const u32x4v *__restrict__ wimg, int slots,
     int n1p, const float *__restrict__ b1, const float *__restrict__ mean, const float *__restrict__ wsum, const float *__restrict__ tail,
     int tail_floats, int n_layers, int d1, int d2, int d3, float *__restrict__ out, uint32_t *redo) {
@@ -771,17 +774,26 @@ __global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
             const int i = tid + v * 64 * kWinWaves, fr = i >> 1;
             if (i < 2 * slots) {
                 const float xs[8] = {lo[v].x - cl.x, lo[v].y - cl.y, lo[v].z - cl.z, lo[v].w - cl.w, hi[v].x - ch.x, hi[v].y - ch.y, hi[v].z - ch.z, hi[v].w - ch.w};
-                u32x4v p0, p1;
+                u32x4v p0, p1, p2;
                 float rng = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a = xs[2 * e], b = xs[2 * e + 1];
-                    rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
-                    p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-                    p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
+                    if (P3) {   // a = a0 + a1 + a2 exactly: a0 = a & 0xffff0000 (a bf16), r = a - a0, a1 = r & 0xffff0000, a2 = r - a1; a packed register = two upper halves
+                        const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+                        p0[e] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+                        p1[e] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+                        p2[e] = __builtin_amdgcn_perm(__float_as_uint(rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u)),
+                                                      __float_as_uint(ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u)), 0x07060302u);
+                    } else {
+                        rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
+                        p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+                        p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
+                    }
                 }
                 A[(0 * 2 + h) * slots + fr] = p0;
                 A[(1 * 2 + h) * slots + fr] = p1;
+                if (P3) A[(2 * 2 + h) * slots + fr] = p2;
                 if (h == 0) flag[fr] = 0u;   // the two halves of a frame belong to neighbouring lanes of one wave: its LDS stores keep their order
                 if (!(rng <= 65504.f)) flag[fr] = 1u;
             }
@@ -795,21 +807,46 @@ __global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    u32x4v wq0[kWinAhead], wq1[kWinAhead];   // the weight fragments of the next kWinAhead frames: [frame][part][k-half][output] 16 bytes
+    constexpr int NPART = P3 ? 3 : 2;
+    u32x4v wq0[kWinAhead], wq1[kWinAhead], wq2[P3 ? kWinAhead : 1];   // the weight fragments of the next kWinAhead frames: [frame][part][k-half][output] 16 bytes
     auto wfetch = [&](int f, int j) __attribute__((always_inline)) {
         const int fc = f < fe ? f : fe - 1;
-        wq0[j] = wimg[(((size_t)fc * 2 + 0) * 2 + lh) * 32 + lr];
-        wq1[j] = wimg[(((size_t)fc * 2 + 1) * 2 + lh) * 32 + lr];
+        wq0[j] = wimg[(((size_t)fc * NPART + 0) * 2 + lh) * 32 + lr];
+        wq1[j] = wimg[(((size_t)fc * NPART + 1) * 2 + lh) * 32 + lr];
+        if (P3) wq2[j] = wimg[(((size_t)fc * NPART + 2) * 2 + lh) * 32 + lr];
     };
     if (fb < fe) {
 #pragma unroll
         for (int j = 0; j < kWinAhead; ++j) wfetch(fb + j, j);
         const u32x4v *A0 = A + (0 * 2 + lh) * slots + lr, *A1 = A + (1 * 2 + lh) * slots + lr;
+        const u32x4v *A2 = A + ((P3 ? 2 : 0) * 2 + lh) * slots + lr;
+        (void)A2;
         for (int f0 = fb; f0 < fe; f0 += kWinAhead) {
 #pragma unroll
             for (int j = 0; j < kWinAhead; ++j) {
                 const int f = f0 + j;
                 if (f < fe) {   // wave-uniform
+                    if (P3) {   // six products per tile, smallest first; tiles in pairs so that consecutive matrix instructions do not wait on each other
+                        const bf16x8 c0 = __builtin_bit_cast(bf16x8, wq0[j]), c1 = __builtin_bit_cast(bf16x8, wq1[j]), c2 = __builtin_bit_cast(bf16x8, wq2[j]);
+                        wfetch(f + kWinAhead, j);
+#pragma unroll
+                        for (int t = 0; t < NT; t += 2) {
+                            const bool two = t + 1 < NT;
+                            const bf16x8 x0 = __builtin_bit_cast(bf16x8, A0[t * kWinTile + f]), x1 = __builtin_bit_cast(bf16x8, A1[t * kWinTile + f]),
+                                         x2 = __builtin_bit_cast(bf16x8, A2[t * kWinTile + f]);
+                            bf16x8 y0 = x0, y1 = x1, y2 = x2;
+                            if (two) {
+                                y0 = __builtin_bit_cast(bf16x8, A0[(t + 1) * kWinTile + f]); y1 = __builtin_bit_cast(bf16x8, A1[(t + 1) * kWinTile + f]);
+                                y2 = __builtin_bit_cast(bf16x8, A2[(t + 1) * kWinTile + f]);
+                            }
+#define RP_WIN6(XA, XB, WB)                                                                                            \
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XA, WB, acc[t], 0, 0, 0);                 \
+                            if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XB, WB, acc[t + 1], 0, 0, 0);
+                            RP_WIN6(x0, y0, c2) RP_WIN6(x1, y1, c1) RP_WIN6(x2, y2, c0) RP_WIN6(x0, y0, c1) RP_WIN6(x1, y1, c0) RP_WIN6(x0, y0, c0)
+#undef RP_WIN6
+                        }
+                        continue;
+                    }
                     const f16x8 b0 = __builtin_bit_cast(f16x8, wq0[j]), b1v = __builtin_bit_cast(f16x8, wq1[j]);
                     wfetch(f + kWinAhead, j);
                     // tiles in pairs: the two parts of two tiles live at a time (all NT at once cost 8 NT registers and the third wave
@@ -905,7 +942,7 @@ __global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
         {
             const bool row_ok = wrow0 + lr < rows_here;
             const size_t orow = s * n_win + w0 + wrow0 + lr;
-            if (lh == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
+            if (!P3 && lh == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
                 unsigned far = 0u;
                 for (int f = 0; f < L; ++f) far |= flag[wrow0 + lr + f];
                 if (far) mlp_redo_append(redo, (uint32_t)orow, (size_t)(gridDim.x / blocks_per_stream) * n_win);
@@ -945,7 +982,7 @@ __global__ __launch_bounds__(64 * kWinWaves, 3) void mlp_windows_kernel(
 // times) -- no partial sums to add up; the tiles then meet in LDS row tile by row tile ([32][32 NQ + 1] floats) for the tail layers, which
 // every lane of the workgroup shares (row, output phase).  mlp_mfma_kernel in window mode, which these shapes had until now: 5.6 ms
 // (Medium) / 13.5 ms (Large) per 8 192 streams.
-template <int NT, int NQ>
+template <int NT, int NQ, bool P3>
 __global__ __launch_bounds__(64 * NQ, 2) void mlp_windows_wide_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_win, int L, unsigned blocks_per_stream, const u32x4v *__restrict__ wimg, int slots,
     int n1p, const float *__restrict__ b1, const float *__restrict__ mean, const float *__restrict__ wsum, const float *__restrict__ tail,
@@ -982,17 +1019,26 @@ __global__ __launch_bounds__(64 * NQ, 2) void mlp_windows_wide_kernel(
             const int i = tid + v * NTHR, fr = i >> 1;
             if (i < 2 * slots) {
                 const float xs[8] = {lo[v].x - cl.x, lo[v].y - cl.y, lo[v].z - cl.z, lo[v].w - cl.w, hi[v].x - ch.x, hi[v].y - ch.y, hi[v].z - ch.z, hi[v].w - ch.w};
-                u32x4v p0, p1;
+                u32x4v p0, p1, p2;
                 float rng = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a = xs[2 * e], b = xs[2 * e + 1];
-                    rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
-                    p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-                    p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
+                    if (P3) {   // a = a0 + a1 + a2 exactly: a0 = a & 0xffff0000 (a bf16), r = a - a0, a1 = r & 0xffff0000, a2 = r - a1; a packed register = two upper halves
+                        const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+                        p0[e] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+                        p1[e] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+                        p2[e] = __builtin_amdgcn_perm(__float_as_uint(rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u)),
+                                                      __float_as_uint(ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u)), 0x07060302u);
+                    } else {
+                        rng = fmaxf(fmaxf(rng, fabsf(a)), fabsf(b));
+                        p0[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+                        p1[e] = pk_f16_second(a - __uint_as_float(__float_as_uint(a) & 0xffffe000u), b - __uint_as_float(__float_as_uint(b) & 0xffffe000u));
+                    }
                 }
                 A[(0 * 2 + h) * slots + fr] = p0;
                 A[(1 * 2 + h) * slots + fr] = p1;
+                if (P3) A[(2 * 2 + h) * slots + fr] = p2;
                 if (h == 0) flag[fr] = 0u;
                 if (!(rng <= 65504.f)) flag[fr] = 1u;
             }
@@ -1005,21 +1051,46 @@ __global__ __launch_bounds__(64 * NQ, 2) void mlp_windows_wide_kernel(
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    u32x4v wq0[kWinAhead], wq1[kWinAhead];
+    constexpr int NPART = P3 ? 3 : 2;
+    u32x4v wq0[kWinAhead], wq1[kWinAhead], wq2[P3 ? kWinAhead : 1];
     auto wfetch = [&](int f, int j) __attribute__((always_inline)) {
         const int fc = f < L ? f : L - 1;
-        wq0[j] = wimg[((((size_t)fc * NQ + q) * 2 + 0) * 2 + lh) * 32 + lr];
-        wq1[j] = wimg[((((size_t)fc * NQ + q) * 2 + 1) * 2 + lh) * 32 + lr];
+        wq0[j] = wimg[((((size_t)fc * NQ + q) * NPART + 0) * 2 + lh) * 32 + lr];
+        wq1[j] = wimg[((((size_t)fc * NQ + q) * NPART + 1) * 2 + lh) * 32 + lr];
+        if (P3) wq2[j] = wimg[((((size_t)fc * NQ + q) * NPART + 2) * 2 + lh) * 32 + lr];
     };
     {
 #pragma unroll
         for (int j = 0; j < kWinAhead; ++j) wfetch(j, j);
         const u32x4v *A0 = A + (0 * 2 + lh) * slots + lr, *A1 = A + (1 * 2 + lh) * slots + lr;
+        const u32x4v *A2 = A + ((P3 ? 2 : 0) * 2 + lh) * slots + lr;
+        (void)A2;
         for (int f0 = 0; f0 < L; f0 += kWinAhead) {
 #pragma unroll
             for (int j = 0; j < kWinAhead; ++j) {
                 const int f = f0 + j;
                 if (f < L) {   // wave-uniform
+                    if (P3) {
+                        const bf16x8 c0 = __builtin_bit_cast(bf16x8, wq0[j]), c1 = __builtin_bit_cast(bf16x8, wq1[j]), c2 = __builtin_bit_cast(bf16x8, wq2[j]);
+                        wfetch(f + kWinAhead, j);
+#pragma unroll
+                        for (int t = 0; t < NT; t += 2) {
+                            const bool two = t + 1 < NT;
+                            const bf16x8 x0 = __builtin_bit_cast(bf16x8, A0[t * kWinTile + f]), x1 = __builtin_bit_cast(bf16x8, A1[t * kWinTile + f]),
+                                         x2 = __builtin_bit_cast(bf16x8, A2[t * kWinTile + f]);
+                            bf16x8 y0 = x0, y1 = x1, y2 = x2;
+                            if (two) {
+                                y0 = __builtin_bit_cast(bf16x8, A0[(t + 1) * kWinTile + f]); y1 = __builtin_bit_cast(bf16x8, A1[(t + 1) * kWinTile + f]);
+                                y2 = __builtin_bit_cast(bf16x8, A2[(t + 1) * kWinTile + f]);
+                            }
+#define RP_WIN6(XA, XB, WB)                                                                                            \
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XA, WB, acc[t], 0, 0, 0);                 \
+                            if (two) acc[t + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(XB, WB, acc[t + 1], 0, 0, 0);
+                            RP_WIN6(x0, y0, c2) RP_WIN6(x1, y1, c1) RP_WIN6(x2, y2, c0) RP_WIN6(x0, y0, c1) RP_WIN6(x1, y1, c0) RP_WIN6(x0, y0, c0)
+#undef RP_WIN6
+                        }
+                        continue;
+                    }
                     const f16x8 b0 = __builtin_bit_cast(f16x8, wq0[j]), b1v = __builtin_bit_cast(f16x8, wq1[j]);
                     wfetch(f + kWinAhead, j);
 #pragma unroll
@@ -1077,7 +1148,7 @@ __global__ __launch_bounds__(64 * NQ, 2) void mlp_windows_wide_kernel(
         __syncthreads();
         const bool row_ok = wrow0 + prow < rows_here;
         const size_t orow = s * n_win + w0 + wrow0 + prow;
-        if (ph == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
+        if (!P3 && ph == 0 && row_ok) {   // a window holding a frame beyond the f16 range: listed for the f32 pass
             unsigned far = 0u;
             for (int f = 0; f < L; ++f) far |= flag[wrow0 + prow + f];
             if (far) mlp_redo_append(redo, (uint32_t)orow, (size_t)(gridDim.x / blocks_per_stream) * n_win);
@@ -1113,8 +1184,8 @@ __global__ __launch_bounds__(64 * NQ, 2) void mlp_windows_wide_kernel(
     }
 }
 
-int mlp_windows_supported(const MlpDev &m, size_t n_win, int K) {
-    if (!m.wwin || K != 16 || m.dims[0] % 16 != 0 || m.dims[1] > 160 || n_win < 32) return 0;
+int mlp_windows_supported(const MlpDev &m, size_t n_win, int K, bool three_part) {
+    if (!(three_part ? m.wwin3 : m.wwin) || K != 16 || m.dims[0] % 16 != 0 || m.dims[1] > 160 || n_win < 32) return 0;
     const int L = m.dims[0] / 16;
     if (L > 256 || m.tail_floats > 6144) return 0;
     for (int l2 = 2; l2 <= m.n_layers; ++l2) if (m.dims[l2] > 32) return 0;
@@ -1123,62 +1194,64 @@ int mlp_windows_supported(const MlpDev &m, size_t n_win, int K) {
     return m.dims[1] <= 32 ? 1 : 2;
 }
 
-template <int NT, int NQ>
+template <int NT, int NQ, bool P3>
 static hipError_t launch_mlp_windows_wide_nq(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
                                              const float *wsum, float *out, uint32_t *redo, size_t pitch) {
     const int L = m.dims[0] / 16;
     const size_t bps = (n_win + NT * kWinTile - 1) / (NT * kWinTile), blocks = bps * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const int slots = (NT * kWinTile + L + 3) & ~3;
-    const size_t region = std::max((size_t)4 * slots * 16, (size_t)32 * (32 * NQ + 1) * 4 + (size_t)32 * 33 * 4);
+    const size_t region = std::max((size_t)(P3 ? 6 : 4) * slots * 16, (size_t)32 * (32 * NQ + 1) * 4 + (size_t)32 * 33 * 4);
     const size_t lds = (size_t)((m.tail_floats + 3) & ~3) * 4 + (size_t)slots * 4 + region;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_wide_kernel<NT, NQ>), 160 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL((mlp_windows_wide_kernel<NT, NQ>), dim3((unsigned)blocks), dim3(64 * NQ), lds, st, mfcc, pitch, n_win, L, (unsigned)bps,
-                       static_cast<const u32x4v *>(m.wwin), slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_wide_kernel<NT, NQ, P3>), 160 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mlp_windows_wide_kernel<NT, NQ, P3>), dim3((unsigned)blocks), dim3(64 * NQ), lds, st, mfcc, pitch, n_win, L, (unsigned)bps,
+                       static_cast<const u32x4v *>(P3 ? m.wwin3 : m.wwin), slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
                        m.dims[3], out, redo);
     return hipGetLastError();
 }
 
-template <int NT>
+template <int NT, bool P3>
 static hipError_t launch_mlp_windows_wide_nt(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
                                              const float *wsum, float *out, uint32_t *redo, size_t pitch) {
     switch ((m.dims[1] + 31) / 32) {
-    case 2: return launch_mlp_windows_wide_nq<NT, 2>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 3: return launch_mlp_windows_wide_nq<NT, 3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 4: return launch_mlp_windows_wide_nq<NT, 4>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 5: return launch_mlp_windows_wide_nq<NT, 5>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 2: return launch_mlp_windows_wide_nq<NT, 2, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 3: return launch_mlp_windows_wide_nq<NT, 3, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 4: return launch_mlp_windows_wide_nq<NT, 4, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 5: return launch_mlp_windows_wide_nq<NT, 5, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
     }
     return hipErrorInvalidValue;
 }
 
+template <bool P3>
 static hipError_t launch_mlp_windows_wide(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
                                           const float *wsum, float *out, uint32_t *redo, size_t pitch) {
     // row tiles per workgroup: 2 or 4 (measured per 8 192 streams x 202 windows, Medium / Large: 7 tiles 3.87 / 8.62 ms at two waves per SIMD,
     // 4 tiles 3.36 / 7.90 at four, 2 tiles 3.84 / 11.2 -- the weights once per 64 rows)
     const size_t tiles = (n_win + kWinTile - 1) / kWinTile, wgs = (tiles + 3) / 4, per = (tiles + wgs - 1) / wgs;
-    if (per <= 2) return launch_mlp_windows_wide_nt<2>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    return launch_mlp_windows_wide_nt<4>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    if (per <= 2) return launch_mlp_windows_wide_nt<2, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    return launch_mlp_windows_wide_nt<4, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
 }
 
-template <int NT>
+template <int NT, bool P3>
 static hipError_t launch_mlp_windows_nt(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_win, const float *mean,
                                         const float *wsum, float *out, uint32_t *redo, size_t pitch) {
     const int L = m.dims[0] / 16;
     const size_t bps = (n_win + NT * kWinTile - 1) / (NT * kWinTile), blocks = bps * S;
     if (blocks > 0x7fffffffULL) return hipErrorInvalidValue;
     const int slots = (NT * kWinTile + L + 3) & ~3;
-    // frame planes; later the sums of the tiles (h1 of a tile in its place) + h2 of the four waves
-    const size_t region = std::max((size_t)4 * slots * 16, (size_t)NT * 4096 + (size_t)kWinWaves * 4096);
+    // frame planes (two or three parts x two k-halves); later the sums of the tiles (h1 of a tile in its place) + h2 of the four waves
+    const size_t region = std::max((size_t)(P3 ? 6 : 4) * slots * 16, (size_t)NT * 4096 + (size_t)kWinWaves * 4096);
     const size_t lds = (size_t)((m.tail_floats + 3) & ~3) * 4 + (size_t)slots * 4 + region;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_kernel<NT>), 160 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL(mlp_windows_kernel<NT>, dim3((unsigned)blocks), dim3(64 * kWinWaves), lds, st, mfcc, pitch, n_win, L, (unsigned)bps,
-                       static_cast<const u32x4v *>(m.wwin), slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(mlp_windows_kernel<NT, P3>), 160 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((mlp_windows_kernel<NT, P3>), dim3((unsigned)blocks), dim3(64 * kWinWaves), lds, st, mfcc, pitch, n_win, L, (unsigned)bps,
+                       static_cast<const u32x4v *>(P3 ? m.wwin3 : m.wwin), slots, 16 * m.nt, m.b1, mean, wsum, m.tail, m.tail_floats, m.n_layers, m.dims[1], m.dims[2],
                        m.dims[3], out, redo);
     return hipGetLastError();
 }
 
+template <bool P3>
 static hipError_t launch_mlp_windows(hipStream_t st, const MlpDev &m, const float *mfcc, size_t S, size_t n_frames, size_t n_win, const float *mean,
                                      const float *wsum, float *out, uint32_t *redo, size_t pitch) {
     (void)n_frames;
@@ -1187,13 +1260,13 @@ static hipError_t launch_mlp_windows(hipStream_t st, const MlpDev &m, const floa
     const size_t cap = cap_env >= 1 && cap_env <= kWinMaxTiles ? (size_t)cap_env : (size_t)kWinMaxTiles;
     const size_t tiles = (n_win + kWinTile - 1) / kWinTile, wgs = (tiles + cap - 1) / cap, per = (tiles + wgs - 1) / wgs;
     switch (per) {
-    case 1: return launch_mlp_windows_nt<1>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 2: return launch_mlp_windows_nt<2>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 3: return launch_mlp_windows_nt<3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 4: return launch_mlp_windows_nt<4>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 5: return launch_mlp_windows_nt<5>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 6: return launch_mlp_windows_nt<6>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
-    case 7: return launch_mlp_windows_nt<7>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 1: return launch_mlp_windows_nt<1, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 2: return launch_mlp_windows_nt<2, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 3: return launch_mlp_windows_nt<3, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 4: return launch_mlp_windows_nt<4, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 5: return launch_mlp_windows_nt<5, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 6: return launch_mlp_windows_nt<6, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+    case 7: return launch_mlp_windows_nt<7, P3>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
     }
     return hipErrorInvalidValue;
 }
@@ -1209,12 +1282,20 @@ hipError_t launch_mlp_mfma_windows(hipStream_t st, const MlpDev &m, const float 
     if (pitch < n_win) return hipErrorInvalidValue;
     (void)n_frames;
     const size_t skip = (pitch - n_win) * K;
-    // the staged-frame kernels (mlp_windows_kernel / mlp_windows_wide_kernel) multiply two-part f16 splits: RP_MLP_F32_FAST only
-    if (const int form = (precision == kMlpF16x2 && redo) ? mlp_windows_supported(m, n_win, K) : 0) {
+    // the staged-frame kernels (mlp_windows_kernel / mlp_windows_wide_kernel): three bf16 parts for RP_MLP_F32 (exact operands, nothing to
+    // list), two f16 parts for RP_MLP_F32_FAST (+ the listed rows again with the f32 instructions)
+    if (precision == kMlpF32 && redo) {
+        if (const int form = mlp_windows_supported(m, n_win, K, true)) {
+            if (S * n_win > 0xffffffffULL) return hipErrorInvalidValue;
+            return form == 1 ? launch_mlp_windows<true>(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch)
+                             : launch_mlp_windows_wide<true>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch);
+        }
+    }
+    if (const int form = (precision == kMlpF16x2 && redo) ? mlp_windows_supported(m, n_win, K, false) : 0) {
         // whole streams (or long runs of windows): the frames staged once per workgroup; then the listed rows with the f32 instructions
         if (S * n_win > 0xffffffffULL) return hipErrorInvalidValue;
-        if (hipError_t e = form == 1 ? launch_mlp_windows(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch)
-                                     : launch_mlp_windows_wide(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch); e != hipSuccess)
+        if (hipError_t e = form == 1 ? launch_mlp_windows<false>(st, m, mfcc, S, n_frames, n_win, mean, wsum, out, redo, pitch)
+                                     : launch_mlp_windows_wide<false>(st, m, mfcc, S, n_win, mean, wsum, out, redo, pitch); e != hipSuccess)
             return mlp_redo_abort(st, redo, e);
         hipError_t e2 = hipErrorInvalidValue;   // (launch_mlp_nt puts the words back itself when ITS launch fails)
         switch (m.nt) {

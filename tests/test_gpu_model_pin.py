@@ -121,9 +121,9 @@ def test_forward_of_the_fixture_model_kernel_and_oracle_are_equally_far_from_f64
     assert np.array_equal(np.argmax(got32, axis=1), np.argmax(tru, axis=1))
 
 
-def test_whole_stream_forward_bits_depend_on_the_stream_alone(ra, ctx):
-    """RP_MLP_F32_FAST (two f16 parts per operand: the staged-frame kernels exist in that arithmetic; the default RP_MLP_F32 reads every
-    window in place through mlp_mfma_kernel with three bf16 parts, one form for live and offline calls).  The whole-stream form of the forward (mlp_windows_kernel: a stream's frames staged once per workgroup, minus the mean of that
+@pytest.mark.parametrize("prec", ["f32", "f32_fast"])
+def test_whole_stream_forward_bits_depend_on_the_stream_alone(ra, ctx, prec):
+    """RP_MLP_F32 (three bf16 parts) and RP_MLP_F32_FAST (two f16 parts): the staged-frame kernels exist in both arithmetics.  The whole-stream form of the forward (mlp_windows_kernel: a stream's frames staged once per workgroup, minus the mean of that
     workgroup's middle window) and the live form (mlp_mfma_kernel: a few new windows per call, the row's own mean) agree within the logit gate
     (1e-5 of the row's scale; 2e-6 on the scores derived from them), not bit for bit.  What IS bit-stable: a stream's logits do not depend on the batch it is scored in, nor on the call
     being repeated -- the workgroups of a stream are cut the same way whatever else is in the launch."""
@@ -133,14 +133,14 @@ def test_whole_stream_forward_bits_depend_on_the_stream_alone(ra, ctx):
     K = m["mfcc_size"]
     rng = np.random.default_rng(12)
     mf = np.stack([orc.mfcc_stream((rng.standard_normal(480 * 160) * 0.05).astype(np.float32), K) for _ in range(5)])
-    whole = ctx.mlp_forward_windows(mf, model, "f32_fast")
+    whole = ctx.mlp_forward_windows(mf, model, prec)
     assert whole.shape[1] >= 200 and np.isfinite(whole).all()
-    assert np.array_equal(whole, ctx.mlp_forward_windows(mf, model, "f32_fast"))
-    assert np.array_equal(whole[3], ctx.mlp_forward_windows(mf[3:4], model, "f32_fast")[0])
-    assert np.array_equal(whole[1:], ctx.mlp_forward_windows(mf[1:], model, "f32_fast"))
+    assert np.array_equal(whole, ctx.mlp_forward_windows(mf, model, prec))
+    assert np.array_equal(whole[3], ctx.mlp_forward_windows(mf[3:4], model, prec)[0])
+    assert np.array_equal(whole[1:], ctx.mlp_forward_windows(mf[1:], model, prec))
     # a shorter run of the same stream (fewer than 32 windows: the live form's kernel) -- same logits within 1e-5 of the row's scale
     L = model.n_in // K
-    short = ctx.mlp_forward_windows(mf[2:3, : L + 20], model, "f32_fast")[0]
+    short = ctx.mlp_forward_windows(mf[2:3, : L + 20], model, prec)[0]
     scale = np.maximum(np.abs(whole[2][:21]).max(axis=1, keepdims=True), 1.0)
     assert np.all(np.abs(short - whole[2][:21]) <= 1e-5 * scale)
     assert not np.array_equal(short, whole[2][:21])   # (the two forms really are different kernels)

@@ -656,7 +656,10 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
             d.rest_runs = 0;
         }
     }
-    d.n_chunks_total = (int)chunks.size();
+    // chunks that index the call's tile counters (DtwWork::sched): every chunk but the ragged ones at the end of the array -- dtw_ragged_kernel
+    // takes its tiles by index and uses no counter (round-5 advice: its chunks must not count against the limit of a kernel that never runs
+    // in the default arithmetic)
+    d.n_chunks_total = d.rag_count > 0 ? d.rag_first : (int)chunks.size();
     if (d.n_chunks_total > kDtwSchedChunks) { set_last_error("wakeword reference with too many template lengths for the device kernels"); return nullptr; }
     return tp.release();
 }

@@ -148,7 +148,7 @@ struct TemplatesDev {
     // mfcc_size 13 / 16: the sample templates once more as chunks of up to 8 same-length templates for dtw_mfma_wide_kernel (only when
     // every length occurs at least three times: the matrix kernel always pays for eight template slots)
     int wide8_first = 0, wide8_count = 0;
-    int n_chunks_total = 0;   // entries of `chunks` (the matrix-core kernels' tile counters live in the CALL's workspace, DtwWork::sched)
+    int n_chunks_total = 0;   // entries of `chunks` that index tile counters (all but the ragged chunks at its end; the counters live in the CALL's workspace, DtwWork::sched)
     // The reference forms the cosine as dot_ab / sqrt(dot_a * dot_b) in f32 (comparator.rs:28-48): the PRODUCT of the squared norms
     // can underflow (-> "magnitude == 0" -> similarity 0) or overflow where neither factor does.  The kernels above are scale
     // invariant (unit-length rows and frames), so they only agree with it while both squared norms stay in a range where the product

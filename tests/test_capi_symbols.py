@@ -42,6 +42,38 @@ def test_default_config_matches_reference_constants():
     assert L.rp_mfcc_num_frames(18150) == 108 and L.rp_mfcc_num_frames(479) == 0 and L.rp_mfcc_num_frames(64000) == 396
 
 
+def test_arithmetic_is_part_of_the_abi():
+    """The arithmetic of the DTW cost's products and of the model forward is chosen through the ABI (the reference's config-is-a-struct
+    convention, src/config.rs:172-219), not through the environment: the header declares the context flags, the RP_ARITH_* values, the setter /
+    getter and the reporting bits; the Python harness and the Rust binding carry the same numbers; no product source reads the retired
+    RP_DTW_MFMA / RP_DTW_RAGGED switches; a NULL context is refused by the setter like by every other entry point."""
+    import ctypes as C
+    import rustpotter_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "rustpotter_hip.h")).read()
+    consts = {k: int(v) for k, v in re.findall(r"\b(RP_[A-Z0-9_]+)\s*=\s*(\d+)", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S))}
+    assert (consts["RP_CTX_HOST_POINTERS"], consts["RP_CTX_FULL_SCORES"], consts["RP_CTX_ARITH_STRICT_F32"], consts["RP_CTX_ARITH_FAST_SPLIT"],
+            consts["RP_CTX_RAGGED_MATRIX"]) == (1, 2, 4, 8, 16)
+    assert (consts["RP_ARITH_F32_MATRIX"], consts["RP_ARITH_STRICT_F32"], consts["RP_ARITH_FAST_SPLIT"]) == (0, 1, 2)   # 0 = the default: f32-grade
+    assert (consts["RP_DTW_PRODUCTS_BF16X3"], consts["RP_DTW_PRODUCTS_F16X2"]) == (256, 512)
+    assert (consts["RP_MLP_F32"], consts["RP_MLP_BF16"], consts["RP_MLP_F32_STRICT"], consts["RP_MLP_F32_FAST"]) == (0, 1, 2, 3)
+    assert rustpotter_amd.BatchContext.ARITH == {"f32_matrix": 0, "strict_f32": 1, "fast_split": 2}
+    from rustpotter_amd.api import MLP_PRECISION
+    assert MLP_PRECISION == {"f32": 0, "bf16": 1, "f32_strict": 2, "f32_fast": 3}
+    rs = open(os.path.join(root, "bindings", "rustpotter_hip.rs")).read()
+    for name in ("RP_CTX_ARITH_STRICT_F32", "RP_CTX_ARITH_FAST_SPLIT", "RP_CTX_RAGGED_MATRIX", "RP_ARITH_F32_MATRIX", "RP_ARITH_STRICT_F32",
+                 "RP_ARITH_FAST_SPLIT", "RP_DTW_PRODUCTS_BF16X3", "RP_DTW_PRODUCTS_F16X2", "RP_MLP_F32_FAST"):
+        m = re.search(r"pub const %s: c_int = (\d+);" % name, rs)
+        assert m and int(m.group(1)) == consts[name], name
+    L = rustpotter_amd.load_library()
+    assert L.rp_ctx_set_arithmetic(None, 0, 0) < 0 and L.rp_ctx_arithmetic(None, None) < 0
+    src_dir = os.path.join(root, "rustpotter_amd", "csrc")
+    for f in os.listdir(src_dir):
+        if f.endswith((".hip", ".cpp", ".h")):
+            txt = open(os.path.join(src_dir, f)).read()
+            assert 'getenv("RP_DTW_MFMA")' not in txt and 'getenv("RP_DTW_RAGGED")' not in txt, f
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

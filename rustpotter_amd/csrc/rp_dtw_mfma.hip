@@ -22,12 +22,23 @@
 //     v_min3_f32 x2 + add x2 per cell), each tile's MFMA for column c+1 is issued right after the last cell that reads the tile, and
 //     the frame of column c+2 is prepared in ten pieces between the cells.  Columns are unrolled 12 at a time so that every
 //     slot, tile and band index is a compile-time register.
+//   * Two arithmetics (P3, round 6; chosen by the context, rp_ctx_set_arithmetic).  P3 = true, the default (RP_ARITH_F32_MATRIX): f32-GRADE products.
+//     Both operands are split into THREE bf16 parts, exactly (x0 = x & 0xffff0000, r = x - x0, x1 = r & 0xffff0000, x2 = r - x1: 3 x 8 significant
+//     bits = an f32's 24; the template rows on the host, rounded to nearest), and the six partial products x_i a_j with i + j <= 2 of the five
+//     components + 1.0 x 1.0 fill 31 of the 32 k-slots of TWO v_mfma_f32_32x32x16_bf16 chained on one accumulator (the second one band cell
+//     after the first).  What is dropped (x1 a2 + x2 a1 + x2 a2) is below 2^-22 of a product, 2^-25.7 rms -- an f32 multiply rounds by up to
+//     2^-24; tests/test_gpu_dtw_f64.py holds the scores to the strict-f32 oracle's own distance from an f64 evaluation.  The window side's two
+//     operands are one run of six registers (the middle two shared), the A image is 512 bytes per template row (append_mfma_image3,
+//     rp_ctx.cpp), 223 registers = two waves per SIMD, eight per workgroup.  P3 = false (RP_ARITH_FAST_SPLIT, opt-in): the two-part f16 form
+//     described above, 22-bit products.
 //   * Two shapes (NT): eight template slots as described (chunks of 5..8 templates, band 3..5), or four (chunks of 3..4, band 5): a
-//     tile is then 8 row slots x 4 templates, 16 circular row slots = 2 tiles, one template pair per lane, columns unrolled 16 at a time.
+//     tile is then 8 row slots x 4 templates, 16 circular row slots = 2 tiles, one template pair per lane, columns unrolled 16 at a time (two-part
+//     form only: the three-part build of this shape does not fit the registers).
 //     mfcc_size 13 / 16 have their own K axis: rp_dtw_mfma_wide.hip.
 // Measured (tools/scratch/dtw_mfma_probe2.hip, 8 192 streams x 288 windows x 8 templates of 100 frames): 1.62 ms against 2.36 ms at
 // dtw_band_kernel's C3 rate; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles), matrix pipe 21 % busy.  In the product
-// at C3: 19.5 -> 12.0 ms (profiles/r03_final_*).
+// at C3: 19.5 ms (vector kernels) -> 11.6-11.9 (two-part form) / 14.4-15.3 (three-part form, matrix pipe 39 % busy) (DESIGN.md §4.2,
+// profiles/r06_final_*).
 #include "rp_device.h"
 
 #include <cstdlib>

@@ -336,10 +336,15 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None, products=
     if mfma_used and not mfma_wide:
         f_exec_mat = ksteps5 * sum((mfma_chunks(c)[0] * 3 + mfma_chunks(c)[1] * 2) * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
         f_exec_vec = sum((c - mfma_chunks(c)[2]) * Lt * 2 * W * 3 + (mfma_chunks(c)[0] + mfma_chunks(c)[1]) * Lt * 40 for Lt, c in by_len.items())
+    wide3 = mfma_wide and prod == "bf16x3"   # dtw_mfma_wide3_kernel: chunks of up to FOUR templates, 2 tiles x 6 k-steps per column
     if mfma_wide:
         ksteps = 3   # (round 5: mfcc_size 16 starts its sum at the C operand instead of spending a fourth k-step on the constant slot)
         f_exec_mat = sum(-(-c // 8) * 3 * ksteps * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
         f_exec_vec = sum(c * Lt * 2 * W * 3 + -(-c // 8) * Lt * 8 * K for Lt, c in by_len.items())
+    if wide3:
+        kernel = "dtw_mfma_wide3_kernel"
+        f_exec_mat = sum(-(-c // 4) * 2 * 6 * (Lt + 1) * 32768 / 32.0 for Lt, c in by_len.items())
+        f_exec_vec = sum(c * Lt * 2 * W * 3 + -(-c // 4) * Lt * 14 * K for Lt, c in by_len.items())
     if ragged:
         # per window and column: two v_mfma_f32_32x32x16_f16 per 64 windows, and 3 vector ops per band cell + the norm + the mean term
         f_exec_mat += sum((Lt + 1) * 2 * 32768 / 64.0 for Lt in rag_lens)
@@ -373,7 +378,7 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None, products=
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
                                                                                                          mix["valu_issue_cycles_per_trip"])})
         # a matrix instruction takes ~19 issue cycles from the vector work beside it at three waves per SIMD (tools/scratch/mfma_valu_overlap_probe.hip:
-        # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions); the three-part form runs two waves per SIMD
+        # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions); the three-part form runs three waves per SIMD at C3 too (two for small batches)
         # with six matrix instructions per column -- the same price is used (measured there: 17 from the kernel's own time, 25 in the probe)
         extra["valu_plus_matrix_issue_frac"] = (cyc + 19.0 * trips * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         if grouped:
@@ -393,7 +398,18 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None, products=
         extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/dtw_ragged_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
                       "instructions, %.0f SIMD issue cycles per 16-column block of one template for the 64 windows of a wave" % (
                           mix["classes"]["valu"], mix["classes"]["mfma"], mix["valu_issue_cycles_per_trip"])})
-    elif mfma_wide and K == 16 and n_win >= 32 and load_json("profiles/dtw_mfma_wide_isa_mix.json"):
+    elif wide3 and K == 16 and n_win >= 32 and load_json("profiles/dtw_mfma_wide3_isa_mix.json"):
+        mix = load_json("profiles/dtw_mfma_wide3_isa_mix.json")
+        # the hot loop is one block of 16 columns of one 32-window tile of one chunk of up to four templates
+        trips = sum(-(-c // 4) * Lt / 16.0 for Lt, c in by_len.items()) * -(-rows // 32)
+        cyc = trips * mix["valu_issue_cycles_per_trip"]
+        pipes["valu_issue"] = cyc / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        extra["frac_at_architectural_rates"] = trips * mix["valu_issue_cycles_per_trip_architectural"] / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        extra["valu_plus_matrix_issue_frac"] = trips * (mix["valu_issue_cycles_per_trip"] + 25.0 * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
+        extra.update({"valu_issue_cycles_per_launch": cyc, "isa_mix": "profiles/dtw_mfma_wide3_isa_mix.json x profiles/valu_rate_table.json: %d VALU + %d MFMA "
+                      "instructions, %.0f SIMD issue cycles per 16-column block of a 32-window tile of four templates (two waves per SIMD)" % (
+                          mix["classes"]["valu"], mix["classes"]["mfma"], mix["valu_issue_cycles_per_trip"])})
+    elif mfma_wide and not wide3 and K == 16 and n_win >= 32 and load_json("profiles/dtw_mfma_wide_isa_mix.json"):
         mix = load_json("profiles/dtw_mfma_wide_isa_mix.json")
         # the hot loop is one block of 12 columns of one 32-window tile of one chunk of up to eight templates
         trips = sum(-(-c // 8) * Lt / 12.0 for Lt, c in by_len.items()) * -(-rows // 32)

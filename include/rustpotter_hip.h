@@ -191,8 +191,9 @@ int rp_ctx_new(int device, int flags, rp_ctx **out);
  * a band cell are formed and how many bits of them are kept:
  *   RP_ARITH_F32_MATRIX (default)  matrix cores, f32-grade: both operands as three bf16 parts (exact: 3 x 8 = an f32's 24 significant bits),
  *       six of the nine partial products accumulated in f32 -- what is dropped is below 2^-22 of a product (2^-25.7 rms; an f32 multiply
- *       rounds by up to 2^-24, 2^-25.3 rms).  Template sets with no such kernel (unequal lengths, mfcc_size 13 / 16, a band other than
- *       3..5) run the f32 vector kernels.
+ *       rounds by up to 2^-24, 2^-25.3 rms): mfcc_size 5 in chunks of 3..8 templates of one length, mfcc_size 13 / 16 in chunks of up to
+ *       four.  Template sets with no such kernel (lengths that occur once or twice, other frame sizes, a band other than 3..5) run the
+ *       f32 vector kernels.
  *   RP_ARITH_STRICT_F32            f32 vector FMAs for every product (the "register" kernels), nothing on the matrix cores.
  *   RP_ARITH_FAST_SPLIT            matrix cores with two f16 parts per operand (22 significant bits, one partial product dropped): the
  *       fastest form, NARROWER than the reference's f32 products; scores stay within the 1e-5 parity gate for score_ref >= 0.05.
@@ -219,7 +220,7 @@ int rp_ctx_dtw_ref_pairs(rp_ctx *ctx, uint64_t *pairs);
  * it to name the kernel a measurement belongs to. */
 enum {
     RP_DTW_KERNEL_MFMA = 1,      /* dtw_mfma_kernel: chunks of 3..8 same-length templates, mfcc_size 5, cosines on the matrix cores */
-    RP_DTW_KERNEL_MFMA_WIDE = 2, /* dtw_mfma_wide_kernel: mfcc_size 13 / 16 */
+    RP_DTW_KERNEL_MFMA_WIDE = 2, /* dtw_mfma_wide3_kernel (three bf16 parts) / dtw_mfma_wide_kernel (two f16 parts): mfcc_size 13 / 16 */
     RP_DTW_KERNEL_RAGGED = 4,    /* dtw_ragged_kernel: templates of unequal length on the matrix cores, mfcc_size 5 */
     RP_DTW_KERNEL_REGISTER = 8,  /* dtw_band_kernel / dtw_band2_kernel / dtw_band_wide_kernel: f32 vector arithmetic throughout */
     RP_DTW_KERNEL_GENERIC = 16,  /* dtw_generic_kernel */

@@ -420,6 +420,44 @@ static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c
             }
 }
 
+// dtw_mfma_wide3_kernel's A operand of one chunk of up to four templates (rp_dtw_mfma_wide3.hip): per template row [k-step 6][k half 2][template
+// slot 4] x 8 bf16.  Lane half kh owns components kh * CHM .. kh * CHM + CHM - 1 (zero beyond K); a = -(unit row) = a0 + a1 + a2 exactly.  The
+// 24 registers of a half: per component pair (p, q) (a0p, a0q) x 3, (a1p, a1q) x 2, (a2p, a2q) against the window side's (x0, x0), (x1, x1),
+// (x2, x2), (x0, x0), (x1, x1), (x0, x0); an odd last component s: (a0s, a0s), (a0s, a1s), (a1s, a2s) against (x0s, x1s), (x2s, x0s),
+// (x1s, x0s), then (1.0, 0) in half 1: the 1 of 1 - a.x (an even count starts the sum at 1 instead).
+static void append_mfma_wide3_image(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad, int K) {
+    const int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, KS = kDtwWide3KSteps, row_bytes = kDtwWide3RowBytes;
+    const size_t base = img.size();
+    img.resize(base + (size_t)(c.len + 16) * row_bytes / 2, 0);
+    for (int r = 0; r < c.len; ++r)
+        for (int t = 0; t < c.count; ++t)
+            for (int kh = 0; kh < 2; ++kh) {
+                std::vector<uint16_t> v(8 * KS, 0);  // 4 KS registers of two bf16
+                auto parts = [&](int j, uint16_t p[3]) {
+                    const int comp = kh * CHM + j;
+                    p[0] = p[1] = p[2] = 0;
+                    if (comp < K) bf16_split3(-unit[((size_t)c.tid[t] * Lpad + r) * K + comp], p);
+                };
+                for (int j = 0; j < NPAIR; ++j) {
+                    uint16_t a[3], b[3];
+                    parts(2 * j, a); parts(2 * j + 1, b);
+                    const int which[6] = {0, 0, 0, 1, 1, 2};
+                    for (int i = 0; i < 6; ++i) { v[2 * (6 * j + i)] = a[which[i]]; v[2 * (6 * j + i) + 1] = b[which[i]]; }
+                }
+                if (CHM % 2) {
+                    uint16_t s3[3];
+                    parts(CHM - 1, s3);
+                    const int o = 6 * NPAIR;
+                    v[2 * o] = s3[0]; v[2 * o + 1] = s3[0];
+                    v[2 * (o + 1)] = s3[0]; v[2 * (o + 1) + 1] = s3[1];
+                    v[2 * (o + 2)] = s3[1]; v[2 * (o + 2) + 1] = s3[2];
+                    v[2 * (o + 3)] = kh ? 0x3f80 : 0; v[2 * (o + 3) + 1] = 0;
+                }
+                for (int ks = 0; ks < KS; ++ks)
+                    std::memcpy(&img[base + ((size_t)r * row_bytes + ks * 128 + kh * 64 + t * 16) / 2], &v[8 * ks], 16);
+            }
+}
+
 // Template rows are scaled to unit L2 norm in f64 and rounded once to f32; an all-zero
 // row stays zero so that its cosine similarity is 0 (src/mfcc/comparator.rs:43-47).
 Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const float *feats, int avg_len,
@@ -574,6 +612,27 @@ Templates *Templates::create(Ctx *ctx, int T, int K, const int *lens, const floa
                 append_mfma_wide_image(aimg, c, unit.data(), Lpad, K);
                 d.mfma_min_len = d.mfma_min_len == 0 ? c.len : std::min(d.mfma_min_len, c.len);
                 chunks.push_back(c);
+            }
+            // the same templates as chunks of up to FOUR for the three-part kernel (dtw_mfma_wide3_kernel): a length's templates spread evenly
+            // over its chunks (five: 3 + 2, not 4 + 1)
+            d.wide4_first = (int)chunks.size();
+            for (int i = 0; i < T;) {
+                int j = i;
+                while (j < T && hl[order[j]] == hl[order[i]]) ++j;
+                const int nch = (j - i + 3) / 4;
+                for (int b = i, ci = 0; ci < nch; ++ci) {
+                    const int cnt = (j - b + (nch - ci) - 1) / (nch - ci);
+                    DtwChunk c{};
+                    c.len = hl[order[i]]; c.count = cnt; c.tc = 4; c.rows_off = 0; c.aimg_off = 0;
+                    for (int q = 0; q < kChunkMax; ++q) c.tid[q] = order[b + (q < cnt ? q : 0)];
+                    c.aimg3_off = (int)(aimg3.size() * sizeof(uint16_t) / 16);
+                    append_mfma_wide3_image(aimg3, c, unit.data(), Lpad, K);
+                    d.wide4_min_len = d.wide4_min_len == 0 ? c.len : std::min(d.wide4_min_len, c.len);
+                    chunks.push_back(c);
+                    ++d.wide4_count;
+                    b += cnt;
+                }
+                i = j;
             }
         }
     }

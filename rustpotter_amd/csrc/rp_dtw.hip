@@ -994,6 +994,13 @@ static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int
                                       float *avg, bool few, GateList gl = GateList{}, bool padded = false) {
     // every length at least three times, band 5, rows with slack behind them: the sample templates on the matrix cores
     // (rp_dtw_mfma_wide.hip), the averaged template -- if it is to be scored here -- through the one-template register kernel
+    if (W == 5 && (padded || few || gl.list) && dtw_mfma_wide3_supported(t, W)) {   // the default arithmetic: three bf16 parts, chunks of four
+        if (t.has_avg && n1 == t.class_count[3])
+            if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
+                                                        few, gl, t.class_first[3] + t.class_count[3] - 1); e != hipSuccess) return e;
+        return launch_dtw_mfma_wide3(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg,
+                                     gl.list, gl.count, gl.dense_min, gl.abandon_nc);
+    }
     if (W == 5 && (padded || few || gl.list) && dtw_mfma_wide_supported(t, W, score_ref)) {
         if (t.has_avg && n1 == t.class_count[3])
             if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
@@ -1323,7 +1330,7 @@ static hipError_t launch_dtw_gated_impl(hipStream_t st, const DtwWork &wk, const
     // (as in launch_dtw: one stream alone is scored like a batch when the matrix-core kernel serves its templates)
     const bool mfma_batch = few_windows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8, score_ref)) ||
                                                           (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4, score_ref)))) ||
-                                            dtw_mfma_wide_supported(t, band, score_ref));
+                                            dtw_mfma_wide_supported(t, band, score_ref) || dtw_mfma_wide3_supported(t, band));
     const bool few = few_windows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const int avg_chunk = t.class_first[3] + t.class_count[3] - 1;  // the averaged template: last of the single-template chunks
     hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), st);
@@ -1386,7 +1393,7 @@ static hipError_t launch_dtw_fast(hipStream_t st, const DtwWork &wk, const Templ
     // batch it is scored in, live or offline -- only the single-stream mirror, which never passes padded_rows, keeps dtw_single_kernel)
     const bool mfma_batch = padded_rows && ((t.K == 5 && ((t.class_count[2] > 0 && dtw_mfma_supported(t, band, n_win, true, 8, score_ref)) ||
                                                            (t.class_count[1] > 0 && dtw_mfma_supported(t, band, n_win, true, 4, score_ref)))) ||
-                                            dtw_mfma_wide_supported(t, band, score_ref));
+                                            dtw_mfma_wide_supported(t, band, score_ref) || dtw_mfma_wide3_supported(t, band));
     const bool few = padded_rows && (S > 1 || mfma_batch) && n_win < (size_t)kDtwWin;
     const bool do_avg = with_avg && t.has_avg;
     const int Ttot = t.T + (do_avg ? 1 : 0);

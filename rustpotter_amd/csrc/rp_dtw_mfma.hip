@@ -29,12 +29,14 @@
 //     after the first).  What is dropped (x1 a2 + x2 a1 + x2 a2) is below 2^-22 of a product, 2^-25.7 rms -- an f32 multiply rounds by up to
 //     2^-24; tests/test_gpu_dtw_f64.py holds the scores to the strict-f32 oracle's own distance from an f64 evaluation.  The window side's two
 //     operands are one run of six registers (the middle two shared), the A image is 512 bytes per template row (append_mfma_image3,
-//     rp_ctx.cpp), 223 registers = two waves per SIMD, eight per workgroup.  P3 = false (RP_ARITH_FAST_SPLIT, opt-in): the two-part f16 form
+//     rp_ctx.cpp); 168 registers = three waves per SIMD (twelve per workgroup) for large batches, 220 = two (eight) for small ones.  P3 = false (RP_ARITH_FAST_SPLIT, opt-in): the two-part f16 form
 //     described above, 22-bit products.
 //   * Two shapes (NT): eight template slots as described (chunks of 5..8 templates, band 3..5), or four (chunks of 3..4, band 5): a
-//     tile is then 8 row slots x 4 templates, 16 circular row slots = 2 tiles, one template pair per lane, columns unrolled 16 at a time (two-part
-//     form only: the three-part build of this shape does not fit the registers).
-//     mfcc_size 13 / 16 have their own K axis: rp_dtw_mfma_wide.hip.
+//     tile is then 8 row slots x 4 templates, 16 circular row slots = 2 tiles, one template pair per lane, columns unrolled 16 at a time, twelve
+//     waves per workgroup in both arithmetics.  mfcc_size 13 / 16 have their own K axis: rp_dtw_mfma_wide3.hip / rp_dtw_mfma_wide.hip.
+//   * BUILD: the 12 / 16-column blocks are `#pragma unroll` loops whose bodies exceed the compiler's budget for pragma-requested full
+//     unrolling; this file is compiled with -mllvm -pragma-unroll-threshold=200000 (Makefile FILE_FLAGS_rp_dtw_mfma.hip).  Without it the
+//     three-part four-slot build keeps a rolled loop, indexes its accumulators at run time and spills 13 709 values.
 // Measured (tools/scratch/dtw_mfma_probe2.hip, 8 192 streams x 288 windows x 8 templates of 100 frames): 1.62 ms against 2.36 ms at
 // dtw_band_kernel's C3 rate; VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles), matrix pipe 21 % busy.  In the product
 // at C3: 19.5 ms (vector kernels) -> 11.6-11.9 (two-part form) / 14.4-15.3 (three-part form, matrix pipe 39 % busy) (DESIGN.md §4.2,
@@ -543,10 +545,6 @@ bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from
     const int mode = t.arith_mode();   // the context's arithmetic (rp_ctx_set_arithmetic), read per call
     if (mode == kArithStrictF32 || t.K != kMK || !(mode == kArithFastSplit ? t.aimg : t.aimg3) || t.max_diff != 0) return false;
     const bool p3 = mode != kArithFastSplit;
-    // chunks of 3..4 templates: the four-slot shape exists for the two-part form only (its three-part build does not fit the registers: the
-    // allocator spills thousands of values in the 16-column block); in the three-part arithmetic such chunks keep the tc-4 register kernel --
-    // the eight-slot shape would pay for eight templates and measures slower than that kernel for three
-    if (p3 && slots != 8) return false;
     // the two-part form: the score's sensitivity to the cost grows like 1 / score_ref (rp_kernels.h); the three-part form's products are
     // f32-grade, it needs no floor
     if (!p3 && !(score_ref >= kDtwMfmaMinScoreRef)) return false;
@@ -554,8 +552,8 @@ bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from
     if (!from_global && n_win < (size_t)kMWin) return false;            // a staged tile holds at most two stream segments
     // the first 12 (16) columns are one guarded block
     if (slots == 8 ? t.mfma_min_len < mfma_slots(8) : t.mfma_min_len4 < mfma_slots(4)) return false;
-    // long templates: the A image leaves room for eight waves' frame stages only.  The four-slot form is built for twelve waves (its
-    // eight-wave build spills: the register allocator loses its way in the 16-column unroll) -- such chunks keep the tc-4 register kernel
+    // long templates: the A image leaves room for eight waves' frame stages only.  The four-slot form is built for twelve waves -- longer
+    // chunks of 3..4 keep the tc-4 register kernel
     return dtw_mfma_lds_bytes(t.max_len, slots == 8 ? 8 : 12, p3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes) <= 160 * 1024;
 }
 
@@ -575,10 +573,14 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
     const int row_bytes = p3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes;
     int nw = dtw_mfma_lds_bytes(t.max_len, 12, row_bytes) <= 160 * 1024 ? 12 : 8;
     if (p3 && slots == 8) {
-        // the three-part form runs two waves per SIMD (8 per workgroup, 233 registers, nothing spilled): measured 14.6-14.7 ms against 15.2 for
-        // three per SIMD at 168 registers (82 spilled, scratch traffic inside the column loop) at BASELINE C3.  RP_MFMA3_WAVES=12: A/B runs
+        // the three-part form: two waves per SIMD (8 per workgroup, 220 registers, nothing spilled) or three (12 per workgroup, 168 registers, 59
+        // values spilled, ten scratch accesses per 12-column block).  Measured at BASELINE C3 (2 376 tiles per CU), alternating three times:
+        // 14.93-14.94 ms with twelve waves against 15.11-15.21 with eight; at C2 (37 tiles per CU: three rounds of twelve waves) 0.304 against
+        // 0.293.  Twelve when every wave has at least eight tiles to take; the frames-from-global build spills 135 values and keeps eight.
+        // RP_MFMA3_WAVES=8 / 12: A/B runs
         static const int env_nw = [] { const char *e = std::getenv("RP_MFMA3_WAVES"); return e ? std::atoi(e) : 0; }();
-        if (env_nw != 12) nw = 8;
+        const bool many = !from_global && total_tiles >= (size_t)device_cu_count() * 12 * 8;
+        if (env_nw == 8 || (env_nw != 12 && !many)) nw = 8;
     }
     const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw, row_bytes);
     const void *image = p3 ? t.aimg3 : t.aimg;
@@ -609,8 +611,8 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
         else { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, false, NT); else RP_LAUNCH_MFMA(WW, 8, false, NT); }                            \
     } while (0)
     if (slots == 4) {
-        if (band != 5 || nw != 12 || p3) return hipErrorNotSupported;
-        if (from_global) RP_LAUNCH_MFMA_P(5, 12, true, 4, false); else RP_LAUNCH_MFMA_P(5, 12, false, 4, false);
+        if (band != 5 || nw != 12) return hipErrorNotSupported;
+        if (from_global) RP_LAUNCH_MFMA(5, 12, true, 4); else RP_LAUNCH_MFMA(5, 12, false, 4);
     } else {
         switch (band) {
         case 3: RP_LAUNCH_MFMA_W(3, 8); break;

@@ -89,6 +89,11 @@ __host__ __device__ constexpr int dtw_mfma_wide_ksteps(int K) {
 // time = two row slots x 128 bytes; a pitch that is a multiple of 256 bytes put both on the same 32 banks (SQ_LDS_BANK_CONFLICT = half of
 // the kernel's LDS cycles, profiles/r05_wide_pmc.txt)
 __host__ __device__ constexpr int dtw_mfma_wide_row_bytes(int K) { return dtw_mfma_wide_ksteps(K) * 256 + 128; }
+// dtw_mfma_wide3_kernel (rp_dtw_mfma_wide3.hip; mfcc_size 13 / 16 in the three-part bf16 arithmetic): FOUR template slots per wave, six k-steps
+// of 16 slots; A image = per template row [k-step 6][k half 2][template 4] x 8 bf16 = 768 bytes + 64 (the four row slots a ds_read_b128 serves
+// fall on different banks)
+constexpr int kDtwWide3KSteps = 6;
+constexpr int kDtwWide3RowBytes = kDtwWide3KSteps * 128 + 64;
 // Tiles a wave of the matrix-core DTW kernels takes by its own index before it turns to the chunk's atomic counter: every whole round
 // of a launch of at most three rounds (live-stream calls, BASELINE config C2 -- the waves start together and would ask for their
 // tickets together; the counter then hands out what is left), the first round of longer launches (the waves drift apart by themselves
@@ -148,6 +153,8 @@ struct TemplatesDev {
     // mfcc_size 13 / 16: the sample templates once more as chunks of up to 8 same-length templates for dtw_mfma_wide_kernel (only when
     // every length occurs at least three times: the matrix kernel always pays for eight template slots)
     int wide8_first = 0, wide8_count = 0;
+    // ... and as chunks of up to 4 for dtw_mfma_wide3_kernel (three-part bf16 images in aimg3, DtwChunk::aimg3_off)
+    int wide4_first = 0, wide4_count = 0, wide4_min_len = 0;
     int n_chunks_total = 0;   // entries of `chunks` that index tile counters (all but the ragged chunks at its end; the counters live in the CALL's workspace, DtwWork::sched)
     // The reference forms the cosine as dot_ab / sqrt(dot_a * dot_b) in f32 (comparator.rs:28-48): the PRODUCT of the squared norms
     // can underflow (-> "magnitude == 0" -> similarity 0) or overflow where neither factor does.  The kernels above are scale
@@ -216,6 +223,11 @@ bool dtw_mfma_wide_supported(const TemplatesDev &t, int band, float score_ref);
 hipError_t launch_dtw_mfma_wide(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
                                 size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, const uint32_t *list,
                                 const uint32_t *count, uint32_t dense_min, float abandon_nc);
+// the same shapes in the default arithmetic (three bf16 parts per operand, no score_ref floor): chunks of up to four templates
+bool dtw_mfma_wide3_supported(const TemplatesDev &t, int band);
+hipError_t launch_dtw_mfma_wide3(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, const float *mfcc, size_t S, size_t frame_pitch, size_t first_win,
+                                 size_t n_win, size_t out_win_pitch, float score_ref, float *scores, float *avg, const uint32_t *list,
+                                 const uint32_t *count, uint32_t dense_min, float abandon_nc);
 // ScoreMode::Max folded into the matrix-core DTW kernel when ONE chunk holds every sample template of the reference and no averaged
 // template is scored in the call (BASELINE C2 / C3, a live-stream call with same-length templates): the lane pair of a window holds all
 // its scores, so the kernel also writes agg[row] = max_t score and raises the stream's `hot` flag like agg_store (rp_dtw.hip) -- the

@@ -67,10 +67,11 @@ def test_what_each_arithmetic_launches(ra):
     assert not np.array_equal(out["fast_split"], out["strict_f32"])
 
 
-def test_shapes_without_an_f32_grade_matrix_kernel_run_the_vector_kernels_by_default(ra):
-    """mfcc_size 16 (dtw_mfma_wide_kernel) and templates of unequal length (dtw_ragged_kernel) exist as two-part f16 kernels only: the default
-    arithmetic scores them with the f32 vector kernels -- bit for bit what RP_ARITH_STRICT_F32 gives -- and the opt-ins bring the matrix
-    kernels back."""
+def test_wide_frames_and_ragged_sets_per_arithmetic(ra):
+    """mfcc_size 16: dtw_mfma_wide3_kernel (three bf16 parts, chunks of four) by default, dtw_mfma_wide_kernel (two f16 parts, chunks of
+    eight) in RP_ARITH_FAST_SPLIT, the wide register kernels in RP_ARITH_STRICT_F32.  Templates of unequal length (dtw_ragged_kernel)
+    exist as a two-part f16 kernel only: the default arithmetic scores them with the f32 vector kernels -- bit for bit what
+    RP_ARITH_STRICT_F32 gives -- and the opt-in brings the matrix kernel back."""
     ctx = ra.BatchContext(device=0, host_pointers=True)
     cfg = ra.DetectorConfig()
     cfg.avg_threshold = 0.0
@@ -80,15 +81,19 @@ def test_shapes_without_an_f32_grade_matrix_kernel_run_the_vector_kernels_by_def
     tm16 = ra.Templates(ctx, t16)
     ctx.dtw_kernels()
     _, _, dflt, _ = ctx.batch_detect(pcm, tm16, cfg, want_scores=True)
-    assert ctx.dtw_kernels() == ["register kernels"] and ctx.last_dtw_products == []
+    assert ctx.dtw_kernels() == ["dtw_mfma_wide_kernel"] and ctx.last_dtw_products == ["bf16x3"]
     with ctx.arithmetic("strict_f32"):
         _, _, strict, _ = ctx.batch_detect(pcm, tm16, cfg, want_scores=True)
-    assert np.array_equal(dflt, strict)
+        assert ctx.dtw_kernels() == ["register kernels"] and ctx.last_dtw_products == []
+    assert not np.array_equal(dflt, strict) and np.all(np.abs(dflt - strict) <= 2e-6 * strict)
     with ctx.arithmetic("fast_split"):
-        ctx.dtw_kernels()
         _, _, fast, _ = ctx.batch_detect(pcm, tm16, cfg, want_scores=True)
         assert "dtw_mfma_wide_kernel" in ctx.dtw_kernels() and ctx.last_dtw_products == ["f16x2"]
-    assert not np.array_equal(fast, dflt) and np.all(np.abs(fast - dflt) <= 2e-6 * dflt)
+    assert not np.array_equal(fast, dflt) and np.all(np.abs(fast - strict) <= 2e-6 * strict)
+    for s in range(2):
+        ref_s, _ = orc.score_stream(orc.mfcc_stream(pcm[s], 16), t16)
+        for got in (dflt, strict, fast):
+            assert np.all(np.abs(got[s] - ref_s) <= 1e-5 * ref_s)
     # mfcc_size 5, five templates of unequal length (the shape of the reference's oye_casa_g.rpw), whole streams
     tt = orc.synth_templates(SEED + 5, 5, 108, 5)
     rag = [np.ascontiguousarray(t[:n]) for t, n in zip(tt, (108, 96, 90, 93, 102))]

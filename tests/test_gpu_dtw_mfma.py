@@ -70,8 +70,7 @@ def test_scores_match_the_oracle(ra, ctx, L, T):
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm)
     assert rel_close(scores, reg, 2e-6), np.abs(scores / reg - 1).max()
-    # (chunks of 3..4 templates: the four-slot shape exists for the two-part f16 arithmetic only)
-    matrix = (T >= 5 and L >= 12) or (3 <= T <= 4 and L >= 16 and _fast(ctx))
+    matrix = (T >= 5 and L >= 12) or (3 <= T <= 4 and L >= 16)
     assert np.array_equal(scores, reg) == (not matrix), "which chunks take the matrix-core kernel"
 
 
@@ -311,10 +310,8 @@ def test_max_inside_the_dtw_kernel_equals_the_aggregate_pass(ra, ctx, T, L):
     assert np.array_equal(scores, scores2) and np.array_equal(agg, agg2) and np.array_equal(agg, scores.max(axis=2))
     assert np.array_equal(n_det, n2) and np.array_equal(det, det2)
     assert np.array_equal(n_only, n_only2) and np.array_equal(det_only, det_only2) and np.array_equal(n_only, n_det)
-    # launches of the aggregate pass inside the two calls (chunks of 3..4 templates reach the matrix kernel in the two-part arithmetic only:
-    # in the default one the register kernels score them and the pass runs)
-    fused_here = T >= 5 or _fast(ctx)
-    assert n_fused == (0 if fused_here else 1) and n_pass == 1, (n_fused, n_pass)
+    # launches of the aggregate pass inside the two calls
+    assert n_fused == 0 and n_pass == 1, (n_fused, n_pass)
     for cpc in (1, 4):
         out = []
         for fused in (True, False):
@@ -372,8 +369,8 @@ def test_matrix_core_sweep_few_cases(ra):
 
 @pytest.mark.parametrize("K,L,T", [(16, 40, 8), (16, 12, 3), (16, 61, 11), (13, 37, 5), (13, 24, 8), (13, 100, 3)])
 def test_wide_frames_match_the_oracle(ra, ctx, K, L, T):
-    """mfcc_size 13 / 16 (dtw_mfma_wide_kernel, rp_dtw_mfma_wide.hip; two-part f16 products: RP_ARITH_FAST_SPLIT only -- in the default
-    arithmetic these sets run the wide register kernels): every length at least three times, band 5, through the batched
+    """mfcc_size 13 / 16 (dtw_mfma_wide3_kernel, rp_dtw_mfma_wide3.hip: three bf16 parts, chunks of four, the default arithmetic;
+    dtw_mfma_wide_kernel, rp_dtw_mfma_wide.hip: two f16 parts, chunks of eight, RP_ARITH_FAST_SPLIT): every length at least three times, band 5, through the batched
     detector (its frame rows end with slack: the kernel reads its frames from global memory).  Scores against the oracle, against the
     wide register kernels (2e-6, not the same bits), and the live-stream batch against the offline call bit for bit."""
     S, N = 3, 480 * 45
@@ -389,8 +386,12 @@ def test_wide_frames_match_the_oracle(ra, ctx, K, L, T):
         assert rel_close(agg[s], ref_a)
     with _registers_only():
         _, _, reg, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
-    # (RP_ARITH_F32_MATRIX has no matrix kernel for these frame sizes: the wide register kernels score, the switch changes nothing)
-    assert rel_close(scores, reg, 2e-6) and np.array_equal(scores, reg) == (not _fast(ctx))
+    matrix = _fast(ctx) or L >= 16          # the three-part kernel's first block is 16 columns (the two-part one's 12)
+    assert rel_close(scores, reg, 2e-6) and np.array_equal(scores, reg) == (not matrix)
+    ctx.dtw_kernels()
+    ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    if matrix:
+        assert "dtw_mfma_wide_kernel" in ctx.dtw_kernels() and ctx.last_dtw_products == (["f16x2"] if _fast(ctx) else ["bf16x3"])
     sb = ra.StreamBatch(ctx, tm, cfg, S, max_chunks_per_call=2)
     compared = 0
     for i in range(0, N, 960):

@@ -62,8 +62,7 @@ def test_matrix_core_shapes_at_low_score_ref(ra, ctx, K, T, L, band, score_ref, 
     assert worst <= 1e-5, worst
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm, score_ref=score_ref, band_size=band)
-    # (the four-slot shape for chunks of 3..4 templates exists in the two-part f16 arithmetic only)
-    matrix = (T >= 5 and band <= 5) or (T >= 3 and band == 5 and arith == "fast_split")
+    matrix = (T >= 5 and band <= 5) or (T >= 3 and band == 5)
     assert np.array_equal(scores, reg) == (not matrix), "the matrix-core kernel serves these shapes down to score_ref 0.05"
     assert rel_err(scores, reg) <= 4e-6 * 0.22 / score_ref
 

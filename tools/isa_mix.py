@@ -13,6 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-pass-failed"]
 
 
+def file_flags(src):
+    """the per-file flags of rustpotter_amd/csrc/Makefile (FILE_FLAGS_<source>: the pragma-unroll budget of the matrix DTW kernels)"""
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rustpotter_amd", "csrc"), "print-file-flags", "F=" + os.path.basename(src)],
+                         stdout=subprocess.PIPE, text=True).stdout
+    return out.split()
+
+
 def rate_of(op, table):
     for pat, cyc in table["rates"]:
         if re.fullmatch(pat, op):
@@ -38,7 +45,7 @@ def main():
     table = json.load(open(os.path.join(ROOT, "profiles", "valu_rate_table.json")))
     with tempfile.TemporaryDirectory() as d:
         asm = os.path.join(d, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + flags + ["--cuda-device-only", "-S", "-o", asm,
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + file_flags(src) + flags + ["--cuda-device-only", "-S", "-o", asm,
                                src if os.path.isabs(src) or os.path.exists(src) else os.path.join(ROOT, "rustpotter_amd", "csrc", src)], stderr=subprocess.DEVNULL)
         lines = open(asm).read().splitlines()
     # kernel bodies: "<mangled>:" ... "s_endpgm" / ".Lfunc_end"

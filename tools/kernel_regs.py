@@ -8,8 +8,15 @@ extra = []
 if "--" in args:
     i = args.index("--"); extra = args[i + 1:]; args = args[:i]
 src = args[0] if os.path.isabs(args[0]) else os.path.join(ROOT, "rustpotter_amd", "csrc", args[0])
+def file_flags(src):
+    """the per-file flags of rustpotter_amd/csrc/Makefile (FILE_FLAGS_<source>: the pragma-unroll budget of the matrix DTW kernels)"""
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rustpotter_amd", "csrc"), "print-file-flags", "F=" + os.path.basename(src)],
+                         stdout=subprocess.PIPE, text=True).stdout
+    return out.split()
+
+
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
-       "-Wno-pass-failed", "--cuda-device-only", "-c", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", src] + extra
+       "-Wno-pass-failed", "--cuda-device-only", "-c", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", src] + file_flags(src) + extra
 err = subprocess.run(cmd, stderr=subprocess.PIPE, text=True).stderr
 cur = None
 rows = {}

@@ -1186,7 +1186,7 @@ if __name__ == "__main__":
         ("sweep", a.cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True),
          lambda r: "%d cases, %d detections compared, %d threshold ties skipped" % r),
         ("matrix-core DTW sweep, RP_ARITH_F32_MATRIX (default: three bf16 parts)", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True, arith="f32_matrix"),
-         lambda r: "%d cases (mfcc_size 5 at band 3..5: dtw_mfma_kernel; mfcc_size 13 / 16 and everything else on the f32 vector kernels; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44), %d detections compared, %d threshold ties skipped" % r),
+         lambda r: "%d cases (mfcc_size 5 at band 3..5: dtw_mfma_kernel in chunks of 3..8; mfcc_size 13 / 16 at band 5: dtw_mfma_wide3_kernel in chunks of up to four; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44), %d detections compared, %d threshold ties skipped" % r),
         ("matrix-core DTW sweep, RP_ARITH_FAST_SPLIT (two f16 parts)", a.mfma_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, mfma=True, arith="fast_split"),
          lambda r: "%d cases (mfcc_size 5 at band 3..5, mfcc_size 13 / 16 at band 5; 3..16 same-length templates, one case in eight of mfcc_size 5 with 32..44: dtw_mfma_group_kernel), %d detections compared, %d threshold ties skipped" % r),
         ("ragged matrix-core DTW sweep (RP_ARITH_FAST_SPLIT + ragged_matrix)", a.ragged_cases, lambda n: run_sweep(ra, ctx, n, a.seed, verbose=True, ragged=True),

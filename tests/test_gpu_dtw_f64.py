@@ -74,7 +74,7 @@ def _errors(got, tru):
     return float(np.sqrt((e * e).mean())), float(e.max()), float(((got - tru) / tru).mean())
 
 
-def _measure(sample, arithmetic, expect_kernel, expect_products):
+def _measure(sample, arithmetic, expect_kernel, expect_products, min_size=16 * 297 * 8):
     ctx, mf, tm, ref, tru = sample
     with ctx.arithmetic(arithmetic):
         ctx.dtw_kernels()
@@ -82,7 +82,7 @@ def _measure(sample, arithmetic, expect_kernel, expect_products):
         ran = ctx.dtw_kernels()
     assert expect_kernel in ran, ran
     assert ctx.last_dtw_products == expect_products, ctx.last_dtw_products
-    assert got.shape == ref.shape == tru.shape and got.size >= 16 * 297 * 8
+    assert got.shape == ref.shape == tru.shape and got.size >= min_size
     k_rms, k_max, k_mean = _errors(got, tru)
     o_rms, o_max, o_mean = _errors(ref, tru)
     print("\n%-11s rel. score error vs f64: kernel rms %.3e max %.3e mean %+.2e | oracle rms %.3e max %.3e mean %+.2e | ratio rms %.3f max %.3f | kernel vs oracle max %.3e"
@@ -96,6 +96,34 @@ def test_f32_matrix_scores_are_f32_grade(sample):
     """The default arithmetic: three bf16 parts per operand on the matrix cores.  As good an f32 evaluation as the oracle itself."""
     r_rms, r_max = _measure(sample, "f32_matrix", "dtw_mfma_kernel", ["bf16x3"])
     assert r_rms <= 1.25 and r_max <= 1.25, (r_rms, r_max)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K_, T_, kernel", [(5, 4, "dtw_mfma_kernel"), (5, 3, "dtw_mfma_kernel"), (16, 8, "dtw_mfma_wide_kernel"), (13, 5, "dtw_mfma_wide_kernel")])
+def test_the_other_three_part_shapes_are_f32_grade(ra, K_, T_, kernel):
+    """The same bar for the other kernels of the default arithmetic: the four-slot shape of dtw_mfma_kernel (chunks of 3..4 templates) and
+    dtw_mfma_wide3_kernel (mfcc_size 13 / 16: six k-steps of three-part products, reported as dtw_mfma_wide_kernel + bf16x3)."""
+    ctx = ra.BatchContext(device=0, host_pointers=True)
+    S, N = 16, 64000
+    templates = orc.synth_templates(SEED + 31 * K_ + T_, T_, L, K_)
+    pcm = ctx.synth_pcm(SEED, 100, S, N)
+    mf = ctx.mfcc(pcm, K_)
+    ref = np.stack([orc.score_stream(mf[s], templates, BAND, SCORE_REF)[0] for s in range(S)]).astype(np.float64)
+    tru = np.stack([f64_scores(mf[s], templates) for s in range(S)])
+    # through the batched detector (the wide kernels read their frames from rows with slack behind them: the library's own MFCC buffer)
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold, cfg.score_ref, cfg.band_size = 0.0, SCORE_REF, BAND
+    tm = ra.Templates(ctx, templates)
+    ctx.dtw_kernels()
+    got = ctx.batch_detect(pcm, tm, cfg, want_scores=True)[2].astype(np.float64)
+    assert kernel in ctx.dtw_kernels() and ctx.last_dtw_products == ["bf16x3"]
+    assert got.shape == ref.shape == tru.shape == (S, 297, T_)
+    assert np.all(np.abs(got - ref) <= 1e-5 * ref), "the 1e-5 parity contract against the oracle"
+    k_rms, k_max, _ = _errors(got, tru)
+    o_rms, o_max, _ = _errors(ref, tru)
+    print("\nmfcc_size %d, %d templates: rel. score error vs f64: kernel rms %.3e max %.3e | oracle rms %.3e max %.3e | ratio rms %.3f max %.3f"
+          % (K_, T_, k_rms, k_max, o_rms, o_max, k_rms / o_rms, k_max / o_max))
+    assert k_rms <= 1.25 * o_rms and k_max <= 1.25 * o_max, (k_rms / o_rms, k_max / o_max)
 
 
 @pytest.mark.gpu

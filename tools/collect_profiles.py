@@ -81,7 +81,9 @@ names = {"bench_default": R + "_final_bench", "stream1": "bench_%s_stream_1chunk
          "ragged3_alexa_matrix": "bench_%s_ragged3_alexa_lens_matrix_optin" % R,
          "c3_fast_split": "bench_%s_c3_fast_split" % R, "c3_strict_f32": "bench_%s_c3_strict_f32" % R, "c2_fast_split": "bench_%s_c2_fast_split" % R,
          "c4_fast_split": "bench_%s_c4_per_gpu_fast_split" % R, "k16_fast_split": "bench_%s_k16_8192streams_fast_split" % R,
-         "c5_f32_fast": "bench_%s_c5_f32_fast" % R, "c5_f32_strict": "bench_%s_c5_f32_strict" % R}
+         "c5_f32_fast": "bench_%s_c5_f32_fast" % R, "c5_f32_strict": "bench_%s_c5_f32_strict" % R,
+         "k16_strict_f32": "bench_%s_k16_8192streams_strict_f32" % R, "k13_strict_f32": "bench_%s_k13_8192streams_strict_f32" % R,
+         "t4": "bench_%s_t4" % R, "t4_strict_f32": "bench_%s_t4_strict_f32" % R, "t4_fast_split": "bench_%s_t4_fast_split" % R}
 for a, b in names.items():
     src = "gpurun_out/final/%s.json" % a
     if os.path.exists(src) and os.path.getsize(src) > 10:

@@ -25,6 +25,12 @@ $B --no-cpu-baseline --template-lens 117,126,99 2>/dev/null | line > $O/ragged3_
 $B --no-cpu-baseline --arith fast_split --ragged-matrix --template-lens 117,126,99 2>/dev/null | line > $O/ragged3_alexa_matrix.json
 $B --no-cpu-baseline --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16.json
 $B --no-cpu-baseline --arith fast_split --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16_fast_split.json
+$B --no-cpu-baseline --arith strict_f32 --streams 8192 --mfcc-size 16 2>/dev/null | line > $O/k16_strict_f32.json
+$B --no-cpu-baseline --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13.json
+$B --no-cpu-baseline --arith strict_f32 --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13_strict_f32.json
+$B --no-cpu-baseline --templates 4 2>/dev/null | line > $O/t4.json
+$B --no-cpu-baseline --arith strict_f32 --templates 4 2>/dev/null | line > $O/t4_strict_f32.json
+$B --no-cpu-baseline --arith fast_split --templates 4 2>/dev/null | line > $O/t4_fast_split.json
 $B --no-cpu-baseline --mode mlp --mlp-precision bf16 2>/dev/null | line > $O/c5_bf16.json
 $B --no-cpu-baseline --mode mlp --mlp-precision f32 2>/dev/null | line > $O/c5_f32.json
 $B --no-cpu-baseline --mode mlp --mlp-precision f32_fast 2>/dev/null | line > $O/c5_f32_fast.json
@@ -44,7 +50,6 @@ $B --no-cpu-baseline --mode stream --chunks-per-call 8 2>/dev/null | line > $O/s
 $B --no-cpu-baseline --mode resample --streams 8192 2>/dev/null | line > $O/rs_fft.json
 RP_RESAMPLE_GEMM=1 $B --no-cpu-baseline --mode resample --streams 8192 2>/dev/null | line > $O/rs_gemm.json
 $B --no-cpu-baseline --mode resample --streams 8192 --pcm-format i16 --channels 2 2>/dev/null | line > $O/rs_fft_i16_stereo.json
-$B --no-cpu-baseline --streams 8192 --mfcc-size 13 2>/dev/null | line > $O/k13.json
 for m in small medium large; do python3 bench.py --mode model --model-type $m --streams 32768 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | line > $O/model_$m.json; done
 python3 bench.py --ingest --ingest-format f32 --no-cpu-baseline 2>/dev/null | line > $O/ingest_f32.json
 python3 bench.py --ingest --ingest-format i16 --no-cpu-baseline 2>/dev/null | line > $O/ingest_i16.json

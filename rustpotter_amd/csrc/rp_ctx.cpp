@@ -438,6 +438,14 @@ static void append_mfma_wide3_image(std::vector<uint16_t> &img, const DtwChunk &
                     p[0] = p[1] = p[2] = 0;
                     if (comp < K) bf16_split3(-unit[((size_t)c.tid[t] * Lpad + r) * K + comp], p);
                 };
+                if (dtw_mfma_wide3_run(K)) {   // the kernel reads its twelve window-side registers as one run (rp_kernels.h)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int i = 0; i < 4; ++i) {
+                            uint16_t a[3], b[3];
+                            parts(2 * kDtwWide3RunPair[ks][i], a); parts(2 * kDtwWide3RunPair[ks][i] + 1, b);
+                            v[2 * (4 * ks + i)] = a[kDtwWide3RunPart[ks][i]]; v[2 * (4 * ks + i) + 1] = b[kDtwWide3RunPart[ks][i]];
+                        }
+                } else
                 for (int j = 0; j < NPAIR; ++j) {
                     uint16_t a[3], b[3];
                     parts(2 * j, a); parts(2 * j + 1, b);

@@ -13,7 +13,9 @@
 //   * lane half h owns CHM = ceil(K / 2) components; a component pair (a, b) fills six registers of the B operand,
 //       [(x0a, x0b), (x1a, x1b), (x2a, x2b), (x0a, x0b), (x1a, x1b), (x0a, x0b)] against [(a0, a0) x 3, (a1, a1) x 2, (a2, a2)],
 //     an odd last component s three: [(x0s, x1s), (x2s, x0s), (x1s, x0s)] against [(a0, a0), (a0, a1), (a1, a2)], and (mfcc_size 13) the
-//     constant (1.0, 0) x (1.0, 0) in half 1.
+//     constant (1.0, 0) x (1.0, 0) in half 1.  mfcc_size 16 keeps the twelve DIFFERENT registers of a half as one run and reads it in overlapping
+//     pieces (w3_run_piece below; −85 vector instructions per 16-column block, measured 6.43-6.48 ms against 6.44-6.57: the matrix pipe is as
+//     loaded as the vector pipe here, fewer copies buy almost nothing).
 // Frames are read from global memory (the caller leaves slack behind the last stream's frames, launch_dtw `padded_rows`), as in the two-part
 // kernel.  Two waves per SIMD (eight per workgroup): 233 / 240 registers, nothing spilled.
 // BUILD: the 16-column block (192 matrix instructions, ~2 700 instructions) is a `#pragma unroll` loop far beyond the compiler's default budget for
@@ -31,6 +33,21 @@ namespace {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x12 __attribute__((ext_vector_type(12)));
+
+// mfcc_size 16 (four component pairs per lane half, no odd component): the B operand's 24 register slots hold only 12 different registers
+// (per pair P0 = (x0, x0) three times, P1 twice, P2 once).  They are kept as ONE run, [P2a P2b P1a P1b P0a P0b P0c P0d P1c P1d P2c P2d], and
+// the six k-steps read overlapping four-register pieces of it at offsets 0, 2, 4, 4, 6, 8 -- no copies; the A image pairs every slot with
+// the template part that completes its product (kW3RunPart, the same table in append_mfma_wide3_image, rp_ctx.cpp).
+__device__ __forceinline__ u32x4 w3_run_piece(const u32x12 &r, int ks) {
+    switch (ks) {
+    case 0: return __builtin_shufflevector(r, r, 0, 1, 2, 3);
+    case 1: return __builtin_shufflevector(r, r, 2, 3, 4, 5);
+    case 2: case 3: return __builtin_shufflevector(r, r, 4, 5, 6, 7);
+    case 4: return __builtin_shufflevector(r, r, 6, 7, 8, 9);
+    default: return __builtin_shufflevector(r, r, 8, 9, 10, 11);
+    }
+}
 
 constexpr int kW3Win = 32, kW3Slots = 16, kW3Tiles = 2, kW3SPT = 8, kW3KS = kDtwWide3KSteps;
 
@@ -83,6 +100,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
     const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds, uint32_t *__restrict__ fix) {
     constexpr int B = 2 * W, NS = kW3Slots, NTILE = kW3Tiles, SPT = kW3SPT, KS = kW3KS;
     constexpr int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, ODD = CHM % 2;
+    constexpr bool RUN = dtw_mfma_wide3_run(K);   // mfcc_size 16: the B operand as one run of twelve registers
     constexpr int kRowBytes = kDtwWide3RowBytes;
     constexpr W3IssueTable kIssue = w3_issue_table<W>();
     static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 16 row slots");
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
                 Areg[g][ks] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)(r - 1) * kRowBytes + ks * 128);
         }
         v16f acc[NTILE];
+        u32x12 brun;        // (RUN) the same, twelve registers
         u32x4 bop[1][KS];   // ONE buffer: the operand of column c + 2 is built after the last matrix instruction of column c + 1 is out (end of step c)
         float chk = 0.f;
 
@@ -198,15 +217,20 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
             const float ua_ = d_[2 * j] * inv_, ub_ = d_[2 * j + 1] * inv_;                                                   \
             const float ra_ = ua_ - top16(ua_), rb_ = ub_ - top16(ub_);                                                       \
             const unsigned p0_ = hi2(ub_, ua_), p1_ = hi2(rb_, ra_), p2_ = hi2(rb_ - top16(rb_), ra_ - top16(ra_));           \
-            v_[6 * j] = p0_; v_[6 * j + 1] = p1_; v_[6 * j + 2] = p2_; v_[6 * j + 3] = p0_; v_[6 * j + 4] = p1_; v_[6 * j + 5] = p0_; \
+            if (RUN) {   /* pairs 0, 1 from the front of the run, pairs 2, 3 from its back */                                  \
+                brun[4 + j] = p0_; brun[j < 2 ? 2 + j : 6 + j] = p1_; brun[j < 2 ? j : 8 + j] = p2_;           \
+            } else {                                                                                                          \
+                v_[6 * j] = p0_; v_[6 * j + 1] = p1_; v_[6 * j + 2] = p2_; v_[6 * j + 3] = p0_; v_[6 * j + 4] = p1_; v_[6 * j + 5] = p0_; \
+            }                                                                                                                 \
         }                                                                                                                     \
         if (ODD) {                                                                                                            \
             const float us_ = d_[CHM - 1] * inv_, rs_ = us_ - top16(us_), x2_ = rs_ - top16(rs_);                             \
             v_[6 * NPAIR] = hi2(rs_, us_); v_[6 * NPAIR + 1] = hi2(us_, x2_); v_[6 * NPAIR + 2] = hi2(us_, rs_);              \
             v_[6 * NPAIR + 3] = h ? 0x00003f80u : 0u;   /* the constant 1.0 of 1 - a.x (half 1) */                            \
         }                                                                                                                     \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                                     \
-            bop[par][ks] = (u32x4){v_[4 * ks], v_[4 * ks + 1], v_[4 * ks + 2], v_[4 * ks + 3]};                               \
+        if (!RUN)                                                                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                                 \
+                bop[par][ks] = (u32x4){v_[4 * ks], v_[4 * ks + 1], v_[4 * ks + 2], v_[4 * ks + 3]};                           \
     } while (0)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 16)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
@@ -221,8 +245,9 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
     do {                                                                                                                      \
         constexpr float c1_ = ODD ? 0.f : 1.f;   /* an even component count has no product slot for the 1 of 1 - a.x: it starts the sum */ \
         const v16f in16_ = {c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_};                   \
-        if ((ks) == 0) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][0]), __builtin_bit_cast(bf16x8, bop[par][0]), in16_, 0, 0, 0); \
-        else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][ks]), __builtin_bit_cast(bf16x8, bop[par][ks]), acc[g], 0, 0, 0); \
+        const u32x4 b4_ = RUN ? w3_run_piece(brun, ks) : bop[par][ks];                                                        \
+        if ((ks) == 0) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][0]), __builtin_bit_cast(bf16x8, b4_), in16_, 0, 0, 0); \
+        else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][ks]), __builtin_bit_cast(bf16x8, b4_), acc[g], 0, 0, 0); \
     } while (0)
 // column c (c = 1 + u mod 16): the B operand of column c + 2 is built first (its frame was requested one column earlier), then the
 // frame of column c + 3 is requested, then the cells; a tile's k-steps for column c + 1 go out after the last cell that reads the tile

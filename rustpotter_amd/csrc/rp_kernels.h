@@ -94,6 +94,14 @@ __host__ __device__ constexpr int dtw_mfma_wide_row_bytes(int K) { return dtw_mf
 // fall on different banks)
 constexpr int kDtwWide3KSteps = 6;
 constexpr int kDtwWide3RowBytes = kDtwWide3KSteps * 128 + 64;
+// mfcc_size 16: the window side's twelve different operand registers are one run read in overlapping pieces (rp_dtw_mfma_wide3.hip,
+// w3_run_piece); slot i of k-step ks then holds component pair kDtwWide3RunPair[ks][i] of the half, template part kDtwWide3RunPart[ks][i]
+#ifndef RP_W3_RUN
+#define RP_W3_RUN 1
+#endif
+__host__ __device__ constexpr bool dtw_mfma_wide3_run(int K) { return RP_W3_RUN && K == 16; }
+constexpr int kDtwWide3RunPair[6][4] = {{0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 2, 3}, {0, 1, 2, 3}, {2, 3, 2, 3}, {2, 3, 2, 3}};
+constexpr int kDtwWide3RunPart[6][4] = {{0, 0, 0, 0}, {1, 1, 0, 0}, {1, 1, 0, 0}, {2, 2, 1, 1}, {2, 2, 0, 0}, {1, 1, 0, 0}};
 // Tiles a wave of the matrix-core DTW kernels takes by its own index before it turns to the chunk's atomic counter: every whole round
 // of a launch of at most three rounds (live-stream calls, BASELINE config C2 -- the waves start together and would ask for their
 // tickets together; the counter then hands out what is left), the first round of longer launches (the waves drift apart by themselves

@@ -112,6 +112,28 @@ def test_avg_gate_skip_wide_frames(ra, K):
         assert n_f.sum() > S // 4 and np.array_equal(n_g, n_f) and det_g.tobytes() == det_f.tobytes()
 
 
+@pytest.mark.parametrize("K,T,kernel", [(16, 8, "dtw_mfma_wide_kernel"), (13, 6, "dtw_mfma_wide_kernel"), (5, 4, "dtw_mfma_kernel"), (5, 11, "dtw_mfma_kernel")])
+def test_avg_gate_skip_through_the_three_part_matrix_kernels_list_mode(ra, K, T, kernel):
+    """Same-length template sets in the default arithmetic: the windows that pass the gate are a LIST for dtw_mfma_wide3_kernel (mfcc_size
+    13 / 16, chunks of up to four) and for both shapes of dtw_mfma_kernel (a chunk of four; eight + three) -- the detections are those of
+    full scoring bit for bit, and the library reports the three-part products."""
+    S, N, L = 200, 480 * 50, 40
+    templates = orc.synth_templates(SEED + K, T, L, K)
+    avg = np.mean(templates, axis=0, dtype=np.float32)
+    gated, full = ra.BatchContext(0), ra.BatchContext(0, full_scores=True)
+    pcm = gated.synth_pcm(SEED, 0, S, N)
+    tg, tf = ra.Templates(gated, templates, avg=avg), ra.Templates(full, templates, avg=avg)
+    _, av, ag = gated.dtw_scores(gated.mfcc(pcm, K), tg, with_avg=True)
+    cfg = ra.DetectorConfig()
+    cfg.min_scores = 2
+    cfg.avg_threshold, cfg.threshold = float(np.quantile(av, 0.6)), float(np.quantile(ag, 0.7))
+    gated.dtw_kernels()
+    det_g, n_g = gated.batch_detect(pcm, tg, cfg, max_det=6)
+    assert kernel in gated.dtw_kernels() and gated.last_dtw_products == ["bf16x3"]
+    det_f, n_f = full.batch_detect(pcm, tf, cfg, max_det=6)
+    assert n_f.sum() > S // 4 and np.array_equal(n_g, n_f) and det_g.tobytes() == det_f.tobytes()
+
+
 @pytest.mark.parametrize("avg_threshold,chunks_per_call", [(0.2, 1), (0.5, 1), (0.5, 4), (0.62, 7)])
 def test_avg_gate_skip_in_live_stream_batches(ra, avg_threshold, chunks_per_call):
     """rp_stream_batch_process skips the sample templates of gated windows too: fed chunk by chunk it reports the detections

@@ -21,7 +21,8 @@ What the one JSON line carries besides the contract's fields (round 4):
                      profiles/valu_rate_table.json), matrix flops, HBM bytes, LDS cycles -- each <= 1 by construction; the
                      reference-shaped flop rate of SURVEY 8d sits beside it as ref_flop_rate_vs_vector_peak
   vector_only        the same step with the cosine products on the vector pipe (RP_DTW_MFMA=0), 2 steps
-  extra_configs      short timed runs of BASELINE configs C2, C5 (bf16) and C5 (f32), of the wakeword-model detector and of the filter front-end in the same process
+  extra_configs      short timed runs of BASELINE configs C2, C5 (bf16) and C5 (f32), of the wakeword-model detector, of the filter front-end, of one GPU's
+                     share of C4, of mfcc_size 16 and of five templates of unequal length in the same process
   h2d_included       a bounded sample of the same path with the PCM starting in pinned HOST memory (see --ingest)
   cpu_baseline       the oracle on all granted host cores, and on one thread (one_thread)
   config.*           host CPU model, build id of the library, and for N > 1 the world size RCCL reports and every rank's device UUID
@@ -797,10 +798,18 @@ def bench_dtw(env):
             extras["C4_share"] = extra_c4_share(env, K, N)
         except Exception as e:
             extras["C4_share"] = {"error": repr(e)}
+        # SURVEY 8d's second frame size and the shape of the reference's own wakeword files, default arithmetic
+        for name, S_, lens_, K_, what in (
+                ("K16", 8192, [100] * 8, 16, "8192 synthetic streams x 8 templates of 100 frames, mfcc_size 16 (the wakeword-model front-end's frame size)"),
+                ("ragged5", 65536, [108, 96, 90, 93, 102], K, "65536 synthetic streams x 5 templates of 108/96/90/93/102 frames (the shape of the reference's oye_casa_g.rpw)")):
+            try:
+                extras[name] = extra_dtw_shape(env, S_, lens_, K_, N, what)
+            except Exception as e:
+                extras[name] = {"error": repr(e)}
         out["extra_configs"] = extras
         # the other BASELINE configs where the driver's record keeps them: scalars first, then the same numbers as one block
         oc = {}
-        for name in ("C2", "C4_share", "C5_bf16", "C5_f32"):
+        for name in ("C2", "C4_share", "C5_bf16", "C5_f32", "K16", "ragged5"):
             e = extras.get(name, {})
             if "value" in e:
                 oc[name] = {"value": e["value"], "unit": e["unit"], "ms_per_step": e["ms_per_step"], "frac": e["roofline"]["frac"], "bound": e["roofline"]["bound"]}
@@ -871,6 +880,24 @@ def extra_c4_share(env, K, N):
            "roofline": {"bound": r["bound"], "kernel": r["kernel"], "frac": r["frac"], "pipes": r["pipes"]},
            "path_hbm_frac": S4 * c4.n_win * 10 / dt * (640 + 4 * (T4 + 2)) / HBM_PEAK}
     del c4
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_dtw_shape(env, S, lens, K, N, what):
+    """One more shape of the same path in the default arithmetic, short: (S streams, templates of `lens` frames, mfcc_size K)."""
+    torch = env.torch
+    c = DtwCase(env, S, lens, K, N, first_stream=0)
+    dt = c.time_steps(2, 10)
+    k = c.kernel_times(3)
+    ran = c.ctx.dtw_kernels()
+    r = dtw_kernel_model(env, S, c.n_win, lens, K, k["dtw"][0] * 1e-3, None, ran, list(c.ctx.last_dtw_products))
+    res = {"workload": what, "value": S * c.n_win * 10 / dt, "unit": "scorings/s", "steps": 10, "warmup": 2, "ms_per_step": dt / 10 * 1e3, "dtype": DTYPE_DTW,
+           "kernels_ms": {kk: round(v[0], 4) for kk, v in k.items()}, "dtw_kernels_launched": ", ".join(ran), "products": list(c.ctx.last_dtw_products),
+           "roofline": {"bound": r["bound"], "kernel": r["kernel"], "frac": r["frac"], "pipes": r["pipes"]}}
+    if "valu_plus_matrix_issue_frac" in r:
+        res["roofline"]["valu_plus_matrix_issue_frac"] = r["valu_plus_matrix_issue_frac"]
+    del c
     torch.cuda.empty_cache()
     return res
 

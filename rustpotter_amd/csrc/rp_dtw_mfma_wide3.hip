@@ -17,7 +17,9 @@
 //     pieces (w3_run_piece below; −85 vector instructions per 16-column block, measured 6.43-6.48 ms against 6.44-6.57: the matrix pipe is as
 //     loaded as the vector pipe here, fewer copies buy almost nothing).
 // Frames are read from global memory (the caller leaves slack behind the last stream's frames, launch_dtw `padded_rows`), as in the two-part
-// kernel.  Two waves per SIMD (eight per workgroup): 233 / 240 registers, nothing spilled.
+// kernel.  Two waves per SIMD (eight per workgroup): 208 / 215 registers, nothing spilled.  mfcc_size 16 double-buffers the window side's
+// operand and issues half of a column's matrix instructions between the pieces of the next frame's preparation (SPREAD, see w3_issue_table:
+// 6.27-6.29 ms against 6.39-6.41 at 8 192 streams x 8 templates).
 // BUILD: the 16-column block (192 matrix instructions, ~2 700 instructions) is a `#pragma unroll` loop far beyond the compiler's default budget for
 // pragma-requested full unrolling; this file is compiled with -mllvm -pragma-unroll-threshold=200000 (Makefile FILE_FLAGS_rp_dtw_mfma_wide3.hip).
 // Without it the loop stays rolled, the row-slot -> accumulator mapping becomes a run-time index and the build shows 256 registers with
@@ -63,13 +65,31 @@ __host__ __device__ constexpr int w3_last_use(int u, int g) {
 }
 
 // band cell after which k-step ks of tile g goes out in column phase u: tiles in the order they come free, k-steps in order, at most one per
-// cell until the column's last cell takes what is left (twelve instructions, ten cells)
+// cell until the column's last cell takes what is left (twelve instructions, ten cells).
+// SPREAD (the window side's operand double-buffered: mfcc_size 16): in every column one tile is read by the column's last or last but one
+// cell, so half of the column's matrix instructions -- one dependent chain of six -- would go out in one burst behind the last cell and hold
+// the wave for five instructions' pipe time.  With a second operand buffer the frame preparation of column c + 2 may run WHILE column
+// c + 1's instructions are still being issued: issue points 2W .. 2W + tail - 1 lie behind the pieces of that preparation (its head, then
+// one component pair each), and each tile's chain goes out one instruction per issue point from the cell that frees the tile.
+#ifndef RP_W3_SPREAD
+#define RP_W3_SPREAD 1
+#endif
 struct W3IssueTable { int at[kW3Slots][kW3Tiles][kW3KS]; };
 template <int W>
-__host__ __device__ constexpr W3IssueTable w3_issue_table() {
+__host__ __device__ constexpr W3IssueTable w3_issue_table(int tail) {
     W3IssueTable t{};
     for (int u = 0; u < kW3Slots; ++u) {
         const int lu0 = w3_last_use<W>(u, 0), lu1 = w3_last_use<W>(u, 1);
+        if (tail > 0) {
+            for (int g = 0; g < kW3Tiles; ++g)
+                for (int ks = 0; ks < kW3KS; ++ks) {
+                    int at = (g == 0 ? lu0 : lu1) + ks;
+                    if (at < 0) at = 0;
+                    if (at > 2 * W + tail - 1) at = 2 * W + tail - 1;
+                    t.at[u][g][ks] = at;
+                }
+            continue;
+        }
         const int first = lu1 < lu0 ? 1 : 0, second = 1 - first;
         int prev = -1;
         for (int i = 0; i < 2; ++i) {
@@ -102,7 +122,9 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
     constexpr int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, ODD = CHM % 2;
     constexpr bool RUN = dtw_mfma_wide3_run(K);   // mfcc_size 16: the B operand as one run of twelve registers
     constexpr int kRowBytes = kDtwWide3RowBytes;
-    constexpr W3IssueTable kIssue = w3_issue_table<W>();
+    constexpr bool SPREAD = RUN && RP_W3_SPREAD;  // two operand buffers, the matrix instructions spread into the frame preparation
+    constexpr int TAIL = SPREAD ? 1 + NPAIR : 0;  // issue points behind the cells: the preparation's head, then one per component pair
+    constexpr W3IssueTable kIssue = w3_issue_table<W>(TAIL);
     static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 16 row slots");
     static_assert(6 * NPAIR + 3 * ODD + (ODD ? 1 : 0) <= 4 * KS, "the half's product registers must fit six k-steps");
     size_t total_entries = n_streams * n_win;
@@ -197,40 +219,48 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
                 Areg[g][ks] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)(r - 1) * kRowBytes + ks * 128);
         }
         v16f acc[NTILE];
-        u32x12 brun;        // (RUN) the same, twelve registers
-        u32x4 bop[1][KS];   // ONE buffer: the operand of column c + 2 is built after the last matrix instruction of column c + 1 is out (end of step c)
+        u32x12 brun[2];     // (RUN) the same, twelve registers; SPREAD: column c's operand in brun[c & 1]
+        u32x4 bop[1][KS];   // (!RUN) ONE buffer: the operand of column c + 2 is built after the last matrix instruction of column c + 1 is out (end of step c)
         float chk = 0.f;
+        float pd_[CHM], pinv_ = 0.f;   // the frame being prepared: centred components, 1 / norm
+        unsigned pv_[4 * KS];          // (!RUN) its product registers
 
 // the frame in fl[] (column cc) -> B operand bop[par]: centre, scale to unit length (the two halves' squared norms meet through
 // v_permlane32_swap; zero frame -> zero vector -> cost 1, comparator.rs:43-47), split in three bf16 parts, pack
-#define RP_PREP(par)                                                                                                          \
+#define RP_PREP_HEAD()                                                                                                        \
     do {                                                                                                                      \
-        float d_[CHM], own_ = 0.f;                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < CHM; ++j) { d_[j] = fl[j] - mu[j]; own_ = fmaf(d_[j], d_[j], own_); }            \
+        float own_ = 0.f;                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < CHM; ++j) { pd_[j] = fl[j] - mu[j]; own_ = fmaf(pd_[j], pd_[j], own_); }         \
         const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(own_), __float_as_uint(own_), false, false);        \
         const float bb_ = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);                                                  \
-        const float inv_ = bb_ > 0.f ? __builtin_amdgcn_rsqf(bb_) : 0.f;                                                      \
-        chk = fmaxf(fmaxf(chk, inv_), bb_); /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */            \
-        unsigned v_[4 * KS];                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < 4 * KS; ++i) v_[i] = 0u;                                                        \
-        _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) {                                                                   \
-            const float ua_ = d_[2 * j] * inv_, ub_ = d_[2 * j + 1] * inv_;                                                   \
-            const float ra_ = ua_ - top16(ua_), rb_ = ub_ - top16(ub_);                                                       \
-            const unsigned p0_ = hi2(ub_, ua_), p1_ = hi2(rb_, ra_), p2_ = hi2(rb_ - top16(rb_), ra_ - top16(ra_));           \
-            if (RUN) {   /* pairs 0, 1 from the front of the run, pairs 2, 3 from its back */                                  \
-                brun[4 + j] = p0_; brun[j < 2 ? 2 + j : 6 + j] = p1_; brun[j < 2 ? j : 8 + j] = p2_;           \
-            } else {                                                                                                          \
-                v_[6 * j] = p0_; v_[6 * j + 1] = p1_; v_[6 * j + 2] = p2_; v_[6 * j + 3] = p0_; v_[6 * j + 4] = p1_; v_[6 * j + 5] = p0_; \
-            }                                                                                                                 \
+        pinv_ = bb_ > 0.f ? __builtin_amdgcn_rsqf(bb_) : 0.f;                                                                 \
+        chk = fmaxf(fmaxf(chk, pinv_), bb_); /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */           \
+    } while (0)
+// component pair j of the prepared frame -> its three registers of brun[par] (RUN) / its six slots of pv_[] (!RUN)
+#define RP_PREP_PAIR(par, j)                                                                                                  \
+    do {                                                                                                                      \
+        const float ua_ = pd_[2 * (j)] * pinv_, ub_ = pd_[2 * (j) + 1] * pinv_;                                               \
+        const float ra_ = ua_ - top16(ua_), rb_ = ub_ - top16(ub_);                                                           \
+        const unsigned p0_ = hi2(ub_, ua_), p1_ = hi2(rb_, ra_), p2_ = hi2(rb_ - top16(rb_), ra_ - top16(ra_));               \
+        if (RUN) {   /* pairs 0, 1 from the front of the run, pairs 2, 3 from its back */                                      \
+            brun[par][4 + (j)] = p0_; brun[par][(j) < 2 ? 2 + (j) : 6 + (j)] = p1_; brun[par][(j) < 2 ? (j) : 8 + (j)] = p2_;  \
+        } else {                                                                                                              \
+            pv_[6 * (j)] = p0_; pv_[6 * (j) + 1] = p1_; pv_[6 * (j) + 2] = p2_; pv_[6 * (j) + 3] = p0_; pv_[6 * (j) + 4] = p1_; pv_[6 * (j) + 5] = p0_; \
         }                                                                                                                     \
+    } while (0)
+#define RP_PREP(par)                                                                                                          \
+    do {                                                                                                                      \
+        RP_PREP_HEAD();                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4 * KS; ++i) pv_[i] = 0u;                                                       \
+        _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) RP_PREP_PAIR(par, j);                                               \
         if (ODD) {                                                                                                            \
-            const float us_ = d_[CHM - 1] * inv_, rs_ = us_ - top16(us_), x2_ = rs_ - top16(rs_);                             \
-            v_[6 * NPAIR] = hi2(rs_, us_); v_[6 * NPAIR + 1] = hi2(us_, x2_); v_[6 * NPAIR + 2] = hi2(us_, rs_);              \
-            v_[6 * NPAIR + 3] = h ? 0x00003f80u : 0u;   /* the constant 1.0 of 1 - a.x (half 1) */                            \
+            const float us_ = pd_[CHM - 1] * pinv_, rs_ = us_ - top16(us_), x2_ = rs_ - top16(rs_);                           \
+            pv_[6 * NPAIR] = hi2(rs_, us_); pv_[6 * NPAIR + 1] = hi2(us_, x2_); pv_[6 * NPAIR + 2] = hi2(us_, rs_);           \
+            pv_[6 * NPAIR + 3] = h ? 0x00003f80u : 0u;   /* the constant 1.0 of 1 - a.x (half 1) */                           \
         }                                                                                                                     \
         if (!RUN)                                                                                                             \
             _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                                 \
-                bop[par][ks] = (u32x4){v_[4 * ks], v_[4 * ks + 1], v_[4 * ks + 2], v_[4 * ks + 3]};                           \
+                bop[0][ks] = (u32x4){pv_[4 * ks], pv_[4 * ks + 1], pv_[4 * ks + 2], pv_[4 * ks + 3]};                         \
     } while (0)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 16)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
@@ -245,14 +275,20 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
     do {                                                                                                                      \
         constexpr float c1_ = ODD ? 0.f : 1.f;   /* an even component count has no product slot for the 1 of 1 - a.x: it starts the sum */ \
         const v16f in16_ = {c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_};                   \
-        const u32x4 b4_ = RUN ? w3_run_piece(brun, ks) : bop[par][ks];                                                        \
+        const u32x4 b4_ = RUN ? w3_run_piece(brun[par], ks) : bop[0][ks];                                                        \
         if ((ks) == 0) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][0]), __builtin_bit_cast(bf16x8, b4_), in16_, 0, 0, 0); \
         else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][ks]), __builtin_bit_cast(bf16x8, b4_), acc[g], 0, 0, 0); \
     } while (0)
 // column c (c = 1 + u mod 16): the B operand of column c + 2 is built first (its frame was requested one column earlier), then the
 // frame of column c + 3 is requested, then the cells; a tile's k-steps for column c + 1 go out after the last cell that reads the tile
+#define RP_ISSUE(at_)                                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                                     \
+            if (kIssue.at[u][g][ks] == (at_)) RP_MFMA1(g, ks, MPAR);
 #define RP_STEP(GUARD)                                                                                                        \
     do {                                                                                                                      \
+        /* operand buffers (SPREAD; c0 is odd): column c + 1's in brun[(c + 1) & 1] = brun[u & 1], column c + 2's goes to the other */ \
+        const int MPAR = SPREAD ? (u & 1) : 0, PPAR = SPREAD ? ((u + 1) & 1) : 0;                                              \
         RP_AREF(c + 1, (u + 1) % NS, GUARD)                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
         v2f up = (v2f){RP_INF, RP_INF};                                                                                       \
@@ -266,24 +302,33 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
             if (GUARD) v = (c - W + 1 + q >= 1) ? v : (v2f){RP_INF, RP_INF};                                                  \
             Q[q] = v;                                                                                                         \
             up = v;                                                                                                           \
-            _Pragma("unroll") for (int g = 0; g < NTILE; ++g)                                                                 \
-                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                             \
-                    if (kIssue.at[u][g][ks] == q) RP_MFMA1(g, ks, 0);                                                         \
+            RP_ISSUE(q)                                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
-        RP_PREP(0);        /* column c + 2, from the frame requested one column ago */                                        \
+        if (SPREAD) {      /* column c + 2's operand, piece by piece, the rest of column c + 1's matrix instructions between the pieces */ \
+            RP_PREP_HEAD();                                                                                                   \
+            RP_ISSUE(B)                                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
+            _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) {                                                               \
+                RP_PREP_PAIR(PPAR, j);                                                                                        \
+                RP_ISSUE(B + 1 + j)                                                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                            \
+            }                                                                                                                 \
+        } else {                                                                                                              \
+            RP_PREP(PPAR);        /* column c + 2, from the frame requested one column ago */                                 \
+        }                                                                                                                     \
         RP_LOADF(c + 3);                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
     } while (0)
 
         RP_AREF(1, 0, true)
         RP_LOADF(1);
-        RP_PREP(0);
+        RP_PREP(SPREAD ? 1 : 0);   // column 1's operand (SPREAD: column c's lives in brun[c & 1])
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { RP_MFMA1(0, ks, 0); RP_MFMA1(1, ks, 0); }
+        for (int ks = 0; ks < KS; ++ks) { RP_MFMA1(0, ks, SPREAD ? 1 : 0); RP_MFMA1(1, ks, SPREAD ? 1 : 0); }
         RP_LOADF(2);
         __builtin_amdgcn_sched_barrier(0);
-        RP_PREP(0);
+        RP_PREP(0);                // column 2's
         RP_LOADF(3);  // step c builds the B operand of column c + 2 from fl[] at its end: fl[] holds column 3 for step 1
         __builtin_amdgcn_sched_barrier(0);
         int c0 = 1;
@@ -317,9 +362,12 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
         }
 #undef RP_ABANDON_CHECK
 #undef RP_STEP
+#undef RP_ISSUE
 #undef RP_MFMA1
 #undef RP_AREF
 #undef RP_PREP
+#undef RP_PREP_PAIR
+#undef RP_PREP_HEAD
 #undef RP_LOADF
 
         if (valid) {

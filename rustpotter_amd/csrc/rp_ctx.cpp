@@ -424,7 +424,9 @@ static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c
 // slot 4] x 8 bf16.  Lane half kh owns components kh * CHM .. kh * CHM + CHM - 1 (zero beyond K); a = -(unit row) = a0 + a1 + a2 exactly.  The
 // 24 registers of a half: per component pair (p, q) (a0p, a0q) x 3, (a1p, a1q) x 2, (a2p, a2q) against the window side's (x0, x0), (x1, x1),
 // (x2, x2), (x0, x0), (x1, x1), (x0, x0); an odd last component s: (a0s, a0s), (a0s, a1s), (a1s, a2s) against (x0s, x1s), (x2s, x0s),
-// (x1s, x0s), then (1.0, 0) in half 1: the 1 of 1 - a.x (an even count starts the sum at 1 instead).
+// (x1s, x0s), then (1.0, 0) in half 1: the 1 of 1 - a.x (an even count starts the sum at 1 instead).  mfcc_size 16: the kernel reads its twelve
+// different window-side registers as one run in overlapping pieces, and slot i of k-step ks holds part kDtwWide3RunPart[ks][i] of pair
+// kDtwWide3RunPair[ks][i] (rp_kernels.h) -- the same six products per component in another order.
 static void append_mfma_wide3_image(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad, int K) {
     const int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, KS = kDtwWide3KSteps, row_bytes = kDtwWide3RowBytes;
     const size_t base = img.size();
@@ -445,12 +447,13 @@ static void append_mfma_wide3_image(std::vector<uint16_t> &img, const DtwChunk &
                             parts(2 * kDtwWide3RunPair[ks][i], a); parts(2 * kDtwWide3RunPair[ks][i] + 1, b);
                             v[2 * (4 * ks + i)] = a[kDtwWide3RunPart[ks][i]]; v[2 * (4 * ks + i) + 1] = b[kDtwWide3RunPart[ks][i]];
                         }
-                } else
-                for (int j = 0; j < NPAIR; ++j) {
-                    uint16_t a[3], b[3];
-                    parts(2 * j, a); parts(2 * j + 1, b);
-                    const int which[6] = {0, 0, 0, 1, 1, 2};
-                    for (int i = 0; i < 6; ++i) { v[2 * (6 * j + i)] = a[which[i]]; v[2 * (6 * j + i) + 1] = b[which[i]]; }
+                } else {
+                    for (int j = 0; j < NPAIR; ++j) {
+                        uint16_t a[3], b[3];
+                        parts(2 * j, a); parts(2 * j + 1, b);
+                        const int which[6] = {0, 0, 0, 1, 1, 2};
+                        for (int i = 0; i < 6; ++i) { v[2 * (6 * j + i)] = a[which[i]]; v[2 * (6 * j + i) + 1] = b[which[i]]; }
+                    }
                 }
                 if (CHM % 2) {
                     uint16_t s3[3];

@@ -40,7 +40,7 @@ typedef unsigned u32x12 __attribute__((ext_vector_type(12)));
 // mfcc_size 16 (four component pairs per lane half, no odd component): the B operand's 24 register slots hold only 12 different registers
 // (per pair P0 = (x0, x0) three times, P1 twice, P2 once).  They are kept as ONE run, [P2a P2b P1a P1b P0a P0b P0c P0d P1c P1d P2c P2d], and
 // the six k-steps read overlapping four-register pieces of it at offsets 0, 2, 4, 4, 6, 8 -- no copies; the A image pairs every slot with
-// the template part that completes its product (kW3RunPart, the same table in append_mfma_wide3_image, rp_ctx.cpp).
+// the template part that completes its product (kDtwWide3RunPair / kDtwWide3RunPart, rp_kernels.h: the table append_mfma_wide3_image follows).
 __device__ __forceinline__ u32x4 w3_run_piece(const u32x12 &r, int ks) {
     switch (ks) {
     case 0: return __builtin_shufflevector(r, r, 0, 1, 2, 3);

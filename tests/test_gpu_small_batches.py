@@ -91,3 +91,37 @@ np.save(sys.argv[1], scores)
     for s in (0, S // 2, S - 1):
         ref_s, _ = orc.score_stream(orc.mfcc_stream(orc.synth_pcm(SEED, s, 480 * 50), 5), templates)
         assert np.all(np.abs(outs[0][s] - ref_s) <= 1e-5 * np.abs(ref_s))
+
+
+def test_eight_and_twelve_wave_builds_of_the_three_part_kernel_give_the_same_bits(tmp_path):
+    """dtw_mfma_kernel<5, 8 | 12, false, 8, true>: two builds of one arithmetic (220 registers, two waves per SIMD, for small batches; 168
+    registers, three per SIMD, for large ones -- the launcher picks by the number of tiles).  RP_MFMA3_WAVES pins one of them for a process:
+    the scores of the same batch must not differ by a bit (child processes: the variable is read once)."""
+    import subprocess
+    import sys
+    child = r"""
+import hashlib, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import rustpotter_amd as ra
+from oracle import rp_oracle as orc
+SEED = 0x5EED000000000001
+ctx = ra.BatchContext(device=0, host_pointers=True)
+templates = orc.synth_templates(SEED + 9, 8, 60, 5)
+pcm = ctx.synth_pcm(SEED, 500, 96, 480 * 70)
+cfg = ra.DetectorConfig(); cfg.avg_threshold = 0.0
+ctx.dtw_kernels()
+_, _, scores, agg = ctx.batch_detect(pcm, ra.Templates(ctx, templates), cfg, want_scores=True)
+assert ctx.dtw_kernels() == ["dtw_mfma_kernel"] and ctx.last_dtw_products == ["bf16x3"]
+print("sha", hashlib.sha256(scores.tobytes() + agg.tobytes()).hexdigest(), scores.shape)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "waves_child.py"
+    script.write_text(child)
+    out = []
+    for nw in ("8", "12"):
+        e = dict(os.environ)
+        e["RP_MFMA3_WAVES"] = nw
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("sha")][-1])
+    assert out[0] == out[1], out

@@ -113,8 +113,16 @@ __host__ __device__ constexpr int mfma_last_use(int u, int g) {
 #define RP_TRACE(slot)
 #endif
 
+#ifndef RP_MFMA_WAVES_PER_EU   // experiment builds: cap every instantiation at the registers of N waves per SIMD (3: 168), e.g. to leave room
+#define RP_MFMA_WAVES_PER_EU 0 // for another kernel's waves beside an eight-wave workgroup
+#endif
+#if RP_MFMA_WAVES_PER_EU
+#define RP_MFMA_OCC __attribute__((amdgpu_waves_per_eu(RP_MFMA_WAVES_PER_EU, RP_MFMA_WAVES_PER_EU)))
+#else
+#define RP_MFMA_OCC
+#endif
 template <int W, int NW, bool GX, int NT, bool P3>
-__global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
+RP_MFMA_OCC __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
     const float *__restrict__ mfcc, size_t frame_pitch, size_t n_frames_total, size_t total_tiles, unsigned n_chunks, int chunk_base,
     size_t first_win, size_t n_win, size_t out_win_pitch, const DtwChunk *__restrict__ chunks, const uint4 *__restrict__ aimg, int T,
     float score_ref, float *__restrict__ scores, float *__restrict__ avg, size_t n_streams, int max_len, const uint32_t *__restrict__ list,

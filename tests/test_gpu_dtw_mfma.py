@@ -214,6 +214,32 @@ def test_long_templates_in_a_chunk_of_four_keep_the_register_kernel(ra, ctx):
         assert rel_close(scores[1, w, 3], orc.score_window(mf[1][w:w + L], templates[3]))
 
 
+@pytest.mark.parametrize("K,T,L,matrix", [(5, 8, 179, True), (5, 8, 180, False),      # eight slots, eight waves: (L + 16) x 512 + 8 stages <= 160 KB
+                                         (5, 4, 147, True), (5, 4, 148, False),      # four slots, twelve waves
+                                         (16, 4, 180, True), (16, 4, 181, False)])   # dtw_mfma_wide3_kernel: (L + 16) x 832 <= 160 KB
+def test_the_longest_templates_the_three_part_images_hold(ra, K, T, L, matrix):
+    """RP_ARITH_F32_MATRIX at the edge of the CU's LDS: the longest template each shape's A image (and frame stages) still fits, and one frame
+    more -- the set then keeps the register kernels.  Scores against the oracle at a few windows either way."""
+    ctx = ra.BatchContext(device=0, host_pointers=True)
+    S, N = 2, 480 * (L // 3 + 14)
+    templates = orc.synth_templates(SEED + L, T, L, K)
+    tm = ra.Templates(ctx, templates)
+    pcm = np.stack([orc.synth_pcm(SEED, 900 + s, N) for s in range(S)])
+    cfg = ra.DetectorConfig()
+    cfg.avg_threshold = 0.0
+    ctx.dtw_kernels()
+    _, _, scores, _ = ctx.batch_detect(pcm, tm, cfg, want_scores=True)
+    ran = ctx.dtw_kernels()
+    assert (ran != ["register kernels"]) == matrix and ctx.last_dtw_products == (["bf16x3"] if matrix else []), (ran, ctx.last_dtw_products)
+    n_win = scores.shape[1]
+    assert n_win >= 20
+    for s in range(S):
+        mf = orc.mfcc_stream(pcm[s], K)
+        for w in (0, 1, n_win // 2, n_win - 1):
+            for t in (0, T - 1):
+                assert rel_close(scores[s, w, t], orc.score_window(mf[w:w + L], templates[t]))
+
+
 def test_many_streams_equal_their_single_stream_scores(ra, ctx):
     """Size-independent property at a size the oracle does not reach: 1 500 streams x 77 windows x 8 templates in one launch (every
     wave takes several tiles, most tiles straddle two streams) give, stream by stream, the bits of that stream scored alone."""

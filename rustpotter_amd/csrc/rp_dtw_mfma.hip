@@ -33,7 +33,7 @@
 //     described above, 22-bit products.
 //   * Two shapes (NT): eight template slots as described (chunks of 5..8 templates, band 3..5), or four (chunks of 3..4, band 5): a
 //     tile is then 8 row slots x 4 templates, 16 circular row slots = 2 tiles, one template pair per lane, columns unrolled 16 at a time, twelve
-//     waves per workgroup in both arithmetics.  mfcc_size 13 / 16 have their own K axis: rp_dtw_mfma_wide3.hip / rp_dtw_mfma_wide.hip.
+//     waves per workgroup (eight where twelve waves' frame stages no longer fit beside the A image) in both arithmetics.  mfcc_size 13 / 16 have their own K axis: rp_dtw_mfma_wide3.hip / rp_dtw_mfma_wide.hip.
 //   * BUILD: the 12 / 16-column blocks are `#pragma unroll` loops whose bodies exceed the compiler's budget for pragma-requested full
 //     unrolling; this file is compiled with -mllvm -pragma-unroll-threshold=200000 (Makefile FILE_FLAGS_rp_dtw_mfma.hip).  Without it the
 //     three-part four-slot build keeps a rolled loop, indexes its accumulators at run time and spills 13 709 values.
@@ -560,9 +560,8 @@ bool dtw_mfma_supported(const TemplatesDev &t, int band, size_t n_win, bool from
     if (!from_global && n_win < (size_t)kMWin) return false;            // a staged tile holds at most two stream segments
     // the first 12 (16) columns are one guarded block
     if (slots == 8 ? t.mfma_min_len < mfma_slots(8) : t.mfma_min_len4 < mfma_slots(4)) return false;
-    // long templates: the A image leaves room for eight waves' frame stages only.  The four-slot form is built for twelve waves -- longer
-    // chunks of 3..4 keep the tc-4 register kernel
-    return dtw_mfma_lds_bytes(t.max_len, slots == 8 ? 8 : 12, p3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes) <= 160 * 1024;
+    // long templates: the A image leaves room for eight waves' frame stages only
+    return dtw_mfma_lds_bytes(t.max_len, 8, p3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes) <= 160 * 1024;
 }
 
 hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev &t, int band, int slots, int chunk_base, int n_chunks, const float *mfcc, size_t S,
@@ -619,8 +618,8 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
         else { if (nw == 12) RP_LAUNCH_MFMA(WW, 12, false, NT); else RP_LAUNCH_MFMA(WW, 8, false, NT); }                            \
     } while (0)
     if (slots == 4) {
-        if (band != 5 || nw != 12) return hipErrorNotSupported;
-        if (from_global) RP_LAUNCH_MFMA(5, 12, true, 4); else RP_LAUNCH_MFMA(5, 12, false, 4);
+        if (band != 5) return hipErrorNotSupported;
+        RP_LAUNCH_MFMA_W(5, 4);
     } else {
         switch (band) {
         case 3: RP_LAUNCH_MFMA_W(3, 8); break;

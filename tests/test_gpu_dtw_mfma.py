@@ -199,9 +199,10 @@ def test_templates_too_long_for_the_three_part_image_keep_the_register_kernels(r
         assert rel_close(scores[1, w, 2], orc.score_window(mf[1][w:w + L], templates[2]))
 
 
-def test_long_templates_in_a_chunk_of_four_keep_the_register_kernel(ra, ctx):
-    """250-frame templates, four of them: twelve waves' frame stages do not fit beside the A image and the four-slot form exists for
-    twelve waves only -- the chunk stays with the tc-4 register kernel (the switch changes nothing), scores against the oracle."""
+def test_long_templates_in_a_chunk_of_four(ra, ctx):
+    """250-frame templates, four of them: twelve waves' frame stages do not fit beside the A image -- the four-slot form falls back to eight
+    waves per workgroup in the two-part arithmetic (68 KB of image); the three-part image (136 KB) leaves no room for the stages and the
+    chunk stays with the tc-4 register kernel (the switch changes nothing).  Scores against the oracle."""
     K, L, T = 5, 250, 4
     templates = orc.synth_templates(SEED + 23, T, L, K)
     mf = _streams(2, L + 33, K, first=95)
@@ -209,13 +210,13 @@ def test_long_templates_in_a_chunk_of_four_keep_the_register_kernel(ra, ctx):
     scores, _, _ = ctx.dtw_scores(mf, tm)
     with _registers_only():
         reg, _, _ = ctx.dtw_scores(mf, tm)
-    assert np.array_equal(scores, reg)
+    assert rel_close(scores, reg, 2e-6) and np.array_equal(scores, reg) == (not _fast(ctx))
     for w in (0, 17, 33):
         assert rel_close(scores[1, w, 3], orc.score_window(mf[1][w:w + L], templates[3]))
 
 
 @pytest.mark.parametrize("K,T,L,matrix", [(5, 8, 179, True), (5, 8, 180, False),      # eight slots, eight waves: (L + 16) x 512 + 8 stages <= 160 KB
-                                         (5, 4, 147, True), (5, 4, 148, False),      # four slots, twelve waves
+                                         (5, 4, 147, True), (5, 4, 148, True), (5, 4, 179, True), (5, 4, 180, False),   # four slots: twelve waves up to 147 frames, then eight
                                          (16, 4, 180, True), (16, 4, 181, False)])   # dtw_mfma_wide3_kernel: (L + 16) x 832 <= 160 KB
 def test_the_longest_templates_the_three_part_images_hold(ra, K, T, L, matrix):
     """RP_ARITH_F32_MATRIX at the edge of the CU's LDS: the longest template each shape's A image (and frame stages) still fits, and one frame

@@ -43,11 +43,24 @@ def main():
         i = args.index("--min-mfma"); min_mfma = int(args[i + 1]); del args[i:i + 2]
     src, want = args[0], args[1]
     table = json.load(open(os.path.join(ROOT, "profiles", "valu_rate_table.json")))
-    with tempfile.TemporaryDirectory() as d:
-        asm = os.path.join(d, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + file_flags(src) + flags + ["--cuda-device-only", "-S", "-o", asm,
-                               src if os.path.isabs(src) or os.path.exists(src) else os.path.join(ROOT, "rustpotter_amd", "csrc", src)], stderr=subprocess.DEVNULL)
-        lines = open(asm).read().splitlines()
+    path = src if os.path.isabs(src) or os.path.exists(src) else os.path.join(ROOT, "rustpotter_amd", "csrc", src)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950"] + FLAGS + file_flags(src) + flags + ["--cuda-device-only", "-S"]
+    # one compilation per (sources, command): the assembly of a file is kept under the temp directory (tests price several kernels of one file)
+    import hashlib
+    h = hashlib.sha256(" ".join(cmd).encode())
+    csrc = os.path.join(ROOT, "rustpotter_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(path, "rb").read())
+    cache = os.path.join(tempfile.gettempdir(), "rp_isa_mix_cache")
+    os.makedirs(cache, exist_ok=True)
+    asm = os.path.join(cache, h.hexdigest()[:32] + ".s")
+    if not os.path.exists(asm):
+        tmp = asm + ".%d.tmp" % os.getpid()
+        subprocess.check_call(cmd + ["-o", tmp, path], stderr=subprocess.DEVNULL)
+        os.replace(tmp, asm)
+    lines = open(asm).read().splitlines()
     # kernel bodies: "<mangled>:" ... "s_endpgm" / ".Lfunc_end"
     start = None
     for i, l in enumerate(lines):

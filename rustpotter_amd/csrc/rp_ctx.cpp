@@ -422,48 +422,30 @@ static void append_mfma_wide_image(std::vector<uint16_t> &img, const DtwChunk &c
 
 // dtw_mfma_wide3_kernel's A operand of one chunk of up to four templates (rp_dtw_mfma_wide3.hip): per template row [k-step 6][k half 2][template
 // slot 4] x 8 bf16.  Lane half kh owns components kh * CHM .. kh * CHM + CHM - 1 (zero beyond K); a = -(unit row) = a0 + a1 + a2 exactly.  The
-// 24 registers of a half: per component pair (p, q) (a0p, a0q) x 3, (a1p, a1q) x 2, (a2p, a2q) against the window side's (x0, x0), (x1, x1),
-// (x2, x2), (x0, x0), (x1, x1), (x0, x0); an odd last component s: (a0s, a0s), (a0s, a1s), (a1s, a2s) against (x0s, x1s), (x2s, x0s),
-// (x1s, x0s), then (1.0, 0) in half 1: the 1 of 1 - a.x (an even count starts the sum at 1 instead).  mfcc_size 16: the kernel reads its twelve
-// different window-side registers as one run in overlapping pieces, and slot i of k-step ks holds part kDtwWide3RunPart[ks][i] of pair
-// kDtwWide3RunPair[ks][i] (rp_kernels.h) -- the same six products per component in another order.
+// 24 registers of a half pair the window side's run of twelve registers with the template parts that complete the six products x_i a_j
+// (i + j <= 2) of every component: slot i of k-step ks holds what dtw_mfma_wide3_slot(K, ks, i) says (rp_kernels.h).
 static void append_mfma_wide3_image(std::vector<uint16_t> &img, const DtwChunk &c, const float *unit, int Lpad, int K) {
-    const int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, KS = kDtwWide3KSteps, row_bytes = kDtwWide3RowBytes;
+    const int CHM = dtw_mfma_wide_chm(K), KS = kDtwWide3KSteps, row_bytes = kDtwWide3RowBytes;
     const size_t base = img.size();
     img.resize(base + (size_t)(c.len + 16) * row_bytes / 2, 0);
     for (int r = 0; r < c.len; ++r)
         for (int t = 0; t < c.count; ++t)
             for (int kh = 0; kh < 2; ++kh) {
                 std::vector<uint16_t> v(8 * KS, 0);  // 4 KS registers of two bf16
-                auto parts = [&](int j, uint16_t p[3]) {
+                auto part = [&](int j, int which) -> uint16_t {   // part `which` of component j of this half; -1: zero; -2: the constant (half 1)
+                    if (j == -2) return kh ? 0x3f80 : 0;
                     const int comp = kh * CHM + j;
-                    p[0] = p[1] = p[2] = 0;
-                    if (comp < K) bf16_split3(-unit[((size_t)c.tid[t] * Lpad + r) * K + comp], p);
+                    if (j < 0 || j >= CHM || comp >= K) return 0;
+                    uint16_t p[3];
+                    bf16_split3(-unit[((size_t)c.tid[t] * Lpad + r) * K + comp], p);
+                    return p[which];
                 };
-                if (dtw_mfma_wide3_run(K)) {   // the kernel reads its twelve window-side registers as one run (rp_kernels.h)
-                    for (int ks = 0; ks < KS; ++ks)
-                        for (int i = 0; i < 4; ++i) {
-                            uint16_t a[3], b[3];
-                            parts(2 * kDtwWide3RunPair[ks][i], a); parts(2 * kDtwWide3RunPair[ks][i] + 1, b);
-                            v[2 * (4 * ks + i)] = a[kDtwWide3RunPart[ks][i]]; v[2 * (4 * ks + i) + 1] = b[kDtwWide3RunPart[ks][i]];
-                        }
-                } else {
-                    for (int j = 0; j < NPAIR; ++j) {
-                        uint16_t a[3], b[3];
-                        parts(2 * j, a); parts(2 * j + 1, b);
-                        const int which[6] = {0, 0, 0, 1, 1, 2};
-                        for (int i = 0; i < 6; ++i) { v[2 * (6 * j + i)] = a[which[i]]; v[2 * (6 * j + i) + 1] = b[which[i]]; }
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int i = 0; i < 4; ++i) {
+                        const W3Slot sl = dtw_mfma_wide3_slot(K, ks, i);
+                        v[2 * (4 * ks + i)] = part(sl.c0, sl.p0);
+                        v[2 * (4 * ks + i) + 1] = part(sl.c1, sl.p1);
                     }
-                }
-                if (CHM % 2) {
-                    uint16_t s3[3];
-                    parts(CHM - 1, s3);
-                    const int o = 6 * NPAIR;
-                    v[2 * o] = s3[0]; v[2 * o + 1] = s3[0];
-                    v[2 * (o + 1)] = s3[0]; v[2 * (o + 1) + 1] = s3[1];
-                    v[2 * (o + 2)] = s3[1]; v[2 * (o + 2) + 1] = s3[2];
-                    v[2 * (o + 3)] = kh ? 0x3f80 : 0; v[2 * (o + 3) + 1] = 0;
-                }
                 for (int ks = 0; ks < KS; ++ks)
                     std::memcpy(&img[base + ((size_t)r * row_bytes + ks * 128 + kh * 64 + t * 16) / 2], &v[8 * ks], 16);
             }

@@ -10,16 +10,17 @@
 //     banks).  A tile is 8 row slots x 4 templates, 16 circular row slots = 2 tiles, a lane (window, half h) runs ONE template pair
 //     (templates 2h, 2h + 1): the C/D layout puts row 8 G + 4 h + 2 sp + e = (row slot 2 G + sp, template 2 h + e) into register 4 G + 2 sp + e.
 //     Columns are unrolled 16 at a time.  12 matrix instructions per column and four templates.
-//   * lane half h owns CHM = ceil(K / 2) components; a component pair (a, b) fills six registers of the B operand,
-//       [(x0a, x0b), (x1a, x1b), (x2a, x2b), (x0a, x0b), (x1a, x1b), (x0a, x0b)] against [(a0, a0) x 3, (a1, a1) x 2, (a2, a2)],
-//     an odd last component s three: [(x0s, x1s), (x2s, x0s), (x1s, x0s)] against [(a0, a0), (a0, a1), (a1, a2)], and (mfcc_size 13) the
-//     constant (1.0, 0) x (1.0, 0) in half 1.  mfcc_size 16 keeps the twelve DIFFERENT registers of a half as one run and reads it in overlapping
-//     pieces (w3_run_piece below; −85 vector instructions per 16-column block, measured 6.43-6.48 ms against 6.44-6.57: the matrix pipe is as
-//     loaded as the vector pipe here, fewer copies buy almost nothing).
+//   * lane half h owns CHM = ceil(K / 2) components.  Per component pair (a, b) the window side has three registers P0 = (x0a, x0b), P1, P2; the
+//     products need P0 three times (against a0, a1, a2), P1 twice, P2 once -- 24 register slots per half and k-step run, but only twelve different
+//     registers.  They are kept as ONE run and the six k-steps read overlapping four-register pieces of it (w3_run_piece; the layouts of both
+//     frame sizes and the A image's side of every slot: dtw_mfma_wide3_slot, rp_kernels.h).  mfcc_size 13's odd seventh component rides in two
+//     registers, (x0s, x1s) read three times and (x2s, the constant 1.0 of half 1) -- an even component count starts the sum at 1 instead.
+//   * schedule: two run buffers (column c's operand in brun[c & 1]).  In every column one of the two tiles is still read by the last or last but
+//     one band cell, so its chain of six dependent matrix instructions cannot leave before the cells are done; it goes out between the pieces
+//     of the NEXT frame's preparation (its head, one piece per component pair, the odd component), which writes the other buffer
+//     (w3_issue_table).  6.27-6.29 ms against 6.39-6.41 for one buffer at 8 192 streams x 8 templates of mfcc_size 16.
 // Frames are read from global memory (the caller leaves slack behind the last stream's frames, launch_dtw `padded_rows`), as in the two-part
-// kernel.  Two waves per SIMD (eight per workgroup): 208 / 215 registers, nothing spilled.  mfcc_size 16 double-buffers the window side's
-// operand and issues half of a column's matrix instructions between the pieces of the next frame's preparation (SPREAD, see w3_issue_table:
-// 6.27-6.29 ms against 6.39-6.41 at 8 192 streams x 8 templates).
+// kernel.  Two waves per SIMD (eight per workgroup), nothing spilled.
 // BUILD: the 16-column block (192 matrix instructions, ~2 700 instructions) is a `#pragma unroll` loop far beyond the compiler's default budget for
 // pragma-requested full unrolling; this file is compiled with -mllvm -pragma-unroll-threshold=200000 (Makefile FILE_FLAGS_rp_dtw_mfma_wide3.hip).
 // Without it the loop stays rolled, the row-slot -> accumulator mapping becomes a run-time index and the build shows 256 registers with
@@ -37,10 +38,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x12 __attribute__((ext_vector_type(12)));
 
-// mfcc_size 16 (four component pairs per lane half, no odd component): the B operand's 24 register slots hold only 12 different registers
-// (per pair P0 = (x0, x0) three times, P1 twice, P2 once).  They are kept as ONE run, [P2a P2b P1a P1b P0a P0b P0c P0d P1c P1d P2c P2d], and
-// the six k-steps read overlapping four-register pieces of it at offsets 0, 2, 4, 4, 6, 8 -- no copies; the A image pairs every slot with
-// the template part that completes its product (kDtwWide3RunPair / kDtwWide3RunPart, rp_kernels.h: the table append_mfma_wide3_image follows).
+// k-step ks of the window side's operand: a four-register piece of the half's run of twelve (see above)
 __device__ __forceinline__ u32x4 w3_run_piece(const u32x12 &r, int ks) {
     switch (ks) {
     case 0: return __builtin_shufflevector(r, r, 0, 1, 2, 3);
@@ -64,46 +62,20 @@ __host__ __device__ constexpr int w3_last_use(int u, int g) {
     return last;
 }
 
-// band cell after which k-step ks of tile g goes out in column phase u: tiles in the order they come free, k-steps in order, at most one per
-// cell until the column's last cell takes what is left (twelve instructions, ten cells).
-// SPREAD (the window side's operand double-buffered: mfcc_size 16): in every column one tile is read by the column's last or last but one
-// cell, so half of the column's matrix instructions -- one dependent chain of six -- would go out in one burst behind the last cell and hold
-// the wave for five instructions' pipe time.  With a second operand buffer the frame preparation of column c + 2 may run WHILE column
-// c + 1's instructions are still being issued: issue points 2W .. 2W + tail - 1 lie behind the pieces of that preparation (its head, then
-// one component pair each), and each tile's chain goes out one instruction per issue point from the cell that frees the tile.
-#ifndef RP_W3_SPREAD
-#define RP_W3_SPREAD 1
-#endif
+// issue point of k-step ks of tile g in column phase u: points 0 .. 2W - 1 lie behind the band cells, 2W .. 2W + tail - 1 behind the pieces of the
+// next frame's preparation.  A tile's chain goes out one instruction per point from the cell that reads the tile last.
 struct W3IssueTable { int at[kW3Slots][kW3Tiles][kW3KS]; };
 template <int W>
 __host__ __device__ constexpr W3IssueTable w3_issue_table(int tail) {
     W3IssueTable t{};
-    for (int u = 0; u < kW3Slots; ++u) {
-        const int lu0 = w3_last_use<W>(u, 0), lu1 = w3_last_use<W>(u, 1);
-        if (tail > 0) {
-            for (int g = 0; g < kW3Tiles; ++g)
-                for (int ks = 0; ks < kW3KS; ++ks) {
-                    int at = (g == 0 ? lu0 : lu1) + ks;
-                    if (at < 0) at = 0;
-                    if (at > 2 * W + tail - 1) at = 2 * W + tail - 1;
-                    t.at[u][g][ks] = at;
-                }
-            continue;
-        }
-        const int first = lu1 < lu0 ? 1 : 0, second = 1 - first;
-        int prev = -1;
-        for (int i = 0; i < 2; ++i) {
-            const int g = i == 0 ? first : second;
-            const int lu = g == 0 ? lu0 : lu1;
+    for (int u = 0; u < kW3Slots; ++u)
+        for (int g = 0; g < kW3Tiles; ++g)
             for (int ks = 0; ks < kW3KS; ++ks) {
-                int at = lu > prev + 1 ? lu : prev + 1;
+                int at = w3_last_use<W>(u, g) + ks;
                 if (at < 0) at = 0;
-                if (at > 2 * W - 1) at = 2 * W - 1;
+                if (at > 2 * W + tail - 1) at = 2 * W + tail - 1;
                 t.at[u][g][ks] = at;
-                prev = at;
             }
-        }
-    }
     return t;
 }
 
@@ -120,13 +92,11 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
     const uint32_t *__restrict__ count, uint32_t dense_min, float abandon_nc, uint32_t *__restrict__ sched, unsigned static_rounds, uint32_t *__restrict__ fix) {
     constexpr int B = 2 * W, NS = kW3Slots, NTILE = kW3Tiles, SPT = kW3SPT, KS = kW3KS;
     constexpr int CHM = dtw_mfma_wide_chm(K), NPAIR = CHM / 2, ODD = CHM % 2;
-    constexpr bool RUN = dtw_mfma_wide3_run(K);   // mfcc_size 16: the B operand as one run of twelve registers
     constexpr int kRowBytes = kDtwWide3RowBytes;
-    constexpr bool SPREAD = RUN && RP_W3_SPREAD;  // two operand buffers, the matrix instructions spread into the frame preparation
-    constexpr int TAIL = SPREAD ? 1 + NPAIR : 0;  // issue points behind the cells: the preparation's head, then one per component pair
+    constexpr int TAIL = 1 + NPAIR + ODD;         // issue points behind the cells: the preparation's head, one per component pair, the odd component
     constexpr W3IssueTable kIssue = w3_issue_table<W>(TAIL);
     static_assert(B + 2 <= NS, "the band and its two neighbours must fit the 16 row slots");
-    static_assert(6 * NPAIR + 3 * ODD + (ODD ? 1 : 0) <= 4 * KS, "the half's product registers must fit six k-steps");
+    static_assert(K == 13 || K == 16, "dtw_mfma_wide3_slot knows these two layouts");
     size_t total_entries = n_streams * n_win;
     if (list) {
         const uint32_t n_listed = *count;
@@ -219,13 +189,11 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
                 Areg[g][ks] = *reinterpret_cast<const u32x4 *>(smem + a_lane + (unsigned)(r - 1) * kRowBytes + ks * 128);
         }
         v16f acc[NTILE];
-        u32x12 brun[2];     // (RUN) the same, twelve registers; SPREAD: column c's operand in brun[c & 1]
-        u32x4 bop[1][KS];   // (!RUN) ONE buffer: the operand of column c + 2 is built after the last matrix instruction of column c + 1 is out (end of step c)
+        u32x12 brun[2];     // the window side's operand: column c's in brun[c & 1]
         float chk = 0.f;
         float pd_[CHM], pinv_ = 0.f;   // the frame being prepared: centred components, 1 / norm
-        unsigned pv_[4 * KS];          // (!RUN) its product registers
 
-// the frame in fl[] (column cc) -> B operand bop[par]: centre, scale to unit length (the two halves' squared norms meet through
+// the frame in fl[] (column cc) -> the window side's operand brun[par]: centre, scale to unit length (the two halves' squared norms meet through
 // v_permlane32_swap; zero frame -> zero vector -> cost 1, comparator.rs:43-47), split in three bf16 parts, pack
 #define RP_PREP_HEAD()                                                                                                        \
     do {                                                                                                                      \
@@ -236,31 +204,28 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
         pinv_ = bb_ > 0.f ? __builtin_amdgcn_rsqf(bb_) : 0.f;                                                                 \
         chk = fmaxf(fmaxf(chk, pinv_), bb_); /* one v_max3_f32: the norm-range test (kDtwFixLimit, rp_kernels.h) */           \
     } while (0)
-// component pair j of the prepared frame -> its three registers of brun[par] (RUN) / its six slots of pv_[] (!RUN)
+// component pair j of the prepared frame -> its three registers of brun[par]: pairs 0, 1 from the front of the run, 2, 3 from its back
 #define RP_PREP_PAIR(par, j)                                                                                                  \
     do {                                                                                                                      \
         const float ua_ = pd_[2 * (j)] * pinv_, ub_ = pd_[2 * (j) + 1] * pinv_;                                               \
         const float ra_ = ua_ - top16(ua_), rb_ = ub_ - top16(ub_);                                                           \
-        const unsigned p0_ = hi2(ub_, ua_), p1_ = hi2(rb_, ra_), p2_ = hi2(rb_ - top16(rb_), ra_ - top16(ra_));               \
-        if (RUN) {   /* pairs 0, 1 from the front of the run, pairs 2, 3 from its back */                                      \
-            brun[par][4 + (j)] = p0_; brun[par][(j) < 2 ? 2 + (j) : 6 + (j)] = p1_; brun[par][(j) < 2 ? (j) : 8 + (j)] = p2_;  \
-        } else {                                                                                                              \
-            pv_[6 * (j)] = p0_; pv_[6 * (j) + 1] = p1_; pv_[6 * (j) + 2] = p2_; pv_[6 * (j) + 3] = p0_; pv_[6 * (j) + 4] = p1_; pv_[6 * (j) + 5] = p0_; \
-        }                                                                                                                     \
+        brun[par][4 + (j)] = hi2(ub_, ua_);                                                                                   \
+        brun[par][(j) < 2 ? 2 + (j) : 6 + (j)] = hi2(rb_, ra_);                                                               \
+        brun[par][(j) < 2 ? (j) : 8 + (j)] = hi2(rb_ - top16(rb_), ra_ - top16(ra_));                                         \
+    } while (0)
+// mfcc_size 13's seventh component: (x0s, x1s) where the fourth pair's P0 would be, (x2s, the constant 1.0 of half 1) for its P1, 0 for its P2
+#define RP_PREP_ODD(par)                                                                                                      \
+    do {                                                                                                                      \
+        const float us_ = pd_[CHM - 1] * pinv_, rs_ = us_ - top16(us_);                                                       \
+        brun[par][7] = hi2(rs_, us_);                                                                                         \
+        brun[par][9] = hi2(h ? 1.f : 0.f, rs_ - top16(rs_));                                                                  \
+        brun[par][11] = 0u;                                                                                                   \
     } while (0)
 #define RP_PREP(par)                                                                                                          \
     do {                                                                                                                      \
         RP_PREP_HEAD();                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4 * KS; ++i) pv_[i] = 0u;                                                       \
         _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) RP_PREP_PAIR(par, j);                                               \
-        if (ODD) {                                                                                                            \
-            const float us_ = pd_[CHM - 1] * pinv_, rs_ = us_ - top16(us_), x2_ = rs_ - top16(rs_);                           \
-            pv_[6 * NPAIR] = hi2(rs_, us_); pv_[6 * NPAIR + 1] = hi2(us_, x2_); pv_[6 * NPAIR + 2] = hi2(us_, rs_);           \
-            pv_[6 * NPAIR + 3] = h ? 0x00003f80u : 0u;   /* the constant 1.0 of 1 - a.x (half 1) */                           \
-        }                                                                                                                     \
-        if (!RUN)                                                                                                             \
-            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                                                 \
-                bop[0][ks] = (u32x4){pv_[4 * ks], pv_[4 * ks + 1], pv_[4 * ks + 2], pv_[4 * ks + 3]};                         \
+        if (ODD) RP_PREP_ODD(par);                                                                                            \
     } while (0)
 // the A tile that receives template row cc + W (cc = 1 + uu mod 16)
 #define RP_AREF(cc, uu, GUARD)                                                                                                \
@@ -275,7 +240,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
     do {                                                                                                                      \
         constexpr float c1_ = ODD ? 0.f : 1.f;   /* an even component count has no product slot for the 1 of 1 - a.x: it starts the sum */ \
         const v16f in16_ = {c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_, c1_};                   \
-        const u32x4 b4_ = RUN ? w3_run_piece(brun[par], ks) : bop[0][ks];                                                        \
+        const u32x4 b4_ = w3_run_piece(brun[par], ks);                                                        \
         if ((ks) == 0) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][0]), __builtin_bit_cast(bf16x8, b4_), in16_, 0, 0, 0); \
         else acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Areg[g][ks]), __builtin_bit_cast(bf16x8, b4_), acc[g], 0, 0, 0); \
     } while (0)
@@ -287,8 +252,8 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
             if (kIssue.at[u][g][ks] == (at_)) RP_MFMA1(g, ks, MPAR);
 #define RP_STEP(GUARD)                                                                                                        \
     do {                                                                                                                      \
-        /* operand buffers (SPREAD; c0 is odd): column c + 1's in brun[(c + 1) & 1] = brun[u & 1], column c + 2's goes to the other */ \
-        const int MPAR = SPREAD ? (u & 1) : 0, PPAR = SPREAD ? ((u + 1) & 1) : 0;                                              \
+        /* operand buffers (c0 is odd): column c + 1's in brun[(c + 1) & 1] = brun[u & 1], column c + 2's goes to the other */        \
+        const int MPAR = u & 1, PPAR = (u + 1) & 1;                                                                            \
         RP_AREF(c + 1, (u + 1) % NS, GUARD)                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
         v2f up = (v2f){RP_INF, RP_INF};                                                                                       \
@@ -305,17 +270,19 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
             RP_ISSUE(q)                                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
-        if (SPREAD) {      /* column c + 2's operand, piece by piece, the rest of column c + 1's matrix instructions between the pieces */ \
-            RP_PREP_HEAD();                                                                                                   \
-            RP_ISSUE(B)                                                                                                       \
+        /* column c + 2's operand, piece by piece, the rest of column c + 1's matrix instructions between the pieces */           \
+        RP_PREP_HEAD();                                                                                                       \
+        RP_ISSUE(B)                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) {                                                                   \
+            RP_PREP_PAIR(PPAR, j);                                                                                            \
+            RP_ISSUE(B + 1 + j)                                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                                                \
-            _Pragma("unroll") for (int j = 0; j < NPAIR; ++j) {                                                               \
-                RP_PREP_PAIR(PPAR, j);                                                                                        \
-                RP_ISSUE(B + 1 + j)                                                                                           \
-                __builtin_amdgcn_sched_barrier(0);                                                                            \
-            }                                                                                                                 \
-        } else {                                                                                                              \
-            RP_PREP(PPAR);        /* column c + 2, from the frame requested one column ago */                                 \
+        }                                                                                                                     \
+        if (ODD) {                                                                                                            \
+            RP_PREP_ODD(PPAR);                                                                                                \
+            RP_ISSUE(B + 1 + NPAIR)                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
         }                                                                                                                     \
         RP_LOADF(c + 3);                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                    \
@@ -323,9 +290,9 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
 
         RP_AREF(1, 0, true)
         RP_LOADF(1);
-        RP_PREP(SPREAD ? 1 : 0);   // column 1's operand (SPREAD: column c's lives in brun[c & 1])
+        RP_PREP(1);                // column 1's operand (column c's lives in brun[c & 1])
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { RP_MFMA1(0, ks, SPREAD ? 1 : 0); RP_MFMA1(1, ks, SPREAD ? 1 : 0); }
+        for (int ks = 0; ks < KS; ++ks) { RP_MFMA1(0, ks, 1); RP_MFMA1(1, ks, 1); }
         RP_LOADF(2);
         __builtin_amdgcn_sched_barrier(0);
         RP_PREP(0);                // column 2's
@@ -366,6 +333,7 @@ __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_wide3_kernel(
 #undef RP_MFMA1
 #undef RP_AREF
 #undef RP_PREP
+#undef RP_PREP_ODD
 #undef RP_PREP_PAIR
 #undef RP_PREP_HEAD
 #undef RP_LOADF

@@ -94,14 +94,27 @@ __host__ __device__ constexpr int dtw_mfma_wide_row_bytes(int K) { return dtw_mf
 // fall on different banks)
 constexpr int kDtwWide3KSteps = 6;
 constexpr int kDtwWide3RowBytes = kDtwWide3KSteps * 128 + 64;
-// mfcc_size 16: the window side's twelve different operand registers are one run read in overlapping pieces (rp_dtw_mfma_wide3.hip,
-// w3_run_piece); slot i of k-step ks then holds component pair kDtwWide3RunPair[ks][i] of the half, template part kDtwWide3RunPart[ks][i]
-#ifndef RP_W3_RUN
-#define RP_W3_RUN 1
-#endif
-__host__ __device__ constexpr bool dtw_mfma_wide3_run(int K) { return RP_W3_RUN && K == 16; }
-constexpr int kDtwWide3RunPair[6][4] = {{0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 2, 3}, {0, 1, 2, 3}, {2, 3, 2, 3}, {2, 3, 2, 3}};
-constexpr int kDtwWide3RunPart[6][4] = {{0, 0, 0, 0}, {1, 1, 0, 0}, {1, 1, 0, 0}, {2, 2, 1, 1}, {2, 2, 0, 0}, {1, 1, 0, 0}};
+// The window side's operand of a lane half is ONE run of twelve registers read in overlapping four-register pieces at offsets 0, 2, 4, 4, 6, 8
+// (rp_dtw_mfma_wide3.hip, w3_run_piece):
+//   mfcc_size 16 (four component pairs a..d):          [P2a P2b P1a P1b P0a P0b P0c P0d P1c P1d P2c P2d]
+//   mfcc_size 13 (three pairs a..c + one component s): [P2a P2b P1a P1b P0a P0b P0c S01 P1c S2C P2c  0 ]
+// with Pk of a pair = (xk of its first component, xk of its second), S01 = (x0s, x1s), S2C = (x2s, the 1.0 of 1 - a.x in half 1).  Slot i of
+// k-step ks of the A image holds the template parts that complete the products: W3Slot{component, part} for the slot's two bf16 (component
+// within the lane half; -1: zero; -2: the constant's 1.0, half 1 only).  S01 is read three times -- against (a0s, a0s), (a1s, a1s), (a2s, 0) --
+// so the odd component needs no register of its own per product; registers read more often than they have products meet zeros.
+struct W3Slot { int c0, p0, c1, p1; };
+__host__ __device__ constexpr W3Slot dtw_mfma_wide3_slot(int K, int ks, int i) {
+    constexpr int pair16[6][4] = {{0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 2, 3}, {0, 1, 2, 3}, {2, 3, 2, 3}, {2, 3, 2, 3}};
+    constexpr int part16[6][4] = {{0, 0, 0, 0}, {1, 1, 0, 0}, {1, 1, 0, 0}, {2, 2, 1, 1}, {2, 2, 0, 0}, {1, 1, 0, 0}};
+    constexpr W3Slot s13[6][4] = {
+        {{0, 0, 1, 0}, {2, 0, 3, 0}, {0, 0, 1, 0}, {2, 0, 3, 0}},      // P2a P2b P1a P1b  x a0
+        {{0, 1, 1, 1}, {2, 1, 3, 1}, {0, 0, 1, 0}, {2, 0, 3, 0}},      // P1a P1b x a1, P0a P0b x a0
+        {{0, 1, 1, 1}, {2, 1, 3, 1}, {4, 0, 5, 0}, {6, 0, 6, 0}},      // P0a P0b x a1, P0c x a0, S01 x (a0s, a0s)
+        {{0, 2, 1, 2}, {2, 2, 3, 2}, {4, 1, 5, 1}, {6, 1, 6, 1}},      // P0a P0b x a2, P0c x a1, S01 x (a1s, a1s)
+        {{4, 2, 5, 2}, {6, 2, -1, 0}, {4, 0, 5, 0}, {6, 0, -2, 0}},    // P0c x a2, S01 x (a2s, 0), P1c x a0, S2C x (a0s, 1.0)
+        {{4, 1, 5, 1}, {-1, 0, -1, 0}, {4, 0, 5, 0}, {-1, 0, -1, 0}}}; // P1c x a1, S2C x 0, P2c x a0, 0 x 0
+    return K == 16 ? W3Slot{2 * pair16[ks][i], part16[ks][i], 2 * pair16[ks][i] + 1, part16[ks][i]} : s13[ks][i];
+}
 // Tiles a wave of the matrix-core DTW kernels takes by its own index before it turns to the chunk's atomic counter: every whole round
 // of a launch of at most three rounds (live-stream calls, BASELINE config C2 -- the waves start together and would ask for their
 // tickets together; the counter then hands out what is left), the first round of longer launches (the waves drift apart by themselves

@@ -994,19 +994,15 @@ static hipError_t launch_dtw_wide_all(hipStream_t st, const TemplatesDev &t, int
                                       float *avg, bool few, GateList gl = GateList{}, bool padded = false) {
     // every length at least three times, band 5, rows with slack behind them: the sample templates on the matrix cores
     // (rp_dtw_mfma_wide.hip), the averaged template -- if it is to be scored here -- through the one-template register kernel
-    if (W == 5 && (padded || few || gl.list) && dtw_mfma_wide3_supported(t, W)) {   // the default arithmetic: three bf16 parts, chunks of four
+    const bool rows_ok = W == 5 && (padded || few || gl.list);
+    const bool three_part = rows_ok && dtw_mfma_wide3_supported(t, W);                       // the default arithmetic: chunks of four
+    const bool two_part = rows_ok && !three_part && dtw_mfma_wide_supported(t, W, score_ref);  // RP_ARITH_FAST_SPLIT: chunks of eight
+    if (three_part || two_part) {
         if (t.has_avg && n1 == t.class_count[3])
             if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
                                                         few, gl, t.class_first[3] + t.class_count[3] - 1); e != hipSuccess) return e;
-        return launch_dtw_mfma_wide3(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg,
-                                     gl.list, gl.count, gl.dense_min, gl.abandon_nc);
-    }
-    if (W == 5 && (padded || few || gl.list) && dtw_mfma_wide_supported(t, W, score_ref)) {
-        if (t.has_avg && n1 == t.class_count[3])
-            if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, 1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg,
-                                                        few, gl, t.class_first[3] + t.class_count[3] - 1); e != hipSuccess) return e;
-        return launch_dtw_mfma_wide(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref, scores, avg,
-                                    gl.list, gl.count, gl.dense_min, gl.abandon_nc);
+        return (three_part ? launch_dtw_mfma_wide3 : launch_dtw_mfma_wide)(st, gl.work(), t, W, mfcc, S, frame_pitch, first_win, n_win, out_win_pitch, score_ref,
+                                                                          scores, avg, gl.list, gl.count, gl.dense_min, gl.abandon_nc);
     }
     if (hipError_t e = launch_dtw_wide<K, W, 1>(st, t, 3, n1, mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl); e != hipSuccess) return e;
     return launch_dtw_wide<K, W, 2>(st, t, 0, t.class_count[0], mfcc, S, frame_pitch, tiles, first_win, n_win, out_win_pitch, score_ref, scores, avg, few, gl);

@@ -379,7 +379,7 @@ def dtw_kernel_model(env, S, n_win, lens, K, dtw_s, pmc_dtw, ran=None, products=
                       "instructions, %.0f SIMD issue cycles per 12-column block of a 32-window tile" % (mix["classes"]["valu"], mix["classes"]["mfma"],
                                                                                                          mix["valu_issue_cycles_per_trip"])})
         # a matrix instruction takes ~19 issue cycles from the vector work beside it at three waves per SIMD (tools/scratch/mfma_valu_overlap_probe.hip:
-        # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions); the three-part form runs three waves per SIMD at C3 too (two for small batches)
+        # 310 cycles for 108 vector instructions alone, 369 with the column's three matrix instructions); the three-part form runs two waves per SIMD
         # with six matrix instructions per column -- the same price is used (measured there: 17 from the kernel's own time, 25 in the probe)
         extra["valu_plus_matrix_issue_frac"] = (cyc + 19.0 * trips * mix["classes"]["mfma"]) / (n_simds(torch, env.dev) * CLOCK_PEAK * dtw_s)
         if grouped:

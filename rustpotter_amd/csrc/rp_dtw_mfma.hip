@@ -29,7 +29,7 @@
 //     after the first).  What is dropped (x1 a2 + x2 a1 + x2 a2) is below 2^-22 of a product, 2^-25.7 rms -- an f32 multiply rounds by up to
 //     2^-24; tests/test_gpu_dtw_f64.py holds the scores to the strict-f32 oracle's own distance from an f64 evaluation.  The window side's two
 //     operands are one run of six registers (the middle two shared), the A image is 512 bytes per template row (append_mfma_image3,
-//     rp_ctx.cpp); 168 registers = three waves per SIMD (twelve per workgroup) for large batches, 220 = two (eight) for small ones.  P3 = false (RP_ARITH_FAST_SPLIT, opt-in): the two-part f16 form
+//     rp_ctx.cpp); 219 registers = two waves per SIMD, eight per workgroup (a twelve-wave build exists: RP_MFMA3_WAVES=12, see the launcher).  P3 = false (RP_ARITH_FAST_SPLIT, opt-in): the two-part f16 form
 //     described above, 22-bit products.
 //   * Two shapes (NT): eight template slots as described (chunks of 5..8 templates, band 3..5), or four (chunks of 3..4, band 5): a
 //     tile is then 8 row slots x 4 templates, 16 circular row slots = 2 tiles, one template pair per lane, columns unrolled 16 at a time, twelve
@@ -54,7 +54,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));   // the window side's run of six registers (P3)
 
 constexpr int kMK = 5;         // MFCC coefficients per frame
 constexpr int kMWin = 32;      // windows per wave
@@ -311,7 +311,7 @@ RP_MFMA_OCC __global__ __launch_bounds__(64 * NW, 1) void dtw_mfma_kernel(
         // P3: the two k-steps' B operands as ONE run of six registers per column, [0..3] the first k-step's and [2..5] the second's: the
         // registers both need -- (x0a, x0b) and (x1a, x1b) -- sit in the middle and are written once (slot order: append_mfma_image3,
         // rp_ctx.cpp).  Measured neutral against two separate operands with three copies per column (15.0 ms either way), ten registers fewer.
-        u32x8 bv[P3 ? 2 : 1];
+        u32x6 bv[P3 ? 2 : 1];
         (void)bv;
 
 // The frame work of column cc, cut into ten pieces P0..P9 that are placed between the cells of the recurrence.
@@ -580,14 +580,13 @@ hipError_t launch_dtw_mfma(hipStream_t st, const DtwWork &wk, const TemplatesDev
     const int row_bytes = p3 ? kDtwMfma3RowBytes : kDtwMfmaRowBytes;
     int nw = dtw_mfma_lds_bytes(t.max_len, 12, row_bytes) <= 160 * 1024 ? 12 : 8;
     if (p3 && slots == 8) {
-        // the three-part form: two waves per SIMD (8 per workgroup, 220 registers, nothing spilled) or three (12 per workgroup, 168 registers, 59
-        // values spilled, ten scratch accesses per 12-column block).  Measured at BASELINE C3 (2 376 tiles per CU), alternating three times:
-        // 14.93-14.94 ms with twelve waves against 15.11-15.21 with eight; at C2 (37 tiles per CU: three rounds of twelve waves) 0.304 against
-        // 0.293.  Twelve when every wave has at least eight tiles to take; the frames-from-global build spills 135 values and keeps eight.
-        // RP_MFMA3_WAVES=8 / 12: A/B runs
+        // the three-part form runs two waves per SIMD (8 per workgroup, 219 registers, nothing spilled).  Its twelve-wave build (168 registers,
+        // 49 values spilled) is 1.3 % faster at BASELINE C3 -- 14.93-14.94 ms against 15.11-15.21, alternated three times -- and pays for it with
+        // three scratch stores and three reloads per 12-column block that reach the HBM: 5.7 GB per launch against 1.47 (the algorithmic bytes
+        // are 1.17 GB).  Harmless for the time (0.38 TB/s), but it is waste on the one counter this path is judged against: not the default.
+        // RP_MFMA3_WAVES=12 selects it (same bits)
         static const int env_nw = [] { const char *e = std::getenv("RP_MFMA3_WAVES"); return e ? std::atoi(e) : 0; }();
-        const bool many = !from_global && total_tiles >= (size_t)device_cu_count() * 12 * 8;
-        if (env_nw == 8 || (env_nw != 12 && !many)) nw = 8;
+        if (env_nw != 12) nw = 8;
     }
     const size_t lds = dtw_mfma_lds_bytes(t.max_len, nw, row_bytes);
     const void *image = p3 ? t.aimg3 : t.aimg;

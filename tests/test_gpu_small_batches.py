@@ -94,9 +94,8 @@ np.save(sys.argv[1], scores)
 
 
 def test_eight_and_twelve_wave_builds_of_the_three_part_kernel_give_the_same_bits(tmp_path):
-    """dtw_mfma_kernel<5, 8 | 12, false, 8, true>: two builds of one arithmetic (220 registers, two waves per SIMD, for small batches; 168
-    registers, three per SIMD, for large ones -- the launcher picks by the number of tiles).  RP_MFMA3_WAVES pins one of them for a process:
-    the scores of the same batch must not differ by a bit (child processes: the variable is read once)."""
+    """dtw_mfma_kernel<5, 8 | 12, false, 8, true>: two builds of one arithmetic (219 registers, two waves per SIMD: the default; 168 registers,
+    three per SIMD: RP_MFMA3_WAVES=12).  The scores of the same batch must not differ by a bit (child processes: the variable is read once)."""
     import subprocess
     import sys
     child = r"""

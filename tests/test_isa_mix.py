@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     # the headline kernel: three bf16 parts per operand (RP_ARITH_F32_MATRIX), two matrix instructions per tile and column
-    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8, true>", ["--min-mfma", "72", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/dtw_mfma_isa_mix.json"),
+    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 8, false, 8, true>", ["--min-mfma", "72", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/dtw_mfma_isa_mix.json"),
     ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8, false>", ["--min-mfma", "36", "--flags", "-DRP_MFMA_PRICE_NO_ABANDON"], "profiles/dtw_mfma_f16x2_isa_mix.json"),
     ("rp_mfcc.hip", "mfcc_kernel<true, 6, float, false>", [], "profiles/mfcc_isa_mix.json"),
     ("rp_dtw_ragged.hip", "dtw_ragged_kernel<5>", ["--min-mfma", "32"], "profiles/dtw_ragged_isa_mix.json"),

@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("rp_dtw_mfma_wide3.hip", "dtw_mfma_wide3_kernel<16, 5, 8>", 0, 256),
     ("rp_dtw_mfma_wide3.hip", "dtw_mfma_wide3_kernel<13, 5, 8>", 0, 256),
-    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8, true>", 96, 168),    # the headline kernel: three waves per SIMD
-    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 8, false, 8, true>", 0, 256),
+    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 8, false, 8, true>", 0, 256),      # the headline kernel: two waves per SIMD, nothing spilled
+    ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8, true>", 96, 168),    # its twelve-wave build (RP_MFMA3_WAVES=12)
     ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 4, true>", 64, 168),    # chunks of 3..4 templates
     ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, true, 4, true>", 64, 168),
     ("rp_dtw_mfma.hip", "dtw_mfma_kernel<5, 12, false, 8, false>", 64, 168),   # RP_ARITH_FAST_SPLIT
